@@ -1,0 +1,87 @@
+"""Case tables and closed-form input generators shared by make_golden.py (which
+runs the REFERENCE on them, build container only) and by the tests (which run
+the oracle / the HIP path on the same inputs and compare with the recorded
+reference outputs).  Nothing here comes from the reference."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import a2c_oracle as O  # noqa: E402
+
+null_prep = lambda pic: pic[None]   # preprocessing.py:8-9 restated
+
+
+def hashf(n, seed, lo=0.0, hi=1.0):
+    return (lo + (hi - lo) * O.formula_frames(1, (n,), seed=seed)[0]).astype(np.float32)
+
+
+
+MODEL_CASES = [  # kind, state_shape, n_actions, h_size, batch
+    ("A3CModel", (4, 84, 84), 3, 256, 3),
+    ("ConvModel", (4, 84, 84), 4, 256, 2),
+    ("ConvModel", (4, 20, 20), 3, 32, 3),
+    ("GRUModel", (4, 84, 84), 3, 256, 3),
+    ("FCModel", (4, 4), 2, 200, 5),
+    ("FCModel", (4, 84, 84), 3, 256, 2),
+    ("GRUFCModel", (4, 4), 2, 64, 5),
+]
+
+
+
+def base_hyps(**kw):
+    h = dict(gamma=.99, lambda_=.98, n_tsteps=8, n_rollouts=2, n_frame_stack=4, action_shift=0,
+             render=False, env_type="FakeBreakout", use_bptt=False, use_nstep_rets=False,
+             norm_advs=True, entr_coef=.005, pi_coef=1.0, val_coef=.5, max_norm=.5, lr=1e-4,
+             optim_type="RMSprop", is_discrete=True, h_size=256, preprocessor=null_prep, seed=0)
+    h.update(kw)
+    return h
+
+
+ROLLOUT_CASES = [
+    # name, kind, env_type, T, n_slots, env kwargs, A
+    ("a3c_pong", "A3CModel", "FakePong-v0", 12, 2, dict(env_id=1, rew_period=5, done_period=17), 3),
+    ("gru_brk", "GRUModel", "FakeBreakout", 8, 3, dict(env_id=0, rew_period=3, done_period=8), 4),
+    ("a3c_brk", "A3CModel", "FakeBreakout", 6, 2, dict(env_id=2, rew_period=4, done_period=9), 4),
+]
+
+
+
+def synth_shared(kind, ss, A, h, R_, T, seed, recurrent):
+    """Closed-form shared_data (regenerated identically by the tests)."""
+    N = R_ * T
+    D = dict(states=torch.from_numpy(O.formula_frames(N, ss, seed=seed, binary=(ss[-1] == 84))),
+             rewards=torch.from_numpy(np.round(hashf(N, seed + 1, -1.4, 1.4)).astype(np.float32)),
+             deltas=torch.from_numpy(hashf(N, seed + 2, -1, 1)),
+             actions=torch.from_numpy((hashf(N, seed + 3) * A).astype(np.int64).clip(0, A - 1)))
+    d = (hashf(N, seed + 4) < 0.15).astype(np.float32)
+    d[T - 1::T] = 1.0
+    D["dones"] = torch.from_numpy(d)
+    if recurrent:
+        D["h_states"] = torch.from_numpy(hashf(N * h, seed + 5, -1, 1).reshape(N, h))
+    return D
+
+
+UPDATE_CASES = [
+    # name, kind, state_shape, A, h, n_rollouts, T, optim, norm_advs, nstep, bptt, n_updates
+    ("a3c_rms", "A3CModel", (4, 84, 84), 3, 256, 4, 8, "RMSprop", True, False, False, 2),
+    ("a3c_adam", "A3CModel", (4, 84, 84), 3, 256, 4, 8, "Adam", True, False, False, 2),
+    ("a3c_nonorm_nstep", "A3CModel", (4, 84, 84), 3, 256, 3, 5, "RMSprop", False, True, False, 1),
+    ("conv_small_rms", "ConvModel", (4, 20, 20), 3, 32, 3, 4, "RMSprop", True, False, False, 2),
+    ("conv_full_adam", "ConvModel", (4, 84, 84), 4, 256, 2, 3, "Adam", True, False, False, 1),
+    ("gru_rms", "GRUModel", (4, 84, 84), 3, 256, 3, 6, "RMSprop", True, False, False, 2),
+    ("gru_bptt_rms", "GRUModel", (4, 84, 84), 3, 256, 3, 6, "RMSprop", True, False, True, 2),
+    ("gru_bptt_adam_nstep", "GRUModel", (4, 84, 84), 3, 256, 2, 5, "Adam", True, True, True, 1),
+    ("fc_cartpole_rms", "FCModel", (4, 4), 2, 200, 4, 32, "RMSprop", True, False, False, 2),
+    ("fc_full_adam", "FCModel", (4, 84, 84), 3, 256, 2, 4, "Adam", True, False, False, 1),
+    ("grufc_bptt_rms", "GRUFCModel", (4, 4), 2, 64, 3, 7, "RMSprop", True, False, True, 2),
+]
+SAMPLE = 24   # elements sampled per tensor
+
+
+def sample_idx(n):
+    return (np.arange(SAMPLE, dtype=np.int64) * 2654435761 % max(n, 1)).astype(np.int64)
+
+

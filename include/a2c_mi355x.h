@@ -1,0 +1,242 @@
+/*
+ * a2c_mi355x.h -- C ABI of liba2c_mi355x.so: the MI355X (gfx950 / CDNA4) kernels of
+ * the A2C rollout+update hot path of grantsrb/PyTorch-A2C.
+ *
+ * The reference has no FFI layer (it is pure Python on torch); its boundary is the
+ * Python API of a2c/runner.py, a2c/updater.py, a2c/models.py and a2c/utils.py.
+ * Each entry point below replaces the arithmetic of one reference call site
+ * (cited as file:line into /root/reference/a2c/).  The Python package
+ * pytorch-a2c_amd/a2c_amd binds these with ctypes and mirrors the reference API.
+ *
+ * Conventions
+ *   - plain C, no torch types: raw DEVICE pointers into caller-owned memory, sizes,
+ *     and the HIP stream (hipStream_t passed as void*; NULL = default stream);
+ *   - no allocation, no ownership transfer, no host synchronisation, no global
+ *     state: every call only enqueues kernels on `stream` (graph-capturable);
+ *     scratch memory is passed in as `ws` / `ws_bytes` and sized by the
+ *     matching *_ws_bytes() query;
+ *   - all floating-point data is IEEE fp32, row-major, contiguous unless a
+ *     leading dimension / stride argument says otherwise; actions are int64;
+ *   - return value: 0 = A2C_OK, negative = error (a2c_error_string()).
+ */
+#ifndef A2C_MI355X_H
+#define A2C_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A2C_OK 0
+#define A2C_ERR_ARG (-1)      /* invalid argument (NULL pointer, bad size, unsupported shape) */
+#define A2C_ERR_LAUNCH (-2)   /* hipGetLastError() after the launch was not hipSuccess          */
+#define A2C_ERR_WORKSPACE (-3)/* ws_bytes smaller than the matching *_ws_bytes() query          */
+
+typedef void *a2c_stream_t;   /* hipStream_t */
+
+int a2c_version(void);                 /* ABI version, currently 1 */
+const char *a2c_error_string(int code);
+
+/* ------------------------------------------------------------------ a5 / a7: scans
+ * utils.discount (utils.py:63-79): y[i] = x[i] + g * (dones[i]==1 ? 0 : y[i+1]),
+ * evaluated strictly sequentially per row (fp32 multiply then fp32 add, no FMA), so the
+ * result is bit-identical to the reference.  The input is n_seg independent rows of
+ * length T (row r = elements [r*T, (r+1)*T)); the running sum starts at 0 at each row end.
+ * With n_seg == 1 this is exactly utils.discount on a flat array of T elements.
+ * When n_seg > 1 the rows are only independent if every row ends with dones == 1
+ * (Runner guarantees it: runner.py:223,244); err_flag (device int, may be NULL) is set
+ * to 1 when a row violates this.                                                       */
+int a2c_discount_scan(const float *x, const float *dones, float *y, int64_t n_seg,
+                      int64_t T, float g, int *err_flag, a2c_stream_t stream);
+/* updater.py:70-71 + 86-88 fused: advs = discount(deltas, dones, g_adv) and
+ * rets = discount(rewards, dones, g_ret) in one pass over the three inputs.            */
+int a2c_gae_returns_fused(const float *deltas, const float *rewards, const float *dones,
+                          float *advs, float *rets, int64_t n_seg, int64_t T, float g_adv,
+                          float g_ret, int *err_flag, a2c_stream_t stream);
+/* sums[0] = sum x, sums[1] = sum x*x in double (zeroed by the call); feeds the
+ * mean / unbiased-std normalisations of updater.py:89-98.                              */
+int a2c_moments(const float *x, int64_t n, double *sums, a2c_stream_t stream);
+/* y = (x - mean) / (std + eps), mean/std (unbiased) derived from sums (a2c_moments,
+ * possibly all-reduced across ranks) over n_global elements: updater.py:98.            */
+int a2c_normalize(const float *x, float *y, int64_t n, const double *sums, int64_t n_global,
+                  float eps, a2c_stream_t stream);
+/* y = a + b (returns = advs + vals.data, updater.py:84)                                */
+int a2c_add(const float *a, const float *b, float *y, int64_t n, a2c_stream_t stream);
+
+/* ------------------------------------------------------------------ a1: frame stack
+ * utils.next_state (utils.py:26-43) + the state write of runner.py:199, batched over B
+ * envs.  out[b] = reset_mask[b] ? [0,..,0, frame_new[b]] : [prev[b][1:], frame_new[b]];
+ * C = n_frame_stack planes of HW floats.  prev / out are addressed with a per-env stride
+ * in floats so they can point into the rollout buffer `states[idx*T + t]`.              */
+int a2c_frame_stack_push(const float *frame_new, const float *reset_mask, const float *prev,
+                         int64_t prev_stride, float *out, int64_t out_stride, int B, int C,
+                         int HW, a2c_stream_t stream);
+
+/* ------------------------------------------------------------------ a2: sampler
+ * SequentialEnvironment.get_action discrete branch (runner.py:94-97) + utils.sample_action
+ * (utils.py:45-60): p = softmax(logits); running fp32 cumsum in index order; first a with
+ * cumsum >= u[b]; -1 if none.  actions int64 with element stride act_stride;
+ * probs (B,A) optional (may be NULL).                                                   */
+int a2c_softmax_sample(const float *logits, int64_t ld_logits, const float *u, int64_t *actions,
+                       int64_t act_stride, float *probs, int B, int A, a2c_stream_t stream);
+/* utils.sample_action on given probabilities (no softmax); actions as fp32 like the
+ * reference's return value.                                                             */
+int a2c_sample_probs(const float *probs, const float *u, float *actions, int64_t B, int A,
+                     a2c_stream_t stream);
+
+/* ------------------------------------------------------------------ a3: rollout records
+ * One env-step of Runner.rollout bookkeeping for B slots (runner.py:212-232): with
+ * e = slot*T + t, writes rewards[e] = rew, dones[e] = done_eff where
+ * done_eff = done || (pong && rew != 0) (runner.py:213-214), and, when t > 0,
+ * deltas[e-1] = rewards[e-1] + (gamma*val[b])*(1-dones[e-1]) - val_prev[b] (runner.py:231);
+ * then val_prev[b] = val[b].  If h != NULL (recurrent, hdim columns) rows of h whose
+ * done_eff is set are zeroed (runner.py:219-220).                                       */
+int a2c_rollout_record(const float *rew, const float *done, const float *val, int64_t val_stride,
+                       float *val_prev,
+                       float *rewards, float *dones, float *deltas, float *done_eff_out,
+                       float *h, int hdim, int B, int64_t T, int64_t t, int64_t slot0,
+                       float gamma, int pong, a2c_stream_t stream);
+/* End of slot (runner.py:236-245): e = slot*T + T-1; if dones[e] == 0:
+ * rewards[e] += gamma*val_boot[b], dones[e] = 1; then deltas[e] = rewards[e] - val_prev[b]. */
+int a2c_rollout_bootstrap(const float *val_boot, int64_t val_stride, const float *val_prev, float *rewards,
+                          float *dones, float *deltas, int B, int64_t T, int64_t slot0,
+                          float gamma, a2c_stream_t stream);
+/* dst[b*dst_stride + j] = src[b*src_stride + j], j < n  (h_states[e] = h, runner.py:201;
+ * gathers/scatters of per-step rows of the rollout-major buffers)                       */
+int a2c_copy_rows(const float *src, int64_t src_stride, float *dst, int64_t dst_stride, int B,
+                  int64_t n, a2c_stream_t stream);
+/* x[b, :] *= (1 - dones[b*done_stride])   (hs = hs*(1-dones[:,i]), updater.py:164)      */
+int a2c_mask_rows(float *x, int64_t ld, const float *dones, int64_t done_stride, int B, int n,
+                  a2c_stream_t stream);
+/* dst[(t*R + r)*n + j] = src[(r*T + t)*n + j]: swaps the two leading axes of a (R,T,n) array
+ * (rollout-major <-> time-major views of the buffers for the BPTT unroll, updater.py:155-168) */
+int a2c_permute_rows(const float *src, float *dst, int64_t R, int64_t T, int64_t n,
+                     a2c_stream_t stream);
+
+/* ------------------------------------------------------------------ a8: loss
+ * updater.py:100-106,124-127 forward AND backward in one pass over N_local rows:
+ *   lsm = log_softmax(logits); log_p = lsm[n, actions[n]];
+ *   Entropy = -entr_coef * mean_n sum_a lsm*softmax;  Pi_Loss = -pi_coef * mean(log_p*adv);
+ *   ValLoss = val_coef * mean((V-R)^2);  Loss = Pi_Loss + ValLoss - Entropy,
+ * means over n_global rows (n_global > n_local when the batch is sharded over GPUs).
+ * If adv_sums != NULL the advantages are normalised on the fly as in a2c_normalize
+ * (norm_advs, updater.py:97-98) using eps 1e-6.
+ * Outputs: dlogits (N, ldd) = dLoss/dlogits, dvals (N) = dLoss/dV,
+ * loss_sums[0..2] (double, zeroed by the call) = sum log_p*adv, sum (V-R)^2, sum_n sum_a p*lsm
+ * over the local rows.                                                                  */
+int a2c_loss_fwd_bwd(const float *logits, int64_t ld_logits, const float *vals, int64_t val_stride,
+                     const int64_t *actions, const float *advs, const float *returns,
+                     const double *adv_sums, int64_t n_local, int64_t n_global, int A,
+                     float pi_coef, float val_coef, float entr_coef, float *dlogits, int64_t ldd,
+                     float *dvals, int64_t dval_stride, double *loss_sums, a2c_stream_t stream);
+
+/* ------------------------------------------------------------------ a6: dense layers
+ * C[M,N] = (accumulate ? C : 0) + opA(A)[M,K] * opB(B)[K,N] (+ bias[N]) ; then optional ReLU ; then optional
+ * multiply by (mask[m*ldmask+n] > 0) (the ReLU derivative of the layer below, fused into
+ * the producer).  fp32 in / fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32:
+ * exact fp32 FMA chain in k order).
+ *   transA = 0: A stored [M][lda] (k contiguous);  transA = 1: A stored [K][lda] (m contiguous)
+ *   transB = 0: B stored [K][ldb] (n contiguous);  transB = 1: B stored [N][ldb] (k contiguous)
+ * splitk > 1 splits K over gridDim.z into partial slabs in ws that a second kernel sums in
+ * fixed order (deterministic); ws_bytes >= a2c_gemm_ws_bytes(M,N,splitk).
+ * Linear forward  y = x W^T + b  (torch.nn.Linear, models.py:73,84,85 ...): transA=0, transB=1.
+ * Linear backward dx = dy W: transA=0, transB=0;  dW = dy^T x: transA=1, transB=0.       */
+size_t a2c_gemm_ws_bytes(int64_t M, int64_t N, int splitk);
+int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A,
+                 int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                 const float *bias, int relu, const float *mask, int64_t ldmask, int accumulate,
+                 int splitk, void *ws, size_t ws_bytes, a2c_stream_t stream);
+int a2c_gemm_f32_nt(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
+                    int64_t ldb, float *C, int64_t ldc, const float *bias, int relu,
+                    a2c_stream_t stream);
+int a2c_gemm_f32_nn(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
+                    int64_t ldb, float *C, int64_t ldc, const float *mask, int64_t ldmask,
+                    a2c_stream_t stream);
+int a2c_gemm_f32_tn(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
+                    int64_t ldb, float *C, int64_t ldc, int splitk, void *ws, size_t ws_bytes,
+                    a2c_stream_t stream);
+/* out[n] = sum_m x[m*ld + n]   (bias gradients), deterministic two-stage reduction;
+ * ws_bytes >= a2c_colsum_ws_bytes(N)                                                    */
+size_t a2c_colsum_ws_bytes(int64_t N);
+int a2c_colsum(const float *x, int64_t ld, int64_t M, int64_t N, float *out, void *ws,
+               size_t ws_bytes, a2c_stream_t stream);
+
+/* ------------------------------------------------------------------ a6: convolutions
+ * torch.nn.Conv2d (+ReLU) of the model classes (models.py:98,312,685), NCHW fp32,
+ * square kernel ks, stride, zero padding pad.  LDS-staged input tiles, implicit-GEMM inner
+ * product on the fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+ * `in` samples are addressed with a per-sample stride in floats (so a forward can read
+ * states[idx*T+t] straight out of the rollout buffer); planes are contiguous H*W.
+ * Constraints: Cin % 4 == 0, Cout % 4 == 0 (true for every reference layer).
+ * wprep holds the weights re-laid as matrix-core A fragments; build it with
+ * a2c_conv2d_prep_weights after every optimiser step (sizes from a2c_conv2d_prep_floats).
+ *   kind 0: forward fragments      kind 1: backward-data fragments                      */
+typedef struct {
+  int Cin, H, W;      /* input planes and size              */
+  int Cout, ks, stride, pad;
+  int OH, OW;         /* output size = (H - ks + 2 pad)/stride + 1 */
+} a2c_conv_desc;
+size_t a2c_conv2d_prep_floats(const a2c_conv_desc *d, int kind);
+int a2c_conv2d_prep_weights(const a2c_conv_desc *d, int kind, const float *weight, float *wprep,
+                            a2c_stream_t stream);
+/* out = relu?(conv(in, W) + bias)                                                       */
+int a2c_conv2d_fwd(const a2c_conv_desc *d, const float *in, int64_t in_bstride,
+                   const float *wprep_fwd, const float *bias, int relu, float *out,
+                   int64_t out_bstride, int B, a2c_stream_t stream);
+/* din = conv_transpose(dout, W), then optionally din *= (mask > 0) where mask is the
+ * (B,Cin,H,W) activation that fed this conv (the ReLU below it)                          */
+int a2c_conv2d_bwd_data(const a2c_conv_desc *d, const float *dout, const float *wprep_bwd,
+                        const float *mask, float *din, int B, a2c_stream_t stream);
+/* dW (Cout,Cin,ks,ks) and db (Cout) summed over the batch: per-workgroup partial slabs in
+ * ws + fixed-order reduction (deterministic).                                            */
+size_t a2c_conv2d_bwd_weight_ws_bytes(const a2c_conv_desc *d, int B);
+int a2c_conv2d_bwd_weight(const a2c_conv_desc *d, const float *in, int64_t in_bstride,
+                          const float *dout, float *dW, float *db, int B, void *ws,
+                          size_t ws_bytes, a2c_stream_t stream);
+
+/* ------------------------------------------------------------------ a6: GRU cell, LayerNorm
+ * models.GRU.forward (models.py:465-476) given the six pre-activation products:
+ *   gx = x [Wx0|Wx1|Wx2] (B,3h),  gh = h [Wh0|Wh1] (B,2h),  and, after r is known,
+ *   rh_u = (r*h) Wh2 (B,h).  Two elementwise stages around the (r*h) GEMM:
+ *   stage1: z = sig(gx0+gh0+b0), r = sig(gx1+gh1+b1), rh = r*h
+ *   stage2: c = tanh(gx2 + rh_u + b2), h_new = z*h + (1-z)*c                             */
+int a2c_gru_gates(const float *gx, const float *gh, const float *b, const float *h, float *z,
+                  float *r, float *rh, int B, int hdim, a2c_stream_t stream);
+int a2c_gru_out(const float *gx, const float *rh_u, const float *b, const float *h,
+                const float *z, float *c, float *h_new, int B, int hdim, a2c_stream_t stream);
+/* backward of stage2: given dh_new (B,h): dc_pre = dh_new*(1-z)*(1-c^2) (B,h) ;
+ * dz = dh_new*(h - c) ; dh_direct = dh_new*z                                            */
+int a2c_gru_out_bwd(const float *dh_new, const float *h, const float *z, const float *c,
+                    float *dc_pre, float *dz, float *dh, int B, int hdim, a2c_stream_t stream);
+/* backward of stage1: d_rh (B,h) from the Wh2 GEMM; dz from above:
+ * dz_pre = dz*z*(1-z) ; dr = d_rh*h ; dr_pre = dr*r*(1-r) ; dh += d_rh*r               */
+int a2c_gru_gates_bwd(const float *d_rh, const float *dz, const float *h, const float *z,
+                      const float *r, float *dz_pre, float *dr_pre, float *dh, int B, int hdim,
+                      a2c_stream_t stream);
+/* torch.nn.LayerNorm over the last dim n (eps 1e-5), FCModel value head (models.py:392) */
+int a2c_layernorm_fwd(const float *x, const float *w, const float *b, float *y, float *mean,
+                      float *rstd, int64_t rows, int n, a2c_stream_t stream);
+int a2c_layernorm_bwd(const float *dy, const float *x, const float *w, const float *mean,
+                      const float *rstd, float *dx, float *dw_rows, int64_t rows, int n,
+                      int accumulate_dx, a2c_stream_t stream);
+
+/* ------------------------------------------------------------------ a9: clip + optimiser
+ * sumsq[0] (double, zeroed by the call) = sum g^2 over the flat gradient arena
+ * (nn.utils.clip_grad_norm_, updater.py:129).                                           */
+int a2c_gradnorm_sq(const float *grads, int64_t n, double *sumsq, a2c_stream_t stream);
+/* clip (coef = min(1, max_norm/(norm+1e-6)), grads scaled in place like torch) and
+ * torch.optim.RMSprop step (alpha, eps; momentum 0, not centered): updater.py:131,227-228 */
+int a2c_clip_rmsprop(float *params, float *grads, float *square_avg, int64_t n,
+                     const double *sumsq, double max_norm, double lr, double alpha, double eps,
+                     float *norm_out, a2c_stream_t stream);
+/* same with torch.optim.Adam (beta1, beta2, eps, no amsgrad); step = 1-based step count */
+int a2c_clip_adam(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                  const double *sumsq, double max_norm, double lr, double beta1, double beta2,
+                  double eps, int64_t step, float *norm_out, a2c_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A2C_MI355X_H */

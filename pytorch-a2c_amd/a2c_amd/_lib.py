@@ -1,0 +1,99 @@
+"""ctypes binding of liba2c_mi355x.so (the C ABI declared in include/a2c_mi355x.h).
+
+The library is built in-tree by ``pytorch-a2c_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is no CPU fallback: if the library is missing, or a kernel is asked to run on a
+non-CUDA tensor, this module raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liba2c_mi355x.so")
+
+
+class ConvDesc(Structure):
+    """a2c_conv_desc"""
+    _fields_ = [("Cin", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("ks", c_int),
+                ("stride", c_int), ("pad", c_int), ("OH", c_int), ("OW", c_int)]
+
+
+P = c_void_p
+PD = POINTER(ConvDesc)
+
+# name -> (restype, argtypes); one entry per prototype in include/a2c_mi355x.h
+SIGNATURES = {
+    "a2c_version": (c_int, []),
+    "a2c_error_string": (c_char_p, [c_int]),
+    "a2c_discount_scan": (c_int, [P, P, P, c_int64, c_int64, c_float, P, P]),
+    "a2c_gae_returns_fused": (c_int, [P, P, P, P, P, c_int64, c_int64, c_float, c_float, P, P]),
+    "a2c_moments": (c_int, [P, c_int64, P, P]),
+    "a2c_normalize": (c_int, [P, P, c_int64, P, c_int64, c_float, P]),
+    "a2c_add": (c_int, [P, P, P, c_int64, P]),
+    "a2c_frame_stack_push": (c_int, [P, P, P, c_int64, P, c_int64, c_int, c_int, c_int, P]),
+    "a2c_softmax_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int, c_int, P]),
+    "a2c_sample_probs": (c_int, [P, P, P, c_int64, c_int, P]),
+    "a2c_rollout_record": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_int64, c_int64, c_int64,
+                                    c_float, c_int, P]),
+    "a2c_rollout_bootstrap": (c_int, [P, c_int64, P, P, P, P, c_int, c_int64, c_int64, c_float, P]),
+    "a2c_copy_rows": (c_int, [P, c_int64, P, c_int64, c_int, c_int64, P]),
+    "a2c_mask_rows": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P]),
+    "a2c_permute_rows": (c_int, [P, P, c_int64, c_int64, c_int64, P]),
+    "a2c_loss_fwd_bwd": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, c_int64, c_int, c_float, c_float,
+                                  c_float, P, c_int64, P, c_int64, P, P]),
+    "a2c_gemm_ws_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "a2c_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64,
+                              P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
+    "a2c_gemm_f32_nt": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int, P]),
+    "a2c_gemm_f32_nn": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P]),
+    "a2c_gemm_f32_tn": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int, P,
+                                 c_size_t, P]),
+    "a2c_colsum_ws_bytes": (c_size_t, [c_int64]),
+    "a2c_colsum": (c_int, [P, c_int64, c_int64, c_int64, P, P, c_size_t, P]),
+    "a2c_conv2d_prep_floats": (c_size_t, [PD, c_int]),
+    "a2c_conv2d_prep_weights": (c_int, [PD, c_int, P, P, P]),
+    "a2c_conv2d_fwd": (c_int, [PD, P, c_int64, P, P, c_int, P, c_int64, c_int, P]),
+    "a2c_conv2d_bwd_data": (c_int, [PD, P, P, P, P, c_int, P]),
+    "a2c_conv2d_bwd_weight_ws_bytes": (c_size_t, [PD, c_int]),
+    "a2c_conv2d_bwd_weight": (c_int, [PD, P, c_int64, P, P, P, c_int, P, c_size_t, P]),
+    "a2c_gru_gates": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
+    "a2c_gru_out": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
+    "a2c_gru_out_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
+    "a2c_gru_gates_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "a2c_layernorm_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int, P]),
+    "a2c_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
+    "a2c_gradnorm_sq": (c_int, [P, c_int64, P, P]),
+    "a2c_clip_rmsprop": (c_int, [P, P, P, c_int64, P, c_double, c_double, c_double, c_double, P, P]),
+    "a2c_clip_adam": (c_int, [P, P, P, P, c_int64, P, c_double, c_double, c_double, c_double, c_double,
+                               c_int64, P, P]),
+}
+
+_lib = None
+
+
+class A2CKernelError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once) and declare every prototype.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP kernels first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C pytorch-a2c_amd/csrc). a2c_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().a2c_error_string(rc).decode()
+        raise A2CKernelError(f"{what}: {msg} (code {rc})")

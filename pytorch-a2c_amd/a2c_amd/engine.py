@@ -1,0 +1,116 @@
+"""Host-side building blocks shared by the model classes: the flat parameter arena, conv /
+linear layer launch helpers with their backward passes.  Everything here only enqueues HIP
+kernels through ``ops`` (the C ABI); no arithmetic happens on the host."""
+import torch
+
+from . import ops
+
+ALIGN = 4  # floats: every tensor starts 16 B aligned in the arena
+
+
+class Arena:
+    """All parameters of a net in ONE contiguous fp32 device buffer (+ a parallel gradient
+    buffer).  Parameters that receive gradients come first (``[0, n_train)``): that prefix is
+    what clip+optimiser kernels sweep and what RCCL all-reduces.  ``nn.Parameter.data`` of every
+    parameter is re-pointed to a view of the arena, so ``state_dict`` / ``load_state_dict`` /
+    checkpoints keep working unchanged."""
+
+    def __init__(self, named_params, trainable_names, device):
+        train = [(n, p) for n, p in named_params if n in trainable_names]
+        rest = [(n, p) for n, p in named_params if n not in trainable_names]
+        self.offsets = {}
+        off = 0
+        for n, p in train:
+            self.offsets[n] = (off, p.numel(), tuple(p.shape))
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.n_train = off
+        for n, p in rest:
+            self.offsets[n] = (off, p.numel(), tuple(p.shape))
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.size = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=device)
+        self.trainable = [n for n, _ in train]
+        with torch.no_grad():
+            for n, p in train + rest:
+                o, k, shp = self.offsets[n]
+                view = self.params[o:o + k].view(shp)
+                view.copy_(p.data)
+                p.data = view
+        self._named = dict(train + rest)
+        self.attach_grads()
+
+    def attach_grads(self):
+        """Point ``p.grad`` of every trainable parameter at its slice of the gradient arena."""
+        for n in self.trainable:
+            o, k, shp = self.offsets[n]
+            self._named[n].grad = self.grads[o:o + k].view(shp)
+
+    def grad(self, name):
+        o, k, shp = self.offsets[name]
+        return self.grads[o:o + k].view(shp)
+
+    def train_params(self):
+        return self.params[:self.n_train]
+
+    def train_grads(self):
+        return self.grads[:self.n_train]
+
+
+class ConvLayer:
+    """One nn.Conv2d(+ReLU) block of a model: descriptor, matrix-core weight fragments."""
+
+    def __init__(self, Cin, H, W, Cout, ks, stride, pad, need_bwd_data):
+        self.d = ops.conv_desc(Cin, H, W, Cout, ks, stride, pad)
+        self.need_bwd_data = need_bwd_data
+        self.out_shape = (Cout, self.d.OH, self.d.OW)
+        self.in_floats = Cin * H * W
+        self.wf = self.wb = None
+
+    def prep(self, weight, st):
+        if self.wf is None:
+            self.wf = torch.empty(ops.conv_prep_floats(self.d, 0), dtype=torch.float32, device=weight.device)
+            if self.need_bwd_data:
+                self.wb = torch.empty(ops.conv_prep_floats(self.d, 1), dtype=torch.float32, device=weight.device)
+        ops.conv_prep(self.d, 0, weight, self.wf, st)
+        if self.need_bwd_data:
+            ops.conv_prep(self.d, 1, weight, self.wb, st)
+
+    def fwd(self, in_ptr, in_bstride, bias, out, B, st, relu=True):
+        ops.conv_fwd(self.d, in_ptr, in_bstride, self.wf, bias, relu, out, B, st)
+
+    def bwd_weight(self, in_ptr, in_bstride, dout, dW, db, B, ws, st):
+        buf = ws.bytes("conv_wgrad_ws", ops.conv_bwd_weight_ws_bytes(self.d, B))
+        ops.conv_bwd_weight(self.d, in_ptr, in_bstride, dout, dW, db, B, buf, st)
+
+    def bwd_data(self, dout, mask, din, B, st):
+        ops.conv_bwd_data(self.d, dout, self.wb, mask, din, B, st)
+
+
+def linear_fwd(ws, x_ptr, ldx, W, b, out, M, st, relu=False):
+    """out[M,N] = x[M,K] W[N,K]^T + b   (nn.Linear)"""
+    N, K = W.shape
+    sk = ops.pick_splitk(M, N, K)
+    buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(M, N, sk)) if sk > 1 else None
+    ops.gemm(0, 1, M, N, K, x_ptr, ldx, W.data_ptr(), K, out.data_ptr(), out.stride(0), bias=b, relu=relu,
+             splitk=sk, ws=buf, st=st)
+
+
+def linear_bwd_data(ws, dy, W, dx, M, st, mask=None, n_cols=None):
+    """dx[M,K] = dy[M,:n] W[:n,K]  (* (mask > 0)): gradient wrt the layer input, with the ReLU
+    derivative of the producer of that input fused in."""
+    N, K = W.shape
+    n = N if n_cols is None else n_cols
+    ops.gemm(0, 0, M, K, n, dy.data_ptr(), dy.stride(0), W.data_ptr(), K, dx.data_ptr(), dx.stride(0),
+             mask_ptr=0 if mask is None else mask.data_ptr(), ldmask=0 if mask is None else K, st=st)
+
+
+def linear_bwd_weight(ws, dy, x_ptr, ldx, dW, db, M, st):
+    """dW[N,K] = dy[M,N]^T x[M,K];  db[N] = sum_m dy[m,:]"""
+    N, K = dW.shape
+    sk = ops.pick_splitk(N, K, M)
+    buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(N, K, sk)) if sk > 1 else None
+    ops.gemm(1, 0, N, K, M, dy.data_ptr(), dy.stride(0), x_ptr, ldx, dW.data_ptr(), K, splitk=sk, ws=buf, st=st)
+    if db is not None:
+        cs = ws.bytes("colsum_ws", ops.colsum_ws_bytes(N))
+        ops.colsum(dy.data_ptr(), dy.stride(0), M, N, db, cs, st)

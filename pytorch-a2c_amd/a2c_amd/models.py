@@ -1,0 +1,805 @@
+"""Drop-in for the reference's ``a2c/models.py``: same class names, constructor arguments,
+``forward`` signatures / return values, attributes (``is_recurrent``, ``h_size``,
+``req_grads``) and ``state_dict`` keys -- but forward AND backward run on the MI355X kernels
+of liba2c_mi355x.so (LDS-tiled matrix-core convolutions, fp32 MFMA GEMMs, fused GRU gates).
+
+The torch ``nn`` sub-modules created here are only parameter containers (they give the
+reference's exact key names, parameter order and default initialisation); their own
+``forward`` is never called.  All parameters live in one flat HBM arena (engine.Arena).
+
+Quirks of the reference that change results and are reproduced:
+  * A3CModel: no activation after ``proj_matrx`` (models.py:73); the value head reads a
+    DETACHED embedding (models.py:85) so the value loss never reaches the encoder;
+    ``emb_bnorm`` exists but is unused -> its parameters never get a gradient.
+  * GRUModel ``conv_block(activation="lerelu")`` resolves to ReLU (models.py:681-689).
+  * GRU cell: h = z*h_old + (1-z)*tanh(x Wx2 + (r*h_old) Wh2 + b2), weights (3,in,h) used as
+    ``x.mm(W)`` (models.py:472-475).
+  * FCModel / GRUFCModel value head = LayerNorm -> Linear(h,1) -> Linear(1,1) (models.py:392-394).
+Out of scope: ``bnorm=True`` paths, continuous actions, the unused noise helpers.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .engine import Arena, ConvLayer, linear_bwd_data, linear_bwd_weight, linear_fwd
+
+
+def _conv_block(cin, cout, ks, stride, pad):
+    return nn.Sequential(nn.Conv2d(cin, cout, ks, stride=stride, padding=pad), nn.ReLU())
+
+
+class _HipNet(nn.Module):
+    """Machinery shared by every model: arena, workspaces, public forward, autograd bridge."""
+
+    is_recurrent = False
+    _unused_params = ()          # parameter names that never receive a gradient
+
+    # ------------------------------------------------------------------ arena / device
+    def _post_init(self):
+        self._arena = None
+        self._ws = {}
+        self._dirty = True
+        self._saved = {}
+
+    def _arena_order(self):
+        return [n for n, _ in self.named_parameters()]
+
+    def _ensure_device(self):
+        if self._arena is not None:
+            return
+        if not torch.cuda.is_available():
+            raise RuntimeError("a2c_amd models need a HIP device: there is no CPU fallback")
+        named = dict(self.named_parameters())
+        dev = torch.device("cuda", torch.cuda.current_device())
+        for b_name, b in self.named_buffers():
+            b.data = b.data.to(dev)
+        order = self._arena_order()
+        trainable = [n for n in order if n not in self._unused_params]
+        self._arena = Arena([(n, named[n]) for n in order], set(trainable), dev)
+        self._dev = dev
+        self._dirty = True
+        self._bind_params()
+
+    def _apply(self, fn, *a, **k):
+        # .cuda()/.to()/.share_memory() rebuild per-parameter storage: drop the arena, it is
+        # rebuilt (from the moved parameters) at the next kernel call.
+        out = super()._apply(fn, *a, **k)
+        self._arena = None
+        self._ws = {}
+        self._dirty = True
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._dirty = True
+        return out
+
+    def mark_dirty(self):
+        """Tell the net its parameters changed (re-derives the conv weight fragments)."""
+        self._dirty = True
+
+    def ws(self, tag):
+        w = self._ws.get(tag)
+        if w is None:
+            w = self._ws[tag] = ops.Workspace(self._dev)
+        return w
+
+    def _refresh(self, st):
+        if self._dirty:
+            self._prep(st)
+            self._dirty = False
+
+    def _prep(self, st):
+        pass
+
+    def P(self, name):
+        return self._pd[name]
+
+    def _bind_params(self):
+        self._pd = dict(self.named_parameters())
+
+    def G(self, name):
+        return self._arena.grad(name)
+
+    def req_grads(self, calc_bool):
+        for p in self.parameters():
+            p.requires_grad = calc_bool
+
+    def check_grads(self):
+        for p in self.parameters():
+            if torch.sum(p.data != p.data) > 0:
+                print("NaNs in Grad!")
+
+    # ------------------------------------------------------------------ public forward
+    def _to_dev(self, t):
+        self._ensure_device()
+        return t.detach().to(device=self._dev, dtype=torch.float32).contiguous()
+
+    def forward(self, x, old_h=None):
+        """(val (B,1), logits (B,A)[, h (B,h_size)]) like the reference.  With autograd enabled
+        and parameters requiring grad, the result is differentiable (HIP backward kernels)."""
+        self._ensure_device()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        xd = self._to_dev(x)
+        hd = self._to_dev(old_h) if self.is_recurrent else None
+        if self.is_recurrent and old_h is None:
+            raise TypeError("recurrent model: forward(x, old_h)")
+        if not need_grad:
+            out = self._run_forward(xd, hd, "pub", save=False)
+            return tuple(o.clone() for o in out)
+        params = [p for n, p in self.named_parameters() if n not in self._unused_params]
+        h_arg = old_h if (self.is_recurrent and torch.is_tensor(old_h) and old_h.requires_grad) else None
+        return _NetFunction.apply(self, xd, hd, h_arg, *params)
+
+    def _run_forward(self, xd, hd, tag, save):
+        B = xd.shape[0]
+        st = ops.stream()
+        self._refresh(st)
+        bstride = xd[0].numel()
+        if self.is_recurrent:
+            o = self._fwd(xd.data_ptr(), bstride, B, tag, st, save, h_in=hd)
+            return o["vals"].view(B, 1), o["logits"], o["h"]
+        o = self._fwd(xd.data_ptr(), bstride, B, tag, st, save)
+        return o["vals"].view(B, 1), o["logits"]
+
+    # heads buffer: (B, A+1) = [logits | value]; gradient buffer has the same layout
+    def _heads(self, tag, B):
+        A = self.output_space
+        hb = self.ws(tag).get("heads", (B, A + 1))
+        return hb, hb[:, :A], hb[:, A]
+
+    def dheads(self, tag, B):
+        A = self.output_space
+        db = self.ws(tag).get("dheads", (B, A + 1))
+        return db, db[:, :A], db[:, A]
+
+
+class _NetFunction(torch.autograd.Function):
+    """Autograd bridge for the public ``net(x)`` call: backward runs the HIP backward pass."""
+
+    @staticmethod
+    def forward(ctx, net, xd, hd, h_arg, *params):
+        out = net._run_forward(xd, hd, "ag", save=True)
+        ctx.net, ctx.xd, ctx.hd = net, xd, hd
+        ctx.has_h = h_arg is not None
+        return tuple(o.clone() for o in out)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        net, xd = ctx.net, ctx.xd
+        B = xd.shape[0]
+        st = ops.stream()
+        A = net.output_space
+        db, dl, dv = net.dheads("ag", B)
+        db.zero_()
+        if gouts[1] is not None:
+            dl.copy_(gouts[1])
+        if gouts[0] is not None:
+            dv.copy_(gouts[0].reshape(B))
+        dh_next = None
+        if net.is_recurrent and len(gouts) > 2 and gouts[2] is not None:
+            dh_next = gouts[2].contiguous()
+        dh_in = net._bwd(xd.data_ptr(), xd[0].numel(), B, "ag", st, dh_next=dh_next) if net.is_recurrent else \
+            net._bwd(xd.data_ptr(), xd[0].numel(), B, "ag", st)
+        grads = [net.G(n).clone() for n, _ in net.named_parameters() if n not in net._unused_params]
+        gh = dh_in.clone() if (ctx.has_h and dh_in is not None) else None
+        return (None, None, None, gh, *grads)
+
+
+# ====================================================================== A3CModel
+class A3CModel(_HipNet):
+    """models.py:7-175."""
+    _unused_params = ("emb_bnorm.weight", "emb_bnorm.bias")
+
+    def __init__(self, input_space, output_space, h_size=256, bnorm=False, is_discrete=True, **kwargs):
+        super().__init__()
+        if bnorm or not is_discrete:
+            raise NotImplementedError("a2c_amd: bnorm / continuous actions are out of scope (see DESIGN.md)")
+        self.is_recurrent = False
+        self.input_space, self.output_space, self.h_size, self.is_discrete = input_space, output_space, h_size, True
+        C, H, W = input_space[-3:]
+        self.convs = nn.ModuleList([])
+        self.conv1 = _conv_block(C, 16, 8, 4, 0)
+        self.convs.append(self.conv1)
+        self.conv2 = _conv_block(16, 32, 4, 2, 0)
+        self.convs.append(self.conv2)
+        self.features = nn.Sequential(*self.convs)
+        self._c1 = ConvLayer(C, H, W, 16, 8, 4, 0, need_bwd_data=False)
+        _, h1, w1 = self._c1.out_shape
+        self._c2 = ConvLayer(16, h1, w1, 32, 4, 2, 0, need_bwd_data=True)
+        self.flat_size = int(np.prod(self._c2.out_shape))
+        self.proj_matrx = nn.Linear(self.flat_size, h_size)
+        self.emb_bnorm = nn.BatchNorm1d(h_size)
+        self.pi = nn.Linear(h_size, output_space)
+        self.value = nn.Linear(h_size, 1)
+        self._post_init()
+
+    def _arena_order(self):
+        return ["convs.0.0.weight", "convs.0.0.bias", "convs.1.0.weight", "convs.1.0.bias", "proj_matrx.weight",
+                "proj_matrx.bias", "pi.weight", "value.weight", "pi.bias", "value.bias", "emb_bnorm.weight",
+                "emb_bnorm.bias"]
+
+    def _prep(self, st):
+        self._c1.prep(self.P("convs.0.0.weight"), st)
+        self._c2.prep(self.P("convs.1.0.weight"), st)
+
+    def _fwd(self, x_ptr, bstride, B, tag, st, save):
+        ws, P = self.ws(tag), self.P
+        A, h = self.output_space, self.h_size
+        a1 = ws.get("a1", (B,) + self._c1.out_shape)
+        a2 = ws.get("a2", (B,) + self._c2.out_shape)
+        emb = ws.get("emb", (B, h))
+        self._c1.fwd(x_ptr, bstride, P("convs.0.0.bias"), a1, B, st)
+        self._c2.fwd(a1.data_ptr(), a1[0].numel(), P("convs.1.0.bias"), a2, B, st)
+        linear_fwd(ws, a2.data_ptr(), self.flat_size, P("proj_matrx.weight"), P("proj_matrx.bias"), emb, B, st)
+        hb, logits, vals = self._heads(tag, B)
+        # [pi.weight; value.weight] and [pi.bias | value.bias] are adjacent in the arena: one GEMM
+        Wh = self._arena.params[self._arena.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
+        bh = self._arena.params[self._arena.offsets["pi.bias"][0]:][:A + 1]
+        linear_fwd(ws, emb.data_ptr(), h, Wh, bh, hb, B, st)
+        return dict(logits=logits, vals=vals)
+
+    def _bwd(self, x_ptr, bstride, B, tag, st):
+        ws, P, G = self.ws(tag), self.P, self.G
+        A, h = self.output_space, self.h_size
+        a1 = ws.get("a1", (B,) + self._c1.out_shape)
+        a2 = ws.get("a2", (B,) + self._c2.out_shape)
+        emb = ws.get("emb", (B, h))
+        db, dl, dv = self.dheads(tag, B)
+        ar = self._arena
+        dWh = ar.grads[ar.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
+        dbh = ar.grads[ar.offsets["pi.bias"][0]:][:A + 1]
+        linear_bwd_weight(ws, db, emb.data_ptr(), h, dWh, dbh, B, st)
+        demb = ws.get("demb", (B, h))
+        linear_bwd_data(ws, db, P("pi.weight"), demb, B, st, n_cols=A)        # value head is detached
+        linear_bwd_weight(ws, demb, a2.data_ptr(), self.flat_size, G("proj_matrx.weight"), G("proj_matrx.bias"), B, st)
+        da2 = ws.get("da2", (B,) + self._c2.out_shape)
+        linear_bwd_data(ws, demb, P("proj_matrx.weight"), da2.view(B, -1), B, st, mask=a2)
+        self._c2.bwd_weight(a1.data_ptr(), a1[0].numel(), da2, G("convs.1.0.weight"), G("convs.1.0.bias"), B, ws, st)
+        da1 = ws.get("da1", (B,) + self._c1.out_shape)
+        self._c2.bwd_data(da2, a1, da1, B, st)
+        self._c1.bwd_weight(x_ptr, bstride, da1, G("convs.0.0.weight"), G("convs.0.0.bias"), B, ws, st)
+
+
+# ====================================================================== conv-stack models
+class _ConvStackNet(_HipNet):
+    """Shared by ConvModel and GRUModel: a stack of 3x3 conv+ReLU blocks."""
+
+    def _build_convs(self, input_space, specs):
+        C, H, W = input_space[-3:]
+        self.convs = nn.ModuleList([])
+        self._cl = []
+        for i, (co, ks, s, p) in enumerate(specs):
+            self.convs.append(_conv_block(C, co, ks, s, p))
+            layer = ConvLayer(C, H, W, co, ks, s, p, need_bwd_data=(i > 0))
+            self._cl.append(layer)
+            C, H, W = layer.out_shape
+        self.features = nn.Sequential(*self.convs)
+        self.flat_size = C * H * W
+
+    def _prep(self, st):
+        for i, l in enumerate(self._cl):
+            l.prep(self.P(f"convs.{i}.0.weight"), st)
+
+    def _convs_fwd(self, x_ptr, bstride, B, ws, st):
+        acts = []
+        ptr, bs = x_ptr, bstride
+        for i, l in enumerate(self._cl):
+            a = ws.get(f"a{i}", (B,) + l.out_shape)
+            l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), a, B, st)
+            acts.append(a)
+            ptr, bs = a.data_ptr(), a[0].numel()
+        return acts
+
+    def _convs_bwd(self, x_ptr, bstride, B, ws, st, d_last):
+        """d_last: gradient wrt the last conv's pre-activation output (ReLU mask already applied)."""
+        n = len(self._cl)
+        acts = [ws.get(f"a{i}", (B,) + l.out_shape) for i, l in enumerate(self._cl)]
+        d = d_last
+        for i in range(n - 1, -1, -1):
+            l = self._cl[i]
+            in_ptr, in_bs = (x_ptr, bstride) if i == 0 else (acts[i - 1].data_ptr(), acts[i - 1][0].numel())
+            l.bwd_weight(in_ptr, in_bs, d, self.G(f"convs.{i}.0.weight"), self.G(f"convs.{i}.0.bias"), B, ws, st)
+            if i > 0:
+                dprev = ws.get(f"da{i-1}", (B,) + self._cl[i - 1].out_shape)
+                l.bwd_data(d, acts[i - 1], dprev, B, st)
+                d = dprev
+
+
+class ConvModel(_ConvStackNet):
+    """models.py:177-365."""
+    SPECS = [(16, 3, 1, 1), (24, 3, 1, 1), (32, 3, 2, 1), (64, 3, 2, 1)]
+    CONV_H = 2000
+
+    def __init__(self, input_space, output_space, h_size=288, bnorm=False, is_discrete=True, **kwargs):
+        super().__init__()
+        if bnorm or not is_discrete:
+            raise NotImplementedError("a2c_amd: bnorm / continuous actions are out of scope (see DESIGN.md)")
+        self.is_recurrent = False
+        self.input_space, self.output_space, self.h_size = input_space, output_space, h_size
+        self.bnorm, self.is_discrete = False, True
+        self._build_convs(input_space, self.SPECS)
+        print("Flat Features Size:", self.flat_size)
+        ch = self.CONV_H
+        self.resize_emb = nn.Sequential(nn.Linear(self.flat_size, ch), nn.ReLU())
+        self.pi = nn.Sequential(nn.Linear(ch, h_size), nn.ReLU(), nn.Linear(h_size, output_space))
+        self.value = nn.Sequential(nn.Linear(ch, h_size), nn.ReLU(), nn.Linear(h_size, 1))
+        if h_size % 4:
+            raise ValueError("a2c_amd ConvModel: h_size must be a multiple of 4")
+        self._post_init()
+
+    def _arena_order(self):
+        names = []
+        for i in range(4):
+            names += [f"convs.{i}.0.weight", f"convs.{i}.0.bias"]
+        # pi.0 / value.0 adjacent: the two hidden layers run as ONE (2h x 2000) GEMM
+        return names + ["resize_emb.0.weight", "resize_emb.0.bias", "pi.0.weight", "value.0.weight", "pi.0.bias",
+                        "value.0.bias", "pi.2.weight", "pi.2.bias", "value.2.weight", "value.2.bias"]
+
+    def _cat(self, buf, name, rows, cols=None):
+        o = self._arena.offsets[name][0]
+        t = buf[o:o + rows * (cols or 1)]
+        return t.view(rows, cols) if cols else t
+
+    def _fwd(self, x_ptr, bstride, B, tag, st, save):
+        ws, P = self.ws(tag), self.P
+        A, h, ch = self.output_space, self.h_size, self.CONV_H
+        acts = self._convs_fwd(x_ptr, bstride, B, ws, st)
+        e = ws.get("e", (B, ch))
+        linear_fwd(ws, acts[-1].data_ptr(), self.flat_size, P("resize_emb.0.weight"), P("resize_emb.0.bias"), e, B, st,
+                   relu=True)
+        hid = ws.get("hid", (B, 2 * h))
+        linear_fwd(ws, e.data_ptr(), ch, self._cat(self._arena.params, "pi.0.weight", 2 * h, ch),
+                   self._cat(self._arena.params, "pi.0.bias", 2 * h), hid, B, st, relu=True)
+        hb, logits, vals = self._heads(tag, B)
+        linear_fwd(ws, hid.data_ptr(), 2 * h, P("pi.2.weight"), P("pi.2.bias"), logits, B, st)
+        linear_fwd(ws, hid.data_ptr() + 4 * h, 2 * h, P("value.2.weight"), P("value.2.bias"), hb[:, A:], B, st)
+        return dict(logits=logits, vals=vals)
+
+    def _bwd(self, x_ptr, bstride, B, tag, st):
+        ws, P, G = self.ws(tag), self.P, self.G
+        A, h, ch = self.output_space, self.h_size, self.CONV_H
+        acts = [ws.get(f"a{i}", (B,) + l.out_shape) for i, l in enumerate(self._cl)]
+        e = ws.get("e", (B, ch))
+        hid = ws.get("hid", (B, 2 * h))
+        db, dl, dv = self.dheads(tag, B)
+        dvm = db[:, A:]
+        linear_bwd_weight(ws, dl, hid.data_ptr(), 2 * h, G("pi.2.weight"), G("pi.2.bias"), B, st)
+        linear_bwd_weight(ws, dvm, hid.data_ptr() + 4 * h, 2 * h, G("value.2.weight"), G("value.2.bias"), B, st)
+        dhid = ws.get("dhid", (B, 2 * h))
+        ops.gemm(0, 0, B, h, A, dl.data_ptr(), A + 1, P("pi.2.weight").data_ptr(), h, dhid.data_ptr(), 2 * h,
+                 mask_ptr=hid.data_ptr(), ldmask=2 * h, st=st)
+        ops.gemm(0, 0, B, h, 1, dvm.data_ptr(), A + 1, P("value.2.weight").data_ptr(), h, dhid.data_ptr() + 4 * h,
+                 2 * h, mask_ptr=hid.data_ptr() + 4 * h, ldmask=2 * h, st=st)
+        linear_bwd_weight(ws, dhid, e.data_ptr(), ch, self._cat(self._arena.grads, "pi.0.weight", 2 * h, ch),
+                          self._cat(self._arena.grads, "pi.0.bias", 2 * h), B, st)
+        de = ws.get("de", (B, ch))
+        linear_bwd_data(ws, dhid, self._cat(self._arena.params, "pi.0.weight", 2 * h, ch), de, B, st, mask=e)
+        linear_bwd_weight(ws, de, acts[-1].data_ptr(), self.flat_size, G("resize_emb.0.weight"),
+                          G("resize_emb.0.bias"), B, st)
+        dlast = ws.get(f"da{len(acts)-1}", (B,) + self._cl[-1].out_shape)
+        linear_bwd_data(ws, de, P("resize_emb.0.weight"), dlast.view(B, -1), B, st, mask=acts[-1])
+        self._convs_bwd(x_ptr, bstride, B, ws, st, dlast)
+
+
+# ====================================================================== GRU cell helper
+class GRU(nn.Module):
+    """Parameter container with the reference's names / shapes / init (models.py:426-481)."""
+
+    def __init__(self, x_size=256, h_size=256, layer_norm=False, **kwargs):
+        super().__init__()
+        self.x_size, self.h_size, self.n_state_vars = x_size, h_size, 1
+        std = 1 / float(np.sqrt(h_size))
+        self.W_x = nn.Parameter(torch.normal(torch.zeros(3, x_size, h_size), std=std), requires_grad=True)
+        self.W_h = nn.Parameter(torch.normal(torch.zeros(3, h_size, h_size), std=std), requires_grad=True)
+        self.b = nn.Parameter(torch.zeros(3, 1, h_size), requires_grad=True)
+
+    def forward(self, x, old_h):
+        raise RuntimeError("a2c_amd.GRU is a parameter container; call the owning model")
+
+
+class _GruMixin:
+    """GRU cell forward / backward over B rows on the HIP kernels (6 GEMMs + 2 fused gate
+    kernels forward).  Buffers are (B, h) contiguous; `pre` prefixes workspace names so the
+    BPTT unroll can keep one set per time step (time-major)."""
+
+    def _gru_fwd(self, ws, x, h_in, B, st, bufs):
+        hd, xs = self.h_size, self.gru.x_size
+        Wx, Wh, b = self.P("gru.W_x"), self.P("gru.W_h"), self.P("gru.b")
+        gx, gh, z, r, rh, rhu, c, hn = (bufs[k] for k in ("gx", "gh", "z", "r", "rh", "rhu", "c", "hn"))
+        if x is not None:   # gx may have been precomputed for all time steps at once
+            for g in range(3):
+                ops.gemm(0, 0, B, hd, xs, x.data_ptr(), xs, Wx[g].data_ptr(), hd, gx.data_ptr() + 4 * g * hd, 3 * hd,
+                         st=st)
+        for g in range(2):
+            ops.gemm(0, 0, B, hd, hd, h_in.data_ptr(), hd, Wh[g].data_ptr(), hd, gh.data_ptr() + 4 * g * hd, 2 * hd,
+                     st=st)
+        ops.gru_gates(gx, gh, b, h_in, z, r, rh, st)
+        ops.gemm(0, 0, B, hd, hd, rh.data_ptr(), hd, Wh[2].data_ptr(), hd, rhu.data_ptr(), hd, st=st)
+        ops.gru_out(gx, rhu, b, h_in, z, c, hn, st)
+
+    def _gru_bwd_step(self, ws, dhn, h_in, B, st, bufs, dbufs):
+        """dhn (B,h) total gradient wrt this step's h_new.  Fills dbufs dz_pre/dr_pre/dc_pre and
+        returns dh_in (B,h) in dbufs['dh']."""
+        hd = self.h_size
+        Wh = self.P("gru.W_h")
+        z, r, c = bufs["z"], bufs["r"], bufs["c"]
+        dzp, drp, dcp, dz, drh, dh = (dbufs[k] for k in ("dz_pre", "dr_pre", "dc_pre", "dz", "d_rh", "dh"))
+        ops.gru_out_bwd(dhn, h_in, z, c, dcp, dz, dh, st)
+        ops.gemm(0, 1, B, hd, hd, dcp.data_ptr(), hd, Wh[2].data_ptr(), hd, drh.data_ptr(), hd, st=st)   # dc_pre Wh2^T
+        ops.gru_gates_bwd(drh, dz, h_in, z, r, dzp, drp, dh, st)
+        ops.gemm(0, 1, B, hd, hd, dzp.data_ptr(), hd, Wh[0].data_ptr(), hd, dh.data_ptr(), hd, accumulate=True, st=st)
+        ops.gemm(0, 1, B, hd, hd, drp.data_ptr(), hd, Wh[1].data_ptr(), hd, dh.data_ptr(), hd, accumulate=True, st=st)
+        return dh
+
+    def _gru_bwd_weights(self, ws, x, h_in, rh, dzp, drp, dcp, dx, M, st, x_mask=None):
+        """Batched over M rows (all time steps at once): dW_x, dW_h, db and dx = sum_g dG_g Wx_g^T."""
+        hd, xs = self.h_size, self.gru.x_size
+        Wx = self.P("gru.W_x")
+        dWx, dWh, dbg = self.G("gru.W_x"), self.G("gru.W_h"), self.G("gru.b")
+        dgs = (dzp, drp, dcp)
+        lefts = (h_in, h_in, rh)
+        cs = ws.bytes("colsum_ws", ops.colsum_ws_bytes(hd))
+        for g in range(3):
+            sk = ops.pick_splitk(xs, hd, M)
+            buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(xs, hd, sk)) if sk > 1 else None
+            ops.gemm(1, 0, xs, hd, M, x.data_ptr(), xs, dgs[g].data_ptr(), hd, dWx[g].data_ptr(), hd, splitk=sk, ws=buf,
+                     st=st)
+            sk = ops.pick_splitk(hd, hd, M)
+            buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(hd, hd, sk)) if sk > 1 else None
+            ops.gemm(1, 0, hd, hd, M, lefts[g].data_ptr(), hd, dgs[g].data_ptr(), hd, dWh[g].data_ptr(), hd, splitk=sk,
+                     ws=buf, st=st)
+            ops.colsum(dgs[g].data_ptr(), hd, M, hd, dbg[g], cs, st)
+        for g in range(3):
+            last = g == 2
+            ops.gemm(0, 1, M, xs, hd, dgs[g].data_ptr(), hd, Wx[g].data_ptr(), hd, dx.data_ptr(), xs,
+                     mask_ptr=x_mask.data_ptr() if (last and x_mask is not None) else 0, ldmask=xs,
+                     accumulate=(g > 0), st=st)
+
+    # ---- the recurrent part of the BPTT unroll (updater.py:161-166), time-major (T,R,.) buffers
+    def _tm_bufs(self, ws, R, T):
+        h = self.h_size
+        return {k: ws.get("tm_" + k, (T, R, s)) for k, s in
+                dict(gx=3 * h, gh=2 * h, z=h, r=h, rh=h, rhu=h, c=h, hn=h, h_in=h).items()}
+
+    def _bptt_cells_fwd(self, ws, x_tm, h_states, dones, R, T, st):
+        h, xs = self.h_size, self.gru.x_size
+        N = R * T
+        Wx = self.P("gru.W_x")
+        tm = self._tm_bufs(ws, R, T)
+        for g in range(3):   # x-side gate products for all steps at once
+            ops.gemm(0, 0, N, h, xs, x_tm.data_ptr(), xs, Wx[g].data_ptr(), h, tm["gx"].data_ptr() + 4 * g * h, 3 * h,
+                     st=st)
+        ops.copy_rows(h_states.data_ptr(), T * h, tm["h_in"][0].data_ptr(), h, R, h, st)   # hs = h_states[:,0]
+        for t in range(T):
+            bufs = {k: tm[k][t] for k in ("gx", "gh", "z", "r", "rh", "rhu", "c", "hn")}
+            self._gru_fwd(ws, None, tm["h_in"][t], R, st, bufs)
+            if t + 1 < T:     # hs = hs * (1 - dones[:, t])
+                nxt = tm["h_in"][t + 1]
+                ops.copy_rows(tm["hn"][t].data_ptr(), h, nxt.data_ptr(), h, R, h, st)
+                ops.mask_rows(nxt, dones.data_ptr() + 4 * t, T, st)
+        return tm
+
+    def _bptt_cells_bwd(self, ws, x_tm, dhn_tm, dones, R, T, st, x_mask):
+        """dhn_tm (T,R,h): gradient wrt every step's h_new coming from the heads.  Returns the
+        gradient wrt x_tm (time-major) and fills the GRU parameter gradients."""
+        h = self.h_size
+        N = R * T
+        tm = self._tm_bufs(ws, R, T)
+        dtm = {k: ws.get("tm_" + k, (T, R, h)) for k in ("dz_pre", "dr_pre", "dc_pre")}
+        scratch = {k: ws.get("bp_" + k, (R, h)) for k in ("dz", "d_rh", "dh")}
+        carry = None
+        for t in range(T - 1, -1, -1):
+            dhn = dhn_tm[t]
+            if carry is not None:
+                ops.add(dhn, carry, dhn, st)
+            bufs = {k: tm[k][t] for k in ("z", "r", "c")}
+            dbufs = dict(dz_pre=dtm["dz_pre"][t], dr_pre=dtm["dr_pre"][t], dc_pre=dtm["dc_pre"][t], **scratch)
+            dh = self._gru_bwd_step(ws, dhn, tm["h_in"][t], R, st, bufs, dbufs)
+            if t > 0:      # h_in[t] = hn[t-1] * (1 - dones[:, t-1])
+                ops.mask_rows(dh, dones.data_ptr() + 4 * (t - 1), T, st)
+                carry = dh
+        dx_tm = ws.get("dx_tm", (T, R, self.gru.x_size))
+        flat = lambda t_: t_.view(N, -1)
+        self._gru_bwd_weights(ws, flat(x_tm), flat(tm["h_in"]), flat(tm["rh"]), flat(dtm["dz_pre"]),
+                              flat(dtm["dr_pre"]), flat(dtm["dc_pre"]), flat(dx_tm), N, st,
+                              x_mask=None if x_mask is None else flat(x_mask))
+        return dx_tm
+
+    def _cell_bufs(self, ws, B, pre=""):
+        hd = self.h_size
+        shapes = dict(gx=(B, 3 * hd), gh=(B, 2 * hd), z=(B, hd), r=(B, hd), rh=(B, hd), rhu=(B, hd), c=(B, hd),
+                      hn=(B, hd))
+        return {k: ws.get(pre + k, s) for k, s in shapes.items()}
+
+    def _cell_dbufs(self, ws, B, pre=""):
+        hd = self.h_size
+        return {k: ws.get(pre + k, (B, hd)) for k in ("dz_pre", "dr_pre", "dc_pre", "dz", "d_rh", "dh")}
+
+
+class _LNValueMixin:
+    """value_out = LayerNorm -> Linear(h,1) -> Linear(1,1) (models.py:392-394)."""
+
+    def _value_fwd(self, ws, feat, B, st, vals_col):
+        P, h = self.P, self.h_size
+        ln, mean, rstd, v1 = ws.get("ln", (B, h)), ws.get("ln_mean", (B,)), ws.get("ln_rstd", (B,)), ws.get("v1", (B, 1))
+        ops.layernorm_fwd(feat, P("value_out.0.weight"), P("value_out.0.bias"), ln, mean, rstd, st)
+        linear_fwd(ws, ln.data_ptr(), h, P("value_out.1.weight"), P("value_out.1.bias"), v1, B, st)
+        linear_fwd(ws, v1.data_ptr(), 1, P("value_out.2.weight"), P("value_out.2.bias"), vals_col, B, st)
+
+    def _value_bwd(self, ws, feat, dvm, dfeat, B, st):
+        """dvm (B,1) strided column of the dheads buffer; writes dfeat (overwrite)."""
+        P, G, h = self.P, self.G, self.h_size
+        ln, mean, rstd, v1 = ws.get("ln", (B, h)), ws.get("ln_mean", (B,)), ws.get("ln_rstd", (B,)), ws.get("v1", (B, 1))
+        linear_bwd_weight(ws, dvm, v1.data_ptr(), 1, G("value_out.2.weight"), G("value_out.2.bias"), B, st)
+        dv1 = ws.get("dv1", (B, 1))
+        linear_bwd_data(ws, dvm, P("value_out.2.weight"), dv1, B, st)
+        linear_bwd_weight(ws, dv1, ln.data_ptr(), h, G("value_out.1.weight"), G("value_out.1.bias"), B, st)
+        dln = ws.get("dln", (B, h))
+        linear_bwd_data(ws, dv1, P("value_out.1.weight"), dln, B, st)
+        dwr = ws.get("ln_dw_rows", (B, h))
+        ops.layernorm_bwd(dln, feat, P("value_out.0.weight"), mean, rstd, dfeat, dwr, accumulate=False, st=st)
+        cs = ws.bytes("colsum_ws", ops.colsum_ws_bytes(h))
+        ops.colsum(dwr.data_ptr(), h, B, h, G("value_out.0.weight"), cs, st)
+        ops.colsum(dln.data_ptr(), h, B, h, G("value_out.0.bias"), cs, st)
+
+
+# ====================================================================== GRUModel
+class GRUModel(_ConvStackNet, _GruMixin):
+    """models.py:546-713."""
+    SPECS = [(16, 3, 1, 1), (24, 3, 2, 1), (32, 3, 2, 1), (48, 3, 2, 1), (64, 3, 2, 1)]
+
+    def __init__(self, input_space, output_space, h_size=288, bnorm=False, is_discrete=True, **kwargs):
+        super().__init__()
+        if bnorm or not is_discrete:
+            raise NotImplementedError("a2c_amd: bnorm / continuous actions are out of scope (see DESIGN.md)")
+        self.is_recurrent = True
+        self.input_space, self.output_space, self.h_size = input_space, output_space, h_size
+        self.bnorm, self.is_discrete = False, True
+        self._build_convs(input_space, self.SPECS)
+        print("Flat Features Size:", self.flat_size)
+        self.resize_emb = nn.Sequential(nn.Linear(self.flat_size, h_size), nn.ReLU())
+        self.gru = GRU(x_size=h_size, h_size=h_size)
+        self.pi = nn.Linear(h_size, output_space)
+        self.value = nn.Linear(h_size, 1)
+        if h_size % 4:
+            raise ValueError("a2c_amd GRUModel: h_size must be a multiple of 4")
+        self._post_init()
+
+    def _arena_order(self):
+        names = []
+        for i in range(5):
+            names += [f"convs.{i}.0.weight", f"convs.{i}.0.bias"]
+        return names + ["resize_emb.0.weight", "resize_emb.0.bias", "gru.W_x", "gru.W_h", "gru.b", "pi.weight",
+                        "value.weight", "pi.bias", "value.bias"]
+
+    def _head_w(self, buf):
+        A, h = self.output_space, self.h_size
+        ar = self._arena
+        return (buf[ar.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h), buf[ar.offsets["pi.bias"][0]:][:A + 1])
+
+    def _embed_fwd(self, x_ptr, bstride, B, ws, st):
+        acts = self._convs_fwd(x_ptr, bstride, B, ws, st)
+        e = ws.get("e", (B, self.h_size))
+        linear_fwd(ws, acts[-1].data_ptr(), self.flat_size, self.P("resize_emb.0.weight"),
+                   self.P("resize_emb.0.bias"), e, B, st, relu=True)
+        return e
+
+    def _embed_bwd(self, x_ptr, bstride, B, ws, st, de):
+        """de: gradient wrt e (ReLU mask already applied)."""
+        last = self._cl[-1]
+        a_last = ws.get(f"a{len(self._cl)-1}", (B,) + last.out_shape)
+        linear_bwd_weight(ws, de, a_last.data_ptr(), self.flat_size, self.G("resize_emb.0.weight"),
+                          self.G("resize_emb.0.bias"), B, st)
+        dlast = ws.get(f"da{len(self._cl)-1}", (B,) + last.out_shape)
+        linear_bwd_data(ws, de, self.P("resize_emb.0.weight"), dlast.view(B, -1), B, st, mask=a_last)
+        self._convs_bwd(x_ptr, bstride, B, ws, st, dlast)
+
+    def _fwd(self, x_ptr, bstride, B, tag, st, save, h_in):
+        ws = self.ws(tag)
+        e = self._embed_fwd(x_ptr, bstride, B, ws, st)
+        bufs = self._cell_bufs(ws, B)
+        hin = ws.get("h_in", (B, self.h_size))
+        hin.copy_(h_in)
+        self._gru_fwd(ws, e, hin, B, st, bufs)
+        hb, logits, vals = self._heads(tag, B)
+        Wh, bh = self._head_w(self._arena.params)
+        linear_fwd(ws, bufs["hn"].data_ptr(), self.h_size, Wh, bh, hb, B, st)
+        return dict(logits=logits, vals=vals, h=bufs["hn"])
+
+    def _bwd(self, x_ptr, bstride, B, tag, st, dh_next=None):
+        ws = self.ws(tag)
+        h = self.h_size
+        bufs, dbufs = self._cell_bufs(ws, B), self._cell_dbufs(ws, B)
+        hin, e = ws.get("h_in", (B, h)), ws.get("e", (B, h))
+        db, dl, dv = self.dheads(tag, B)
+        dWh, dbh = self._head_w(self._arena.grads)
+        linear_bwd_weight(ws, db, bufs["hn"].data_ptr(), h, dWh, dbh, B, st)
+        dhn = ws.get("dhn", (B, h))
+        Wh, _ = self._head_w(self._arena.params)
+        linear_bwd_data(ws, db, Wh, dhn, B, st)
+        if dh_next is not None:
+            ops.add(dhn, dh_next, dhn, st)
+        dh = self._gru_bwd_step(ws, dhn, hin, B, st, bufs, dbufs)
+        de = ws.get("de", (B, h))
+        self._gru_bwd_weights(ws, e, hin, bufs["rh"], dbufs["dz_pre"], dbufs["dr_pre"], dbufs["dc_pre"], de, B, st,
+                              x_mask=e)
+        self._embed_bwd(x_ptr, bstride, B, ws, st, de)
+        return dh
+
+    # ---- BPTT unroll (Updater.bptt, updater.py:139-169): R slots x T steps, time-major scratch
+    def bptt_forward(self, states, h_states, dones, R, T, tag, st):
+        ws, h, A = self.ws(tag), self.h_size, self.output_space
+        N = R * T
+        self._refresh(st)
+        e = self._embed_fwd(states.data_ptr(), states[0].numel(), N, ws, st)          # rollout-major (N,h)
+        e_tm = ws.get("e_tm", (T, R, h))
+        ops.permute_rows(e, e_tm, R, T, h, st)
+        tm = self._bptt_cells_fwd(ws, e_tm, h_states, dones, R, T, st)
+        heads_tm = ws.get("heads_tm", (N, A + 1))
+        Wh, bh = self._head_w(self._arena.params)
+        linear_fwd(ws, tm["hn"].data_ptr(), h, Wh, bh, heads_tm, N, st)
+        hb, logits, vals = self._heads(tag, N)
+        ops.permute_rows(heads_tm, hb, T, R, A + 1, st)          # back to rollout-major
+        return vals, logits
+
+    def bptt_backward(self, states, dones, R, T, tag, st):
+        ws, h, A = self.ws(tag), self.h_size, self.output_space
+        N = R * T
+        e_tm = ws.get("e_tm", (T, R, h))
+        hn_tm = ws.get("tm_hn", (T, R, h))
+        db, dl, dv = self.dheads(tag, N)
+        db_tm = ws.get("dheads_tm", (N, A + 1))
+        ops.permute_rows(db, db_tm, R, T, A + 1, st)
+        dWh, dbh = self._head_w(self._arena.grads)
+        linear_bwd_weight(ws, db_tm, hn_tm.data_ptr(), h, dWh, dbh, N, st)
+        dhn_tm = ws.get("dhn_tm", (T, R, h))
+        Wh, _ = self._head_w(self._arena.params)
+        linear_bwd_data(ws, db_tm, Wh, dhn_tm.view(N, h), N, st)
+        de_tm = self._bptt_cells_bwd(ws, e_tm, dhn_tm, dones, R, T, st, x_mask=e_tm)
+        de = ws.get("de", (N, h))
+        ops.permute_rows(de_tm, de, T, R, h, st)
+        self._embed_bwd(states.data_ptr(), states[0].numel(), N, ws, st, de)
+
+
+# ====================================================================== FCModel / GRUFCModel
+class _FCBase(_HipNet, _LNValueMixin):
+    def _build_base(self, input_shape, output_space, h_size):
+        self.flat_size = int(np.prod(input_shape[-3:]))
+        self.input_shape, self.output_space, self.h_size = input_shape, output_space, h_size
+        self.base = nn.Sequential(nn.Linear(self.flat_size, h_size), nn.ReLU(), nn.Linear(h_size, h_size))
+
+    def _build_heads(self, output_space, h_size):
+        self.action_out = nn.Linear(h_size, output_space)
+        self.value_out = nn.Sequential(nn.LayerNorm(h_size), nn.Linear(h_size, 1), nn.Linear(1, 1))
+
+    def _base_fwd(self, x_ptr, bstride, B, ws, st):
+        P, h = self.P, self.h_size
+        t1, fx = ws.get("t1", (B, h)), ws.get("fx", (B, h))
+        linear_fwd(ws, x_ptr, bstride, P("base.0.weight"), P("base.0.bias"), t1, B, st, relu=True)
+        linear_fwd(ws, t1.data_ptr(), h, P("base.2.weight"), P("base.2.bias"), fx, B, st)
+        return fx
+
+    def _base_bwd(self, x_ptr, bstride, B, ws, st, dfx):
+        P, G, h = self.P, self.G, self.h_size
+        t1 = ws.get("t1", (B, h))
+        linear_bwd_weight(ws, dfx, t1.data_ptr(), h, G("base.2.weight"), G("base.2.bias"), B, st)
+        dt1 = ws.get("dt1", (B, h))
+        linear_bwd_data(ws, dfx, P("base.2.weight"), dt1, B, st, mask=t1)
+        linear_bwd_weight(ws, dt1, x_ptr, bstride, G("base.0.weight"), G("base.0.bias"), B, st)
+
+
+class FCModel(_FCBase):
+    """models.py:367-424."""
+
+    def __init__(self, input_shape, output_space, h_size=200, bnorm=False, is_discrete=True, **kwargs):
+        super().__init__()
+        if bnorm or not is_discrete:
+            raise NotImplementedError("a2c_amd: bnorm / continuous actions are out of scope (see DESIGN.md)")
+        self.is_discrete, self.is_recurrent = True, False
+        self._build_base(input_shape, output_space, h_size)
+        self._build_heads(output_space, h_size)
+        self._post_init()
+
+    def _fwd(self, x_ptr, bstride, B, tag, st, save):
+        ws, P, h = self.ws(tag), self.P, self.h_size
+        fx = self._base_fwd(x_ptr, bstride, B, ws, st)
+        hb, logits, vals = self._heads(tag, B)
+        linear_fwd(ws, fx.data_ptr(), h, P("action_out.weight"), P("action_out.bias"), logits, B, st)
+        self._value_fwd(ws, fx, B, st, hb[:, self.output_space:])
+        return dict(logits=logits, vals=vals)
+
+    def _bwd(self, x_ptr, bstride, B, tag, st):
+        ws, P, G, h, A = self.ws(tag), self.P, self.G, self.h_size, self.output_space
+        fx = ws.get("fx", (B, h))
+        db, dl, dv = self.dheads(tag, B)
+        dfx = ws.get("dfx", (B, h))
+        self._value_bwd(ws, fx, db[:, A:], dfx, B, st)
+        linear_bwd_weight(ws, dl, fx.data_ptr(), h, G("action_out.weight"), G("action_out.bias"), B, st)
+        ops.gemm(0, 0, B, h, A, dl.data_ptr(), A + 1, P("action_out.weight").data_ptr(), h, dfx.data_ptr(), h,
+                 accumulate=True, st=st)
+        self._base_bwd(x_ptr, bstride, B, ws, st, dfx)
+
+
+class GRUFCModel(_FCBase, _GruMixin):
+    """models.py:483-543."""
+
+    def __init__(self, input_shape, output_space, h_size=200, bnorm=False, is_discrete=True, **kwargs):
+        super().__init__()
+        if bnorm or not is_discrete:
+            raise NotImplementedError("a2c_amd: bnorm / continuous actions are out of scope (see DESIGN.md)")
+        self.is_discrete, self.is_recurrent = True, True
+        self._build_base(input_shape, output_space, h_size)
+        self.gru = GRU(x_size=h_size, h_size=h_size)
+        self._build_heads(output_space, h_size)
+        self._post_init()
+
+    def _heads_fwd(self, ws, hn, B, hb, st):
+        A = self.output_space
+        linear_fwd(ws, hn.data_ptr(), self.h_size, self.P("action_out.weight"), self.P("action_out.bias"), hb[:, :A], B,
+                   st)
+        self._value_fwd(ws, hn, B, st, hb[:, A:])
+
+    def _heads_bwd(self, ws, hn, B, db, dhn, st):
+        A, h = self.output_space, self.h_size
+        self._value_bwd(ws, hn, db[:, A:], dhn, B, st)
+        dl = db[:, :A]
+        linear_bwd_weight(ws, dl, hn.data_ptr(), h, self.G("action_out.weight"), self.G("action_out.bias"), B, st)
+        ops.gemm(0, 0, B, h, A, dl.data_ptr(), A + 1, self.P("action_out.weight").data_ptr(), h, dhn.data_ptr(), h,
+                 accumulate=True, st=st)
+
+    def _fwd(self, x_ptr, bstride, B, tag, st, save, h_in):
+        ws = self.ws(tag)
+        fx = self._base_fwd(x_ptr, bstride, B, ws, st)
+        bufs = self._cell_bufs(ws, B)
+        hin = ws.get("h_in", (B, self.h_size))
+        hin.copy_(h_in)
+        self._gru_fwd(ws, fx, hin, B, st, bufs)
+        hb, logits, vals = self._heads(tag, B)
+        self._heads_fwd(ws, bufs["hn"], B, hb, st)
+        return dict(logits=logits, vals=vals, h=bufs["hn"])
+
+    def _bwd(self, x_ptr, bstride, B, tag, st, dh_next=None):
+        ws, h = self.ws(tag), self.h_size
+        bufs, dbufs = self._cell_bufs(ws, B), self._cell_dbufs(ws, B)
+        hin, fx = ws.get("h_in", (B, h)), ws.get("fx", (B, h))
+        dhn = ws.get("dhn", (B, h))
+        self._heads_bwd(ws, bufs["hn"], B, self.dheads(tag, B)[0], dhn, st)
+        if dh_next is not None:
+            ops.add(dhn, dh_next, dhn, st)
+        dh = self._gru_bwd_step(ws, dhn, hin, B, st, bufs, dbufs)
+        dfx = ws.get("dfx", (B, h))
+        self._gru_bwd_weights(ws, fx, hin, bufs["rh"], dbufs["dz_pre"], dbufs["dr_pre"], dbufs["dc_pre"], dfx, B, st)
+        self._base_bwd(x_ptr, bstride, B, ws, st, dfx)
+        return dh
+
+    # BPTT (updater.py:139-169): base MLP batched rollout-major, GRU cells + heads time-major
+    def bptt_forward(self, states, h_states, dones, R, T, tag, st):
+        ws, h, A = self.ws(tag), self.h_size, self.output_space
+        N = R * T
+        self._refresh(st)
+        fx = self._base_fwd(states.data_ptr(), states[0].numel(), N, ws, st)
+        fx_tm = ws.get("fx_tm", (T, R, h))
+        ops.permute_rows(fx, fx_tm, R, T, h, st)
+        tm = self._bptt_cells_fwd(ws, fx_tm, h_states, dones, R, T, st)
+        heads_tm = ws.get("heads_tm", (N, A + 1))
+        self._heads_fwd(ws, tm["hn"].view(N, h), N, heads_tm, st)
+        hb, logits, vals = self._heads(tag, N)
+        ops.permute_rows(heads_tm, hb, T, R, A + 1, st)
+        return vals, logits
+
+    def bptt_backward(self, states, dones, R, T, tag, st):
+        ws, h, A = self.ws(tag), self.h_size, self.output_space
+        N = R * T
+        fx_tm = ws.get("fx_tm", (T, R, h))
+        hn_tm = ws.get("tm_hn", (T, R, h))
+        db, dl, dv = self.dheads(tag, N)
+        db_tm = ws.get("dheads_tm", (N, A + 1))
+        ops.permute_rows(db, db_tm, R, T, A + 1, st)
+        dhn_tm = ws.get("dhn_tm", (T, R, h))
+        self._heads_bwd(ws, hn_tm.view(N, h), N, db_tm, dhn_tm.view(N, h), st)
+        dfx_tm = self._bptt_cells_bwd(ws, fx_tm, dhn_tm, dones, R, T, st, x_mask=None)
+        dfx = ws.get("dfx", (N, h))
+        ops.permute_rows(dfx_tm, dfx, T, R, h, st)
+        self._base_bwd(states.data_ptr(), states[0].numel(), N, ws, st, dfx)

@@ -1,0 +1,281 @@
+"""Tensor-level wrappers of the C ABI (include/a2c_mi355x.h).
+
+Every function takes torch tensors that already live in HBM, checks device / dtype /
+layout, and enqueues the HIP kernels on torch's current stream.  Nothing here computes
+on the CPU: a non-CUDA tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+_F32 = torch.float32
+
+
+def lib():
+    return _lib.load()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, name, dtype=_F32, contig=True):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"a2c_amd: `{name}` must be a CUDA (HIP) tensor; the MI355X kernels have no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"a2c_amd: `{name}` must be {dtype}, got {t.dtype}")
+    if contig and not t.is_contiguous():
+        raise ValueError(f"a2c_amd: `{name}` must be contiguous")
+
+
+class Workspace:
+    """Named, persistent device buffers (no allocation inside steady-state steps, so the
+    launch sequences are hipGraph-capturable and pointers are stable across updates)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._bufs = {}
+
+    def get(self, name, shape, dtype=_F32, zero=False):
+        shape = tuple(int(s) for s in shape)
+        key = (name, dtype)
+        n = 1
+        for s in shape:
+            n *= s
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._bufs[key] = buf
+            if zero:
+                buf.zero_()
+        return buf[:n].view(shape)
+
+    def bytes(self, name, nbytes):
+        n = (int(nbytes) + 3) // 4
+        return self.get(name, (max(n, 1),))
+
+
+# ---------------------------------------------------------------- scans / normalisation
+def discount_rows(x, dones, factor, n_seg, T, out=None, err=None, st=None):
+    _chk(x, "x"); _chk(dones, "dones")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().a2c_discount_scan(_p(x), _p(dones), _p(out), n_seg, T, float(factor), _p(err),
+                                  st if st is not None else stream()), "a2c_discount_scan")
+    return out
+
+
+def gae_returns(deltas, rewards, dones, g_adv, g_ret, n_seg, T, advs, rets, err=None, st=None):
+    for n, t in (("deltas", deltas), ("rewards", rewards), ("dones", dones), ("advs", advs), ("rets", rets)):
+        _chk(t, n)
+    check(lib().a2c_gae_returns_fused(_p(deltas), _p(rewards), _p(dones), _p(advs), _p(rets), n_seg, T,
+                                      float(g_adv), float(g_ret), _p(err), st if st is not None else stream()),
+          "a2c_gae_returns_fused")
+
+
+def moments(x, sums, st=None):
+    _chk(x, "x"); _chk(sums, "sums", torch.float64)
+    check(lib().a2c_moments(_p(x), x.numel(), _p(sums), st if st is not None else stream()), "a2c_moments")
+
+
+def normalize(x, y, sums, n_global, eps=1e-6, st=None):
+    _chk(x, "x"); _chk(y, "y"); _chk(sums, "sums", torch.float64)
+    check(lib().a2c_normalize(_p(x), _p(y), x.numel(), _p(sums), n_global, eps, st if st is not None else stream()),
+          "a2c_normalize")
+
+
+def add(a, b, y, st=None):
+    _chk(a, "a"); _chk(b, "b"); _chk(y, "y")
+    check(lib().a2c_add(_p(a), _p(b), _p(y), a.numel(), st if st is not None else stream()), "a2c_add")
+
+
+# ---------------------------------------------------------------- rollout step kernels
+def frame_stack_push(frame_new, reset_mask, prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW, st=None):
+    check(lib().a2c_frame_stack_push(_p(frame_new), _p(reset_mask), prev_ptr, prev_stride, out_ptr, out_stride,
+                                     B, C, HW, st if st is not None else stream()), "a2c_frame_stack_push")
+
+
+def softmax_sample(logits, u, actions_ptr, act_stride, B, A, probs=None, st=None):
+    _chk(logits, "logits", contig=False); _chk(u, "u")
+    check(lib().a2c_softmax_sample(_p(logits), logits.stride(0), _p(u), actions_ptr, act_stride, _p(probs), B, A,
+                                   st if st is not None else stream()), "a2c_softmax_sample")
+
+
+def sample_probs(probs, u, out, st=None):
+    _chk(probs, "probs"); _chk(u, "u"); _chk(out, "out")
+    A = probs.shape[-1]
+    check(lib().a2c_sample_probs(_p(probs), _p(u), _p(out), probs.numel() // A, A,
+                                 st if st is not None else stream()), "a2c_sample_probs")
+
+
+def rollout_record(rew, done, val_ptr, val_stride, val_prev, rewards, dones, deltas, done_eff, h, B, T, t, slot0,
+                   gamma, pong, st=None):
+    check(lib().a2c_rollout_record(_p(rew), _p(done), val_ptr, val_stride, _p(val_prev), _p(rewards), _p(dones), _p(deltas),
+                                   _p(done_eff), _p(h), 0 if h is None else h.shape[-1], B, T, t, slot0,
+                                   float(gamma), int(bool(pong)), st if st is not None else stream()),
+          "a2c_rollout_record")
+
+
+def rollout_bootstrap(val_ptr, val_stride, val_prev, rewards, dones, deltas, B, T, slot0, gamma, st=None):
+    check(lib().a2c_rollout_bootstrap(val_ptr, val_stride, _p(val_prev), _p(rewards), _p(dones), _p(deltas), B, T, slot0,
+                                      float(gamma), st if st is not None else stream()), "a2c_rollout_bootstrap")
+
+
+def copy_rows(src_ptr, src_stride, dst_ptr, dst_stride, B, n, st=None):
+    check(lib().a2c_copy_rows(src_ptr, src_stride, dst_ptr, dst_stride, B, n, st if st is not None else stream()),
+          "a2c_copy_rows")
+
+
+def mask_rows(x, dones_ptr, done_stride, st=None):
+    _chk(x, "x")
+    check(lib().a2c_mask_rows(_p(x), x.stride(0), dones_ptr, done_stride, x.shape[0], x.shape[1],
+                              st if st is not None else stream()), "a2c_mask_rows")
+
+
+def permute_rows(src, dst, R, T, n, st=None):
+    check(lib().a2c_permute_rows(_p(src), _p(dst), R, T, n, st if st is not None else stream()), "a2c_permute_rows")
+
+
+# ---------------------------------------------------------------- loss
+def loss_fwd_bwd(logits, vals, actions, advs, returns, adv_sums, n_global, pi_coef, val_coef, entr_coef, dlogits,
+                 dvals, loss_sums, st=None):
+    """logits (N,A) / dlogits (N,A) may be column slices of wider (N,A+1) buffers and vals / dvals
+    their last column: only stride(0) is used for addressing."""
+    _chk(logits, "logits", contig=False); _chk(vals, "vals", contig=False)
+    _chk(actions, "actions", torch.int64)
+    _chk(advs, "advs"); _chk(returns, "returns"); _chk(dlogits, "dlogits", contig=False)
+    _chk(dvals, "dvals", contig=False); _chk(loss_sums, "loss_sums", torch.float64)
+    n, A = logits.shape
+    check(lib().a2c_loss_fwd_bwd(_p(logits), logits.stride(0), _p(vals), vals.stride(0), _p(actions), _p(advs),
+                                 _p(returns), _p(adv_sums), n, n_global, A, float(pi_coef), float(val_coef),
+                                 float(entr_coef), _p(dlogits), dlogits.stride(0), _p(dvals), dvals.stride(0),
+                                 _p(loss_sums), st if st is not None else stream()), "a2c_loss_fwd_bwd")
+
+
+# ---------------------------------------------------------------- dense
+def pick_splitk(M, N, K, target_wgs=512, min_k=64):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= target_wgs // 2:
+        return 1
+    s = max(1, min(target_wgs // tiles, K // min_k))
+    return int(s)
+
+
+def gemm(transA, transB, M, N, K, A_ptr, lda, B_ptr, ldb, C_ptr, ldc, bias=None, relu=False, mask_ptr=0, ldmask=0,
+         accumulate=False, splitk=1, ws=None, st=None):
+    ws_ptr, ws_bytes = (0, 0) if ws is None else (ws.data_ptr(), ws.numel() * ws.element_size())
+    check(lib().a2c_gemm_f32(int(transA), int(transB), M, N, K, A_ptr, lda, B_ptr, ldb, C_ptr, ldc, _p(bias),
+                             int(bool(relu)), mask_ptr, ldmask, int(bool(accumulate)), splitk, ws_ptr, ws_bytes,
+                             st if st is not None else stream()), "a2c_gemm_f32")
+
+
+def gemm_ws_bytes(M, N, splitk):
+    return lib().a2c_gemm_ws_bytes(M, N, splitk)
+
+
+def colsum(x_ptr, ld, M, N, out, ws, st=None):
+    check(lib().a2c_colsum(x_ptr, ld, M, N, _p(out), ws.data_ptr(), ws.numel() * ws.element_size(),
+                           st if st is not None else stream()), "a2c_colsum")
+
+
+def colsum_ws_bytes(N):
+    return lib().a2c_colsum_ws_bytes(N)
+
+
+# ---------------------------------------------------------------- conv
+def conv_desc(Cin, H, W, Cout, ks, stride, pad):
+    OH = (H - ks + 2 * pad) // stride + 1
+    OW = (W - ks + 2 * pad) // stride + 1
+    return ConvDesc(Cin, H, W, Cout, ks, stride, pad, OH, OW)
+
+
+def conv_prep_floats(d, kind):
+    return lib().a2c_conv2d_prep_floats(ctypes.byref(d), kind)
+
+
+def conv_prep(d, kind, weight, wprep, st=None):
+    check(lib().a2c_conv2d_prep_weights(ctypes.byref(d), kind, _p(weight), _p(wprep),
+                                        st if st is not None else stream()), "a2c_conv2d_prep_weights")
+
+
+def conv_fwd(d, in_ptr, in_bstride, wprep, bias, relu, out, B, st=None):
+    check(lib().a2c_conv2d_fwd(ctypes.byref(d), in_ptr, in_bstride, _p(wprep), _p(bias), int(bool(relu)), _p(out),
+                               d.Cout * d.OH * d.OW, B, st if st is not None else stream()), "a2c_conv2d_fwd")
+
+
+def conv_bwd_data(d, dout, wprep_bwd, mask, din, B, st=None):
+    check(lib().a2c_conv2d_bwd_data(ctypes.byref(d), _p(dout), _p(wprep_bwd), _p(mask), _p(din), B,
+                                    st if st is not None else stream()), "a2c_conv2d_bwd_data")
+
+
+def conv_bwd_weight_ws_bytes(d, B):
+    return lib().a2c_conv2d_bwd_weight_ws_bytes(ctypes.byref(d), B)
+
+
+def conv_bwd_weight(d, in_ptr, in_bstride, dout, dW, db, B, ws, st=None):
+    check(lib().a2c_conv2d_bwd_weight(ctypes.byref(d), in_ptr, in_bstride, _p(dout), _p(dW), _p(db), B,
+                                      ws.data_ptr(), ws.numel() * ws.element_size(),
+                                      st if st is not None else stream()), "a2c_conv2d_bwd_weight")
+
+
+# ---------------------------------------------------------------- GRU / LayerNorm
+def gru_gates(gx, gh, b, h, z, r, rh, st=None):
+    B, hd = h.shape
+    check(lib().a2c_gru_gates(_p(gx), _p(gh), _p(b), _p(h), _p(z), _p(r), _p(rh), B, hd,
+                              st if st is not None else stream()), "a2c_gru_gates")
+
+
+def gru_out(gx, rh_u, b, h, z, c, h_new, st=None):
+    B, hd = h.shape
+    check(lib().a2c_gru_out(_p(gx), _p(rh_u), _p(b), _p(h), _p(z), _p(c), _p(h_new), B, hd,
+                            st if st is not None else stream()), "a2c_gru_out")
+
+
+def gru_out_bwd(dh_new, h, z, c, dc_pre, dz, dh, st=None):
+    B, hd = h.shape
+    check(lib().a2c_gru_out_bwd(_p(dh_new), _p(h), _p(z), _p(c), _p(dc_pre), _p(dz), _p(dh), B, hd,
+                                st if st is not None else stream()), "a2c_gru_out_bwd")
+
+
+def gru_gates_bwd(d_rh, dz, h, z, r, dz_pre, dr_pre, dh, st=None):
+    B, hd = h.shape
+    check(lib().a2c_gru_gates_bwd(_p(d_rh), _p(dz), _p(h), _p(z), _p(r), _p(dz_pre), _p(dr_pre), _p(dh), B, hd,
+                                  st if st is not None else stream()), "a2c_gru_gates_bwd")
+
+
+def layernorm_fwd(x, w, b, y, mean, rstd, st=None):
+    rows, n = x.shape
+    check(lib().a2c_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), rows, n,
+                                  st if st is not None else stream()), "a2c_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dx, dw_rows, accumulate=False, st=None):
+    rows, n = x.shape
+    check(lib().a2c_layernorm_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw_rows), rows, n,
+                                  int(bool(accumulate)), st if st is not None else stream()), "a2c_layernorm_bwd")
+
+
+# ---------------------------------------------------------------- clip + optimiser
+def gradnorm_sq(grads, sumsq, st=None):
+    check(lib().a2c_gradnorm_sq(_p(grads), grads.numel(), _p(sumsq), st if st is not None else stream()),
+          "a2c_gradnorm_sq")
+
+
+def clip_rmsprop(params, grads, square_avg, sumsq, max_norm, lr, alpha, eps, norm_out, st=None):
+    check(lib().a2c_clip_rmsprop(_p(params), _p(grads), _p(square_avg), params.numel(), _p(sumsq), max_norm, lr,
+                                 alpha, eps, _p(norm_out), st if st is not None else stream()), "a2c_clip_rmsprop")
+
+
+def clip_adam(params, grads, exp_avg, exp_avg_sq, sumsq, max_norm, lr, beta1, beta2, eps, step, norm_out, st=None):
+    check(lib().a2c_clip_adam(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), _p(sumsq),
+                              max_norm, lr, beta1, beta2, eps, step, _p(norm_out),
+                              st if st is not None else stream()), "a2c_clip_adam")

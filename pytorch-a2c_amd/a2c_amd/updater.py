@@ -1,0 +1,196 @@
+"""Drop-in for the reference's ``a2c/updater.py``: ``Updater(net, hyps)`` with
+``update_model(shared_data) -> info`` / ``bptt`` / ``save_model`` / ``new_lr`` / ``new_optim`` /
+``print_statistics`` / ``log_statistics`` and the attributes ``net optim info norm hyps
+is_discrete ret_mean ret_std`` (updater.py:9-229).
+
+One ``update_model`` call enqueues, on one HIP stream and without host round trips until the
+final read-back of five scalars:
+  fused GAE + returns scan -> model forward (N = n_rollouts*n_tsteps samples, or the BPTT unroll)
+  -> advantage statistics -> fused loss forward+backward -> model backward into the flat gradient
+  arena -> [RCCL all-reduce when sharded] -> grad-norm reduction -> fused clip + RMSprop/Adam.
+"""
+import torch
+
+from . import ops, optim as fused_optim
+from .parallel import Shard
+from .utils import try_key
+
+
+class Updater:
+    def __init__(self, net, hyps, shard=None):
+        self.net = net
+        self.hyps = hyps
+        self.is_discrete = hyps["is_discrete"]
+        if not self.is_discrete:
+            raise NotImplementedError("a2c_amd: continuous action spaces are out of scope (see DESIGN.md)")
+        self.shard = shard if shard is not None else Shard()
+        self.optim = self.new_optim(hyps["lr"])
+        self.info = {}
+        self.norm = 0
+        self.ret_mean = None
+        self.ret_std = None
+        self._bufs = None
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, t, dtype=torch.float32):
+        dev = self.net._dev
+        if t.device != dev or t.dtype != dtype or not t.is_contiguous():
+            t = t.to(device=dev, dtype=dtype).contiguous()
+        return t
+
+    def _buffers(self, N):
+        b = self._bufs
+        if b is None or b["N"] != N:
+            dev = self.net._dev
+            b = dict(N=N,
+                     advs=torch.empty(N, device=dev), rets=torch.empty(N, device=dev),
+                     vals_c=torch.empty(N, device=dev),
+                     stats=torch.zeros(8, dtype=torch.float64, device=dev),   # [adv sums 0:2 | loss sums 2:5 | ret 5:7]
+                     err=torch.zeros(1, dtype=torch.int32, device=dev),
+                     host=torch.zeros(8, dtype=torch.float64).pin_memory() if torch.cuda.is_available() else None)
+            self._bufs = b
+        return b
+
+    # ------------------------------------------------------------------ the update
+    def update_model(self, shared_data):
+        hyps, net, sh = self.hyps, self.net, self.shard
+        net._ensure_device()
+        net.req_grads(True)
+        st = ops.stream()
+        states = self._dev(shared_data["states"])
+        rewards = self._dev(shared_data["rewards"]).reshape(-1)
+        dones = self._dev(shared_data["dones"]).reshape(-1)
+        deltas = self._dev(shared_data["deltas"]).reshape(-1)
+        actions = self._dev(shared_data["actions"], torch.int64).reshape(-1)
+        N = states.shape[0]
+        T = int(hyps["n_tsteps"])
+        if N % T:
+            raise ValueError("len(states) is not a multiple of n_tsteps")
+        R = N // T
+        n_global = sh.global_count(N)
+        b = self._buffers(N)
+        advs, rets, stats = b["advs"], b["rets"], b["stats"]
+
+        # advantages (gamma*lambda) and discounted returns (gamma) in one pass (updater.py:70-71, 86-88)
+        ops.gae_returns(deltas, rewards, dones, hyps["gamma"] * hyps["lambda_"], hyps["gamma"], R, T, advs, rets,
+                        err=b["err"], st=st)
+
+        # forward pass (updater.py:73-80)
+        recurrent = "h_states" in shared_data
+        use_bptt = recurrent and bool(hyps["use_bptt"])
+        if recurrent:
+            h_states = self._dev(shared_data["h_states"])
+            if use_bptt:
+                net.bptt_forward(states, h_states, dones, R, T, "train", st)
+            else:
+                net._refresh(st)
+                net._fwd(states.data_ptr(), states[0].numel(), N, "train", st, True, h_in=h_states)
+        else:
+            net._refresh(st)
+            net._fwd(states.data_ptr(), states[0].numel(), N, "train", st, True)
+        hb, logits, vals = net._heads("train", N)
+
+        if hyps["use_nstep_rets"]:      # returns = advs + vals.data (updater.py:84)
+            ops.copy_rows(vals.data_ptr(), vals.stride(0), b["vals_c"].data_ptr(), 1, N, 1, st)
+            ops.add(advs, b["vals_c"], rets, st)
+        if try_key(hyps, "norm_returns", False):
+            self._norm_returns(rets, stats, n_global, st)
+
+        adv_sums = None
+        if hyps["norm_advs"]:           # (advs - mean)/(std + 1e-6) over the WHOLE batch (updater.py:97-98)
+            adv_sums = stats[0:2]
+            ops.moments(advs, adv_sums, st)
+            sh.allreduce_(adv_sums)
+
+        db, dl, dv = net.dheads("train", N)
+        ops.loss_fwd_bwd(logits, vals, actions, advs, rets, adv_sums, n_global, try_key(hyps, "pi_coef", 1.0), hyps["val_coef"],
+                         hyps["entr_coef"], dl, dv, stats[2:5], st)
+
+        # backward into the flat gradient arena
+        if use_bptt:
+            net.bptt_backward(states, dones, R, T, "train", st)
+        else:
+            net._bwd(states.data_ptr(), states[0].numel(), N, "train", st)
+        net._arena.attach_grads()
+        if sh.active:                   # ONE all-reduce over xGMI per update
+            sh.allreduce_(net._arena.train_grads())
+            sh.allreduce_(stats[2:5])
+
+        # clip_grad_norm_ + optimiser step (updater.py:129-132), fused
+        self.optim.step(max_norm=hyps["max_norm"], st=st)
+        self.optim.zero_grad()
+
+        # five scalars back to the host (the reference's .item() calls, updater.py:134-136)
+        host = torch.cat([stats[2:5], self.optim.grad_norm().double(), b["err"].double()]).cpu()
+        if int(host[4]):
+            raise ValueError("shared_data['dones']: a slot does not end with done == 1 (runner.py:244 invariant)")
+        s_pi, s_val, s_ent = (float(host[i]) for i in range(3))
+        pi_loss = try_key(hyps, "pi_coef", 1.0) * -(s_pi / n_global)
+        val_loss = hyps["val_coef"] * (s_val / n_global)
+        entr_loss = -hyps["entr_coef"] * (s_ent / n_global)
+        self.norm = float(host[3])
+        self.info = {"Loss": pi_loss + val_loss - entr_loss, "Pi_Loss": pi_loss, "ValLoss": val_loss,
+                     "Entropy": entr_loss, "GradNorm": self.norm}
+        return self.info
+
+    def _norm_returns(self, rets, stats, n_global, st):
+        """EMA-normalised returns (updater.py:89-96, default off): needs the batch mean/std on the
+        host to update the running values, hence one extra read-back."""
+        sums = stats[5:7]
+        ops.moments(rets, sums, st)
+        self.shard.allreduce_(sums)
+        s0, s1 = (float(v) for v in sums.cpu())
+        mean = s0 / n_global
+        std = max((s1 - n_global * mean * mean) / (n_global - 1), 0.0) ** 0.5
+        if self.ret_mean is None:
+            self.ret_mean, self.ret_std = mean, std
+        else:
+            self.ret_mean = 0.01 * mean + 0.99 * self.ret_mean
+            self.ret_std = 0.01 * std + 0.99 * self.ret_std
+        # encode (ret_mean, ret_std) as moment sums of a virtual population so the same kernel applies them
+        n = float(n_global)
+        fake = torch.tensor([self.ret_mean * n, (self.ret_std ** 2) * (n - 1) + n * self.ret_mean ** 2],
+                            dtype=torch.float64, device=rets.device)
+        ops.normalize(rets, rets, fake, n_global, 1e-6, st)
+
+    def bptt(self, states, h_states, dones):
+        """updater.py:139-169: unrolled recurrent forward; returns (vals (N,), logits (N,A))."""
+        hyps, net = self.hyps, self.net
+        net._ensure_device()
+        R, T = int(hyps["n_rollouts"]), int(hyps["n_tsteps"])
+        vals, logits = net.bptt_forward(self._dev(states), self._dev(h_states), self._dev(dones).reshape(-1), R, T,
+                                        "train", ops.stream())
+        return vals.clone(), logits.clone()
+
+    def gae(self, rewards, values, next_vals, dones, gamma, lambda_):
+        """updater.py:172-189 (unused by the reference's own loop; kept for API parity)."""
+        from .utils import discount
+        deltas = rewards + gamma * next_vals * (1 - dones) - values
+        return discount(deltas, dones, gamma * lambda_)
+
+    # ------------------------------------------------------------------ bookkeeping API
+    def print_statistics(self):
+        nums = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in self.info.items()}
+        print(" – ".join(k + ": " + str(round(v, 5)) for k, v in sorted(nums.items())))
+
+    def log_statistics(self, log, T, reward, avg_action, best_avg_rew):
+        nums = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in self.info.items()}
+        arr = [k + ": " + (str(round(v, 5)) if "ntropy" not in k else str(v)) for k, v in nums.items()]
+        arr += ["EpRew: " + str(reward), "AvgAction: " + str(avg_action), "BestRew:" + str(best_avg_rew)]
+        log.write("Step:" + str(T) + " – " + " – ".join(arr) + "\n")
+        log.flush()
+
+    def save_model(self, net_file_name, optim_file_name):
+        torch.save(self.net.state_dict(), net_file_name)
+        if optim_file_name is not None:
+            torch.save(self.optim.state_dict(), optim_file_name)
+
+    def new_lr(self, new_lr):
+        # like the reference: a new optimiser that then loads the old state (which, as in the
+        # reference, also restores the old lr: updater.py:221-224)
+        new_optim = self.new_optim(new_lr)
+        new_optim.load_state_dict(self.optim.state_dict())
+        self.optim = new_optim
+
+    def new_optim(self, lr):
+        return getattr(fused_optim, self.hyps["optim_type"])(self.net, lr=lr)

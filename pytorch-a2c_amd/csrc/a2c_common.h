@@ -1,0 +1,40 @@
+// Shared helpers for the gfx950 kernels of liba2c_mi355x.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/a2c_mi355x.h"
+
+#define A2C_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH; \
+  } while (0)
+
+static inline hipStream_t a2c_s(a2c_stream_t s) { return (hipStream_t)s; }
+
+// memory-bound elementwise kernels: cap the grid and grid-stride (guide G11)
+static inline int a2c_grid_1d(int64_t n, int block, int max_blocks = 2048) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+
+// wave64 sum (all lanes get the result)
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block sum for blockDim.x == 256 (4 waves); result valid in thread 0
+template <typename T>
+__device__ __forceinline__ T block_sum_256(T v, T* sm /* >= 4 */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  T r = sm[0] + sm[1] + sm[2] + sm[3];
+  __syncthreads();
+  return r;
+}

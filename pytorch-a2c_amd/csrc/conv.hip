@@ -1,0 +1,557 @@
+// Convolutions of the model classes (nn.Conv2d + ReLU: models.py:98, 312, 685), forward,
+// backward-data and backward-weight, NCHW fp32.
+//
+// Structure (all three): a 256-thread workgroup stages an input tile (all input planes x the
+// rows one band of output rows needs) into LDS with coalesced loads, then its 4 waves run an
+// implicit GEMM over that tile on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32
+// FMA chain).  The LDS image of a row is PHASE-SPLIT by the conv stride S: source column x is
+// stored at (x % S)*WPS + x / S, so the 16 lanes of an MFMA B-operand read (16 adjacent output
+// pixels, i.e. input columns S apart) hit 16 consecutive banks for every stride, and the four
+// k-groups of a wave (4 input planes) sit PLANE = 16 mod 32 floats apart: conflict-free.
+//
+//  forward:  D[co, pix] = sum_k W[co,k] X[k,pix];  k = (tap, ci) with ci fastest, one MFMA step =
+//            4 input planes at one tap; A fragments (weights) pre-laid by a2c_conv2d_prep_weights
+//            and read coalesced from L1/L2; B fragments gathered from the LDS tile.
+//  bwd-data: the S*S output-parity classes of dX are S*S stride-1 correlations of dOut with a
+//            sub-kernel of W (taps ky = ry + S*a), i.e. the SAME kernel with other tables.
+//            The ReLU derivative of the layer below is fused into the store (mask > 0).
+//  bwd-weight: dW[co,k] = sum_pix dOut[co,pix] X[k,pix]: A = dOut tile (LDS), B = input tile
+//            (LDS), accumulators persist in registers across all samples of a workgroup,
+//            per-workgroup partial slabs + fixed-order reduction (deterministic), bias gradient
+//            from the same dOut tile.
+#include "a2c_common.h"
+
+namespace {
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int MAX_TAPS = 64;
+constexpr int IGEMM_LDS_BUDGET = 64 * 1024;   // 2 workgroups / CU
+constexpr int WGRAD_LDS_BUDGET = 76 * 1024;
+constexpr int LDS_HARD_MAX = 160 * 1024;
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+// ------------------------------------------------------------------ tile geometry
+struct SrcTile {         // how a band of TPH pixel rows maps onto an LDS image of the source
+  int Cp, IH, IW;        // source planes / size
+  int SY, SXl;           // source rows per pixel row; phase count of the LDS row (= source cols per pixel col)
+  int sy0, sx0;          // source row/col of (pixel 0, tap 0)
+  int span_y, span_x;    // tap extent
+  int PH, PW;            // pixel grid
+  int TPH, TIH, WPS, WP, PLANE, tiles;
+};
+
+static void plan_src(SrcTile& t, int extra_floats_per_row_of_pixels, int extra_fixed, int budget) {
+  const int ncols = (t.PW - 1) * t.SXl + t.span_x;
+  t.WPS = ceil_div(ncols, t.SXl);
+  t.WP = t.WPS * t.SXl;
+  int best = 1;
+  for (int tph = 1; tph <= t.PH; ++tph) {
+    const int tih = (tph - 1) * t.SY + t.span_y;
+    const int plane = ((tih * t.WP + 31) / 32) * 32 + 16;
+    const long bytes = 4L * ((long)t.Cp * plane + (long)extra_floats_per_row_of_pixels * tph + extra_fixed + 64);
+    if (bytes <= budget) best = tph; else break;
+  }
+  t.TPH = best;
+  t.TIH = (best - 1) * t.SY + t.span_y;
+  t.PLANE = ((t.TIH * t.WP + 31) / 32) * 32 + 16;
+  t.tiles = ceil_div(t.PH, t.TPH);
+}
+
+// ------------------------------------------------------------------ staging (device)
+struct StageP {
+  const float* src; long bstride;   // sample stride (floats)
+  int Cp, IH, IW, TIH, WPS, WP, PLANE, SXl, sxsh, sx0, fast;
+};
+
+// all 4 waves: one (plane,row) per wave iteration, lanes along the row.
+__device__ __forceinline__ void stage_tile(const StageP& s, float* __restrict__ lds, long b, int y_lo) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ntask = s.Cp * s.TIH;
+  const int smask = s.SXl - 1;
+  for (int rt = w; rt < ntask; rt += 4) {
+    const int c = rt / s.TIH, r = rt - c * s.TIH;
+    const int ys = y_lo + r;
+    const bool rowok = (ys >= 0) && (ys < s.IH);
+    float* dst = lds + c * s.PLANE + r * s.WP;
+    const float* src = s.src + b * s.bstride + ((long)c * s.IH + (rowok ? ys : 0)) * s.IW;
+    if (s.fast) {   // sx0 == 0, IW % 4 == 0, 16 B aligned rows: one float4 per lane
+      for (int i = lane; i < (s.IW >> 2); i += 64) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowok) v = reinterpret_cast<const float4*>(src)[i];
+        const int x = i << 2;
+        dst[((x + 0) & smask) * s.WPS + ((x + 0) >> s.sxsh)] = v.x;
+        dst[((x + 1) & smask) * s.WPS + ((x + 1) >> s.sxsh)] = v.y;
+        dst[((x + 2) & smask) * s.WPS + ((x + 2) >> s.sxsh)] = v.z;
+        dst[((x + 3) & smask) * s.WPS + ((x + 3) >> s.sxsh)] = v.w;
+      }
+      // columns beyond IW (if any) are only read by discarded lanes: keep them finite
+      for (int x = s.IW + lane; x < s.WP; x += 64) dst[(x & smask) * s.WPS + (x >> s.sxsh)] = 0.f;
+    } else {
+      for (int x = lane; x < s.WP; x += 64) {
+        const int xs = x + s.sx0;
+        float v = 0.f;
+        if (rowok && xs >= 0 && xs < s.IW) v = src[xs];
+        dst[(x & smask) * s.WPS + (x >> s.sxsh)] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ forward / backward-data
+struct IgemmP {
+  StageP st;
+  float* out; long out_bs; int Mch, OHf, OWf;      // output tensor (B, Mch, OHf, OWf)
+  const float* wfrag; const float* bias; const float* mask; int relu;
+  int ntaps, c4n;
+  int PH, PW, oy_mul, oy_add, ox_mul, ox_add;       // pixel (q,p) -> out (q*oy_mul+oy_add, p*ox_mul+ox_add)
+  int SY, sy0, TPH, tiles, B;
+  int tapoff[MAX_TAPS];
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const long total = (long)p.B * p.tiles;
+  const int WP = p.st.WP, PLANE = p.st.PLANE;
+  for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const long b = tile / p.tiles;
+    const int ti = (int)(tile - b * p.tiles);
+    const int qq0 = ti * p.TPH;
+    const int rows = min(p.TPH, p.PH - qq0);
+    const int NP = rows * p.PW;
+    __syncthreads();                       // readers of the previous tile are done
+    stage_tile(p.st, lds, b, qq0 * p.SY + p.sy0);
+    __syncthreads();
+    const int npairs = (NP + 31) >> 5;
+    for (int pr = w; pr < npairs; pr += 4) {
+      const int idx0 = pr * 32 + j, idx1 = idx0 + 16;
+      const bool ok0 = idx0 < NP, ok1 = idx1 < NP;
+      const int i0 = ok0 ? idx0 : 0, i1 = ok1 ? idx1 : 0;
+      const int r0 = i0 / p.PW, c0 = i0 - r0 * p.PW;
+      const int r1 = i1 / p.PW, c1 = i1 - r1 * p.PW;
+      const int base0 = r0 * p.SY * WP + c0 + g * PLANE;
+      const int base1 = r1 * p.SY * WP + c1 + g * PLANE;
+      f32x4 acc[MT][2];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      const float* __restrict__ wf = p.wfrag + lane;
+      for (int t = 0; t < p.ntaps; ++t) {
+        const int to = p.tapoff[t];
+        for (int c4 = 0; c4 < p.c4n; ++c4) {
+          const int off = to + c4 * 4 * PLANE;
+          const float b0 = lds[base0 + off];
+          const float b1 = lds[base1 + off];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float a = wf[0];
+            wf += 64;
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[m][1], 0, 0, 0);
+          }
+        }
+      }
+      // D map of the 16x16 tile: col (pixel) = lane & 15, row (channel) = 4*(lane>>4) + reg
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (!(nt ? ok1 : ok0)) continue;
+        const int r = nt ? r1 : r0, c = nt ? c1 : c0;
+        const long yo = (long)(qq0 + r) * p.oy_mul + p.oy_add;
+        const long xo = (long)c * p.ox_mul + p.ox_add;
+        const long pix = yo * p.OWf + xo;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int co = m * 16 + 4 * g + rr;
+            if (co < p.Mch) {
+              const long o = b * p.out_bs + (long)co * p.OHf * p.OWf + pix;
+              float v = acc[m][nt][rr];
+              if (p.bias) v += p.bias[co];
+              if (p.relu) v = fmaxf(v, 0.f);
+              if (p.mask && !(p.mask[o] > 0.f)) v = 0.f;
+              p.out[o] = v;
+            }
+          }
+      }
+    }
+  }
+}
+
+// weights -> A fragments.  kind 0 (forward): step s = tap*(Cin/4) + c4, lane l:
+//   W[co = mt*16 + (l&15)][ci = 4*c4 + (l>>4)][ky][kx],  tap = ky*ks + kx.
+// kind 1 (backward-data), class (ry,rx), taps (a,b): ky = ry + S*a, kx = rx + S*b,
+//   step s = tap*(Cout/4) + c4, lane l: W[co = 4*c4 + (l>>4)][ci = mt*16 + (l&15)][ky][kx].
+__global__ __launch_bounds__(256) void prep_fwd_kernel(const float* __restrict__ W, float* __restrict__ out, int Cin,
+                                                       int Cout, int ks, int MT, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int l = (int)(i & 63);
+    long q = i >> 6;
+    const int mt = (int)(q % MT);
+    q /= MT;
+    const int c4n = Cin >> 2;
+    const int c4 = (int)(q % c4n), tap = (int)(q / c4n);
+    const int ky = tap / ks, kx = tap - ky * ks;
+    const int co = mt * 16 + (l & 15), ci = 4 * c4 + (l >> 4);
+    out[i] = co < Cout ? W[(((long)co * Cin + ci) * ks + ky) * ks + kx] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void prep_bwd_kernel(const float* __restrict__ W, float* __restrict__ out, int Cin,
+                                                       int Cout, int ks, int S, int ry, int rx, int nb, int MT,
+                                                       long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int l = (int)(i & 63);
+    long q = i >> 6;
+    const int mt = (int)(q % MT);
+    q /= MT;
+    const int c4n = Cout >> 2;
+    const int c4 = (int)(q % c4n), tap = (int)(q / c4n);
+    const int a = tap / nb, bb = tap - a * nb;
+    const int ky = ry + S * a, kx = rx + S * bb;
+    const int co = 4 * c4 + (l >> 4), ci = mt * 16 + (l & 15);
+    out[i] = ci < Cin ? W[(((long)co * Cin + ci) * ks + ky) * ks + kx] : 0.f;
+  }
+}
+
+static inline int ntaps_1d(int ks, int S, int r) { return r < ks ? (ks - r + S - 1) / S : 0; }
+
+static bool desc_ok(const a2c_conv_desc* d) {
+  if (!d) return false;
+  if (d->Cin < 4 || d->Cin % 4 || d->Cout < 4 || d->Cout % 4 || d->Cout > 64 || d->Cin > 64) return false;
+  if (d->ks < 1 || d->stride < 1 || d->stride > 4 || (d->stride & (d->stride - 1)) || d->pad < 0 || d->pad >= d->ks) return false;
+  if (d->ks * d->ks > MAX_TAPS) return false;
+  if (d->OH != (d->H - d->ks + 2 * d->pad) / d->stride + 1 || d->OW != (d->W - d->ks + 2 * d->pad) / d->stride + 1) return false;
+  return d->OH >= 1 && d->OW >= 1;
+}
+
+static size_t bwd_class_offset(const a2c_conv_desc* d, int cls) {   // floats before class `cls`
+  const int S = d->stride, MTb = ceil_div(d->Cin, 16);
+  size_t off = 0;
+  for (int c = 0; c < cls; ++c) {
+    const int ry = c / S, rx = c % S;
+    off += (size_t)ntaps_1d(d->ks, S, ry) * ntaps_1d(d->ks, S, rx) * (d->Cout / 4) * MTb * 64;
+  }
+  return off;
+}
+
+template <int MT>
+static void launch_igemm_t(const IgemmP& p, int grid, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(igemm_kernel<MT>, dim3(grid), dim3(256), lds, st, p);
+}
+
+static int launch_igemm(const IgemmP& p, int MT, hipStream_t st) {
+  const size_t lds = 4 * ((size_t)p.st.Cp * p.st.PLANE + 64);
+  if (lds > LDS_HARD_MAX) return A2C_ERR_ARG;
+  const long total = (long)p.B * p.tiles;
+  const int grid = (int)(total < 2048 ? total : 2048);
+  switch (MT) {
+    case 1: launch_igemm_t<1>(p, grid, lds, st); break;
+    case 2: launch_igemm_t<2>(p, grid, lds, st); break;
+    case 3: launch_igemm_t<3>(p, grid, lds, st); break;
+    case 4: launch_igemm_t<4>(p, grid, lds, st); break;
+    default: return A2C_ERR_ARG;
+  }
+  if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
+  return A2C_OK;
+}
+
+static void fill_stage(StageP& s, const SrcTile& t, const float* src, long bstride) {
+  s.src = src; s.bstride = bstride;
+  s.Cp = t.Cp; s.IH = t.IH; s.IW = t.IW; s.TIH = t.TIH; s.WPS = t.WPS; s.WP = t.WP; s.PLANE = t.PLANE;
+  s.SXl = t.SXl; s.sxsh = ilog2(t.SXl); s.sx0 = t.sx0;
+  s.fast = (t.sx0 == 0) && (t.IW % 4 == 0) && (t.IW <= t.WP) && (((long)t.IH * t.IW) % 4 == 0) && (bstride % 4 == 0) &&
+           ((uintptr_t)src % 16 == 0);
+}
+
+// ------------------------------------------------------------------ backward-weight
+struct WgradP {
+  StageP st;                      // input tile
+  const float* dout;              // (B, Cout, OH, OW) contiguous
+  float* slab;                    // [grid][Cout*K + Cout]
+  int Cout, K, ks, OH, OW, OWp;   // OWp = OW rounded up to 4
+  int S, sy0, TPH, tiles, B;
+  int PLANEo;                     // dOut LDS plane stride (= 2 mod 32)
+  int nkt;                        // ceil(K/16)
+};
+
+template <int MT, int KTW>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int kk = lane >> 4, j = lane & 15;
+  const int WP = p.st.WP, PLANE = p.st.PLANE, WPS = p.st.WPS;
+  const int in_floats = p.st.Cp * PLANE;
+  float* ldo = lds + in_floats;                       // dOut tile: [MT*16][PLANEo]
+  const int lds_total = in_floats + MT * 16 * p.PLANEo + 64;
+  for (int i = threadIdx.x; i < lds_total; i += 256) lds[i] = 0.f;   // padding stays 0 (finite) forever
+
+  // this lane's k offsets (natural weight order k = (ci*ks + ky)*ks + kx), k-tiles w, w+4, ...
+  int koff[KTW];
+  const int smask = p.st.SXl - 1;
+#pragma unroll
+  for (int q = 0; q < KTW; ++q) {
+    const int k = (w + 4 * q) * 16 + j;
+    int o = 0;
+    if (k < p.K) {
+      const int ci = k / (p.ks * p.ks), rem = k - ci * p.ks * p.ks;
+      const int ky = rem / p.ks, kx = rem - ky * p.ks;
+      o = ci * PLANE + ky * WP + (kx & smask) * WPS + (kx >> p.st.sxsh);
+    }
+    koff[q] = o + kk;                                 // + pixel (4*c4 + kk) of the step
+  }
+  f32x4 acc[MT][KTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < KTW; ++q) acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient: thread -> (channel, part)
+  const int Cm = MT * 16;
+  const int nparts = 256 / Cm;
+  const int bco = threadIdx.x % Cm, bpart = threadIdx.x / Cm;
+  float dbacc = 0.f;
+
+  const long total = (long)p.B * p.tiles;
+  const int c4n = p.OWp >> 2;
+  for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const long b = tile / p.tiles;
+    const int ti = (int)(tile - b * p.tiles);
+    const int q0 = ti * p.TPH;
+    const int rows = min(p.TPH, p.OH - q0);
+    __syncthreads();
+    stage_tile(p.st, lds, b, q0 * p.S + p.sy0);
+    {  // dOut rows q0..q0+rows of every channel -> ldo[co][r*OWp + c]; pad columns stay 0
+      const int ntask = p.Cout * rows;
+      for (int rt = w; rt < ntask; rt += 4) {
+        const int co = rt / rows, r = rt - co * rows;
+        const float* src = p.dout + ((b * p.Cout + co) * p.OH + q0 + r) * (long)p.OW;
+        float* dst = ldo + co * p.PLANEo + r * p.OWp;
+        for (int x = lane; x < p.OW; x += 64) dst[x] = src[x];
+      }
+    }
+    __syncthreads();
+    // bias partial sums over this tile
+    if (bpart < nparts && bco < p.Cout) {
+      const float* pl = ldo + bco * p.PLANEo;
+      const int n = rows * p.OWp;
+      float s = 0.f;
+      for (int i = bpart; i < n; i += nparts) s += pl[i];
+      dbacc += s;
+    }
+    // implicit GEMM over the tile's pixels, 4 pixels per MFMA step
+    for (int r = 0; r < rows; ++r) {
+      const int arow = r * p.OWp + kk;
+      const int brow = r * p.S * WP;
+      for (int c4 = 0; c4 < c4n; ++c4) {
+        float a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = ldo[(m * 16 + j) * p.PLANEo + arow + 4 * c4];
+#pragma unroll
+        for (int q = 0; q < KTW; ++q) {
+          if (w + 4 * q < p.nkt) {   // wave-uniform
+            const float bv = lds[koff[q] + brow + 4 * c4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][q], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // write this workgroup's partials: D row (co) = 4*(lane>>4)+reg, col (k) = lane&15
+  float* sl = p.slab + (long)blockIdx.x * ((long)p.Cout * p.K + p.Cout);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < KTW; ++q) {
+      const int k = (w + 4 * q) * 16 + j;
+      if (w + 4 * q < p.nkt && k < p.K) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int co = m * 16 + 4 * kk + rr;
+          if (co < p.Cout) sl[(long)co * p.K + k] = acc[m][q][rr];
+        }
+      }
+    }
+  __syncthreads();
+  float* red = lds;   // reuse: [nparts][Cm]
+  if (bpart < nparts) red[bpart * Cm + bco] = dbacc;
+  __syncthreads();
+  if (threadIdx.x < p.Cout) {
+    float s = 0.f;
+    for (int q = 0; q < nparts; ++q) s += red[q * Cm + threadIdx.x];
+    sl[(long)p.Cout * p.K + threadIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, long per,
+                                                           long nW, float* __restrict__ dW, float* __restrict__ db) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += gridDim.x * 256L) {
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += slab[(long)z * per + i];
+    if (i < nW) dW[i] = s;
+    else if (db) db[i - nW] = s;
+  }
+}
+
+struct WgradPlan { SrcTile t; int OWp, PLANEo, MT, KTW, grid; size_t lds; };
+
+static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl) {
+  SrcTile& t = pl.t;
+  t.Cp = d->Cin; t.IH = d->H; t.IW = d->W; t.SY = d->stride; t.SXl = d->stride;
+  t.sy0 = -d->pad; t.sx0 = -d->pad; t.span_y = d->ks; t.span_x = d->ks; t.PH = d->OH;
+  pl.OWp = ceil_div(d->OW, 4) * 4;
+  t.PW = pl.OWp;                      // padded pixel columns read (finite, x0) input columns too
+  const int mt = ceil_div(d->Cout, 16);
+  const int nkt = ceil_div(d->Cin * d->ks * d->ks, 16);
+  const int ktw = ceil_div(nkt, 4);
+  if (mt == 1 && ktw <= 1) { pl.MT = 1; pl.KTW = 1; }
+  else if (mt == 1 && ktw <= 4) { pl.MT = 1; pl.KTW = 4; }
+  else if (mt <= 2 && ktw <= 4) { pl.MT = 2; pl.KTW = 4; }
+  else if (mt <= 4 && ktw <= 7) { pl.MT = 4; pl.KTW = 7; }
+  else return false;
+  // dOut tile floats per pixel row: MT*16 planes * OWp (+ plane padding, fixed)
+  plan_src(t, pl.MT * 16 * pl.OWp, pl.MT * 16 * 34, WGRAD_LDS_BUDGET);
+  pl.PLANEo = ((t.TPH * pl.OWp + 31) / 32) * 32 + 2;
+  pl.lds = 4 * ((size_t)t.Cp * t.PLANE + (size_t)pl.MT * 16 * pl.PLANEo + 64);
+  if (pl.lds > LDS_HARD_MAX) return false;
+  const long total = (long)B * t.tiles;
+  pl.grid = (int)(total < 1024 ? (total > 0 ? total : 1) : 1024);
+  return true;
+}
+
+template <int MT, int KTW>
+static void launch_wgrad_t(const WgradP& p, int grid, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<MT, KTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((wgrad_kernel<MT, KTW>), dim3(grid), dim3(256), lds, st, p);
+}
+}  // namespace
+
+extern "C" {
+size_t a2c_conv2d_prep_floats(const a2c_conv_desc* d, int kind) {
+  if (!desc_ok(d)) return 0;
+  if (kind == 0) return (size_t)d->ks * d->ks * (d->Cin / 4) * ceil_div(d->Cout, 16) * 64;
+  return bwd_class_offset(d, d->stride * d->stride);
+}
+
+int a2c_conv2d_prep_weights(const a2c_conv_desc* d, int kind, const float* weight, float* wprep,
+                            a2c_stream_t stream) {
+  if (!desc_ok(d) || !weight || !wprep) return A2C_ERR_ARG;
+  hipStream_t st = a2c_s(stream);
+  if (kind == 0) {
+    const int MT = ceil_div(d->Cout, 16);
+    const long total = (long)a2c_conv2d_prep_floats(d, 0);
+    hipLaunchKernelGGL(prep_fwd_kernel, dim3(a2c_grid_1d(total, 256)), dim3(256), 0, st, weight, wprep, d->Cin, d->Cout,
+                       d->ks, MT, total);
+    A2C_CHECK_LAUNCH();
+    return A2C_OK;
+  }
+  const int S = d->stride, MTb = ceil_div(d->Cin, 16);
+  for (int cls = 0; cls < S * S; ++cls) {
+    const int ry = cls / S, rx = cls % S;
+    const int na = ntaps_1d(d->ks, S, ry), nb = ntaps_1d(d->ks, S, rx);
+    const long total = (long)na * nb * (d->Cout / 4) * MTb * 64;
+    if (total == 0) continue;
+    hipLaunchKernelGGL(prep_bwd_kernel, dim3(a2c_grid_1d(total, 256)), dim3(256), 0, st, weight,
+                       wprep + bwd_class_offset(d, cls), d->Cin, d->Cout, d->ks, S, ry, rx, nb, MTb, total);
+    A2C_CHECK_LAUNCH();
+  }
+  return A2C_OK;
+}
+
+int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* wprep_fwd,
+                   const float* bias, int relu, float* out, int64_t out_bstride, int B, a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!in || !wprep_fwd || !out) return A2C_ERR_ARG;
+  SrcTile t;
+  t.Cp = d->Cin; t.IH = d->H; t.IW = d->W; t.SY = d->stride; t.SXl = d->stride;
+  t.sy0 = -d->pad; t.sx0 = -d->pad; t.span_y = d->ks; t.span_x = d->ks; t.PH = d->OH; t.PW = d->OW;
+  plan_src(t, 0, 0, IGEMM_LDS_BUDGET);
+  IgemmP p;
+  fill_stage(p.st, t, in, in_bstride);
+  p.out = out; p.out_bs = out_bstride; p.Mch = d->Cout; p.OHf = d->OH; p.OWf = d->OW;
+  p.wfrag = wprep_fwd; p.bias = bias; p.mask = nullptr; p.relu = relu;
+  p.ntaps = d->ks * d->ks; p.c4n = d->Cin / 4;
+  p.PH = d->OH; p.PW = d->OW; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0;
+  p.SY = t.SY; p.sy0 = t.sy0; p.TPH = t.TPH; p.tiles = t.tiles; p.B = B;
+  const int sm = t.SXl - 1, sh = ilog2(t.SXl);
+  for (int ky = 0; ky < d->ks; ++ky)
+    for (int kx = 0; kx < d->ks; ++kx) p.tapoff[ky * d->ks + kx] = ky * t.WP + (kx & sm) * t.WPS + (kx >> sh);
+  return launch_igemm(p, ceil_div(d->Cout, 16), a2c_s(stream));
+}
+
+int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask,
+                        float* din, int B, a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!dout || !wprep_bwd || !din) return A2C_ERR_ARG;
+  const int S = d->stride, P = d->pad;
+  for (int cls = 0; cls < S * S; ++cls) {
+    const int ry = cls / S, rx = cls % S;
+    const int na = ntaps_1d(d->ks, S, ry), nb = ntaps_1d(d->ks, S, rx);
+    // dX row y = S*q + ry - P, q in [qy0, qy1]
+    const int qy0 = (P - ry) > 0 ? ceil_div(P - ry, S) : 0;
+    const int qx0 = (P - rx) > 0 ? ceil_div(P - rx, S) : 0;
+    const int ny = (d->H - 1 + P - ry) >= 0 ? (d->H - 1 + P - ry) / S - qy0 + 1 : 0;
+    const int nx = (d->W - 1 + P - rx) >= 0 ? (d->W - 1 + P - rx) / S - qx0 + 1 : 0;
+    if (ny <= 0 || nx <= 0) continue;
+    SrcTile t;
+    t.Cp = d->Cout; t.IH = d->OH; t.IW = d->OW; t.SY = 1; t.SXl = 1;
+    const int sa = na > 0 ? na : 1, sb = nb > 0 ? nb : 1;
+    t.sy0 = qy0 - (sa - 1); t.sx0 = qx0 - (sb - 1); t.span_y = sa; t.span_x = sb; t.PH = ny; t.PW = nx;
+    plan_src(t, 0, 0, IGEMM_LDS_BUDGET);
+    IgemmP p;
+    fill_stage(p.st, t, dout, (long)d->Cout * d->OH * d->OW);
+    p.out = din; p.out_bs = (long)d->Cin * d->H * d->W; p.Mch = d->Cin; p.OHf = d->H; p.OWf = d->W;
+    p.wfrag = wprep_bwd + bwd_class_offset(d, cls); p.bias = nullptr; p.mask = mask; p.relu = 0;
+    p.ntaps = na * nb; p.c4n = d->Cout / 4;
+    p.PH = ny; p.PW = nx; p.oy_mul = S; p.oy_add = S * qy0 + ry - P; p.ox_mul = S; p.ox_add = S * qx0 + rx - P;
+    p.SY = 1; p.sy0 = t.sy0; p.TPH = t.TPH; p.tiles = t.tiles; p.B = B;
+    for (int a = 0; a < na; ++a)
+      for (int b = 0; b < nb; ++b) p.tapoff[a * nb + b] = (sa - 1 - a) * t.WP + (sb - 1 - b);
+    const int rc = launch_igemm(p, ceil_div(d->Cin, 16), a2c_s(stream));
+    if (rc != A2C_OK) return rc;
+  }
+  return A2C_OK;
+}
+
+size_t a2c_conv2d_bwd_weight_ws_bytes(const a2c_conv_desc* d, int B) {
+  WgradPlan pl;
+  if (!desc_ok(d) || B < 0 || !plan_wgrad(d, B, pl)) return 0;
+  return (size_t)pl.grid * ((size_t)d->Cout * d->Cin * d->ks * d->ks + d->Cout) * sizeof(float);
+}
+
+int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* dout, float* dW,
+                          float* db, int B, void* ws, size_t ws_bytes, a2c_stream_t stream) {
+  WgradPlan pl;
+  if (!desc_ok(d) || B < 1 || !in || !dout || !dW) return A2C_ERR_ARG;
+  if (!plan_wgrad(d, B, pl)) return A2C_ERR_ARG;
+  if (!ws || ws_bytes < a2c_conv2d_bwd_weight_ws_bytes(d, B)) return A2C_ERR_WORKSPACE;
+  hipStream_t st = a2c_s(stream);
+  WgradP p;
+  fill_stage(p.st, pl.t, in, in_bstride);
+  p.dout = dout; p.slab = (float*)ws;
+  p.Cout = d->Cout; p.K = d->Cin * d->ks * d->ks; p.ks = d->ks; p.OH = d->OH; p.OW = d->OW; p.OWp = pl.OWp;
+  p.S = d->stride; p.sy0 = pl.t.sy0; p.TPH = pl.t.TPH; p.tiles = pl.t.tiles; p.B = B;
+  p.PLANEo = pl.PLANEo; p.nkt = ceil_div(p.K, 16);
+  if (pl.MT == 1 && pl.KTW == 1) launch_wgrad_t<1, 1>(p, pl.grid, pl.lds, st);
+  else if (pl.MT == 1 && pl.KTW == 4) launch_wgrad_t<1, 4>(p, pl.grid, pl.lds, st);
+  else if (pl.MT == 2 && pl.KTW == 4) launch_wgrad_t<2, 4>(p, pl.grid, pl.lds, st);
+  else launch_wgrad_t<4, 7>(p, pl.grid, pl.lds, st);
+  A2C_CHECK_LAUNCH();
+  const long nW = (long)p.Cout * p.K, per = nW + p.Cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(per, 256)), dim3(256), 0, st, (const float*)ws, pl.grid, per,
+                     nW, dW, db);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+}

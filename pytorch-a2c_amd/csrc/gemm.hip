@@ -1,0 +1,276 @@
+// fp32 GEMM on the CDNA4 matrix cores for the dense layers of the model classes
+// (proj_matrx / resize_emb / pi / value / GRU gates: models.py:40-47,246-264,472-475,626-636)
+// and their backward passes.
+//
+// v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-for-bit a k-ordered fmaf chain
+// (no reduced precision; gfx950 has no xf32).  Workgroup = 256 threads = 4 waves (2x2), block
+// tile 128x128x16, each wave a 64x64 sub-tile = 2x2 MFMA tiles (64 accumulator VGPRs).
+// Operands are staged global -> registers -> LDS as As[k][m], Bs[k][n] so that an MFMA operand
+// read is one conflict-free ds_read_b32 per lane (lane l: A[i=l&31][k=l>>5]); the next K-tile's
+// global loads are issued before the current tile's MFMAs (register prefetch).
+// Split-K writes partial slabs that a second kernel sums in fixed order (deterministic), which
+// also applies the epilogue (bias, ReLU, ReLU-derivative mask of the layer below).
+#include "a2c_common.h"
+
+namespace {
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LD_T = 130;  // operand arrives k-contiguous: transposing scalar LDS stores, 4*LD_T % 32 == 8
+constexpr int LD_D = 132;  // operand arrives m/n-contiguous: float4 LDS stores (16 B aligned rows)
+
+struct Frag { float4 v[2]; };
+
+// KC = true : rows of the block tile are k-contiguous in memory: elem(i,k) = P[(r0+i)*ld + k]
+// KC = false: k-rows are i-contiguous in memory:                 elem(i,k) = P[k*ld + r0+i]
+template <bool KC>
+__device__ __forceinline__ void load_tile(Frag& f, const float* __restrict__ P, long ld, long r0, long R, long k0,
+                                          long kend, bool vec) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int q = t + 256 * it;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      const long i = r0 + (q >> 2), k = k0 + (q & 3) * 4;
+      if (i < R) {
+        const float* p = P + i * ld + k;
+        if (vec && k + 3 < kend) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (k + 0 < kend) v.x = p[0];
+          if (k + 1 < kend) v.y = p[1];
+          if (k + 2 < kend) v.z = p[2];
+          if (k + 3 < kend) v.w = p[3];
+        }
+      }
+    } else {
+      const long k = k0 + (q >> 5), i = r0 + (q & 31) * 4;
+      if (k < kend) {
+        const float* p = P + k * ld + i;
+        if (vec && i + 3 < R) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (i + 0 < R) v.x = p[0];
+          if (i + 1 < R) v.y = p[1];
+          if (i + 2 < R) v.z = p[2];
+          if (i + 3 < R) v.w = p[3];
+        }
+      }
+    }
+    f.v[it] = v;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(const Frag& f, float* __restrict__ S) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int q = t + 256 * it;
+    const float4 v = f.v[it];
+    if (KC) {
+      const int i = q >> 2, k = (q & 3) * 4;
+      S[(k + 0) * LD_T + i] = v.x;
+      S[(k + 1) * LD_T + i] = v.y;
+      S[(k + 2) * LD_T + i] = v.z;
+      S[(k + 3) * LD_T + i] = v.w;
+    } else {
+      const int k = q >> 5, i = (q & 31) * 4;
+      *reinterpret_cast<float4*>(&S[k * LD_D + i]) = v;
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_kernel(long M, long N, long K, const float* __restrict__ A, long lda,
+                                                   const float* __restrict__ B, long ldb, float* __restrict__ C,
+                                                   long ldc, const float* __restrict__ bias, int relu,
+                                                   const float* __restrict__ mask, long ldmask, int accumulate,
+                                                   long k_per_split, float* __restrict__ slab, int vecA, int vecB) {
+  constexpr int LDA = A_KC ? LD_T : LD_D;
+  constexpr int LDB = B_KC ? LD_T : LD_D;
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
+  const long kbeg = (long)blockIdx.z * k_per_split;
+  const long kend = min(K, kbeg + k_per_split);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int li = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Frag fa, fb;
+  load_tile<A_KC>(fa, A, lda, m0, M, kbeg, kend, vecA);
+  load_tile<B_KC>(fb, B, ldb, n0, N, kbeg, kend, vecB);
+  for (long k0 = kbeg; k0 < kend; k0 += BK) {
+    store_tile<A_KC>(fa, As);
+    store_tile<B_KC>(fb, Bs);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      load_tile<A_KC>(fa, A, lda, m0, M, k0 + BK, kend, vecA);
+      load_tile<B_KC>(fb, B, ldb, n0, N, k0 + BK, kend, vecB);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = As[(kk + lk) * LDA + wr * 64 + li];
+      const float a1 = As[(kk + lk) * LDA + wr * 64 + 32 + li];
+      const float b0 = Bs[(kk + lk) * LDB + wc * 64 + li];
+      const float b1 = Bs[(kk + lk) * LDB + wc * 64 + 32 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool direct = (slab == nullptr);
+  float* out = direct ? C : slab + (long)blockIdx.z * M * N;
+  const long ldo = direct ? ldc : N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long n = n0 + wc * 64 + j * 32 + li;
+      if (n >= N) continue;
+      const float bv = (direct && bias) ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= M) continue;
+        float v = acc[i][j][r];
+        if (direct) {
+          if (accumulate) v += out[m * ldo + n];
+          v += bv;
+          if (relu) v = fmaxf(v, 0.f);
+          if (mask && !(mask[m * ldmask + n] > 0.f)) v = 0.f;
+        }
+        out[m * ldo + n] = v;
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, long M,
+                                                            long N, float* __restrict__ C, long ldc,
+                                                            const float* __restrict__ bias, int relu,
+                                                            const float* __restrict__ mask, long ldmask,
+                                                            int accumulate) {
+  const long tot = M * N;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < tot; i += gridDim.x * 256L) {
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += slab[(long)z * tot + i];
+    const long m = i / N, n = i - m * N;
+    if (accumulate) v += C[m * ldc + n];
+    if (bias) v += bias[n];
+    if (relu) v = fmaxf(v, 0.f);
+    if (mask && !(mask[m * ldmask + n] > 0.f)) v = 0.f;
+    C[m * ldc + n] = v;
+  }
+}
+
+// out[n] = sum_m x[m*ld+n]: stage 1 = per-workgroup partial column sums over a row band,
+// stage 2 = fixed-order sum of the partials.
+constexpr int CS_BANDS = 256;
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x, long ld, long M, long N,
+                                                     float* __restrict__ part) {
+  const long rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  const long n = blockIdx.x * 256L + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (long m = r0; m < r1; ++m) s += x[m * ld + n];
+  part[(long)blockIdx.y * N + n] = s;
+}
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int bands, long N,
+                                                     float* __restrict__ out) {
+  const long n = blockIdx.x * 256L + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < bands; ++b) s += part[(long)b * N + n];
+  out[n] = s;
+}
+
+template <bool A_KC, bool B_KC>
+void launch_gemm(dim3 grid, hipStream_t st, long M, long N, long K, const float* A, long lda, const float* B, long ldb,
+                 float* C, long ldc, const float* bias, int relu, const float* mask, long ldmask, int acc, long kps,
+                 float* slab, int vecA, int vecB) {
+  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu,
+                     mask, ldmask, acc, kps, slab, vecA, vecB);
+}
+}  // namespace
+
+extern "C" {
+size_t a2c_gemm_ws_bytes(int64_t M, int64_t N, int splitk) {
+  return splitk > 1 ? (size_t)splitk * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                 const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu, const float* mask,
+                 int64_t ldmask, int accumulate, int splitk, void* ws, size_t ws_bytes, a2c_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0) return A2C_ERR_ARG;
+  if (M == 0 || N == 0) return A2C_OK;
+  if (!A || !B || !C || K == 0) return A2C_ERR_ARG;
+  if (splitk < 1) splitk = 1;
+  long kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;  // multiple of BK keeps 16 B alignment of k0
+  splitk = (int)((K + kps - 1) / kps);
+  float* slab = nullptr;
+  if (splitk > 1) {
+    if (!ws || ws_bytes < a2c_gemm_ws_bytes(M, N, splitk)) return A2C_ERR_WORKSPACE;
+    slab = (float*)ws;
+  }
+  const int vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
+  const int vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
+  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)splitk);
+  hipStream_t st = a2c_s(stream);
+  const bool a_kc = (transA == 0), b_kc = (transB != 0);
+  if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
+  else if (a_kc && !b_kc) launch_gemm<true, false>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
+  else if (!a_kc && b_kc) launch_gemm<false, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
+  else launch_gemm<false, false>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
+  A2C_CHECK_LAUNCH();
+  if (splitk > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(a2c_grid_1d(M * N, 256)), dim3(256), 0, st, slab, splitk, (long)M,
+                       (long)N, C, (long)ldc, bias, relu, mask, (long)ldmask, accumulate);
+    A2C_CHECK_LAUNCH();
+  }
+  return A2C_OK;
+}
+
+int a2c_gemm_f32_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, const float* bias, int relu, a2c_stream_t stream) {
+  return a2c_gemm_f32(0, 1, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, nullptr, 0, 0, 1, nullptr, 0, stream);
+}
+int a2c_gemm_f32_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, const float* mask, int64_t ldmask, a2c_stream_t stream) {
+  return a2c_gemm_f32(0, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, mask, ldmask, 0, 1, nullptr, 0, stream);
+}
+int a2c_gemm_f32_tn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, int splitk, void* ws, size_t ws_bytes, a2c_stream_t stream) {
+  return a2c_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, 0, 0, splitk, ws, ws_bytes, stream);
+}
+
+size_t a2c_colsum_ws_bytes(int64_t N) { return (size_t)CS_BANDS * (size_t)(N > 0 ? N : 0) * sizeof(float); }
+
+int a2c_colsum(const float* x, int64_t ld, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes,
+               a2c_stream_t stream) {
+  if (M < 0 || N < 0) return A2C_ERR_ARG;
+  if (N == 0) return A2C_OK;
+  if (!out || (M > 0 && !x)) return A2C_ERR_ARG;
+  if (!ws || ws_bytes < a2c_colsum_ws_bytes(N)) return A2C_ERR_WORKSPACE;
+  int bands = (int)(M < CS_BANDS ? (M > 0 ? M : 1) : CS_BANDS);
+  dim3 g1((unsigned)((N + 255) / 256), (unsigned)bands);
+  hipLaunchKernelGGL(colsum_stage1, g1, dim3(256), 0, a2c_s(stream), x, (long)ld, (long)M, (long)N, (float*)ws);
+  A2C_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, a2c_s(stream), (const float*)ws,
+                     bands, (long)N, out);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+}

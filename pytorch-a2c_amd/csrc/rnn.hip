@@ -1,0 +1,180 @@
+// Elementwise stages of the reference's custom GRU cell (models.GRU.forward, models.py:465-476)
+//   z = sig(x Wx0 + h Wh0 + b0);  r = sig(x Wx1 + h Wh1 + b1)
+//   h' = z*h + (1-z)*tanh(x Wx2 + (r*h) Wh2 + b2)
+// and torch.nn.LayerNorm of the FCModel/GRUFCModel value head (models.py:392, 510).
+// The six matrix products run on a2c_gemm_f32; these kernels are the fused gate math between
+// them (memory-bound, B*h elements), forward and backward.
+#include "a2c_common.h"
+
+namespace {
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict__ gx, const float* __restrict__ gh,
+                                                        const float* __restrict__ b, const float* __restrict__ h,
+                                                        float* __restrict__ z, float* __restrict__ r,
+                                                        float* __restrict__ rh, long B, int hd) {
+  const long n = B * hd;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const long row = i / hd;
+    const int c = (int)(i - row * hd);
+    const float zz = sigmoidf_((gx[row * 3 * hd + c] + gh[row * 2 * hd + c]) + b[c]);
+    const float rr = sigmoidf_((gx[row * 3 * hd + hd + c] + gh[row * 2 * hd + hd + c]) + b[hd + c]);
+    z[i] = zz;
+    r[i] = rr;
+    rh[i] = rr * h[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_out_kernel(const float* __restrict__ gx, const float* __restrict__ rhu,
+                                                      const float* __restrict__ b, const float* __restrict__ h,
+                                                      const float* __restrict__ z, float* __restrict__ cnd,
+                                                      float* __restrict__ hn, long B, int hd) {
+  const long n = B * hd;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const long row = i / hd;
+    const int c = (int)(i - row * hd);
+    const float cc = tanhf((gx[row * 3 * hd + 2 * hd + c] + rhu[i]) + b[2 * hd + c]);
+    const float zz = z[i];
+    if (cnd) cnd[i] = cc;
+    hn[i] = zz * h[i] + (1.f - zz) * cc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_out_bwd_kernel(const float* __restrict__ dhn, const float* __restrict__ h,
+                                                          const float* __restrict__ z, const float* __restrict__ c,
+                                                          float* __restrict__ dc_pre, float* __restrict__ dz,
+                                                          float* __restrict__ dh, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const float g = dhn[i], zz = z[i], cc = c[i];
+    dc_pre[i] = g * (1.f - zz) * (1.f - cc * cc);
+    dz[i] = g * (h[i] - cc);
+    dh[i] = g * zz;
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restrict__ d_rh,
+                                                            const float* __restrict__ dz, const float* __restrict__ h,
+                                                            const float* __restrict__ z, const float* __restrict__ r,
+                                                            float* __restrict__ dz_pre, float* __restrict__ dr_pre,
+                                                            float* __restrict__ dh, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const float zz = z[i], rr = r[i], drh = d_rh[i];
+    dz_pre[i] = dz[i] * zz * (1.f - zz);
+    dr_pre[i] = drh * h[i] * rr * (1.f - rr);
+    dh[i] += drh * rr;
+  }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            long rows, int n) {
+  const int lane = threadIdx.x & 63;
+  for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4L) {
+    const float* xr = x + row * n;
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += xr[i];
+    const float m = wave_sum(s) / (float)n;
+    float v = 0.f;
+    for (int i = lane; i < n; i += 64) { const float d = xr[i] - m; v += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum(v) / (float)n + 1e-5f);
+    for (int i = lane; i < n; i += 64) y[row * n + i] = (xr[i] - m) * rs * w[i] + b[i];
+    if (lane == 0) { mean[row] = m; rstd[row] = rs; }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ w, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            float* __restrict__ dw_rows, long rows, int n, int accum) {
+  const int lane = threadIdx.x & 63;
+  for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4L) {
+    const float m = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      const float xh = (x[row * n + i] - m) * rs;
+      const float g = dy[row * n + i] * w[i];
+      s1 += g;
+      s2 += g * xh;
+    }
+    s1 = wave_sum(s1) / (float)n;
+    s2 = wave_sum(s2) / (float)n;
+    for (int i = lane; i < n; i += 64) {
+      const float xh = (x[row * n + i] - m) * rs;
+      const float d = dy[row * n + i];
+      const float v = rs * (d * w[i] - s1 - xh * s2);
+      if (accum) dx[row * n + i] += v; else dx[row * n + i] = v;
+      dw_rows[row * n + i] = d * xh;
+    }
+  }
+}
+}  // namespace
+
+extern "C" {
+int a2c_gru_gates(const float* gx, const float* gh, const float* b, const float* h, float* z, float* r, float* rh,
+                  int B, int hdim, a2c_stream_t stream) {
+  if (B < 0 || hdim < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!gx || !gh || !b || !h || !z || !r || !rh) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(gru_gates_kernel, dim3(a2c_grid_1d((long)B * hdim, 256)), dim3(256), 0, a2c_s(stream), gx, gh, b,
+                     h, z, r, rh, (long)B, hdim);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_gru_out(const float* gx, const float* rh_u, const float* b, const float* h, const float* z, float* c,
+                float* h_new, int B, int hdim, a2c_stream_t stream) {
+  if (B < 0 || hdim < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!gx || !rh_u || !b || !h || !z || !h_new) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(gru_out_kernel, dim3(a2c_grid_1d((long)B * hdim, 256)), dim3(256), 0, a2c_s(stream), gx, rh_u, b,
+                     h, z, c, h_new, (long)B, hdim);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_gru_out_bwd(const float* dh_new, const float* h, const float* z, const float* c, float* dc_pre, float* dz,
+                    float* dh, int B, int hdim, a2c_stream_t stream) {
+  if (B < 0 || hdim < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!dh_new || !h || !z || !c || !dc_pre || !dz || !dh) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(gru_out_bwd_kernel, dim3(a2c_grid_1d((long)B * hdim, 256)), dim3(256), 0, a2c_s(stream), dh_new,
+                     h, z, c, dc_pre, dz, dh, (long)B * hdim);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_gru_gates_bwd(const float* d_rh, const float* dz, const float* h, const float* z, const float* r,
+                      float* dz_pre, float* dr_pre, float* dh, int B, int hdim, a2c_stream_t stream) {
+  if (B < 0 || hdim < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!d_rh || !dz || !h || !z || !r || !dz_pre || !dr_pre || !dh) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(a2c_grid_1d((long)B * hdim, 256)), dim3(256), 0, a2c_s(stream), d_rh,
+                     dz, h, z, r, dz_pre, dr_pre, dh, (long)B * hdim);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                      int64_t rows, int n, a2c_stream_t stream) {
+  if (rows < 0 || n < 1) return A2C_ERR_ARG;
+  if (rows == 0) return A2C_OK;
+  if (!x || !w || !b || !y || !mean || !rstd) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(a2c_grid_1d(rows, 4)), dim3(256), 0, a2c_s(stream), x, w, b, y, mean,
+                     rstd, (long)rows, n);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                      float* dx, float* dw_rows, int64_t rows, int n, int accumulate_dx, a2c_stream_t stream) {
+  if (rows < 0 || n < 1) return A2C_ERR_ARG;
+  if (rows == 0) return A2C_OK;
+  if (!dy || !x || !w || !mean || !rstd || !dx || !dw_rows) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(a2c_grid_1d(rows, 4)), dim3(256), 0, a2c_s(stream), dy, x, w, mean,
+                     rstd, dx, dw_rows, (long)rows, n, accumulate_dx);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+}

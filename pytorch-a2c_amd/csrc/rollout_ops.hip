@@ -1,0 +1,245 @@
+// Per-env-step kernels of Runner.rollout (runner.py:174-248), batched over B slots.
+// All memory-bound / latency-bound; the rollout buffers keep the reference's rollout-major
+// layout (element e = slot*T + t, training.py:88-101), so a "row of step t" is a strided
+// gather over slots: each kernel takes explicit strides instead of staging copies.
+#include "a2c_common.h"
+
+namespace {
+
+// a1: frame stack.  One workgroup column per (env, plane); 16 B per lane when HW % 4 == 0.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void frame_stack_kernel(const float* __restrict__ frame_new,
+                                                          const float* __restrict__ reset_mask,
+                                                          const float* __restrict__ prev, long prev_stride,
+                                                          float* __restrict__ out, long out_stride, int C,
+                                                          int HW) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.z;
+  const bool rst = reset_mask != nullptr && reset_mask[b] != 0.f;
+  float* o = out + (long)b * out_stride + (long)c * HW;
+  const float* src = nullptr;  // nullptr => zeros
+  if (c == C - 1) src = frame_new + (long)b * HW;
+  else if (!rst) src = prev + (long)b * prev_stride + (long)(c + 1) * HW;
+  if (VEC4) {
+    const int n4 = HW >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (src) v = reinterpret_cast<const float4*>(src)[i];
+      reinterpret_cast<float4*>(o)[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) o[i] = src ? src[i] : 0.f;
+  }
+}
+
+// a2: softmax + inverse-CDF sampling, one lane per env (A is small: 2..18).
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, long ld,
+                                                     const float* __restrict__ u, int64_t* __restrict__ act_i,
+                                                     long act_stride, float* __restrict__ act_f,
+                                                     float* __restrict__ probs, long B, int A) {
+  for (long b = blockIdx.x * 256L + threadIdx.x; b < B; b += gridDim.x * 256L) {
+    const float* row = logits + b * ld;
+    float mx = -INFINITY, den = 1.f;
+    if (SOFTMAX) {
+      for (int a = 0; a < A; ++a) mx = fmaxf(mx, row[a]);
+      den = 0.f;
+      for (int a = 0; a < A; ++a) den += expf(row[a] - mx);
+    }
+    const float ub = u[b];
+    float cs = 0.f;
+    int pick = -1;
+    for (int a = 0; a < A; ++a) {
+      const float p = SOFTMAX ? expf(row[a] - mx) / den : row[a];
+      if (probs) probs[b * A + a] = p;
+      cs = __fadd_rn(cs, p);
+      if (pick < 0 && cs >= ub) pick = a;
+    }
+    if (act_i) act_i[b * act_stride] = (int64_t)pick;
+    if (act_f) act_f[b] = (float)pick;
+  }
+}
+
+// a3: rewards / dones / TD deltas of one env step (runner.py:212-232)
+__global__ __launch_bounds__(256) void record_kernel(const float* __restrict__ rew, const float* __restrict__ done,
+                                                     const float* __restrict__ val, long vstride,
+                                                     float* __restrict__ val_prev,
+                                                     float* __restrict__ rewards, float* __restrict__ dones,
+                                                     float* __restrict__ deltas, float* __restrict__ done_eff_out,
+                                                     int B, long T, long t, long slot0, float gamma, int pong) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const long e = (slot0 + b) * T + t;
+  const float r = rew[b];
+  float d = done[b] != 0.f ? 1.f : 0.f;
+  if (pong && r != 0.f) d = 1.f;
+  rewards[e] = r;
+  dones[e] = d;
+  if (done_eff_out) done_eff_out[b] = d;
+  const float v = val[b * vstride];
+  if (t > 0) {
+    // delta = prev_rew + gamma*val*(1-prev_done) - prev_val, left to right, each op rounded
+    const float pr = rewards[e - 1], pd = dones[e - 1];
+    const float gv = __fmul_rn(gamma, v);
+    deltas[e - 1] = __fsub_rn(__fadd_rn(pr, __fmul_rn(gv, __fsub_rn(1.f, pd))), val_prev[b]);
+  }
+  val_prev[b] = v;
+}
+
+__global__ __launch_bounds__(256) void zero_done_rows_kernel(float* __restrict__ h, int hdim,
+                                                             const float* __restrict__ done_eff, int B) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= (long)B * hdim) return;
+  if (done_eff[i / hdim] != 0.f) h[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void bootstrap_kernel(const float* __restrict__ val_boot, long vstride,
+                                                        const float* __restrict__ val_prev,
+                                                        float* __restrict__ rewards, float* __restrict__ dones,
+                                                        float* __restrict__ deltas, int B, long T, long slot0,
+                                                        float gamma) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const long e = (slot0 + b) * T + T - 1;
+  float r = rewards[e];
+  if (dones[e] == 0.f) {
+    r = __fadd_rn(r, __fmul_rn(gamma, val_boot[b * vstride]));
+    rewards[e] = r;
+    dones[e] = 1.f;
+  }
+  deltas[e] = __fsub_rn(r, val_prev[b]);
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, long ss,
+                                                        float* __restrict__ dst, long ds, long n) {
+  const int b = blockIdx.y;
+  for (long j = blockIdx.x * 256L + threadIdx.x; j < n; j += gridDim.x * 256L) dst[b * ds + j] = src[b * ss + j];
+}
+
+__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, long ld,
+                                                        const float* __restrict__ dones, long dstride, int B,
+                                                        int n) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= (long)B * n) return;
+  const long b = i / n, j = i - b * n;
+  x[b * ld + j] *= (1.f - dones[b * dstride]);
+}
+__global__ __launch_bounds__(256) void permute_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           long R, long T, long n) {
+  const long tot = R * T * n;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < tot; i += gridDim.x * 256L) {
+    const long row = i / n, j = i - row * n;      // dst row = t*R + r
+    const long t = row / R, r = row - t * R;
+    dst[i] = src[(r * T + t) * n + j];
+  }
+}
+}  // namespace
+
+extern "C" {
+int a2c_permute_rows(const float* src, float* dst, int64_t R, int64_t T, int64_t n, a2c_stream_t stream) {
+  if (R < 0 || T < 0 || n < 0) return A2C_ERR_ARG;
+  if (R * T * n == 0) return A2C_OK;
+  if (!src || !dst) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(permute_rows_kernel, dim3(a2c_grid_1d(R * T * n, 256)), dim3(256), 0, a2c_s(stream), src, dst,
+                     (long)R, (long)T, (long)n);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_frame_stack_push(const float* frame_new, const float* reset_mask, const float* prev, int64_t prev_stride,
+                         float* out, int64_t out_stride, int B, int C, int HW, a2c_stream_t stream) {
+  if (B < 0 || C < 1 || HW < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!frame_new || !out || (C > 1 && !prev)) return A2C_ERR_ARG;
+  const bool vec = (HW % 4 == 0) && (prev_stride % 4 == 0) && (out_stride % 4 == 0) &&
+                   (((uintptr_t)frame_new | (uintptr_t)prev | (uintptr_t)out) % 16 == 0);
+  const int work = vec ? HW / 4 : HW;
+  dim3 grid((work + 255) / 256 > 8 ? 8 : (work + 255) / 256, B, C);
+  if (vec)
+    hipLaunchKernelGGL(frame_stack_kernel<true>, grid, dim3(256), 0, a2c_s(stream), frame_new, reset_mask, prev,
+                       (long)prev_stride, out, (long)out_stride, C, HW);
+  else
+    hipLaunchKernelGGL(frame_stack_kernel<false>, grid, dim3(256), 0, a2c_s(stream), frame_new, reset_mask, prev,
+                       (long)prev_stride, out, (long)out_stride, C, HW);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_softmax_sample(const float* logits, int64_t ld_logits, const float* u, int64_t* actions,
+                       int64_t act_stride, float* probs, int B, int A, a2c_stream_t stream) {
+  if (B < 0 || A < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!logits || !u || !actions) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(sample_kernel<true>, dim3(a2c_grid_1d(B, 256)), dim3(256), 0, a2c_s(stream), logits,
+                     (long)ld_logits, u, actions, (long)act_stride, (float*)nullptr, probs, (long)B, A);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_sample_probs(const float* probs, const float* u, float* actions, int64_t B, int A, a2c_stream_t stream) {
+  if (B < 0 || A < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!probs || !u || !actions) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(sample_kernel<false>, dim3(a2c_grid_1d(B, 256)), dim3(256), 0, a2c_s(stream), probs, (long)A, u,
+                     (int64_t*)nullptr, 0L, actions, (float*)nullptr, (long)B, A);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_rollout_record(const float* rew, const float* done, const float* val, int64_t val_stride, float* val_prev,
+                       float* rewards,
+                       float* dones, float* deltas, float* done_eff_out, float* h, int hdim, int B, int64_t T,
+                       int64_t t, int64_t slot0, float gamma, int pong, a2c_stream_t stream) {
+  if (B < 0 || T < 1 || t < 0 || t >= T) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!rew || !done || !val || !val_prev || !rewards || !dones || !deltas) return A2C_ERR_ARG;
+  if (h && (!done_eff_out || hdim < 1)) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(record_kernel, dim3((B + 255) / 256), dim3(256), 0, a2c_s(stream), rew, done, val,
+                     (long)val_stride, val_prev, rewards, dones, deltas, done_eff_out, B, (long)T, (long)t, (long)slot0,
+                     gamma, pong);
+  A2C_CHECK_LAUNCH();
+  if (h) {
+    const long n = (long)B * hdim;
+    hipLaunchKernelGGL(zero_done_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a2c_s(stream), h, hdim,
+                       done_eff_out, B);
+    A2C_CHECK_LAUNCH();
+  }
+  return A2C_OK;
+}
+
+int a2c_rollout_bootstrap(const float* val_boot, int64_t val_stride, const float* val_prev, float* rewards,
+                          float* dones, float* deltas,
+                          int B, int64_t T, int64_t slot0, float gamma, a2c_stream_t stream) {
+  if (B < 0 || T < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!val_boot || !val_prev || !rewards || !dones || !deltas) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(bootstrap_kernel, dim3((B + 255) / 256), dim3(256), 0, a2c_s(stream), val_boot,
+                     (long)val_stride, val_prev, rewards, dones, deltas, B, (long)T, (long)slot0, gamma);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_copy_rows(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int B, int64_t n,
+                  a2c_stream_t stream) {
+  if (B < 0 || n < 0) return A2C_ERR_ARG;
+  if (B == 0 || n == 0) return A2C_OK;
+  if (!src || !dst) return A2C_ERR_ARG;
+  dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), B);
+  hipLaunchKernelGGL(copy_rows_kernel, grid, dim3(256), 0, a2c_s(stream), src, (long)src_stride, dst,
+                     (long)dst_stride, (long)n);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_mask_rows(float* x, int64_t ld, const float* dones, int64_t done_stride, int B, int n,
+                  a2c_stream_t stream) {
+  if (B < 0 || n < 0) return A2C_ERR_ARG;
+  if (B == 0 || n == 0) return A2C_OK;
+  if (!x || !dones) return A2C_ERR_ARG;
+  const long tot = (long)B * n;
+  hipLaunchKernelGGL(mask_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, a2c_s(stream), x, (long)ld,
+                     dones, (long)done_stride, B, n);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+}

@@ -1,0 +1,224 @@
+// Reverse segmented discounted scans (utils.discount, utils.py:63-79) and the
+// normalisation helpers of Updater.update_model (updater.py:70-98).
+//
+// Layout: n_seg rows of T contiguous fp32 (rollout-major buffers, training.py:88-101).
+// One 64-lane workgroup owns S consecutive rows (S*ld <= TILE floats per array): the rows
+// are one contiguous span in HBM, so the loads/stores are fully coalesced; they go through
+// LDS with row stride ld = T|1 (odd => the per-lane walk is bank-conflict free), and lane j
+// then walks row j backwards with the reference's exact operation order
+//   run = x[i] + g*run   (one fp32 multiply, one fp32 add; no FMA contraction)
+// so the result is bit-identical to the reference's Python loop.
+// Algorithmic traffic: 12 B/element (x, dones in; y out); fused advs+returns: 20 B/element.
+#include "a2c_common.h"
+
+namespace {
+constexpr int TILE = 2048;  // floats per array per workgroup -> 24 KB LDS (fused) => 6 WG/CU
+
+template <int NARR>
+__global__ __launch_bounds__(64) void scan_rows_kernel(const float* __restrict__ x0,
+                                                       const float* __restrict__ x1,
+                                                       const float* __restrict__ dn,
+                                                       float* __restrict__ y0, float* __restrict__ y1,
+                                                       long n_seg, int T, int S, int ld, float g0,
+                                                       float g1, int* err) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s0 = smem;
+  float* sd = smem + S * ld;
+  float* s1 = smem + 2 * S * ld;
+  const int lane = threadIdx.x;
+  const long n_tasks = (n_seg + S - 1) / S;
+  for (long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    const long row0 = task * S;
+    const int rows = (int)min((long)S, n_seg - row0);
+    const long base = row0 * (long)T;
+    const int cnt = rows * T;
+    for (int e = lane; e < cnt; e += 64) {
+      const int j = e / T, t = e - j * T, a = j * ld + t;
+      s0[a] = x0[base + e];
+      sd[a] = dn[base + e];
+      if (NARR == 2) s1[a] = x1[base + e];
+    }
+    __syncthreads();
+    if (lane < rows) {
+      int a = lane * ld + T - 1;
+      if (err != nullptr && n_seg > 1 && sd[a] != 1.0f) *err = 1;
+      float r0 = 0.f, r1 = 0.f;
+      for (int t = T - 1; t >= 0; --t, --a) {
+        if (sd[a] == 1.0f) { r0 = 0.f; r1 = 0.f; }
+        r0 = __fadd_rn(s0[a], __fmul_rn(g0, r0));
+        s0[a] = r0;
+        if (NARR == 2) {
+          r1 = __fadd_rn(s1[a], __fmul_rn(g1, r1));
+          s1[a] = r1;
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = lane; e < cnt; e += 64) {
+      const int j = e / T, t = e - j * T, a = j * ld + t;
+      y0[base + e] = s0[a];
+      if (NARR == 2) y1[base + e] = s1[a];
+    }
+    __syncthreads();
+  }
+}
+
+// rows longer than the LDS tile: one workgroup per row, time-chunks walked from the end with
+// the running sums carried in registers of lane 0 (exact; used for the flat n_seg==1 form).
+template <int NARR>
+__global__ __launch_bounds__(64) void scan_long_kernel(const float* __restrict__ x0,
+                                                       const float* __restrict__ x1,
+                                                       const float* __restrict__ dn,
+                                                       float* __restrict__ y0, float* __restrict__ y1,
+                                                       long n_seg, long T, float g0, float g1, int* err) {
+  __shared__ float s0[TILE], sd[TILE], s1[NARR == 2 ? TILE : 1];
+  const int lane = threadIdx.x;
+  for (long row = blockIdx.x; row < n_seg; row += gridDim.x) {
+    const long base = row * T;
+    float r0 = 0.f, r1 = 0.f;
+    for (long hi = T; hi > 0; hi -= TILE) {
+      const long lo = hi > TILE ? hi - TILE : 0;
+      const int cnt = (int)(hi - lo);
+      for (int e = lane; e < cnt; e += 64) {
+        s0[e] = x0[base + lo + e];
+        sd[e] = dn[base + lo + e];
+        if (NARR == 2) s1[e] = x1[base + lo + e];
+      }
+      __syncthreads();
+      if (lane == 0) {
+        if (hi == T && err != nullptr && n_seg > 1 && sd[cnt - 1] != 1.0f) *err = 1;
+        for (int a = cnt - 1; a >= 0; --a) {
+          if (sd[a] == 1.0f) { r0 = 0.f; r1 = 0.f; }
+          r0 = __fadd_rn(s0[a], __fmul_rn(g0, r0));
+          s0[a] = r0;
+          if (NARR == 2) {
+            r1 = __fadd_rn(s1[a], __fmul_rn(g1, r1));
+            s1[a] = r1;
+          }
+        }
+      }
+      __syncthreads();
+      for (int e = lane; e < cnt; e += 64) {
+        y0[base + lo + e] = s0[e];
+        if (NARR == 2) y1[base + lo + e] = s1[e];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int NARR>
+int launch_scan(const float* x0, const float* x1, const float* dn, float* y0, float* y1, int64_t n_seg,
+                int64_t T, float g0, float g1, int* err, hipStream_t st) {
+  if (n_seg < 0 || T < 0) return A2C_ERR_ARG;
+  if (n_seg == 0 || T == 0) return A2C_OK;
+  if (!x0 || !dn || !y0 || (NARR == 2 && (!x1 || !y1))) return A2C_ERR_ARG;
+  if (err) (void)hipMemsetAsync(err, 0, sizeof(int), st);
+  const int64_t ld = T | 1;
+  if (ld <= TILE) {
+    int S = (int)(TILE / ld);
+    if (S > 64) S = 64;
+    if (S > n_seg) S = (int)n_seg;
+    const int64_t n_tasks = (n_seg + S - 1) / S;
+    const int grid = (int)(n_tasks < 256 * 6 ? n_tasks : 256 * 6);
+    const size_t lds = (size_t)(NARR + 1) * S * ld * sizeof(float);
+    hipLaunchKernelGGL(scan_rows_kernel<NARR>, dim3(grid), dim3(64), lds, st, x0, x1, dn, y0, y1,
+                       (long)n_seg, (int)T, S, (int)ld, g0, g1, err);
+  } else {
+    const int grid = (int)(n_seg < 1024 ? n_seg : 1024);
+    hipLaunchKernelGGL(scan_long_kernel<NARR>, dim3(grid), dim3(64), 0, st, x0, x1, dn, y0, y1,
+                       (long)n_seg, (long)T, g0, g1, err);
+  }
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, long n, double* sums) {
+  __shared__ double sm[4];
+  double a = 0.0, b = 0.0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const double v = (double)x[i];
+    a += v;
+    b += v * v;
+  }
+  a = block_sum_256(a, sm);
+  b = block_sum_256(b, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], a);
+    atomicAdd(&sums[1], b);
+  }
+}
+
+__device__ __forceinline__ void mean_std(const double* sums, long n, float& mean, float& stdv) {
+  const double m = sums[0] / (double)n;
+  double var = (sums[1] - (double)n * m * m) / (double)(n - 1);  // unbiased (Tensor.std)
+  if (var < 0.0) var = 0.0;
+  mean = (float)m;
+  stdv = (float)sqrt(var);
+}
+
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        long n, const double* sums, long n_global, float eps) {
+  float mean, stdv;
+  mean_std(sums, n_global, mean, stdv);
+  const float den = stdv + eps;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) y[i] = (x[i] - mean) / den;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) y[i] = a[i] + b[i];
+}
+}  // namespace
+
+extern "C" {
+int a2c_version(void) { return 1; }
+
+const char* a2c_error_string(int code) {
+  switch (code) {
+    case A2C_OK: return "ok";
+    case A2C_ERR_ARG: return "invalid argument";
+    case A2C_ERR_LAUNCH: return "kernel launch failed";
+    case A2C_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown error";
+  }
+}
+
+int a2c_discount_scan(const float* x, const float* dones, float* y, int64_t n_seg, int64_t T, float g,
+                      int* err_flag, a2c_stream_t stream) {
+  return launch_scan<1>(x, nullptr, dones, y, nullptr, n_seg, T, g, 0.f, err_flag, a2c_s(stream));
+}
+
+int a2c_gae_returns_fused(const float* deltas, const float* rewards, const float* dones, float* advs,
+                          float* rets, int64_t n_seg, int64_t T, float g_adv, float g_ret, int* err_flag,
+                          a2c_stream_t stream) {
+  return launch_scan<2>(deltas, rewards, dones, advs, rets, n_seg, T, g_adv, g_ret, err_flag, a2c_s(stream));
+}
+
+int a2c_moments(const float* x, int64_t n, double* sums, a2c_stream_t stream) {
+  if (!sums || n < 0 || (n > 0 && !x)) return A2C_ERR_ARG;
+  (void)hipMemsetAsync(sums, 0, 2 * sizeof(double), a2c_s(stream));
+  if (n == 0) return A2C_OK;
+  hipLaunchKernelGGL(moments_kernel, dim3(a2c_grid_1d(n, 256, 1024)), dim3(256), 0, a2c_s(stream), x, (long)n, sums);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_normalize(const float* x, float* y, int64_t n, const double* sums, int64_t n_global, float eps,
+                  a2c_stream_t stream) {
+  if (n < 0 || n_global < 2 || !sums || (n > 0 && (!x || !y))) return A2C_ERR_ARG;
+  if (n == 0) return A2C_OK;
+  hipLaunchKernelGGL(normalize_kernel, dim3(a2c_grid_1d(n, 256)), dim3(256), 0, a2c_s(stream), x, y, (long)n, sums,
+                     (long)n_global, eps);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_add(const float* a, const float* b, float* y, int64_t n, a2c_stream_t stream) {
+  if (n < 0 || (n > 0 && (!a || !b || !y))) return A2C_ERR_ARG;
+  if (n == 0) return A2C_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(a2c_grid_1d(n, 256)), dim3(256), 0, a2c_s(stream), a, b, y, (long)n);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+}

@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/a2c_mi355x.h declares
+(no compute calls here: there is no GPU in the build container)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_prototypes():
+    src = open(os.path.join(ROOT, "include", "a2c_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(a2c_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_lists_the_path_functions():
+    names = header_prototypes()
+    for n in ("a2c_discount_scan", "a2c_gae_returns_fused", "a2c_frame_stack_push", "a2c_softmax_sample",
+              "a2c_rollout_record", "a2c_loss_fwd_bwd", "a2c_gemm_f32", "a2c_conv2d_fwd", "a2c_conv2d_bwd_data",
+              "a2c_conv2d_bwd_weight", "a2c_gru_gates", "a2c_layernorm_fwd", "a2c_clip_rmsprop", "a2c_clip_adam"):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    from a2c_amd import _lib
+    lib = _lib.load()                      # raises if the .so is missing or a symbol is absent
+    names = header_prototypes()
+    assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (a2c_[a-z0-9_]+)", out))
+    assert set(names) <= exported, set(names) - exported
+    assert lib.a2c_version() == 1
+    assert lib.a2c_error_string(-1) == b"invalid argument"
+
+
+def test_argument_validation_without_gpu():
+    """launchers reject bad arguments before touching the device"""
+    from a2c_amd import _lib
+    lib = _lib.load()
+    assert lib.a2c_discount_scan(None, None, None, -1, 4, 0.9, None, None) == -1
+    assert lib.a2c_discount_scan(None, None, None, 0, 4, 0.9, None, None) == 0          # empty input is a no-op
+    assert lib.a2c_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, None, 0, 0, 1, None, 0, None) == -1
+    assert lib.a2c_loss_fwd_bwd(None, 3, None, 1, None, None, None, None, 4, 4, 64, 1.0, .5, .005, None, 3, None, 1,
+                                None, None) == -1
+    d = _lib.ConvDesc(3, 8, 8, 16, 3, 1, 1, 8, 8)       # Cin % 4 != 0
+    import ctypes
+    assert lib.a2c_conv2d_prep_floats(ctypes.byref(d), 0) == 0
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+    from a2c_amd import ops, utils
+    with pytest.raises(RuntimeError):
+        ops.discount_rows(torch.zeros(4), torch.zeros(4), 0.9, 1, 4)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            utils.discount(torch.zeros(4), torch.zeros(4), 0.9)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pytorch-a2c_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                for line in open(os.path.join(dp, f)).read().splitlines():
+                    low = line.lower()
+                    assert not ("oracle" in low and ("import" in low or "include" in low)), (f, line)

@@ -1,0 +1,466 @@
+"""-m gpu: every kernel family of liba2c_mi355x.so, called through the C ABI (a2c_amd.ops), against
+the CPU oracle / the same torch CPU operator the reference calls, on seeded inputs.
+Tolerances: bit-exact for the scans, sampler and integer outputs; 1e-5 (fp32, the north-star
+tolerance) for dense arithmetic, scaled by the magnitude of the accumulated terms."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import a2c_oracle as O  # noqa: E402
+from cases import hashf  # noqa: E402
+
+DEV = "cuda"
+
+
+def _ops():
+    from a2c_amd import ops
+    return ops
+
+
+def close(name, got, want, atol=1e-5, rtol=1e-5):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, dtype=np.float64)
+    want = want.detach().cpu().double().numpy() if torch.is_tensor(want) else np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    bad = err > tol
+    if bad.any():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{name}: {bad.sum()}/{bad.size} off, max abs err {err.max():.3e} at {i}: "
+                             f"got {got[i]:.8g} want {want[i]:.8g} (scale {np.abs(want).max():.3g})")
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy(hashf(n, seed, lo, hi).reshape(shape))
+
+
+# ------------------------------------------------------------------ scans
+def test_discount_golden_bitexact(golden):
+    from a2c_amd.utils import discount
+    g = golden["g1_discount"]
+    for i in range(int(g["n_cases"])):
+        y = discount(g[f"x{i}"], g[f"d{i}"], float(g[f"g{i}"]))
+        assert np.array_equal(y.cpu().numpy(), g[f"y{i}"]), i
+
+
+@pytest.mark.parametrize("n_seg,T", [(1, 1), (3, 5), (64, 128), (257, 33), (2, 2047), (2, 2048), (3, 5000), (2048, 128)])
+def test_discount_rows_vs_oracle(n_seg, T):
+    ops = _ops()
+    x = rnd((n_seg * T,), 1, -1, 1)
+    d = (rnd((n_seg * T,), 2, 0, 1) < 0.07).float()
+    d[T - 1::T] = 1.0
+    r = rnd((n_seg * T,), 3, -1, 1)
+    want = np.concatenate([O.discount_np(x[i * T:(i + 1) * T], d[i * T:(i + 1) * T], 0.9702) for i in range(n_seg)])
+    xd, dd, rd = x.to(DEV), d.to(DEV), r.to(DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    y = ops.discount_rows(xd, dd, 0.9702, n_seg, T, err=err)
+    assert np.array_equal(y.cpu().numpy(), want)
+    assert int(err.item()) == 0
+    advs, rets = torch.empty_like(xd), torch.empty_like(xd)
+    ops.gae_returns(xd, rd, dd, 0.9702, 0.99, n_seg, T, advs, rets)
+    want_r = np.concatenate([O.discount_np(r[i * T:(i + 1) * T], d[i * T:(i + 1) * T], 0.99) for i in range(n_seg)])
+    assert np.array_equal(advs.cpu().numpy(), want)
+    assert np.array_equal(rets.cpu().numpy(), want_r)
+
+
+def test_discount_row_invariant_flag_and_flat_fallback():
+    from a2c_amd.utils import discount
+    ops = _ops()
+    x = rnd((40,), 4).to(DEV)
+    d = torch.zeros(40, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.discount_rows(x, d, 0.9, 4, 10, err=err)
+    assert int(err.item()) == 1
+    with pytest.raises(ValueError):
+        discount(x, d, 0.9, n_tsteps=10)
+    y = discount(x, d, 0.9)            # flat: carries across everything, exactly like the reference
+    assert np.array_equal(y.cpu().numpy(), O.discount_np(x.cpu().numpy(), d.cpu().numpy(), 0.9))
+    assert discount(torch.zeros(0), torch.zeros(0), 0.9).numel() == 0
+
+
+def test_discount_full_size_properties():
+    """BASELINE size (n_envs=2048 x T=128) and the saturating size: linearity in x and a sampled
+    comparison with the oracle (the oracle's python loop cannot walk 2^24 elements in seconds)."""
+    ops = _ops()
+    for n_seg, T in [(2048, 128), (1 << 17, 128)]:
+        N = n_seg * T
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        x = torch.rand(N, device=DEV, generator=gen) * 2 - 1
+        d = (torch.rand(N, device=DEV, generator=gen) < 0.02).float()
+        d[T - 1::T] = 1
+        y = ops.discount_rows(x, d, 0.99, n_seg, T)
+        y2 = ops.discount_rows(2 * x, d, 0.99, n_seg, T)
+        assert torch.equal(y2, 2 * y)                       # scaling by 2 is exact in fp32
+        for row in (0, 1, n_seg // 2, n_seg - 1):
+            sl = slice(row * T, (row + 1) * T)
+            assert np.array_equal(y[sl].cpu().numpy(), O.discount_np(x[sl].cpu().numpy(), d[sl].cpu().numpy(), 0.99))
+        # a done step keeps its own value
+        assert torch.equal(y[d == 1], x[d == 1])
+
+
+def test_moments_normalize_add():
+    ops = _ops()
+    x = rnd((5000,), 7, -3, 5)
+    xd = x.to(DEV)
+    sums = torch.zeros(2, dtype=torch.float64, device=DEV)
+    ops.moments(xd, sums)
+    y = torch.empty_like(xd)
+    ops.normalize(xd, y, sums, x.numel(), 1e-6)
+    close("normalize", y, (x - x.mean()) / (x.std() + 1e-6), 2e-6, 1e-5)
+    z = torch.empty_like(xd)
+    ops.add(xd, y, z)
+    assert torch.equal(z, xd + y)
+    assert torch.allclose(torch.tensor([1., 2, 3, 4]).std(), torch.tensor(1.2909944))
+
+
+# ------------------------------------------------------------------ sampler / rollout step kernels
+def test_sample_action_golden(golden):
+    from a2c_amd.utils import sample_action
+    g = golden["g2_sample_action"]
+    for i in range(int(g["n_cases"])):
+        a = sample_action(torch.from_numpy(g[f"p{i}"]), torch.from_numpy(g[f"u{i}"]))
+        assert np.array_equal(a.cpu().numpy(), g[f"a{i}"]), i
+
+
+@pytest.mark.parametrize("A", [2, 3, 4, 6, 18])
+def test_softmax_sample_vs_oracle(A):
+    ops = _ops()
+    B = 777
+    logits = rnd((B, A + 1), 10 + A, -4, 4)          # strided rows, like the heads buffer
+    u = rnd((B,), 30 + A, 0, 1)
+    want = O.sample_action(F.softmax(logits[:, :A], dim=-1), u).long()
+    ld, ud = logits.to(DEV), u.to(DEV)
+    acts = torch.full((B, 3), -7, dtype=torch.int64, device=DEV)
+    probs = torch.empty(B, A, device=DEV)
+    ops.softmax_sample(ld[:, :A], ud, acts.data_ptr() + 8, 3, B, A, probs=probs)
+    close("probs", probs, F.softmax(logits[:, :A], dim=-1), 1e-6, 1e-5)
+    got = acts[:, 1].cpu()
+    mism = (got != want).nonzero().flatten()
+    # a flip is only legitimate when the cumsum is within rounding of u
+    cs = torch.cumsum(F.softmax(logits[:, :A], -1), -1)
+    for i in mism.tolist():
+        assert (cs[i] - u[i]).abs().min() < 1e-6, (i, got[i], want[i])
+    assert len(mism) <= 1
+    assert (acts[:, 0] == -7).all() and (acts[:, 2] == -7).all()
+
+
+def test_frame_stack_push():
+    ops = _ops()
+    B, C, HW, T = 5, 4, 84 * 84, 3
+    buf = rnd((B, T, C * HW), 40).to(DEV)           # rollout-major rows
+    frames = rnd((B, HW), 41).to(DEV)
+    reset = torch.tensor([0., 1, 0, 0, 1], device=DEV)
+    want = buf.clone()
+    prev = buf[:, 0].view(B, C, HW)
+    new = torch.cat([prev[:, 1:], frames[:, None]], 1)
+    new[reset.bool(), :C - 1] = 0
+    want[:, 1] = new.view(B, -1)
+    ops.frame_stack_push(frames, reset, buf.data_ptr(), T * C * HW, buf.data_ptr() + 4 * C * HW, T * C * HW, B, C, HW)
+    assert torch.equal(buf, want)
+    # unaligned / odd size path
+    B, C, HW = 3, 3, 7
+    buf = rnd((B, 2, C * HW), 42).to(DEV)
+    frames = rnd((B, HW), 43).to(DEV)
+    want = buf.clone()
+    want[:, 1] = torch.cat([buf[:, 0].view(B, C, HW)[:, 1:], frames[:, None]], 1).view(B, -1)
+    ops.frame_stack_push(frames, None, buf.data_ptr(), 2 * C * HW, buf.data_ptr() + 4 * C * HW, 2 * C * HW, B, C, HW)
+    assert torch.equal(buf, want)
+
+
+def test_rollout_record_and_bootstrap():
+    ops = _ops()
+    B, T, slot0, n_slots, hd = 6, 5, 2, 9, 8
+    gamma = 0.99
+    rewards = rnd((n_slots * T,), 50)
+    dones = (rnd((n_slots * T,), 51, 0, 1) < 0.3).float()
+    deltas = rnd((n_slots * T,), 52)
+    rw, dn, dl = rewards.to(DEV), dones.to(DEV), deltas.to(DEV)
+    val_prev = rnd((B,), 53)
+    vp = val_prev.to(DEV)
+    h = rnd((B, hd), 54).to(DEV)
+    h0 = h.clone()
+    t = 3
+    rew = torch.tensor([0., 1, -1, 0, 0, 2])
+    done = torch.tensor([0., 0, 0, 1, 0, 0])
+    val = rnd((B, 4), 55)                      # strided value column
+    de = torch.zeros(B, device=DEV)
+    val_d, rew_d, done_d = val.to(DEV), rew.to(DEV), done.to(DEV)
+    ops.rollout_record(rew_d, done_d, val_d.data_ptr() + 12, 4, vp, rw, dn, dl, de, h, B, T, t, slot0, gamma, True)
+    for b in range(B):
+        e = (slot0 + b) * T + t
+        d_eff = 1.0 if (done[b] != 0 or rew[b] != 0) else 0.0
+        assert rw[e].item() == rew[b].item() and dn[e].item() == d_eff
+        v = val[b, 3]
+        want = (rewards[e - 1] + (torch.tensor(gamma) * v) * (1 - dones[e - 1]) - val_prev[b]).float()
+        assert dl[e - 1].item() == want.item(), b
+        assert vp[b].item() == v.item()
+        assert torch.equal(h[b], torch.zeros(hd, device=DEV) if d_eff else h0[b])
+    # bootstrap
+    vb = rnd((B,), 56)
+    r2, d2, l2 = rw.clone(), dn.clone(), dl.clone()
+    vb_d = vb.to(DEV)
+    ops.rollout_bootstrap(vb_d.data_ptr(), 1, vp, r2, d2, l2, B, T, slot0, gamma)
+    for b in range(B):
+        e = (slot0 + b) * T + T - 1
+        r = rw[e].cpu()
+        if dn[e].item() == 0:
+            r = (r + torch.tensor(gamma) * vb[b]).float()
+        assert r2[e].item() == r.item() and d2[e].item() == 1.0
+        assert l2[e].item() == (r - vp[b].cpu()).float().item()
+
+
+def test_copy_mask_permute_rows():
+    ops = _ops()
+    R, T, n = 5, 7, 12
+    x = rnd((R, T, n), 60).to(DEV)
+    y = torch.empty(T, R, n, device=DEV)
+    ops.permute_rows(x, y, R, T, n)
+    assert torch.equal(y, x.permute(1, 0, 2).contiguous())
+    z = torch.empty(R, n, device=DEV)
+    ops.copy_rows(x.data_ptr() + 4 * 2 * n, T * n, z.data_ptr(), n, R, n)
+    assert torch.equal(z, x[:, 2])
+    d = (rnd((R * T,), 61, 0, 1) < 0.5).float().to(DEV)
+    w = z.clone()
+    ops.mask_rows(w, d.data_ptr() + 4 * 3, T)
+    assert torch.equal(w, z * (1 - d.view(R, T)[:, 3:4]))
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("A,norm", [(2, True), (3, True), (3, False), (4, True), (6, False), (18, True)])
+def test_loss_fwd_bwd_vs_autograd(A, norm):
+    ops = _ops()
+    N, NG = 301, 301
+    heads = rnd((N, A + 1), 70 + A, -3, 3)
+    acts = (rnd((N,), 71, 0, 1) * A).long().clamp(0, A - 1)
+    advs = rnd((N,), 72, -2, 2)
+    rets = rnd((N,), 73, -2, 2)
+    pc, vc, ec = 1.0, 0.5, 0.005
+    lg = heads[:, :A].clone().requires_grad_(True)
+    vl = heads[:, A].clone().requires_grad_(True)
+    a_n = (advs - advs.mean()) / (advs.std() + 1e-6) if norm else advs
+    lsm = F.log_softmax(lg, -1)
+    entr = -ec * (lsm * F.softmax(lg, -1)).sum(-1).mean()
+    pi_loss = pc * -(lsm[torch.arange(N), acts] * a_n).mean()
+    val_loss = vc * F.mse_loss(vl, rets)
+    (pi_loss + val_loss - entr).backward()
+    hd = heads.to(DEV)
+    dh = torch.zeros(N, A + 1, device=DEV)
+    sums = torch.zeros(3, dtype=torch.float64, device=DEV)
+    adv_sums = None
+    if norm:
+        adv_sums = torch.zeros(2, dtype=torch.float64, device=DEV)
+        ops.moments(advs.to(DEV), adv_sums)
+    ops.loss_fwd_bwd(hd[:, :A], hd[:, A], acts.to(DEV), advs.to(DEV), rets.to(DEV), adv_sums, NG, pc, vc, ec,
+                     dh[:, :A], dh[:, A], sums)
+    s = sums.cpu()
+    assert pc * -(s[0] / NG) == pytest.approx(pi_loss.item(), rel=1e-5, abs=1e-7)
+    assert vc * (s[1] / NG) == pytest.approx(val_loss.item(), rel=1e-5, abs=1e-7)
+    assert -ec * (s[2] / NG) == pytest.approx(entr.item(), rel=1e-5, abs=1e-8)
+    close("dlogits", dh[:, :A], lg.grad, 1e-8, 1e-4)
+    close("dvals", dh[:, A], vl.grad, 1e-9, 1e-5)
+
+
+# ------------------------------------------------------------------ GEMM
+def _gemm_ref(A, B, tA, tB):
+    a = A.double().t() if tA else A.double()
+    b = B.double().t() if tB else B.double()
+    return a @ b
+
+
+@pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 3, 7), (128, 128, 16), (130, 257, 100), (256, 256, 2592), (300, 4, 256),
+                                   (3, 256, 1000)])
+def test_gemm_f32(tA, tB, M, N, K):
+    ops = _ops()
+    A = rnd((K, M) if tA else (M, K), 80)
+    B = rnd((N, K) if tB else (K, N), 81)
+    want = _gemm_ref(A, B, tA, tB)
+    scale = 1e-6 * K ** 0.5 + 1e-7
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(tA, tB, M, N, K, Ad.data_ptr(), A.shape[1], Bd.data_ptr(), B.shape[1], C.data_ptr(), N)
+    close("plain", C, want, 5 * scale, 1e-5)
+    # epilogue: bias + relu + mask + accumulate, split-K
+    bias = rnd((N,), 82).to(DEV)
+    mask = rnd((M, N), 83).to(DEV)
+    C0 = rnd((M, N), 84).to(DEV)
+    for sk in (1, 3):
+        Cx = C0.clone()
+        ws = torch.empty(max(1, ops.gemm_ws_bytes(M, N, sk) // 4), device=DEV)
+        ops.gemm(tA, tB, M, N, K, Ad.data_ptr(), A.shape[1], Bd.data_ptr(), B.shape[1], Cx.data_ptr(), N, bias=bias,
+                 relu=True, mask_ptr=mask.data_ptr(), ldmask=N, accumulate=True, splitk=sk, ws=ws)
+        ref = torch.relu(C0.cpu().double() + want + bias.cpu().double()) * (mask.cpu() > 0)
+        close(f"epilogue sk={sk}", Cx, ref, 5 * scale, 1e-5)
+
+
+def test_gemm_strided_views_and_colsum():
+    ops = _ops()
+    M, N, K = 70, 5, 33
+    X = rnd((M, K + 3), 85).to(DEV)          # lda > K
+    W = rnd((N, K), 86).to(DEV)
+    out = torch.zeros(M, N + 2, device=DEV)  # ldc > N
+    ops.gemm(0, 1, M, N, K, X.data_ptr(), K + 3, W.data_ptr(), K, out.data_ptr() + 4, N + 2)
+    close("strided", out[:, 1:N + 1], X[:, :K].cpu().double() @ W.cpu().double().t(), 1e-5, 1e-5)
+    assert (out[:, 0] == 0).all() and (out[:, N + 1] == 0).all()
+    cs = torch.empty(N + 2, device=DEV)
+    ws = torch.empty(ops.colsum_ws_bytes(N + 2) // 4, device=DEV)
+    ops.colsum(out.data_ptr(), N + 2, M, N + 2, cs, ws)
+    close("colsum", cs, out.cpu().double().sum(0), 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------ conv
+CONV_SPECS = [  # Cin, H, W, Cout, ks, stride, pad
+    (4, 84, 84, 16, 8, 4, 0), (16, 20, 20, 32, 4, 2, 0),                                              # A3CModel
+    (4, 84, 84, 16, 3, 1, 1), (16, 84, 84, 24, 3, 1, 1), (24, 84, 84, 32, 3, 2, 1), (32, 42, 42, 64, 3, 2, 1),  # ConvModel
+    (16, 84, 84, 24, 3, 2, 1), (24, 42, 42, 32, 3, 2, 1), (32, 21, 21, 48, 3, 2, 1), (48, 11, 11, 64, 3, 2, 1),  # GRUModel
+    (4, 20, 20, 16, 3, 1, 1), (8, 13, 17, 12, 3, 2, 1), (4, 9, 9, 8, 4, 2, 0), (4, 4, 4, 16, 3, 1, 1),          # small / odd
+]
+
+
+@pytest.mark.parametrize("spec", CONV_SPECS, ids=[str(s) for s in CONV_SPECS])
+def test_conv2d_fwd_bwd(spec):
+    ops = _ops()
+    Cin, H, W, Cout, ks, s, p = spec
+    B = 3
+    d = ops.conv_desc(*spec)
+    x = rnd((B, Cin, H, W), 90, 0, 1)
+    w = rnd((Cout, Cin, ks, ks), 91) / (Cin * ks * ks) ** 0.5
+    bias = rnd((Cout,), 92) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    pre = F.conv2d(xr, wr, br, stride=s, padding=p)
+    y = F.relu(pre)
+    gy = rnd(tuple(y.shape), 93)
+    gpre = gy * (pre > 0)
+    pre.backward(gpre)
+    # strided batch input (rows of a wider buffer, like states[idx*T+t])
+    xbuf = torch.zeros(B, Cin * H * W + 8, device=DEV)
+    xbuf[:, :Cin * H * W] = x.view(B, -1).to(DEV)
+    wd, bd = w.to(DEV), bias.to(DEV)
+    wf = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
+    wb = torch.empty(ops.conv_prep_floats(d, 1), device=DEV)
+    ops.conv_prep(d, 0, wd, wf)
+    ops.conv_prep(d, 1, wd, wb)
+    out = torch.full(tuple(y.shape), float("nan"), device=DEV)
+    ops.conv_fwd(d, xbuf.data_ptr(), xbuf.stride(0), wf, bd, True, out, B)
+    close("fwd", out, y, 2e-6, 1e-5)
+    # backward data (+ fused ReLU mask of the layer below: use x > 0.5 as that mask)
+    dout = gpre.contiguous().to(DEV)
+    mask = (x - 0.5).to(DEV)
+    din = torch.full((B, Cin, H, W), float("nan"), device=DEV)
+    ops.conv_bwd_data(d, dout, wb, mask, din, B)
+    close("bwd_data", din, xr.grad * (x > 0.5), 2e-6, 1e-5)
+    # backward weight + bias
+    dW = torch.full_like(wd, float("nan"))
+    db = torch.full_like(bd, float("nan"))
+    ws = torch.empty(ops.conv_bwd_weight_ws_bytes(d, B) // 4, device=DEV)
+    ops.conv_bwd_weight(d, xbuf.data_ptr(), xbuf.stride(0), dout, dW, db, B, ws)
+    close("bwd_weight", dW, wr.grad, 1e-5, 1e-5)
+    close("bwd_bias", db, br.grad, 1e-5, 1e-5)
+
+
+def test_conv2d_many_samples_persistent_grid():
+    """more tiles than workgroups: exercises the grid-stride / persistent accumulation paths"""
+    ops = _ops()
+    spec = (4, 20, 20, 16, 3, 1, 1)
+    B = 2100
+    d = ops.conv_desc(*spec)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(B, 4, 20, 20, generator=gen)
+    w = (torch.rand(16, 4, 3, 3, generator=gen) - 0.5) * 0.3
+    dout = torch.rand(B, 16, 20, 20, generator=gen) - 0.5
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(x, wr, None, stride=1, padding=1)
+    y.backward(dout)
+    xd, wd, dd = x.to(DEV), w.to(DEV), dout.to(DEV)
+    wf = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
+    ops.conv_prep(d, 0, wd, wf)
+    out = torch.empty(B, 16, 20, 20, device=DEV)
+    ops.conv_fwd(d, xd.data_ptr(), 1600, wf, None, False, out, B)
+    close("fwd", out, y, 2e-6, 1e-5)
+    dW, db = torch.empty_like(wd), torch.empty(16, device=DEV)
+    ws = torch.empty(ops.conv_bwd_weight_ws_bytes(d, B) // 4, device=DEV)
+    ops.conv_bwd_weight(d, xd.data_ptr(), 1600, dd, dW, db, B, ws)
+    close("bwd_weight", dW, wr.grad, 2e-4, 2e-5)
+    close("bwd_bias", db, dout.double().sum((0, 2, 3)), 2e-4, 2e-5)
+
+
+# ------------------------------------------------------------------ GRU gates / LayerNorm
+def test_gru_kernels_vs_autograd():
+    ops = _ops()
+    B, h = 37, 64
+    gx, gh, rhu = rnd((B, 3 * h), 100, -2, 2), rnd((B, 2 * h), 101, -2, 2), rnd((B, h), 102, -2, 2)
+    b, hin = rnd((3, 1, h), 103) * 0.1, rnd((B, h), 104)
+    t = [v.clone().requires_grad_(True) for v in (gx, gh, rhu, hin)]
+    z = torch.sigmoid(t[0][:, :h] + t[1][:, :h] + b[0])
+    r = torch.sigmoid(t[0][:, h:2 * h] + t[1][:, h:] + b[1])
+    rh = r * t[3]
+    c = torch.tanh(t[0][:, 2 * h:] + t[2] + b[2])
+    hn = z * t[3] + (1 - z) * c
+    dev = lambda v: v.detach().to(DEV).contiguous()
+    zd, rd, rhd, cd, hnd = (torch.empty(B, h, device=DEV) for _ in range(5))
+    ops.gru_gates(dev(gx), dev(gh), dev(b), dev(hin), zd, rd, rhd)
+    ops.gru_out(dev(gx), dev(rhu), dev(b), dev(hin), zd, cd, hnd)
+    close("z", zd, z); close("r", rd, r); close("rh", rhd, rh); close("c", cd, c); close("hn", hnd, hn)
+    # backward: d(hn) given, with d(rhu) == dc_pre flowing back through rh (rh_u = rh Wh2 is outside: use identity)
+    g = rnd((B, h), 105)
+    dcp, dz, dh = (torch.empty(B, h, device=DEV) for _ in range(3))
+    ops.gru_out_bwd(dev(g), dev(hin), zd, cd, dcp, dz, dh)
+    close("dc_pre", dcp, g * (1 - z) * (1 - c * c))
+    d_rh = rnd((B, h), 106)
+    dzp, drp = torch.empty(B, h, device=DEV), torch.empty(B, h, device=DEV)
+    ops.gru_gates_bwd(dev(d_rh), dz, dev(hin), zd, rd, dzp, drp, dh)
+    close("dz_pre", dzp, g * (hin - c) * z * (1 - z))
+    close("dr_pre", drp, d_rh * hin * r * (1 - r))
+    close("dh", dh, g * z + d_rh * r)
+
+
+def test_layernorm_vs_torch():
+    ops = _ops()
+    rows, n = 53, 200
+    x, w, b = rnd((rows, n), 110, -2, 2), 1 + 0.1 * rnd((n,), 111), 0.1 * rnd((n,), 112)
+    xr, wr, br = (v.clone().requires_grad_(True) for v in (x, w, b))
+    y = F.layer_norm(xr, (n,), wr, br)
+    g = rnd((rows, n), 113)
+    y.backward(g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    yd, mean, rstd = torch.empty(rows, n, device=DEV), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(xd, wd, bd, yd, mean, rstd)
+    close("ln fwd", yd, y, 2e-6, 1e-5)
+    dx, dwr = torch.empty(rows, n, device=DEV), torch.empty(rows, n, device=DEV)
+    ops.layernorm_bwd(g.to(DEV), xd, wd, mean, rstd, dx, dwr)
+    close("ln dx", dx, xr.grad, 2e-6, 1e-5)
+    close("ln dw", dwr.sum(0), wr.grad, 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------ clip + optimiser
+@pytest.mark.parametrize("kind", ["RMSprop", "Adam"])
+def test_clip_optimizer_vs_torch(kind):
+    ops = _ops()
+    n = 10007
+    p0 = rnd((n,), 120)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = getattr(torch.optim, kind)([ref_p], lr=1e-4)
+    pd = torch.zeros(n + 1, device=DEV)[:n]           # keep 16 B alignment of the base
+    pd.copy_(p0)
+    gd = torch.zeros(n, device=DEV)
+    s1, s2 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sumsq = torch.zeros(1, dtype=torch.float64, device=DEV)
+    norm = torch.zeros(1, device=DEV)
+    for step in range(1, 4):
+        g = rnd((n,), 121 + step) * (0.02 if step == 2 else 0.001)     # step 2 clips, others do not
+        ref_p.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([ref_p], 0.5)
+        opt.step()
+        gd.copy_(g)
+        ops.gradnorm_sq(gd, sumsq)
+        if kind == "RMSprop":
+            ops.clip_rmsprop(pd, gd, s1, sumsq, 0.5, 1e-4, 0.99, 1e-8, norm)
+        else:
+            ops.clip_adam(pd, gd, s1, s2, sumsq, 0.5, 1e-4, 0.9, 0.999, 1e-8, step, norm)
+        assert norm.item() == pytest.approx(float(tn), rel=2e-6)
+        close(f"clipped grad step {step}", gd, ref_p.grad, 1e-10, 2e-6)
+        close(f"params step {step}", pd, ref_p.detach(), 2e-7, 1e-6)

@@ -1,0 +1,260 @@
+"""-m gpu: model classes, Runner and Updater of a2c_amd (HIP path through the C ABI) against
+(1) the outputs recorded from the reference (tests/golden/*.npz) and (2) the CPU oracle on the
+same closed-form inputs.  fp32 tolerance 1e-5 (north star), stated per assertion."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import a2c_oracle as O  # noqa: E402
+from cases import (MODEL_CASES, ROLLOUT_CASES, UPDATE_CASES, hashf, base_hyps, synth_shared,  # noqa: E402
+                   sample_idx)
+from test_gpu_kernels import close  # noqa: E402
+
+DEV = "cuda"
+torch.set_num_threads(4)
+
+
+def make_net(kind, ss, A, h):
+    import a2c_amd
+    net = getattr(a2c_amd.models, kind)(list(ss), A, h_size=h, bnorm=False)
+    sd = O.formula_state_dict(kind, ss, A, h)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    net.load_state_dict(sd)
+    shapes, _ = O.param_shapes(kind, ss, A, h)
+    prim = [k for k in shapes if "running" not in k and "num_batches" not in k]
+    assert [n for n, _ in net.named_parameters()] == prim      # optimiser index order == reference
+    return net
+
+
+@pytest.mark.parametrize("i", range(len(MODEL_CASES)), ids=[f"{c[0]}-{c[1]}" for c in MODEL_CASES])
+def test_model_forward_golden_and_grads(golden, i):
+    g = golden["g4_model_forward"]
+    kind, ss, A, h, B = MODEL_CASES[i]
+    net = make_net(kind, ss, A, h)
+    assert sum(p.numel() for p in net.parameters()) == int(g[f"nparams{i}"])
+    x = torch.from_numpy(O.formula_frames(B, ss, seed=400 + i, binary=(len(ss) == 3 and ss[-1] == 84)))
+    hin = torch.from_numpy(hashf(B * h, 450 + i, -1, 1).reshape(B, h)) if net.is_recurrent else None
+    with torch.no_grad():
+        out = net(x, hin) if net.is_recurrent else net(x)
+    close("val", out[0], g[f"val{i}"], 1e-5, 1e-5)
+    close("pi", out[1], g[f"pi{i}"], 1e-5, 1e-5)
+    if net.is_recurrent:
+        close("h", out[2], g[f"h{i}"], 1e-5, 1e-5)
+    # gradients through the public autograd bridge vs the oracle (torch CPU autograd)
+    onet = O.OracleNet(kind, ss, A, h)
+    gv = torch.from_numpy(hashf(B, 460 + i, -1, 1).reshape(B, 1))
+    gp = torch.from_numpy(hashf(B * A, 470 + i, -1, 1).reshape(B, A))
+    gh = torch.from_numpy(hashf(B * h, 480 + i, -1, 1).reshape(B, h))
+    if net.is_recurrent:
+        hin_o = hin.clone().requires_grad_(True)
+        v, p, hn = onet(x, hin_o)
+        ((v * gv).sum() + (p * gp).sum() + (hn * gh).sum()).backward()
+    else:
+        v, p = onet(x)
+        ((v * gv).sum() + (p * gp).sum()).backward()
+    net.req_grads(True)
+    for q in net.parameters():
+        q.grad = None
+    if net.is_recurrent:
+        hin_d = hin.to(DEV).requires_grad_(True)
+        v2, p2, h2 = net(x, hin_d)
+        ((v2 * gv.to(DEV)).sum() + (p2 * gp.to(DEV)).sum() + (h2 * gh.to(DEV)).sum()).backward()
+        close("d h_in", hin_d.grad, hin_o.grad, 1e-6, 1e-4)
+    else:
+        v2, p2 = net(x)
+        ((v2 * gv.to(DEV)).sum() + (p2 * gp.to(DEV)).sum()).backward()
+    for (n, q), (n2, q2) in zip(net.named_parameters(), onet.named_parameters()):
+        assert n == n2
+        if q2.grad is None:
+            assert q.grad is None or float(q.grad.abs().max()) == 0.0, n
+            continue
+        scale = float(q2.grad.abs().max()) + 1e-12
+        close(f"grad {n}", q.grad, q2.grad, 2e-5 * scale, 2e-5)
+
+
+def test_state_dict_roundtrip_and_alias_keys():
+    net = make_net("A3CModel", (4, 84, 84), 3, 256)
+    net._ensure_device()
+    sd = net.state_dict()
+    for k in ("conv1.0.weight", "convs.0.0.weight", "features.0.0.weight"):
+        assert k in sd
+    assert sd["conv1.0.weight"].data_ptr() == sd["features.0.0.weight"].data_ptr()
+    net2 = make_net("A3CModel", (4, 84, 84), 3, 256)
+    net2.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    x = torch.from_numpy(O.formula_frames(2, (4, 84, 84), seed=1, binary=True))
+    with torch.no_grad():
+        a, b = net(x), net2(x)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_no_cpu_fallback():
+    from a2c_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.discount_rows(torch.zeros(4), torch.zeros(4), 0.9, 1, 4)
+
+
+# ------------------------------------------------------------------ Runner
+def _fake_pool(ekws):
+    from a2c_amd.runner import HostEnvPool
+    return HostEnvPool([O.FakeEnv(**k) for k in ekws])
+
+
+def _datas(N, ss, recurrent, h=256, actions_on_host=True):
+    D = dict(states=torch.zeros(N, *ss, device=DEV), deltas=torch.zeros(N, device=DEV),
+             rewards=torch.zeros(N, device=DEV), dones=torch.zeros(N, device=DEV),
+             actions=torch.zeros(N).long() if actions_on_host else torch.zeros(N, dtype=torch.int64, device=DEV))
+    if recurrent:
+        D["h_states"] = torch.zeros(N, h, device=DEV)
+    return D
+
+
+@pytest.mark.parametrize("case", ROLLOUT_CASES, ids=[c[0] for c in ROLLOUT_CASES])
+def test_runner_rollout_golden(golden, case):
+    """one env playing consecutive slots, against the trace recorded from the reference Runner"""
+    import queue
+    from a2c_amd.runner import Runner
+    g = golden["g5_rollout"]
+    name, kind, env_type, T, n_slots, ekw, A = case
+    hyps = base_hyps(env_type=env_type, n_tsteps=T, n_rollouts=n_slots, action_shift=1 if "Pong" in env_type else 0,
+                     n_envs=1)
+    ss = (4, 84, 84)
+    net = make_net(kind, ss, A, 256)
+    N = T * n_slots
+    D = _datas(N, ss, net.is_recurrent)
+    us = torch.from_numpy(g[f"{name}_uniforms"]).to(DEV)
+    cnt = [0]
+
+    def uniform_fn(t, B, env0):
+        u = us[cnt[0]:cnt[0] + 1]
+        cnt[0] += 1
+        return u
+    rq = queue.Queue(1)
+    rq.put(-1)
+    r = Runner(D, hyps, None, None, rq, env_pool=_fake_pool([ekw]), uniform_fn=uniform_fn)
+    for idx in range(n_slots):
+        r.rollout(net, idx, hyps)
+    torch.cuda.synchronize()
+    assert np.array_equal(D["actions"].numpy(), g[f"{name}_actions"])
+    assert np.array_equal(D["dones"].cpu().numpy(), g[f"{name}_dones"])
+    close("rewards", D["rewards"], g[f"{name}_rewards"], 1e-5, 1e-5)
+    close("deltas", D["deltas"], g[f"{name}_deltas"], 1e-5, 1e-5)
+    fs = D["states"].reshape(N, 4, -1).double().sum(2).cpu().numpy()
+    assert np.array_equal(fs, g[f"{name}_state_frame_sums"])
+    if net.is_recurrent:
+        close("h_states", D["h_states"], g[f"{name}_h_states"], 1e-5, 1e-5)
+        close("h_bookmark", r.h, g[f"{name}_h_bookmark"], 1e-5, 1e-5)
+    assert abs(rq.get() - float(g[f"{name}_avg_rew"])) < 1e-9
+    assert float(r.bookmark.double().sum()) == float(g[f"{name}_bookmark_sum"])
+
+
+@pytest.mark.parametrize("kind,dev_actions", [("A3CModel", False), ("GRUModel", True)])
+def test_runner_batched_vs_oracle(kind, dev_actions):
+    """B envs in lock-step (one batched forward per step) == B independent batch-1 oracle runners"""
+    from a2c_amd.runner import Runner
+    B, T, A, ss = 5, 7, 4, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=3 + j % 3, done_period=5 + 2 * j) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0" if kind == "A3CModel" else "FakeBreakout", n_tsteps=T, n_rollouts=2 * B,
+                     action_shift=0, n_envs=B)
+    net = make_net(kind, ss, A, 256)
+    onet = O.OracleNet(kind, ss, A, 256)
+    N = 2 * B * T
+    D = _datas(N, ss, net.is_recurrent, actions_on_host=not dev_actions)
+    us = torch.from_numpy(hashf(2 * T * B, 900, 0, 1).reshape(2, T, B))
+    usd = us.to(DEV)
+    rnd_ = [0]
+    r = Runner(D, hyps, None, None, None, env_pool=_fake_pool(ekws),
+               uniform_fn=lambda t, Bn, env0: usd[rnd_[0], t, env0:env0 + Bn].contiguous())
+    # oracle: env j plays slot j, then slot B+j
+    Do = dict(states=torch.zeros(N, *ss), deltas=torch.zeros(N), rewards=torch.zeros(N), dones=torch.zeros(N),
+              actions=torch.zeros(N).long())
+    if net.is_recurrent:
+        Do["h_states"] = torch.zeros(N, 256)
+    for j in range(B):
+        seq = iter([float(us[k, t, j]) for k in range(2) for t in range(T)])
+        sr = O.SlotRunner(O.FakeEnv(**ekws[j]), Do, hyps, uniform_fn=lambda seq=seq: next(seq))
+        sr.start(onet)
+        sr.rollout(onet, j)
+        sr.rollout(onet, B + j)
+    for rnd_[0] in range(2):
+        r.rollout(net, list(range(rnd_[0] * B, (rnd_[0] + 1) * B)), hyps)
+    torch.cuda.synchronize()
+    assert torch.equal(D["actions"].cpu(), Do["actions"])
+    assert torch.equal(D["dones"].cpu(), Do["dones"])
+    assert torch.equal(D["states"].cpu(), Do["states"])
+    close("rewards", D["rewards"], Do["rewards"], 1e-5, 1e-5)
+    close("deltas", D["deltas"], Do["deltas"], 1e-5, 1e-5)
+    if net.is_recurrent:
+        close("h_states", D["h_states"], Do["h_states"], 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------ Updater
+@pytest.mark.parametrize("case", UPDATE_CASES, ids=[c[0] for c in UPDATE_CASES])
+def test_updater_golden(golden, case):
+    from a2c_amd.updater import Updater
+    g = golden["g6_update"]
+    name, kind, ss, A, h, R_, T, opt, norm_advs, nstep, use_bptt, n_upd = case
+    net = make_net(kind, ss, A, h)
+    hyps = base_hyps(n_tsteps=T, n_rollouts=R_, optim_type=opt, norm_advs=norm_advs, use_nstep_rets=nstep,
+                     use_bptt=use_bptt, h_size=h)
+    upd = Updater(net, hyps)
+    assert [n for n, _ in net.named_parameters()] == list(g[name + "_param_names"])
+    for u in range(n_upd):
+        D = synth_shared(kind, ss, A, h, R_, T, seed=700 + 10 * u, recurrent=net.is_recurrent)
+        D = {k: (v.to(DEV) if k != "actions" else v) for k, v in D.items()}      # actions stay on the host
+        info = upd.update_model(D)
+        pre = f"{name}_u{u}_"
+        for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy", "GradNorm"):
+            assert info[k] == pytest.approx(float(g[pre + k]), rel=3e-5, abs=2e-6), (k, info[k], float(g[pre + k]))
+        b = upd._bufs
+        assert np.array_equal(b["advs"].cpu().numpy(), g[pre + "advs_raw"])          # scans are bit-exact
+        if not nstep:
+            assert np.array_equal(b["rets"].cpu().numpy(), g[pre + "returns"])
+        gnorm = float(g[pre + "GradNorm"])
+        for j, (n, p) in enumerate(net.named_parameters()):
+            idx = torch.from_numpy(sample_idx(p.numel()))
+            has = bool(g[pre + "has_grad"][j])
+            assert (n not in net._unused_params) == has, n
+            if has:
+                gr = net.G(n)
+                want_n = float(g[pre + "grad_norms"][j])
+                assert float(gr.double().norm()) == pytest.approx(want_n, rel=2e-4, abs=1e-6 * gnorm + 1e-9), n
+                close(f"grad samples {n}", gr.reshape(-1)[idx.to(DEV)], g[pre + "grad_samples"][j],
+                      2e-5 * max(want_n / max(p.numel(), 1) ** 0.5, 1e-7) + 1e-9, 2e-4)
+            assert float(p.detach().double().norm()) == pytest.approx(float(g[pre + "param_norms"][j]), rel=1e-5), n
+            # a first RMSprop/Adam step moves every weight by ~lr*10 / ~lr regardless of |g|, and the
+            # direction of a noise-level gradient is not pinned by fp32: tolerance = 2 steps of lr*10
+            close(f"param samples {n}", p.detach().reshape(-1)[idx.to(DEV)], g[pre + "param_samples"][j], 3e-5, 1e-5)
+
+
+def test_updater_optimizer_state_dict_matches_torch_layout():
+    from a2c_amd.updater import Updater
+    kind, ss, A, h = "A3CModel", (4, 84, 84), 3, 256
+    for opt in ("RMSprop", "Adam"):
+        net = make_net(kind, ss, A, h)
+        hyps = base_hyps(n_tsteps=4, n_rollouts=2, optim_type=opt)
+        upd = Updater(net, hyps)
+        D = synth_shared(kind, ss, A, h, 2, 4, seed=700, recurrent=False)
+        upd.update_model({k: v.to(DEV) for k, v in D.items()})
+        sd = upd.optim.state_dict()
+        onet = O.OracleNet(kind, ss, A, h)
+        oupd = O.OracleUpdater(onet, hyps)
+        oupd.update_model(D)
+        ref = oupd.optim.state_dict()
+        assert sd["param_groups"][0]["params"] == ref["param_groups"][0]["params"]
+        assert set(sd["state"].keys()) == set(ref["state"].keys())       # emb_bnorm has no state
+        for k in ref["state"]:
+            assert set(ref["state"][k].keys()) == set(sd["state"][k].keys())
+            for s in ref["state"][k]:
+                if s == "step":
+                    assert float(sd["state"][k][s]) == float(ref["state"][k][s])
+                else:
+                    close(f"{opt} state {k}.{s}", sd["state"][k][s], ref["state"][k][s], 1e-9, 2e-3)
+        # reload into a fresh updater and into torch itself
+        upd2 = Updater(make_net(kind, ss, A, h), hyps)
+        upd2.optim.load_state_dict(sd)
+        assert upd2.optim._steps == 1
+        getattr(torch.optim, opt)(onet.parameters(), lr=1e-4).load_state_dict(
+            {"state": {k: {s: (v.cpu() if torch.is_tensor(v) else v) for s, v in st.items()}
+                       for k, st in sd["state"].items()}, "param_groups": sd["param_groups"]})

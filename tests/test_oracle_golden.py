@@ -130,3 +130,36 @@ def test_g6_update(golden, case):
                 np.testing.assert_allclose(gr.reshape(-1)[idx].numpy(), g[pre + "grad_samples"][j], rtol=1e-4, atol=1e-7, err_msg=n)
             assert float(p.detach().double().norm()) == pytest.approx(float(g[pre + "param_norms"][j]), rel=1e-6), n
             np.testing.assert_allclose(p.detach().reshape(-1)[idx].numpy(), g[pre + "param_samples"][j], rtol=0, atol=2e-5, err_msg=n)
+
+
+def _c_oracle():
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle")])
+    lib = ctypes.CDLL(os.path.join(root, "oracle", "_ref", "liba2c_oracle.so"))
+    lib.oracle_td_delta.restype = ctypes.c_float
+    lib.oracle_td_delta.argtypes = [ctypes.c_float] * 5
+    return lib, ctypes
+
+
+def test_c_oracle_matches_golden(golden):
+    """the C part of the oracle (oracle/a2c_oracle.c) on the same recorded reference outputs"""
+    lib, ct = _c_oracle()
+    fp = lambda a: a.ctypes.data_as(ct.c_void_p)
+    g = golden["g1_discount"]
+    for i in range(int(g["n_cases"])):
+        x, d, y = np.ascontiguousarray(g[f"x{i}"]), np.ascontiguousarray(g[f"d{i}"]), g[f"y{i}"]
+        out = np.empty_like(x)
+        lib.oracle_discount(fp(x), fp(d), fp(out), ct.c_int64(len(x)), ct.c_float(float(g[f"g{i}"])))
+        assert np.array_equal(out, y), i
+    g = golden["g2_sample_action"]
+    for i in range(int(g["n_cases"])):
+        p, u = np.ascontiguousarray(g[f"p{i}"]), np.ascontiguousarray(g[f"u{i}"])
+        out = np.empty(p.shape[0], np.float32)
+        lib.oracle_sample_action(fp(p), fp(u), fp(out), ct.c_int64(p.shape[0]), ct.c_int(p.shape[1]))
+        assert np.array_equal(out, g[f"a{i}"].reshape(-1)), i
+    t = torch.tensor
+    want = (t(0.5) + t(0.99) * t(0.3) * (1 - t(0.0)) - t(0.2)).item()
+    assert lib.oracle_td_delta(0.5, 0.99, 0.3, 0.0, 0.2) == want

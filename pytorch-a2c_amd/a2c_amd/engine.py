@@ -15,18 +15,24 @@ class Arena:
     parameter is re-pointed to a view of the arena, so ``state_dict`` / ``load_state_dict`` /
     checkpoints keep working unchanged."""
 
-    def __init__(self, named_params, trainable_names, device):
+    def __init__(self, named_params, trainable_names, device, packed_after=()):
+        """``packed_after``: names that must start IMMEDIATELY after the previous tensor (no
+        alignment padding), so that e.g. [pi.bias | value.bias] is one contiguous vector."""
         train = [(n, p) for n, p in named_params if n in trainable_names]
         rest = [(n, p) for n, p in named_params if n not in trainable_names]
         self.offsets = {}
         off = 0
-        for n, p in train:
-            self.offsets[n] = (off, p.numel(), tuple(p.shape))
-            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-        self.n_train = off
-        for n, p in rest:
-            self.offsets[n] = (off, p.numel(), tuple(p.shape))
-            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        end = 0                      # end of the previous tensor (unpadded)
+        for group in (train, rest):
+            for n, p in group:
+                if n in packed_after:
+                    off = end
+                self.offsets[n] = (off, p.numel(), tuple(p.shape))
+                end = off + p.numel()
+                off = (end + ALIGN - 1) // ALIGN * ALIGN
+            if group is train:
+                self.n_train = off
+                end = off
         self.size = off
         self.params = torch.zeros(off, dtype=torch.float32, device=device)
         self.grads = torch.zeros(off, dtype=torch.float32, device=device)

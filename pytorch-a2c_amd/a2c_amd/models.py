@@ -34,6 +34,7 @@ class _HipNet(nn.Module):
 
     is_recurrent = False
     _unused_params = ()          # parameter names that never receive a gradient
+    _packed_after = ()           # parameter names laid out right behind their predecessor in the arena
 
     # ------------------------------------------------------------------ arena / device
     def _post_init(self):
@@ -56,7 +57,7 @@ class _HipNet(nn.Module):
             b.data = b.data.to(dev)
         order = self._arena_order()
         trainable = [n for n in order if n not in self._unused_params]
-        self._arena = Arena([(n, named[n]) for n in order], set(trainable), dev)
+        self._arena = Arena([(n, named[n]) for n in order], set(trainable), dev, set(self._packed_after))
         self._dev = dev
         self._dirty = True
         self._bind_params()
@@ -191,6 +192,7 @@ class _NetFunction(torch.autograd.Function):
 class A3CModel(_HipNet):
     """models.py:7-175."""
     _unused_params = ("emb_bnorm.weight", "emb_bnorm.bias")
+    _packed_after = ("value.weight", "value.bias")     # [pi.weight; value.weight], [pi.bias | value.bias]
 
     def __init__(self, input_space, output_space, h_size=256, bnorm=False, is_discrete=True, **kwargs):
         super().__init__()
@@ -309,6 +311,7 @@ class _ConvStackNet(_HipNet):
 
 class ConvModel(_ConvStackNet):
     """models.py:177-365."""
+    _packed_after = ("value.0.weight", "value.0.bias")
     SPECS = [(16, 3, 1, 1), (24, 3, 1, 1), (32, 3, 2, 1), (64, 3, 2, 1)]
     CONV_H = 2000
 
@@ -548,6 +551,7 @@ class _LNValueMixin:
 # ====================================================================== GRUModel
 class GRUModel(_ConvStackNet, _GruMixin):
     """models.py:546-713."""
+    _packed_after = ("value.weight", "value.bias")
     SPECS = [(16, 3, 1, 1), (24, 3, 2, 1), (32, 3, 2, 1), (48, 3, 2, 1), (64, 3, 2, 1)]
 
     def __init__(self, input_space, output_space, h_size=288, bnorm=False, is_discrete=True, **kwargs):

@@ -358,8 +358,9 @@ def test_conv2d_fwd_bwd(spec):
     db = torch.full_like(bd, float("nan"))
     ws = torch.empty(ops.conv_bwd_weight_ws_bytes(d, B) // 4, device=DEV)
     ops.conv_bwd_weight(d, xbuf.data_ptr(), xbuf.stride(0), dout, dW, db, B, ws)
-    close("bwd_weight", dW, wr.grad, 1e-5, 1e-5)
-    close("bwd_bias", db, br.grad, 1e-5, 1e-5)
+    # sums over B*OH*OW (up to 21k) fp32 terms: tolerance 1e-5 of the tensor's scale
+    close("bwd_weight", dW, wr.grad, 1e-5 * float(wr.grad.abs().max()), 1e-5)
+    close("bwd_bias", db, br.grad, 1e-5 * float(br.grad.abs().max()), 1e-5)
 
 
 def test_conv2d_many_samples_persistent_grid():
@@ -372,9 +373,9 @@ def test_conv2d_many_samples_persistent_grid():
     x = torch.rand(B, 4, 20, 20, generator=gen)
     w = (torch.rand(16, 4, 3, 3, generator=gen) - 0.5) * 0.3
     dout = torch.rand(B, 16, 20, 20, generator=gen) - 0.5
-    wr = w.clone().requires_grad_(True)
-    y = F.conv2d(x, wr, None, stride=1, padding=1)
-    y.backward(dout)
+    wr = w.double().requires_grad_(True)          # fp64 reference: 840k-term sums
+    y = F.conv2d(x.double(), wr, None, stride=1, padding=1)
+    y.backward(dout.double())
     xd, wd, dd = x.to(DEV), w.to(DEV), dout.to(DEV)
     wf = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
     ops.conv_prep(d, 0, wd, wf)
@@ -384,8 +385,8 @@ def test_conv2d_many_samples_persistent_grid():
     dW, db = torch.empty_like(wd), torch.empty(16, device=DEV)
     ws = torch.empty(ops.conv_bwd_weight_ws_bytes(d, B) // 4, device=DEV)
     ops.conv_bwd_weight(d, xd.data_ptr(), 1600, dd, dW, db, B, ws)
-    close("bwd_weight", dW, wr.grad, 2e-4, 2e-5)
-    close("bwd_bias", db, dout.double().sum((0, 2, 3)), 2e-4, 2e-5)
+    close("bwd_weight", dW, wr.grad, 1e-5 * float(wr.grad.abs().max()), 1e-5)
+    close("bwd_bias", db, dout.double().sum((0, 2, 3)), 1e-5 * float(dout.double().sum((0, 2, 3)).abs().max()), 1e-5)
 
 
 # ------------------------------------------------------------------ GRU gates / LayerNorm

@@ -66,7 +66,8 @@ class Arena:
 class ConvLayer:
     """One nn.Conv2d(+ReLU) block of a model: descriptor, matrix-core weight fragments."""
 
-    def __init__(self, Cin, H, W, Cout, ks, stride, pad, need_bwd_data):
+    def __init__(self, Cin, H, W, Cout, ks, stride, pad, need_bwd_data, name="conv"):
+        self.name = name
         self.d = ops.conv_desc(Cin, H, W, Cout, ks, stride, pad)
         self.need_bwd_data = need_bwd_data
         self.out_shape = (Cout, self.d.OH, self.d.OW)
@@ -83,14 +84,17 @@ class ConvLayer:
             ops.conv_prep(self.d, 1, weight, self.wb, st)
 
     def fwd(self, in_ptr, in_bstride, bias, out, B, st, relu=True):
-        ops.conv_fwd(self.d, in_ptr, in_bstride, self.wf, bias, relu, out, B, st)
+        with ops.span(self.name + ".fwd"):
+            ops.conv_fwd(self.d, in_ptr, in_bstride, self.wf, bias, relu, out, B, st)
 
     def bwd_weight(self, in_ptr, in_bstride, dout, dW, db, B, ws, st):
         buf = ws.bytes("conv_wgrad_ws", ops.conv_bwd_weight_ws_bytes(self.d, B))
-        ops.conv_bwd_weight(self.d, in_ptr, in_bstride, dout, dW, db, B, buf, st)
+        with ops.span(self.name + ".bwd_weight"):
+            ops.conv_bwd_weight(self.d, in_ptr, in_bstride, dout, dW, db, B, buf, st)
 
     def bwd_data(self, dout, mask, din, B, st):
-        ops.conv_bwd_data(self.d, dout, self.wb, mask, din, B, st)
+        with ops.span(self.name + ".bwd_data"):
+            ops.conv_bwd_data(self.d, dout, self.wb, mask, din, B, st)
 
 
 def linear_fwd(ws, x_ptr, ldx, W, b, out, M, st, relu=False):
@@ -98,8 +102,9 @@ def linear_fwd(ws, x_ptr, ldx, W, b, out, M, st, relu=False):
     N, K = W.shape
     sk = ops.pick_splitk(M, N, K)
     buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(M, N, sk)) if sk > 1 else None
-    ops.gemm(0, 1, M, N, K, x_ptr, ldx, W.data_ptr(), K, out.data_ptr(), out.stride(0), bias=b, relu=relu,
-             splitk=sk, ws=buf, st=st)
+    with ops.span(f"linear.fwd {N}x{K}"):
+        ops.gemm(0, 1, M, N, K, x_ptr, ldx, W.data_ptr(), K, out.data_ptr(), out.stride(0), bias=b, relu=relu,
+                 splitk=sk, ws=buf, st=st)
 
 
 def linear_bwd_data(ws, dy, W, dx, M, st, mask=None, n_cols=None):
@@ -107,8 +112,9 @@ def linear_bwd_data(ws, dy, W, dx, M, st, mask=None, n_cols=None):
     derivative of the producer of that input fused in."""
     N, K = W.shape
     n = N if n_cols is None else n_cols
-    ops.gemm(0, 0, M, K, n, dy.data_ptr(), dy.stride(0), W.data_ptr(), K, dx.data_ptr(), dx.stride(0),
-             mask_ptr=0 if mask is None else mask.data_ptr(), ldmask=0 if mask is None else K, st=st)
+    with ops.span(f"linear.bwd_data {N}x{K}"):
+        ops.gemm(0, 0, M, K, n, dy.data_ptr(), dy.stride(0), W.data_ptr(), K, dx.data_ptr(), dx.stride(0),
+                 mask_ptr=0 if mask is None else mask.data_ptr(), ldmask=0 if mask is None else K, st=st)
 
 
 def linear_bwd_weight(ws, dy, x_ptr, ldx, dW, db, M, st):
@@ -116,7 +122,8 @@ def linear_bwd_weight(ws, dy, x_ptr, ldx, dW, db, M, st):
     N, K = dW.shape
     sk = ops.pick_splitk(N, K, M)
     buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(N, K, sk)) if sk > 1 else None
-    ops.gemm(1, 0, N, K, M, dy.data_ptr(), dy.stride(0), x_ptr, ldx, dW.data_ptr(), K, splitk=sk, ws=buf, st=st)
+    with ops.span(f"linear.bwd_weight {N}x{K}"):
+        ops.gemm(1, 0, N, K, M, dy.data_ptr(), dy.stride(0), x_ptr, ldx, dW.data_ptr(), K, splitk=sk, ws=buf, st=st)
     if db is not None:
         cs = ws.bytes("colsum_ws", ops.colsum_ws_bytes(N))
         ops.colsum(dy.data_ptr(), dy.stride(0), M, N, db, cs, st)

@@ -207,9 +207,9 @@ class A3CModel(_HipNet):
         self.conv2 = _conv_block(16, 32, 4, 2, 0)
         self.convs.append(self.conv2)
         self.features = nn.Sequential(*self.convs)
-        self._c1 = ConvLayer(C, H, W, 16, 8, 4, 0, need_bwd_data=False)
+        self._c1 = ConvLayer(C, H, W, 16, 8, 4, 0, need_bwd_data=False, name="conv1")
         _, h1, w1 = self._c1.out_shape
-        self._c2 = ConvLayer(16, h1, w1, 32, 4, 2, 0, need_bwd_data=True)
+        self._c2 = ConvLayer(16, h1, w1, 32, 4, 2, 0, need_bwd_data=True, name="conv2")
         self.flat_size = int(np.prod(self._c2.out_shape))
         self.proj_matrx = nn.Linear(self.flat_size, h_size)
         self.emb_bnorm = nn.BatchNorm1d(h_size)
@@ -274,7 +274,7 @@ class _ConvStackNet(_HipNet):
         self._cl = []
         for i, (co, ks, s, p) in enumerate(specs):
             self.convs.append(_conv_block(C, co, ks, s, p))
-            layer = ConvLayer(C, H, W, co, ks, s, p, need_bwd_data=(i > 0))
+            layer = ConvLayer(C, H, W, co, ks, s, p, need_bwd_data=(i > 0), name=f"conv{i+1}")
             self._cl.append(layer)
             C, H, W = layer.out_shape
         self.features = nn.Sequential(*self.convs)

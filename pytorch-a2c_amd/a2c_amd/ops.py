@@ -37,6 +37,57 @@ def _chk(t, name, dtype=_F32, contig=True):
         raise ValueError(f"a2c_amd: `{name}` must be contiguous")
 
 
+class KernelTimers:
+    """Optional HIP-event timing of named launch sites, recorded on the stream the kernels are
+    launched on (bench.py's roofline figures).  Disabled (None) unless a caller installs one."""
+
+    def __init__(self):
+        self.events = {}
+
+    def span(self, name):
+        return _Span(self, name)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, pairs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = dict(launches=len(ms), avg_ms=sum(ms) / max(len(ms), 1), total_ms=sum(ms))
+        return out
+
+
+class _Span:
+    def __init__(self, timers, name):
+        self.t, self.name = timers, name
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.t.events.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
+class _NoSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+TIMERS = None
+_NOSPAN = _NoSpan()
+
+
+def span(name):
+    return TIMERS.span(name) if TIMERS is not None else _NOSPAN
+
+
 class Workspace:
     """Named, persistent device buffers (no allocation inside steady-state steps, so the
     launch sequences are hipGraph-capturable and pointers are stable across updates)."""

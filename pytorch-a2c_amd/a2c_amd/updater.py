@@ -72,8 +72,9 @@ class Updater:
         advs, rets, stats = b["advs"], b["rets"], b["stats"]
 
         # advantages (gamma*lambda) and discounted returns (gamma) in one pass (updater.py:70-71, 86-88)
-        ops.gae_returns(deltas, rewards, dones, hyps["gamma"] * hyps["lambda_"], hyps["gamma"], R, T, advs, rets,
-                        err=b["err"], st=st)
+        with ops.span("gae_returns_scan"):
+            ops.gae_returns(deltas, rewards, dones, hyps["gamma"] * hyps["lambda_"], hyps["gamma"], R, T, advs, rets,
+                            err=b["err"], st=st)
 
         # forward pass (updater.py:73-80)
         recurrent = "h_states" in shared_data
@@ -117,7 +118,8 @@ class Updater:
             sh.allreduce_(stats[2:5])
 
         # clip_grad_norm_ + optimiser step (updater.py:129-132), fused
-        self.optim.step(max_norm=hyps["max_norm"], st=st)
+        with ops.span("clip_optimizer"):
+            self.optim.step(max_norm=hyps["max_norm"], st=st)
         self.optim.zero_grad()
 
         # five scalars back to the host (the reference's .item() calls, updater.py:134-136)

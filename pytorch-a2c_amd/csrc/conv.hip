@@ -2,16 +2,18 @@
 // backward-data and backward-weight, NCHW fp32.
 //
 // Structure (all three): a 256-thread workgroup stages an input tile (all input planes x the
-// rows one band of output rows needs) into LDS with coalesced loads, then its 4 waves run an
-// implicit GEMM over that tile on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32
-// FMA chain).  The LDS image of a row is PHASE-SPLIT by the conv stride S: source column x is
-// stored at (x % S)*WPS + x / S, so the 16 lanes of an MFMA B-operand read (16 adjacent output
-// pixels, i.e. input columns S apart) hit 16 consecutive banks for every stride, and the four
-// k-groups of a wave (4 input planes) sit PLANE = 16 mod 32 floats apart: conflict-free.
+// rows one band of output rows needs) into LDS -- the whole tile is one flattened index space
+// swept by all 256 threads with 8 independent 16-byte loads in flight per thread (a plane's rows
+// are contiguous in HBM when there is no padding, so the sweep is a straight coalesced copy) --
+// then its 4 waves run an implicit GEMM over that tile on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain).  The four k-groups of a wave (4 input planes)
+// sit PLANE = 16 (mod 32) floats apart so a B-operand read spreads over the LDS banks
+// (stride-1/2 layers conflict-free, the stride-4 layer 2-way).
 //
 //  forward:  D[co, pix] = sum_k W[co,k] X[k,pix];  k = (tap, ci) with ci fastest, one MFMA step =
-//            4 input planes at one tap; A fragments (weights) pre-laid by a2c_conv2d_prep_weights
-//            and read coalesced from L1/L2; B fragments gathered from the LDS tile.
+//            4 input planes at one tap; A fragments (weights) pre-laid by a2c_conv2d_prep_weights,
+//            read coalesced from L1/L2 one 8-step chunk AHEAD of the MFMAs that use them;
+//            B fragments gathered from the LDS tile.
 //  bwd-data: the S*S output-parity classes of dX are S*S stride-1 correlations of dOut with a
 //            sub-kernel of W (taps ky = ry + S*a), i.e. the SAME kernel with other tables.
 //            The ReLU derivative of the layer below is fused into the store (mask > 0).
@@ -35,17 +37,16 @@ static inline int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; 
 // ------------------------------------------------------------------ tile geometry
 struct SrcTile {         // how a band of TPH pixel rows maps onto an LDS image of the source
   int Cp, IH, IW;        // source planes / size
-  int SY, SXl;           // source rows per pixel row; phase count of the LDS row (= source cols per pixel col)
+  int SY, SX;            // source rows / cols per pixel row / col
   int sy0, sx0;          // source row/col of (pixel 0, tap 0)
   int span_y, span_x;    // tap extent
   int PH, PW;            // pixel grid
-  int TPH, TIH, WPS, WP, PLANE, tiles;
+  int TPH, TIH, WP, PLANE, tiles;
 };
 
 static void plan_src(SrcTile& t, int extra_floats_per_row_of_pixels, int extra_fixed, int budget) {
-  const int ncols = (t.PW - 1) * t.SXl + t.span_x;
-  t.WPS = ceil_div(ncols, t.SXl);
-  t.WP = t.WPS * t.SXl;
+  const int ncols = (t.PW - 1) * t.SX + t.span_x;
+  t.WP = (t.sx0 == 0 && ncols <= t.IW) ? t.IW : ncols;    // unpadded layers keep whole rows (contiguous copy)
   int best = 1;
   for (int tph = 1; tph <= t.PH; ++tph) {
     const int tih = (tph - 1) * t.SY + t.span_y;
@@ -62,52 +63,77 @@ static void plan_src(SrcTile& t, int extra_floats_per_row_of_pixels, int extra_f
 // ------------------------------------------------------------------ staging (device)
 struct StageP {
   const float* src; long bstride;   // sample stride (floats)
-  int Cp, IH, IW, TIH, WPS, WP, PLANE, SXl, sxsh, sx0, fast;
+  int Cp, IH, IW, TIH, WP, PLANE, sx0, fast;
 };
 
-// all 4 waves: one (plane,row) per wave iteration, lanes along the row.
+constexpr int STAGE_U = 8;          // independent loads in flight per thread
+
+// All 256 threads sweep the flattened (plane, row, col) space of the LDS image; out-of-image
+// positions (zero padding, rows past the bottom) are written as 0 so every word is finite.
 __device__ __forceinline__ void stage_tile(const StageP& s, float* __restrict__ lds, long b, int y_lo) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int ntask = s.Cp * s.TIH;
-  const int smask = s.SXl - 1;
-  for (int rt = w; rt < ntask; rt += 4) {
-    const int c = rt / s.TIH, r = rt - c * s.TIH;
-    const int ys = y_lo + r;
-    const bool rowok = (ys >= 0) && (ys < s.IH);
-    float* dst = lds + c * s.PLANE + r * s.WP;
-    const float* src = s.src + b * s.bstride + ((long)c * s.IH + (rowok ? ys : 0)) * s.IW;
-    if (s.fast) {   // sx0 == 0, IW % 4 == 0, 16 B aligned rows: one float4 per lane
-      for (int i = lane; i < (s.IW >> 2); i += 64) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rowok) v = reinterpret_cast<const float4*>(src)[i];
-        const int x = i << 2;
-        dst[((x + 0) & smask) * s.WPS + ((x + 0) >> s.sxsh)] = v.x;
-        dst[((x + 1) & smask) * s.WPS + ((x + 1) >> s.sxsh)] = v.y;
-        dst[((x + 2) & smask) * s.WPS + ((x + 2) >> s.sxsh)] = v.z;
-        dst[((x + 3) & smask) * s.WPS + ((x + 3) >> s.sxsh)] = v.w;
+  const int tid = threadIdx.x;
+  const float* __restrict__ base = s.src + b * s.bstride;
+  if (s.fast) {
+    // no padding, WP == IW: plane c of the image is the contiguous run of TIH rows from y_lo
+    const int per4 = (s.TIH * s.IW) >> 2;                       // float4 per plane image
+    const int ok4 = (min(s.TIH, s.IH - y_lo) * s.IW) >> 2;      // float4 that exist in the source
+    const int total = s.Cp * per4;
+    for (int i0 = tid; i0 < total; i0 += 256 * STAGE_U) {
+      float4 v[STAGE_U];
+      int dst[STAGE_U];
+#pragma unroll
+      for (int u = 0; u < STAGE_U; ++u) {
+        const int idx = i0 + u * 256;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[u] = -1;
+        if (idx < total) {
+          const int c = idx / per4, rem = idx - c * per4;
+          dst[u] = c * s.PLANE + (rem << 2);
+          if (rem < ok4) v[u] = *reinterpret_cast<const float4*>(base + ((long)c * s.IH + y_lo) * s.IW + (rem << 2));
+        }
       }
-      // columns beyond IW (if any) are only read by discarded lanes: keep them finite
-      for (int x = s.IW + lane; x < s.WP; x += 64) dst[(x & smask) * s.WPS + (x >> s.sxsh)] = 0.f;
-    } else {
-      for (int x = lane; x < s.WP; x += 64) {
-        const int xs = x + s.sx0;
-        float v = 0.f;
-        if (rowok && xs >= 0 && xs < s.IW) v = src[xs];
-        dst[(x & smask) * s.WPS + (x >> s.sxsh)] = v;
+#pragma unroll
+      for (int u = 0; u < STAGE_U; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<float4*>(lds + dst[u]) = v[u];
+    }
+  } else {
+    const int per = s.TIH * s.WP;
+    const int total = s.Cp * per;
+    for (int i0 = tid; i0 < total; i0 += 256 * STAGE_U) {
+      float v[STAGE_U];
+      int dst[STAGE_U];
+#pragma unroll
+      for (int u = 0; u < STAGE_U; ++u) {
+        const int idx = i0 + u * 256;
+        v[u] = 0.f;
+        dst[u] = -1;
+        if (idx < total) {
+          const int c = idx / per, rem = idx - c * per;
+          const int r = rem / s.WP, x = rem - r * s.WP;
+          const int ys = y_lo + r, xs = x + s.sx0;
+          dst[u] = c * s.PLANE + rem;
+          if (ys >= 0 && ys < s.IH && xs >= 0 && xs < s.IW) v[u] = base[((long)c * s.IH + ys) * s.IW + xs];
+        }
       }
+#pragma unroll
+      for (int u = 0; u < STAGE_U; ++u)
+        if (dst[u] >= 0) lds[dst[u]] = v[u];
     }
   }
 }
 
 // ------------------------------------------------------------------ forward / backward-data
+constexpr int CH = 8;                // MFMA steps per A-fragment chunk (prefetched one chunk ahead)
+constexpr int MAX_STEPS = 128;
+
 struct IgemmP {
   StageP st;
   float* out; long out_bs; int Mch, OHf, OWf;      // output tensor (B, Mch, OHf, OWf)
   const float* wfrag; const float* bias; const float* mask; int relu;
-  int ntaps, c4n;
+  int nchunks;                                      // ceil(nsteps / CH); fragments are zero-padded to it
   int PH, PW, oy_mul, oy_add, ox_mul, ox_add;       // pixel (q,p) -> out (q*oy_mul+oy_add, p*ox_mul+ox_add)
-  int SY, sy0, TPH, tiles, B;
-  int tapoff[MAX_TAPS];
+  int SY, SX, sy0, TPH, tiles, B;
+  int stepoff[MAX_STEPS];                           // LDS offset of step s: tap (dy,dx) + 4*c4 planes
 };
 
 template <int MT>
@@ -133,8 +159,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
       const int i0 = ok0 ? idx0 : 0, i1 = ok1 ? idx1 : 0;
       const int r0 = i0 / p.PW, c0 = i0 - r0 * p.PW;
       const int r1 = i1 / p.PW, c1 = i1 - r1 * p.PW;
-      const int base0 = r0 * p.SY * WP + c0 + g * PLANE;
-      const int base1 = r1 * p.SY * WP + c1 + g * PLANE;
+      const float* __restrict__ l0 = lds + r0 * p.SY * WP + c0 * p.SX + g * PLANE;
+      const float* __restrict__ l1 = lds + r1 * p.SY * WP + c1 * p.SX + g * PLANE;
       f32x4 acc[MT][2];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -142,20 +168,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
         acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
       const float* __restrict__ wf = p.wfrag + lane;
-      for (int t = 0; t < p.ntaps; ++t) {
-        const int to = p.tapoff[t];
-        for (int c4 = 0; c4 < p.c4n; ++c4) {
-          const int off = to + c4 * 4 * PLANE;
-          const float b0 = lds[base0 + off];
-          const float b1 = lds[base1 + off];
+      float a_cur[CH * MT], a_nxt[CH * MT];
+#pragma unroll
+      for (int i = 0; i < CH * MT; ++i) a_cur[i] = wf[i * 64];
+      for (int ck = 0; ck < p.nchunks; ++ck) {
+        if (ck + 1 < p.nchunks) {
+#pragma unroll
+          for (int i = 0; i < CH * MT; ++i) a_nxt[i] = wf[((ck + 1) * CH * MT + i) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int off = p.stepoff[ck * CH + u];
+          const float b0 = l0[off];
+          const float b1 = l1[off];
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const float a = wf[0];
-            wf += 64;
-            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[m][1], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], b0, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], b1, acc[m][1], 0, 0, 0);
           }
         }
+#pragma unroll
+        for (int i = 0; i < CH * MT; ++i) a_cur[i] = a_nxt[i];
       }
       // D map of the 16x16 tile: col (pixel) = lane & 15, row (channel) = 4*(lane>>4) + reg
 #pragma unroll
@@ -199,12 +232,12 @@ __global__ __launch_bounds__(256) void prep_fwd_kernel(const float* __restrict__
     const int c4 = (int)(q % c4n), tap = (int)(q / c4n);
     const int ky = tap / ks, kx = tap - ky * ks;
     const int co = mt * 16 + (l & 15), ci = 4 * c4 + (l >> 4);
-    out[i] = co < Cout ? W[(((long)co * Cin + ci) * ks + ky) * ks + kx] : 0.f;
+    out[i] = (co < Cout && tap < ks * ks) ? W[(((long)co * Cin + ci) * ks + ky) * ks + kx] : 0.f;   // pad steps = 0
   }
 }
 
 __global__ __launch_bounds__(256) void prep_bwd_kernel(const float* __restrict__ W, float* __restrict__ out, int Cin,
-                                                       int Cout, int ks, int S, int ry, int rx, int nb, int MT,
+                                                       int Cout, int ks, int S, int ry, int rx, int na, int nb, int MT,
                                                        long total) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const int l = (int)(i & 63);
@@ -216,17 +249,20 @@ __global__ __launch_bounds__(256) void prep_bwd_kernel(const float* __restrict__
     const int a = tap / nb, bb = tap - a * nb;
     const int ky = ry + S * a, kx = rx + S * bb;
     const int co = 4 * c4 + (l >> 4), ci = mt * 16 + (l & 15);
-    out[i] = ci < Cin ? W[(((long)co * Cin + ci) * ks + ky) * ks + kx] : 0.f;
+    out[i] = (ci < Cin && a < na) ? W[(((long)co * Cin + ci) * ks + ky) * ks + kx] : 0.f;          // pad steps = 0
   }
 }
 
 static inline int ntaps_1d(int ks, int S, int r) { return r < ks ? (ks - r + S - 1) / S : 0; }
+static inline int pad_steps(int nsteps) { return ceil_div(nsteps > 0 ? nsteps : 1, CH) * CH; }
 
 static bool desc_ok(const a2c_conv_desc* d) {
   if (!d) return false;
   if (d->Cin < 4 || d->Cin % 4 || d->Cout < 4 || d->Cout % 4 || d->Cout > 64 || d->Cin > 64) return false;
   if (d->ks < 1 || d->stride < 1 || d->stride > 4 || (d->stride & (d->stride - 1)) || d->pad < 0 || d->pad >= d->ks) return false;
   if (d->ks * d->ks > MAX_TAPS) return false;
+  if (pad_steps(d->ks * d->ks * (d->Cin / 4)) > MAX_STEPS) return false;
+  if (pad_steps(ntaps_1d(d->ks, d->stride, 0) * ntaps_1d(d->ks, d->stride, 0) * (d->Cout / 4)) > MAX_STEPS) return false;
   if (d->OH != (d->H - d->ks + 2 * d->pad) / d->stride + 1 || d->OW != (d->W - d->ks + 2 * d->pad) / d->stride + 1) return false;
   return d->OH >= 1 && d->OW >= 1;
 }
@@ -236,7 +272,7 @@ static size_t bwd_class_offset(const a2c_conv_desc* d, int cls) {   // floats be
   size_t off = 0;
   for (int c = 0; c < cls; ++c) {
     const int ry = c / S, rx = c % S;
-    off += (size_t)ntaps_1d(d->ks, S, ry) * ntaps_1d(d->ks, S, rx) * (d->Cout / 4) * MTb * 64;
+    off += (size_t)pad_steps(ntaps_1d(d->ks, S, ry) * ntaps_1d(d->ks, S, rx) * (d->Cout / 4)) * MTb * 64;
   }
   return off;
 }
@@ -266,9 +302,8 @@ static int launch_igemm(const IgemmP& p, int MT, hipStream_t st) {
 
 static void fill_stage(StageP& s, const SrcTile& t, const float* src, long bstride) {
   s.src = src; s.bstride = bstride;
-  s.Cp = t.Cp; s.IH = t.IH; s.IW = t.IW; s.TIH = t.TIH; s.WPS = t.WPS; s.WP = t.WP; s.PLANE = t.PLANE;
-  s.SXl = t.SXl; s.sxsh = ilog2(t.SXl); s.sx0 = t.sx0;
-  s.fast = (t.sx0 == 0) && (t.IW % 4 == 0) && (t.IW <= t.WP) && (((long)t.IH * t.IW) % 4 == 0) && (bstride % 4 == 0) &&
+  s.Cp = t.Cp; s.IH = t.IH; s.IW = t.IW; s.TIH = t.TIH; s.WP = t.WP; s.PLANE = t.PLANE; s.sx0 = t.sx0;
+  s.fast = (t.sx0 == 0) && (t.sy0 >= 0) && (t.WP == t.IW) && (t.IW % 4 == 0) && (bstride % 4 == 0) &&
            ((uintptr_t)src % 16 == 0);
 }
 
@@ -288,7 +323,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int kk = lane >> 4, j = lane & 15;
-  const int WP = p.st.WP, PLANE = p.st.PLANE, WPS = p.st.WPS;
+  const int WP = p.st.WP, PLANE = p.st.PLANE;
   const int in_floats = p.st.Cp * PLANE;
   float* ldo = lds + in_floats;                       // dOut tile: [MT*16][PLANEo]
   const int lds_total = in_floats + MT * 16 * p.PLANEo + 64;
@@ -296,7 +331,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
 
   // this lane's k offsets (natural weight order k = (ci*ks + ky)*ks + kx), k-tiles w, w+4, ...
   int koff[KTW];
-  const int smask = p.st.SXl - 1;
 #pragma unroll
   for (int q = 0; q < KTW; ++q) {
     const int k = (w + 4 * q) * 16 + j;
@@ -304,9 +338,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
     if (k < p.K) {
       const int ci = k / (p.ks * p.ks), rem = k - ci * p.ks * p.ks;
       const int ky = rem / p.ks, kx = rem - ky * p.ks;
-      o = ci * PLANE + ky * WP + (kx & smask) * WPS + (kx >> p.st.sxsh);
+      o = ci * PLANE + ky * WP + kx;
     }
-    koff[q] = o + kk;                                 // + pixel (4*c4 + kk) of the step
+    koff[q] = o + kk * p.S;                           // + pixel (4*c4 + kk) of the step, S columns apart
   }
   f32x4 acc[MT][KTW];
 #pragma unroll
@@ -328,13 +362,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
     const int rows = min(p.TPH, p.OH - q0);
     __syncthreads();
     stage_tile(p.st, lds, b, q0 * p.S + p.sy0);
-    {  // dOut rows q0..q0+rows of every channel -> ldo[co][r*OWp + c]; pad columns stay 0
-      const int ntask = p.Cout * rows;
-      for (int rt = w; rt < ntask; rt += 4) {
-        const int co = rt / rows, r = rt - co * rows;
-        const float* src = p.dout + ((b * p.Cout + co) * p.OH + q0 + r) * (long)p.OW;
-        float* dst = ldo + co * p.PLANEo + r * p.OWp;
-        for (int x = lane; x < p.OW; x += 64) dst[x] = src[x];
+    {  // dOut rows q0..q0+rows of every channel (a contiguous run per channel) -> ldo[co][r*OWp + c];
+       // pad columns stay 0.  Flattened over all threads, 8 independent loads in flight each.
+      const int per = rows * p.OW;
+      const int tot = p.Cout * per;
+      const float* __restrict__ dsrc = p.dout + (b * p.Cout * p.OH + q0) * (long)p.OW;
+      for (int i0 = threadIdx.x; i0 < tot; i0 += 256 * STAGE_U) {
+        float v[STAGE_U];
+        int dst[STAGE_U];
+#pragma unroll
+        for (int u = 0; u < STAGE_U; ++u) {
+          const int idx = i0 + u * 256;
+          dst[u] = -1;
+          v[u] = 0.f;
+          if (idx < tot) {
+            const int co = idx / per, e = idx - co * per;
+            const int r = e / p.OW, x = e - r * p.OW;
+            dst[u] = co * p.PLANEo + r * p.OWp + x;
+            v[u] = dsrc[(long)co * p.OH * p.OW + e];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < STAGE_U; ++u)
+          if (dst[u] >= 0) ldo[dst[u]] = v[u];
       }
     }
     __syncthreads();
@@ -357,7 +407,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int q = 0; q < KTW; ++q) {
           if (w + 4 * q < p.nkt) {   // wave-uniform
-            const float bv = lds[koff[q] + brow + 4 * c4];
+            const float bv = lds[koff[q] + brow + 4 * c4 * p.S];
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][q], 0, 0, 0);
           }
@@ -405,10 +455,13 @@ struct WgradPlan { SrcTile t; int OWp, PLANEo, MT, KTW, grid; size_t lds; };
 
 static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl) {
   SrcTile& t = pl.t;
-  t.Cp = d->Cin; t.IH = d->H; t.IW = d->W; t.SY = d->stride; t.SXl = d->stride;
+  t.Cp = d->Cin; t.IH = d->H; t.IW = d->W; t.SY = d->stride; t.SX = d->stride;
   t.sy0 = -d->pad; t.sx0 = -d->pad; t.span_y = d->ks; t.span_x = d->ks; t.PH = d->OH;
   pl.OWp = ceil_div(d->OW, 4) * 4;
-  t.PW = pl.OWp;                      // padded pixel columns read (finite, x0) input columns too
+  // Pixel columns are padded to a multiple of 4 (OWp) with dOut = 0; their B reads run up to
+  // (OWp-OW)*S <= 12 floats past a row end, i.e. into the next row / the >= 16-float plane slack,
+  // all of which hold finite values (0 * finite = 0), so the image itself is planned unpadded.
+  t.PW = d->OW;
   const int mt = ceil_div(d->Cout, 16);
   const int nkt = ceil_div(d->Cin * d->ks * d->ks, 16);
   const int ktw = ceil_div(nkt, 4);
@@ -438,7 +491,7 @@ static void launch_wgrad_t(const WgradP& p, int grid, size_t lds, hipStream_t st
 extern "C" {
 size_t a2c_conv2d_prep_floats(const a2c_conv_desc* d, int kind) {
   if (!desc_ok(d)) return 0;
-  if (kind == 0) return (size_t)d->ks * d->ks * (d->Cin / 4) * ceil_div(d->Cout, 16) * 64;
+  if (kind == 0) return (size_t)pad_steps(d->ks * d->ks * (d->Cin / 4)) * ceil_div(d->Cout, 16) * 64;
   return bwd_class_offset(d, d->stride * d->stride);
 }
 
@@ -458,10 +511,10 @@ int a2c_conv2d_prep_weights(const a2c_conv_desc* d, int kind, const float* weigh
   for (int cls = 0; cls < S * S; ++cls) {
     const int ry = cls / S, rx = cls % S;
     const int na = ntaps_1d(d->ks, S, ry), nb = ntaps_1d(d->ks, S, rx);
-    const long total = (long)na * nb * (d->Cout / 4) * MTb * 64;
-    if (total == 0) continue;
+    const long total = (long)pad_steps(na * nb * (d->Cout / 4)) * MTb * 64;
     hipLaunchKernelGGL(prep_bwd_kernel, dim3(a2c_grid_1d(total, 256)), dim3(256), 0, st, weight,
-                       wprep + bwd_class_offset(d, cls), d->Cin, d->Cout, d->ks, S, ry, rx, nb, MTb, total);
+                       wprep + bwd_class_offset(d, cls), d->Cin, d->Cout, d->ks, S, ry, rx, na, nb > 0 ? nb : 1, MTb,
+                       total);
     A2C_CHECK_LAUNCH();
   }
   return A2C_OK;
@@ -473,19 +526,21 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   if (B == 0) return A2C_OK;
   if (!in || !wprep_fwd || !out) return A2C_ERR_ARG;
   SrcTile t;
-  t.Cp = d->Cin; t.IH = d->H; t.IW = d->W; t.SY = d->stride; t.SXl = d->stride;
+  t.Cp = d->Cin; t.IH = d->H; t.IW = d->W; t.SY = d->stride; t.SX = d->stride;
   t.sy0 = -d->pad; t.sx0 = -d->pad; t.span_y = d->ks; t.span_x = d->ks; t.PH = d->OH; t.PW = d->OW;
   plan_src(t, 0, 0, IGEMM_LDS_BUDGET);
   IgemmP p;
   fill_stage(p.st, t, in, in_bstride);
   p.out = out; p.out_bs = out_bstride; p.Mch = d->Cout; p.OHf = d->OH; p.OWf = d->OW;
   p.wfrag = wprep_fwd; p.bias = bias; p.mask = nullptr; p.relu = relu;
-  p.ntaps = d->ks * d->ks; p.c4n = d->Cin / 4;
   p.PH = d->OH; p.PW = d->OW; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0;
-  p.SY = t.SY; p.sy0 = t.sy0; p.TPH = t.TPH; p.tiles = t.tiles; p.B = B;
-  const int sm = t.SXl - 1, sh = ilog2(t.SXl);
+  p.SY = t.SY; p.SX = t.SX; p.sy0 = t.sy0; p.TPH = t.TPH; p.tiles = t.tiles; p.B = B;
+  const int c4n = d->Cin / 4, nsteps = d->ks * d->ks * c4n;
+  p.nchunks = pad_steps(nsteps) / CH;
+  for (int s = 0; s < MAX_STEPS; ++s) p.stepoff[s] = 0;
   for (int ky = 0; ky < d->ks; ++ky)
-    for (int kx = 0; kx < d->ks; ++kx) p.tapoff[ky * d->ks + kx] = ky * t.WP + (kx & sm) * t.WPS + (kx >> sh);
+    for (int kx = 0; kx < d->ks; ++kx)
+      for (int c4 = 0; c4 < c4n; ++c4) p.stepoff[(ky * d->ks + kx) * c4n + c4] = ky * t.WP + kx + c4 * 4 * t.PLANE;
   return launch_igemm(p, ceil_div(d->Cout, 16), a2c_s(stream));
 }
 
@@ -505,7 +560,7 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
     const int nx = (d->W - 1 + P - rx) >= 0 ? (d->W - 1 + P - rx) / S - qx0 + 1 : 0;
     if (ny <= 0 || nx <= 0) continue;
     SrcTile t;
-    t.Cp = d->Cout; t.IH = d->OH; t.IW = d->OW; t.SY = 1; t.SXl = 1;
+    t.Cp = d->Cout; t.IH = d->OH; t.IW = d->OW; t.SY = 1; t.SX = 1;
     const int sa = na > 0 ? na : 1, sb = nb > 0 ? nb : 1;
     t.sy0 = qy0 - (sa - 1); t.sx0 = qx0 - (sb - 1); t.span_y = sa; t.span_x = sb; t.PH = ny; t.PW = nx;
     plan_src(t, 0, 0, IGEMM_LDS_BUDGET);
@@ -513,11 +568,15 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
     fill_stage(p.st, t, dout, (long)d->Cout * d->OH * d->OW);
     p.out = din; p.out_bs = (long)d->Cin * d->H * d->W; p.Mch = d->Cin; p.OHf = d->H; p.OWf = d->W;
     p.wfrag = wprep_bwd + bwd_class_offset(d, cls); p.bias = nullptr; p.mask = mask; p.relu = 0;
-    p.ntaps = na * nb; p.c4n = d->Cout / 4;
     p.PH = ny; p.PW = nx; p.oy_mul = S; p.oy_add = S * qy0 + ry - P; p.ox_mul = S; p.ox_add = S * qx0 + rx - P;
-    p.SY = 1; p.sy0 = t.sy0; p.TPH = t.TPH; p.tiles = t.tiles; p.B = B;
+    p.SY = 1; p.SX = 1; p.sy0 = t.sy0; p.TPH = t.TPH; p.tiles = t.tiles; p.B = B;
+    const int c4n = d->Cout / 4;
+    p.nchunks = pad_steps(na * nb * c4n) / CH;
+    for (int s = 0; s < MAX_STEPS; ++s) p.stepoff[s] = 0;
     for (int a = 0; a < na; ++a)
-      for (int b = 0; b < nb; ++b) p.tapoff[a * nb + b] = (sa - 1 - a) * t.WP + (sb - 1 - b);
+      for (int b = 0; b < nb; ++b)
+        for (int c4 = 0; c4 < c4n; ++c4)
+          p.stepoff[(a * nb + b) * c4n + c4] = (sa - 1 - a) * t.WP + (sb - 1 - b) + c4 * 4 * t.PLANE;
     const int rc = launch_igemm(p, ceil_div(d->Cin, 16), a2c_s(stream));
     if (rc != A2C_OK) return rc;
   }

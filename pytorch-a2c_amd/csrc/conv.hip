@@ -21,17 +21,39 @@
 //            (LDS), accumulators persist in registers across all samples of a workgroup,
 //            per-workgroup partial slabs + fixed-order reduction (deterministic), bias gradient
 //            from the same dOut tile.
+#include <stdlib.h>
 #include "a2c_common.h"
 
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int MAX_TAPS = 64;
-constexpr int IGEMM_LDS_BUDGET = 64 * 1024;   // 2 workgroups / CU
-constexpr int WGRAD_LDS_BUDGET = 76 * 1024;
+static int env_kb(const char* name, int dflt_kb) {
+  const char* v = getenv(name);
+  const int kb = v ? atoi(v) : 0;
+  return (kb > 0 ? kb : dflt_kb) * 1024;
+}
+// LDS per workgroup decides how many workgroups share a CU (160 KB): tunable for experiments
+#define IGEMM_LDS_BUDGET env_kb("A2C_IGEMM_LDS_KB", 64)
+#define WGRAD_LDS_BUDGET env_kb("A2C_WGRAD_LDS_KB", 76)
 constexpr int LDS_HARD_MAX = 160 * 1024;
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// persistent grids: exactly the number of workgroups the chip keeps resident (a static tile
+// stride over a grid that is not a multiple of it leaves the last round mostly idle)
+static int resident_grid(const void* kernel, size_t lds_bytes, long total_tiles) {
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+  hipDeviceProp_t prop;
+  static int cached_cus = 0;
+  if (!cached_cus) {
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached_cus = prop.multiProcessorCount;
+    else cached_cus = 256;
+  }
+  cus = cached_cus;
+  const long g = (long)per_cu * cus;
+  return (int)(total_tiles < g ? (total_tiles > 0 ? total_tiles : 1) : g);
+}
 static inline int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
 // ------------------------------------------------------------------ tile geometry
@@ -133,7 +155,21 @@ struct IgemmP {
   int nchunks;                                      // ceil(nsteps / CH); fragments are zero-padded to it
   int PH, PW, oy_mul, oy_add, ox_mul, ox_add;       // pixel (q,p) -> out (q*oy_mul+oy_add, p*ox_mul+ox_add)
   int SY, SX, sy0, TPH, tiles, B;
-  int stepoff[MAX_STEPS];                           // LDS offset of step s: tap (dy,dx) + 4*c4 planes
+  // LDS offset of MFMA step s = (a*nb + b)*c4n + c4 (tap row a, tap col b, channel quad c4):
+  //   off0 + a*step_a + b*step_b + c4*step_c     -- scalar arithmetic, no table
+  int nsteps, nb, c4n, off0, step_a, step_b, step_c;
+};
+
+struct StepIter {      // wave-uniform walker over the step offsets
+  int off, bi, ci;
+  __device__ __forceinline__ void init(const IgemmP& p) { off = p.off0; bi = 0; ci = 0; }
+  __device__ __forceinline__ void next(const IgemmP& p) {
+    ++ci; off += p.step_c;
+    if (ci == p.c4n) {
+      ci = 0; ++bi; off += p.step_b - p.c4n * p.step_c;
+      if (bi == p.nb) { bi = 0; off += p.step_a - p.nb * p.step_b; }
+    }
+  }
 };
 
 template <int MT>
@@ -171,6 +207,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
       float a_cur[CH * MT], a_nxt[CH * MT];
 #pragma unroll
       for (int i = 0; i < CH * MT; ++i) a_cur[i] = wf[i * 64];
+      StepIter it;
+      it.init(p);
       for (int ck = 0; ck < p.nchunks; ++ck) {
         if (ck + 1 < p.nchunks) {
 #pragma unroll
@@ -178,7 +216,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int off = p.stepoff[ck * CH + u];
+          const int off = (ck * CH + u < p.nsteps) ? it.off : 0;   // padded steps (A = 0) read a valid word
+          it.next(p);
           const float b0 = l0[off];
           const float b1 = l1[off];
 #pragma unroll
@@ -210,6 +249,128 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
               if (p.relu) v = fmaxf(v, 0.f);
               if (p.mask && !(p.mask[o] > 0.f)) v = 0.f;
               p.out[o] = v;
+            }
+          }
+      }
+    }
+  }
+}
+
+// Software-pipelined variant for unpadded layers whose tile image is <= 32 KB and whose weight
+// fragments fit in LDS (the A3CModel convs): the NEXT tile's global loads are issued into
+// registers before the current tile's MFMA phase and written to LDS after it, so HBM latency
+// hides under the matrix work of the same workgroup.  The compute phase touches only LDS
+// (B gathers AND the A fragments, which are copied to LDS once per workgroup) plus the output
+// stores, so no wait on a global load ever drains the prefetch.  Bias is kept in registers.
+constexpr int PF_N = 8;              // float4 prefetch registers per thread  (256*8*16 B = 32 KB tile)
+
+template <int MT>
+__global__ __launch_bounds__(256) void igemm_pf_kernel(IgemmP p, int nfrag) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ ldsA = lds;                 // [nsteps*MT][64] weight fragments
+  float* __restrict__ img = lds + nfrag;          // tile image
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const long total = (long)p.B * p.tiles;
+  const int WP = p.st.WP, PLANE = p.st.PLANE;
+  for (int i = tid; i < nfrag; i += 256) ldsA[i] = p.wfrag[i];
+  float bias_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int co = m * 16 + 4 * g + rr;
+      bias_r[m][rr] = (p.bias && co < p.Mch) ? p.bias[co] : 0.f;
+    }
+  // flattened float4 index space of the image (same as stage_tile's fast path)
+  const int per4 = (p.st.TIH * p.st.IW) >> 2;
+  const int tot4 = p.st.Cp * per4;
+  int dst[PF_N], srcoff[PF_N], rem4[PF_N];
+#pragma unroll
+  for (int u = 0; u < PF_N; ++u) {
+    const int idx = tid + u * 256;
+    dst[u] = -1; srcoff[u] = 0; rem4[u] = 0;
+    if (idx < tot4) {
+      const int c = idx / per4, rem = idx - c * per4;
+      dst[u] = c * PLANE + (rem << 2);
+      srcoff[u] = c * p.st.IH * p.st.IW + (rem << 2);
+      rem4[u] = rem;
+    }
+  }
+  float4 pf[PF_N];
+  auto issue = [&](long tile) {
+    const long b = tile / p.tiles;
+    const int ti = (int)(tile - b * p.tiles);
+    const int y_lo = ti * p.TPH * p.SY + p.sy0;
+    const int ok4 = (min(p.st.TIH, p.st.IH - y_lo) * p.st.IW) >> 2;
+    const float* __restrict__ base = p.st.src + b * p.st.bstride + (long)y_lo * p.st.IW;
+#pragma unroll
+    for (int u = 0; u < PF_N; ++u) {
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dst[u] >= 0 && rem4[u] < ok4) pf[u] = *reinterpret_cast<const float4*>(base + srcoff[u]);
+    }
+  };
+  long tile = blockIdx.x;
+  if (tile < total) issue(tile);
+  for (; tile < total; tile += gridDim.x) {
+    const long b = tile / p.tiles;
+    const int ti = (int)(tile - b * p.tiles);
+    const int qq0 = ti * p.TPH;
+    const int rows = min(p.TPH, p.PH - qq0);
+    const int NP = rows * p.PW;
+    __syncthreads();                       // readers of the previous tile are done
+#pragma unroll
+    for (int u = 0; u < PF_N; ++u)
+      if (dst[u] >= 0) *reinterpret_cast<float4*>(img + dst[u]) = pf[u];
+    __syncthreads();
+    if (tile + gridDim.x < total) issue(tile + gridDim.x);     // in flight during the MFMA phase below
+    const int npairs = (NP + 31) >> 5;
+    for (int pr = w; pr < npairs; pr += 4) {
+      const int idx0 = pr * 32 + j, idx1 = idx0 + 16;
+      const bool ok0 = idx0 < NP, ok1 = idx1 < NP;
+      const int i0 = ok0 ? idx0 : 0, i1 = ok1 ? idx1 : 0;
+      const int r0 = i0 / p.PW, c0 = i0 - r0 * p.PW;
+      const int r1 = i1 / p.PW, c1 = i1 - r1 * p.PW;
+      const float* __restrict__ l0 = img + r0 * p.SY * WP + c0 * p.SX + g * PLANE;
+      const float* __restrict__ l1 = img + r1 * p.SY * WP + c1 * p.SX + g * PLANE;
+      const float* __restrict__ la = ldsA + lane;
+      f32x4 acc[MT][2];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      StepIter it;
+      it.init(p);
+      for (int s0 = 0; s0 < p.nsteps; s0 += CH) {          // nsteps % CH == 0 on this path
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int off = it.off;
+          it.next(p);
+          const float b0 = l0[off];
+          const float b1 = l1[off];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float a = la[((s0 + u) * MT + m) * 64];
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[m][1], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (!(nt ? ok1 : ok0)) continue;
+        const int r = nt ? r1 : r0, c = nt ? c1 : c0;
+        const long pix = ((long)(qq0 + r) * p.oy_mul + p.oy_add) * p.OWf + (long)c * p.ox_mul + p.ox_add;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int co = m * 16 + 4 * g + rr;
+            if (co < p.Mch) {
+              float v = acc[m][nt][rr] + bias_r[m][rr];
+              if (p.relu) v = fmaxf(v, 0.f);
+              p.out[b * p.out_bs + (long)co * p.OHf * p.OWf + pix] = v;
             }
           }
       }
@@ -281,6 +442,7 @@ template <int MT>
 static void launch_igemm_t(const IgemmP& p, int grid, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)igemm_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  grid = resident_grid((const void*)igemm_kernel<MT>, lds, (long)p.B * p.tiles);
   hipLaunchKernelGGL(igemm_kernel<MT>, dim3(grid), dim3(256), lds, st, p);
 }
 
@@ -476,7 +638,11 @@ static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl) {
   pl.lds = 4 * ((size_t)t.Cp * t.PLANE + (size_t)pl.MT * 16 * pl.PLANEo + 64);
   if (pl.lds > LDS_HARD_MAX) return false;
   const long total = (long)B * t.tiles;
-  pl.grid = (int)(total < 1024 ? (total > 0 ? total : 1) : 1024);
+  const void* k = (pl.MT == 1 && pl.KTW == 1) ? (const void*)wgrad_kernel<1, 1>
+                  : (pl.MT == 1 && pl.KTW == 4) ? (const void*)wgrad_kernel<1, 4>
+                  : (pl.MT == 2 && pl.KTW == 4) ? (const void*)wgrad_kernel<2, 4> : (const void*)wgrad_kernel<4, 7>;
+  if (pl.lds > 64 * 1024) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  pl.grid = resident_grid(k, pl.lds, total);
   return true;
 }
 
@@ -536,12 +702,35 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   p.PH = d->OH; p.PW = d->OW; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0;
   p.SY = t.SY; p.SX = t.SX; p.sy0 = t.sy0; p.TPH = t.TPH; p.tiles = t.tiles; p.B = B;
   const int c4n = d->Cin / 4, nsteps = d->ks * d->ks * c4n;
+  const int MT = ceil_div(d->Cout, 16);
   p.nchunks = pad_steps(nsteps) / CH;
-  for (int s = 0; s < MAX_STEPS; ++s) p.stepoff[s] = 0;
-  for (int ky = 0; ky < d->ks; ++ky)
-    for (int kx = 0; kx < d->ks; ++kx)
-      for (int c4 = 0; c4 < c4n; ++c4) p.stepoff[(ky * d->ks + kx) * c4n + c4] = ky * t.WP + kx + c4 * 4 * t.PLANE;
-  return launch_igemm(p, ceil_div(d->Cout, 16), a2c_s(stream));
+  // pipelined variant: unpadded layer, 16 B aligned rows, fragments <= 32 KB, image <= 32 KB
+  const int nfrag = p.nchunks * CH * MT * 64;
+  p.nsteps = nsteps; p.nb = d->ks; p.c4n = c4n; p.off0 = 0; p.step_b = 1;
+  if (d->pad == 0 && d->W % 4 == 0 && in_bstride % 4 == 0 && ((uintptr_t)in % 16 == 0) && nfrag * 4 <= 32 * 1024 &&
+      MT <= 2 && nsteps % CH == 0 && !getenv("A2C_NO_PF")) {
+    int tph = 0;
+    for (int c = 1; c <= d->OH; ++c)
+      if ((long)d->Cin * ((c - 1) * d->stride + d->ks) * d->W <= 256L * PF_N * 4) tph = c; else break;
+    if (tph >= 1) {
+      t.TPH = tph; t.TIH = (tph - 1) * t.SY + t.span_y; t.WP = t.IW;
+      t.PLANE = ((t.TIH * t.WP + 31) / 32) * 32 + 16;
+      t.tiles = ceil_div(t.PH, t.TPH);
+      fill_stage(p.st, t, in, in_bstride);
+      p.TPH = t.TPH; p.tiles = t.tiles;
+      p.step_a = t.WP; p.step_c = 4 * t.PLANE;
+      const size_t lds = 4 * ((size_t)nfrag + (size_t)t.Cp * t.PLANE + 64);
+      const long total = (long)B * t.tiles;
+      if (MT == 1) hipLaunchKernelGGL(igemm_pf_kernel<1>, dim3(resident_grid((const void*)igemm_pf_kernel<1>, lds, total)), dim3(256),
+                                      lds, a2c_s(stream), p, nfrag);
+      else hipLaunchKernelGGL(igemm_pf_kernel<2>, dim3(resident_grid((const void*)igemm_pf_kernel<2>, lds, total)), dim3(256), lds,
+                              a2c_s(stream), p, nfrag);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
+  p.step_a = t.WP; p.step_c = 4 * t.PLANE;
+  return launch_igemm(p, MT, a2c_s(stream));
 }
 
 int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask,
@@ -572,11 +761,8 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
     p.SY = 1; p.SX = 1; p.sy0 = t.sy0; p.TPH = t.TPH; p.tiles = t.tiles; p.B = B;
     const int c4n = d->Cout / 4;
     p.nchunks = pad_steps(na * nb * c4n) / CH;
-    for (int s = 0; s < MAX_STEPS; ++s) p.stepoff[s] = 0;
-    for (int a = 0; a < na; ++a)
-      for (int b = 0; b < nb; ++b)
-        for (int c4 = 0; c4 < c4n; ++c4)
-          p.stepoff[(a * nb + b) * c4n + c4] = (sa - 1 - a) * t.WP + (sb - 1 - b) + c4 * 4 * t.PLANE;
+    p.nsteps = na * nb * c4n; p.nb = sb; p.c4n = c4n;
+    p.off0 = (sa - 1) * t.WP + (sb - 1); p.step_a = -t.WP; p.step_b = -1; p.step_c = 4 * t.PLANE;
     const int rc = launch_igemm(p, ceil_div(d->Cin, 16), a2c_s(stream));
     if (rc != A2C_OK) return rc;
   }

@@ -163,12 +163,14 @@ struct IgemmP {
 struct StepIter {      // wave-uniform walker over the step offsets
   int off, bi, ci;
   __device__ __forceinline__ void init(const IgemmP& p) { off = p.off0; bi = 0; ci = 0; }
-  __device__ __forceinline__ void next(const IgemmP& p) {
-    ++ci; off += p.step_c;
-    if (ci == p.c4n) {
-      ci = 0; ++bi; off += p.step_b - p.c4n * p.step_c;
-      if (bi == p.nb) { bi = 0; off += p.step_a - p.nb * p.step_b; }
-    }
+  __device__ __forceinline__ void next(const IgemmP& p) {   // branch-free: selects only, so a chunk of
+    ++ci;                                                     // steps stays one basic block
+    const bool w1 = (ci == p.c4n);
+    ci = w1 ? 0 : ci;
+    bi += w1 ? 1 : 0;
+    const bool w2 = (bi == p.nb);
+    bi = w2 ? 0 : bi;
+    off += p.step_c + (w1 ? p.step_b - p.c4n * p.step_c : 0) + (w2 ? p.step_a - p.nb * p.step_b : 0);
   }
 };
 
@@ -214,18 +216,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
 #pragma unroll
           for (int i = 0; i < CH * MT; ++i) a_nxt[i] = wf[((ck + 1) * CH * MT + i) * 64];
         }
+        float bv0[CH], bv1[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
+        for (int u = 0; u < CH; ++u) {       // all B gathers of the chunk first ...
           const int off = (ck * CH + u < p.nsteps) ? it.off : 0;   // padded steps (A = 0) read a valid word
           it.next(p);
-          const float b0 = l0[off];
-          const float b1 = l1[off];
+          bv0[u] = l0[off];
+          bv1[u] = l1[off];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)         // ... then its MFMAs back to back
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], b0, acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], b1, acc[m][1], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], bv0[u], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], bv1[u], acc[m][1], 0, 0, 0);
           }
-        }
 #pragma unroll
         for (int i = 0; i < CH * MT; ++i) a_cur[i] = a_nxt[i];
       }
@@ -256,16 +261,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
   }
 }
 
-// Software-pipelined variant for unpadded layers whose tile image is <= 32 KB and whose weight
-// fragments fit in LDS (the A3CModel convs): the NEXT tile's global loads are issued into
-// registers before the current tile's MFMA phase and written to LDS after it, so HBM latency
-// hides under the matrix work of the same workgroup.  The compute phase touches only LDS
-// (B gathers AND the A fragments, which are copied to LDS once per workgroup) plus the output
-// stores, so no wait on a global load ever drains the prefetch.  Bias is kept in registers.
-constexpr int PF_N = 8;              // float4 prefetch registers per thread  (256*8*16 B = 32 KB tile)
+// "Row-run" forward kernel for the unpadded layers (A3CModel: 8x8/s4 and 4x4/s2), software
+// pipelined:
+//  * K is ordered (c4, ky, kx) with kx fastest, so the KS taps of one kernel row are KS
+//    CONTIGUOUS floats of the image per lane (lane = output pixel, byte offset 4*S*ox, i.e.
+//    16 B aligned for S=4, 8 B for S=2): two ds_read_b128 (or b64) feed KS MFMA steps instead of
+//    KS bank-conflicting ds_read_b32 gathers.  PLANE = 0 (b128) / 32 (b64) mod 64 floats makes
+//    the 4 planes of a wave's k-groups fall on distinct 16-lane bank groups: conflict-free.
+//  * the NEXT tile's global loads are issued into registers before the current tile's MFMA
+//    phase and written to LDS after it, so HBM latency hides under the matrix work of the same
+//    workgroup.  The compute phase touches only LDS (B rows AND the A fragments, copied to LDS
+//    once per workgroup) plus the output stores, so no wait on a global load drains the prefetch.
+constexpr int PF_N = 10;             // float4 prefetch registers per thread  (256*10*16 B = 40 KB image)
 
-template <int MT>
-__global__ __launch_bounds__(256) void igemm_pf_kernel(IgemmP p, int nfrag) {
+template <int MT, int KS, int S>
+__global__ __launch_bounds__(256) void igemm_run_kernel(IgemmP p, int nfrag) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* __restrict__ ldsA = lds;                 // [nsteps*MT][64] weight fragments
   float* __restrict__ img = lds + nfrag;          // tile image
@@ -331,8 +341,8 @@ __global__ __launch_bounds__(256) void igemm_pf_kernel(IgemmP p, int nfrag) {
       const int i0 = ok0 ? idx0 : 0, i1 = ok1 ? idx1 : 0;
       const int r0 = i0 / p.PW, c0 = i0 - r0 * p.PW;
       const int r1 = i1 / p.PW, c1 = i1 - r1 * p.PW;
-      const float* __restrict__ l0 = img + r0 * p.SY * WP + c0 * p.SX + g * PLANE;
-      const float* __restrict__ l1 = img + r1 * p.SY * WP + c1 * p.SX + g * PLANE;
+      const float* __restrict__ l0 = img + r0 * S * WP + c0 * S + g * PLANE;
+      const float* __restrict__ l1 = img + r1 * S * WP + c1 * S + g * PLANE;
       const float* __restrict__ la = ldsA + lane;
       f32x4 acc[MT][2];
 #pragma unroll
@@ -340,21 +350,41 @@ __global__ __launch_bounds__(256) void igemm_pf_kernel(IgemmP p, int nfrag) {
         acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      StepIter it;
-      it.init(p);
-      for (int s0 = 0; s0 < p.nsteps; s0 += CH) {          // nsteps % CH == 0 on this path
+      int s = 0;
+      for (int c4 = 0; c4 < p.c4n; ++c4) {
+        const int poff = c4 * 4 * PLANE;
+#pragma unroll 2
+        for (int ky = 0; ky < KS; ++ky, s += KS) {
+          const int off = poff + ky * WP;
+          float bv0[KS], bv1[KS], av[KS * MT];
+          if (S == 4) {                    // 16 B aligned: ds_read_b128
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int off = it.off;
-          it.next(p);
-          const float b0 = l0[off];
-          const float b1 = l1[off];
+            for (int q = 0; q < KS / 4; ++q) {
+              const float4 t0 = *reinterpret_cast<const float4*>(l0 + off + 4 * q);
+              const float4 t1 = *reinterpret_cast<const float4*>(l1 + off + 4 * q);
+              bv0[4 * q] = t0.x; bv0[4 * q + 1] = t0.y; bv0[4 * q + 2] = t0.z; bv0[4 * q + 3] = t0.w;
+              bv1[4 * q] = t1.x; bv1[4 * q + 1] = t1.y; bv1[4 * q + 2] = t1.z; bv1[4 * q + 3] = t1.w;
+            }
+          } else {                         // 8 B aligned: ds_read_b64
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const float a = la[((s0 + u) * MT + m) * 64];
-            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[m][1], 0, 0, 0);
+            for (int q = 0; q < KS / 2; ++q) {
+              const float2 t0 = *reinterpret_cast<const float2*>(l0 + off + 2 * q);
+              const float2 t1 = *reinterpret_cast<const float2*>(l1 + off + 2 * q);
+              bv0[2 * q] = t0.x; bv0[2 * q + 1] = t0.y;
+              bv1[2 * q] = t1.x; bv1[2 * q + 1] = t1.y;
+            }
           }
+#pragma unroll
+          for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[u * MT + m] = la[((s + u) * MT + m) * 64];
+#pragma unroll
+          for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u * MT + m], bv0[u], acc[m][0], 0, 0, 0);
+              acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u * MT + m], bv1[u], acc[m][1], 0, 0, 0);
+            }
         }
       }
 #pragma unroll
@@ -378,20 +408,27 @@ __global__ __launch_bounds__(256) void igemm_pf_kernel(IgemmP p, int nfrag) {
   }
 }
 
+// layers that take the row-run kernel (and therefore the (c4, ky, kx) fragment order)
+static bool run_layout(const a2c_conv_desc* d) {
+  return d->pad == 0 && d->W % 4 == 0 && d->Cout <= 32 &&
+         ((d->ks == 8 && d->stride == 4) || (d->ks == 4 && d->stride == 2));
+}
+
 // weights -> A fragments.  kind 0 (forward): step s = tap*(Cin/4) + c4, lane l:
 //   W[co = mt*16 + (l&15)][ci = 4*c4 + (l>>4)][ky][kx],  tap = ky*ks + kx.
 // kind 1 (backward-data), class (ry,rx), taps (a,b): ky = ry + S*a, kx = rx + S*b,
 //   step s = tap*(Cout/4) + c4, lane l: W[co = 4*c4 + (l>>4)][ci = mt*16 + (l&15)][ky][kx].
 __global__ __launch_bounds__(256) void prep_fwd_kernel(const float* __restrict__ W, float* __restrict__ out, int Cin,
-                                                       int Cout, int ks, int MT, long total) {
+                                                       int Cout, int ks, int MT, int run_order, long total) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const int l = (int)(i & 63);
     long q = i >> 6;
     const int mt = (int)(q % MT);
     q /= MT;
     const int c4n = Cin >> 2;
-    const int c4 = (int)(q % c4n), tap = (int)(q / c4n);
-    const int ky = tap / ks, kx = tap - ky * ks;
+    int c4 = (int)(q % c4n), tap = (int)(q / c4n);          // default: step = tap*c4n + c4
+    if (run_order) { tap = (int)(q % (ks * ks)); c4 = (int)(q / (ks * ks)); if (c4 >= c4n) { c4 = 0; tap = ks * ks; } }
+    const int ky = tap / ks, kx = tap - ky * ks;            // run order: step = (c4*ks + ky)*ks + kx
     const int co = mt * 16 + (l & 15), ci = 4 * c4 + (l >> 4);
     out[i] = (co < Cout && tap < ks * ks) ? W[(((long)co * Cin + ci) * ks + ky) * ks + kx] : 0.f;   // pad steps = 0
   }
@@ -669,7 +706,7 @@ int a2c_conv2d_prep_weights(const a2c_conv_desc* d, int kind, const float* weigh
     const int MT = ceil_div(d->Cout, 16);
     const long total = (long)a2c_conv2d_prep_floats(d, 0);
     hipLaunchKernelGGL(prep_fwd_kernel, dim3(a2c_grid_1d(total, 256)), dim3(256), 0, st, weight, wprep, d->Cin, d->Cout,
-                       d->ks, MT, total);
+                       d->ks, MT, run_layout(d) ? 1 : 0, total);
     A2C_CHECK_LAUNCH();
     return A2C_OK;
   }
@@ -707,27 +744,49 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   // pipelined variant: unpadded layer, 16 B aligned rows, fragments <= 32 KB, image <= 32 KB
   const int nfrag = p.nchunks * CH * MT * 64;
   p.nsteps = nsteps; p.nb = d->ks; p.c4n = c4n; p.off0 = 0; p.step_b = 1;
-  if (d->pad == 0 && d->W % 4 == 0 && in_bstride % 4 == 0 && ((uintptr_t)in % 16 == 0) && nfrag * 4 <= 32 * 1024 &&
-      MT <= 2 && nsteps % CH == 0 && !getenv("A2C_NO_PF")) {
+  const bool run = run_layout(d);
+  if (run && in_bstride % 4 == 0 && ((uintptr_t)in % 16 == 0) && nfrag * 4 <= 32 * 1024 && !getenv("A2C_NO_PF")) {
+    // largest band whose image fits the prefetch registers; prefer bands whose pixel count fills
+    // whole 32-pixel pairs
     int tph = 0;
-    for (int c = 1; c <= d->OH; ++c)
-      if ((long)d->Cin * ((c - 1) * d->stride + d->ks) * d->W <= 256L * PF_N * 4) tph = c; else break;
+    double best = -1.0;
+    for (int c = 1; c <= d->OH; ++c) {
+      if ((long)d->Cin * ((c - 1) * d->stride + d->ks) * d->W > 256L * PF_N * 4) break;
+      const int ntl = ceil_div(d->OH, c);
+      long slots = 0;
+      for (int i = 0; i < ntl; ++i) {
+        const int r = (i + 1 < ntl) ? c : d->OH - c * (ntl - 1);
+        slots += (long)ceil_div(ceil_div(r * d->OW, 32), 4) * 4 * 32;      // 4 waves, pairs of 16-pixel tiles
+      }
+      const double eff = (double)d->OH * d->OW / slots - 0.02 * (double)((c - 1) * d->stride + d->ks) * ntl / d->H;
+      if (eff > best) { best = eff; tph = c; }
+    }
     if (tph >= 1) {
       t.TPH = tph; t.TIH = (tph - 1) * t.SY + t.span_y; t.WP = t.IW;
-      t.PLANE = ((t.TIH * t.WP + 31) / 32) * 32 + 16;
+      t.PLANE = ((t.TIH * t.WP + 63) / 64) * 64 + (d->stride == 4 ? 0 : 32);
       t.tiles = ceil_div(t.PH, t.TPH);
       fill_stage(p.st, t, in, in_bstride);
       p.TPH = t.TPH; p.tiles = t.tiles;
-      p.step_a = t.WP; p.step_c = 4 * t.PLANE;
       const size_t lds = 4 * ((size_t)nfrag + (size_t)t.Cp * t.PLANE + 64);
       const long total = (long)B * t.tiles;
-      if (MT == 1) hipLaunchKernelGGL(igemm_pf_kernel<1>, dim3(resident_grid((const void*)igemm_pf_kernel<1>, lds, total)), dim3(256),
-                                      lds, a2c_s(stream), p, nfrag);
-      else hipLaunchKernelGGL(igemm_pf_kernel<2>, dim3(resident_grid((const void*)igemm_pf_kernel<2>, lds, total)), dim3(256), lds,
-                              a2c_s(stream), p, nfrag);
+      const void* k;
+      if (d->ks == 8) k = MT == 1 ? (const void*)igemm_run_kernel<1, 8, 4> : (const void*)igemm_run_kernel<2, 8, 4>;
+      else k = MT == 1 ? (const void*)igemm_run_kernel<1, 4, 2> : (const void*)igemm_run_kernel<2, 4, 2>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const int grid = resident_grid(k, lds, total);
+      hipStream_t st = a2c_s(stream);
+      if (d->ks == 8 && MT == 1) hipLaunchKernelGGL((igemm_run_kernel<1, 8, 4>), dim3(grid), dim3(256), lds, st, p, nfrag);
+      else if (d->ks == 8) hipLaunchKernelGGL((igemm_run_kernel<2, 8, 4>), dim3(grid), dim3(256), lds, st, p, nfrag);
+      else if (MT == 1) hipLaunchKernelGGL((igemm_run_kernel<1, 4, 2>), dim3(grid), dim3(256), lds, st, p, nfrag);
+      else hipLaunchKernelGGL((igemm_run_kernel<2, 4, 2>), dim3(grid), dim3(256), lds, st, p, nfrag);
       A2C_CHECK_LAUNCH();
       return A2C_OK;
     }
+  }
+  if (run) {   // generic kernel on a run-ordered layer: steps walk (c4, ky, kx)
+    p.nb = d->ks; p.c4n = d->ks;                      // walker levels: outer c4, mid ky, inner kx
+    p.step_a = 4 * t.PLANE; p.step_b = t.WP; p.step_c = 1;
+    return launch_igemm(p, MT, a2c_s(stream));
   }
   p.step_a = t.WP; p.step_c = 4 * t.PLANE;
   return launch_igemm(p, MT, a2c_s(stream));

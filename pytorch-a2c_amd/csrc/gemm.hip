@@ -165,7 +165,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const long tot = M * N;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < tot; i += gridDim.x * 256L) {
     float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += slab[(long)z * tot + i];
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {      // 8 independent loads in flight, summed in fixed order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = slab[(long)(z + u) * tot + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; z < splits; ++z) v += slab[(long)z * tot + i];
     const long m = i / N, n = i - m * N;
     if (accumulate) v += C[m * ldc + n];
     if (bias) v += bias[n];
@@ -197,6 +205,109 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
   out[n] = s;
 }
 
+// ---- skinny layers (policy / value heads: N <= 8 outputs).  y[m, n] = x[m,:] . W[n,:] + b[n]:
+// one wave per row, 16 B per lane, butterfly reduce.  Memory-bound on x.
+constexpr int SN_MAX = 8;
+__global__ __launch_bounds__(256) void small_n_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                          const float* __restrict__ W, const float* __restrict__ b,
+                                                          float* __restrict__ y, long ldy, long M, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const long row0 = blockIdx.x * 4L + (threadIdx.x >> 6);
+  for (long m = row0; m < M; m += gridDim.x * 4L) {
+    float acc[SN_MAX];
+#pragma unroll
+    for (int n = 0; n < SN_MAX; ++n) acc[n] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {           // K % 4 == 0, 16 B aligned rows (checked by the launcher)
+      const float4 xv = *reinterpret_cast<const float4*>(x + m * ldx + k);
+#pragma unroll
+      for (int n = 0; n < SN_MAX; ++n)
+        if (n < N) {
+          const float4 wv = *reinterpret_cast<const float4*>(W + (long)n * K + k);
+          acc[n] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < SN_MAX; ++n)
+      if (n < N) {
+        const float v = wave_sum(acc[n]);
+        if (lane == 0) y[m * ldy + n] = v + (b ? b[n] : 0.f);
+      }
+  }
+}
+
+// dx[m, k] (+)= sum_n dy[m, n] W[n, k]   (n < N <= 8), optional ReLU-derivative mask
+__global__ __launch_bounds__(256) void small_n_bwd_data_kernel(const float* __restrict__ dy, long ldy,
+                                                               const float* __restrict__ W, float* __restrict__ dx,
+                                                               long ldx, const float* __restrict__ mask, long ldmask,
+                                                               long M, int N, int K, int accumulate) {
+  const long tot = M * (K >> 2);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < tot; i += gridDim.x * 256L) {
+    const long m = i / (K >> 2);
+    const int k = (int)(i - m * (K >> 2)) << 2;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = 0; n < N; ++n) {
+      const float g = dy[m * ldy + n];
+      const float4 wv = *reinterpret_cast<const float4*>(W + (long)n * K + k);
+      a.x += g * wv.x; a.y += g * wv.y; a.z += g * wv.z; a.w += g * wv.w;
+    }
+    float4* o = reinterpret_cast<float4*>(dx + m * ldx + k);
+    if (accumulate) { const float4 c = *o; a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; }
+    if (mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(mask + m * ldmask + k);
+      if (!(mk.x > 0.f)) a.x = 0.f;
+      if (!(mk.y > 0.f)) a.y = 0.f;
+      if (!(mk.z > 0.f)) a.z = 0.f;
+      if (!(mk.w > 0.f)) a.w = 0.f;
+    }
+    *o = a;
+  }
+}
+
+// dW[n, k] = sum_m dy[m, n] x[m, k]: each workgroup owns a band of rows and all of (N, K<=1024)
+// with thread t holding columns k = 4t..4t+3; partial slabs [band][N][K] + fixed-order reduce.
+constexpr int SN_BANDS = 512;
+__global__ __launch_bounds__(256) void small_n_bwd_weight_kernel(const float* __restrict__ dy, long ldy,
+                                                                 const float* __restrict__ x, long ldx,
+                                                                 float* __restrict__ part, long M, int N, int K) {
+  const long rows_per = (M + gridDim.x - 1) / gridDim.x;
+  const long r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+  const int k = threadIdx.x * 4;
+  float4 acc[SN_MAX];
+#pragma unroll
+  for (int n = 0; n < SN_MAX; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < K)
+    for (long m = r0; m < r1; ++m) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + m * ldx + k);
+#pragma unroll
+      for (int n = 0; n < SN_MAX; ++n)
+        if (n < N) {
+          const float g = dy[m * ldy + n];
+          acc[n].x += g * xv.x; acc[n].y += g * xv.y; acc[n].z += g * xv.z; acc[n].w += g * xv.w;
+        }
+    }
+  if (k < K) {
+#pragma unroll
+    for (int n = 0; n < SN_MAX; ++n)
+      if (n < N) *reinterpret_cast<float4*>(part + ((long)blockIdx.x * N + n) * K + k) = acc[n];
+  }
+}
+__global__ __launch_bounds__(256) void small_n_bwd_weight_reduce(const float* __restrict__ part, int bands, long per,
+                                                                 float* __restrict__ dW) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += gridDim.x * 256L) {
+    float v = 0.f;
+    int z = 0;
+    for (; z + 8 <= bands; z += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = part[(long)(z + u) * per + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; z < bands; ++z) v += part[(long)z * per + i];
+    dW[i] = v;
+  }
+}
+
 template <bool A_KC, bool B_KC>
 void launch_gemm(dim3 grid, hipStream_t st, long M, long N, long K, const float* A, long lda, const float* B, long ldb,
                  float* C, long ldc, const float* bias, int relu, const float* mask, long ldmask, int acc, long kps,
@@ -208,7 +319,12 @@ void launch_gemm(dim3 grid, hipStream_t st, long M, long N, long K, const float*
 
 extern "C" {
 size_t a2c_gemm_ws_bytes(int64_t M, int64_t N, int splitk) {
-  return splitk > 1 ? (size_t)splitk * (size_t)M * (size_t)N * sizeof(float) : 0;
+  size_t need = splitk > 1 ? (size_t)splitk * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (M <= SN_MAX) {                      // the skinny weight-gradient path wants SN_BANDS slabs
+    const size_t sn = (size_t)SN_BANDS * (size_t)M * (size_t)N * sizeof(float);
+    if (sn > need) need = sn;
+  }
+  return need;
 }
 
 int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -217,6 +333,37 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   if (M < 0 || N < 0 || K < 0) return A2C_ERR_ARG;
   if (M == 0 || N == 0) return A2C_OK;
   if (!A || !B || !C || K == 0) return A2C_ERR_ARG;
+  hipStream_t st0 = a2c_s(stream);
+  const bool al16 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0);
+  // skinny fast paths (heads): exact same maths, fp32 FMA chains in a different (fixed) order
+  if (transA == 0 && transB == 1 && N <= SN_MAX && K % 4 == 0 && lda % 4 == 0 && ldb == K && !relu && !mask &&
+      !accumulate && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0)) {
+    hipLaunchKernelGGL(small_n_fwd_kernel, dim3(a2c_grid_1d(M, 4, 4096)), dim3(256), 0, st0, A, (long)lda, B, bias, C,
+                       (long)ldc, (long)M, (int)N, (int)K);
+    A2C_CHECK_LAUNCH();
+    return A2C_OK;
+  }
+  if (transA == 0 && transB == 0 && K <= SN_MAX && N % 4 == 0 && ldb == N && ldc % 4 == 0 && !relu && !bias &&
+      (!mask || ldmask % 4 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) &&
+      (!mask || (uintptr_t)mask % 16 == 0)) {
+    hipLaunchKernelGGL(small_n_bwd_data_kernel, dim3(a2c_grid_1d(M * (N / 4), 256)), dim3(256), 0, st0, A, (long)lda, B,
+                       C, (long)ldc, mask, (long)ldmask, (long)M, (int)K, (int)N, accumulate);
+    A2C_CHECK_LAUNCH();
+    return A2C_OK;
+  }
+  if (transA == 1 && transB == 0 && M <= SN_MAX && N % 4 == 0 && N <= 1024 && ldb % 4 == 0 && ldc == N && !relu &&
+      !bias && !mask && !accumulate && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && ws &&
+      ws_bytes >= (size_t)SN_BANDS * M * N * sizeof(float)) {
+    const int bands = (int)(K < SN_BANDS ? K : SN_BANDS);
+    hipLaunchKernelGGL(small_n_bwd_weight_kernel, dim3(bands), dim3(256), 0, st0, A, (long)lda, B, (long)ldb, (float*)ws,
+                       (long)K, (int)M, (int)N);
+    A2C_CHECK_LAUNCH();
+    hipLaunchKernelGGL(small_n_bwd_weight_reduce, dim3(a2c_grid_1d(M * N, 256)), dim3(256), 0, st0, (const float*)ws,
+                       bands, (long)(M * N), C);
+    A2C_CHECK_LAUNCH();
+    return A2C_OK;
+  }
+  (void)al16;
   if (splitk < 1) splitk = 1;
   long kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;  // multiple of BK keeps 16 B alignment of k0
   splitk = (int)((K + kps - 1) / kps);

@@ -297,6 +297,31 @@ def test_gemm_f32(tA, tB, M, N, K):
         close(f"epilogue sk={sk}", Cx, ref, 5 * scale, 1e-5)
 
 
+def test_gemm_skinny_head_paths():
+    """N <= 8 layers (policy/value heads) take dedicated wave-per-row kernels"""
+    ops = _ops()
+    M, A, h = 1000, 3, 256
+    emb = rnd((M, h), 87).to(DEV)
+    Wh = rnd((A + 1, h), 88).to(DEV)
+    bh = rnd((A + 1,), 89).to(DEV)
+    heads = torch.zeros(M, A + 1, device=DEV)
+    ops.gemm(0, 1, M, A + 1, h, emb.data_ptr(), h, Wh.data_ptr(), h, heads.data_ptr(), A + 1, bias=bh)
+    close("heads fwd", heads, emb.cpu().double() @ Wh.cpu().double().t() + bh.cpu().double(), 1e-5, 1e-5)
+    dh = rnd((M, A + 1), 90).to(DEV)
+    demb = torch.full((M, h), float("nan"), device=DEV)
+    mask = rnd((M, h), 91).to(DEV)
+    ops.gemm(0, 0, M, h, A, dh.data_ptr(), A + 1, Wh.data_ptr(), h, demb.data_ptr(), h, mask_ptr=mask.data_ptr(), ldmask=h)
+    ref = (dh[:, :A].cpu().double() @ Wh[:A].cpu().double()) * (mask.cpu() > 0)
+    close("heads bwd_data", demb, ref, 1e-5, 1e-5)
+    ops.gemm(0, 0, M, h, A, dh.data_ptr(), A + 1, Wh.data_ptr(), h, demb.data_ptr(), h, accumulate=True)
+    close("heads bwd_data acc", demb, ref + dh[:, :A].cpu().double() @ Wh[:A].cpu().double(), 1e-5, 1e-5)
+    dW = torch.full((A + 1, h), float("nan"), device=DEV)
+    ws = torch.empty(ops.gemm_ws_bytes(A + 1, h, 2) // 4, device=DEV)
+    ops.gemm(1, 0, A + 1, h, M, dh.data_ptr(), A + 1, emb.data_ptr(), h, dW.data_ptr(), h, splitk=2, ws=ws)
+    want = dh.cpu().double().t() @ emb.cpu().double()
+    close("heads bwd_weight", dW, want, 1e-5 * float(want.abs().max()), 1e-5)
+
+
 def test_gemm_strided_views_and_colsum():
     ops = _ops()
     M, N, K = 70, 5, 33

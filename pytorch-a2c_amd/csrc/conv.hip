@@ -640,19 +640,213 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
   }
 }
 
+// "Row-run" weight-gradient kernel for the unpadded layers (ks = 2*S: 8x8/s4, 4x4/s2), software
+// pipelined like igemm_run_kernel.  kx = kxh*S + kxl: for a fixed (ci, ky, kxh) the S taps kxl are
+// S contiguous floats at column S*(ox + kxh), so ONE ds_read_b128 (b64) per lane yields the B
+// operands of S different k-tiles for the same pixel.  Lanes j of a "row group" enumerate the
+// 16 (ci, ky, kxh) combinations cidx = rg*16 + j = (ci*ks + ky)*2 + kxh; wave w owns row groups
+// w, w+4, ...  (conv1: one input plane per wave).  Per MFMA step (4 pixels): MT b32 reads of
+// dOut + RGW vector reads feed MT*RGW*S MFMAs.
+constexpr int PF_D = 12;             // dOut prefetch registers per thread (256*12 floats per tile)
+
+struct WrunP {
+  StageP st;                      // input image (fast layout, WP == IW)
+  const float* dout; float* slab;
+  int Cout, K, ks, OH, OW, OWp, TPH, tiles, B, PLANEo;
+};
+
+template <int MT, int S, int RGW, int C4N>
+__global__ __launch_bounds__(256) void wgrad_run_kernel(WrunP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kk = lane >> 4, j = lane & 15;
+  const int WP = p.st.WP, PLANE = p.st.PLANE;
+  const int in_floats = p.st.Cp * PLANE;
+  float* __restrict__ img = lds;
+  float* __restrict__ ldo = lds + in_floats;          // dOut tile: [MT*16][PLANEo]
+  const int lds_total = in_floats + MT * 16 * p.PLANEo + 64;
+  for (int i = tid; i < lds_total; i += 256) lds[i] = 0.f;          // padding stays 0 (finite) forever
+
+  // this lane's (ci, ky, kxh) per row group -> image offset and natural weight index of kxl = 0
+  int boff[RGW], knat[RGW];
+#pragma unroll
+  for (int q = 0; q < RGW; ++q) {
+    const int cidx = (w + 4 * q) * 16 + j;
+    const int kxh = cidx & 1, cy = cidx >> 1;
+    const int ci = cy / p.ks, ky = cy - ci * p.ks;
+    boff[q] = ci * PLANE + ky * WP + kxh * S + kk * S;                 // + pixel (4*c4 + kk) of the step
+    knat[q] = (ci * p.ks + ky) * p.ks + kxh * S;
+  }
+  f32x4 acc[MT][RGW][S];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < RGW; ++q)
+#pragma unroll
+      for (int x = 0; x < S; ++x) acc[m][q][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int Cm = MT * 16, nparts = 256 / Cm;
+  const int bco = tid % Cm, bpart = tid / Cm;
+  float dbacc = 0.f;
+
+  // prefetch maps (tile independent): image float4s and dOut floats of this thread
+  const int per4 = (p.st.TIH * p.st.IW) >> 2;
+  const int tot4 = p.st.Cp * per4;
+  int idst[PF_N], isrc[PF_N], irem[PF_N];
+#pragma unroll
+  for (int u = 0; u < PF_N; ++u) {
+    const int idx = tid + u * 256;
+    idst[u] = -1; isrc[u] = 0; irem[u] = 0;
+    if (idx < tot4) {
+      const int c = idx / per4, rem = idx - c * per4;
+      idst[u] = c * PLANE + (rem << 2);
+      isrc[u] = c * p.st.IH * p.st.IW + (rem << 2);
+      irem[u] = rem;
+    }
+  }
+  const int dper = p.TPH * p.OW;                      // dOut floats per channel per full tile
+  int ddst[PF_D], dsrc[PF_D], drow[PF_D];
+#pragma unroll
+  for (int u = 0; u < PF_D; ++u) {
+    const int idx = tid + u * 256;
+    ddst[u] = -1; dsrc[u] = 0; drow[u] = 0;
+    if (idx < p.Cout * dper) {
+      const int co = idx / dper, e = idx - co * dper;
+      const int r = e / p.OW, x = e - r * p.OW;
+      ddst[u] = co * p.PLANEo + r * p.OWp + x;
+      dsrc[u] = co * p.OH * p.OW + e;
+      drow[u] = r;
+    }
+  }
+  float4 pfi[PF_N];
+  float pfd[PF_D];
+  const long total = (long)p.B * p.tiles;
+  auto issue = [&](long tile) {
+    const long b = tile / p.tiles;
+    const int ti = (int)(tile - b * p.tiles);
+    const int q0 = ti * p.TPH;
+    const int y_lo = q0 * S;
+    const int ok4 = (min(p.st.TIH, p.st.IH - y_lo) * p.st.IW) >> 2;
+    const int rows = min(p.TPH, p.OH - q0);
+    const float* __restrict__ ib = p.st.src + b * p.st.bstride + (long)y_lo * p.st.IW;
+    const float* __restrict__ db = p.dout + (b * p.Cout * p.OH + q0) * (long)p.OW;
+#pragma unroll
+    for (int u = 0; u < PF_N; ++u) {
+      pfi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idst[u] >= 0 && irem[u] < ok4) pfi[u] = *reinterpret_cast<const float4*>(ib + isrc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < PF_D; ++u) {
+      pfd[u] = 0.f;
+      if (ddst[u] >= 0 && drow[u] < rows) pfd[u] = db[dsrc[u]];
+    }
+  };
+  long tile = blockIdx.x;
+  if (tile < total) issue(tile);
+  for (; tile < total; tile += gridDim.x) {
+    const int ti = (int)(tile % p.tiles);
+    const int rows = min(p.TPH, p.OH - ti * p.TPH);
+    __syncthreads();                       // readers of the previous tile (and the zero fill) are done
+#pragma unroll
+    for (int u = 0; u < PF_N; ++u)
+      if (idst[u] >= 0) *reinterpret_cast<float4*>(img + idst[u]) = pfi[u];
+#pragma unroll
+    for (int u = 0; u < PF_D; ++u)
+      if (ddst[u] >= 0) ldo[ddst[u]] = pfd[u];     // rows past the bottom were loaded as 0
+    __syncthreads();
+    if (tile + gridDim.x < total) issue(tile + gridDim.x);     // in flight during the MFMA phase below
+    if (bpart < nparts && bco < p.Cout) {          // bias partial sums over this tile
+      const float* pl = ldo + bco * p.PLANEo;
+      const int n = rows * p.OWp;
+      float s = 0.f;
+      for (int i = bpart; i < n; i += nparts) s += pl[i];
+      dbacc += s;
+    }
+    for (int r = 0; r < rows; ++r) {
+      const float* __restrict__ arow = ldo + j * p.PLANEo + r * p.OWp + kk;
+      const float* __restrict__ brow = img + r * S * WP;
+      float av[C4N][MT];
+      float bv[C4N][RGW][S];
+#pragma unroll
+      for (int c4 = 0; c4 < C4N; ++c4) {           // all LDS reads of the pixel row first ...
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[c4][m] = arow[m * 16 * p.PLANEo + 4 * c4];
+#pragma unroll
+        for (int q = 0; q < RGW; ++q) {
+          const float* src = brow + boff[q] + 4 * c4 * S;
+          if (S == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(src);
+            bv[c4][q][0] = t.x; bv[c4][q][1] = t.y; bv[c4][q][2] = t.z; bv[c4][q][3] = t.w;
+          } else {
+            const float2 t = *reinterpret_cast<const float2*>(src);
+            bv[c4][q][0] = t.x; bv[c4][q][1] = t.y;
+          }
+        }
+      }
+#pragma unroll
+      for (int c4 = 0; c4 < C4N; ++c4)             // ... then its MFMAs
+#pragma unroll
+        for (int q = 0; q < RGW; ++q)
+#pragma unroll
+          for (int x = 0; x < S; ++x)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[m][q][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c4][m], bv[c4][q][x], acc[m][q][x], 0, 0, 0);
+    }
+  }
+  // partials: D row (co) = 4*(lane>>4)+reg, col = lane&15 -> k = knat[q] + kxl
+  float* sl = p.slab + (long)blockIdx.x * ((long)p.Cout * p.K + p.Cout);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < RGW; ++q)
+#pragma unroll
+      for (int x = 0; x < S; ++x)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int co = m * 16 + 4 * kk + rr;
+          if (co < p.Cout) sl[(long)co * p.K + knat[q] + x] = acc[m][q][x][rr];
+        }
+  __syncthreads();
+  float* red = lds;   // reuse: [nparts][Cm]
+  if (bpart < nparts) red[bpart * Cm + bco] = dbacc;
+  __syncthreads();
+  if (tid < p.Cout) {
+    float s = 0.f;
+    for (int q = 0; q < nparts; ++q) s += red[q * Cm + tid];
+    sl[(long)p.Cout * p.K + tid] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, long per,
                                                            long nW, float* __restrict__ dW, float* __restrict__ db) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += gridDim.x * 256L) {
     float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += slab[(long)z * per + i];
+    int z = 0;
+    for (; z + 8 <= nslab; z += 8) {       // 8 independent loads in flight, fixed summation order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = slab[(long)(z + u) * per + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; z < nslab; ++z) s += slab[(long)z * per + i];
     if (i < nW) dW[i] = s;
     else if (db) db[i - nW] = s;
   }
 }
 
-struct WgradPlan { SrcTile t; int OWp, PLANEo, MT, KTW, grid; size_t lds; };
+struct WgradPlan { SrcTile t; int OWp, PLANEo, MT, KTW, grid, run; size_t lds; };
 
-static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl) {
+// which wgrad_run_kernel instantiation (if any) fits the layer: 1 = <1,4,1,5>, 2 = <2,2,2,3>
+static int wgrad_run_variant(const a2c_conv_desc* d) {
+  if (!run_layout(d) || getenv("A2C_NO_PF")) return 0;
+  const int mt = ceil_div(d->Cout, 16), c4n = ceil_div(d->OW, 4), rgs = d->Cin * d->ks * 2 / 16;
+  if (d->stride == 4 && mt == 1 && rgs == 4 && c4n == 5) return 1;
+  if (d->stride == 2 && mt == 2 && rgs == 8 && c4n == 3) return 2;
+  return 0;
+}
+
+static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl, bool allow_run = true) {
   SrcTile& t = pl.t;
   t.Cp = d->Cin; t.IH = d->H; t.IW = d->W; t.SY = d->stride; t.SX = d->stride;
   t.sy0 = -d->pad; t.sx0 = -d->pad; t.span_y = d->ks; t.span_x = d->ks; t.PH = d->OH;
@@ -661,6 +855,31 @@ static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl) {
   // (OWp-OW)*S <= 12 floats past a row end, i.e. into the next row / the >= 16-float plane slack,
   // all of which hold finite values (0 * finite = 0), so the image itself is planned unpadded.
   t.PW = d->OW;
+  pl.run = allow_run ? wgrad_run_variant(d) : 0;
+  if (pl.run) {
+    pl.MT = ceil_div(d->Cout, 16); pl.KTW = 0;
+    int tph = 0;
+    for (int c = 1; c <= d->OH; ++c) {
+      const int tih = (c - 1) * d->stride + d->ks;
+      const int plane = ((tih * d->W + 63) / 64) * 64;
+      const int planeo = ((c * pl.OWp + 31) / 32) * 32 + 2;
+      const long bytes = 4L * ((long)d->Cin * plane + (long)pl.MT * 16 * planeo + 64);
+      if ((long)d->Cin * tih * d->W <= 256L * PF_N * 4 && (long)d->Cout * c * d->OW <= 256L * PF_D &&
+          bytes <= WGRAD_LDS_BUDGET) tph = c; else break;
+    }
+    if (tph >= 1) {
+      t.WP = t.IW; t.TPH = tph; t.TIH = (tph - 1) * d->stride + d->ks;
+      t.PLANE = ((t.TIH * t.WP + 63) / 64) * 64;
+      t.tiles = ceil_div(t.PH, t.TPH);
+      pl.PLANEo = ((t.TPH * pl.OWp + 31) / 32) * 32 + 2;
+      pl.lds = 4 * ((size_t)t.Cp * t.PLANE + (size_t)pl.MT * 16 * pl.PLANEo + 64);
+      const void* k = pl.run == 1 ? (const void*)wgrad_run_kernel<1, 4, 1, 5> : (const void*)wgrad_run_kernel<2, 2, 2, 3>;
+      if (pl.lds > 64 * 1024) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+      pl.grid = resident_grid(k, pl.lds, (long)B * t.tiles);
+      return true;
+    }
+    pl.run = 0;
+  }
   const int mt = ceil_div(d->Cout, 16);
   const int nkt = ceil_div(d->Cin * d->ks * d->ks, 16);
   const int ktw = ceil_div(nkt, 4);
@@ -829,18 +1048,35 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
 }
 
 size_t a2c_conv2d_bwd_weight_ws_bytes(const a2c_conv_desc* d, int B) {
-  WgradPlan pl;
-  if (!desc_ok(d) || B < 0 || !plan_wgrad(d, B, pl)) return 0;
-  return (size_t)pl.grid * ((size_t)d->Cout * d->Cin * d->ks * d->ks + d->Cout) * sizeof(float);
+  WgradPlan pl, pg;
+  if (!desc_ok(d) || B < 0 || !plan_wgrad(d, B, pl) || !plan_wgrad(d, B, pg, false)) return 0;
+  const int grid = pl.grid > pg.grid ? pl.grid : pg.grid;     // either kernel may be picked at launch
+  return (size_t)grid * ((size_t)d->Cout * d->Cin * d->ks * d->ks + d->Cout) * sizeof(float);
 }
 
 int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* dout, float* dW,
                           float* db, int B, void* ws, size_t ws_bytes, a2c_stream_t stream) {
   WgradPlan pl;
   if (!desc_ok(d) || B < 1 || !in || !dout || !dW) return A2C_ERR_ARG;
-  if (!plan_wgrad(d, B, pl)) return A2C_ERR_ARG;
+  const bool aligned = (in_bstride % 4 == 0) && ((uintptr_t)in % 16 == 0);
+  if (!plan_wgrad(d, B, pl, aligned)) return A2C_ERR_ARG;
   if (!ws || ws_bytes < a2c_conv2d_bwd_weight_ws_bytes(d, B)) return A2C_ERR_WORKSPACE;
   hipStream_t st = a2c_s(stream);
+  if (pl.run) {
+    WrunP q;
+    fill_stage(q.st, pl.t, in, in_bstride);
+    q.dout = dout; q.slab = (float*)ws;
+    q.Cout = d->Cout; q.K = d->Cin * d->ks * d->ks; q.ks = d->ks; q.OH = d->OH; q.OW = d->OW; q.OWp = pl.OWp;
+    q.TPH = pl.t.TPH; q.tiles = pl.t.tiles; q.B = B; q.PLANEo = pl.PLANEo;
+    if (pl.run == 1) hipLaunchKernelGGL((wgrad_run_kernel<1, 4, 1, 5>), dim3(pl.grid), dim3(256), pl.lds, st, q);
+    else hipLaunchKernelGGL((wgrad_run_kernel<2, 2, 2, 3>), dim3(pl.grid), dim3(256), pl.lds, st, q);
+    A2C_CHECK_LAUNCH();
+    const long nWr = (long)q.Cout * q.K, perr = nWr + q.Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(perr, 256)), dim3(256), 0, st, (const float*)ws, pl.grid,
+                       perr, nWr, dW, db);
+    A2C_CHECK_LAUNCH();
+    return A2C_OK;
+  }
   WgradP p;
   fill_stage(p.st, pl.t, in, in_bstride);
   p.dout = dout; p.slab = (float*)ws;

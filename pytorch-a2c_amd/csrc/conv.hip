@@ -640,6 +640,158 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
   }
 }
 
+// Backward-data for the unpadded ks = 2*S layers with ALL S*S output-parity classes fused into one
+// launch: a workgroup stages one sample's dOut (Cout x OH x OW, a contiguous run in HBM) ONCE into
+// a zero-haloed LDS image, then walks the classes; every class is a (ks/S)^2-tap stride-1
+// correlation (class fragments + tables in `cls`).  Software pipelined like igemm_run_kernel:
+// the next sample's dOut is in flight during the MFMA phase; class weight fragments live in LDS.
+constexpr int PF_B = 3;              // float4 prefetch registers per thread (256*3*4 = 3072 dOut floats)
+constexpr int MAX_CLS = 4;
+
+struct BwdClass { int frag_off, nsteps, PH, PW, oy_add, ox_add; };
+struct BwdFusedP {
+  const float* dout; float* din; const float* mask; const float* wfrag;
+  int Cout, OH, OW, Cin, H, W, S, B;
+  int WP, PLANE, nfrag, ncls, nb, c4n, off0, step_a, step_b, step_c;
+  BwdClass cls[MAX_CLS];
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void bwd_fused_kernel(BwdFusedP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ ldsA = lds;
+  float* __restrict__ img = lds + p.nfrag;
+  float* __restrict__ outb = img + p.Cout * p.PLANE + 64;      // dX of the sample, [Cin][H*W], flushed coalesced
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int WP = p.WP, PLANE = p.PLANE;
+  const int HW = p.H * p.W;
+  for (int i = tid; i < p.nfrag; i += 256) ldsA[i] = p.wfrag[i];
+  for (int i = tid; i < p.Cout * PLANE + 64; i += 256) img[i] = 0.f;       // halo stays 0 forever
+  // prefetch map: the sample is Cout*OH*OW contiguous floats; element e -> haloed image position
+  const int nel = p.Cout * p.OH * p.OW;
+  int dst[PF_B][4];
+#pragma unroll
+  for (int u = 0; u < PF_B; ++u)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int e = ((tid + u * 256) << 2) + c;
+      dst[u][c] = -1;
+      if (e < nel) {
+        const int co = e / (p.OH * p.OW), rem = e - co * p.OH * p.OW;
+        const int y = rem / p.OW, x = rem - y * p.OW;
+        dst[u][c] = co * PLANE + (y + 1) * WP + x + 1;
+      }
+    }
+  const bool vec_ok = (nel % 4 == 0);
+  float4 pf[PF_B];
+  auto issue = [&](long b) {
+    const float* __restrict__ src = p.dout + b * nel;
+#pragma unroll
+    for (int u = 0; u < PF_B; ++u) {
+      const int e = (tid + u * 256) << 2;
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec_ok && e + 3 < nel) pf[u] = *reinterpret_cast<const float4*>(src + e);
+      else {
+        if (e + 0 < nel) pf[u].x = src[e + 0];
+        if (e + 1 < nel) pf[u].y = src[e + 1];
+        if (e + 2 < nel) pf[u].z = src[e + 2];
+        if (e + 3 < nel) pf[u].w = src[e + 3];
+      }
+    }
+  };
+  long b = blockIdx.x;
+  if (b < p.B) issue(b);
+  for (; b < p.B; b += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PF_B; ++u) {
+      if (dst[u][0] >= 0) img[dst[u][0]] = pf[u].x;
+      if (dst[u][1] >= 0) img[dst[u][1]] = pf[u].y;
+      if (dst[u][2] >= 0) img[dst[u][2]] = pf[u].z;
+      if (dst[u][3] >= 0) img[dst[u][3]] = pf[u].w;
+    }
+    __syncthreads();
+    if (b + gridDim.x < p.B) issue(b + gridDim.x);
+    for (int c = 0; c < p.ncls; ++c) {
+      const BwdClass& k = p.cls[c];
+      const int NP = k.PH * k.PW;
+      const int npairs = (NP + 31) >> 5;
+      const float* __restrict__ la = ldsA + k.frag_off + lane;
+      for (int pr = w; pr < npairs; pr += 4) {
+        const int idx0 = pr * 32 + j, idx1 = idx0 + 16;
+        const bool ok0 = idx0 < NP, ok1 = idx1 < NP;
+        const int i0 = ok0 ? idx0 : 0, i1 = ok1 ? idx1 : 0;
+        const int r0 = i0 / k.PW, c0 = i0 - r0 * k.PW;
+        const int r1 = i1 / k.PW, c1 = i1 - r1 * k.PW;
+        const float* __restrict__ l0 = img + r0 * WP + c0 + g * PLANE;
+        const float* __restrict__ l1 = img + r1 * WP + c1 + g * PLANE;
+        f32x4 acc[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        int off = p.off0, bi = 0, ci = 0;
+        for (int s0 = 0; s0 < k.nsteps; s0 += CH) {       // nsteps % CH == 0 on this path
+          float bv0[CH], bv1[CH], av[CH * MT];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            bv0[u] = l0[off];
+            bv1[u] = l1[off];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[u * MT + m] = la[((s0 + u) * MT + m) * 64];
+            ++ci;
+            const bool w1 = (ci == p.c4n);
+            ci = w1 ? 0 : ci;
+            bi += w1 ? 1 : 0;
+            const bool w2 = (bi == p.nb);
+            bi = w2 ? 0 : bi;
+            off += p.step_c + (w1 ? p.step_b - p.c4n * p.step_c : 0) + (w2 ? p.step_a - p.nb * p.step_b : 0);
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u * MT + m], bv0[u], acc[m][0], 0, 0, 0);
+              acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u * MT + m], bv1[u], acc[m][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if (!(nt ? ok1 : ok0)) continue;
+          const int r = nt ? r1 : r0, cc = nt ? c1 : c0;
+          const int pix = (r * p.S + k.oy_add) * p.W + cc * p.S + k.ox_add;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int ch = m * 16 + 4 * g + rr;
+              if (ch < p.Cin) outb[ch * HW + pix] = acc[m][nt][rr];
+            }
+        }
+      }
+    }
+    __syncthreads();                                            // every class has landed in outb
+    {  // coalesced flush: 16 B per lane, ReLU-derivative mask of the layer below fused in
+      const int n4 = (p.Cin * HW) >> 2;
+      float4* __restrict__ o4 = reinterpret_cast<float4*>(p.din + b * (long)p.Cin * HW);
+      const float4* __restrict__ m4 = p.mask ? reinterpret_cast<const float4*>(p.mask + b * (long)p.Cin * HW) : nullptr;
+      for (int i = tid; i < n4; i += 256) {
+        float4 v = *reinterpret_cast<const float4*>(outb + (i << 2));
+        if (m4) {
+          const float4 mk = m4[i];
+          if (!(mk.x > 0.f)) v.x = 0.f;
+          if (!(mk.y > 0.f)) v.y = 0.f;
+          if (!(mk.z > 0.f)) v.z = 0.f;
+          if (!(mk.w > 0.f)) v.w = 0.f;
+        }
+        o4[i] = v;
+      }
+    }
+  }
+}
+
 // "Row-run" weight-gradient kernel for the unpadded layers (ks = 2*S: 8x8/s4, 4x4/s2), software
 // pipelined like igemm_run_kernel.  kx = kxh*S + kxl: for a fixed (ci, ky, kxh) the S taps kxl are
 // S contiguous floats at column S*(ox + kxh), so ONE ds_read_b128 (b64) per lane yields the B
@@ -1017,6 +1169,39 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
   if (B == 0) return A2C_OK;
   if (!dout || !wprep_bwd || !din) return A2C_ERR_ARG;
   const int S = d->stride, P = d->pad;
+  {  // fused-class pipelined path (unpadded ks = 2S layers whose dOut sample fits the prefetch registers)
+    const int MTb = ceil_div(d->Cin, 16), c4n = d->Cout / 4;
+    const size_t nfrag = bwd_class_offset(d, S * S);
+    const int nel = d->Cout * d->OH * d->OW;
+    if (run_layout(d) && S * S <= MAX_CLS && MTb <= 2 && nel <= 256 * 4 * PF_B && (4 * c4n) % CH == 0 &&
+        nfrag * 4 <= 48 * 1024 && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)din % 16 == 0) &&
+        (!mask || (uintptr_t)mask % 16 == 0) && (d->H * d->W) % 4 == 0 && !getenv("A2C_NO_PF")) {
+      BwdFusedP q;
+      q.dout = dout; q.din = din; q.mask = mask; q.wfrag = wprep_bwd;
+      q.Cout = d->Cout; q.OH = d->OH; q.OW = d->OW; q.Cin = d->Cin; q.H = d->H; q.W = d->W; q.S = S; q.B = B;
+      q.WP = d->OW + 2;
+      q.PLANE = (((d->OH + 2) * q.WP + 31) / 32) * 32 + 16;
+      q.nfrag = (int)nfrag; q.ncls = S * S; q.nb = 2; q.c4n = c4n;
+      q.off0 = q.WP + 1; q.step_a = -q.WP; q.step_b = -1; q.step_c = 4 * q.PLANE;
+      for (int cls = 0; cls < S * S; ++cls) {
+        const int ry = cls / S, rx = cls % S;
+        q.cls[cls].frag_off = (int)bwd_class_offset(d, cls);
+        q.cls[cls].nsteps = 4 * c4n;
+        q.cls[cls].PH = (d->H - 1 - ry) / S + 1;
+        q.cls[cls].PW = (d->W - 1 - rx) / S + 1;
+        q.cls[cls].oy_add = ry; q.cls[cls].ox_add = rx;
+      }
+      const size_t lds = 4 * (nfrag + (size_t)d->Cout * q.PLANE + 64 + (size_t)d->Cin * d->H * d->W);
+      if (lds > LDS_HARD_MAX) return A2C_ERR_ARG;
+      const void* k = MTb == 1 ? (const void*)bwd_fused_kernel<1> : (const void*)bwd_fused_kernel<2>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const int grid = resident_grid(k, lds, B);
+      if (MTb == 1) hipLaunchKernelGGL(bwd_fused_kernel<1>, dim3(grid), dim3(256), lds, a2c_s(stream), q);
+      else hipLaunchKernelGGL(bwd_fused_kernel<2>, dim3(grid), dim3(256), lds, a2c_s(stream), q);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
   for (int cls = 0; cls < S * S; ++cls) {
     const int ry = cls / S, rx = cls % S;
     const int na = ntaps_1d(d->ks, S, ry), nb = ntaps_1d(d->ks, S, rx);

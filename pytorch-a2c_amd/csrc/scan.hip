@@ -63,6 +63,84 @@ __global__ __launch_bounds__(64) void scan_rows_kernel(const float* __restrict__
   }
 }
 
+// Bandwidth path (T % 4 == 0, 16 B aligned): one wave owns 64 rows and ALL 64 lanes walk (lane j =
+// row j).  The rows are consumed in time chunks of TC = 32 steps from the end; a chunk is 64 row
+// segments of 128 B, loaded 16 B per lane (8 lanes per segment, fully used 128 B lines), transposed
+// through LDS (row stride 33 -> conflict-free column walk) and written back 16 B per lane.  The
+// next chunk's loads are issued before the current chunk is walked, so HBM latency hides under
+// the serial recurrence.  Same operation order as the reference -> bit-identical.
+constexpr int TC = 32;
+constexpr int TCP = TC + 1;
+
+template <int NARR>
+__global__ __launch_bounds__(64) void scan_chunk_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                        const float* __restrict__ dn, float* __restrict__ y0,
+                                                        float* __restrict__ y1, long n_seg, int T, float g0, float g1,
+                                                        int* err) {
+  __shared__ __attribute__((aligned(16))) float s0[64 * TCP], sd[64 * TCP], s1[NARR == 2 ? 64 * TCP : 4];
+  const int lane = threadIdx.x;
+  const int lr = lane >> 3, lc = (lane & 7) << 2;        // this lane's (row within 8, first column) of a load
+  const long n_grp = (n_seg + 63) >> 6;
+  const int nchunk = (T + TC - 1) / TC;
+  for (long grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+    const long row0 = grp << 6;
+    const int rows = (int)min(64L, n_seg - row0);
+    float4 p0[8], pd[8], p1[8];
+    auto issue = [&](int ck) {                            // chunk ck covers t in [lo, lo + TC) clipped to [0, T)
+      const int lo = T - (nchunk - ck) * TC;              // may be negative for the first (partial) chunk
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = i * 8 + lr, t = lo + lc;
+        p0[i] = pd[i] = p1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows && t >= 0) {                         // T % 4 == 0 and lo % 4 == 0: a float4 is all in or all out
+          const long a = (row0 + r) * (long)T + t;
+          p0[i] = *reinterpret_cast<const float4*>(x0 + a);
+          pd[i] = *reinterpret_cast<const float4*>(dn + a);
+          if (NARR == 2) p1[i] = *reinterpret_cast<const float4*>(x1 + a);
+        }
+      }
+    };
+    float r0 = 0.f, r1 = 0.f;
+    issue(nchunk - 1);
+    for (int ck = nchunk - 1; ck >= 0; --ck) {
+      const int lo = T - (nchunk - ck) * TC;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                       // registers -> LDS [row][TCP]
+        const int a = (i * 8 + lr) * TCP + lc;
+        s0[a] = p0[i].x; s0[a + 1] = p0[i].y; s0[a + 2] = p0[i].z; s0[a + 3] = p0[i].w;
+        sd[a] = pd[i].x; sd[a + 1] = pd[i].y; sd[a + 2] = pd[i].z; sd[a + 3] = pd[i].w;
+        if (NARR == 2) { s1[a] = p1[i].x; s1[a + 1] = p1[i].y; s1[a + 2] = p1[i].z; s1[a + 3] = p1[i].w; }
+      }
+      __syncthreads();
+      if (ck > 0) issue(ck - 1);                          // in flight during the walk
+      const int tlo = lo < 0 ? -lo : 0;                   // first valid column of this chunk
+      if (lane < rows) {
+        if (ck == nchunk - 1 && err != nullptr && n_seg > 1 && sd[lane * TCP + TC - 1] != 1.0f) *err = 1;
+#pragma unroll 8
+        for (int c = TC - 1; c >= tlo; --c) {
+          const int a = lane * TCP + c;
+          if (sd[a] == 1.0f) { r0 = 0.f; r1 = 0.f; }
+          r0 = s0[a] + g0 * r0;                           // contraction is off: mul then add, like the reference
+          s0[a] = r0;
+          if (NARR == 2) { r1 = s1[a] + g1 * r1; s1[a] = r1; }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                       // LDS -> HBM, 16 B per lane
+        const int r = i * 8 + lr, t = lo + lc;
+        if (r < rows && t >= 0) {
+          const int a = r * TCP + lc;
+          const long o = (row0 + r) * (long)T + t;
+          *reinterpret_cast<float4*>(y0 + o) = make_float4(s0[a], s0[a + 1], s0[a + 2], s0[a + 3]);
+          if (NARR == 2) *reinterpret_cast<float4*>(y1 + o) = make_float4(s1[a], s1[a + 1], s1[a + 2], s1[a + 3]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // rows longer than the LDS tile: one workgroup per row, time-chunks walked from the end with
 // the running sums carried in registers of lane 0 (exact; used for the flat n_seg==1 form).
 template <int NARR>
@@ -115,7 +193,14 @@ int launch_scan(const float* x0, const float* x1, const float* dn, float* y0, fl
   if (!x0 || !dn || !y0 || (NARR == 2 && (!x1 || !y1))) return A2C_ERR_ARG;
   if (err) (void)hipMemsetAsync(err, 0, sizeof(int), st);
   const int64_t ld = T | 1;
-  if (ld <= TILE) {
+  const bool al16 = (((uintptr_t)x0 | (uintptr_t)dn | (uintptr_t)y0 | (uintptr_t)(NARR == 2 ? x1 : x0) |
+                      (uintptr_t)(NARR == 2 ? y1 : y0)) % 16) == 0;
+  if (T % 4 == 0 && T >= TC && n_seg >= 64 && al16) {
+    const int64_t n_grp = (n_seg + 63) / 64;
+    const int grid = (int)(n_grp < 256 * 6 ? n_grp : 256 * 6);
+    hipLaunchKernelGGL(scan_chunk_kernel<NARR>, dim3(grid), dim3(64), 0, st, x0, x1, dn, y0, y1, (long)n_seg, (int)T, g0,
+                       g1, err);
+  } else if (ld <= TILE) {
     int S = (int)(TILE / ld);
     if (S > 64) S = 64;
     if (S > n_seg) S = (int)n_seg;

@@ -148,6 +148,24 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
                  int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                  const float *bias, int relu, const float *mask, int64_t ldmask, int accumulate,
                  int splitk, void *ws, size_t ws_bytes, a2c_stream_t stream);
+/* Split-K phase only: writes `a2c_gemm_splits(K, splitk)` partial slabs [split][M][N] (dense,
+ * no epilogue) into ws and leaves the fixed-order sum to the consumer (a2c_heads_fused).   */
+int a2c_gemm_splits(int64_t K, int splitk);
+int a2c_gemm_f32_partial(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A,
+                         int64_t lda, const float *B, int64_t ldb, int splitk, void *ws,
+                         size_t ws_bytes, a2c_stream_t stream);
+/* Fused tail of a forward pass (A3CModel: proj_matrx epilogue + pi/value heads + action sampling,
+ * models.py:73,84-85 + runner.py:94-97), one wave per row m:
+ *   x[m,:]  = sum_z xs[z*slab_stride + m*ldx + :]  (z < nslab, fixed order) + bias_in  [ReLU]
+ *   (optionally stored to emb_out[m*ld_emb + :])
+ *   heads[m*ldh + n] = x[m,:] . W[n,:] + b[n]          n < N <= 8, W stored [N][K]
+ *   if u != NULL: actions[m*act_stride] = inverse-CDF sample of softmax(heads[m, :n_logits])
+ * K % 4 == 0, 16 B aligned rows.                                                          */
+int a2c_heads_fused(const float *xs, int nslab, int64_t slab_stride, int64_t ldx,
+                    const float *bias_in, int relu_in, float *emb_out, int64_t ld_emb,
+                    const float *W, const float *b, float *heads, int64_t ldh, int64_t M, int N,
+                    int K, const float *u, int n_logits, int64_t *actions, int64_t act_stride,
+                    a2c_stream_t stream);
 int a2c_gemm_f32_nt(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
                     int64_t ldb, float *C, int64_t ldc, const float *bias, int relu,
                     a2c_stream_t stream);

@@ -44,6 +44,10 @@ SIGNATURES = {
     "a2c_gemm_ws_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "a2c_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64,
                               P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
+    "a2c_gemm_splits": (c_int, [c_int64, c_int]),
+    "a2c_gemm_f32_partial": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, c_int, P, c_size_t, P]),
+    "a2c_heads_fused": (c_int, [P, c_int, c_int64, c_int64, P, c_int, P, c_int64, P, P, P, c_int64, c_int64, c_int, c_int,
+                                 P, c_int, P, c_int64, P]),
     "a2c_gemm_f32_nt": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int, P]),
     "a2c_gemm_f32_nn": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P]),
     "a2c_gemm_f32_tn": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int, P,

@@ -17,6 +17,8 @@ Quirks of the reference that change results and are reproduced (SURVEY.md sectio
   * FCModel / GRUFCModel value head = LayerNorm -> Linear(h,1) -> Linear(1,1) (models.py:392-394).
 Out of scope: ``bnorm=True`` paths, continuous actions, the unused noise helpers.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -226,7 +228,9 @@ class A3CModel(_HipNet):
         self._c1.prep(self.P("convs.0.0.weight"), st)
         self._c2.prep(self.P("convs.1.0.weight"), st)
 
-    def _fwd(self, x_ptr, bstride, B, tag, st, save):
+    _fused_sampling = True       # _fwd(..., sampler=(u, actions_ptr, act_stride)) samples inside the heads kernel
+
+    def _fwd(self, x_ptr, bstride, B, tag, st, save, sampler=None):
         ws, P = self.ws(tag), self.P
         A, h = self.output_space, self.h_size
         a1 = ws.get("a1", (B,) + self._c1.out_shape)
@@ -234,13 +238,26 @@ class A3CModel(_HipNet):
         emb = ws.get("emb", (B, h))
         self._c1.fwd(x_ptr, bstride, P("convs.0.0.bias"), a1, B, st)
         self._c2.fwd(a1.data_ptr(), a1[0].numel(), P("convs.1.0.bias"), a2, B, st)
-        linear_fwd(ws, a2.data_ptr(), self.flat_size, P("proj_matrx.weight"), P("proj_matrx.bias"), emb, B, st)
         hb, logits, vals = self._heads(tag, B)
-        # [pi.weight; value.weight] and [pi.bias | value.bias] are adjacent in the arena: one GEMM
+        # [pi.weight; value.weight] and [pi.bias | value.bias] are adjacent in the arena: one (A+1)-wide head
         Wh = self._arena.params[self._arena.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
         bh = self._arena.params[self._arena.offsets["pi.bias"][0]:][:A + 1]
-        linear_fwd(ws, emb.data_ptr(), h, Wh, bh, hb, B, st)
-        return dict(logits=logits, vals=vals)
+        u, a_ptr, a_stride = sampler if sampler is not None else (None, 0, 0)
+        Wp = P("proj_matrx.weight")
+        sk = ops.pick_splitk(B, h, self.flat_size)
+        if sk > 1 and os.environ.get("A2C_NO_FUSED_TAIL") != "1":
+            # small batch (rollout): split-K slabs are summed by the heads kernel itself -- proj_matrx
+            # epilogue (fixed-order slab sum + bias), both heads and the action sampling in ONE node
+            buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(B, h, sk))
+            with ops.span(f"linear.fwd {h}x{self.flat_size}"):
+                nslab = ops.gemm_partial(0, 1, B, h, self.flat_size, a2.data_ptr(), self.flat_size, Wp.data_ptr(),
+                                         self.flat_size, sk, buf, st)
+            ops.heads_fused(buf.data_ptr(), nslab, B * h, h, P("proj_matrx.bias"), False, emb, Wh, bh, hb, B, u, A,
+                            a_ptr, a_stride, st)
+        else:
+            linear_fwd(ws, a2.data_ptr(), self.flat_size, Wp, P("proj_matrx.bias"), emb, B, st)
+            ops.heads_fused(emb.data_ptr(), 1, 0, h, None, False, None, Wh, bh, hb, B, u, A, a_ptr, a_stride, st)
+        return dict(logits=logits, vals=vals, sampled=u is not None)
 
     def _bwd(self, x_ptr, bstride, B, tag, st):
         ws, P, G = self.ws(tag), self.P, self.G

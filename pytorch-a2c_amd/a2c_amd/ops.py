@@ -229,6 +229,23 @@ def gemm(transA, transB, M, N, K, A_ptr, lda, B_ptr, ldb, C_ptr, ldc, bias=None,
                              st if st is not None else stream()), "a2c_gemm_f32")
 
 
+def gemm_partial(transA, transB, M, N, K, A_ptr, lda, B_ptr, ldb, splitk, ws, st=None):
+    """split-K phase only; returns the number of [M][N] slabs written to ws"""
+    check(lib().a2c_gemm_f32_partial(int(transA), int(transB), M, N, K, A_ptr, lda, B_ptr, ldb, splitk, ws.data_ptr(),
+                                     ws.numel() * ws.element_size(), st if st is not None else stream()),
+          "a2c_gemm_f32_partial")
+    return lib().a2c_gemm_splits(K, splitk)
+
+
+def heads_fused(xs_ptr, nslab, slab_stride, ldx, bias_in, relu_in, emb_out, W, b, heads, M, u=None, n_logits=0,
+                actions_ptr=0, act_stride=0, st=None):
+    N, K = W.shape
+    check(lib().a2c_heads_fused(xs_ptr, nslab, slab_stride, ldx, _p(bias_in), int(bool(relu_in)), _p(emb_out),
+                                0 if emb_out is None else emb_out.stride(0), _p(W), _p(b), _p(heads), heads.stride(0), M,
+                                N, K, _p(u), n_logits, actions_ptr, act_stride, st if st is not None else stream()),
+          "a2c_heads_fused")
+
+
 def gemm_ws_bytes(M, N, splitk):
     return lib().a2c_gemm_ws_bytes(M, N, splitk)
 

@@ -14,6 +14,7 @@ An env pool may instead be *device resident* (``DeviceEnvPool`` protocol: frames
 dones already in HBM, e.g. the synthetic benchmark env); then a whole n_tsteps rollout is
 enqueued without a single host synchronisation and can be captured into one hipGraph.
 """
+import os
 import time
 from collections import deque
 
@@ -194,9 +195,11 @@ class Runner:
             return self.uniform_fn(t, B, env0)
         return torch.rand(B, device=self.net._dev, dtype=torch.float32)
 
-    def _forward(self, net, x_ptr, bstride, B, env0, st):
+    def _forward(self, net, x_ptr, bstride, B, env0, st, sampler=None):
         if net.is_recurrent:
             return net._fwd(x_ptr, bstride, B, "roll", st, False, h_in=self.h[env0:env0 + B])
+        if sampler is not None and getattr(net, "_fused_sampling", False):
+            return net._fwd(x_ptr, bstride, B, "roll", st, False, sampler=sampler)
         return net._fwd(x_ptr, bstride, B, "roll", st, False)
 
     def _rollout_block(self, net, slot0, env0, B, hyps):
@@ -215,6 +218,16 @@ class Runner:
         val_prev, done_eff = self.val_prev[env0:env0 + B], self.done_eff[env0:env0 + B]
         h = None if self.h is None else self.h[env0:env0 + B]
         acts_host_out = D["actions"] if not D["actions"].is_cuda else None
+        # The per-step bookkeeping kernel only feeds later bookkeeping, so it CAN run on a side stream
+        # next to the frame-stack kernel (two branches in the hipGraph).  Measured on MI355X the
+        # fork/join costs more than the 4.8 us it hides (16.0 -> 17.8 ms per 256x128 epoch), so it is
+        # opt-in (A2C_SIDE_STREAM=1).
+        main = torch.cuda.current_stream()
+        side = None
+        if h is None and os.environ.get("A2C_SIDE_STREAM") == "1":
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=net._dev)
+            side = self._side
         # state of step 0 = the bookmark left by the previous slot (runner.py:190)
         ops.copy_rows(bm.data_ptr(), S, sp(0), T * S, B, S, st)
         for t in range(T):
@@ -222,15 +235,16 @@ class Runner:
                 hs = D["h_states"]
                 ops.copy_rows(h.data_ptr(), h.shape[1], hs.data_ptr() + 4 * (slot0 * T + t) * h.shape[1],
                               T * h.shape[1], B, h.shape[1], st)
-            out = self._forward(net, sp(t), T * S, B, env0, st)
-            logits, vals = out["logits"], out["vals"]
             u = self._uniforms(t, B, env0)
             act = self.act_dev[env0:env0 + B]
             if acts_host_out is None:      # device-resident actions buffer: write it in place
                 a_ptr, a_stride = D["actions"].data_ptr() + 8 * (slot0 * T + t), T
             else:
                 a_ptr, a_stride = act.data_ptr(), 1
-            ops.softmax_sample(logits, u, a_ptr, a_stride, B, net.output_space, st=st)
+            out = self._forward(net, sp(t), T * S, B, env0, st, sampler=(u, a_ptr, a_stride))
+            logits, vals = out["logits"], out["vals"]
+            if not out.get("sampled", False):
+                ops.softmax_sample(logits, u, a_ptr, a_stride, B, net.output_space, st=st)
             if h is not None:
                 ops.copy_rows(out["h"].data_ptr(), h.shape[1], h.data_ptr(), h.shape[1], B, h.shape[1], st)
             if self.device_pool:
@@ -238,11 +252,19 @@ class Runner:
             else:
                 frames, rew, done, reset = self._host_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift,
                                                            acts_host_out, pong)
-            ops.rollout_record(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, done_eff, h,
-                               B, T, t, slot0, gamma, pong, st)
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.rollout_record(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas,
+                                       done_eff, None, B, T, t, slot0, gamma, pong, side.cuda_stream)
+            else:
+                ops.rollout_record(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, done_eff,
+                                   h, B, T, t, slot0, gamma, pong, st)
             # next state (utils.next_state): into states[t+1], or the bookmark after the last step
             nxt_ptr, nxt_stride = (sp(t + 1), T * S) if t + 1 < T else (bm.data_ptr(), S)
             ops.frame_stack_push(frames, reset, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
+            if side is not None:
+                main.wait_stream(side)     # join before the next forward overwrites the heads buffer
         # bootstrap (runner.py:236-245): value of the state after the last step
         out = self._forward(net, bm.data_ptr(), S, B, env0, st)
         ops.rollout_bootstrap(out["vals"].data_ptr(), out["vals"].stride(0), val_prev, rewards, dones, deltas, B, T,

@@ -308,6 +308,80 @@ __global__ __launch_bounds__(256) void small_n_bwd_weight_reduce(const float* __
   }
 }
 
+// fused forward tail: slab sum + bias (+ReLU) -> [emb] -> N<=8 heads -> [softmax + inverse-CDF sample]
+__global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restrict__ xs, int nslab, long slab_stride,
+                                                          long ldx, const float* __restrict__ bias_in, int relu_in,
+                                                          float* __restrict__ emb_out, long ld_emb,
+                                                          const float* __restrict__ W, const float* __restrict__ b,
+                                                          float* __restrict__ heads, long ldh, long M, int N, int K,
+                                                          const float* __restrict__ u, int n_logits,
+                                                          int64_t* __restrict__ actions, long act_stride) {
+  const int lane = threadIdx.x & 63;
+  for (long m = blockIdx.x * 4L + (threadIdx.x >> 6); m < M; m += gridDim.x * 4L) {
+    float acc[SN_MAX];
+#pragma unroll
+    for (int n = 0; n < SN_MAX; ++n) acc[n] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+      int z = 0;
+      for (; z + 8 <= nslab; z += 8) {                 // 8 slab loads in flight, fixed summation order
+        float4 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = *reinterpret_cast<const float4*>(xs + (z + q) * slab_stride + m * ldx + k);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { xv.x += t[q].x; xv.y += t[q].y; xv.z += t[q].z; xv.w += t[q].w; }
+      }
+      for (; z < nslab; ++z) {
+        const float4 t = *reinterpret_cast<const float4*>(xs + z * slab_stride + m * ldx + k);
+        xv.x += t.x; xv.y += t.y; xv.z += t.z; xv.w += t.w;
+      }
+      if (bias_in) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_in + k);
+        xv.x += bv.x; xv.y += bv.y; xv.z += bv.z; xv.w += bv.w;
+      }
+      if (relu_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
+      if (emb_out) *reinterpret_cast<float4*>(emb_out + m * ld_emb + k) = xv;
+#pragma unroll
+      for (int n = 0; n < SN_MAX; ++n)
+        if (n < N) {
+          const float4 wv = *reinterpret_cast<const float4*>(W + (long)n * K + k);
+          acc[n] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+    }
+    float h[SN_MAX];
+#pragma unroll
+    for (int n = 0; n < SN_MAX; ++n) {
+      h[n] = 0.f;
+      if (n < N) h[n] = wave_sum(acc[n]) + (b ? b[n] : 0.f);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int n = 0; n < SN_MAX; ++n)
+        if (n < N) heads[m * ldh + n] = h[n];
+      if (u != nullptr) {      // same maths as sample_kernel<true>: softmax, running fp32 cumsum, first >= u
+        float mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < SN_MAX; ++n)
+          if (n < n_logits) mx = fmaxf(mx, h[n]);
+        float den = 0.f;
+#pragma unroll
+        for (int n = 0; n < SN_MAX; ++n)
+          if (n < n_logits) den += expf(h[n] - mx);
+        const float ub = u[m];
+        float cs = 0.f;
+        int pick = -1;
+#pragma unroll
+        for (int n = 0; n < SN_MAX; ++n)
+          if (n < n_logits) {
+            cs = cs + expf(h[n] - mx) / den;
+            if (pick < 0 && cs >= ub) pick = n;
+          }
+        actions[m * act_stride] = (int64_t)pick;
+      }
+    }
+  }
+}
+
 template <bool A_KC, bool B_KC>
 void launch_gemm(dim3 grid, hipStream_t st, long M, long N, long K, const float* A, long lda, const float* B, long ldb,
                  float* C, long ldc, const float* bias, int relu, const float* mask, long ldmask, int acc, long kps,
@@ -387,6 +461,54 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
                        (long)N, C, (long)ldc, bias, relu, mask, (long)ldmask, accumulate);
     A2C_CHECK_LAUNCH();
   }
+  return A2C_OK;
+}
+
+static long gemm_kps(int64_t K, int splitk) {
+  if (splitk < 1) splitk = 1;
+  return ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+}
+
+int a2c_gemm_splits(int64_t K, int splitk) {
+  if (K <= 0) return 0;
+  const long kps = gemm_kps(K, splitk);
+  return (int)((K + kps - 1) / kps);
+}
+
+int a2c_gemm_f32_partial(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                         const float* B, int64_t ldb, int splitk, void* ws, size_t ws_bytes, a2c_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !ws) return A2C_ERR_ARG;
+  const long kps = gemm_kps(K, splitk);
+  const int splits = a2c_gemm_splits(K, splitk);
+  if (ws_bytes < (size_t)splits * M * N * sizeof(float)) return A2C_ERR_WORKSPACE;
+  const int vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
+  const int vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
+  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)splits);
+  hipStream_t st = a2c_s(stream);
+  float* slab = (float*)ws;
+  const bool a_kc = (transA == 0), b_kc = (transB != 0);
+  if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
+  else if (a_kc && !b_kc) launch_gemm<true, false>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
+  else if (!a_kc && b_kc) launch_gemm<false, true>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
+  else launch_gemm<false, false>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_heads_fused(const float* xs, int nslab, int64_t slab_stride, int64_t ldx, const float* bias_in, int relu_in,
+                    float* emb_out, int64_t ld_emb, const float* W, const float* b, float* heads, int64_t ldh, int64_t M,
+                    int N, int K, const float* u, int n_logits, int64_t* actions, int64_t act_stride,
+                    a2c_stream_t stream) {
+  if (M < 0 || N < 1 || N > SN_MAX || K < 4 || K % 4 || nslab < 1) return A2C_ERR_ARG;
+  if (M == 0) return A2C_OK;
+  if (!xs || !W || !heads || (u && (!actions || n_logits < 1 || n_logits > N))) return A2C_ERR_ARG;
+  if (ldx % 4 || slab_stride % 4 || (emb_out && ld_emb % 4)) return A2C_ERR_ARG;
+  if (((uintptr_t)xs | (uintptr_t)W | (uintptr_t)(bias_in ? bias_in : W) | (uintptr_t)(emb_out ? emb_out : (float*)W)) % 16)
+    return A2C_ERR_ARG;
+  hipLaunchKernelGGL(heads_fused_kernel, dim3(a2c_grid_1d(M, 4, 4096)), dim3(256), 0, a2c_s(stream), xs, nslab,
+                     (long)slab_stride, (long)ldx, bias_in, relu_in, emb_out, (long)ld_emb, W, b, heads, (long)ldh,
+                     (long)M, N, K, u, n_logits, actions, (long)act_stride);
+  A2C_CHECK_LAUNCH();
   return A2C_OK;
 }
 

@@ -341,6 +341,13 @@ def main():
             else:
                 out["roofline"] = dict(kernel=dom, bound="mfma", achieved=None, peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
                                        frac=None, traffic=None)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (collected separately:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/run_kernel.py at this exact size)
+        tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        key = {"conv1.fwd": "conv1_fwd", "conv1.bwd_weight": "conv1_wgrad", "conv2.bwd_data": "conv2_bwd_data"}.get(dom)
+        if "roofline" in out and key and args.workload == "a3c" and N == 32768 and os.path.exists(tfile):
+            out["roofline"]["traffic"] = round(json.load(open(tfile))[key]["hbm_bytes_per_launch"])
+            out["roofline"]["traffic_source"] = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KB)"
         # always report conv1 forward (north star: HBM GB/s on the conv forward) and the scan
         if "conv1" in conv_layers and "conv1.fwd" in summ:
             d = conv_layers["conv1"].d

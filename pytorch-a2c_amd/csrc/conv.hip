@@ -69,6 +69,7 @@ struct SrcTile {         // how a band of TPH pixel rows maps onto an LDS image 
 static void plan_src(SrcTile& t, int extra_floats_per_row_of_pixels, int extra_fixed, int budget) {
   const int ncols = (t.PW - 1) * t.SX + t.span_x;
   t.WP = (t.sx0 == 0 && ncols <= t.IW) ? t.IW : ncols;    // unpadded layers keep whole rows (contiguous copy)
+  if (t.WP < t.IW - t.sx0) t.WP = t.IW - t.sx0;            // whole source rows are staged (vector loads)
   int best = 1;
   for (int tph = 1; tph <= t.PH; ++tph) {
     const int tih = (tph - 1) * t.SY + t.span_y;
@@ -86,12 +87,56 @@ static void plan_src(SrcTile& t, int extra_floats_per_row_of_pixels, int extra_f
 struct StageP {
   const float* src; long bstride;   // sample stride (floats)
   int Cp, IH, IW, TIH, WP, PLANE, sx0, fast;
+  int vec;                          // widest aligned load for a source row: 4, 2 or 1 floats
 };
 
 constexpr int STAGE_U = 8;          // independent loads in flight per thread
 
-// All 256 threads sweep the flattened (plane, row, col) space of the LDS image; out-of-image
-// positions (zero padding, rows past the bottom) are written as 0 so every word is finite.
+// zero the whole image once per kernel: halo columns / plane slack are never written again
+__device__ __forceinline__ void stage_zero(const StageP& s, float* __restrict__ lds) {
+  for (int i = threadIdx.x; i < s.Cp * s.PLANE + 64; i += 256) lds[i] = 0.f;
+}
+
+template <int VEC>
+__device__ __forceinline__ void stage_rows(const StageP& s, float* __restrict__ lds, const float* __restrict__ base,
+                                           int y_lo) {
+  // flattened (plane, row, vector) space; every data position of the image is rewritten each tile
+  // (rows outside the source as zeros), halo columns keep the zeros of stage_zero()
+  const int nv = s.IW / VEC;
+  const int total = s.Cp * s.TIH * nv;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * STAGE_U) {
+    float v[STAGE_U][VEC];
+    int dst[STAGE_U];
+#pragma unroll
+    for (int u = 0; u < STAGE_U; ++u) {
+      const int idx = i0 + u * 256;
+      dst[u] = -1;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[u][e] = 0.f;
+      if (idx < total) {
+        const int rt = idx / nv, x = (idx - rt * nv) * VEC;
+        const int c = rt / s.TIH, r = rt - c * s.TIH;
+        const int ys = y_lo + r;
+        dst[u] = c * s.PLANE + r * s.WP + x - s.sx0;
+        if (ys >= 0 && ys < s.IH) {
+          const float* p = base + ((long)c * s.IH + ys) * s.IW + x;
+          if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
+          else if (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[u][0] = t.x; v[u][1] = t.y; }
+          else v[u][0] = p[0];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < STAGE_U; ++u)
+      if (dst[u] >= 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) lds[dst[u] + e] = v[u][e];
+      }
+  }
+}
+
+// All 256 threads sweep the image; `fast` = unpadded full-width rows (a plane is one contiguous
+// run: float4 loads AND float4 LDS stores); otherwise vector loads per row + scalar LDS stores.
 __device__ __forceinline__ void stage_tile(const StageP& s, float* __restrict__ lds, long b, int y_lo) {
   const int tid = threadIdx.x;
   const float* __restrict__ base = s.src + b * s.bstride;
@@ -118,30 +163,9 @@ __device__ __forceinline__ void stage_tile(const StageP& s, float* __restrict__ 
       for (int u = 0; u < STAGE_U; ++u)
         if (dst[u] >= 0) *reinterpret_cast<float4*>(lds + dst[u]) = v[u];
     }
-  } else {
-    const int per = s.TIH * s.WP;
-    const int total = s.Cp * per;
-    for (int i0 = tid; i0 < total; i0 += 256 * STAGE_U) {
-      float v[STAGE_U];
-      int dst[STAGE_U];
-#pragma unroll
-      for (int u = 0; u < STAGE_U; ++u) {
-        const int idx = i0 + u * 256;
-        v[u] = 0.f;
-        dst[u] = -1;
-        if (idx < total) {
-          const int c = idx / per, rem = idx - c * per;
-          const int r = rem / s.WP, x = rem - r * s.WP;
-          const int ys = y_lo + r, xs = x + s.sx0;
-          dst[u] = c * s.PLANE + rem;
-          if (ys >= 0 && ys < s.IH && xs >= 0 && xs < s.IW) v[u] = base[((long)c * s.IH + ys) * s.IW + xs];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < STAGE_U; ++u)
-        if (dst[u] >= 0) lds[dst[u]] = v[u];
-    }
-  }
+  } else if (s.vec == 4) stage_rows<4>(s, lds, base, y_lo);
+  else if (s.vec == 2) stage_rows<2>(s, lds, base, y_lo);
+  else stage_rows<1>(s, lds, base, y_lo);
 }
 
 // ------------------------------------------------------------------ forward / backward-data
@@ -181,13 +205,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
   const int g = lane >> 4, j = lane & 15;
   const long total = (long)p.B * p.tiles;
   const int WP = p.st.WP, PLANE = p.st.PLANE;
+  stage_zero(p.st, lds);
   for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
     const long b = tile / p.tiles;
     const int ti = (int)(tile - b * p.tiles);
     const int qq0 = ti * p.TPH;
     const int rows = min(p.TPH, p.PH - qq0);
     const int NP = rows * p.PW;
-    __syncthreads();                       // readers of the previous tile are done
+    __syncthreads();                       // readers of the previous tile (and the zero fill) are done
     stage_tile(p.st, lds, b, qq0 * p.SY + p.sy0);
     __syncthreads();
     const int npairs = (NP + 31) >> 5;
@@ -499,11 +524,18 @@ static int launch_igemm(const IgemmP& p, int MT, hipStream_t st) {
   return A2C_OK;
 }
 
+static int stage_vec(const float* src, long bstride, int IH, int IW) {
+  if (IW % 4 == 0 && bstride % 4 == 0 && ((long)IH * IW) % 4 == 0 && (uintptr_t)src % 16 == 0) return 4;
+  if (IW % 2 == 0 && bstride % 2 == 0 && ((long)IH * IW) % 2 == 0 && (uintptr_t)src % 8 == 0) return 2;
+  return 1;
+}
+
 static void fill_stage(StageP& s, const SrcTile& t, const float* src, long bstride) {
   s.src = src; s.bstride = bstride;
   s.Cp = t.Cp; s.IH = t.IH; s.IW = t.IW; s.TIH = t.TIH; s.WP = t.WP; s.PLANE = t.PLANE; s.sx0 = t.sx0;
   s.fast = (t.sx0 == 0) && (t.sy0 >= 0) && (t.WP == t.IW) && (t.IW % 4 == 0) && (bstride % 4 == 0) &&
            ((uintptr_t)src % 16 == 0);
+  s.vec = stage_vec(src, bstride, t.IH, t.IW);
 }
 
 // ------------------------------------------------------------------ backward-weight
@@ -787,6 +819,146 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdFusedP p) {
           if (!(mk.w > 0.f)) v.w = 0.f;
         }
         o4[i] = v;
+      }
+    }
+  }
+}
+
+// Generic backward-data, any (ks, S <= 2, pad): a workgroup owns a BAND of TY rows of dX (all
+// columns, all input channels).  It stages the band's dOut rows (with zero halo) once, runs every
+// output-parity class as a stride-1 correlation into an LDS copy of the dX band, then flushes
+// the band with coalesced 16 B stores (ReLU-derivative mask fused, 16 B mask loads).  Replaces S*S
+// launches that each re-staged dOut and scattered 4-byte writes at stride S.
+struct BandClass { int ry, rx, na, nb, frag_off, nsteps, nchunks, p0, PWc; };
+struct BwdBandP {
+  StageP st;                       // dOut image staging (general path, halo)
+  float* din; const float* mask; const float* wfrag;
+  int Cin, H, W, S, P, ks, TY, bands, B, ncls, c4n, ox_lo, out_floats;
+  BandClass cls[MAX_CLS];
+};
+
+__device__ __forceinline__ int fdiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+template <int MT>
+__global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ outb = lds;                         // [Cin][TY*W]
+  float* __restrict__ img = lds + p.out_floats;           // [Cout][PLANE]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int WP = p.st.WP, PLANE = p.st.PLANE;
+  const long total = (long)p.B * p.bands;
+  stage_zero(p.st, img);
+  for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const long b = tile / p.bands;
+    const int Y0 = (int)(tile - b * p.bands) * p.TY;
+    const int rowsY = min(p.TY, p.H - Y0);
+    const int oy_lo = fdiv(Y0 + p.P - (p.ks - 1), p.S);
+    __syncthreads();
+    stage_tile(p.st, img, b, oy_lo);
+    __syncthreads();
+    for (int c = 0; c < p.ncls; ++c) {
+      const BandClass& k = p.cls[c];
+      // class rows in this band: y = S*q + ry - P in [Y0, Y0 + rowsY)
+      int q_lo = (Y0 + p.P - k.ry + p.S - 1) / p.S;
+      if (q_lo < 0) q_lo = 0;
+      const int y_first = p.S * q_lo + k.ry - p.P;
+      const int rows_c = y_first < Y0 + rowsY ? (Y0 + rowsY - 1 - y_first) / p.S + 1 : 0;
+      const int NP = rows_c * k.PWc;
+      const int npairs = (NP + 31) >> 5;
+      for (int pr = w; pr < npairs; pr += 4) {
+        const int idx0 = pr * 32 + j, idx1 = idx0 + 16;
+        const bool ok0 = idx0 < NP, ok1 = idx1 < NP;
+        const int i0 = ok0 ? idx0 : 0, i1 = ok1 ? idx1 : 0;
+        const int r0 = i0 / k.PWc, c0 = i0 - r0 * k.PWc;
+        const int r1 = i1 / k.PWc, c1 = i1 - r1 * k.PWc;
+        // class pixel (q, pc) -> dOut position (q, pc) relative to the image origin (oy_lo, ox_lo)
+        const float* __restrict__ l0 = img + (q_lo + r0 - oy_lo) * WP + (k.p0 + c0 - p.ox_lo) + g * PLANE;
+        const float* __restrict__ l1 = img + (q_lo + r1 - oy_lo) * WP + (k.p0 + c1 - p.ox_lo) + g * PLANE;
+        f32x4 acc[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const float* __restrict__ wf = p.wfrag + k.frag_off + lane;
+        float a_cur[CH * MT], a_nxt[CH * MT];
+#pragma unroll
+        for (int i = 0; i < CH * MT; ++i) a_cur[i] = wf[i * 64];
+        int off = 0, bi = 0, ci = 0;
+        for (int ck = 0; ck < k.nchunks; ++ck) {
+          if (ck + 1 < k.nchunks) {
+#pragma unroll
+            for (int i = 0; i < CH * MT; ++i) a_nxt[i] = wf[((ck + 1) * CH * MT + i) * 64];
+          }
+          float bv0[CH], bv1[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int o = (ck * CH + u < k.nsteps) ? off : 0;     // padded steps (A = 0) read a valid word
+            bv0[u] = l0[o];
+            bv1[u] = l1[o];
+            ++ci;
+            const bool w1 = (ci == p.c4n);
+            ci = w1 ? 0 : ci;
+            bi += w1 ? 1 : 0;
+            const bool w2 = (bi == k.nb);
+            bi = w2 ? 0 : bi;
+            off += 4 * PLANE + (w1 ? -1 - p.c4n * 4 * PLANE : 0) + (w2 ? -WP + k.nb : 0);
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], bv0[u], acc[m][0], 0, 0, 0);
+              acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], bv1[u], acc[m][1], 0, 0, 0);
+            }
+#pragma unroll
+          for (int i = 0; i < CH * MT; ++i) a_cur[i] = a_nxt[i];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if (!(nt ? ok1 : ok0)) continue;
+          const int r = nt ? r1 : r0, cc = nt ? c1 : c0;
+          const int yy = y_first + r * p.S - Y0;                  // row inside the band
+          const int xx = (k.p0 + cc) * p.S + k.rx - p.P;
+          const int pix = yy * p.W + xx;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int ch = m * 16 + 4 * g + rr;
+              if (ch < p.Cin) outb[ch * p.TY * p.W + pix] = acc[m][nt][rr];
+            }
+        }
+      }
+    }
+    __syncthreads();
+    if (p.W & 3) {  // rows not 16 B aligned: coalesced 4 B flush
+      const int per = rowsY * p.W;
+      const int n = p.Cin * per;
+      for (int i = tid; i < n; i += 256) {
+        const int ch = i / per, rem = i - ch * per;
+        const long o = ((b * p.Cin + ch) * (long)p.H + Y0) * p.W + rem;
+        float v = outb[ch * p.TY * p.W + rem];
+        if (p.mask && !(p.mask[o] > 0.f)) v = 0.f;
+        p.din[o] = v;
+      }
+    } else {  // coalesced flush of the band: rows Y0 .. Y0+rowsY of every channel
+      const int row4 = p.W >> 2;
+      const int per = rowsY * row4;
+      const int n4 = p.Cin * per;
+      for (int i = tid; i < n4; i += 256) {
+        const int ch = i / per, rem = i - ch * per;
+        const long o = ((b * p.Cin + ch) * (long)p.H + Y0) * p.W + ((long)rem << 2);
+        float4 v = *reinterpret_cast<const float4*>(outb + ch * p.TY * p.W + (rem << 2));
+        if (p.mask) {
+          const float4 mk = *reinterpret_cast<const float4*>(p.mask + o);
+          if (!(mk.x > 0.f)) v.x = 0.f;
+          if (!(mk.y > 0.f)) v.y = 0.f;
+          if (!(mk.z > 0.f)) v.z = 0.f;
+          if (!(mk.w > 0.f)) v.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(p.din + o) = v;
       }
     }
   }
@@ -1198,6 +1370,55 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
       const int grid = resident_grid(k, lds, B);
       if (MTb == 1) hipLaunchKernelGGL(bwd_fused_kernel<1>, dim3(grid), dim3(256), lds, a2c_s(stream), q);
       else hipLaunchKernelGGL(bwd_fused_kernel<2>, dim3(grid), dim3(256), lds, a2c_s(stream), q);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
+  if (S * S <= MAX_CLS && !getenv("A2C_NO_BAND") && ((uintptr_t)din % 16 == 0) && (!mask || (uintptr_t)mask % 16 == 0)) {
+    // band kernel: all classes fused, dX band assembled in LDS and flushed coalesced
+    const int MTb = ceil_div(d->Cin, 16), c4n = d->Cout / 4;
+    BwdBandP q;
+    q.din = din; q.mask = mask; q.wfrag = wprep_bwd;
+    q.Cin = d->Cin; q.H = d->H; q.W = d->W; q.S = S; q.P = P; q.ks = d->ks; q.B = B; q.ncls = S * S; q.c4n = c4n;
+    const int ox_lo = (P - (d->ks - 1)) >= 0 ? (P - (d->ks - 1)) / S : -((-(P - (d->ks - 1)) + S - 1) / S);
+    const int ox_hi = (d->W - 1 + P) / S;
+    q.ox_lo = ox_lo;
+    const int WPo = ox_hi - ox_lo + 1;
+    int TY = 0, TIH = 0, PLANEo = 0;
+    for (int ty = S; ty <= ((d->H + S - 1) / S) * S; ty += S) {
+      const int tih = (ty - 1 + d->ks - 1) / S + 2;
+      const int plane = ((tih * WPo + 31) / 32) * 32 + 16;
+      const long bytes = 4L * ((long)d->Cin * ty * d->W + (long)d->Cout * plane + 64);
+      if (bytes <= IGEMM_LDS_BUDGET || TY == 0) { TY = ty; TIH = tih; PLANEo = plane; }
+      if (bytes > IGEMM_LDS_BUDGET) break;
+    }
+    q.TY = TY; q.bands = ceil_div(d->H, TY); q.out_floats = d->Cin * TY * d->W;
+    q.st.src = dout; q.st.bstride = (long)d->Cout * d->OH * d->OW; q.st.Cp = d->Cout; q.st.IH = d->OH; q.st.IW = d->OW;
+    q.st.TIH = TIH; q.st.WP = WPo; q.st.PLANE = PLANEo; q.st.sx0 = ox_lo; q.st.fast = 0;
+    q.st.vec = stage_vec(dout, q.st.bstride, d->OH, d->OW);
+    for (int cls = 0; cls < S * S; ++cls) {
+      const int ry = cls / S, rx = cls % S;
+      BandClass& k = q.cls[cls];
+      k.ry = ry; k.rx = rx; k.na = ntaps_1d(d->ks, S, ry); k.nb = ntaps_1d(d->ks, S, rx);
+      if (k.nb < 1) k.nb = 1;
+      k.frag_off = (int)bwd_class_offset(d, cls);
+      k.nsteps = ntaps_1d(d->ks, S, ry) * ntaps_1d(d->ks, S, rx) * c4n;
+      k.nchunks = pad_steps(k.nsteps) / CH;
+      k.p0 = (P - rx) > 0 ? ceil_div(P - rx, S) : 0;
+      k.PWc = (d->W - 1 + P - rx) >= 0 ? (d->W - 1 + P - rx) / S - k.p0 + 1 : 0;
+      if (k.PWc < 0) k.PWc = 0;
+    }
+    const size_t lds = 4 * ((size_t)q.out_floats + (size_t)d->Cout * PLANEo + 64);
+    if (lds <= LDS_HARD_MAX && MTb <= 4) {
+      const void* kf = MTb == 1 ? (const void*)bwd_band_kernel<1> : MTb == 2 ? (const void*)bwd_band_kernel<2>
+                       : MTb == 3 ? (const void*)bwd_band_kernel<3> : (const void*)bwd_band_kernel<4>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const int grid = resident_grid(kf, lds, (long)B * q.bands);
+      hipStream_t st = a2c_s(stream);
+      if (MTb == 1) hipLaunchKernelGGL(bwd_band_kernel<1>, dim3(grid), dim3(256), lds, st, q);
+      else if (MTb == 2) hipLaunchKernelGGL(bwd_band_kernel<2>, dim3(grid), dim3(256), lds, st, q);
+      else if (MTb == 3) hipLaunchKernelGGL(bwd_band_kernel<3>, dim3(grid), dim3(256), lds, st, q);
+      else hipLaunchKernelGGL(bwd_band_kernel<4>, dim3(grid), dim3(256), lds, st, q);
       A2C_CHECK_LAUNCH();
       return A2C_OK;
     }

@@ -30,7 +30,7 @@ class Shard:
         if world <= 1 and not force:
             return cls()
         if not dist.is_initialized():
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("A2C_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
             dist.init_process_group(backend=backend)

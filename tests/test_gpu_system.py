@@ -1,0 +1,171 @@
+"""-m gpu: system-level behaviour of the drop-in -- sharded update == single-process update,
+Runner.run queue protocol, StatsRunner, norm_returns, public autograd path vs Updater path."""
+import os
+import queue
+import socket
+import threading
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import a2c_oracle as O  # noqa: E402
+from cases import base_hyps, hashf, synth_shared  # noqa: E402
+from test_gpu_kernels import close  # noqa: E402
+from test_gpu_models import make_net, _fake_pool, _datas  # noqa: E402
+
+DEV = "cuda"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_worker(rank, world, port, kind, opt, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", A2C_DIST_BACKEND="gloo")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "pytorch-a2c_amd"), os.path.join(root, "tests", "golden"),
+                    os.path.join(root, "tests")]
+    import torch.distributed as dist
+    from a2c_amd.parallel import Shard
+    from a2c_amd.updater import Updater
+    from test_gpu_models import make_net
+    from cases import base_hyps, synth_shared
+    torch.cuda.set_device(0)
+    ss, A, h, R, T = (4, 84, 84), 3, 256, 4, 6
+    sh = Shard.from_env()
+    net = make_net(kind, ss, A, h)
+    lo, hi = sh.slot_range(R)
+    hyps = base_hyps(n_tsteps=T, n_rollouts=hi - lo, optim_type=opt, h_size=h)
+    upd = Updater(net, hyps, shard=sh)
+    infos = []
+    for u in range(2):
+        D = synth_shared(kind, ss, A, h, R, T, seed=700 + 10 * u, recurrent=net.is_recurrent)
+        Dl = {k: v[lo * T:hi * T].cuda() for k, v in D.items()}          # this rank's contiguous slots
+        infos.append(upd.update_model(Dl))
+    q.put((rank, infos, [p.detach().cpu().numpy() for p in net.parameters()]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,opt", [("A3CModel", "RMSprop"), ("GRUModel", "Adam")])
+def test_sharded_update_equals_single_process(kind, opt):
+    """world_size 2 (two processes, gloo all-reduce of the CUDA gradient arena) must reproduce
+    the single-process update on the whole batch: losses, GradNorm and every parameter."""
+    from a2c_amd.updater import Updater
+    ss, A, h, R, T = (4, 84, 84), 3, 256, 4, 6
+    net = make_net(kind, ss, A, h)
+    upd = Updater(net, base_hyps(n_tsteps=T, n_rollouts=R, optim_type=opt, h_size=h))
+    ref_infos = []
+    for u in range(2):
+        D = synth_shared(kind, ss, A, h, R, T, seed=700 + 10 * u, recurrent=net.is_recurrent)
+        ref_infos.append(upd.update_model({k: v.cuda() for k, v in D.items()}))
+    ref_params = [p.detach().cpu().numpy() for p in net.parameters()]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, kind, opt, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, infos, params in res:
+        for u in range(2):
+            for k in ref_infos[u]:
+                assert infos[u][k] == pytest.approx(ref_infos[u][k], rel=2e-5, abs=1e-7), (rank, u, k)
+        for a, b in zip(params, ref_params):
+            np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+    for a, b in zip(res[0][2], res[1][2]):          # ranks stay bit-identical without any broadcast
+        assert np.array_equal(a, b)
+
+
+def test_runner_run_queue_protocol():
+    """Runner.run keeps the reference's gate/stop protocol (runner.py:169-172)"""
+    from a2c_amd.runner import Runner
+    B, T, A, ss = 3, 4, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, n_envs=B)
+    net = make_net("A3CModel", ss, A, 256)
+    D = _datas(B * T, ss, False)
+    gate, stop, rew = queue.Queue(), queue.Queue(), queue.Queue(1)
+    rew.put(-1)
+    ekws = [dict(env_id=j, rew_period=2, done_period=5) for j in range(B)]
+    r = Runner(D, hyps, gate, stop, rew, env_pool=_fake_pool(ekws))
+    th = threading.Thread(target=r.run, args=(net,), daemon=True)
+    for i in range(B):
+        gate.put(i)
+    th.start()
+    got = sorted(stop.get(timeout=120) for _ in range(B))
+    assert got == list(range(B))
+    torch.cuda.synchronize()
+    assert float(D["dones"].view(B, T)[:, -1].min()) == 1.0          # every slot ends done (runner.py:244)
+    assert float(D["states"].abs().sum()) > 0
+    for i in range(B):                                                 # a second epoch re-opens the gate
+        gate.put(i)
+    assert sorted(stop.get(timeout=120) for _ in range(B)) == list(range(B))
+
+
+def test_stats_runner_and_get_action():
+    from a2c_amd.runner import StatsRunner
+
+    class Env:          # SequentialEnvironment surface over the fake env
+        def __init__(self):
+            self.e = O.FakeEnv(env_id=3, rew_period=2, done_period=6)
+
+        def reset(self):
+            return self.e.reset()
+
+        def step(self, a):
+            return self.e.step(a)
+
+        def get_action(self, logits):
+            from a2c_amd.utils import sample_action
+            p = torch.softmax(logits, -1)
+            return int(sample_action(p, torch.full((1,), 0.5)).item())
+    hyps = base_hyps(env_type="FakeBreakout", n_test_eps=3)
+    for kind in ("A3CModel", "GRUModel"):
+        net = make_net(kind, (4, 84, 84), 3, 256)
+        val = StatsRunner(hyps, env=Env()).rollout(net)
+        assert np.isfinite(val)
+
+
+def test_norm_returns_matches_oracle():
+    from a2c_amd.updater import Updater
+    kind, ss, A, h, R, T = "A3CModel", (4, 84, 84), 3, 256, 3, 5
+    hyps = base_hyps(n_tsteps=T, n_rollouts=R, norm_returns=True)
+    net, onet = make_net(kind, ss, A, h), O.OracleNet(kind, ss, A, h)
+    upd, oupd = Updater(net, hyps), O.OracleUpdater(onet, hyps)
+    for u in range(2):
+        D = synth_shared(kind, ss, A, h, R, T, seed=800 + u, recurrent=False)
+        info = upd.update_model({k: v.cuda() for k, v in D.items()})
+        oinfo = oupd.update_model(D)
+        for k in oinfo:
+            assert info[k] == pytest.approx(oinfo[k], rel=5e-5, abs=2e-6), (u, k)
+    assert upd.ret_mean == pytest.approx(float(oupd.ret_mean), rel=1e-5)
+    assert upd.ret_std == pytest.approx(float(oupd.ret_std), rel=1e-5)
+
+
+def test_updater_bptt_api_and_new_lr_quirk():
+    from a2c_amd.updater import Updater
+    kind, ss, A, h, R, T = "GRUModel", (4, 84, 84), 3, 256, 2, 4
+    hyps = base_hyps(n_tsteps=T, n_rollouts=R, use_bptt=True)
+    net, onet = make_net(kind, ss, A, h), O.OracleNet(kind, ss, A, h)
+    D = synth_shared(kind, ss, A, h, R, T, seed=810, recurrent=True)
+    upd = Updater(net, hyps)
+    v, l = upd.bptt(D["states"].cuda(), D["h_states"].cuda(), D["dones"].cuda())
+    with torch.no_grad():
+        ov, ol = O.bptt(onet, D["states"], D["h_states"], D["dones"], hyps)
+    close("bptt vals", v, ov, 1e-5, 1e-5)
+    close("bptt logits", l, ol, 1e-5, 1e-5)
+    upd.update_model({k: t.cuda() for k, t in D.items()})
+    upd.new_lr(5e-5)                       # like the reference, loading the old state restores the old lr
+    assert upd.optim.param_groups[0]["lr"] == 1e-4

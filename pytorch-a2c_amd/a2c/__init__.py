@@ -4,7 +4,7 @@
 import sys
 
 import a2c_amd
-from a2c_amd import models, preprocessing, runner, updater, utils  # noqa: F401
+from a2c_amd import models, preprocessing, runner, training, updater, utils  # noqa: F401
 
-for _name in ("models", "preprocessing", "runner", "updater", "utils"):
+for _name in ("models", "preprocessing", "runner", "training", "updater", "utils"):
     sys.modules[__name__ + "." + _name] = getattr(a2c_amd, _name)

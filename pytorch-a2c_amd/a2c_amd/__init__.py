@@ -7,7 +7,7 @@ SequentialEnvironment), ``a2c_amd.updater`` (Updater), ``a2c_amd.preprocessing``
 All arithmetic runs in liba2c_mi355x.so (hand-written HIP for gfx950, C ABI in
 include/a2c_mi355x.h); there is no CPU fallback.
 """
-from . import _lib, ops, utils, models, optim, parallel, preprocessing, runner, updater  # noqa: F401
+from . import _lib, ops, utils, models, optim, parallel, preprocessing, runner, updater, training  # noqa: F401
 from .models import A3CModel, ConvModel, FCModel, GRU, GRUFCModel, GRUModel  # noqa: F401
 from .runner import Runner, StatsRunner, SequentialEnvironment, HostEnvPool  # noqa: F401
 from .updater import Updater  # noqa: F401

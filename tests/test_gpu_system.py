@@ -169,3 +169,30 @@ def test_updater_bptt_api_and_new_lr_quirk():
     upd.update_model({k: t.cuda() for k, t in D.items()})
     upd.new_lr(5e-5)                       # like the reference, loading the old state restores the old lr
     assert upd.optim.param_groups[0]["lr"] == 1e-4
+
+
+def test_train_driver_two_epochs(tmp_path):
+    """row f1: the reference's epoch loop (gate/stop barrier, save cadence, files) on the engine"""
+    from a2c_amd.training import train
+    hyps = dict(exp_name="t", main_path=str(tmp_path), model="A3CModel", env_type="FakeBreakout", n_envs=3, n_rollouts=3,
+                n_tsteps=5, max_tsteps=1e9, action_size=3, seed=1, n_test_eps=1)
+    best = train(None, hyps, verbose=False, env_fn=lambda j: O.FakeEnv(env_id=j, rew_period=3, done_period=7),
+                 max_epochs=2)
+    folder = os.path.join(str(tmp_path), "t", "t_0")
+    assert sorted(os.listdir(folder)) == ["best_net.p", "log.txt", "net.p", "optim.p"]
+    sd = torch.load(os.path.join(folder, "net.p"))
+    assert set(sd.keys()) == set(O.formula_state_dict("A3CModel", (4, 84, 84), 3, 256).keys())     # reference key set
+    osd = torch.load(os.path.join(folder, "optim.p"))
+    assert len(osd["param_groups"][0]["params"]) == 12 and 6 not in osd["state"]                    # emb_bnorm: no state
+    log = open(os.path.join(folder, "log.txt")).read()
+    assert "Step:15" in log and "Step:30" in log and "BestRew" in log
+    assert np.isfinite(best)
+    # a checkpoint written by the driver loads into a fresh net and into the reference-shaped oracle
+    net = make_net("A3CModel", (4, 84, 84), 3, 256)
+    net.load_state_dict(sd)
+    onet = O.OracleNet("A3CModel", (4, 84, 84), 3, 256, state_dict={k: v.cpu() for k, v in sd.items()})
+    x = torch.from_numpy(O.formula_frames(2, (4, 84, 84), seed=9, binary=True))
+    with torch.no_grad():
+        a, b = net(x), onet(x)
+    close("val", a[0], b[0], 1e-5, 1e-5)
+    close("pi", a[1], b[1], 1e-5, 1e-5)

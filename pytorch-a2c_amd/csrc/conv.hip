@@ -182,6 +182,9 @@ struct IgemmP {
   // LDS offset of MFMA step s = (a*nb + b)*c4n + c4 (tap row a, tap col b, channel quad c4):
   //   off0 + a*step_a + b*step_b + c4*step_c     -- scalar arithmetic, no table
   int nsteps, nb, c4n, off0, step_a, step_b, step_c;
+  // forward only: > 0 = assemble the tile's output [Mch][TPH*PW] in LDS at this float offset and
+  // flush it with coalesced stores (a tile's rows of one channel are one contiguous HBM run)
+  int out_stage, out_vec;
 };
 
 struct StepIter {      // wave-uniform walker over the step offsets
@@ -267,20 +270,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
         const long yo = (long)(qq0 + r) * p.oy_mul + p.oy_add;
         const long xo = (long)c * p.ox_mul + p.ox_add;
         const long pix = yo * p.OWf + xo;
+        const int ip = nt ? i1 : i0;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int co = m * 16 + 4 * g + rr;
             if (co < p.Mch) {
-              const long o = b * p.out_bs + (long)co * p.OHf * p.OWf + pix;
               float v = acc[m][nt][rr];
               if (p.bias) v += p.bias[co];
               if (p.relu) v = fmaxf(v, 0.f);
-              if (p.mask && !(p.mask[o] > 0.f)) v = 0.f;
-              p.out[o] = v;
+              if (p.out_stage > 0) {
+                lds[p.out_stage + co * p.TPH * p.PW + ip] = v;
+              } else {
+                const long o = b * p.out_bs + (long)co * p.OHf * p.OWf + pix;
+                if (p.mask && !(p.mask[o] > 0.f)) v = 0.f;
+                p.out[o] = v;
+              }
             }
           }
+      }
+    }
+    if (p.out_stage > 0) {       // coalesced flush: NP contiguous floats per channel
+      __syncthreads();
+      float* __restrict__ ob = p.out + b * p.out_bs + (long)qq0 * p.OWf;
+      const float* __restrict__ sb = lds + p.out_stage;
+      const long chs = (long)p.OHf * p.OWf;
+      if (p.out_vec) {
+        const int per4 = NP >> 2, n4 = p.Mch * per4;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+          const int co = i / per4, e = (i - co * per4) << 2;
+          *reinterpret_cast<float4*>(ob + co * chs + e) = *reinterpret_cast<const float4*>(sb + co * p.TPH * p.PW + e);
+        }
+      } else {
+        const int n = p.Mch * NP;
+        for (int i = threadIdx.x; i < n; i += 256) {
+          const int co = i / NP, e = i - co * NP;
+          ob[co * chs + e] = sb[co * p.TPH * p.PW + e];
+        }
       }
     }
   }
@@ -509,7 +536,7 @@ static void launch_igemm_t(const IgemmP& p, int grid, size_t lds, hipStream_t st
 }
 
 static int launch_igemm(const IgemmP& p, int MT, hipStream_t st) {
-  const size_t lds = 4 * ((size_t)p.st.Cp * p.st.PLANE + 64);
+  const size_t lds = 4 * ((size_t)p.st.Cp * p.st.PLANE + 64 + (p.out_stage > 0 ? (size_t)p.Mch * p.TPH * p.PW + 16 : 0));
   if (lds > LDS_HARD_MAX) return A2C_ERR_ARG;
   const long total = (long)p.B * p.tiles;
   const int grid = (int)(total < 2048 ? total : 2048);
@@ -547,6 +574,7 @@ struct WgradP {
   int S, sy0, TPH, tiles, B;
   int PLANEo;                     // dOut LDS plane stride (= 2 mod 32)
   int nkt;                        // ceil(K/16)
+  int dvec;                       // dOut rows are 16 B aligned float4 streams
 };
 
 template <int MT, int KTW>
@@ -596,8 +624,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
     {  // dOut rows q0..q0+rows of every channel (a contiguous run per channel) -> ldo[co][r*OWp + c];
        // pad columns stay 0.  Flattened over all threads, 8 independent loads in flight each.
       const int per = rows * p.OW;
-      const int tot = p.Cout * per;
       const float* __restrict__ dsrc = p.dout + (b * p.Cout * p.OH + q0) * (long)p.OW;
+      if (p.dvec) {            // OW % 4 == 0, 16 B aligned: a channel's rows are one float4 stream
+        const int per4 = per >> 2, tot4 = p.Cout * per4;
+        for (int i0 = threadIdx.x; i0 < tot4; i0 += 256 * STAGE_U) {
+          float4 v[STAGE_U];
+          int dst[STAGE_U];
+#pragma unroll
+          for (int u = 0; u < STAGE_U; ++u) {
+            const int idx = i0 + u * 256;
+            dst[u] = -1;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < tot4) {
+              const int co = idx / per4, e = (idx - co * per4) << 2;
+              const int r = e / p.OW, x = e - r * p.OW;
+              dst[u] = co * p.PLANEo + r * p.OWp + x;
+              v[u] = *reinterpret_cast<const float4*>(dsrc + (long)co * p.OH * p.OW + e);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < STAGE_U; ++u)
+            if (dst[u] >= 0) { ldo[dst[u]] = v[u].x; ldo[dst[u] + 1] = v[u].y; ldo[dst[u] + 2] = v[u].z; ldo[dst[u] + 3] = v[u].w; }
+        }
+      } else {
+      const int tot = p.Cout * per;
       for (int i0 = threadIdx.x; i0 < tot; i0 += 256 * STAGE_U) {
         float v[STAGE_U];
         int dst[STAGE_U];
@@ -616,6 +666,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int u = 0; u < STAGE_U; ++u)
           if (dst[u] >= 0) ldo[dst[u]] = v[u];
+      }
       }
     }
     __syncthreads();
@@ -1274,9 +1325,11 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   SrcTile t;
   t.Cp = d->Cin; t.IH = d->H; t.IW = d->W; t.SY = d->stride; t.SX = d->stride;
   t.sy0 = -d->pad; t.sx0 = -d->pad; t.span_y = d->ks; t.span_x = d->ks; t.PH = d->OH; t.PW = d->OW;
-  plan_src(t, 0, 0, IGEMM_LDS_BUDGET);
+  const bool staged_out = !getenv("A2C_NO_OUT_STAGE");
+  plan_src(t, staged_out ? d->Cout * d->OW : 0, 16, IGEMM_LDS_BUDGET);
   IgemmP p;
   fill_stage(p.st, t, in, in_bstride);
+  p.out_stage = 0; p.out_vec = 0;
   p.out = out; p.out_bs = out_bstride; p.Mch = d->Cout; p.OHf = d->OH; p.OWf = d->OW;
   p.wfrag = wprep_fwd; p.bias = bias; p.mask = nullptr; p.relu = relu;
   p.PH = d->OH; p.PW = d->OW; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0;
@@ -1325,6 +1378,10 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
       A2C_CHECK_LAUNCH();
       return A2C_OK;
     }
+  }
+  if (staged_out) {            // generic kernel: output tile assembled in LDS, flushed coalesced
+    p.out_stage = t.Cp * t.PLANE + 64;
+    p.out_vec = (d->OW % 4 == 0) && (out_bstride % 4 == 0) && (((long)d->OH * d->OW) % 4 == 0) && ((uintptr_t)out % 16 == 0);
   }
   if (run) {   // generic kernel on a run-ordered layer: steps walk (c4, ky, kx)
     p.nb = d->ks; p.c4n = d->ks;                      // walker levels: outer c4, mid ky, inner kx
@@ -1441,6 +1498,7 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
     fill_stage(p.st, t, dout, (long)d->Cout * d->OH * d->OW);
     p.out = din; p.out_bs = (long)d->Cin * d->H * d->W; p.Mch = d->Cin; p.OHf = d->H; p.OWf = d->W;
     p.wfrag = wprep_bwd + bwd_class_offset(d, cls); p.bias = nullptr; p.mask = mask; p.relu = 0;
+    p.out_stage = 0; p.out_vec = 0;
     p.PH = ny; p.PW = nx; p.oy_mul = S; p.oy_add = S * qy0 + ry - P; p.ox_mul = S; p.ox_add = S * qx0 + rx - P;
     p.SY = 1; p.SX = 1; p.sy0 = t.sy0; p.TPH = t.TPH; p.tiles = t.tiles; p.B = B;
     const int c4n = d->Cout / 4;
@@ -1489,6 +1547,7 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
   p.Cout = d->Cout; p.K = d->Cin * d->ks * d->ks; p.ks = d->ks; p.OH = d->OH; p.OW = d->OW; p.OWp = pl.OWp;
   p.S = d->stride; p.sy0 = pl.t.sy0; p.TPH = pl.t.TPH; p.tiles = pl.t.tiles; p.B = B;
   p.PLANEo = pl.PLANEo; p.nkt = ceil_div(p.K, 16);
+  p.dvec = (d->OW % 4 == 0) && ((uintptr_t)dout % 16 == 0);
   if (pl.MT == 1 && pl.KTW == 1) launch_wgrad_t<1, 1>(p, pl.grid, pl.lds, st);
   else if (pl.MT == 1 && pl.KTW == 4) launch_wgrad_t<1, 4>(p, pl.grid, pl.lds, st);
   else if (pl.MT == 2 && pl.KTW == 4) launch_wgrad_t<2, 4>(p, pl.grid, pl.lds, st);

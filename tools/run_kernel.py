@@ -25,6 +25,9 @@ if what == "scan":
         ops.gae_returns(x, r, d, .9702, .99, n_seg, T, a, b)
 else:
     spec = (4, 84, 84, 16, 8, 4, 0) if what.startswith("conv1") else (16, 20, 20, 32, 4, 2, 0)
+    if what.startswith("spec:"):      # spec:Cin,H,W,Cout,ks,stride,pad:fwd|wgrad|bwd_data
+        spec = tuple(int(v) for v in what.split(":")[1].split(","))
+        what = "x_" + what.split(":")[2]
     d = ops.conv_desc(*spec)
     Cin, H, W, Cout = spec[:4]
     x = (torch.rand(B, Cin, H, W, device=dev, generator=g) < 0.25).float()

@@ -227,6 +227,22 @@ class A3CModel(_HipNet):
     def _prep(self, st):
         self._c1.prep(self.P("convs.0.0.weight"), st)
         self._c2.prep(self.P("convs.1.0.weight"), st)
+        # Inference-only composition: proj_matrx has NO activation (models.py:73), so
+        #   [logits | value] = (f Wp^T + bp) Wh^T + bh = f (Wh Wp)^T + (Wh bp + bh).
+        # Wc = Wh Wp ((A+1) x flat) lets a rollout step skip the h x flat GEMM entirely; the update
+        # (which needs the embedding for its backward pass) keeps the exact two-step path.
+        A, h, F = self.output_space, self.h_size, self.flat_size
+        ar = self._arena
+        Wh = ar.params[ar.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
+        bh = ar.params[ar.offsets["pi.bias"][0]:][:A + 1]
+        if getattr(self, "_Wc", None) is None:
+            self._Wc = torch.empty(A + 1, F, device=self._dev)
+            self._bc = torch.empty(A + 1, device=self._dev)
+        ops.gemm(0, 0, A + 1, F, h, Wh.data_ptr(), h, self.P("proj_matrx.weight").data_ptr(), F, self._Wc.data_ptr(), F,
+                 st=st)
+        ops.gemm(0, 0, A + 1, 1, h, Wh.data_ptr(), h, self.P("proj_matrx.bias").data_ptr(), 1, self._bc.data_ptr(), 1,
+                 bias=None, st=st)
+        ops.add(self._bc, bh, self._bc, st)
 
     _fused_sampling = True       # _fwd(..., sampler=(u, actions_ptr, act_stride)) samples inside the heads kernel
 
@@ -243,6 +259,11 @@ class A3CModel(_HipNet):
         Wh = self._arena.params[self._arena.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
         bh = self._arena.params[self._arena.offsets["pi.bias"][0]:][:A + 1]
         u, a_ptr, a_stride = sampler if sampler is not None else (None, 0, 0)
+        if sampler is not None and not save and os.environ.get("A2C_NO_COMPOSED_HEADS") != "1":
+            # rollout step: heads straight from the conv features through the composed matrix
+            ops.heads_fused(a2.data_ptr(), 1, 0, self.flat_size, None, False, None, self._Wc, self._bc, hb, B, u, A,
+                            a_ptr, a_stride, st)
+            return dict(logits=logits, vals=vals, sampled=True)
         Wp = P("proj_matrx.weight")
         sk = ops.pick_splitk(B, h, self.flat_size)
         if sk > 1 and os.environ.get("A2C_NO_FUSED_TAIL") != "1":

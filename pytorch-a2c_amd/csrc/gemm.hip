@@ -309,6 +309,8 @@ __global__ __launch_bounds__(256) void small_n_bwd_weight_reduce(const float* __
 }
 
 // fused forward tail: slab sum + bias (+ReLU) -> [emb] -> N<=8 heads -> [softmax + inverse-CDF sample]
+// One WORKGROUP per row: its 4 waves split K (16 B per lane per pass), butterfly + LDS reduce in a
+// fixed order (deterministic), thread 0 finishes the row.
 __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restrict__ xs, int nslab, long slab_stride,
                                                           long ldx, const float* __restrict__ bias_in, int relu_in,
                                                           float* __restrict__ emb_out, long ld_emb,
@@ -316,12 +318,13 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restric
                                                           float* __restrict__ heads, long ldh, long M, int N, int K,
                                                           const float* __restrict__ u, int n_logits,
                                                           int64_t* __restrict__ actions, long act_stride) {
-  const int lane = threadIdx.x & 63;
-  for (long m = blockIdx.x * 4L + (threadIdx.x >> 6); m < M; m += gridDim.x * 4L) {
+  __shared__ float red[4][SN_MAX];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (long m = blockIdx.x; m < M; m += gridDim.x) {
     float acc[SN_MAX];
 #pragma unroll
     for (int n = 0; n < SN_MAX; ++n) acc[n] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
+    for (int k = tid * 4; k < K; k += 1024) {
       float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
       int z = 0;
       for (; z + 8 <= nslab; z += 8) {                 // 8 slab loads in flight, fixed summation order
@@ -344,20 +347,27 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restric
 #pragma unroll
       for (int n = 0; n < SN_MAX; ++n)
         if (n < N) {
-          const float4 wv = *reinterpret_cast<const float4*>(W + (long)n * K + k);
-          acc[n] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+          const float4 wv4 = *reinterpret_cast<const float4*>(W + (long)n * K + k);
+          acc[n] += xv.x * wv4.x + xv.y * wv4.y + xv.z * wv4.z + xv.w * wv4.w;
         }
     }
-    float h[SN_MAX];
 #pragma unroll
-    for (int n = 0; n < SN_MAX; ++n) {
-      h[n] = 0.f;
-      if (n < N) h[n] = wave_sum(acc[n]) + (b ? b[n] : 0.f);
-    }
-    if (lane == 0) {
+    for (int n = 0; n < SN_MAX; ++n)
+      if (n < N) {
+        const float v = wave_sum(acc[n]);
+        if (lane == 0) red[wv][n] = v;
+      }
+    __syncthreads();
+    if (tid == 0) {
+      float h[SN_MAX];
 #pragma unroll
-      for (int n = 0; n < SN_MAX; ++n)
-        if (n < N) heads[m * ldh + n] = h[n];
+      for (int n = 0; n < SN_MAX; ++n) {
+        h[n] = 0.f;
+        if (n < N) {
+          h[n] = ((red[0][n] + red[1][n]) + (red[2][n] + red[3][n])) + (b ? b[n] : 0.f);
+          heads[m * ldh + n] = h[n];
+        }
+      }
       if (u != nullptr) {      // same maths as sample_kernel<true>: softmax, running fp32 cumsum, first >= u
         float mx = -INFINITY;
 #pragma unroll
@@ -379,6 +389,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restric
         actions[m * act_stride] = (int64_t)pick;
       }
     }
+    __syncthreads();
   }
 }
 
@@ -505,7 +516,7 @@ int a2c_heads_fused(const float* xs, int nslab, int64_t slab_stride, int64_t ldx
   if (ldx % 4 || slab_stride % 4 || (emb_out && ld_emb % 4)) return A2C_ERR_ARG;
   if (((uintptr_t)xs | (uintptr_t)W | (uintptr_t)(bias_in ? bias_in : W) | (uintptr_t)(emb_out ? emb_out : (float*)W)) % 16)
     return A2C_ERR_ARG;
-  hipLaunchKernelGGL(heads_fused_kernel, dim3(a2c_grid_1d(M, 4, 4096)), dim3(256), 0, a2c_s(stream), xs, nslab,
+  hipLaunchKernelGGL(heads_fused_kernel, dim3(a2c_grid_1d(M, 1, 8192)), dim3(256), 0, a2c_s(stream), xs, nslab,
                      (long)slab_stride, (long)ldx, bias_in, relu_in, emb_out, (long)ld_emb, W, b, heads, (long)ldh,
                      (long)M, N, K, u, n_logits, actions, (long)act_stride);
   A2C_CHECK_LAUNCH();

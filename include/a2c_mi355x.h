@@ -98,6 +98,13 @@ int a2c_rollout_record(const float *rew, const float *done, const float *val, in
                        float *rewards, float *dones, float *deltas, float *done_eff_out,
                        float *h, int hdim, int B, int64_t T, int64_t t, int64_t slot0,
                        float gamma, int pong, a2c_stream_t stream);
+/* a2c_rollout_record (feed-forward nets: no hidden state) and a2c_frame_stack_push of the same
+ * env step in ONE launch (one hipGraph node fewer per rollout step).                     */
+int a2c_rollout_post(const float *rew, const float *done, const float *val, int64_t val_stride,
+                     float *val_prev, float *rewards, float *dones, float *deltas, int64_t T,
+                     int64_t t, int64_t slot0, float gamma, int pong, const float *frame_new,
+                     const float *reset_mask, const float *prev, int64_t prev_stride, float *out,
+                     int64_t out_stride, int B, int C, int HW, a2c_stream_t stream);
 /* End of slot (runner.py:236-245): e = slot*T + T-1; if dones[e] == 0:
  * rewards[e] += gamma*val_boot[b], dones[e] = 1; then deltas[e] = rewards[e] - val_prev[b]. */
 int a2c_rollout_bootstrap(const float *val_boot, int64_t val_stride, const float *val_prev, float *rewards,

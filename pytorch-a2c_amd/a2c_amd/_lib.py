@@ -35,6 +35,8 @@ SIGNATURES = {
     "a2c_sample_probs": (c_int, [P, P, P, c_int64, c_int, P]),
     "a2c_rollout_record": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_int64, c_int64, c_int64,
                                     c_float, c_int, P]),
+    "a2c_rollout_post": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_int, P, P, P, c_int64,
+                                  P, c_int64, c_int, c_int, c_int, P]),
     "a2c_rollout_bootstrap": (c_int, [P, c_int64, P, P, P, P, c_int, c_int64, c_int64, c_float, P]),
     "a2c_copy_rows": (c_int, [P, c_int64, P, c_int64, c_int, c_int64, P]),
     "a2c_mask_rows": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P]),

@@ -176,6 +176,15 @@ def rollout_record(rew, done, val_ptr, val_stride, val_prev, rewards, dones, del
           "a2c_rollout_record")
 
 
+def rollout_post(rew, done, val_ptr, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma, pong, frame_new,
+                 reset_mask, prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW, st=None):
+    """record + frame_stack_push of one env step in one launch (feed-forward nets)"""
+    check(lib().a2c_rollout_post(_p(rew), _p(done), val_ptr, val_stride, _p(val_prev), _p(rewards), _p(dones),
+                                 _p(deltas), T, t, slot0, float(gamma), int(bool(pong)), _p(frame_new), _p(reset_mask),
+                                 prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW,
+                                 st if st is not None else stream()), "a2c_rollout_post")
+
+
 def rollout_bootstrap(val_ptr, val_stride, val_prev, rewards, dones, deltas, B, T, slot0, gamma, st=None):
     check(lib().a2c_rollout_bootstrap(val_ptr, val_stride, _p(val_prev), _p(rewards), _p(dones), _p(deltas), B, T, slot0,
                                       float(gamma), st if st is not None else stream()), "a2c_rollout_bootstrap")

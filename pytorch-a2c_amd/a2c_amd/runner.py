@@ -252,6 +252,12 @@ class Runner:
             else:
                 frames, rew, done, reset = self._host_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift,
                                                            acts_host_out, pong)
+            nxt_ptr, nxt_stride = (sp(t + 1), T * S) if t + 1 < T else (bm.data_ptr(), S)
+            if h is None and side is None and HW % 4 == 0 and S % 4 == 0 and os.environ.get("A2C_NO_POST_FUSE") != "1":
+                # feed-forward net: bookkeeping + next frame stack in ONE launch
+                ops.rollout_post(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t, slot0,
+                                 gamma, pong, frames, reset, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
+                continue
             if side is not None:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):

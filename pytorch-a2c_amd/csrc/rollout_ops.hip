@@ -86,6 +86,51 @@ __global__ __launch_bounds__(256) void record_kernel(const float* __restrict__ r
   val_prev[b] = v;
 }
 
+// record + frame stack in one launch: blocks with blockIdx.z < C stack plane z, the z == C layer
+// (only its x == 0 blocks, one per 256 envs) does the bookkeeping of record_kernel
+__global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ rew, const float* __restrict__ done,
+                                                   const float* __restrict__ val, long vstride,
+                                                   float* __restrict__ val_prev, float* __restrict__ rewards,
+                                                   float* __restrict__ dones, float* __restrict__ deltas, long T, long t,
+                                                   long slot0, float gamma, int pong,
+                                                   const float* __restrict__ frame_new,
+                                                   const float* __restrict__ reset_mask, const float* __restrict__ prev,
+                                                   long prev_stride, float* __restrict__ out, long out_stride, int B,
+                                                   int C, int HW) {
+  if ((int)blockIdx.z == C) {
+    if (blockIdx.x != 0) return;
+    const int b = blockIdx.y * 256 + threadIdx.x;
+    if (blockIdx.y * 256 >= B || b >= B) return;
+    const long e = (slot0 + b) * T + t;
+    const float r = rew[b];
+    float d = done[b] != 0.f ? 1.f : 0.f;
+    if (pong && r != 0.f) d = 1.f;
+    rewards[e] = r;
+    dones[e] = d;
+    const float v = val[b * vstride];
+    if (t > 0) {
+      const float pr = rewards[e - 1], pd = dones[e - 1];
+      const float gv = gamma * v;
+      deltas[e - 1] = (pr + gv * (1.f - pd)) - val_prev[b];
+    }
+    val_prev[b] = v;
+    return;
+  }
+  const int b = blockIdx.y;
+  const int c = blockIdx.z;
+  const bool rst = reset_mask != nullptr && reset_mask[b] != 0.f;
+  float* o = out + (long)b * out_stride + (long)c * HW;
+  const float* src = nullptr;
+  if (c == C - 1) src = frame_new + (long)b * HW;
+  else if (!rst) src = prev + (long)b * prev_stride + (long)(c + 1) * HW;
+  const int n4 = HW >> 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src) v = reinterpret_cast<const float4*>(src)[i];
+    reinterpret_cast<float4*>(o)[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void zero_done_rows_kernel(float* __restrict__ h, int hdim,
                                                              const float* __restrict__ done_eff, int B) {
   const long i = blockIdx.x * 256L + threadIdx.x;
@@ -204,6 +249,25 @@ int a2c_rollout_record(const float* rew, const float* done, const float* val, in
                        done_eff_out, B);
     A2C_CHECK_LAUNCH();
   }
+  return A2C_OK;
+}
+
+int a2c_rollout_post(const float* rew, const float* done, const float* val, int64_t val_stride, float* val_prev,
+                     float* rewards, float* dones, float* deltas, int64_t T, int64_t t, int64_t slot0, float gamma, int pong,
+                     const float* frame_new, const float* reset_mask, const float* prev, int64_t prev_stride, float* out,
+                     int64_t out_stride, int B, int C, int HW, a2c_stream_t stream) {
+  if (B < 0 || T < 1 || t < 0 || t >= T || C < 1 || HW < 4 || HW % 4) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!rew || !done || !val || !val_prev || !rewards || !dones || !deltas || !frame_new || !out || (C > 1 && !prev))
+    return A2C_ERR_ARG;
+  if (prev_stride % 4 || out_stride % 4 || (((uintptr_t)frame_new | (uintptr_t)prev | (uintptr_t)out) % 16))
+    return A2C_ERR_ARG;
+  const int work = HW / 4;
+  dim3 grid((work + 255) / 256 > 8 ? 8 : (work + 255) / 256, B, C + 1);
+  hipLaunchKernelGGL(post_kernel, grid, dim3(256), 0, a2c_s(stream), rew, done, val, (long)val_stride, val_prev, rewards,
+                     dones, deltas, (long)T, (long)t, (long)slot0, gamma, pong, frame_new, reset_mask, prev,
+                     (long)prev_stride, out, (long)out_stride, B, C, HW);
+  A2C_CHECK_LAUNCH();
   return A2C_OK;
 }
 

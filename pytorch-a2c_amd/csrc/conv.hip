@@ -460,10 +460,163 @@ __global__ __launch_bounds__(256) void igemm_run_kernel(IgemmP p, int nfrag) {
   }
 }
 
+// Same pipeline for the 3x3 / pad 1 layers (ConvModel, GRUModel) whose rows are 16 B aligned
+// (W % 4 == 0): the image keeps a one-column zero halo (LDS column = x + 1, zeroed once), source
+// rows above/below the picture are prefetched as zeros, the three taps of a kernel row are three
+// consecutive LDS words per lane, and the output band is assembled in LDS and flushed with
+// coalesced stores (these layers' outputs are up to 14.8 GB per tensor at 32 768 samples).
+constexpr int PF3 = 16;              // float4 prefetch registers per thread (64 KB image)
+template <int MT, int S>
+__global__ __launch_bounds__(256) void igemm_run3_kernel(IgemmP p, int nfrag) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ ldsA = lds;
+  float* __restrict__ img = lds + nfrag;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const long total = (long)p.B * p.tiles;
+  const int WP = p.st.WP, PLANE = p.st.PLANE;
+  float* __restrict__ outb = img + p.st.Cp * PLANE + 64;          // [Mch][TPH*PW]
+  for (int i = tid; i < nfrag; i += 256) ldsA[i] = p.wfrag[i];
+  for (int i = tid; i < p.st.Cp * PLANE + 64; i += 256) img[i] = 0.f;    // halo columns stay 0
+  float bias_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int co = m * 16 + 4 * g + rr;
+      bias_r[m][rr] = (p.bias && co < p.Mch) ? p.bias[co] : 0.f;
+    }
+  const int nv = p.st.IW >> 2;
+  const int per4 = p.st.TIH * nv;
+  const int tot4 = p.st.Cp * per4;
+  int dst[PF3], srcoff[PF3], rrow[PF3];
+#pragma unroll
+  for (int u = 0; u < PF3; ++u) {
+    const int idx = tid + u * 256;
+    dst[u] = -1; srcoff[u] = 0; rrow[u] = 0;
+    if (idx < tot4) {
+      const int c = idx / per4, rem = idx - c * per4;
+      const int r = rem / nv, x = (rem - r * nv) << 2;
+      dst[u] = c * PLANE + r * WP + x + 1;
+      srcoff[u] = (c * p.st.IH + r) * p.st.IW + x;
+      rrow[u] = r;
+    }
+  }
+  float4 pf[PF3];
+  auto issue = [&](long tile) {
+    const long b = tile / p.tiles;
+    const int ti = (int)(tile - b * p.tiles);
+    const int y_lo = ti * p.TPH * S - 1;
+    const float* __restrict__ base = p.st.src + b * p.st.bstride + (long)y_lo * p.st.IW;
+#pragma unroll
+    for (int u = 0; u < PF3; ++u) {
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ys = y_lo + rrow[u];
+      if (dst[u] >= 0 && ys >= 0 && ys < p.st.IH) pf[u] = *reinterpret_cast<const float4*>(base + srcoff[u]);
+    }
+  };
+  long tile = blockIdx.x;
+  if (tile < total) issue(tile);
+  for (; tile < total; tile += gridDim.x) {
+    const long b = tile / p.tiles;
+    const int ti = (int)(tile - b * p.tiles);
+    const int qq0 = ti * p.TPH;
+    const int rows = min(p.TPH, p.PH - qq0);
+    const int NP = rows * p.PW;
+    __syncthreads();                       // readers of the previous tile (image and out band) are done
+#pragma unroll
+    for (int u = 0; u < PF3; ++u)
+      if (dst[u] >= 0) {
+        img[dst[u]] = pf[u].x; img[dst[u] + 1] = pf[u].y; img[dst[u] + 2] = pf[u].z; img[dst[u] + 3] = pf[u].w;
+      }
+    __syncthreads();
+    if (tile + gridDim.x < total) issue(tile + gridDim.x);
+    const int npairs = (NP + 31) >> 5;
+    for (int pr = w; pr < npairs; pr += 4) {
+      const int idx0 = pr * 32 + j, idx1 = idx0 + 16;
+      const bool ok0 = idx0 < NP, ok1 = idx1 < NP;
+      const int i0 = ok0 ? idx0 : 0, i1 = ok1 ? idx1 : 0;
+      const int r0 = i0 / p.PW, c0 = i0 - r0 * p.PW;
+      const int r1 = i1 / p.PW, c1 = i1 - r1 * p.PW;
+      const float* __restrict__ l0 = img + r0 * S * WP + c0 * S + g * PLANE;
+      const float* __restrict__ l1 = img + r1 * S * WP + c1 * S + g * PLANE;
+      const float* __restrict__ la = ldsA + lane;
+      f32x4 acc[MT][2];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      for (int c4 = 0; c4 < p.c4n; ++c4) {       // 9 MFMA steps (3 kernel rows x 3 taps) per channel quad
+        const int poff = c4 * 4 * PLANE;
+        const int s0 = c4 * 9;
+        float bv0[9], bv1[9], av[9 * MT];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            bv0[ky * 3 + kx] = l0[poff + ky * WP + kx];
+            bv1[ky * 3 + kx] = l1[poff + ky * WP + kx];
+          }
+#pragma unroll
+        for (int u = 0; u < 9; ++u)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) av[u * MT + m] = la[((s0 + u) * MT + m) * 64];
+#pragma unroll
+        for (int u = 0; u < 9; ++u)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u * MT + m], bv0[u], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u * MT + m], bv1[u], acc[m][1], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (!(nt ? ok1 : ok0)) continue;
+        const int ip = nt ? i1 : i0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int co = m * 16 + 4 * g + rr;
+            if (co < p.Mch) {
+              float v = acc[m][nt][rr] + bias_r[m][rr];
+              if (p.relu) v = fmaxf(v, 0.f);
+              outb[co * p.TPH * p.PW + ip] = v;
+            }
+          }
+      }
+    }
+    __syncthreads();
+    {  // coalesced flush: NP contiguous floats per channel
+      float* __restrict__ ob = p.out + b * p.out_bs + (long)qq0 * p.OWf;
+      const long chs = (long)p.OHf * p.OWf;
+      if (p.out_vec) {
+        const int p4 = NP >> 2, n4 = p.Mch * p4;
+        for (int i = tid; i < n4; i += 256) {
+          const int co = i / p4, e = (i - co * p4) << 2;
+          *reinterpret_cast<float4*>(ob + co * chs + e) = *reinterpret_cast<const float4*>(outb + co * p.TPH * p.PW + e);
+        }
+      } else {
+        const int n = p.Mch * NP;
+        for (int i = tid; i < n; i += 256) {
+          const int co = i / NP, e = i - co * NP;
+          ob[co * chs + e] = outb[co * p.TPH * p.PW + e];
+        }
+      }
+    }
+  }
+}
+
 // layers that take the row-run kernel (and therefore the (c4, ky, kx) fragment order)
 static bool run_layout(const a2c_conv_desc* d) {
   return d->pad == 0 && d->W % 4 == 0 && d->Cout <= 32 &&
          ((d->ks == 8 && d->stride == 4) || (d->ks == 4 && d->stride == 2));
+}
+// 3x3 / pad 1 layers with 16 B aligned rows whose fragments fit LDS: igemm_run3_kernel
+static bool run3_layout(const a2c_conv_desc* d) {
+  return d->ks == 3 && d->pad == 1 && d->W % 4 == 0 && d->Cout <= 32 && (d->stride == 1 || d->stride == 2) &&
+         (size_t)9 * (d->Cin / 4) * ((d->Cout + 15) / 16) * 64 * 4 <= 48 * 1024;
 }
 
 // weights -> A fragments.  kind 0 (forward): step s = tap*(Cin/4) + c4, lane l:
@@ -1300,7 +1453,7 @@ int a2c_conv2d_prep_weights(const a2c_conv_desc* d, int kind, const float* weigh
     const int MT = ceil_div(d->Cout, 16);
     const long total = (long)a2c_conv2d_prep_floats(d, 0);
     hipLaunchKernelGGL(prep_fwd_kernel, dim3(a2c_grid_1d(total, 256)), dim3(256), 0, st, weight, wprep, d->Cin, d->Cout,
-                       d->ks, MT, run_layout(d) ? 1 : 0, total);
+                       d->ks, MT, (run_layout(d) || run3_layout(d)) ? 1 : 0, total);
     A2C_CHECK_LAUNCH();
     return A2C_OK;
   }
@@ -1379,11 +1532,54 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
       return A2C_OK;
     }
   }
+  const bool run3 = run3_layout(d);
+  if (run3 && in_bstride % 4 == 0 && ((uintptr_t)in % 16 == 0) && !getenv("A2C_NO_PF") && !getenv("A2C_NO_RUN3")) {
+    const int S = d->stride;
+    const bool ovec = (d->OW % 4 == 0) && (out_bstride % 4 == 0) && (((long)d->OH * d->OW) % 4 == 0) && ((uintptr_t)out % 16 == 0);
+    const long budget = (long)env_kb("A2C_RUN3_LDS_KB", 80);
+    int tph = 0, plane_best = 0;
+    double best = -1.0;
+    for (int c = 1; c <= d->OH; ++c) {
+      const int tih = (c - 1) * S + 3;
+      if ((long)d->Cin * tih * d->W > 256L * PF3 * 4) break;
+      const int wp = d->W + 2;
+      const int plane = ((tih * wp + 31) / 32) * 32 + (S == 1 ? 16 : 1);
+      const long bytes = 4L * ((long)nfrag + (long)d->Cin * plane + 64 + (long)d->Cout * c * d->OW);
+      if (bytes > budget) break;
+      const int ntl = ceil_div(d->OH, c);
+      long slots = 0;
+      for (int i = 0; i < ntl; ++i) {
+        const int r = (i + 1 < ntl) ? c : d->OH - c * (ntl - 1);
+        slots += (long)ceil_div(ceil_div(r * d->OW, 32), 4) * 4 * 32;
+      }
+      const double eff = (double)d->OH * d->OW / slots - 0.02 * (double)tih * ntl / d->H;
+      if (eff > best) { best = eff; tph = c; plane_best = plane; }
+    }
+    if (tph >= 1) {
+      t.TPH = tph; t.TIH = (tph - 1) * S + 3; t.WP = d->W + 2; t.PLANE = plane_best;
+      t.tiles = ceil_div(t.PH, t.TPH);
+      fill_stage(p.st, t, in, in_bstride);
+      p.TPH = t.TPH; p.tiles = t.tiles; p.out_vec = ovec ? 1 : 0;
+      const size_t lds = 4 * ((size_t)nfrag + (size_t)t.Cp * t.PLANE + 64 + (size_t)d->Cout * t.TPH * d->OW);
+      const long total = (long)B * t.tiles;
+      const void* k = S == 1 ? (MT == 1 ? (const void*)igemm_run3_kernel<1, 1> : (const void*)igemm_run3_kernel<2, 1>)
+                             : (MT == 1 ? (const void*)igemm_run3_kernel<1, 2> : (const void*)igemm_run3_kernel<2, 2>);
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const int grid = resident_grid(k, lds, total);
+      hipStream_t st = a2c_s(stream);
+      if (S == 1 && MT == 1) hipLaunchKernelGGL((igemm_run3_kernel<1, 1>), dim3(grid), dim3(256), lds, st, p, nfrag);
+      else if (S == 1) hipLaunchKernelGGL((igemm_run3_kernel<2, 1>), dim3(grid), dim3(256), lds, st, p, nfrag);
+      else if (MT == 1) hipLaunchKernelGGL((igemm_run3_kernel<1, 2>), dim3(grid), dim3(256), lds, st, p, nfrag);
+      else hipLaunchKernelGGL((igemm_run3_kernel<2, 2>), dim3(grid), dim3(256), lds, st, p, nfrag);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
   if (staged_out) {            // generic kernel: output tile assembled in LDS, flushed coalesced
     p.out_stage = t.Cp * t.PLANE + 64;
     p.out_vec = (d->OW % 4 == 0) && (out_bstride % 4 == 0) && (((long)d->OH * d->OW) % 4 == 0) && ((uintptr_t)out % 16 == 0);
   }
-  if (run) {   // generic kernel on a run-ordered layer: steps walk (c4, ky, kx)
+  if (run || run3) {   // generic kernel on a run-ordered layer: steps walk (c4, ky, kx)
     p.nb = d->ks; p.c4n = d->ks;                      // walker levels: outer c4, mid ky, inner kx
     p.step_a = 4 * t.PLANE; p.step_b = t.WP; p.step_c = 1;
     return launch_igemm(p, MT, a2c_s(stream));

@@ -42,12 +42,20 @@ else:
     dW, db = torch.empty_like(w), torch.empty(Cout, device=dev)
     ws = torch.empty(max(1, ops.conv_bwd_weight_ws_bytes(d, B) // 4), device=dev)
     din = torch.empty_like(x)
-    for _ in range(reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(reps + 1):
+        if it == 1:
+            e0.record()
         if what.endswith("_fwd"):
             ops.conv_fwd(d, x.data_ptr(), Cin * H * W, wf, bias, True, out, B)
         elif what.endswith("_wgrad"):
             ops.conv_bwd_weight(d, x.data_ptr(), Cin * H * W, dout, dW, db, B, ws)
         else:
             ops.conv_bwd_data(d, dout, wb, x, din, B)
+    e1.record()
+    torch.cuda.synchronize()
+    fl = 2.0 * B * Cout * d.OH * d.OW * Cin * spec[4] * spec[4]
+    ms = e0.elapsed_time(e1) / reps
+    print(f"{what} {spec} B={B}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
 torch.cuda.synchronize()
 print("done", what, B, reps)

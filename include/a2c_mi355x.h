@@ -110,6 +110,41 @@ int a2c_rollout_post(const float *rew, const float *done, const float *val, int6
 int a2c_rollout_bootstrap(const float *val_boot, int64_t val_stride, const float *val_prev, float *rewards,
                           float *dones, float *deltas, int B, int64_t T, int64_t slot0,
                           float gamma, a2c_stream_t stream);
+/* One whole rollout step of the A3CModel-shaped policy (models.py:60-90: conv 8x8/s4 -> 16,
+ * conv 4x4/s2 -> 32, proj_matrx WITHOUT activation, pi/value heads) in ONE launch, one workgroup
+ * per env; replaces, per step of Runner.rollout (runner.py:190-232):
+ *   1. (rew != NULL) a2c_rollout_record of the env step that produced this state: step index
+ *      t_rec, value read from heads[b*ldh + n_actions] as left by the previous call;
+ *   2. the state: frame_new != NULL: a2c_frame_stack_push(prev, frame_new, reset_mask);
+ *      frame_new == NULL: the rows of prev as they are.  If out != NULL the state is also written
+ *      to out[b*out_stride ..] (the states row of the rollout buffer / the bookmark);
+ *   3. the forward pass on that state with the weights prepared for inference:
+ *      wfrag1/wfrag2 = a2c_conv2d_prep_weights(kind 0) of the two conv layers,
+ *      Wc ((n_actions+1) x F) = [pi.weight; value.weight] . proj_matrx.weight, bc likewise;
+ *      heads[b*ldh + 0..n_actions] = [logits | value];
+ *   4. (u != NULL) a2c_softmax_sample of the logits into actions[b*act_stride];
+ *   5. (bootstrap != 0, t_rec == T-1) a2c_rollout_bootstrap with the value just computed
+ *      (runner.py:236-245).
+ * Requires C == 4, W % 4 == 0 and the state + activations to fit one CU's LDS
+ * (a2c_a3c_step_supported); other shapes use the per-layer entry points.               */
+typedef struct {
+  int B, C, H, W, n_actions;
+  const float *prev; int64_t prev_stride;
+  const float *frame_new;          /* (B, H*W) or NULL                                   */
+  const float *reset_mask;         /* (B,) or NULL                                       */
+  float *out; int64_t out_stride;  /* or NULL                                            */
+  const float *wfrag1, *bias1, *wfrag2, *bias2, *Wc, *bc;
+  float *heads; int64_t ldh;
+  const float *u;                  /* (B,) uniforms or NULL (no sampling)                */
+  int64_t *actions; int64_t act_stride;
+  const float *rew, *done;         /* (B,) of env step t_rec, or NULL (no bookkeeping)   */
+  float *val_prev, *rewards, *dones, *deltas;
+  int64_t T, t_rec, slot0;
+  float gamma;
+  int pong, bootstrap;
+} a2c_a3c_step_args;
+int a2c_a3c_step_supported(int C, int H, int W, int n_actions);
+int a2c_a3c_step(const a2c_a3c_step_args *args, a2c_stream_t stream);
 /* dst[b*dst_stride + j] = src[b*src_stride + j], j < n  (h_states[e] = h, runner.py:201;
  * gathers/scatters of per-step rows of the rollout-major buffers)                       */
 int a2c_copy_rows(const float *src, int64_t src_stride, float *dst, int64_t dst_stride, int B,

@@ -21,6 +21,21 @@ class ConvDesc(Structure):
 P = c_void_p
 PD = POINTER(ConvDesc)
 
+
+class A3CStepArgs(Structure):
+    """a2c_a3c_step_args"""
+    _fields_ = [("B", c_int), ("C", c_int), ("H", c_int), ("W", c_int), ("n_actions", c_int),
+                ("prev", P), ("prev_stride", c_int64), ("frame_new", P), ("reset_mask", P),
+                ("out", P), ("out_stride", c_int64),
+                ("wfrag1", P), ("bias1", P), ("wfrag2", P), ("bias2", P), ("Wc", P), ("bc", P),
+                ("heads", P), ("ldh", c_int64), ("u", P), ("actions", P), ("act_stride", c_int64),
+                ("rew", P), ("done", P), ("val_prev", P), ("rewards", P), ("dones", P), ("deltas", P),
+                ("T", c_int64), ("t_rec", c_int64), ("slot0", c_int64), ("gamma", c_float),
+                ("pong", c_int), ("bootstrap", c_int)]
+
+
+PS = POINTER(A3CStepArgs)
+
 # name -> (restype, argtypes); one entry per prototype in include/a2c_mi355x.h
 SIGNATURES = {
     "a2c_version": (c_int, []),
@@ -57,6 +72,8 @@ SIGNATURES = {
     "a2c_colsum_ws_bytes": (c_size_t, [c_int64]),
     "a2c_colsum": (c_int, [P, c_int64, c_int64, c_int64, P, P, c_size_t, P]),
     "a2c_conv2d_prep_floats": (c_size_t, [PD, c_int]),
+    "a2c_a3c_step_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "a2c_a3c_step": (c_int, [PS, P]),
     "a2c_conv2d_prep_weights": (c_int, [PD, c_int, P, P, P]),
     "a2c_conv2d_fwd": (c_int, [PD, P, c_int64, P, P, c_int, P, c_int64, c_int, P]),
     "a2c_conv2d_bwd_data": (c_int, [PD, P, P, P, P, c_int, P]),

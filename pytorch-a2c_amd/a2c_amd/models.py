@@ -280,6 +280,25 @@ class A3CModel(_HipNet):
             ops.heads_fused(emb.data_ptr(), 1, 0, h, None, False, None, Wh, bh, hb, B, u, A, a_ptr, a_stride, st)
         return dict(logits=logits, vals=vals, sampled=u is not None)
 
+    def _step_supported(self):
+        """True when the one-launch rollout step (a2c_a3c_step) covers this net's shapes."""
+        if os.environ.get("A2C_NO_FUSED_STEP") == "1" or os.environ.get("A2C_NO_COMPOSED_HEADS") == "1":
+            return False
+        C, H, W = self.input_space[-3:]
+        return ops.a3c_step_supported(C, H, W, self.output_space)
+
+    def _step(self, B, st, **kw):
+        """[bookkeeping] + [frame stack] + forward + [sample] + [bootstrap] of one rollout step in ONE
+        launch; ``kw`` = the state/bookkeeping fields of a2c_a3c_step_args."""
+        C, H, W = self.input_space[-3:]
+        hb, logits, vals = self._heads("roll", B)
+        P = self.P
+        ops.a3c_step(st, B=B, C=C, H=H, W=W, n_actions=self.output_space, wfrag1=self._c1.wf.data_ptr(),
+                     bias1=P("convs.0.0.bias").data_ptr(), wfrag2=self._c2.wf.data_ptr(),
+                     bias2=P("convs.1.0.bias").data_ptr(), Wc=self._Wc.data_ptr(), bc=self._bc.data_ptr(),
+                     heads=hb.data_ptr(), ldh=hb.stride(0), **kw)
+        return dict(logits=logits, vals=vals, sampled=True)
+
     def _bwd(self, x_ptr, bstride, B, tag, st):
         ws, P, G = self.ws(tag), self.P, self.G
         A, h = self.output_space, self.h_size

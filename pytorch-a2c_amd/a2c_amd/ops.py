@@ -185,6 +185,19 @@ def rollout_post(rew, done, val_ptr, val_stride, val_prev, rewards, dones, delta
                                  st if st is not None else stream()), "a2c_rollout_post")
 
 
+def a3c_step_supported(C, H, W, n_actions):
+    return bool(lib().a2c_a3c_step_supported(int(C), int(H), int(W), int(n_actions)))
+
+
+def a3c_step(st=None, **kw):
+    """One whole rollout step of the A3CModel-shaped policy in one launch (see a2c_a3c_step in the
+    header).  Keyword arguments are the fields of a2c_a3c_step_args (pointers as ints, 0 = NULL)."""
+    args = _lib.A3CStepArgs()
+    for k, v in kw.items():
+        setattr(args, k, v)
+    check(lib().a2c_a3c_step(ctypes.byref(args), st if st is not None else stream()), "a2c_a3c_step")
+
+
 def rollout_bootstrap(val_ptr, val_stride, val_prev, rewards, dones, deltas, B, T, slot0, gamma, st=None):
     check(lib().a2c_rollout_bootstrap(val_ptr, val_stride, _p(val_prev), _p(rewards), _p(dones), _p(deltas), B, T, slot0,
                                       float(gamma), st if st is not None else stream()), "a2c_rollout_bootstrap")

@@ -228,6 +228,8 @@ class Runner:
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(device=net._dev)
             side = self._side
+        if h is None and side is None and getattr(net, "_step_supported", lambda: False)():
+            return self._rollout_block_fused(net, slot0, env0, B, hyps, sp, bm, val_prev, acts_host_out, st)
         # state of step 0 = the bookmark left by the previous slot (runner.py:190)
         ops.copy_rows(bm.data_ptr(), S, sp(0), T * S, B, S, st)
         for t in range(T):
@@ -275,6 +277,42 @@ class Runner:
         out = self._forward(net, bm.data_ptr(), S, B, env0, st)
         ops.rollout_bootstrap(out["vals"].data_ptr(), out["vals"].stride(0), val_prev, rewards, dones, deltas, B, T,
                               slot0, gamma, st)
+
+    def _rollout_block_fused(self, net, slot0, env0, B, hyps, sp, bm, val_prev, acts_host_out, st):
+        """The same slot with ONE launch per step (a2c_a3c_step): launch t writes state t (frame
+        stack of the frame env step t-1 returned), records env step t-1, runs the policy and samples
+        action t; launch T records step T-1, leaves the bookmark and bootstraps (runner.py:174-248)."""
+        D, pool = self.datas, self.env_pool
+        T, S = int(hyps["n_tsteps"]), self.S
+        gamma, pong, shift = hyps["gamma"], "Pong" in hyps["env_type"], hyps["action_shift"]
+        rec = dict(val_prev=val_prev.data_ptr(), rewards=D["rewards"].data_ptr(), dones=D["dones"].data_ptr(),
+                   deltas=D["deltas"].data_ptr(), T=T, slot0=slot0, gamma=float(gamma), pong=int(pong))
+        frames = rew = done = reset = None
+        for t in range(T + 1):
+            kw = dict(rec)
+            if t == 0:        # state of step 0 = the bookmark left by the previous slot (runner.py:190)
+                kw.update(prev=bm.data_ptr(), prev_stride=S, out=sp(0), out_stride=T * S)
+            else:
+                out_ptr, out_stride = (sp(t), T * S) if t < T else (bm.data_ptr(), S)
+                kw.update(prev=sp(t - 1), prev_stride=T * S, frame_new=frames.data_ptr(), reset_mask=reset.data_ptr(),
+                          out=out_ptr, out_stride=out_stride, rew=rew.data_ptr(), done=done.data_ptr(), t_rec=t - 1)
+            if t == T:
+                net._step(B, st, bootstrap=1, **kw)
+                break
+            u = self._uniforms(t, B, env0)
+            act = self.act_dev[env0:env0 + B]
+            if acts_host_out is None:
+                a_ptr, a_stride = D["actions"].data_ptr() + 8 * (slot0 * T + t), T
+            else:
+                a_ptr, a_stride = act.data_ptr(), 1
+            net._step(B, st, u=u.data_ptr(), actions=a_ptr, act_stride=a_stride, **kw)
+            if self.device_pool:
+                frames, rew, done, reset = pool.device_step(t, env0, B)
+            else:
+                frames, rew, done, reset = self._host_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift,
+                                                           acts_host_out, pong)
+            for name, x in (("frames", frames), ("rew", rew), ("done", done), ("reset", reset)):
+                ops._chk(x, name)
 
     def _host_step(self, pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong):
         """actions D2H -> env.step on the host -> frames/rewards/dones H2D through pinned buffers."""

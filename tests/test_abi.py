@@ -47,6 +47,13 @@ def test_argument_validation_without_gpu():
     d = _lib.ConvDesc(3, 8, 8, 16, 3, 1, 1, 8, 8)       # Cin % 4 != 0
     import ctypes
     assert lib.a2c_conv2d_prep_floats(ctypes.byref(d), 0) == 0
+    # one-launch rollout step: shape gate is host logic, bad argument blocks are refused
+    assert lib.a2c_a3c_step_supported(4, 84, 84, 6) == 1
+    assert lib.a2c_a3c_step_supported(3, 84, 84, 6) == 0 and lib.a2c_a3c_step_supported(4, 84, 82, 6) == 0
+    assert lib.a2c_a3c_step_supported(4, 200, 200, 6) == 0          # state does not fit one CU's LDS
+    assert lib.a2c_a3c_step(None, None) == -1
+    args = _lib.A3CStepArgs(B=2, C=4, H=84, W=84, n_actions=6)       # all pointers NULL
+    assert lib.a2c_a3c_step(ctypes.byref(args), None) == -1
 
 
 def test_product_refuses_cpu_tensors():

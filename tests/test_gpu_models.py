@@ -110,10 +110,16 @@ def _datas(N, ss, recurrent, h=256, actions_on_host=True):
     return D
 
 
+@pytest.mark.parametrize("fused_step", [True, False], ids=["step_kernel", "layered"])
 @pytest.mark.parametrize("case", ROLLOUT_CASES, ids=[c[0] for c in ROLLOUT_CASES])
-def test_runner_rollout_golden(golden, case):
-    """one env playing consecutive slots, against the trace recorded from the reference Runner"""
+def test_runner_rollout_golden(golden, case, fused_step, monkeypatch):
+    """one env playing consecutive slots, against the trace recorded from the reference Runner
+    (A3CModel: through the one-launch step kernel and through the per-layer path)"""
     import queue
+    if not fused_step:
+        if case[1] != "A3CModel":
+            pytest.skip("only A3CModel has a one-launch step kernel")
+        monkeypatch.setenv("A2C_NO_FUSED_STEP", "1")
     from a2c_amd.runner import Runner
     g = golden["g5_rollout"]
     name, kind, env_type, T, n_slots, ekw, A = case
@@ -149,10 +155,15 @@ def test_runner_rollout_golden(golden, case):
     assert float(r.bookmark.double().sum()) == float(g[f"{name}_bookmark_sum"])
 
 
-@pytest.mark.parametrize("kind,dev_actions", [("A3CModel", False), ("GRUModel", True)])
-def test_runner_batched_vs_oracle(kind, dev_actions):
+@pytest.mark.parametrize("kind,dev_actions,fused_step", [("A3CModel", False, True), ("A3CModel", True, True),
+                                                        ("A3CModel", False, False), ("GRUModel", True, False)])
+def test_runner_batched_vs_oracle(kind, dev_actions, fused_step, monkeypatch):
     """B envs in lock-step (one batched forward per step) == B independent batch-1 oracle runners"""
     from a2c_amd.runner import Runner
+    if not fused_step:
+        monkeypatch.setenv("A2C_NO_FUSED_STEP", "1")
+    else:
+        assert make_net(kind, (4, 84, 84), 4, 256)._step_supported()
     B, T, A, ss = 5, 7, 4, (4, 84, 84)
     ekws = [dict(env_id=j, rew_period=3 + j % 3, done_period=5 + 2 * j) for j in range(B)]
     hyps = base_hyps(env_type="FakePong-v0" if kind == "A3CModel" else "FakeBreakout", n_tsteps=T, n_rollouts=2 * B,
@@ -187,6 +198,75 @@ def test_runner_batched_vs_oracle(kind, dev_actions):
     close("deltas", D["deltas"], Do["deltas"], 1e-5, 1e-5)
     if net.is_recurrent:
         close("h_states", D["h_states"], Do["h_states"], 1e-5, 1e-5)
+
+
+def test_a3c_step_kernel_matches_layered_ops():
+    """a2c_a3c_step == frame_stack_push + conv/conv/composed heads + softmax_sample + record/bootstrap"""
+    from a2c_amd import ops
+    B, T, A, ss = 9, 5, 6, (4, 84, 84)
+    net = make_net("A3CModel", ss, A, 256)
+    net._ensure_device()
+    st = ops.stream()
+    net._refresh(st)
+    S = 4 * 84 * 84
+    prev = (torch.from_numpy(hashf(B * S, 31, 0, 1).reshape(B, S)) < 0.3).float().to(DEV)
+    frame = (torch.from_numpy(hashf(B * 7056, 32, 0, 1).reshape(B, 7056)) < 0.3).float().to(DEV)
+    reset = torch.zeros(B, device=DEV)
+    reset[2] = 1
+    u = torch.from_numpy(hashf(B, 33, 0, 1)).to(DEV)
+    rew = torch.tensor([0, 1, 0, -1, 0, 0, 2, 0, 0], dtype=torch.float32, device=DEV)
+    done = torch.tensor([0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=torch.float32, device=DEV)
+    N = B * T
+    for t_rec, boot in ((2, 0), (T - 1, 1)):
+        mk = lambda seed: torch.from_numpy(hashf(N, seed, -1, 1)).to(DEV)
+        bufs = {k: [mk(40 + i), mk(40 + i)] for i, k in enumerate(("rewards", "dones", "deltas"))}
+        for k in (0, 1):
+            bufs["dones"][k].copy_((bufs["dones"][k] > 0.5).float())
+        vp = [torch.from_numpy(hashf(B, 50, -1, 1)).to(DEV) for _ in range(2)]
+        hb_prev = torch.from_numpy(hashf(B * (A + 1), 51, -1, 1).reshape(B, A + 1)).to(DEV)
+        # layered reference on device
+        want_state = torch.empty(B, S, device=DEV)
+        ops.rollout_post(rew, done, hb_prev[:, A].data_ptr(), A + 1, vp[0], bufs["rewards"][0], bufs["dones"][0],
+                         bufs["deltas"][0], T, t_rec, 0, 0.99, True, frame, reset, prev.data_ptr(), S,
+                         want_state.data_ptr(), S, B, 4, 7056, st)
+        acts0 = torch.zeros(B, dtype=torch.int64, device=DEV)
+        out = net._fwd(want_state.data_ptr(), S, B, "roll", st, False, sampler=(u, acts0.data_ptr(), 1))
+        want_heads = torch.cat([out["logits"], out["vals"][:, None]], 1).clone()
+        if boot:
+            ops.rollout_bootstrap(out["vals"].data_ptr(), out["vals"].stride(0), vp[0], bufs["rewards"][0],
+                                  bufs["dones"][0], bufs["deltas"][0], B, T, 0, 0.99, st)
+        # one launch
+        hb, _, _ = net._heads("roll", B)
+        hb.copy_(hb_prev)
+        got_state = torch.empty(B, S, device=DEV)
+        acts1 = torch.zeros(B, dtype=torch.int64, device=DEV)
+        net._step(B, st, prev=prev.data_ptr(), prev_stride=S, frame_new=frame.data_ptr(), reset_mask=reset.data_ptr(),
+                  out=got_state.data_ptr(), out_stride=S, u=u.data_ptr(), actions=acts1.data_ptr(), act_stride=1,
+                  rew=rew.data_ptr(), done=done.data_ptr(), val_prev=vp[1].data_ptr(),
+                  rewards=bufs["rewards"][1].data_ptr(), dones=bufs["dones"][1].data_ptr(),
+                  deltas=bufs["deltas"][1].data_ptr(), T=T, t_rec=t_rec, slot0=0, gamma=0.99, pong=1, bootstrap=boot)
+        torch.cuda.synchronize()
+        assert torch.equal(got_state, want_state)
+        close("heads", hb, want_heads, 1e-5, 1e-5)             # fp32, different summation order
+        assert torch.equal(acts1, acts0)
+        assert torch.equal(vp[1], vp[0])
+        assert torch.equal(bufs["dones"][1], bufs["dones"][0])
+        if boot:          # bootstrap adds gamma * V computed by either path: tolerance of the heads
+            close("rewards", bufs["rewards"][1], bufs["rewards"][0], 1e-5, 1e-5)
+            close("deltas", bufs["deltas"][1], bufs["deltas"][0], 1e-5, 1e-5)
+        else:
+            assert torch.equal(bufs["rewards"][1], bufs["rewards"][0])
+            assert torch.equal(bufs["deltas"][1], bufs["deltas"][0])
+    # copy mode (step 0 of a slot): state = prev rows as they are, no bookkeeping
+    got_state = torch.empty(B, S, device=DEV)
+    net._step(B, st, prev=prev.data_ptr(), prev_stride=S, out=got_state.data_ptr(), out_stride=S)
+    out = net._fwd(prev.data_ptr(), S, B, "upd", st, False)
+    torch.cuda.synchronize()
+    assert torch.equal(got_state, prev)
+    close("vals", net._heads("roll", B)[2], out["vals"], 1e-5, 1e-5)
+    # unsupported shapes are refused, not silently mis-computed
+    assert not ops.a3c_step_supported(3, 84, 84, 6) and not ops.a3c_step_supported(4, 84, 84, 9)
+    assert ops.a3c_step_supported(4, 84, 84, 6)
 
 
 # ------------------------------------------------------------------ Updater

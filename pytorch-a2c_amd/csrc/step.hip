@@ -16,91 +16,142 @@
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int NT = 512;        // threads per workgroup
-constexpr int NST = 14;        // float4 staging registers per thread (covers 4 x 84 x 84)
+constexpr int NT = 512;        // threads per workgroup (8 waves, 2 per SIMD)
+constexpr int NCH = 3;         // the state arrives in 3 row chunks; conv1 runs on chunk k while k+1.. are in flight
+constexpr int SL0 = 6, SL1 = 5, SL2 = 5;   // float4 staging registers per thread and chunk
 constexpr int HN = 8;          // max heads (n_actions + 1)
+constexpr int NF1 = 64 * 64;   // conv1 fragments (64 steps x 64 lanes)
+constexpr int NF2 = 64 * 2 * 64;
+
+#ifdef A2C_STEP_TIMING
+__device__ unsigned long long a2c_step_ts[16];
+__device__ int a2c_step_skip;       // debug: bit 0 no row stores, 1 no conv1, 2 no conv2, 3 no heads, 4 no state loads
+#define TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) a2c_step_ts[i] = wall_clock64(); } while (0)
+#define SKIP(bit) (a2c_step_skip & (1 << (bit)))
+#else
+#define TS(i)
+#define SKIP(bit) false
+#endif
 
 struct StepP {
   a2c_a3c_step_args a;
   int OH1, OW1, OH2, OW2, PLANE1, PLANE2, F, F4;
+  int row_end[NCH];            // chunk k = input rows [row_end[k-1], row_end[k])
+  int tile_end[NCH];           // conv1 16-pixel tiles computable once chunk k is in LDS
 };
 
+// plane c of state_t comes from: the new frame (c == 3) / plane c+1 of the previous state (frame
+// stack, utils.py:26-43) or, without a new frame, plane c of `prev` itself.  Rows of a reset env
+// are read anyway (valid memory) and zeroed at commit time, so no load waits on the reset flag.
+// Every thread executes the SAME number of global loads/stores (out-of-range slots are clamped onto
+// the chunk's last element: a benign duplicate), so the s_waitcnt vmcnt(n) the compiler derives for
+// "chunk k has landed" is exact and never drains the younger loads and the row stores behind it.
+template <int N>
+__device__ __forceinline__ void issue_chunk(float4 (&pf)[N], const a2c_a3c_step_args& a, int b, int r0, int q4, int HW,
+                                            int W, int tid) {
+  const float* __restrict__ pb = a.prev + (long)b * a.prev_stride + (a.frame_new ? HW : 0);
+  const float* __restrict__ p3 = a.frame_new ? a.frame_new + (long)b * HW : pb + 3L * HW;
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int idx = min(tid + u * NT, 4 * q4 - 1);
+    const int c = (idx >= q4) + (idx >= 2 * q4) + (idx >= 3 * q4);
+    const int rem = idx - c * q4;
+    const long off = (c == 3) ? (long)(p3 - pb) : (long)c * HW;       // uniform select, no branch
+    pf[u] = SKIP(4) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(pb + off + r0 * W + (rem << 2));
+  }
+}
+
+template <bool OUT, int N>
+__device__ __forceinline__ void commit_chunk(const float4 (&pf)[N], const a2c_a3c_step_args& a, int b, int r0, int q4,
+                                             int HW, int W, int tid, bool zero_old, float* __restrict__ img, int PLANE1) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int idx = min(tid + u * NT, 4 * q4 - 1);
+    const int c = (idx >= q4) + (idx >= 2 * q4) + (idx >= 3 * q4);
+    const int rem = idx - c * q4;
+    float4 v = pf[u];
+    if (zero_old && c != 3) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(img + c * PLANE1 + r0 * W + (rem << 2)) = v;
+    if (OUT && !SKIP(0)) *reinterpret_cast<float4*>(a.out + (long)b * a.out_stride + (long)c * HW + r0 * W + (rem << 2)) = v;
+  }
+}
+
+template <bool OUT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void a3c_step_kernel(StepP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (SKIP(6)) return;
   const a2c_a3c_step_args& a = p.a;
-  float* __restrict__ img = lds;
+  float* __restrict__ fr1 = lds;                     // conv1 fragments
+  float* __restrict__ img = fr1 + NF1;               // state; later conv2 fragments | a2
   float* __restrict__ a1 = img + 4 * p.PLANE1;
-  float* __restrict__ a2 = a1 + 16 * p.PLANE2;
-  float* __restrict__ red = a2 + p.F4;
+  float* __restrict__ red = a1 + 16 * p.PLANE2;
+  float* __restrict__ a2 = img + NF2;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int HW = a.H * a.W, W = a.W;
-  const int per4 = HW >> 2, tot4 = 4 * per4;
   const int N = a.n_actions + 1;
+  const bool tail = tid == NT - 64;                  // lane 0 of the last wave (fewest conv tiles): bookkeeping + sampling
+  TS(0);
 
-  // ---- issue the state loads: plane c of state_t
-  const bool rst = a.reset_mask != nullptr && a.reset_mask[b] != 0.f;
-  float4 pf[NST];
-#pragma unroll
-  for (int u = 0; u < NST; ++u) {
-    const int idx = tid + u * NT;
-    pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx < tot4) {
-      const int c = idx / per4, rem = idx - c * per4;
-      const float* src;
-      if (a.frame_new) src = (c == 3) ? a.frame_new + (long)b * HW : (rst ? nullptr : a.prev + (long)b * a.prev_stride + (long)(c + 1) * HW);
-      else src = a.prev + (long)b * a.prev_stride + (long)c * HW;
-      if (src) pf[u] = *reinterpret_cast<const float4*>(src + (rem << 2));
-    }
-  }
-  // ---- weights that do not depend on the state
-  float af[64];
-#pragma unroll
-  for (int s = 0; s < 64; ++s) af[s] = a.wfrag1[s * 64 + lane];
-  const float4* __restrict__ wf2v = reinterpret_cast<const float4*>(a.wfrag2);
-  const float4 w2a = wf2v[tid], w2b = wf2v[tid + NT], w2c = wf2v[tid + 2 * NT], w2d = wf2v[tid + 3 * NT];
-  float b1[4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) b1[rr] = a.bias1[4 * g + rr];
+  // ---- every global load of the kernel is issued here, in the order it is consumed.
+  // Bookkeeping inputs first (oldest in the in-order vmcnt queue), from always-valid addresses.
+  const float4 b1v = *reinterpret_cast<const float4*>(a.bias1 + 4 * g);
+  const float b1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
+  const float ld_b2 = a.bias2[tid & 31];
+  const bool rec = a.rew != nullptr;
+  const long bk_e = rec ? (a.slot0 + b) * a.T + a.t_rec : 0;
+  const float* __restrict__ safe = a.heads + (long)b * a.ldh;
+  const float ld_r = *(rec ? a.rew + b : safe);
+  const float ld_d = *(rec ? a.done + b : safe);
+  const float ld_v = safe[a.n_actions];                      // value of the state the env step left
+  const float ld_pr = *((rec && a.t_rec > 0) ? a.rewards + bk_e - 1 : safe);
+  const float ld_pd = *((rec && a.t_rec > 0) ? a.dones + bk_e - 1 : safe);
+  const float ld_vp = *(rec ? a.val_prev + b : safe);
+  const float ld_rst = *((a.frame_new && a.reset_mask) ? a.reset_mask + b : safe);
+  const float4* __restrict__ wf1v = reinterpret_cast<const float4*>(a.wfrag1);
+  const float4 f1a = SKIP(5) ? make_float4(0.f, 0.f, 0.f, 0.f) : wf1v[tid], f1b = SKIP(5) ? make_float4(0.f, 0.f, 0.f, 0.f) : wf1v[tid + NT];
+  const int q0 = (p.row_end[0] * W) >> 2, q1 = ((p.row_end[1] - p.row_end[0]) * W) >> 2, q2 = ((p.row_end[2] - p.row_end[1]) * W) >> 2;
+  float4 pf0[SL0], pf1[SL1], pf2[SL2];
+  issue_chunk(pf0, a, b, 0, q0, HW, W, tid);
+  issue_chunk(pf1, a, b, p.row_end[0], q1, HW, W, tid);
+  const bool zero_old = a.frame_new != nullptr && a.reset_mask != nullptr && ld_rst != 0.f;
+  TS(1);
 
-  // ---- bookkeeping of the previous env step (one thread; its loads overlap the staging)
-  float bk_r = 0.f, bk_d = 0.f, bk_v = 0.f;
-  long bk_e = 0;
-  if (tid == 0 && a.rew) {
-    bk_e = (a.slot0 + b) * a.T + a.t_rec;
-    bk_r = a.rew[b];
-    bk_d = a.done[b] != 0.f ? 1.f : 0.f;
-    if (a.pong && bk_r != 0.f) bk_d = 1.f;
-    a.rewards[bk_e] = bk_r;
-    a.dones[bk_e] = bk_d;
-    bk_v = a.heads[(long)b * a.ldh + a.n_actions];          // value of the state the env step left
-    if (a.t_rec > 0) {
-      const float pr = a.rewards[bk_e - 1], pd = a.dones[bk_e - 1];
-      const float gv = a.gamma * bk_v;
-      a.deltas[bk_e - 1] = (pr + gv * (1.f - pd)) - a.val_prev[b];
-    }
-    a.val_prev[b] = bk_v;
-  }
-
-  // ---- state -> LDS (+ the rollout buffer row)
-#pragma unroll
-  for (int u = 0; u < NST; ++u) {
-    const int idx = tid + u * NT;
-    if (idx < tot4) {
-      const int c = idx / per4, rem = idx - c * per4;
-      *reinterpret_cast<float4*>(img + c * p.PLANE1 + (rem << 2)) = pf[u];
-      if (a.out) *reinterpret_cast<float4*>(a.out + (long)b * a.out_stride + (long)c * HW + (rem << 2)) = pf[u];
-    }
-  }
-  __syncthreads();
-
-  // ---- conv1: 16 x (OH1*OW1) = A[16 x 256] . im2col, one 16-pixel tile per wave pass
+  // ---- conv1 (16 x OH1*OW1, K = 256), chunk by chunk as the state lands in LDS.  The loads of
+  // chunk k+2 / the later weights are issued right before the matrix phase of chunk k, so the
+  // vector-memory pipe works while the MFMAs run.
   {
-    const int NP = p.OH1 * p.OW1, ntile = (NP + 15) >> 4;
-    for (int tile = w; tile < ntile; tile += NT / 64) {
+    float4* __restrict__ fv = reinterpret_cast<float4*>(fr1);
+    fv[tid] = f1a; fv[tid + NT] = f1b;
+    if (tid < 32) red[HN + tid] = ld_b2;             // conv2 bias for the K-half epilogue
+  }
+  const int NP1 = p.OH1 * p.OW1;
+  const float* __restrict__ la1 = fr1 + lane;
+  float4 w2a = make_float4(0.f, 0.f, 0.f, 0.f), w2b = w2a, w2c = w2a, w2d = w2a;
+  float4 wc[2][HN];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    if (k == 0) commit_chunk<OUT>(pf0, a, b, 0, q0, HW, W, tid, zero_old, img, p.PLANE1);
+    else if (k == 1) commit_chunk<OUT>(pf1, a, b, p.row_end[0], q1, HW, W, tid, zero_old, img, p.PLANE1);
+    else commit_chunk<OUT>(pf2, a, b, p.row_end[1], q2, HW, W, tid, zero_old, img, p.PLANE1);
+    __syncthreads();
+    TS(2 + k);
+    if (k == 0) issue_chunk(pf2, a, b, p.row_end[1], q2, HW, W, tid);
+    if (k == 1 && !SKIP(5)) {
+      const float4* __restrict__ wf2v = reinterpret_cast<const float4*>(a.wfrag2);
+      w2a = wf2v[tid]; w2b = wf2v[tid + NT]; w2c = wf2v[tid + 2 * NT]; w2d = wf2v[tid + 3 * NT];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int kk = (tid << 2) + q * (NT * 4);
+#pragma unroll
+        for (int n = 0; n < HN; ++n)
+          wc[q][n] = *reinterpret_cast<const float4*>(a.Wc + (long)min(n, N - 1) * p.F + min(kk, p.F - 4));
+      }
+    }
+    for (int tile = (k ? p.tile_end[k - 1] : 0) + w; tile < p.tile_end[k] && !SKIP(1); tile += NT / 64) {
       const int idx = tile * 16 + j;
-      const bool ok = idx < NP;
+      const bool ok = idx < NP1;
       const int i = ok ? idx : 0;
       const int r = i / p.OW1, c = i - r * p.OW1;
       const float* __restrict__ l = img + r * 4 * W + c * 4 + g * p.PLANE1;
@@ -109,14 +160,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int ky = 0; ky < 8; ++ky) {
         const float4 t0 = *reinterpret_cast<const float4*>(l + ky * W);
         const float4 t1 = *reinterpret_cast<const float4*>(l + ky * W + 4);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 0], t0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 1], t0.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 2], t0.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 3], t0.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 4], t1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 5], t1.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 6], t1.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 7], t1.w, acc, 0, 0, 0);
+        float av[8];
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) av[kx] = la1[(ky * 8 + kx) * 64];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], t0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], t0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], t0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], t0.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4], t1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[5], t1.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[6], t1.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[7], t1.w, acc, 0, 0, 0);
       }
       if (ok) {
 #pragma unroll
@@ -125,40 +179,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
   }
   __syncthreads();                                   // img consumed, a1 complete
+  TS(5);
   {
     float4* __restrict__ iv = reinterpret_cast<float4*>(img);
     iv[tid] = w2a; iv[tid + NT] = w2b; iv[tid + 2 * NT] = w2c; iv[tid + 3 * NT] = w2d;
   }
-  // head weights for this thread's K slices: in flight during conv2
-  float4 wc[2][HN];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int k = (tid << 2) + q * (NT * 4);
-#pragma unroll
-    for (int n = 0; n < HN; ++n) {
-      wc[q][n] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N && k < p.F) wc[q][n] = *reinterpret_cast<const float4*>(a.Wc + (long)n * p.F + k);
-    }
-  }
   __syncthreads();
 
-  // ---- conv2: 32 x (OH2*OW2), unit = (16-pixel tile, 16-channel half)
+  // ---- conv2: 32 x (OH2*OW2), K = 256 split in two halves so that the 4*ntile units spread
+  // evenly over the 8 waves; unit = (16-pixel tile, 16-channel half m, K half kh) writes its raw
+  // partial sums to LDS, the epilogue adds the halves in a fixed order (+ bias, ReLU).
+  const int NP2 = p.OH2 * p.OW2, ntile2 = (NP2 + 15) >> 4;
+  float* __restrict__ part = a2 + p.F4;              // [2][ntile2*2][256]
   {
-    const int NP = p.OH2 * p.OW2, ntile = (NP + 15) >> 4;
     const float* __restrict__ la = img + lane;
-    for (int unit = w; unit < ntile * 2; unit += NT / 64) {
-      const int tile = unit >> 1, m = unit & 1;
+    for (int unit = w; unit < ntile2 * 4 && !SKIP(2); unit += NT / 64) {
+      const int kh = unit & 1, m = (unit >> 1) & 1, tile = unit >> 2;
       const int idx = tile * 16 + j;
-      const bool ok = idx < NP;
-      const int i = ok ? idx : 0;
+      const int i = idx < NP2 ? idx : 0;
       const int r = i / p.OW2, c = i - r * p.OW2;
       const float* __restrict__ l = a1 + r * 2 * p.OW1 + c * 2 + g * p.PLANE2;
-      float b2[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) b2[rr] = a.bias2[m * 16 + 4 * g + rr];
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c4 = kh * 2 + cc;
         float bv[16], av[16];
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
@@ -172,15 +216,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
       }
-      if (ok) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) a2[(m * 16 + 4 * g + rr) * NP + i] = fmaxf(acc[rr] + b2[rr], 0.f);
-      }
+      *reinterpret_cast<float4*>(part + ((kh * ntile2 + tile) * 2 + m) * 256 + lane * 4) = (float4){acc[0], acc[1], acc[2], acc[3]};
     }
   }
   __syncthreads();
+  for (int o = tid; o < p.F; o += NT) {               // a2 flat (co, pixel) = relu((half0 + half1) + bias)
+    const int co = o / NP2, px = o - co * NP2;
+    const int slot = (((px >> 4) * 2 + (co >> 4)) * 256) + ((px & 15) + 16 * ((co & 15) >> 2)) * 4 + (co & 3);
+    a2[o] = fmaxf((part[slot] + part[ntile2 * 512 + slot]) + red[HN + co], 0.f);
+  }
+  __syncthreads();
+  TS(6);
 
-  // ---- heads: N dot products of length F; fixed-order reduction (deterministic)
+  // ---- heads: N dot products of length F.  Per-thread partials are transposed through LDS so
+  // that wave n reduces head n with ONE butterfly; summation order is fixed (deterministic).
+  float* __restrict__ hp = part + ntile2 * 1024;      // [HN][NT]
   {
     float acc[HN];
 #pragma unroll
@@ -188,7 +238,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int k = (tid << 2) + q * (NT * 4);
-      if (k < p.F) {
+      if (k < p.F && !SKIP(3)) {
         const float4 x = *reinterpret_cast<const float4*>(a2 + k);
 #pragma unroll
         for (int n = 0; n < HN; ++n)
@@ -197,20 +247,38 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 #pragma unroll
     for (int n = 0; n < HN; ++n)
-      if (n < N) {
-        const float v = wave_sum(acc[n]);
-        if (lane == 0) red[w * HN + n] = v;
-      }
+      if (n < N) hp[n * NT + tid] = acc[n];
   }
   __syncthreads();
-  if (tid == 0) {
+  if (w < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < NT / 64; ++q) v += hp[w * NT + q * 64 + lane];
+    v = wave_sum(v);
+    if (lane == 0) red[w] = v;
+  }
+  __syncthreads();
+  TS(7);
+  if (tail) {
+    // bookkeeping of the env step that produced this state (runner.py:212-232)
+    const float bk_r = ld_r, bk_v = ld_v;
+    float bk_d = ld_d != 0.f ? 1.f : 0.f;
+    if (a.pong && bk_r != 0.f) bk_d = 1.f;
+    if (rec) {
+      a.rewards[bk_e] = bk_r;
+      a.dones[bk_e] = bk_d;
+      if (a.t_rec > 0) {
+        const float gv = a.gamma * bk_v;
+        a.deltas[bk_e - 1] = (ld_pr + gv * (1.f - ld_pd)) - ld_vp;
+      }
+      a.val_prev[b] = bk_v;
+    }
     float h[HN], vboot = 0.f;
 #pragma unroll
     for (int n = 0; n < HN; ++n) {
       h[n] = 0.f;
       if (n < N) {
-        h[n] = (((red[0 * HN + n] + red[1 * HN + n]) + (red[2 * HN + n] + red[3 * HN + n])) +
-                ((red[4 * HN + n] + red[5 * HN + n]) + (red[6 * HN + n] + red[7 * HN + n]))) + a.bc[n];
+        h[n] = red[n] + a.bc[n];
         a.heads[(long)b * a.ldh + n] = h[n];
         if (n == a.n_actions) vboot = h[n];
       }
@@ -235,7 +303,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
       a.actions[(long)b * a.act_stride] = (int64_t)pick;
     }
-    if (a.bootstrap && a.rew) {  // runner.py:236-245 on the step recorded above (e = slot*T + T-1)
+    if (a.bootstrap && rec) {  // runner.py:236-245 on the step recorded above (e = slot*T + T-1)
       float r = bk_r;
       if (bk_d == 0.f) {
         r = r + a.gamma * vboot;
@@ -245,6 +313,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       a.deltas[bk_e] = r - bk_v;
     }
   }
+  TS(8);
 }
 
 static inline int plane_pad(int n, int mod64) {      // smallest p >= n with p % 64 == mod64
@@ -263,14 +332,33 @@ static bool step_shapes(int C, int H, int W, int n_actions, StepP& p) {
   p.F = 32 * p.OH2 * p.OW2;
   p.F4 = ((p.F + 3) / 4) * 4;
   if (p.F % 4 || p.F > 2 * NT * 4) return false;
-  if (C * H * W > NT * NST * 4) return false;
-  if (4 * p.PLANE1 < 8192) return false;             // conv2's fragments reuse the image region
+  const int ntile2 = (p.OH2 * p.OW2 + 15) / 16;
+  if (4 * p.PLANE1 < NF2 + p.F4 + ntile2 * 1024 + HN * NT) return false;   // conv2 fragments | a2 | K-half partials | head partials reuse the image region
+  // chunks: output rows split 7/20, 14/20, rest -> input rows 4*r+8 (the last chunk takes the remainder)
+  const int or0 = (p.OH1 * 7 + 19) / 20, or1 = (p.OH1 * 14 + 19) / 20;
+  p.row_end[0] = 4 * (or0 - 1) + 8; p.row_end[1] = 4 * (or1 - 1) + 8; p.row_end[2] = H;
+  if (!(0 < p.row_end[0] && p.row_end[0] < p.row_end[1] && p.row_end[1] < H)) return false;
+  const int ntile = (p.OH1 * p.OW1 + 15) / 16;
+  p.tile_end[0] = or0 * p.OW1 / 16; p.tile_end[1] = or1 * p.OW1 / 16; p.tile_end[2] = ntile;
+  const int cap[NCH] = {SL0, SL1, SL2};
+  for (int k = 0; k < NCH; ++k) {
+    const int rows = p.row_end[k] - (k ? p.row_end[k - 1] : 0);
+    if (rows * W > cap[k] * NT) return false;          // 4 planes * rows * W / 4 float4 over NT threads
+  }
   return true;
 }
-static size_t step_lds(const StepP& p) { return 4 * ((size_t)4 * p.PLANE1 + (size_t)16 * p.PLANE2 + p.F4 + 8 * HN + 16); }
+static size_t step_lds(const StepP& p) { return 4 * ((size_t)NF1 + (size_t)4 * p.PLANE1 + (size_t)16 * p.PLANE2 + 8 * HN + 16); }
 }  // namespace
 
 extern "C" {
+#ifdef A2C_STEP_TIMING
+int a2c_debug_step_skip(int mask) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(a2c_step_skip), &mask, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+int a2c_debug_step_ts(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(a2c_step_ts), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 int a2c_a3c_step_supported(int C, int H, int W, int n_actions) {
   StepP p;
   return step_shapes(C, H, W, n_actions, p) && step_lds(p) <= 160 * 1024 ? 1 : 0;
@@ -295,11 +383,13 @@ int a2c_a3c_step(const a2c_a3c_step_args* args, a2c_stream_t stream) {
   const size_t lds = step_lds(p);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)a3c_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)a3c_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)a3c_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return A2C_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(a3c_step_kernel, dim3(a.B), dim3(NT), lds, a2c_s(stream), p);
+  if (a.out) hipLaunchKernelGGL(a3c_step_kernel<true>, dim3(a.B), dim3(NT), lds, a2c_s(stream), p);
+  else hipLaunchKernelGGL(a3c_step_kernel<false>, dim3(a.B), dim3(NT), lds, a2c_s(stream), p);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Run one kernel family in isolation (for rocprofv3 --pmc / --kernel-trace passes).
-    python tools/run_kernel.py conv1_fwd|conv1_wgrad|conv2_fwd|conv2_bwd_data|conv2_wgrad|scan [B] [reps]"""
+    python tools/run_kernel.py conv1_fwd|conv1_wgrad|conv2_fwd|conv2_bwd_data|conv2_wgrad|scan|step [B] [reps]
+"step" = a2c_a3c_step walking the rows of a (B*16, 4, 84, 84) rollout buffer like Runner does (B envs)."""
 import os
 import sys
 
@@ -14,7 +15,33 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
-if what == "scan":
+if what == "step":
+    import a2c_amd
+    T, A = 16, 6
+    net = a2c_amd.models.A3CModel([4, 84, 84], A, h_size=256)
+    net._ensure_device()
+    st = ops.stream()
+    net._refresh(st)
+    S = 4 * 84 * 84
+    states = (torch.rand(B * T, S, device=dev, generator=g) < 0.25).float()
+    frames = (torch.rand(T, B, 7056, device=dev, generator=g) < 0.25).float()
+    u = torch.rand(B, device=dev, generator=g)
+    acts = torch.zeros(B, dtype=torch.int64, device=dev)
+    reset = torch.zeros(B, device=dev)
+    sp = lambda t: states.data_ptr() + 4 * t * S
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 0
+    for it in range(reps + 1):
+        if it == 1:
+            e0.record()
+        for t in range(1, T):
+            net._step(B, st, prev=sp(t - 1), prev_stride=T * S, frame_new=frames[t].data_ptr(), reset_mask=reset.data_ptr(),
+                      out=sp(t), out_stride=T * S, u=u.data_ptr(), actions=acts.data_ptr(), act_stride=1)
+            n += it > 0
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"step B={B}: {e0.elapsed_time(e1) / n * 1e3:.1f} us per launch (eager, host-launch bound if > kernel time)")
+elif what == "scan":
     n_seg, T = B, 128
     N = n_seg * T
     x, r = torch.randn(N, device=dev, generator=g), torch.randn(N, device=dev, generator=g)

@@ -460,6 +460,172 @@ __global__ __launch_bounds__(256) void igemm_run_kernel(IgemmP p, int nfrag) {
   }
 }
 
+// "Streaming" forward kernel for the 8x8 / stride 4 layer on 4 input planes (A3CModel conv1) at
+// large batch: ONE persistent 8-wave workgroup per CU, a whole input sample in LDS, the NEXT
+// sample in flight in registers (14 float4 per thread, issued right before the matrix phase, i.e. a
+// full sample of lead time), outputs staged in LDS and flushed with coalesced float4 stores.  Two
+// barriers per sample; between them the 25 16-pixel tiles run back to back (A fragments in
+// registers, B rows by ds_read_b128).  Every thread executes the same number of global loads and
+// stores (out-of-range slots are clamped onto a valid element), so the s_waitcnt vmcnt(n) before
+// the LDS commit is exact and the flush stores never stall the prefetch.
+constexpr int ST_NT = 512;
+constexpr int ST_NS = 14;            // float4 prefetch slots per thread: 4 planes x H*W <= 14*512*4 floats
+constexpr int ST_FL = 4;             // float4 flush slots per thread:   Cout x OH*OW <= 4*512*4 floats
+
+struct StreamP {
+  const float* in; long in_bs;
+  const float* wfrag; const float* bias;
+  float* out; long out_bs;
+  int B, H, W, OH, OW, Mch, relu, PLANE1, PLANEo;
+  int dbg;      // experiments (A2C_STREAM_DBG): 1 = no matrix phase, 2 = no input loads, 4 = no output stores
+};
+
+// one float4 slot of the sample: global -> register / register -> LDS.  Named scalars, not arrays:
+// the prefetch registers live across the persistent loop's back edge and must not end up in scratch.
+#define ST_LD(var, u, src) \
+  if (!(p.dbg & 2)) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * ST_NT, tot4 - 1) << 2));
+#define ST_ST(var, u)                                                                          \
+  {                                                                                            \
+    const int idx_ = min(tid + (u) * ST_NT, tot4 - 1);                                          \
+    const int c_ = (idx_ >= per4) + (idx_ >= 2 * per4) + (idx_ >= 3 * per4);                   \
+    *reinterpret_cast<float4*>(img + c_ * p.PLANE1 + ((idx_ - c_ * per4) << 2)) = var;          \
+  }
+#define ST_LDALL(src) ST_LD(v0, 0, src) ST_LD(v1, 1, src) ST_LD(v2, 2, src) ST_LD(v3, 3, src) ST_LD(v4, 4, src) ST_LD(v5, 5, src) ST_LD(v6, 6, src) \
+  ST_LD(v7, 7, src) ST_LD(v8, 8, src) ST_LD(v9, 9, src) ST_LD(v10, 10, src) ST_LD(v11, 11, src) ST_LD(v12, 12, src) ST_LD(v13, 13, src)
+#define ST_STALL ST_ST(v0, 0) ST_ST(v1, 1) ST_ST(v2, 2) ST_ST(v3, 3) ST_ST(v4, 4) ST_ST(v5, 5) ST_ST(v6, 6) ST_ST(v7, 7) ST_ST(v8, 8) \
+  ST_ST(v9, 9) ST_ST(v10, 10) ST_ST(v11, 11) ST_ST(v12, 12) ST_ST(v13, 13)
+
+__global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_stream_kernel(StreamP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ img = lds;
+  float* __restrict__ ob = img + 4 * p.PLANE1;        // [16][PLANEo] output staging (+ bias in the 4 spare words per row)
+  float* __restrict__ part = ob + 16 * p.PLANEo;      // [8][256] K-split partials of the leftover tile
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int HW = p.H * p.W, W = p.W, NP = p.OH * p.OW;
+  const int per4 = HW >> 2, tot4 = 4 * per4;
+  // A fragments: all 64 steps in registers (every tile uses them), plus kernel row `w` once more
+  // for the K-split leftover tile (register arrays cannot be indexed by the wave id)
+  float af[64], aw[8];
+#pragma unroll
+  for (int s = 0; s < 64; ++s) af[s] = p.wfrag[s * 64 + lane];
+#pragma unroll
+  for (int kx = 0; kx < 8; ++kx) aw[kx] = p.wfrag[(w * 8 + kx) * 64 + lane];
+  const float b10 = (p.bias && 4 * g + 0 < p.Mch) ? p.bias[4 * g + 0] : 0.f, b11 = (p.bias && 4 * g + 1 < p.Mch) ? p.bias[4 * g + 1] : 0.f;
+  const float b12 = (p.bias && 4 * g + 2 < p.Mch) ? p.bias[4 * g + 2] : 0.f, b13 = (p.bias && 4 * g + 3 < p.Mch) ? p.bias[4 * g + 3] : 0.f;
+  if (tid < 16) ob[tid * p.PLANEo + NP] = (p.bias && tid < p.Mch) ? p.bias[tid] : 0.f;
+  const int ntile = (NP + 15) >> 4;
+  const int nfull = ntile - (ntile & 7);             // tiles done whole by one wave; the (at most one) leftover is K-split
+  const int split0 = nfull * 16;                     // first pixel of the leftover tile (== NP rounded down if none)
+  const int out4 = split0 >> 2, otot = p.Mch * out4;  // float4 per channel flushed from the staging rows
+  float4 v0 = {}, v1 = {}, v2 = {}, v3 = {}, v4 = {}, v5 = {}, v6 = {}, v7 = {}, v8 = {}, v9 = {}, v10 = {}, v11 = {}, v12 = {}, v13 = {};
+  long n = blockIdx.x;
+  if (n >= p.B) return;
+  {
+    const float* __restrict__ src = p.in + n * p.in_bs;
+    ST_LDALL(src)
+  }
+  for (; n < p.B; n += gridDim.x) {
+    const long nn = (n + gridDim.x < p.B) ? n + gridDim.x : n;        // past the end: re-read this sample (discarded)
+    const float* __restrict__ nsrc = p.in + nn * p.in_bs;
+    float* __restrict__ dst = p.out + n * p.out_bs;
+    ST_STALL                                         // sample n: registers -> LDS
+    __syncthreads();
+    // matrix phase: 3 whole tiles per wave + one kernel row of the leftover tile, unrolled so that the
+    // loads of sample n + grid are issued in instalments between the tiles.  The instalments are
+    // straight-line code on purpose: any branch around a global load (even a uniform one) makes the
+    // compiler fall back to conservative vmcnt waits (measured 1.36 ms vs 1.23 ms); one burst before
+    // the first tile costs 1.45 ms, one load per kernel row inside the tiles 1.50 ms.
+#define ST_TILE(T)                                                                                          \
+    if (!(p.dbg & 1) && (T) * (ST_NT / 64) + w < nfull) {                                                   \
+      const int idx = ((T) * (ST_NT / 64) + w) * 16 + j;                                                    \
+      const bool ok = idx < NP;                                                                             \
+      const int i = ok ? idx : 0;                                                                           \
+      const int r = i / p.OW, c = i - r * p.OW;                                                             \
+      const float* __restrict__ l = img + r * 4 * W + c * 4 + g * p.PLANE1;                                 \
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};                                                              \
+      _Pragma("unroll") for (int ky = 0; ky < 8; ++ky) {                                                    \
+        const float4 t0v = *reinterpret_cast<const float4*>(l + ky * W);                                    \
+        const float4 t1v = *reinterpret_cast<const float4*>(l + ky * W + 4);                                \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 0], t0v.x, acc, 0, 0, 0);                    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 1], t0v.y, acc, 0, 0, 0);                    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 2], t0v.z, acc, 0, 0, 0);                    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 3], t0v.w, acc, 0, 0, 0);                    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 4], t1v.x, acc, 0, 0, 0);                    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 5], t1v.y, acc, 0, 0, 0);                    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 6], t1v.z, acc, 0, 0, 0);                    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky * 8 + 7], t1v.w, acc, 0, 0, 0);                    \
+      }                                                                                                     \
+      if (ok) {                                                                                             \
+        float o0 = acc[0] + b10, o1 = acc[1] + b11, o2 = acc[2] + b12, o3 = acc[3] + b13;                   \
+        if (p.relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); } \
+        ob[(4 * g + 0) * p.PLANEo + i] = o0; ob[(4 * g + 1) * p.PLANEo + i] = o1;                           \
+        ob[(4 * g + 2) * p.PLANEo + i] = o2; ob[(4 * g + 3) * p.PLANEo + i] = o3;                           \
+      }                                                                                                     \
+    }
+    ST_LD(v0, 0, nsrc) ST_LD(v1, 1, nsrc) ST_LD(v2, 2, nsrc) ST_LD(v3, 3, nsrc)
+    ST_TILE(0)
+    ST_LD(v4, 4, nsrc) ST_LD(v5, 5, nsrc) ST_LD(v6, 6, nsrc) ST_LD(v7, 7, nsrc)
+    ST_TILE(1)
+    ST_LD(v8, 8, nsrc) ST_LD(v9, 9, nsrc) ST_LD(v10, 10, nsrc) ST_LD(v11, 11, nsrc)
+    ST_TILE(2)
+    ST_LD(v12, 12, nsrc) ST_LD(v13, 13, nsrc)
+    if (!(p.dbg & 1) && nfull < ntile) {             // leftover tile: this wave's kernel row ky = w (8 of its 64 steps)
+      const int idx = nfull * 16 + j;
+      const int i = idx < NP ? idx : 0;
+      const int r = i / p.OW, c = i - r * p.OW;
+      const float* __restrict__ l = img + r * 4 * W + c * 4 + g * p.PLANE1 + w * W;
+      const float4 t0v = *reinterpret_cast<const float4*>(l);
+      const float4 t1v = *reinterpret_cast<const float4*>(l + 4);
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[0], t0v.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[1], t0v.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[2], t0v.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[3], t0v.w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[4], t1v.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[5], t1v.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[6], t1v.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[7], t1v.w, acc, 0, 0, 0);
+      *reinterpret_cast<float4*>(part + w * 256 + lane * 4) = (float4){acc[0], acc[1], acc[2], acc[3]};
+    }
+    __syncthreads();
+    if (nfull < ntile) {                             // leftover tile: one output per thread, kernel rows summed in a
+      const int k = tid & 255, co = min(k >> 4, p.Mch - 1), jx = k & 15;      // fixed order, + bias, ReLU (threads >= 256 duplicate)
+      const int slot = (jx + 16 * (co >> 2)) * 4 + (co & 3);
+      float q[ST_NT / 64];
+#pragma unroll
+      for (int x = 0; x < ST_NT / 64; ++x) q[x] = part[x * 256 + slot];
+      float sum = q[0];
+#pragma unroll
+      for (int x = 1; x < ST_NT / 64; ++x) sum += q[x];
+      sum += ob[co * p.PLANEo + NP];
+      if (p.relu) sum = fmaxf(sum, 0.f);
+      if (!(p.dbg & 4)) dst[(long)co * NP + split0 + jx] = sum;
+    }
+#pragma unroll
+    for (int u = 0; u < ST_FL; ++u) {                // outputs of the whole tiles of sample n: LDS -> HBM
+      const int idx = min(tid + u * ST_NT, otot - 1);
+      const int co = idx / out4, e = (idx - co * out4) << 2;
+      const float4 t = *reinterpret_cast<const float4*>(ob + co * p.PLANEo + e);
+      if (!(p.dbg & 4)) *reinterpret_cast<float4*>(dst + (long)co * NP + e) = t;
+    }
+  }
+}
+
+static size_t stream_lds(const StreamP& p) { return 4 * (size_t)(4 * p.PLANE1 + 16 * p.PLANEo + 8 * 256); }
+static bool plan_stream(const a2c_conv_desc* d, StreamP& p) {
+  if (!(d->ks == 8 && d->stride == 4 && d->pad == 0 && d->Cin == 4 && d->Cout <= 16 && d->W % 4 == 0)) return false;
+  const int NP = d->OH * d->OW;
+  if (NP % 4) return false;
+  p.H = d->H; p.W = d->W; p.OH = d->OH; p.OW = d->OW; p.Mch = d->Cout;
+  p.PLANE1 = ((d->H * d->W + 63) / 64) * 64;
+  p.PLANEo = ((NP + 7) / 8) * 8 + 4;
+  if (d->H * d->W > ST_NS * ST_NT || d->Cout * NP > ST_FL * ST_NT * 4) return false;
+  const int ntile = (NP + 15) / 16;
+  if (ntile / 8 > 3 || ntile % 8 > 1 || NP % 16) return false;   // 3 whole tiles per wave + at most one K-split leftover
+  return stream_lds(p) <= 160 * 1024;
+}
+
 // Same pipeline for the 3x3 / pad 1 layers (ConvModel, GRUModel) whose rows are 16 B aligned
 // (W % 4 == 0): the image keeps a one-column zero halo (LDS column = x + 1, zeroed once), source
 // rows above/below the picture are prefetched as zeros, the three taps of a kernel row are three
@@ -1493,6 +1659,27 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   // pipelined variant: unpadded layer, 16 B aligned rows, fragments <= 32 KB, image <= 32 KB
   const int nfrag = p.nchunks * CH * MT * 64;
   p.nsteps = nsteps; p.nb = d->ks; p.c4n = c4n; p.off0 = 0; p.step_b = 1;
+  {  // streaming kernel: A3C conv1 class at large batch
+    StreamP sp;
+    static const int n_cu = []() { int dev = 0, n = 0; (void)hipGetDevice(&dev);
+                                   (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    if (B >= 8 * n_cu && !getenv("A2C_NO_STREAM") && !getenv("A2C_NO_PF") && in_bstride % 4 == 0 && out_bstride % 4 == 0 &&
+        ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && plan_stream(d, sp)) {
+      sp.in = in; sp.in_bs = in_bstride; sp.wfrag = wprep_fwd; sp.bias = bias; sp.out = out; sp.out_bs = out_bstride;
+      sp.B = B; sp.relu = relu;
+      { const char* e = getenv("A2C_STREAM_DBG"); sp.dbg = e ? atoi(e) : 0; }
+      const size_t lds = stream_lds(sp);
+      static bool attr = false;
+      if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          return A2C_ERR_LAUNCH;
+        attr = true;
+      }
+      hipLaunchKernelGGL(conv_stream_kernel, dim3(n_cu), dim3(ST_NT), lds, a2c_s(stream), sp);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
   const bool run = run_layout(d);
   if (run && in_bstride % 4 == 0 && ((uintptr_t)in % 16 == 0) && nfrag * 4 <= 32 * 1024 && !getenv("A2C_NO_PF")) {
     // largest band whose image fits the prefetch registers; prefer bands whose pixel count fills

@@ -414,6 +414,39 @@ def test_conv2d_many_samples_persistent_grid():
     close("bwd_bias", db, dout.double().sum((0, 2, 3)), 1e-5 * float(dout.double().sum((0, 2, 3)).abs().max()), 1e-5)
 
 
+def test_conv2d_streaming_forward_matches_tiled_kernel(monkeypatch):
+    """A3C conv1 at update-sized batch goes through the persistent streaming kernel; the tiled
+    kernel walks K in the same (c4, ky, kx) order, so the two must agree bit for bit -- except the
+    25th (leftover) 16-pixel tile, whose 8 kernel rows are summed by 8 waves and combined in a fixed
+    order (fp32 re-association: 1e-6).  Batch not a multiple of the grid, strided input rows, with
+    and without bias / ReLU."""
+    ops = _ops()
+    spec = (4, 84, 84, 16, 8, 4, 0)
+    B = 2048 + 77
+    d = ops.conv_desc(*spec)
+    gen = torch.Generator().manual_seed(11)
+    xbuf = torch.zeros(B, 4 * 84 * 84 + 12, device=DEV)
+    xbuf[:, :4 * 84 * 84] = (torch.rand(B, 4 * 84 * 84, generator=gen) < 0.3).float().to(DEV) * \
+        torch.rand(B, 4 * 84 * 84, generator=gen).to(DEV)
+    w = ((torch.rand(16, 4, 8, 8, generator=gen) - 0.5) * 0.2).to(DEV)
+    bias = ((torch.rand(16, generator=gen) - 0.5) * 0.2).to(DEV)
+    wf = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
+    ops.conv_prep(d, 0, w, wf)
+    for b_, relu in ((bias, True), (None, False)):
+        got = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+        ops.conv_fwd(d, xbuf.data_ptr(), xbuf.stride(0), wf, b_, relu, got, B)
+        monkeypatch.setenv("A2C_NO_STREAM", "1")
+        want = torch.empty(B, 16, 20, 20, device=DEV)
+        ops.conv_fwd(d, xbuf.data_ptr(), xbuf.stride(0), wf, b_, relu, want, B)
+        monkeypatch.delenv("A2C_NO_STREAM")
+        torch.cuda.synchronize()
+        gf, wf_ = got.view(B, 16, 400), want.view(B, 16, 400)
+        assert torch.equal(gf[:, :, :384], wf_[:, :, :384])
+        close("leftover tile", gf[:, :, 384:], wf_[:, :, 384:], 1e-6, 1e-6)
+    ref = F.conv2d(xbuf[:64, :4 * 84 * 84].view(64, 4, 84, 84).cpu().double(), w.cpu().double(), None, stride=4)
+    close("fwd vs fp64", got[:64], ref, 1e-5, 1e-5)
+
+
 # ------------------------------------------------------------------ GRU gates / LayerNorm
 def test_gru_kernels_vs_autograd():
     ops = _ops()

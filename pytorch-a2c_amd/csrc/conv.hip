@@ -1511,6 +1511,159 @@ __global__ __launch_bounds__(256) void wgrad_run_kernel(WrunP p) {
   }
 }
 
+// "Streaming" backward-weight kernel for the 8x8 / stride 4 layer on 4 input planes (A3CModel
+// conv1), the twin of conv_stream_kernel: one persistent 8-wave workgroup per CU, the input sample
+// and its dOut in LDS, the NEXT sample's 18 float4 per thread in flight in registers (issued in
+// three straight-line instalments between the row segments of the matrix phase).  Wave (q, h):
+// k-group q = 64 of the 256 weight columns (4 accumulators), output rows of parity h; the two
+// parities are added in a fixed order at the end, per-workgroup slabs go to wgrad_reduce_kernel.
+// dW[co][k] += sum_px dOut[co][px] * x[k][px]:  A = dOut (16 co x 4 px), B = image (4 px x 16 k).
+struct WstreamP {
+  const float* in; long in_bs;
+  const float* dout;              // (B, Cout, OH, OW) contiguous
+  float* slab;                    // [grid][Cout*K + Cout]
+  int B, H, W, OH, OW, Cout, K, PLANE1, PLANEo;
+};
+#define WS_LDI(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * ST_NT, tot4 - 1) << 2));
+#define WS_LDD(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * ST_NT, dtot4 - 1) << 2));
+#define WS_STI(var, u)                                                                         \
+  {                                                                                            \
+    const int idx_ = min(tid + (u) * ST_NT, tot4 - 1);                                          \
+    const int c_ = (idx_ >= per4) + (idx_ >= 2 * per4) + (idx_ >= 3 * per4);                   \
+    *reinterpret_cast<float4*>(img + c_ * p.PLANE1 + ((idx_ - c_ * per4) << 2)) = var;          \
+  }
+#define WS_STD(var, u)                                                                         \
+  {                                                                                            \
+    const int idx_ = min(tid + (u) * ST_NT, dtot4 - 1);                                         \
+    const int co_ = idx_ / dper4;                                                              \
+    *reinterpret_cast<float4*>(ldo + co_ * p.PLANEo + ((idx_ - co_ * dper4) << 2)) = var;       \
+  }
+
+__global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_stream_kernel(WstreamP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ img = lds;
+  float* __restrict__ ldo = lds + 4 * p.PLANE1;       // dOut of the sample: [16][PLANEo], rows >= Cout stay 0
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kk = lane >> 4, j = lane & 15;
+  const int q = w & 3, h = w >> 2;
+  const int HW = p.H * p.W, W = p.W, NP = p.OH * p.OW;
+  const int per4 = HW >> 2, tot4 = 4 * per4;
+  const int dper4 = NP >> 2, dtot4 = p.Cout * dper4;
+  for (int i = tid; i < 16 * p.PLANEo; i += ST_NT) ldo[i] = 0.f;
+  // this lane's weight column group: (ci, ky, kxh), the 4 accumulators are kxl = 0..3
+  const int cidx = q * 16 + j;
+  const int kxh = cidx & 1, cy = cidx >> 1;
+  const int ci = cy >> 3, ky = cy & 7;
+  const int boff = ci * p.PLANE1 + ky * W + kxh * 4 + kk * 4;
+  const int knat = (ci * 8 + ky) * 8 + kxh * 4;
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  const int bco = tid & 15, bpart = tid >> 4;        // bias gradient: 32 partial sums per channel
+  float dbacc = 0.f;
+  float4 v0 = {}, v1 = {}, v2 = {}, v3 = {}, v4 = {}, v5 = {}, v6 = {}, v7 = {}, v8 = {}, v9 = {}, v10 = {}, v11 = {}, v12 = {}, v13 = {};
+  float4 d0 = {}, d1 = {}, d2 = {}, d3 = {};
+  long n = blockIdx.x;
+  if (n < p.B) {
+    const float* __restrict__ src = p.in + n * p.in_bs;
+    const float* __restrict__ dsrc = p.dout + n * (long)p.Cout * NP;
+    WS_LDD(d0, 0, dsrc) WS_LDD(d1, 1, dsrc) WS_LDD(d2, 2, dsrc) WS_LDD(d3, 3, dsrc)
+    WS_LDI(v0, 0, src) WS_LDI(v1, 1, src) WS_LDI(v2, 2, src) WS_LDI(v3, 3, src) WS_LDI(v4, 4, src) WS_LDI(v5, 5, src) WS_LDI(v6, 6, src)
+    WS_LDI(v7, 7, src) WS_LDI(v8, 8, src) WS_LDI(v9, 9, src) WS_LDI(v10, 10, src) WS_LDI(v11, 11, src) WS_LDI(v12, 12, src) WS_LDI(v13, 13, src)
+  }
+  const int nrow = (p.OH - h + 1) >> 1;              // output rows h, h+2, ...
+  const int s1 = nrow / 3, s2 = (2 * nrow) / 3;
+  const int c4n = p.OW >> 2;
+  for (; n < p.B; n += gridDim.x) {
+    const long nn = (n + gridDim.x < p.B) ? n + gridDim.x : n;        // past the end: re-read this sample (discarded)
+    const float* __restrict__ nsrc = p.in + nn * p.in_bs;
+    const float* __restrict__ ndsrc = p.dout + nn * (long)p.Cout * NP;
+    __syncthreads();                                 // everyone is done with the previous sample
+    WS_STD(d0, 0) WS_STD(d1, 1) WS_STD(d2, 2) WS_STD(d3, 3)
+    WS_STI(v0, 0) WS_STI(v1, 1) WS_STI(v2, 2) WS_STI(v3, 3) WS_STI(v4, 4) WS_STI(v5, 5) WS_STI(v6, 6)
+    WS_STI(v7, 7) WS_STI(v8, 8) WS_STI(v9, 9) WS_STI(v10, 10) WS_STI(v11, 11) WS_STI(v12, 12) WS_STI(v13, 13)
+    __syncthreads();
+    if (bco < p.Cout) {                              // bias gradient partials from the dOut tile
+      const float* __restrict__ pl = ldo + bco * p.PLANEo;
+      float sb = 0.f;
+      for (int i = bpart; i < NP; i += ST_NT / 16) sb += pl[i];
+      dbacc += sb;
+    }
+#define WS_ROWS(R0, R1)                                                                                     \
+    for (int rr = (R0); rr < (R1); ++rr) {                                                                  \
+      const int r = 2 * rr + h;                                                                             \
+      const float* __restrict__ arow = ldo + j * p.PLANEo + r * p.OW + kk;                                  \
+      const float* __restrict__ brow = img + r * 4 * W + boff;                                              \
+      for (int c0 = 0; c0 < c4n; c0 += 5) {                                                                 \
+        float av[5];                                                                                        \
+        float4 bv[5];                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < 5; ++u) {                                                     \
+          const int c4 = min(c0 + u, c4n - 1);                                                              \
+          av[u] = (c0 + u < c4n) ? arow[4 * c4] : 0.f;                                                      \
+          bv[u] = *reinterpret_cast<const float4*>(brow + 16 * c4);                                         \
+        }                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < 5; ++u) {                                                     \
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u].x, acc0, 0, 0, 0);                       \
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u].y, acc1, 0, 0, 0);                       \
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u].z, acc2, 0, 0, 0);                       \
+          acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u].w, acc3, 0, 0, 0);                       \
+        }                                                                                                   \
+      }                                                                                                     \
+    }
+    WS_LDD(d0, 0, ndsrc) WS_LDD(d1, 1, ndsrc) WS_LDD(d2, 2, ndsrc) WS_LDD(d3, 3, ndsrc) WS_LDI(v0, 0, nsrc) WS_LDI(v1, 1, nsrc)
+    WS_ROWS(0, s1)
+    WS_LDI(v2, 2, nsrc) WS_LDI(v3, 3, nsrc) WS_LDI(v4, 4, nsrc) WS_LDI(v5, 5, nsrc) WS_LDI(v6, 6, nsrc) WS_LDI(v7, 7, nsrc)
+    WS_ROWS(s1, s2)
+    WS_LDI(v8, 8, nsrc) WS_LDI(v9, 9, nsrc) WS_LDI(v10, 10, nsrc) WS_LDI(v11, 11, nsrc) WS_LDI(v12, 12, nsrc) WS_LDI(v13, 13, nsrc)
+    WS_ROWS(s2, nrow)
+  }
+  // epilogue: add the two row parities in a fixed order, write this workgroup's slab
+  __syncthreads();
+  float* __restrict__ scr = lds;                      // [4 k-groups][4 acc][256]
+  if (h == 1) {
+    *reinterpret_cast<float4*>(scr + ((q * 4 + 0) * 64 + lane) * 4) = (float4){acc0[0], acc0[1], acc0[2], acc0[3]};
+    *reinterpret_cast<float4*>(scr + ((q * 4 + 1) * 64 + lane) * 4) = (float4){acc1[0], acc1[1], acc1[2], acc1[3]};
+    *reinterpret_cast<float4*>(scr + ((q * 4 + 2) * 64 + lane) * 4) = (float4){acc2[0], acc2[1], acc2[2], acc2[3]};
+    *reinterpret_cast<float4*>(scr + ((q * 4 + 3) * 64 + lane) * 4) = (float4){acc3[0], acc3[1], acc3[2], acc3[3]};
+  }
+  float* __restrict__ red = lds + 4096;               // [32][16] bias partials
+  red[bpart * 16 + bco] = dbacc;
+  __syncthreads();
+  float* __restrict__ sl = p.slab + (long)blockIdx.x * ((long)p.Cout * p.K + p.Cout);
+  if (h == 0) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const float4 o = *reinterpret_cast<const float4*>(scr + ((q * 4 + x) * 64 + lane) * 4);
+      const f32x4 a = x == 0 ? acc0 : x == 1 ? acc1 : x == 2 ? acc2 : acc3;
+      const float t[4] = {a[0] + o.x, a[1] + o.y, a[2] + o.z, a[3] + o.w};
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = 4 * kk + rr;
+        if (co < p.Cout) sl[(long)co * p.K + knat + x] = t[rr];
+      }
+    }
+  }
+  if (tid < p.Cout) {
+    float sb = 0.f;
+    for (int x = 0; x < ST_NT / 16; ++x) sb += red[x * 16 + tid];
+    sl[(long)p.Cout * p.K + tid] = sb;
+  }
+}
+
+static bool plan_wstream(const a2c_conv_desc* d, WstreamP& p) {
+  if (!(d->ks == 8 && d->stride == 4 && d->pad == 0 && d->Cin == 4 && d->Cout <= 16 && d->W % 4 == 0 && d->OW % 4 == 0)) return false;
+  const int NP = d->OH * d->OW;
+  p.H = d->H; p.W = d->W; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.K = d->Cin * 64;
+  p.PLANE1 = ((d->H * d->W + 63) / 64) * 64;
+  p.PLANEo = ((NP + 7) / 8) * 8 + 4;
+  if (d->H * d->W > ST_NS * ST_NT || d->Cout * NP > 4 * ST_NT * 4 || d->OH < 6) return false;
+  if (4 * p.PLANE1 < 4096 + 512) return false;         // epilogue scratch reuses the image region
+  return 4 * (size_t)(4 * p.PLANE1 + 16 * p.PLANEo) <= 160 * 1024;
+}
+static int stream_grid() {
+  static const int n_cu = []() { int dev = 0, n = 0; (void)hipGetDevice(&dev);
+                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  return n_cu;
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, long per,
                                                            long nW, float* __restrict__ dW, float* __restrict__ db) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += gridDim.x * 256L) {
@@ -1661,8 +1814,7 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   p.nsteps = nsteps; p.nb = d->ks; p.c4n = c4n; p.off0 = 0; p.step_b = 1;
   {  // streaming kernel: A3C conv1 class at large batch
     StreamP sp;
-    static const int n_cu = []() { int dev = 0, n = 0; (void)hipGetDevice(&dev);
-                                   (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int n_cu = stream_grid();
     if (B >= 8 * n_cu && !getenv("A2C_NO_STREAM") && !getenv("A2C_NO_PF") && in_bstride % 4 == 0 && out_bstride % 4 == 0 &&
         ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && plan_stream(d, sp)) {
       sp.in = in; sp.in_bs = in_bstride; sp.wfrag = wprep_fwd; sp.bias = bias; sp.out = out; sp.out_bs = out_bstride;
@@ -1897,7 +2049,9 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
 size_t a2c_conv2d_bwd_weight_ws_bytes(const a2c_conv_desc* d, int B) {
   WgradPlan pl, pg;
   if (!desc_ok(d) || B < 0 || !plan_wgrad(d, B, pl) || !plan_wgrad(d, B, pg, false)) return 0;
-  const int grid = pl.grid > pg.grid ? pl.grid : pg.grid;     // either kernel may be picked at launch
+  int grid = pl.grid > pg.grid ? pl.grid : pg.grid;           // any of the kernels may be picked at launch
+  WstreamP wp;
+  if (plan_wstream(d, wp) && stream_grid() > grid) grid = stream_grid();
   return (size_t)grid * ((size_t)d->Cout * d->Cin * d->ks * d->ks + d->Cout) * sizeof(float);
 }
 
@@ -1909,6 +2063,28 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
   if (!plan_wgrad(d, B, pl, aligned)) return A2C_ERR_ARG;
   if (!ws || ws_bytes < a2c_conv2d_bwd_weight_ws_bytes(d, B)) return A2C_ERR_WORKSPACE;
   hipStream_t st = a2c_s(stream);
+  {  // streaming kernel: A3C conv1 class at large batch
+    WstreamP wp;
+    const int grid = stream_grid();
+    if (aligned && B >= 8 * grid && ((uintptr_t)dout % 16 == 0) && !getenv("A2C_NO_STREAM") && !getenv("A2C_NO_PF") &&
+        plan_wstream(d, wp)) {
+      wp.in = in; wp.in_bs = in_bstride; wp.dout = dout; wp.slab = (float*)ws; wp.B = B;
+      const size_t lds = 4 * (size_t)(4 * wp.PLANE1 + 16 * wp.PLANEo);
+      static bool attr = false;
+      if (!attr) {
+        if (hipFuncSetAttribute((const void*)wgrad_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          return A2C_ERR_LAUNCH;
+        attr = true;
+      }
+      hipLaunchKernelGGL(wgrad_stream_kernel, dim3(grid), dim3(ST_NT), lds, st, wp);
+      A2C_CHECK_LAUNCH();
+      const long nWs = (long)wp.Cout * wp.K, pers = nWs + wp.Cout;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(pers, 256)), dim3(256), 0, st, (const float*)ws, grid, pers, nWs,
+                         dW, db);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
   if (pl.run) {
     WrunP q;
     fill_stage(q.st, pl.t, in, in_bstride);

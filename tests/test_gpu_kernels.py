@@ -447,6 +447,39 @@ def test_conv2d_streaming_forward_matches_tiled_kernel(monkeypatch):
     close("fwd vs fp64", got[:64], ref, 1e-5, 1e-5)
 
 
+def test_conv2d_streaming_backward_weight(monkeypatch):
+    """A3C conv1 weight gradient at update-sized batch (persistent streaming kernel) against an fp64
+    reference and against the tiled kernel (same sums, different association over samples)."""
+    ops = _ops()
+    spec = (4, 84, 84, 16, 8, 4, 0)
+    B = 2048 + 77
+    d = ops.conv_desc(*spec)
+    gen = torch.Generator().manual_seed(12)
+    x = (torch.rand(B, 4, 84, 84, generator=gen) < 0.3).float() * torch.rand(B, 4, 84, 84, generator=gen)
+    dout = (torch.rand(B, 16, 20, 20, generator=gen) - 0.5) * (torch.rand(B, 16, 20, 20, generator=gen) < 0.5).float()
+    xbuf = torch.zeros(B, 4 * 84 * 84 + 12, device=DEV)
+    xbuf[:, :4 * 84 * 84] = x.view(B, -1).to(DEV)
+    dd = dout.to(DEV)
+    # fp64 reference of dW = sum_b corr(x_b, dout_b) on a few hundred samples is too slow on CPU for all B:
+    # use the unfold identity on the device in fp64 instead
+    cols = F.unfold(x.to(DEV).double(), kernel_size=8, stride=4)                  # (B, 256, 400)
+    want = torch.einsum("bcp,bkp->ck", dd.double().view(B, 16, 400), cols).view(16, 4, 8, 8)
+    want_b = dd.double().sum((0, 2, 3))
+    ws = torch.empty(max(1, ops.conv_bwd_weight_ws_bytes(d, B) // 4), device=DEV)
+    dW, db = torch.full((16, 4, 8, 8), float("nan"), device=DEV), torch.full((16,), float("nan"), device=DEV)
+    ops.conv_bwd_weight(d, xbuf.data_ptr(), xbuf.stride(0), dd, dW, db, B, ws)
+    monkeypatch.setenv("A2C_NO_STREAM", "1")
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    ops.conv_bwd_weight(d, xbuf.data_ptr(), xbuf.stride(0), dd, dW2, db2, B, ws)
+    monkeypatch.delenv("A2C_NO_STREAM")
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    close("dW vs fp64", dW, want, 1e-5 * scale, 1e-5)
+    close("db vs fp64", db, want_b, 1e-5 * float(want_b.abs().max()), 1e-5)
+    close("dW vs tiled", dW, dW2, 1e-5 * scale, 1e-5)
+    close("db vs tiled", db, db2, 1e-5 * float(want_b.abs().max()), 1e-5)
+
+
 # ------------------------------------------------------------------ GRU gates / LayerNorm
 def test_gru_kernels_vs_autograd():
     ops = _ops()

@@ -41,9 +41,9 @@ constexpr int LDS_HARD_MAX = 160 * 1024;
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // persistent grids: exactly the number of workgroups the chip keeps resident (a static tile
 // stride over a grid that is not a multiple of it leaves the last round mostly idle)
-static int resident_grid(const void* kernel, size_t lds_bytes, long total_tiles) {
+static int resident_grid(const void* kernel, size_t lds_bytes, long total_tiles, int block = 256) {
   int per_cu = 0, dev = 0, cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
   hipDeviceProp_t prop;
   static int cached_cus = 0;
   if (!cached_cus) {
@@ -1194,6 +1194,108 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(BwdFusedP p) {
   }
 }
 
+// "Streaming" backward-data kernel for the 4x4 / stride 2 layer with Cout = 32, Cin <= 16 (A3CModel
+// conv2) at large batch.  Same skeleton as conv_stream_kernel: persistent 8-wave workgroups, the
+// sample's dOut (haloed) in LDS, the next sample's dOut and this sample's ReLU mask in flight in
+// registers, dX assembled in LDS and flushed with coalesced float4 stores.  Wave (class, half): one
+// of the 4 output-parity classes (its 32 A fragments live in registers for the whole kernel) and
+// every other 16-pixel tile of that class's 10 x 10 pixel grid -- 7 tiles per SIMD and sample.
+constexpr int BS_NT = 512, BS_PD = 6, BS_PM = 4;
+struct BstreamP {
+  const float* dout; float* din; const float* mask; const float* wfrag;
+  int Cout, OH, OW, Cin, H, W, B;
+  int WP, PLANE, off0, step_a, step_b, step_c;
+  BwdClass cls[4];
+};
+#define BS_LDD(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * BS_NT, nel4 - 1) << 2));
+#define BS_LDM(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * BS_NT, n4 - 1) << 2));
+#define BS_STD(var, u)                                                                          \
+  {                                                                                             \
+    const int e_ = min(tid + (u) * BS_NT, nel4 - 1) << 2;                                        \
+    const int co_ = e_ / ohw, rem_ = e_ - co_ * ohw;                                            \
+    const float t_[4] = {var.x, var.y, var.z, var.w};                                           \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                          \
+      int cc_ = co_, r_ = rem_ + c_;                                                            \
+      if (r_ >= ohw) { r_ -= ohw; ++cc_; }                                                      \
+      const int y_ = r_ / p.OW, x_ = r_ - y_ * p.OW;                                            \
+      img[cc_ * PLANE + (y_ + 1) * WP + x_ + 1] = t_[c_];                                       \
+    }                                                                                           \
+  }
+
+template <bool MASK>
+__global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_stream_kernel(BstreamP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ img = lds;                              // dOut of the sample with a one-pixel zero halo
+  float* __restrict__ outb = lds + p.Cout * p.PLANE + 64;     // dX of the sample, [Cin][H*W]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int WP = p.WP, PLANE = p.PLANE, HW = p.H * p.W;
+  const int ohw = p.OH * p.OW, nel4 = (p.Cout * ohw) >> 2, n4 = (p.Cin * HW) >> 2;
+  for (int i = tid; i < p.Cout * PLANE + 64; i += BS_NT) img[i] = 0.f;       // halo stays 0 forever
+  const BwdClass k = p.cls[w & 3];
+  const int half = w >> 2;
+  float af[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) af[s] = p.wfrag[k.frag_off + s * 64 + lane];
+  const int NP = k.PH * k.PW, ntile = (NP + 15) >> 4;
+  float4 d0 = {}, d1 = {}, d2 = {}, d3 = {}, d4 = {}, d5 = {}, m0 = {}, m1 = {}, m2 = {}, m3 = {};
+  long b = blockIdx.x;
+  if (b >= p.B) return;
+  {
+    const float* __restrict__ src = p.dout + b * (long)p.Cout * ohw;
+    BS_LDD(d0, 0, src) BS_LDD(d1, 1, src) BS_LDD(d2, 2, src) BS_LDD(d3, 3, src) BS_LDD(d4, 4, src) BS_LDD(d5, 5, src)
+  }
+  for (; b < p.B; b += gridDim.x) {
+    const long nb = (b + gridDim.x < p.B) ? b + gridDim.x : b;          // past the end: re-read this sample (discarded)
+    const float* __restrict__ nsrc = p.dout + nb * (long)p.Cout * ohw;
+    const float* __restrict__ msrc = p.mask + b * (long)p.Cin * HW;
+    float* __restrict__ dst = p.din + b * (long)p.Cin * HW;
+    BS_STD(d0, 0) BS_STD(d1, 1) BS_STD(d2, 2) BS_STD(d3, 3) BS_STD(d4, 4) BS_STD(d5, 5)
+    __syncthreads();
+#define BS_TILES(T0, T1)                                                                                    \
+    for (int t = (T0) * 2 + half; t < (T1) * 2 && t < ntile; t += 2) {                                      \
+      const int idx = t * 16 + j;                                                                           \
+      const bool ok = idx < NP;                                                                             \
+      const int i = ok ? idx : 0;                                                                           \
+      const int r = i / k.PW, c = i - r * k.PW;                                                             \
+      const float* __restrict__ l = img + r * WP + c + g * PLANE + p.off0;                                  \
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};                                                              \
+      _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                       \
+        float bv[16];                                                                                       \
+        _Pragma("unroll") for (int bb = 0; bb < 2; ++bb)                                                    \
+          _Pragma("unroll") for (int c4 = 0; c4 < 8; ++c4)                                                  \
+            bv[bb * 8 + c4] = l[a * p.step_a + bb * p.step_b + c4 * p.step_c];                              \
+        _Pragma("unroll") for (int s = 0; s < 16; ++s)                                                      \
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a * 16 + s], bv[s], acc, 0, 0, 0);                  \
+      }                                                                                                     \
+      if (ok) {                                                                                             \
+        const int pix = (r * 2 + k.oy_add) * p.W + c * 2 + k.ox_add;                                        \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                                    \
+          if (4 * g + rr < p.Cin) outb[(4 * g + rr) * HW + pix] = acc[rr];                                  \
+      }                                                                                                     \
+    }
+    if (MASK) { BS_LDM(m0, 0, msrc) BS_LDM(m1, 1, msrc) BS_LDM(m2, 2, msrc) BS_LDM(m3, 3, msrc) }
+    BS_LDD(d0, 0, nsrc) BS_LDD(d1, 1, nsrc) BS_LDD(d2, 2, nsrc)
+    BS_TILES(0, 2)
+    BS_LDD(d3, 3, nsrc) BS_LDD(d4, 4, nsrc) BS_LDD(d5, 5, nsrc)
+    BS_TILES(2, 64)
+    __syncthreads();                                            // every class has landed in outb
+#define BS_FLUSH(mv, u)                                                                         \
+    {                                                                                           \
+      const int i_ = min(tid + (u) * BS_NT, n4 - 1) << 2;                                        \
+      float4 v_ = *reinterpret_cast<const float4*>(outb + i_);                                  \
+      if (MASK) {                                                                               \
+        if (!(mv.x > 0.f)) v_.x = 0.f;                                                          \
+        if (!(mv.y > 0.f)) v_.y = 0.f;                                                          \
+        if (!(mv.z > 0.f)) v_.z = 0.f;                                                          \
+        if (!(mv.w > 0.f)) v_.w = 0.f;                                                          \
+      }                                                                                         \
+      *reinterpret_cast<float4*>(dst + i_) = v_;                                                \
+    }
+    BS_FLUSH(m0, 0) BS_FLUSH(m1, 1) BS_FLUSH(m2, 2) BS_FLUSH(m3, 3)
+  }
+}
+
 // Generic backward-data, any (ks, S <= 2, pad): a workgroup owns a BAND of TY rows of dX (all
 // columns, all input channels).  It stages the band's dOut rows (with zero halo) once, runs every
 // output-parity class as a stride-1 correlation into an LDS copy of the dX band, then flushes
@@ -1954,6 +2056,22 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
         q.cls[cls].PH = (d->H - 1 - ry) / S + 1;
         q.cls[cls].PW = (d->W - 1 - rx) / S + 1;
         q.cls[cls].oy_add = ry; q.cls[cls].ox_add = rx;
+      }
+      if (S == 2 && d->ks == 4 && MTb == 1 && c4n == 8 && nel % 4 == 0 && nel <= BS_PD * BS_NT * 4 &&
+          d->Cin * d->H * d->W <= BS_PM * BS_NT * 4 && B >= 8 * stream_grid() && !getenv("A2C_NO_STREAM")) {
+        BstreamP sp;
+        sp.dout = dout; sp.din = din; sp.mask = mask; sp.wfrag = wprep_bwd;
+        sp.Cout = d->Cout; sp.OH = d->OH; sp.OW = d->OW; sp.Cin = d->Cin; sp.H = d->H; sp.W = d->W; sp.B = B;
+        sp.WP = q.WP; sp.PLANE = q.PLANE; sp.off0 = q.off0; sp.step_a = q.step_a; sp.step_b = q.step_b; sp.step_c = q.step_c;
+        for (int cls = 0; cls < 4; ++cls) sp.cls[cls] = q.cls[cls];
+        const size_t slds = 4 * ((size_t)d->Cout * q.PLANE + 64 + (size_t)d->Cin * d->H * d->W);
+        const void* sk = mask ? (const void*)bwd_stream_kernel<true> : (const void*)bwd_stream_kernel<false>;
+        if (slds > 64 * 1024) (void)hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+        const int sgrid = resident_grid(sk, slds, B, BS_NT);
+        if (mask) hipLaunchKernelGGL(bwd_stream_kernel<true>, dim3(sgrid), dim3(BS_NT), slds, a2c_s(stream), sp);
+        else hipLaunchKernelGGL(bwd_stream_kernel<false>, dim3(sgrid), dim3(BS_NT), slds, a2c_s(stream), sp);
+        A2C_CHECK_LAUNCH();
+        return A2C_OK;
       }
       const size_t lds = 4 * (nfrag + (size_t)d->Cout * q.PLANE + 64 + (size_t)d->Cin * d->H * d->W);
       if (lds > LDS_HARD_MAX) return A2C_ERR_ARG;

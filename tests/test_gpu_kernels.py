@@ -480,6 +480,35 @@ def test_conv2d_streaming_backward_weight(monkeypatch):
     close("db vs tiled", db, db2, 1e-5 * float(want_b.abs().max()), 1e-5)
 
 
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_conv2d_streaming_backward_data_matches_tiled_kernel(monkeypatch, with_mask):
+    """A3C conv2 input gradient at update-sized batch (persistent streaming kernel) == the tiled
+    kernel bit for bit (same (tap, channel-quad) order of the fp32 MFMA chain), and == fp64 to 1e-5."""
+    ops = _ops()
+    spec = (16, 20, 20, 32, 4, 2, 0)
+    B = 2048 + 55
+    d = ops.conv_desc(*spec)
+    gen = torch.Generator().manual_seed(13)
+    w = ((torch.rand(32, 16, 4, 4, generator=gen) - 0.5) * 0.2)
+    dout = ((torch.rand(B, 32, 9, 9, generator=gen) - 0.5) * (torch.rand(B, 32, 9, 9, generator=gen) < 0.6).float())
+    mask = (torch.rand(B, 16, 20, 20, generator=gen) - 0.4).to(DEV) if with_mask else None
+    wb = torch.empty(ops.conv_prep_floats(d, 1), device=DEV)
+    ops.conv_prep(d, 1, w.to(DEV), wb)
+    dd = dout.to(DEV)
+    got = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+    ops.conv_bwd_data(d, dd, wb, mask, got, B)
+    monkeypatch.setenv("A2C_NO_STREAM", "1")
+    want = torch.empty(B, 16, 20, 20, device=DEV)
+    ops.conv_bwd_data(d, dd, wb, mask, want, B)
+    monkeypatch.delenv("A2C_NO_STREAM")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = F.conv_transpose2d(dout[:32].double(), w.double(), stride=2)
+    if with_mask:
+        ref = ref * (mask[:32].cpu() > 0)
+    close("vs fp64", got[:32], ref, 1e-5 * float(ref.abs().max()), 1e-5)
+
+
 # ------------------------------------------------------------------ GRU gates / LayerNorm
 def test_gru_kernels_vs_autograd():
     ops = _ops()

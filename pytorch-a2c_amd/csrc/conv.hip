@@ -626,6 +626,118 @@ static bool plan_stream(const a2c_conv_desc* d, StreamP& p) {
   return stream_lds(p) <= 160 * 1024;
 }
 
+// "Streaming" forward kernel for the 4x4 / stride 2 layer 16 -> 32 channels (A3CModel conv2) at
+// large batch: persistent 8-wave workgroups, TWO samples per iteration so that the 2 x 6 tiles x 2
+// channel halves = 24 units spread evenly (3 per wave, no K split); wave w keeps the 64 A
+// fragments of its channel half m = w & 1 in registers; the next pair of samples is in flight in
+// registers; outputs staged in LDS and flushed with coalesced float4 stores.
+constexpr int S2_NT = 512, S2_NS = 7, S2_FL = 3;
+struct Stream2P {
+  const float* in; long in_bs;
+  const float* wfrag; const float* bias;
+  float* out; long out_bs;
+  int B, H, W, OH, OW, Mch, relu, PLANE;
+};
+#define S2_LD(var, u)                                                                          \
+  {                                                                                            \
+    const int idx_ = min(tid + (u) * S2_NT, 2 * tot4 - 1);                                      \
+    const int hs_ = idx_ >= tot4;                                                              \
+    var = *reinterpret_cast<const float4*>((hs_ ? nsrc1 : nsrc0) + ((idx_ - hs_ * tot4) << 2)); \
+  }
+#define S2_ST(var, u)                                                                          \
+  {                                                                                            \
+    const int idx_ = min(tid + (u) * S2_NT, 2 * tot4 - 1);                                      \
+    const int pl_ = idx_ / per4;                                                               \
+    *reinterpret_cast<float4*>(img + pl_ * p.PLANE + ((idx_ - pl_ * per4) << 2)) = var;         \
+  }
+
+__global__ __launch_bounds__(S2_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv2_stream_kernel(Stream2P p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ img = lds;                       // [2 samples][16 planes][PLANE]
+  float* __restrict__ ob = lds + 32 * p.PLANE;         // [2 samples][Mch*NP] flat (c, y, x)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int HW = p.H * p.W, NP = p.OH * p.OW;
+  const int per4 = HW >> 2, tot4 = 16 * per4;          // float4 per plane / per sample
+  const int on = p.Mch * NP, on4 = on >> 2;            // output floats / float4 per sample
+  const int m = w & 1, wq = w >> 1;                    // channel half; 4 waves share a half
+  float af[64];
+#pragma unroll
+  for (int s = 0; s < 64; ++s) af[s] = p.wfrag[(s * 2 + m) * 64 + lane];
+  float bz[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) bz[rr] = (p.bias && m * 16 + 4 * g + rr < p.Mch) ? p.bias[m * 16 + 4 * g + rr] : 0.f;
+  const int ntile = (NP + 15) >> 4;                    // per sample
+  float4 v0 = {}, v1 = {}, v2 = {}, v3 = {}, v4 = {}, v5 = {}, v6 = {};
+  const long npair = (p.B + 1) >> 1;
+  long n = blockIdx.x;
+  if (n >= npair) return;
+  {
+    const float* __restrict__ nsrc0 = p.in + (2 * n) * p.in_bs;
+    const float* __restrict__ nsrc1 = p.in + min(2 * n + 1, (long)p.B - 1) * p.in_bs;
+    S2_LD(v0, 0) S2_LD(v1, 1) S2_LD(v2, 2) S2_LD(v3, 3) S2_LD(v4, 4) S2_LD(v5, 5) S2_LD(v6, 6)
+  }
+  for (; n < npair; n += gridDim.x) {
+    const long nn = (n + gridDim.x < npair) ? n + gridDim.x : n;     // past the end: re-read this pair (discarded)
+    const float* __restrict__ nsrc0 = p.in + (2 * nn) * p.in_bs;
+    const float* __restrict__ nsrc1 = p.in + min(2 * nn + 1, (long)p.B - 1) * p.in_bs;
+    float* __restrict__ dst0 = p.out + (2 * n) * p.out_bs;
+    float* __restrict__ dst1 = p.out + min(2 * n + 1, (long)p.B - 1) * p.out_bs;
+    S2_ST(v0, 0) S2_ST(v1, 1) S2_ST(v2, 2) S2_ST(v3, 3) S2_ST(v4, 4) S2_ST(v5, 5) S2_ST(v6, 6)
+    __syncthreads();
+#define S2_UNITS(U0, U1)                                                                                    \
+    for (int un = (U0) * 4 + wq; un < (U1) * 4 && un < 2 * ntile; un += 4) {                                \
+      const int sm = un >= ntile, tile = un - sm * ntile;                                                   \
+      const int idx = tile * 16 + j;                                                                        \
+      const bool ok = idx < NP;                                                                             \
+      const int i = ok ? idx : 0;                                                                           \
+      const int r = i / p.OW, c = i - r * p.OW;                                                             \
+      const float* __restrict__ l = img + (sm * 16 + g) * p.PLANE + r * 2 * p.W + c * 2;                    \
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};                                                              \
+      _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) {                                                    \
+        float bv[16];                                                                                       \
+        _Pragma("unroll") for (int ky = 0; ky < 4; ++ky) {                                                  \
+          const int off = c4 * 4 * p.PLANE + ky * p.W;                                                      \
+          const float2 t0 = *reinterpret_cast<const float2*>(l + off);                                      \
+          const float2 t1 = *reinterpret_cast<const float2*>(l + off + 2);                                  \
+          bv[ky * 4 + 0] = t0.x; bv[ky * 4 + 1] = t0.y; bv[ky * 4 + 2] = t1.x; bv[ky * 4 + 3] = t1.y;       \
+        }                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < 16; ++u)                                                      \
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c4 * 16 + u], bv[u], acc, 0, 0, 0);                 \
+      }                                                                                                     \
+      if (ok) {                                                                                             \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                  \
+          const int co = m * 16 + 4 * g + rr;                                                               \
+          float o = acc[rr] + bz[rr];                                                                       \
+          if (p.relu) o = fmaxf(o, 0.f);                                                                    \
+          if (co < p.Mch) ob[sm * on + co * NP + i] = o;                                                    \
+        }                                                                                                   \
+      }                                                                                                     \
+    }
+    S2_LD(v0, 0) S2_LD(v1, 1) S2_LD(v2, 2) S2_LD(v3, 3)
+    S2_UNITS(0, 1)
+    S2_LD(v4, 4) S2_LD(v5, 5) S2_LD(v6, 6)
+    S2_UNITS(1, 64)
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < S2_FL; ++u) {                  // both samples' outputs: LDS -> HBM
+      const int idx = min(tid + u * S2_NT, 2 * on4 - 1);
+      const int hs = idx >= on4, e = (idx - hs * on4) << 2;
+      *reinterpret_cast<float4*>((hs ? dst1 : dst0) + e) = *reinterpret_cast<const float4*>(ob + hs * on + e);
+    }
+  }
+}
+
+static bool plan_stream2(const a2c_conv_desc* d, Stream2P& p) {
+  if (!(d->ks == 4 && d->stride == 2 && d->pad == 0 && d->Cin == 16 && d->Cout > 16 && d->Cout <= 32 && d->W % 2 == 0)) return false;
+  const int HW = d->H * d->W, NP = d->OH * d->OW;
+  if (HW % 4 || (d->Cout * NP) % 4) return false;
+  p.H = d->H; p.W = d->W; p.OH = d->OH; p.OW = d->OW; p.Mch = d->Cout;
+  p.PLANE = ((HW + 63) / 64) * 64 + 32;                // planes 32 mod 64 floats apart: conflict-free ds_read_b64
+  if (2 * 16 * HW > S2_NS * S2_NT * 4 || 2 * d->Cout * NP > S2_FL * S2_NT * 4) return false;
+  return 4 * (size_t)(32 * p.PLANE + 2 * d->Cout * NP) <= 160 * 1024;
+}
+
 // Same pipeline for the 3x3 / pad 1 layers (ConvModel, GRUModel) whose rows are 16 B aligned
 // (W % 4 == 0): the image keeps a one-column zero halo (LDS column = x + 1, zeroed once), source
 // rows above/below the picture are prefetched as zeros, the three taps of a kernel row are three
@@ -1930,6 +2042,20 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
         attr = true;
       }
       hipLaunchKernelGGL(conv_stream_kernel, dim3(n_cu), dim3(ST_NT), lds, a2c_s(stream), sp);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
+  {  // streaming kernel: A3C conv2 class at large batch
+    Stream2P sp;
+    if (B >= 16 * stream_grid() && !getenv("A2C_NO_STREAM") && !getenv("A2C_NO_PF") && in_bstride % 4 == 0 && out_bstride % 4 == 0 &&
+        ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && plan_stream2(d, sp)) {
+      sp.in = in; sp.in_bs = in_bstride; sp.wfrag = wprep_fwd; sp.bias = bias; sp.out = out; sp.out_bs = out_bstride;
+      sp.B = B; sp.relu = relu;
+      const size_t lds = 4 * (size_t)(32 * sp.PLANE + 2 * d->Cout * d->OH * d->OW);
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv2_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const int grid = resident_grid((const void*)conv2_stream_kernel, lds, (B + 1) / 2, S2_NT);
+      hipLaunchKernelGGL(conv2_stream_kernel, dim3(grid), dim3(S2_NT), lds, a2c_s(stream), sp);
       A2C_CHECK_LAUNCH();
       return A2C_OK;
     }

@@ -480,6 +480,31 @@ def test_conv2d_streaming_backward_weight(monkeypatch):
     close("db vs tiled", db, db2, 1e-5 * float(want_b.abs().max()), 1e-5)
 
 
+@pytest.mark.parametrize("B", [4096 + 54, 4096 + 55])
+def test_conv2d_streaming_forward_conv2_matches_tiled_kernel(monkeypatch, B):
+    """A3C conv2 forward at update-sized batch (two samples per iteration of the persistent kernel;
+    odd batch: the last pair is one sample twice) == the tiled kernel bit for bit."""
+    ops = _ops()
+    spec = (16, 20, 20, 32, 4, 2, 0)
+    d = ops.conv_desc(*spec)
+    gen = torch.Generator().manual_seed(14)
+    x = (torch.rand(B, 16, 20, 20, generator=gen) * (torch.rand(B, 16, 20, 20, generator=gen) < 0.5).float()).to(DEV)
+    w = ((torch.rand(32, 16, 4, 4, generator=gen) - 0.5) * 0.2).to(DEV)
+    bias = ((torch.rand(32, generator=gen) - 0.5) * 0.2).to(DEV)
+    wf = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
+    ops.conv_prep(d, 0, w, wf)
+    got = torch.full((B, 32, 9, 9), float("nan"), device=DEV)
+    ops.conv_fwd(d, x.data_ptr(), 6400, wf, bias, True, got, B)
+    monkeypatch.setenv("A2C_NO_STREAM", "1")
+    want = torch.empty(B, 32, 9, 9, device=DEV)
+    ops.conv_fwd(d, x.data_ptr(), 6400, wf, bias, True, want, B)
+    monkeypatch.delenv("A2C_NO_STREAM")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = F.relu(F.conv2d(x[:64].cpu().double(), w.cpu().double(), bias.cpu().double(), stride=2))
+    close("fwd vs fp64", got[:64], ref, 1e-5, 1e-5)
+
+
 @pytest.mark.parametrize("with_mask", [True, False])
 def test_conv2d_streaming_backward_data_matches_tiled_kernel(monkeypatch, with_mask):
     """A3C conv2 input gradient at update-sized batch (persistent streaming kernel) == the tiled

@@ -262,6 +262,7 @@ def main():
     def rollout():
         if graph is not None:
             graph.replay()
+            net._dirty = False        # the captured rollout re-derived the inference weights (conv fragments, Wc)
         else:
             net.mark_dirty()
             runner.rollout(net, slots, hyps)

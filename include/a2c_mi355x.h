@@ -217,6 +217,13 @@ int a2c_gemm_f32_nn(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda
 int a2c_gemm_f32_tn(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
                     int64_t ldb, float *C, int64_t ldc, int splitk, void *ws, size_t ws_bytes,
                     a2c_stream_t stream);
+/* Inference-only composition of two stacked nn.Linear layers with NO activation in between
+ * (A3CModel: emb = proj_matrx(flat), then pi(emb) / value(emb); models.py:73, 84-85):
+ *   Wc (N x F) = Wh (N x H) . Wp (H x F)        bc (N) = Wh . bp + bh
+ * so that [logits | value] = flat . Wc^T + bc in one skinny layer (a2c_heads_fused / a2c_a3c_step).
+ * N <= 8.  Rebuilt after every optimiser step; the update keeps the exact two-layer path.        */
+int a2c_compose_heads(const float *Wh, const float *bh, const float *Wp, const float *bp, float *Wc,
+                      float *bc, int N, int H, int F, a2c_stream_t stream);
 /* out[n] = sum_m x[m*ld + n]   (bias gradients), deterministic two-stage reduction;
  * ws_bytes >= a2c_colsum_ws_bytes(N)                                                    */
 size_t a2c_colsum_ws_bytes(int64_t N);

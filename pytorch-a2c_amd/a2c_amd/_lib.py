@@ -72,6 +72,7 @@ SIGNATURES = {
     "a2c_colsum_ws_bytes": (c_size_t, [c_int64]),
     "a2c_colsum": (c_int, [P, c_int64, c_int64, c_int64, P, P, c_size_t, P]),
     "a2c_conv2d_prep_floats": (c_size_t, [PD, c_int]),
+    "a2c_compose_heads": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "a2c_a3c_step_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "a2c_a3c_step": (c_int, [PS, P]),
     "a2c_conv2d_prep_weights": (c_int, [PD, c_int, P, P, P]),

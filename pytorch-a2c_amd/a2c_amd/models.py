@@ -238,11 +238,7 @@ class A3CModel(_HipNet):
         if getattr(self, "_Wc", None) is None:
             self._Wc = torch.empty(A + 1, F, device=self._dev)
             self._bc = torch.empty(A + 1, device=self._dev)
-        ops.gemm(0, 0, A + 1, F, h, Wh.data_ptr(), h, self.P("proj_matrx.weight").data_ptr(), F, self._Wc.data_ptr(), F,
-                 st=st)
-        ops.gemm(0, 0, A + 1, 1, h, Wh.data_ptr(), h, self.P("proj_matrx.bias").data_ptr(), 1, self._bc.data_ptr(), 1,
-                 bias=None, st=st)
-        ops.add(self._bc, bh, self._bc, st)
+        ops.compose_heads(Wh, bh, self.P("proj_matrx.weight").data, self.P("proj_matrx.bias").data, self._Wc, self._bc, st)
 
     _fused_sampling = True       # _fwd(..., sampler=(u, actions_ptr, act_stride)) samples inside the heads kernel
 
@@ -277,7 +273,10 @@ class A3CModel(_HipNet):
                             a_ptr, a_stride, st)
         else:
             linear_fwd(ws, a2.data_ptr(), self.flat_size, Wp, P("proj_matrx.bias"), emb, B, st)
-            ops.heads_fused(emb.data_ptr(), 1, 0, h, None, False, None, Wh, bh, hb, B, u, A, a_ptr, a_stride, st)
+            if u is None:         # update: plain skinny layer (wave per row); nothing to sample
+                linear_fwd(ws, emb.data_ptr(), h, Wh, bh, hb, B, st)
+            else:
+                ops.heads_fused(emb.data_ptr(), 1, 0, h, None, False, None, Wh, bh, hb, B, u, A, a_ptr, a_stride, st)
         return dict(logits=logits, vals=vals, sampled=u is not None)
 
     def _step_supported(self):

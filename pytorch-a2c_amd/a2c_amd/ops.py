@@ -185,6 +185,16 @@ def rollout_post(rew, done, val_ptr, val_stride, val_prev, rewards, dones, delta
                                  st if st is not None else stream()), "a2c_rollout_post")
 
 
+def compose_heads(Wh, bh, Wp, bp, Wc, bc, st=None):
+    """Wc = Wh . Wp, bc = Wh . bp + bh (inference-only composition of two activation-free linear layers)"""
+    for t, n in ((Wh, "Wh"), (bh, "bh"), (Wp, "Wp"), (bp, "bp"), (Wc, "Wc"), (bc, "bc")):
+        _chk(t, n)
+    N, H = Wh.shape
+    F = Wp.shape[1]
+    check(lib().a2c_compose_heads(_p(Wh), _p(bh), _p(Wp), _p(bp), _p(Wc), _p(bc), N, H, F,
+                                  st if st is not None else stream()), "a2c_compose_heads")
+
+
 def a3c_step_supported(C, H, W, n_actions):
     return bool(lib().a2c_a3c_step_supported(int(C), int(H), int(W), int(n_actions)))
 

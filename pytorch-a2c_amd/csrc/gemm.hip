@@ -193,7 +193,15 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x
   const long n = blockIdx.x * 256L + threadIdx.x;
   if (n >= N) return;
   float s = 0.f;
-  for (long m = r0; m < r1; ++m) s += x[m * ld + n];
+  long m = r0;
+  for (; m + 8 <= r1; m += 8) {              // 8 independent loads in flight, fixed summation order
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = x[(m + u) * ld + n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; m < r1; ++m) s += x[m * ld + n];
   part[(long)blockIdx.y * N + n] = s;
 }
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int bands, long N,
@@ -201,7 +209,15 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
   const long n = blockIdx.x * 256L + threadIdx.x;
   if (n >= N) return;
   float s = 0.f;
-  for (int b = 0; b < bands; ++b) s += part[(long)b * N + n];
+  int b = 0;
+  for (; b + 8 <= bands; b += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = part[(long)(b + u) * N + n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; b < bands; ++b) s += part[(long)b * N + n];
   out[n] = s;
 }
 
@@ -269,14 +285,20 @@ constexpr int SN_BANDS = 512;
 __global__ __launch_bounds__(256) void small_n_bwd_weight_kernel(const float* __restrict__ dy, long ldy,
                                                                  const float* __restrict__ x, long ldx,
                                                                  float* __restrict__ part, long M, int N, int K) {
+  // threads: kq = column quad, rp = row sub-band (K/4 < 256 leaves threads for several rows at once)
+  __shared__ float4 sm[256];
   const long rows_per = (M + gridDim.x - 1) / gridDim.x;
   const long r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
-  const int k = threadIdx.x * 4;
+  const int kq4 = K >> 2;                                  // float4 columns
+  const int nrp = kq4 >= 256 ? 1 : 256 / kq4;              // row sub-bands
+  const int kq = threadIdx.x % kq4, rp = threadIdx.x / kq4;
+  const int k = kq * 4;
+  const bool live = rp < nrp && (kq4 <= 256 ? true : threadIdx.x * 4 < K);
   float4 acc[SN_MAX];
 #pragma unroll
   for (int n = 0; n < SN_MAX; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (k < K)
-    for (long m = r0; m < r1; ++m) {
+  if (live)
+    for (long m = r0 + rp; m < r1; m += nrp) {
       const float4 xv = *reinterpret_cast<const float4*>(x + m * ldx + k);
 #pragma unroll
       for (int n = 0; n < SN_MAX; ++n)
@@ -285,10 +307,21 @@ __global__ __launch_bounds__(256) void small_n_bwd_weight_kernel(const float* __
           acc[n].x += g * xv.x; acc[n].y += g * xv.y; acc[n].z += g * xv.z; acc[n].w += g * xv.w;
         }
     }
-  if (k < K) {
+  // fixed-order sum of the row sub-bands through LDS, one head at a time
 #pragma unroll
-    for (int n = 0; n < SN_MAX; ++n)
-      if (n < N) *reinterpret_cast<float4*>(part + ((long)blockIdx.x * N + n) * K + k) = acc[n];
+  for (int n = 0; n < SN_MAX; ++n) {
+    if (n >= N) break;
+    __syncthreads();
+    sm[threadIdx.x] = acc[n];
+    __syncthreads();
+    if (rp == 0 && live) {
+      float4 t = sm[kq];
+      for (int q = 1; q < nrp; ++q) {
+        const float4 o = sm[q * kq4 + kq];
+        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+      }
+      *reinterpret_cast<float4*>(part + ((long)blockIdx.x * N + n) * K + k) = t;
+    }
   }
 }
 __global__ __launch_bounds__(256) void small_n_bwd_weight_reduce(const float* __restrict__ part, int bands, long per,
@@ -391,6 +424,42 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restric
     }
     __syncthreads();
   }
+}
+
+// Inference-only composition of two stacked linear layers with no activation in between
+// (A3CModel: proj_matrx then [pi; value], models.py:73,84-85):
+//   Wc[n][f] = sum_h Wh[n][h] * Wp[h][f]      bc[n] = sum_h Wh[n][h] * bp[h] + bh[n]
+// One thread per column f (Wp rows read coalesced), all N <= 8 heads at once, h in fixed order.
+__global__ __launch_bounds__(256) void compose_heads_kernel(const float* __restrict__ Wh, const float* __restrict__ bh,
+                                                            const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                            float* __restrict__ Wc, float* __restrict__ bc, int N, int H,
+                                                            int F) {
+  const int f = blockIdx.x * 256 + threadIdx.x;         // f == F: the bias column
+  if (f > F) return;
+  float acc[SN_MAX];
+#pragma unroll
+  for (int n = 0; n < SN_MAX; ++n) acc[n] = 0.f;
+  for (int h0 = 0; h0 < H; h0 += 8) {
+    float xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int h = min(h0 + u, H - 1);
+      xv[u] = (f < F) ? Wp[(long)h * F + f] : bp[h];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (h0 + u < H) {
+#pragma unroll
+        for (int n = 0; n < SN_MAX; ++n)
+          if (n < N) acc[n] += Wh[n * H + h0 + u] * xv[u];
+      }
+  }
+#pragma unroll
+  for (int n = 0; n < SN_MAX; ++n)
+    if (n < N) {
+      if (f < F) Wc[(long)n * F + f] = acc[n];
+      else bc[n] = acc[n] + bh[n];
+    }
 }
 
 template <bool A_KC, bool B_KC>
@@ -534,6 +603,15 @@ int a2c_gemm_f32_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
 int a2c_gemm_f32_tn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                     float* C, int64_t ldc, int splitk, void* ws, size_t ws_bytes, a2c_stream_t stream) {
   return a2c_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, 0, 0, splitk, ws, ws_bytes, stream);
+}
+
+int a2c_compose_heads(const float* Wh, const float* bh, const float* Wp, const float* bp, float* Wc, float* bc, int N,
+                      int H, int F, a2c_stream_t stream) {
+  if (N < 1 || N > SN_MAX || H < 1 || F < 1 || !Wh || !bh || !Wp || !bp || !Wc || !bc) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(compose_heads_kernel, dim3((unsigned)((F + 1 + 255) / 256)), dim3(256), 0, a2c_s(stream), Wh, bh, Wp, bp,
+                     Wc, bc, N, H, F);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
 }
 
 size_t a2c_colsum_ws_bytes(int64_t N) { return (size_t)CS_BANDS * (size_t)(N > 0 ? N : 0) * sizeof(float); }

@@ -72,7 +72,27 @@ __device__ __forceinline__ void commit_chunk(const float4 (&pf)[N], const a2c_a3
     float4 v = pf[u];
     if (zero_old && c != 3) v = make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(img + c * PLANE1 + r0 * W + (rem << 2)) = v;
-    if (OUT && !SKIP(0)) *reinterpret_cast<float4*>(a.out + (long)b * a.out_stride + (long)c * HW + r0 * W + (rem << 2)) = v;
+  }
+}
+
+// the same chunk to the rollout buffer row (states[e] / bookmark).  Issued one matrix phase AFTER
+// the chunk was committed to LDS: at the start of the kernel HBM belongs to the state loads (the
+// critical path); the row stores drain under the conv phases instead of competing with them.
+template <int N>
+__device__ __forceinline__ void store_chunk(const float4 (&pf)[N], const a2c_a3c_step_args& a, int b, int r0, int q4,
+                                            int HW, int W, int tid, bool zero_old) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int idx = min(tid + u * NT, 4 * q4 - 1);
+    const int c = (idx >= q4) + (idx >= 2 * q4) + (idx >= 3 * q4);
+    const int rem = idx - c * q4;
+    float4 v = pf[u];
+    if (zero_old && c != 3) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    // streaming store: the rows are not re-read by this kernel, and a write-back line left dirty in
+    // the XCD's L2 would have to be flushed at the kernel boundary (serialised after the last wave)
+    if (!SKIP(0))
+      __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w},
+                                  reinterpret_cast<f32x4*>(a.out + (long)b * a.out_stride + (long)c * HW + r0 * W + (rem << 2)));
   }
 }
 
@@ -138,6 +158,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __syncthreads();
     TS(2 + k);
     if (k == 0) issue_chunk(pf2, a, b, p.row_end[1], q2, HW, W, tid);
+#ifdef A2C_STEP_EARLY_STORES
+    if (OUT && k == 0) store_chunk(pf0, a, b, 0, q0, HW, W, tid, zero_old);
+    if (OUT && k == 1) store_chunk(pf1, a, b, p.row_end[0], q1, HW, W, tid, zero_old);
+    if (OUT && k == 2) store_chunk(pf2, a, b, p.row_end[1], q2, HW, W, tid, zero_old);
+#else
+    if (OUT && k == 1) store_chunk(pf0, a, b, 0, q0, HW, W, tid, zero_old);
+    if (OUT && k == 2) store_chunk(pf1, a, b, p.row_end[0], q1, HW, W, tid, zero_old);
+#endif
     if (k == 1 && !SKIP(5)) {
       const float4* __restrict__ wf2v = reinterpret_cast<const float4*>(a.wfrag2);
       w2a = wf2v[tid]; w2b = wf2v[tid + NT]; w2c = wf2v[tid + 2 * NT]; w2d = wf2v[tid + 3 * NT];
@@ -180,6 +208,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
   __syncthreads();                                   // img consumed, a1 complete
   TS(5);
+#ifndef A2C_STEP_EARLY_STORES
+  if (OUT) store_chunk(pf2, a, b, p.row_end[1], q2, HW, W, tid, zero_old);
+#endif
   {
     float4* __restrict__ iv = reinterpret_cast<float4*>(img);
     iv[tid] = w2a; iv[tid + NT] = w2b; iv[tid + 2 * NT] = w2c; iv[tid + 3 * NT] = w2d;

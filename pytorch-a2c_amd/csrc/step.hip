@@ -57,7 +57,9 @@ __device__ __forceinline__ void issue_chunk(float4 (&pf)[N], const a2c_a3c_step_
     const int c = (idx >= q4) + (idx >= 2 * q4) + (idx >= 3 * q4);
     const int rem = idx - c * q4;
     const long off = (c == 3) ? (long)(p3 - pb) : (long)c * HW;       // uniform select, no branch
-    pf[u] = SKIP(4) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(pb + off + r0 * W + (rem << 2));
+    // streaming load: every state row is read once per launch
+    const f32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pb + off + r0 * W + (rem << 2)));
+    pf[u] = SKIP(4) ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(t_[0], t_[1], t_[2], t_[3]);
   }
 }
 

@@ -429,37 +429,47 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restric
 // Inference-only composition of two stacked linear layers with no activation in between
 // (A3CModel: proj_matrx then [pi; value], models.py:73,84-85):
 //   Wc[n][f] = sum_h Wh[n][h] * Wp[h][f]      bc[n] = sum_h Wh[n][h] * bp[h] + bh[n]
-// One thread per column f (Wp rows read coalesced), all N <= 8 heads at once, h in fixed order.
+// 64 columns f per workgroup (Wp rows read coalesced), the hidden index h split over the 4 waves and
+// summed through LDS in a fixed order; all N <= 8 heads at once.
 __global__ __launch_bounds__(256) void compose_heads_kernel(const float* __restrict__ Wh, const float* __restrict__ bh,
                                                             const float* __restrict__ Wp, const float* __restrict__ bp,
                                                             float* __restrict__ Wc, float* __restrict__ bc, int N, int H,
                                                             int F) {
-  const int f = blockIdx.x * 256 + threadIdx.x;         // f == F: the bias column
-  if (f > F) return;
+  __shared__ float sm[4][SN_MAX][64];
+  const int fq = threadIdx.x & 63, hq = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + fq;                   // f == F: the bias column
+  const int hper = (H + 3) / 4, h_lo = hq * hper, h_hi = min(H, h_lo + hper);
   float acc[SN_MAX];
 #pragma unroll
   for (int n = 0; n < SN_MAX; ++n) acc[n] = 0.f;
-  for (int h0 = 0; h0 < H; h0 += 8) {
-    float xv[8];
+  if (f <= F)
+    for (int h0 = h_lo; h0 < h_hi; h0 += 8) {
+      float xv[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int h = min(h0 + u, H - 1);
-      xv[u] = (f < F) ? Wp[(long)h * F + f] : bp[h];
+      for (int u = 0; u < 8; ++u) {
+        const int h = min(h0 + u, H - 1);
+        xv[u] = (f < F) ? Wp[(long)h * F + f] : bp[h];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (h0 + u < h_hi) {
+#pragma unroll
+          for (int n = 0; n < SN_MAX; ++n)
+            if (n < N) acc[n] += Wh[n * H + h0 + u] * xv[u];
+        }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (h0 + u < H) {
+  for (int n = 0; n < SN_MAX; ++n) sm[hq][n][fq] = acc[n];
+  __syncthreads();
+  if (hq == 0 && f <= F) {
 #pragma unroll
-        for (int n = 0; n < SN_MAX; ++n)
-          if (n < N) acc[n] += Wh[n * H + h0 + u] * xv[u];
+    for (int n = 0; n < SN_MAX; ++n)
+      if (n < N) {
+        const float v = ((sm[0][n][fq] + sm[1][n][fq]) + sm[2][n][fq]) + sm[3][n][fq];
+        if (f < F) Wc[(long)n * F + f] = v;
+        else bc[n] = v + bh[n];
       }
   }
-#pragma unroll
-  for (int n = 0; n < SN_MAX; ++n)
-    if (n < N) {
-      if (f < F) Wc[(long)n * F + f] = acc[n];
-      else bc[n] = acc[n] + bh[n];
-    }
 }
 
 template <bool A_KC, bool B_KC>
@@ -608,7 +618,7 @@ int a2c_gemm_f32_tn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
 int a2c_compose_heads(const float* Wh, const float* bh, const float* Wp, const float* bp, float* Wc, float* bc, int N,
                       int H, int F, a2c_stream_t stream) {
   if (N < 1 || N > SN_MAX || H < 1 || F < 1 || !Wh || !bh || !Wp || !bp || !Wc || !bc) return A2C_ERR_ARG;
-  hipLaunchKernelGGL(compose_heads_kernel, dim3((unsigned)((F + 1 + 255) / 256)), dim3(256), 0, a2c_s(stream), Wh, bh, Wp, bp,
+  hipLaunchKernelGGL(compose_heads_kernel, dim3((unsigned)((F + 1 + 63) / 64)), dim3(256), 0, a2c_s(stream), Wh, bh, Wp, bp,
                      Wc, bc, N, H, F);
   A2C_CHECK_LAUNCH();
   return A2C_OK;

@@ -78,6 +78,12 @@ UPDATE_CASES = [
     ("fc_full_adam", "FCModel", (4, 84, 84), 3, 256, 2, 4, "Adam", True, False, False, 1),
     ("grufc_bptt_rms", "GRUFCModel", (4, 4), 2, 64, 3, 7, "RMSprop", True, False, True, 2),
 ]
+# checkpoints written by the reference's Updater.save_model after one update; resumed for a second one
+CHECKPOINT_CASES = [
+    # name, kind, state_shape, A, h, n_rollouts, T, optim, bptt
+    ("fc_rms", "FCModel", (4, 4), 2, 24, 3, 8, "RMSprop", False),
+    ("grufc_adam", "GRUFCModel", (4, 4), 2, 16, 3, 6, "Adam", True),
+]
 SAMPLE = 24   # elements sampled per tensor
 
 

@@ -91,7 +91,7 @@ def load_reference():
 
 
 R = load_reference()
-from cases import (MODEL_CASES, ROLLOUT_CASES, UPDATE_CASES, SAMPLE, hashf, base_hyps, synth_shared,  # noqa: E402
+from cases import (MODEL_CASES, ROLLOUT_CASES, UPDATE_CASES, CHECKPOINT_CASES, SAMPLE, hashf, base_hyps, synth_shared,  # noqa: E402
                    sample_idx, null_prep)
 
 
@@ -295,5 +295,28 @@ def g6():
     save("g6_update.npz", **out)
 
 
+def g7():
+    """Checkpoint resume: update once, Updater.save_model (updater.py:211-219), update again."""
+    out = {}
+    here = os.path.dirname(os.path.abspath(__file__))
+    for (name, kind, ss, A, h, R_, T, opt, use_bptt) in CHECKPOINT_CASES:
+        net = ref_model(kind, ss, A, h)
+        hyps = base_hyps(n_tsteps=T, n_rollouts=R_, optim_type=opt, use_bptt=use_bptt, h_size=h)
+        upd = R["updater"].Updater(net, hyps)
+        upd.update_model(synth_shared(kind, ss, A, h, R_, T, seed=910, recurrent=net.is_recurrent))
+        upd.save_model(os.path.join(here, f"g7_{name}_net.p"), os.path.join(here, f"g7_{name}_optim.p"))
+        info = upd.update_model(synth_shared(kind, ss, A, h, R_, T, seed=920, recurrent=net.is_recurrent))
+        for k, v in info.items():
+            out[f"{name}_{k}"] = np.array(float(v))
+        out[name + "_param_names"] = np.array([n for n, _ in net.named_parameters()])
+        for n, p in net.named_parameters():
+            out[f"{name}_param_{n}"] = p.detach().numpy().copy()
+    save("g7_checkpoint.npz", **out)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g5(); g6()
+    if len(sys.argv) > 1:
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+    else:
+        g1(); g2(); g3(); g4(); g5(); g6(); g7()

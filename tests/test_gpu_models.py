@@ -1,6 +1,8 @@
 """-m gpu: model classes, Runner and Updater of a2c_amd (HIP path through the C ABI) against
 (1) the outputs recorded from the reference (tests/golden/*.npz) and (2) the CPU oracle on the
 same closed-form inputs.  fp32 tolerance 1e-5 (north star), stated per assertion."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -8,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import a2c_oracle as O  # noqa: E402
-from cases import (MODEL_CASES, ROLLOUT_CASES, UPDATE_CASES, hashf, base_hyps, synth_shared,  # noqa: E402
+from cases import (MODEL_CASES, ROLLOUT_CASES, UPDATE_CASES, CHECKPOINT_CASES, hashf, base_hyps, synth_shared,  # noqa: E402
                    sample_idx)
 from test_gpu_kernels import close  # noqa: E402
 
@@ -310,6 +312,33 @@ def test_updater_golden(golden, case):
             # a first RMSprop/Adam step moves every weight by ~lr*10 / ~lr regardless of |g|, and the
             # direction of a noise-level gradient is not pinned by fp32: tolerance = 2 steps of lr*10
             close(f"param samples {n}", p.detach().reshape(-1)[idx.to(DEV)], g[pre + "param_samples"][j], 3e-5, 1e-5)
+
+
+@pytest.mark.parametrize("case", CHECKPOINT_CASES, ids=[c[0] for c in CHECKPOINT_CASES])
+def test_resume_from_reference_written_checkpoint(golden, case):
+    """tests/golden/g7_*_{net,optim}.p were written by the REFERENCE's Updater.save_model
+    (updater.py:211-219) after one update; loading them here (training.py's resume path:
+    net.load_state_dict / optim.load_state_dict) and running the next update must land on the
+    weights the reference reached."""
+    from a2c_amd.updater import Updater
+    g = golden["g7_checkpoint"]
+    name, kind, ss, A, h, R_, T, opt, use_bptt = case
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import a2c_amd
+    net = getattr(a2c_amd.models, kind)(list(ss), A, h_size=h, bnorm=False)
+    net.load_state_dict(torch.load(os.path.join(gdir, f"g7_{name}_net.p"), weights_only=False))
+    hyps = base_hyps(n_tsteps=T, n_rollouts=R_, optim_type=opt, use_bptt=use_bptt, h_size=h)
+    upd = Updater(net, hyps)
+    upd.optim.load_state_dict(torch.load(os.path.join(gdir, f"g7_{name}_optim.p"), weights_only=False))
+    D = synth_shared(kind, ss, A, h, R_, T, seed=920, recurrent=net.is_recurrent)
+    D = {k: (v.to(DEV) if k != "actions" else v) for k, v in D.items()}
+    info = upd.update_model(D)
+    for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy"):
+        assert info[k] == pytest.approx(float(g[f"{name}_{k}"]), rel=3e-5, abs=2e-6), k
+    assert info["GradNorm"] == pytest.approx(float(g[f"{name}_GradNorm"]), rel=3e-4)
+    assert [n for n, _ in net.named_parameters()] == list(g[name + "_param_names"])
+    for n, p in net.named_parameters():
+        close(f"param {n}", p.detach(), g[f"{name}_param_{n}"], 3e-5, 1e-5)     # two optimiser steps of lr*10 (see above)
 
 
 def test_updater_optimizer_state_dict_matches_torch_layout():

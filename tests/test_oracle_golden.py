@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import a2c_oracle as O
-from cases import (MODEL_CASES, ROLLOUT_CASES, UPDATE_CASES, SAMPLE, hashf, base_hyps, synth_shared,
+from cases import (MODEL_CASES, ROLLOUT_CASES, UPDATE_CASES, CHECKPOINT_CASES, SAMPLE, hashf, base_hyps, synth_shared,
                    sample_idx)
 
 torch.set_num_threads(1)
@@ -142,6 +142,27 @@ def _c_oracle():
     lib.oracle_td_delta.restype = ctypes.c_float
     lib.oracle_td_delta.argtypes = [ctypes.c_float] * 5
     return lib, ctypes
+
+
+@pytest.mark.parametrize("case", CHECKPOINT_CASES, ids=[c[0] for c in CHECKPOINT_CASES])
+def test_g7_resume_from_reference_checkpoint(golden, case):
+    """the oracle resumed from the checkpoint files the reference wrote (Updater.save_model,
+    updater.py:211-219) reaches the reference's next weights"""
+    import os
+    g = golden["g7_checkpoint"]
+    name, kind, ss, A, h, R_, T, opt, use_bptt = case
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sd = torch.load(os.path.join(gdir, f"g7_{name}_net.p"), weights_only=False)
+    net = O.OracleNet(kind, ss, A, h, state_dict=sd)
+    hyps = base_hyps(n_tsteps=T, n_rollouts=R_, optim_type=opt, use_bptt=use_bptt, h_size=h)
+    upd = O.OracleUpdater(net, hyps)
+    upd.optim.load_state_dict(torch.load(os.path.join(gdir, f"g7_{name}_optim.p"), weights_only=False))
+    info = upd.update_model(synth_shared(kind, ss, A, h, R_, T, seed=920, recurrent=net.is_recurrent))
+    for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy", "GradNorm"):
+        assert float(info[k]) == pytest.approx(float(g[f"{name}_{k}"]), rel=1e-5, abs=1e-7), k
+    assert [n for n, _ in net.named_parameters()] == list(g[name + "_param_names"])
+    for n, p in net.named_parameters():
+        np.testing.assert_allclose(p.detach().numpy(), g[f"{name}_param_{n}"], rtol=1e-5, atol=1e-6, err_msg=n)
 
 
 def test_c_oracle_matches_golden(golden):

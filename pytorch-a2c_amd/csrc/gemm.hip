@@ -85,11 +85,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(long M, long N, long K, const
                                                    const float* __restrict__ B, long ldb, float* __restrict__ C,
                                                    long ldc, const float* __restrict__ bias, int relu,
                                                    const float* __restrict__ mask, long ldmask, int accumulate,
-                                                   long k_per_split, float* __restrict__ slab, int vecA, int vecB) {
+                                                   long k_per_split, float* __restrict__ slab, int vecA, int vecB, int vec_epi) {
   constexpr int LDA = A_KC ? LD_T : LD_D;
   constexpr int LDB = B_KC ? LD_T : LD_D;
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];     // >= 4 x 32 x 32 floats: reused by the epilogue
+  float* __restrict__ As = smem;
+  float* __restrict__ Bs = smem + BK * LDA;
   const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
   const long kbeg = (long)blockIdx.z * k_per_split;
   const long kend = min(K, kbeg + k_per_split);
@@ -132,6 +133,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(long M, long N, long K, const
 
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool direct = (slab == nullptr);
+  if (direct && vec_epi) {
+    // Row-major epilogue: each 32x32 block goes through this wave's 4 KB of LDS and leaves as
+    // float4 rows, so bias / accumulate / ReLU-mask are 16 B loads and the stores full 128 B rows:
+    // 4 + 4 vector memory instructions per block and lane instead of 16 + 16 dependent dword ones.
+    float* __restrict__ stg = smem + w * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lk) * 32 + li] = acc[i][j][r];
+        const int c4 = (lane & 7) * 4;
+        const long n = n0 + wc * 64 + j * 32 + c4;
+        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && n < N) bv4 = *reinterpret_cast<const float4*>(bias + n);
+        float4 mk[4], od[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const long m = min(m0 + wr * 64 + i * 32 + q * 8 + (lane >> 3), M - 1);
+          const long nc = min(n, N - 4);
+          mk[q] = mask ? *reinterpret_cast<const float4*>(mask + m * ldmask + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
+          od[q] = accumulate ? *reinterpret_cast<const float4*>(C + m * ldc + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = q * 8 + (lane >> 3);
+          const long m = m0 + wr * 64 + i * 32 + row;
+          float4 v = *reinterpret_cast<const float4*>(stg + row * 32 + c4);
+          v.x = (v.x + od[q].x) + bv4.x; v.y = (v.y + od[q].y) + bv4.y;      // same order as the scalar path
+          v.z = (v.z + od[q].z) + bv4.z; v.w = (v.w + od[q].w) + bv4.w;
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (!(mk[q].x > 0.f)) v.x = 0.f;
+          if (!(mk[q].y > 0.f)) v.y = 0.f;
+          if (!(mk[q].z > 0.f)) v.z = 0.f;
+          if (!(mk[q].w > 0.f)) v.w = 0.f;
+          if (m < M && n < N) *reinterpret_cast<float4*>(C + m * ldc + n) = v;
+        }
+      }
+    return;
+  }
   float* out = direct ? C : slab + (long)blockIdx.z * M * N;
   const long ldo = direct ? ldc : N;
 #pragma unroll
@@ -476,8 +517,12 @@ template <bool A_KC, bool B_KC>
 void launch_gemm(dim3 grid, hipStream_t st, long M, long N, long K, const float* A, long lda, const float* B, long ldb,
                  float* C, long ldc, const float* bias, int relu, const float* mask, long ldmask, int acc, long kps,
                  float* slab, int vecA, int vecB) {
+  // row-major float4 epilogue when every row segment is 16 B aligned
+  const int vec_epi = slab == nullptr && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) &&
+                      (!mask || (ldmask % 4 == 0 && (uintptr_t)mask % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0) &&
+                      !getenv("A2C_GEMM_SCALAR_EPILOGUE");
   hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu,
-                     mask, ldmask, acc, kps, slab, vecA, vecB);
+                     mask, ldmask, acc, kps, slab, vecA, vecB, vec_epi);
 }
 }  // namespace
 

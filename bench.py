@@ -234,6 +234,8 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("A2C_BENCH_ONE_DEVICE") == "1":      # test hook: N ranks share cuda:0 (use with A2C_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     shard = Shard.from_env()
     dev = torch.device("cuda", local)

@@ -67,7 +67,12 @@ class Updater:
         if N % T:
             raise ValueError("len(states) is not a multiple of n_tsteps")
         R = N // T
-        n_global = sh.global_count(N)
+        # global batch size: one blocking scalar all-reduce the first time a batch size is seen
+        # (every rank steps with the same shapes, so the answer cannot change afterwards)
+        cache = self.__dict__.setdefault("_n_global", {})
+        if N not in cache:
+            cache[N] = sh.global_count(N)
+        n_global = cache[N]
         b = self._buffers(N)
         advs, rets, stats = b["advs"], b["rets"], b["stats"]
 

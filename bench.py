@@ -283,7 +283,9 @@ def main():
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 net.mark_dirty()
-                with torch.cuda.graph(g):
+                # thread_local: the RCCL watchdog thread of a multi-GPU run may query events while
+                # this thread captures; that must not invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     runner.rollout(net, slots, hyps)
                 graph = g
             except Exception as e:      # noqa: BLE001

@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--n-envs", type=int, default=None)
     ap.add_argument("--optim", default="RMSprop", choices=["RMSprop", "Adam"])
     ap.add_argument("--no-graph", action="store_true", help="do not capture the rollout into a hipGraph")
+    ap.add_argument("--no-update-graph", action="store_true", help="do not capture the update into a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
@@ -293,8 +294,32 @@ def main():
                     print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); eager rollout", file=sys.stderr)
                 graph = None
                 torch.cuda.synchronize()
+    # the update as a second hipGraph (single GPU, RMSprop: no collective and no per-step scalar
+    # argument inside): ~40 dependent launches whose 5-10 us stream gaps shrink to graph-edge gaps
+    ugraph, udev = None, None
+    if graph is not None and not shard.active and args.optim == "RMSprop" and not args.no_update_graph:
+        try:
+            torch.cuda.synchronize()
+            ug = torch.cuda.CUDAGraph()
+            net._dirty = False
+            with torch.cuda.graph(ug, capture_error_mode="thread_local"):
+                udev, u_nglobal = updater._enqueue_update(D)
+            ugraph = ug
+            net._dirty = True          # the capture itself did not run: the optimiser step has not happened
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] update hipGraph capture failed ({type(e).__name__}: {e}); eager update", file=sys.stderr)
+            ugraph = None
+            torch.cuda.synchronize()
+
+    def update():
+        if ugraph is not None:
+            ugraph.replay()
+            updater.optim._steps += 1
+            return updater._finish_update(udev, u_nglobal)
+        return updater.update_model(D)
+
     timers = None
-    if not args.no_kernel_timers:
+    if not args.no_kernel_timers and ugraph is None:
         timers = ops.KernelTimers()
 
     shard.barrier()
@@ -303,7 +328,7 @@ def main():
     roll_ev = []
     for _ in range(args.steps):
         ops.TIMERS = None
-        if timers is not None:       # HIP events on the launch stream around the rollout (one hipGraph replay)
+        if not args.no_kernel_timers:  # HIP events on the launch stream around the rollout (one hipGraph replay)
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
             rollout()
@@ -312,11 +337,23 @@ def main():
         else:
             rollout()
         ops.TIMERS = timers
-        info = updater.update_model(D)
+        info = update()
     torch.cuda.synchronize()
     shard.barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMERS = None
+    sites_note = "HIP events per launch site inside the timed region"
+    if ugraph is not None and not args.no_kernel_timers:
+        # per-site timings cannot be taken inside a graph replay: two extra EAGER updates after the
+        # timed region (same kernels, same data) provide them; the rollout is still timed live above
+        timers = ops.KernelTimers()
+        for _ in range(2):
+            rollout()
+            ops.TIMERS = timers
+            updater.update_model(D)
+            ops.TIMERS = None
+        torch.cuda.synchronize()
+        sites_note = "HIP events per launch site, 2 eager updates after the timed region (the timed updates are hipGraph replays)"
     if shard.active:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -341,6 +378,9 @@ def main():
         kern = {k: dict(avg_ms=round(v["avg_ms"], 4), launches=v["launches"]) for k, v in
                 sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
         out["update_launch_sites_ms"] = kern
+        out["update_launch_sites_note"] = sites_note
+        if ugraph is not None:
+            out["config"]["update"] = "hipGraph"
         layers = getattr(net, "_cl", None)
         if layers is None and hasattr(net, "_c1"):
             layers = [net._c1, net._c2]
@@ -349,7 +389,8 @@ def main():
         rollout_ms = sum(a.elapsed_time(b) for a, b in roll_ev) / max(len(roll_ev), 1)
         out["rollout_ms"] = round(rollout_ms, 3)
         fused_step = graph is not None and getattr(net, "_step_supported", lambda: False)()
-        dom_ms = summ[dom]["total_ms"] / args.steps if dom is not None else 0.0
+        n_upd = 2 if ugraph is not None else args.steps          # updates the launch-site timers saw
+        dom_ms = summ[dom]["total_ms"] / n_upd if dom is not None else 0.0
         if fused_step and rollout_ms > dom_ms:
             # the one-launch rollout step is the kernel the epoch spends most time in: T+1 launches
             # per hipGraph replay; average launch duration = replay time / (T+1) (includes the

@@ -53,6 +53,12 @@ class Updater:
 
     # ------------------------------------------------------------------ the update
     def update_model(self, shared_data):
+        """One A2C update (updater.py:53-137).  Everything up to the five scalars the reference reads
+        back is enqueued on the stream without a host round trip (``_enqueue_update``: a launch-bound
+        caller may capture that part into a hipGraph); ``_finish_update`` then syncs once."""
+        return self._finish_update(*self._enqueue_update(shared_data))
+
+    def _enqueue_update(self, shared_data):
         hyps, net, sh = self.hyps, self.net, self.shard
         net._ensure_device()
         net.req_grads(True)
@@ -127,8 +133,12 @@ class Updater:
             self.optim.step(max_norm=hyps["max_norm"], st=st)
         self.optim.zero_grad()
 
-        # five scalars back to the host (the reference's .item() calls, updater.py:134-136)
-        host = torch.cat([stats[2:5], self.optim.grad_norm().double(), b["err"].double()]).cpu()
+        # five scalars for the host (the reference's .item() calls, updater.py:134-136)
+        return torch.cat([stats[2:5], self.optim.grad_norm().double(), b["err"].double()]), n_global
+
+    def _finish_update(self, dev_vec, n_global):
+        hyps = self.hyps
+        host = dev_vec.cpu()
         if int(host[4]):
             raise ValueError("shared_data['dones']: a slot does not end with done == 1 (runner.py:244 invariant)")
         s_pi, s_val, s_ent = (float(host[i]) for i in range(3))

@@ -253,10 +253,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
   }
   __syncthreads();
-  for (int o = tid; o < p.F; o += NT) {               // a2 flat (co, pixel) = relu((half0 + half1) + bias)
-    const int co = o / NP2, px = o - co * NP2;
-    const int slot = (((px >> 4) * 2 + (co >> 4)) * 256) + ((px & 15) + 16 * ((co & 15) >> 2)) * 4 + (co & 3);
-    a2[o] = fmaxf((part[slot] + part[ntile2 * 512 + slot]) + red[HN + co], 0.f);
+  {  // a2 flat (co, pixel) = relu((half0 + half1) + bias): thread = (channel, pixel lane), no division
+    const int co = tid >> 4, pl = tid & 15;
+    const float bias2 = red[HN + co];
+    const int cslot = (co >> 4) * 256 + 16 * ((co & 15) >> 2) * 4 + (co & 3);
+    for (int px = pl; px < NP2; px += 16) {
+      const int slot = (px >> 4) * 512 + (px & 15) * 4 + cslot;
+      a2[co * NP2 + px] = fmaxf((part[slot] + part[ntile2 * 512 + slot]) + bias2, 0.f);
+    }
   }
   __syncthreads();
   TS(6);

@@ -114,6 +114,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int HW = a.H * a.W, W = a.W;
   const int N = a.n_actions + 1;
   const bool tail = tid == NT - 64;                  // lane 0 of the last wave (fewest conv tiles): bookkeeping + sampling
+  // One batch of kernarg loads: left alone the compiler fetches the ~290 B argument block piecemeal,
+  // in six dependent s_load -> s_waitcnt rounds before the first state load can issue.
+  asm volatile("" ::"s"(a.prev), "s"(a.prev_stride), "s"(a.frame_new), "s"(a.reset_mask), "s"(a.out), "s"(a.out_stride),
+               "s"(a.wfrag1), "s"(a.bias1), "s"(a.bias2), "s"(a.heads), "s"(a.ldh), "s"(a.rew), "s"(a.done),
+               "s"(a.val_prev), "s"(a.rewards), "s"(a.dones), "s"(a.T), "s"(a.t_rec), "s"(a.slot0), "s"(a.H), "s"(a.W),
+               "s"(a.n_actions), "s"(p.PLANE1), "s"(p.row_end[0]), "s"(p.row_end[1]), "s"(p.row_end[2]));
   TS(0);
 
   // ---- every global load of the kernel is issued here, in the order it is consumed.

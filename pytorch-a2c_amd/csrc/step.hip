@@ -177,13 +177,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (k == 1 && !SKIP(5)) {
       const float4* __restrict__ wf2v = reinterpret_cast<const float4*>(a.wfrag2);
       w2a = wf2v[tid]; w2b = wf2v[tid + NT]; w2c = wf2v[tid + 2 * NT]; w2d = wf2v[tid + 3 * NT];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int kk = (tid << 2) + q * (NT * 4);
-#pragma unroll
-        for (int n = 0; n < HN; ++n)
-          wc[q][n] = *reinterpret_cast<const float4*>(a.Wc + (long)min(n, N - 1) * p.F + min(kk, p.F - 4));
-      }
     }
     for (int tile = (k ? p.tile_end[k - 1] : 0) + w; tile < p.tile_end[k] && !SKIP(1); tile += NT / 64) {
       const int idx = tile * 16 + j;
@@ -219,6 +212,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #ifndef A2C_STEP_EARLY_STORES
   if (OUT) store_chunk(pf2, a, b, p.row_end[1], q2, HW, W, tid, zero_old);
 #endif
+  // head weights for this thread's K slices: issued here (not with conv2's fragments before phase 2:
+  // 16 more float4 per thread on the vector-memory pipe delayed that matrix phase), in flight during conv2
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int kk = (tid << 2) + q * (NT * 4);
+#pragma unroll
+    for (int n = 0; n < HN; ++n)
+      wc[q][n] = *reinterpret_cast<const float4*>(a.Wc + (long)min(n, N - 1) * p.F + min(kk, p.F - 4));
+  }
   {
     float4* __restrict__ iv = reinterpret_cast<float4*>(img);
     iv[tid] = w2a; iv[tid + NT] = w2b; iv[tid + 2 * NT] = w2c; iv[tid + 3 * NT] = w2d;

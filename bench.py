@@ -229,7 +229,6 @@ def main():
     from a2c_amd.parallel import Shard
     from a2c_amd.runner import Runner
     from a2c_amd.updater import Updater
-    from oracle import a2c_oracle as O       # closed-form initial weights only (no compute)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
@@ -246,8 +245,8 @@ def main():
         n_envs = args.n_envs
     hyps = hyps_for(model, n_envs, T, use_bptt, args.optim)
     ss = (4, 84, 84)
+    torch.manual_seed(20260101)                # the reference's default init, identical on every rank
     net = getattr(a2c_amd.models, model)(list(ss), A, h_size=256)
-    net.load_state_dict(O.formula_state_dict(model, ss, A, 256))      # identical weights on every rank
     N = n_envs * T
     D = dict(states=torch.zeros(N, *ss, device=dev), deltas=torch.zeros(N, device=dev),
              rewards=torch.zeros(N, device=dev), dones=torch.zeros(N, device=dev),

@@ -1736,7 +1736,7 @@ struct WstreamP {
   const float* in; long in_bs;
   const float* dout;              // (B, Cout, OH, OW) contiguous
   float* slab;                    // [grid][Cout*K + Cout]
-  int B, H, W, OH, OW, Cout, K, PLANE1, PLANEo;
+  int B, H, W, OH, OW, Cout, K, PLANE1, PLANEo, WP;
 };
 #define WS_LDI(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * ST_NT, tot4 - 1) << 2));
 #define WS_LDD(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * ST_NT, dtot4 - 1) << 2));
@@ -1744,13 +1744,16 @@ struct WstreamP {
   {                                                                                            \
     const int idx_ = min(tid + (u) * ST_NT, tot4 - 1);                                          \
     const int c_ = (idx_ >= per4) + (idx_ >= 2 * per4) + (idx_ >= 3 * per4);                   \
-    *reinterpret_cast<float4*>(img + c_ * p.PLANE1 + ((idx_ - c_ * per4) << 2)) = var;          \
+    const int rem_ = idx_ - c_ * per4, row_ = rem_ / w4;                                       \
+    *reinterpret_cast<float4*>(img + c_ * p.PLANE1 + row_ * p.WP + ((rem_ - row_ * w4) << 2)) = var; \
   }
 #define WS_STD(var, u)                                                                         \
   {                                                                                            \
     const int idx_ = min(tid + (u) * ST_NT, dtot4 - 1);                                         \
     const int co_ = idx_ / dper4;                                                              \
-    *reinterpret_cast<float4*>(ldo + co_ * p.PLANEo + ((idx_ - co_ * dper4) << 2)) = var;       \
+    float* d_ = ldo + co_ * p.PLANEo + ((idx_ - co_ * dper4) << 2);        /* rows 2 mod 32 floats apart: 8 B aligned */ \
+    *reinterpret_cast<float2*>(d_) = make_float2(var.x, var.y);                                \
+    *reinterpret_cast<float2*>(d_ + 2) = make_float2(var.z, var.w);                            \
   }
 
 __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_stream_kernel(WstreamP p) {
@@ -1761,14 +1764,14 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   const int kk = lane >> 4, j = lane & 15;
   const int q = w & 3, h = w >> 2;
   const int HW = p.H * p.W, W = p.W, NP = p.OH * p.OW;
-  const int per4 = HW >> 2, tot4 = 4 * per4;
+  const int per4 = HW >> 2, tot4 = 4 * per4, w4 = W >> 2;
   const int dper4 = NP >> 2, dtot4 = p.Cout * dper4;
   for (int i = tid; i < 16 * p.PLANEo; i += ST_NT) ldo[i] = 0.f;
   // this lane's weight column group: (ci, ky, kxh), the 4 accumulators are kxl = 0..3
   const int cidx = q * 16 + j;
   const int kxh = cidx & 1, cy = cidx >> 1;
   const int ci = cy >> 3, ky = cy & 7;
-  const int boff = ci * p.PLANE1 + ky * W + kxh * 4 + kk * 4;
+  const int boff = ci * p.PLANE1 + ky * p.WP + kxh * 4 + kk * 4;
   const int knat = (ci * 8 + ky) * 8 + kxh * 4;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   const int bco = tid & 15, bpart = tid >> 4;        // bias gradient: 32 partial sums per channel
@@ -1805,7 +1808,7 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     for (int rr = (R0); rr < (R1); ++rr) {                                                                  \
       const int r = 2 * rr + h;                                                                             \
       const float* __restrict__ arow = ldo + j * p.PLANEo + r * p.OW + kk;                                  \
-      const float* __restrict__ brow = img + r * 4 * W + boff;                                              \
+      const float* __restrict__ brow = img + r * 4 * p.WP + boff;                                              \
       for (int c0 = 0; c0 < c4n; c0 += 5) {                                                                 \
         float av[5];                                                                                        \
         float4 bv[5];                                                                                       \
@@ -1866,8 +1869,9 @@ static bool plan_wstream(const a2c_conv_desc* d, WstreamP& p) {
   if (!(d->ks == 8 && d->stride == 4 && d->pad == 0 && d->Cin == 4 && d->Cout <= 16 && d->W % 4 == 0 && d->OW % 4 == 0)) return false;
   const int NP = d->OH * d->OW;
   p.H = d->H; p.W = d->W; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.K = d->Cin * 64;
-  p.PLANE1 = ((d->H * d->W + 63) / 64) * 64;
-  p.PLANEo = ((NP + 7) / 8) * 8 + 4;
+  p.WP = d->W;      // (no row padding: no pitch makes the 4 x 16 lane groups of the B reads (ds_read_b128) conflict-free, measured)
+  p.PLANE1 = ((d->H * p.WP + 63) / 64) * 64;
+  p.PLANEo = ((NP + 31) / 32) * 32 + 2;                // A reads: lanes (channel j, pixel kk) hit banks 2j + kk: conflict-free
   if (d->H * d->W > ST_NS * ST_NT || d->Cout * NP > 4 * ST_NT * 4 || d->OH < 6) return false;
   if (4 * p.PLANE1 < 4096 + 512) return false;         // epilogue scratch reuses the image region
   return 4 * (size_t)(4 * p.PLANE1 + 16 * p.PLANEo) <= 160 * 1024;

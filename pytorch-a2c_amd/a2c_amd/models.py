@@ -235,12 +235,17 @@ class A3CModel(_HipNet):
         ar = self._arena
         Wh = ar.params[ar.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
         bh = ar.params[ar.offsets["pi.bias"][0]:][:A + 1]
+        if A + 1 > 8:               # wide action spaces: no skinny-head kernels, plain GEMMs + the sampling kernel
+            return
         if getattr(self, "_Wc", None) is None:
             self._Wc = torch.empty(A + 1, F, device=self._dev)
             self._bc = torch.empty(A + 1, device=self._dev)
         ops.compose_heads(Wh, bh, self.P("proj_matrx.weight").data, self.P("proj_matrx.bias").data, self._Wc, self._bc, st)
 
-    _fused_sampling = True       # _fwd(..., sampler=(u, actions_ptr, act_stride)) samples inside the heads kernel
+    @property
+    def _fused_sampling(self):
+        """_fwd(..., sampler=(u, actions_ptr, act_stride)) samples inside the heads kernel (up to 7 actions)"""
+        return self.output_space + 1 <= 8
 
     def _fwd(self, x_ptr, bstride, B, tag, st, save, sampler=None):
         ws, P = self.ws(tag), self.P
@@ -255,6 +260,10 @@ class A3CModel(_HipNet):
         Wh = self._arena.params[self._arena.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
         bh = self._arena.params[self._arena.offsets["pi.bias"][0]:][:A + 1]
         u, a_ptr, a_stride = sampler if sampler is not None else (None, 0, 0)
+        if A + 1 > 8:               # wide heads: two plain GEMMs; the runner samples with a2c_softmax_sample
+            linear_fwd(ws, a2.data_ptr(), self.flat_size, P("proj_matrx.weight"), P("proj_matrx.bias"), emb, B, st)
+            linear_fwd(ws, emb.data_ptr(), h, Wh, bh, hb, B, st)
+            return dict(logits=logits, vals=vals, sampled=False)
         if sampler is not None and not save and os.environ.get("A2C_NO_COMPOSED_HEADS") != "1":
             # rollout step: heads straight from the conv features through the composed matrix
             ops.heads_fused(a2.data_ptr(), 1, 0, self.flat_size, None, False, None, self._Wc, self._bc, hb, B, u, A,
@@ -284,7 +293,7 @@ class A3CModel(_HipNet):
         if os.environ.get("A2C_NO_FUSED_STEP") == "1" or os.environ.get("A2C_NO_COMPOSED_HEADS") == "1":
             return False
         C, H, W = self.input_space[-3:]
-        return ops.a3c_step_supported(C, H, W, self.output_space)
+        return self.output_space + 1 <= 8 and ops.a3c_step_supported(C, H, W, self.output_space)
 
     def _step(self, B, st, **kw):
         """[bookkeeping] + [frame stack] + forward + [sample] + [bootstrap] of one rollout step in ONE

@@ -202,6 +202,41 @@ def test_runner_batched_vs_oracle(kind, dev_actions, fused_step, monkeypatch):
         close("h_states", D["h_states"], Do["h_states"], 1e-5, 1e-5)
 
 
+def test_a3c_wide_action_space_falls_back_to_plain_gemms():
+    """18 actions (full Atari set): no skinny-head / composed-head / step kernels; forward, sampling
+    through the Runner and one update against the oracle"""
+    from a2c_amd.runner import Runner
+    from a2c_amd.updater import Updater
+    A, ss, B, T = 18, (4, 84, 84), 3, 4
+    net = make_net("A3CModel", ss, A, 256)
+    assert not net._step_supported() and not net._fused_sampling
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    hyps = base_hyps(env_type="FakeBreakout", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    ekws = [dict(env_id=j, rew_period=3, done_period=5 + j) for j in range(B)]
+    N = B * T
+    D = _datas(N, ss, False, actions_on_host=False)
+    us = torch.from_numpy(hashf(T * B, 901, 0, 1).reshape(T, B))
+    usd = us.to(DEV)
+    r = Runner(D, hyps, None, None, None, env_pool=_fake_pool(ekws), uniform_fn=lambda t, Bn, e0: usd[t, e0:e0 + Bn].contiguous())
+    r.rollout(net, list(range(B)), hyps)
+    Do = dict(states=torch.zeros(N, *ss), deltas=torch.zeros(N), rewards=torch.zeros(N), dones=torch.zeros(N),
+              actions=torch.zeros(N).long())
+    for j in range(B):
+        seq = iter([float(us[t, j]) for t in range(T)])
+        sr = O.SlotRunner(O.FakeEnv(**ekws[j]), Do, hyps, uniform_fn=lambda seq=seq: next(seq))
+        sr.start(onet)
+        sr.rollout(onet, j)
+    torch.cuda.synchronize()
+    assert torch.equal(D["actions"].cpu(), Do["actions"])
+    close("deltas", D["deltas"], Do["deltas"], 1e-5, 1e-5)
+    info = Updater(net, hyps).update_model(D)
+    oinfo = O.OracleUpdater(onet, hyps).update_model(Do)
+    for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy"):
+        assert info[k] == pytest.approx(float(oinfo[k]), rel=3e-5, abs=2e-6), k
+    for (n, p), (_, q) in zip(net.named_parameters(), onet.named_parameters()):
+        close(f"param {n}", p.detach(), q.detach(), 3e-5, 1e-5)
+
+
 def test_a3c_step_kernel_matches_layered_ops():
     """a2c_a3c_step == frame_stack_push + conv/conv/composed heads + softmax_sample + record/bootstrap"""
     from a2c_amd import ops

@@ -64,35 +64,70 @@ class Arena:
 
 
 class ConvLayer:
-    """One nn.Conv2d(+ReLU) block of a model: descriptor, matrix-core weight fragments."""
+    """One nn.Conv2d(+ReLU) block of a model: descriptor, matrix-core weight fragments.
+
+    The kernels take input planes in quads (4 planes = one MFMA k-step).  A layer whose Cin is not a
+    multiple of 4 (the reference's shipped hyperparams stack 3 frames) runs on a zero-padded copy:
+    the input rows are copied into a (B, Cin_pad, H, W) buffer whose extra planes stay 0, the weights
+    into a (Cout, Cin_pad, ks, ks) buffer whose extra slices stay 0, and the weight gradient is
+    computed padded and sliced back.  Correct, not tuned: the tuned paths are for Cin % 4 == 0."""
 
     def __init__(self, Cin, H, W, Cout, ks, stride, pad, need_bwd_data, name="conv"):
         self.name = name
-        self.d = ops.conv_desc(Cin, H, W, Cout, ks, stride, pad)
+        self.cin, self.cin_pad = Cin, (Cin + 3) // 4 * 4
+        self.padded = self.cin_pad != Cin
+        self.d = ops.conv_desc(self.cin_pad, H, W, Cout, ks, stride, pad)
         self.need_bwd_data = need_bwd_data
         self.out_shape = (Cout, self.d.OH, self.d.OW)
+        self.hw = H * W
         self.in_floats = Cin * H * W
         self.wf = self.wb = None
+        self._xpad, self._wpad, self._dwpad = {}, None, None
+
+    def _input(self, in_ptr, in_bstride, B, dev, st):
+        if not self.padded:
+            return in_ptr, in_bstride
+        buf = self._xpad.get(B)
+        if buf is None:
+            buf = self._xpad[B] = torch.zeros(B, self.cin_pad * self.hw, dtype=torch.float32, device=dev)
+        ops.copy_rows(in_ptr, in_bstride, buf.data_ptr(), self.cin_pad * self.hw, B, self.cin * self.hw, st)
+        return buf.data_ptr(), self.cin_pad * self.hw
 
     def prep(self, weight, st):
         if self.wf is None:
             self.wf = torch.empty(ops.conv_prep_floats(self.d, 0), dtype=torch.float32, device=weight.device)
             if self.need_bwd_data:
                 self.wb = torch.empty(ops.conv_prep_floats(self.d, 1), dtype=torch.float32, device=weight.device)
+        if self.padded:
+            if self._wpad is None:
+                self._wpad = torch.zeros(weight.shape[0], self.cin_pad, *weight.shape[2:], device=weight.device)
+            self._wpad[:, :self.cin].copy_(weight.detach())
+            weight = self._wpad
         ops.conv_prep(self.d, 0, weight, self.wf, st)
         if self.need_bwd_data:
             ops.conv_prep(self.d, 1, weight, self.wb, st)
 
     def fwd(self, in_ptr, in_bstride, bias, out, B, st, relu=True):
+        in_ptr, in_bstride = self._input(in_ptr, in_bstride, B, out.device, st)
         with ops.span(self.name + ".fwd"):
             ops.conv_fwd(self.d, in_ptr, in_bstride, self.wf, bias, relu, out, B, st)
 
     def bwd_weight(self, in_ptr, in_bstride, dout, dW, db, B, ws, st):
+        in_ptr, in_bstride = self._input(in_ptr, in_bstride, B, dout.device, st)
         buf = ws.bytes("conv_wgrad_ws", ops.conv_bwd_weight_ws_bytes(self.d, B))
+        dst = dW
+        if self.padded:
+            if self._dwpad is None:
+                self._dwpad = torch.empty(dW.shape[0], self.cin_pad, *dW.shape[2:], device=dW.device)
+            dst = self._dwpad
         with ops.span(self.name + ".bwd_weight"):
-            ops.conv_bwd_weight(self.d, in_ptr, in_bstride, dout, dW, db, B, buf, st)
+            ops.conv_bwd_weight(self.d, in_ptr, in_bstride, dout, dst, db, B, buf, st)
+        if self.padded:
+            dW.copy_(dst[:, :self.cin])
 
     def bwd_data(self, dout, mask, din, B, st):
+        if self.padded:
+            raise NotImplementedError("a2c_amd: input gradient of a channel-padded conv layer (only first layers are padded)")
         with ops.span(self.name + ".bwd_data"):
             ops.conv_bwd_data(self.d, dout, self.wb, mask, din, B, st)
 

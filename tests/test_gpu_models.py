@@ -237,6 +237,50 @@ def test_a3c_wide_action_space_falls_back_to_plain_gemms():
         close(f"param {n}", p.detach(), q.detach(), 3e-5, 1e-5)
 
 
+@pytest.mark.parametrize("kind", ["A3CModel", "GRUModel"])
+def test_three_stacked_frames(kind):
+    """n_frame_stack = 3 (the reference's shipped hyperparams.json): the first conv layer has 3 input
+    planes and runs on the zero-padded 4-plane copy.  Rollout through the Runner + one update vs the oracle."""
+    from a2c_amd.runner import Runner
+    from a2c_amd.updater import Updater
+    A, ss, B, T = 4, (3, 84, 84), 3, 4
+    net = make_net(kind, ss, A, 256)
+    onet = O.OracleNet(kind, ss, A, 256)
+    hyps = base_hyps(env_type="FakeBreakout", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, n_frame_stack=3)
+    ekws = [dict(env_id=j, rew_period=3, done_period=5 + j) for j in range(B)]
+    N = B * T
+    D = _datas(N, ss, net.is_recurrent, actions_on_host=False)
+    us = torch.from_numpy(hashf(T * B, 902, 0, 1).reshape(T, B))
+    usd = us.to(DEV)
+    r = Runner(D, hyps, None, None, None, env_pool=_fake_pool(ekws), uniform_fn=lambda t, Bn, e0: usd[t, e0:e0 + Bn].contiguous())
+    r.rollout(net, list(range(B)), hyps)
+    Do = dict(states=torch.zeros(N, *ss), deltas=torch.zeros(N), rewards=torch.zeros(N), dones=torch.zeros(N),
+              actions=torch.zeros(N).long())
+    if net.is_recurrent:
+        Do["h_states"] = torch.zeros(N, 256)
+    for j in range(B):
+        seq = iter([float(us[t, j]) for t in range(T)])
+        sr = O.SlotRunner(O.FakeEnv(**ekws[j]), Do, hyps, uniform_fn=lambda seq=seq: next(seq))
+        sr.start(onet)
+        sr.rollout(onet, j)
+    torch.cuda.synchronize()
+    assert torch.equal(D["actions"].cpu(), Do["actions"])
+    assert torch.equal(D["states"].cpu(), Do["states"])
+    close("deltas", D["deltas"], Do["deltas"], 1e-5, 1e-5)
+    info = Updater(net, hyps).update_model(D)
+    oinfo = O.OracleUpdater(onet, hyps).update_model(Do)
+    for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy"):
+        assert info[k] == pytest.approx(float(oinfo[k]), rel=3e-5, abs=2e-6), k
+    # one RMSprop step moves a weight by lr * g / (sqrt(0.01 g^2) + eps) ~ lr * 10 * sign(g) = 1e-3 whatever
+    # |g| is: for a noise-level gradient fp32 does not pin the sign, so single elements may differ by up to
+    # two steps; everything else must agree to 3e-5
+    for (n, p), (_, q) in zip(net.named_parameters(), onet.named_parameters()):
+        diff = (p.detach().cpu() - q.detach()).abs()
+        assert float(diff.max()) <= 2.1e-3, (n, float(diff.max()))
+        n_off = int((diff > 3e-5 + 1e-5 * q.detach().abs()).sum())
+        assert n_off <= max(1, int(2e-3 * diff.numel())), (n, n_off, diff.numel())
+
+
 def test_a3c_step_kernel_matches_layered_ops():
     """a2c_a3c_step == frame_stack_push + conv/conv/composed heads + softmax_sample + record/bootstrap"""
     from a2c_amd import ops

@@ -472,19 +472,25 @@ class _GruMixin:
     kernels forward).  Buffers are (B, h) contiguous; `pre` prefixes workspace names so the
     BPTT unroll can keep one set per time step (time-major)."""
 
+    @staticmethod
+    def _mm(ws, ta, tb, M, N, K, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, st, accumulate=False):
+        """One of the cell's h x h products.  At rollout batch these are 2 x 2 tiles of 128 x 128: split K
+        (deterministic slab reduce) so that more than 4 workgroups share the work."""
+        sk = ops.pick_splitk(M, N, K)
+        buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(M, N, sk)) if sk > 1 else None
+        ops.gemm(ta, tb, M, N, K, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, accumulate=accumulate, splitk=sk, ws=buf, st=st)
+
     def _gru_fwd(self, ws, x, h_in, B, st, bufs):
         hd, xs = self.h_size, self.gru.x_size
         Wx, Wh, b = self.P("gru.W_x"), self.P("gru.W_h"), self.P("gru.b")
         gx, gh, z, r, rh, rhu, c, hn = (bufs[k] for k in ("gx", "gh", "z", "r", "rh", "rhu", "c", "hn"))
         if x is not None:   # gx may have been precomputed for all time steps at once
             for g in range(3):
-                ops.gemm(0, 0, B, hd, xs, x.data_ptr(), xs, Wx[g].data_ptr(), hd, gx.data_ptr() + 4 * g * hd, 3 * hd,
-                         st=st)
+                self._mm(ws, 0, 0, B, hd, xs, x.data_ptr(), xs, Wx[g].data_ptr(), hd, gx.data_ptr() + 4 * g * hd, 3 * hd, st)
         for g in range(2):
-            ops.gemm(0, 0, B, hd, hd, h_in.data_ptr(), hd, Wh[g].data_ptr(), hd, gh.data_ptr() + 4 * g * hd, 2 * hd,
-                     st=st)
+            self._mm(ws, 0, 0, B, hd, hd, h_in.data_ptr(), hd, Wh[g].data_ptr(), hd, gh.data_ptr() + 4 * g * hd, 2 * hd, st)
         ops.gru_gates(gx, gh, b, h_in, z, r, rh, st)
-        ops.gemm(0, 0, B, hd, hd, rh.data_ptr(), hd, Wh[2].data_ptr(), hd, rhu.data_ptr(), hd, st=st)
+        self._mm(ws, 0, 0, B, hd, hd, rh.data_ptr(), hd, Wh[2].data_ptr(), hd, rhu.data_ptr(), hd, st)
         ops.gru_out(gx, rhu, b, h_in, z, c, hn, st)
 
     def _gru_bwd_step(self, ws, dhn, h_in, B, st, bufs, dbufs):
@@ -495,10 +501,10 @@ class _GruMixin:
         z, r, c = bufs["z"], bufs["r"], bufs["c"]
         dzp, drp, dcp, dz, drh, dh = (dbufs[k] for k in ("dz_pre", "dr_pre", "dc_pre", "dz", "d_rh", "dh"))
         ops.gru_out_bwd(dhn, h_in, z, c, dcp, dz, dh, st)
-        ops.gemm(0, 1, B, hd, hd, dcp.data_ptr(), hd, Wh[2].data_ptr(), hd, drh.data_ptr(), hd, st=st)   # dc_pre Wh2^T
+        self._mm(ws, 0, 1, B, hd, hd, dcp.data_ptr(), hd, Wh[2].data_ptr(), hd, drh.data_ptr(), hd, st)   # dc_pre Wh2^T
         ops.gru_gates_bwd(drh, dz, h_in, z, r, dzp, drp, dh, st)
-        ops.gemm(0, 1, B, hd, hd, dzp.data_ptr(), hd, Wh[0].data_ptr(), hd, dh.data_ptr(), hd, accumulate=True, st=st)
-        ops.gemm(0, 1, B, hd, hd, drp.data_ptr(), hd, Wh[1].data_ptr(), hd, dh.data_ptr(), hd, accumulate=True, st=st)
+        self._mm(ws, 0, 1, B, hd, hd, dzp.data_ptr(), hd, Wh[0].data_ptr(), hd, dh.data_ptr(), hd, st, accumulate=True)
+        self._mm(ws, 0, 1, B, hd, hd, drp.data_ptr(), hd, Wh[1].data_ptr(), hd, dh.data_ptr(), hd, st, accumulate=True)
         return dh
 
     def _gru_bwd_weights(self, ws, x, h_in, rh, dzp, drp, dcp, dx, M, st, x_mask=None):

@@ -1517,32 +1517,44 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
       }
     }
     __syncthreads();
-    if (p.W & 3) {  // rows not 16 B aligned: coalesced 4 B flush
+    // coalesced flush of the band: rows Y0 .. Y0+rowsY of every channel are ONE contiguous run of
+    // rowsY*W floats per channel; a wave takes a channel at a time (no per-element division), with
+    // the widest vector the row pitch allows (W % 4 == 0: 16 B, W % 2 == 0: 8 B, else 4 B)
+    {
       const int per = rowsY * p.W;
-      const int n = p.Cin * per;
-      for (int i = tid; i < n; i += 256) {
-        const int ch = i / per, rem = i - ch * per;
-        const long o = ((b * p.Cin + ch) * (long)p.H + Y0) * p.W + rem;
-        float v = outb[ch * p.TY * p.W + rem];
-        if (p.mask && !(p.mask[o] > 0.f)) v = 0.f;
-        p.din[o] = v;
-      }
-    } else {  // coalesced flush of the band: rows Y0 .. Y0+rowsY of every channel
-      const int row4 = p.W >> 2;
-      const int per = rowsY * row4;
-      const int n4 = p.Cin * per;
-      for (int i = tid; i < n4; i += 256) {
-        const int ch = i / per, rem = i - ch * per;
-        const long o = ((b * p.Cin + ch) * (long)p.H + Y0) * p.W + ((long)rem << 2);
-        float4 v = *reinterpret_cast<const float4*>(outb + ch * p.TY * p.W + (rem << 2));
-        if (p.mask) {
-          const float4 mk = *reinterpret_cast<const float4*>(p.mask + o);
-          if (!(mk.x > 0.f)) v.x = 0.f;
-          if (!(mk.y > 0.f)) v.y = 0.f;
-          if (!(mk.z > 0.f)) v.z = 0.f;
-          if (!(mk.w > 0.f)) v.w = 0.f;
+      const int vec = (p.W & 3) == 0 ? 4 : (p.W & 1) == 0 ? 2 : 1;
+      for (int ch = w; ch < p.Cin; ch += 4) {
+        const long o0 = ((b * p.Cin + ch) * (long)p.H + Y0) * p.W;
+        const float* __restrict__ sb = outb + ch * p.TY * p.W;
+        if (vec == 4) {
+          for (int e = lane << 2; e < per; e += 256) {
+            float4 v = *reinterpret_cast<const float4*>(sb + e);
+            if (p.mask) {
+              const float4 mk = *reinterpret_cast<const float4*>(p.mask + o0 + e);
+              if (!(mk.x > 0.f)) v.x = 0.f;
+              if (!(mk.y > 0.f)) v.y = 0.f;
+              if (!(mk.z > 0.f)) v.z = 0.f;
+              if (!(mk.w > 0.f)) v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(p.din + o0 + e) = v;
+          }
+        } else if (vec == 2) {
+          for (int e = lane << 1; e < per; e += 128) {
+            float2 v = *reinterpret_cast<const float2*>(sb + e);
+            if (p.mask) {
+              const float2 mk = *reinterpret_cast<const float2*>(p.mask + o0 + e);
+              if (!(mk.x > 0.f)) v.x = 0.f;
+              if (!(mk.y > 0.f)) v.y = 0.f;
+            }
+            *reinterpret_cast<float2*>(p.din + o0 + e) = v;
+          }
+        } else {
+          for (int e = lane; e < per; e += 64) {
+            float v = sb[e];
+            if (p.mask && !(p.mask[o0 + e] > 0.f)) v = 0.f;
+            p.din[o0 + e] = v;
+          }
         }
-        *reinterpret_cast<float4*>(p.din + o) = v;
       }
     }
   }

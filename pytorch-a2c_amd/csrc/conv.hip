@@ -296,17 +296,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
       float* __restrict__ ob = p.out + b * p.out_bs + (long)qq0 * p.OWf;
       const float* __restrict__ sb = lds + p.out_stage;
       const long chs = (long)p.OHf * p.OWf;
-      if (p.out_vec) {
-        const int per4 = NP >> 2, n4 = p.Mch * per4;
-        for (int i = threadIdx.x; i < n4; i += 256) {
-          const int co = i / per4, e = (i - co * per4) << 2;
-          *reinterpret_cast<float4*>(ob + co * chs + e) = *reinterpret_cast<const float4*>(sb + co * p.TPH * p.PW + e);
-        }
-      } else {
-        const int n = p.Mch * NP;
-        for (int i = threadIdx.x; i < n; i += 256) {
-          const int co = i / NP, e = i - co * NP;
-          ob[co * chs + e] = sb[co * p.TPH * p.PW + e];
+      // a wave takes one channel at a time (no per-element division); 16 B vectors when the
+      // launcher found every run aligned, else 4 B
+      for (int co = w; co < p.Mch; co += 4) {
+        float* __restrict__ oc = ob + co * chs;
+        const float* __restrict__ sc = sb + co * p.TPH * p.PW;
+        if (p.out_vec) {
+          for (int e = lane << 2; e < NP; e += 256) *reinterpret_cast<float4*>(oc + e) = *reinterpret_cast<const float4*>(sc + e);
+        } else {
+          for (int e = lane; e < NP; e += 64) oc[e] = sc[e];
         }
       }
     }

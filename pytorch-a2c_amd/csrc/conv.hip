@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
        // pad columns stay 0.  Flattened over all threads, 8 independent loads in flight each.
       const int per = rows * p.OW;
       const float* __restrict__ dsrc = p.dout + (b * p.Cout * p.OH + q0) * (long)p.OW;
-      if (p.dvec) {            // OW % 4 == 0, 16 B aligned: a channel's rows are one float4 stream
+      if (p.dvec == 4) {       // OW % 4 == 0, 16 B aligned: a channel's rows are one float4 stream
         const int per4 = per >> 2, tot4 = p.Cout * per4;
         for (int i0 = threadIdx.x; i0 < tot4; i0 += 256 * STAGE_U) {
           float4 v[STAGE_U];
@@ -1074,6 +1074,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
 #pragma unroll
           for (int u = 0; u < STAGE_U; ++u)
             if (dst[u] >= 0) { ldo[dst[u]] = v[u].x; ldo[dst[u] + 1] = v[u].y; ldo[dst[u] + 2] = v[u].z; ldo[dst[u] + 3] = v[u].w; }
+        }
+      } else if (p.dvec == 2) {   // OW % 2 == 0, 8 B aligned (42-wide layers): float2 stream, never across a row
+        const int per2 = per >> 1, tot2 = p.Cout * per2;
+        for (int i0 = threadIdx.x; i0 < tot2; i0 += 256 * STAGE_U) {
+          float2 v[STAGE_U];
+          int dst[STAGE_U];
+#pragma unroll
+          for (int u = 0; u < STAGE_U; ++u) {
+            const int idx = i0 + u * 256;
+            dst[u] = -1;
+            v[u] = make_float2(0.f, 0.f);
+            if (idx < tot2) {
+              const int co = idx / per2, e = (idx - co * per2) << 1;
+              const int r = e / p.OW, x = e - r * p.OW;
+              dst[u] = co * p.PLANEo + r * p.OWp + x;
+              v[u] = *reinterpret_cast<const float2*>(dsrc + (long)co * p.OH * p.OW + e);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < STAGE_U; ++u)
+            if (dst[u] >= 0) { ldo[dst[u]] = v[u].x; ldo[dst[u] + 1] = v[u].y; }
         }
       } else {
       const int tot = p.Cout * per;
@@ -2364,7 +2385,7 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
   p.Cout = d->Cout; p.K = d->Cin * d->ks * d->ks; p.ks = d->ks; p.OH = d->OH; p.OW = d->OW; p.OWp = pl.OWp;
   p.S = d->stride; p.sy0 = pl.t.sy0; p.TPH = pl.t.TPH; p.tiles = pl.t.tiles; p.B = B;
   p.PLANEo = pl.PLANEo; p.nkt = ceil_div(p.K, 16);
-  p.dvec = (d->OW % 4 == 0) && ((uintptr_t)dout % 16 == 0);
+  p.dvec = ((d->OW % 4 == 0) && ((uintptr_t)dout % 16 == 0)) ? 4 : ((d->OW % 2 == 0) && ((uintptr_t)dout % 8 == 0)) ? 2 : 0;
   if (pl.MT == 1 && pl.KTW == 1) launch_wgrad_t<1, 1>(p, pl.grid, pl.lds, st);
   else if (pl.MT == 1 && pl.KTW == 4) launch_wgrad_t<1, 4>(p, pl.grid, pl.lds, st);
   else if (pl.MT == 2 && pl.KTW == 4) launch_wgrad_t<2, 4>(p, pl.grid, pl.lds, st);

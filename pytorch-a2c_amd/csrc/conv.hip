@@ -35,7 +35,7 @@ static int env_kb(const char* name, int dflt_kb) {
 }
 // LDS per workgroup decides how many workgroups share a CU (160 KB): tunable for experiments
 #define IGEMM_LDS_BUDGET env_kb("A2C_IGEMM_LDS_KB", 64)
-#define WGRAD_LDS_BUDGET env_kb("A2C_WGRAD_LDS_KB", 76)
+#define WGRAD_LDS_BUDGET env_kb("A2C_WGRAD_LDS_KB", 48)   // 3 workgroups per CU: the tiled kernels stage synchronously and rely on neighbours for overlap (76 KB: -10..25 % on the 3x3 layers)
 constexpr int LDS_HARD_MAX = 160 * 1024;
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -80,7 +80,7 @@ __device__ __forceinline__ void store_tile(const Frag& f, float* __restrict__ S)
   }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool SKINNY>
 __global__ __launch_bounds__(256) void gemm_kernel(long M, long N, long K, const float* __restrict__ A, long lda,
                                                    const float* __restrict__ B, long ldb, float* __restrict__ C,
                                                    long ldc, const float* __restrict__ bias, int relu,
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(long M, long N, long K, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool rows0 = m0 + wr * 64 < M, rows1 = m0 + wr * 64 + 32 < M;
   Frag fa, fb;
   load_tile<A_KC>(fa, A, lda, m0, M, kbeg, kend, vecA);
   load_tile<B_KC>(fb, B, ldb, n0, N, kbeg, kend, vecB);
@@ -123,10 +124,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(long M, long N, long K, const
       const float a1 = As[(kk + lk) * LDA + wr * 64 + 32 + li];
       const float b0 = Bs[(kk + lk) * LDB + wc * 64 + li];
       const float b1 = Bs[(kk + lk) * LDB + wc * 64 + 32 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if (!SKINNY || rows0) {   // SKINNY (M <= 96, e.g. M = n_envs of a small rollout): wave-uniform skip of 32-row blocks that are all padding
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      }
+      if (!SKINNY || rows1) {
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -521,8 +526,12 @@ void launch_gemm(dim3 grid, hipStream_t st, long M, long N, long K, const float*
   const int vec_epi = slab == nullptr && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) &&
                       (!mask || (ldmask % 4 == 0 && (uintptr_t)mask % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0) &&
                       !getenv("A2C_GEMM_SCALAR_EPILOGUE");
-  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu,
-                     mask, ldmask, acc, kps, slab, vecA, vecB, vec_epi);
+  if (M <= 96)
+    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu,
+                       mask, ldmask, acc, kps, slab, vecA, vecB, vec_epi);
+  else
+    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu,
+                       mask, ldmask, acc, kps, slab, vecA, vecB, vec_epi);
 }
 }  // namespace
 

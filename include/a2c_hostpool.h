@@ -1,0 +1,100 @@
+/*
+ * a2c_hostpool.h -- C ABI of liba2c_hostpool.so: the HOST side of the rollout ingest
+ * (plain C, no HIP, no torch; env worker processes load it without touching the GPU).
+ *
+ * Reference structure it replaces: n_envs OS processes each stepping one gym env and writing its
+ * state / reward / done straight into shared tensors, one element at a time, across the
+ * host-device boundary (/root/reference/a2c/training.py:109-121, runner.py:199,208,222-226).
+ * Here env stepping stays on host CPUs (worker processes or threads), but every env talks to the
+ * MI355X through ONE region of pinned host memory (POSIX shared memory that the GPU process
+ * registers with hipHostRegister), laid out as
+ *
+ *     header | cmd[n_envs] | rec[n_envs] | frames[n_envs][frame_stride]
+ *
+ *   cmd[j]  8-byte granule written by the DEVICE (persistent rollout kernel, system-scope store) or
+ *           by the GPU process after a D2H copy:   (seq << 32) | (uint32) action
+ *           "perform env step number `seq` of env j with this action"  (runner.py:207-208)
+ *   rec[j]  8-byte granule written by the env WORKER after the step (release store, after the
+ *           frame bytes):   ((seq << 1 | done) << 32) | float_bits(reward)
+ *           "frame number `seq` is in frames[j]";  seq counts the env steps taken so far, frame 0 is
+ *           the frame of the initial env.reset() (done = 1: the frame stack restarts, utils.py:37-42).
+ *           `done` is the env's real done (the worker has already called env.reset() and stored the
+ *           reset observation, utils.py:36-38); the Pong override done = (rew != 0) of
+ *           runner.py:212-214 is applied on the device.
+ *   frames  the prepped observation (preprocessing.py), uint8 or fp32, one slot per env; a slot is
+ *           rewritten only after the device has published cmd for the next step, i.e. after it consumed it.
+ * One naturally aligned 8-byte store per hand-off, data and tag in the same granule: no flag can
+ * overtake its payload.  The device reads frames with system-scope (sc0 sc1) loads either directly
+ * from this memory (zero-copy ingest inside a2c_a3c_rollout) or after a hipMemcpyAsync of the
+ * frames block into HBM (memcpy ingest, a2c_frame_stack_push_u8 / a2c_a3c_step).
+ */
+#ifndef A2C_HOSTPOOL_H
+#define A2C_HOSTPOOL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A2C_POOL_MAGIC 0x4132435F504F4F4CULL /* "A2C_POOL" */
+#define A2C_POOL_VERSION 1
+#define A2C_POOL_IDLE 0     /* between rollouts: workers sleep-poll                    */
+#define A2C_POOL_ROLLOUT 1  /* a rollout is running: workers spin on their cmd granules */
+#define A2C_POOL_SHUTDOWN 2
+#define A2C_FRAME_U8 0
+#define A2C_FRAME_F32 1
+
+typedef struct {
+  uint64_t magic;
+  uint32_t version, n_envs, frame_bytes, frame_stride, frame_dtype, n_workers;
+  uint64_t off_cmd, off_rec, off_frames, total_bytes;
+  volatile uint32_t phase;          /* A2C_POOL_*                                            */
+  volatile uint32_t workers_ready;  /* workers that have published frame 0 of all their envs  */
+  volatile uint32_t worker_error;   /* 1 + id of a worker that died with an exception         */
+  volatile uint32_t ema_lock;
+  volatile double rew_ema;          /* runner.py:216: .99*ema + .01*episode reward            */
+  volatile uint64_t episodes;       /* finished episodes (all envs)                           */
+} a2c_pool_header;
+
+/* bytes of the region for n_envs envs with frame_bytes per frame (page aligned)             */
+size_t a2c_pool_bytes(int n_envs, int frame_bytes);
+/* format a zero-filled region (GPU process, before the workers attach); 0 or -1             */
+int a2c_pool_init(void *base, size_t bytes, int n_envs, int frame_bytes, int frame_dtype,
+                  int n_workers, double rew_ema0);
+/* 0 when base holds a formatted region                                                      */
+int a2c_pool_check(const void *base);
+void a2c_pool_set_phase(void *base, uint32_t phase);
+uint32_t a2c_pool_phase(const void *base);
+
+/* ---- worker side ---------------------------------------------------------------------- */
+/* Spin until one of the envs env0..env0+n-1 has cmd.seq == next_seq[i]; returns i, or -1 after
+ * spin_ns without one, or -2 when the phase is SHUTDOWN.  While the phase is IDLE the call sleeps
+ * between polls instead of spinning.                                                         */
+int a2c_pool_poll(void *base, int env0, int n, const uint32_t *next_seq, int64_t spin_ns);
+int32_t a2c_pool_action(const void *base, int env);
+/* a2c_pool_poll + a2c_pool_action in one call: *action = the action of the env returned              */
+int a2c_pool_take(void *base, int env0, int n, const uint32_t *next_seq, int64_t spin_ns,
+                  int32_t *action);
+/* frames[env] = frame (frame_bytes), then rec[env] = {seq, done, rew} with release order     */
+void a2c_pool_publish(void *base, int env, const void *frame, uint32_t seq, float rew, int done);
+/* episode finished with total reward ep_rew: ema = .99*ema + .01*ep_rew under a spin lock    */
+void a2c_pool_episode(void *base, double ep_rew);
+void a2c_pool_worker_ready(void *base);
+void a2c_pool_worker_failed(void *base, int worker_id);
+
+/* ---- GPU-process side (memcpy ingest: the host relays actions and records) -------------- */
+/* cmd[env0+i] = (seq << 32) | actions[i*stride]                                              */
+void a2c_pool_post_actions(void *base, int env0, int n, const int64_t *actions, int64_t stride,
+                           uint32_t seq);
+/* wait until rec.seq == seq for all envs env0..env0+n-1: 0, or -1 on timeout, -3 on worker error */
+int a2c_pool_wait_frames(void *base, int env0, int n, uint32_t seq, int64_t timeout_ns);
+/* unpack rec[env0..] into rew[i], done[i] (floats, e.g. a pinned staging buffer)             */
+void a2c_pool_unpack(const void *base, int env0, int n, float *rew, float *done);
+double a2c_pool_rew_ema(const void *base);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A2C_HOSTPOOL_H */

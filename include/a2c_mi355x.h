@@ -36,7 +36,7 @@ extern "C" {
 
 typedef void *a2c_stream_t;   /* hipStream_t */
 
-int a2c_version(void);                 /* ABI version, currently 1 */
+int a2c_version(void);                 /* ABI version, currently 2 */
 const char *a2c_error_string(int code);
 
 /* ------------------------------------------------------------------ a5 / a7: scans
@@ -73,6 +73,12 @@ int a2c_add(const float *a, const float *b, float *y, int64_t n, a2c_stream_t st
 int a2c_frame_stack_push(const float *frame_new, const float *reset_mask, const float *prev,
                          int64_t prev_stride, float *out, int64_t out_stride, int B, int C,
                          int HW, a2c_stream_t stream);
+/* The same with the new frame as UINT8 pixels (the host pool's transport format: pong_prep,
+ * preprocessing.py:11-17, yields uint8; runner.py:199 `FloatTensor(state)` is the expansion):
+ * frame_u8[b*frame_stride + i], i < HW, frame_stride in bytes (% 4 == 0); HW % 4 == 0.     */
+int a2c_frame_stack_push_u8(const uint8_t *frame_u8, int64_t frame_stride, const float *reset_mask,
+                            const float *prev, int64_t prev_stride, float *out, int64_t out_stride,
+                            int B, int C, int HW, a2c_stream_t stream);
 
 /* ------------------------------------------------------------------ a2: sampler
  * SequentialEnvironment.get_action discrete branch (runner.py:94-97) + utils.sample_action
@@ -105,6 +111,12 @@ int a2c_rollout_post(const float *rew, const float *done, const float *val, int6
                      int64_t t, int64_t slot0, float gamma, int pong, const float *frame_new,
                      const float *reset_mask, const float *prev, int64_t prev_stride, float *out,
                      int64_t out_stride, int B, int C, int HW, a2c_stream_t stream);
+int a2c_rollout_post_u8(const float *rew, const float *done, const float *val, int64_t val_stride,
+                        float *val_prev, float *rewards, float *dones, float *deltas, int64_t T,
+                        int64_t t, int64_t slot0, float gamma, int pong, const uint8_t *frame_u8,
+                        int64_t frame_stride, const float *reset_mask, const float *prev,
+                        int64_t prev_stride, float *out, int64_t out_stride, int B, int C, int HW,
+                        a2c_stream_t stream);
 /* End of slot (runner.py:236-245): e = slot*T + T-1; if dones[e] == 0:
  * rewards[e] += gamma*val_boot[b], dones[e] = 1; then deltas[e] = rewards[e] - val_prev[b]. */
 int a2c_rollout_bootstrap(const float *val_boot, int64_t val_stride, const float *val_prev, float *rewards,
@@ -142,9 +154,62 @@ typedef struct {
   int64_t T, t_rec, slot0;
   float gamma;
   int pong, bootstrap;
+  const uint8_t *frame_u8;         /* instead of frame_new: uint8 frame (B, frame_stride bytes), */
+  int64_t frame_stride;            /* e.g. the pool's frames block after its H2D copy            */
 } a2c_a3c_step_args;
 int a2c_a3c_step_supported(int C, int H, int W, int n_actions);
 int a2c_a3c_step(const a2c_a3c_step_args *args, a2c_stream_t stream);
+
+/* A WHOLE rollout slot of the A3CModel-shaped policy -- all n_tsteps iterations of the loop of
+ * Runner.rollout (runner.py:198-232) plus the bootstrap (runner.py:236-245) for B envs -- in ONE
+ * persistent launch that talks to the host env workers directly through the pinned pool region
+ * (include/a2c_hostpool.h), with no host code and no kernel boundary between steps:
+ *   iteration t of env b (one workgroup per env, workgroups of several envs take turns):
+ *     t > 0: wait for rec[env0+b].seq == seq0+t, read reward/done from the granule and the uint8
+ *            frame straight from the pinned frames slot (system-scope loads over PCIe), record env
+ *            step t-1 exactly like a2c_a3c_step;  t == 0: the state is bookmark[b];
+ *     state -> states[(slot0+b)*T + t] (t == T: -> bookmark[b]); forward; 
+ *     t < T: sample with u[t*u_stride + b] -> actions[(slot0+b)*T + t], and publish
+ *            cmd[env0+b] = (seq0+t) << 32 | action with one 8-byte system-scope store: the worker
+ *            that owns the env steps it as soon as it sees the granule;  t == T: bootstrap.
+ * Results are identical to T+1 calls of a2c_a3c_step.  Every wait on the host is bounded by
+ * timeout_ticks (100 MHz ticks); on a timeout *err is set to 1 and the workgroup stops.
+ * Shapes as a2c_a3c_step_supported, uint8 frames, (H*W) % 16 == 0.                          */
+typedef struct {
+  int B, C, H, W, n_actions;
+  float *states;                   /* rollout buffer, rows of S = C*H*W floats                */
+  float *bookmark;                 /* (B, S)                                                  */
+  const float *wfrag1, *bias1, *wfrag2, *bias2, *Wc, *bc;
+  float *heads; int64_t ldh;
+  const float *u; int64_t u_stride;
+  int64_t *actions;
+  float *val_prev, *rewards, *dones, *deltas;
+  int64_t T, slot0;
+  float gamma;
+  int pong;
+  uint64_t *cmd;                   /* device-mapped pool arrays (a2c_rollout_buffer_create)   */
+  const uint64_t *rec;
+  const uint8_t *frames; int64_t frame_stride;
+  uint32_t seq0;                   /* env steps every env has taken before this slot          */
+  int env0;                        /* pool index of env b is env0 + b                         */
+  int *err;                        /* device int                                              */
+  int64_t timeout_ticks;
+} a2c_a3c_rollout_args;
+int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
+
+/* ------------------------------------------------------------------ b: pinned staging
+ * The pool region lives in POSIX shared memory (shm_open name `shm_name`, created by this call)
+ * so that env worker processes can map it; it is pinned and mapped into the device's address
+ * space with hipHostRegister (no copy): *host_out = the mapping in this process, *dev_out = the
+ * address kernels and hipMemcpyAsync use.  Replaces the reference's share_memory_() tensors
+ * (training.py:93-101) for the data that crosses the host-device boundary every env step.     */
+int a2c_rollout_buffer_create(const char *shm_name, size_t bytes, void **host_out, void **dev_out);
+int a2c_rollout_buffer_destroy(const char *shm_name, void *host, size_t bytes);
+/* pin + map an existing host range (page aligned) / undo it                                  */
+int a2c_pinned_register(void *host, size_t bytes, void **dev_out);
+int a2c_pinned_unregister(void *host);
+/* hipMemcpyAsync on `stream`: kind 1 = host->device, 2 = device->host, 3 = device->device      */
+int a2c_memcpy_async(void *dst, const void *src, size_t bytes, int kind, a2c_stream_t stream);
 /* dst[b*dst_stride + j] = src[b*src_stride + j], j < n  (h_states[e] = h, runner.py:201;
  * gathers/scatters of per-step rows of the rollout-major buffers)                       */
 int a2c_copy_rows(const float *src, int64_t src_stride, float *dst, int64_t dst_stride, int B,

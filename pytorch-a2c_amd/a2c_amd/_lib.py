@@ -6,7 +6,7 @@ non-CUDA tensor, this module raises.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liba2c_mi355x.so")
@@ -31,10 +31,23 @@ class A3CStepArgs(Structure):
                 ("heads", P), ("ldh", c_int64), ("u", P), ("actions", P), ("act_stride", c_int64),
                 ("rew", P), ("done", P), ("val_prev", P), ("rewards", P), ("dones", P), ("deltas", P),
                 ("T", c_int64), ("t_rec", c_int64), ("slot0", c_int64), ("gamma", c_float),
-                ("pong", c_int), ("bootstrap", c_int)]
+                ("pong", c_int), ("bootstrap", c_int), ("frame_u8", P), ("frame_stride", c_int64)]
+
+
+class A3CRolloutArgs(Structure):
+    """a2c_a3c_rollout_args"""
+    _fields_ = [("B", c_int), ("C", c_int), ("H", c_int), ("W", c_int), ("n_actions", c_int),
+                ("states", P), ("bookmark", P),
+                ("wfrag1", P), ("bias1", P), ("wfrag2", P), ("bias2", P), ("Wc", P), ("bc", P),
+                ("heads", P), ("ldh", c_int64), ("u", P), ("u_stride", c_int64), ("actions", P),
+                ("val_prev", P), ("rewards", P), ("dones", P), ("deltas", P),
+                ("T", c_int64), ("slot0", c_int64), ("gamma", c_float), ("pong", c_int),
+                ("cmd", P), ("rec", P), ("frames", P), ("frame_stride", c_int64),
+                ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64)]
 
 
 PS = POINTER(A3CStepArgs)
+PR = POINTER(A3CRolloutArgs)
 
 # name -> (restype, argtypes); one entry per prototype in include/a2c_mi355x.h
 SIGNATURES = {
@@ -46,12 +59,15 @@ SIGNATURES = {
     "a2c_normalize": (c_int, [P, P, c_int64, P, c_int64, c_float, P]),
     "a2c_add": (c_int, [P, P, P, c_int64, P]),
     "a2c_frame_stack_push": (c_int, [P, P, P, c_int64, P, c_int64, c_int, c_int, c_int, P]),
+    "a2c_frame_stack_push_u8": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int, c_int, P]),
     "a2c_softmax_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int, c_int, P]),
     "a2c_sample_probs": (c_int, [P, P, P, c_int64, c_int, P]),
     "a2c_rollout_record": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_int64, c_int64, c_int64,
                                     c_float, c_int, P]),
     "a2c_rollout_post": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_int, P, P, P, c_int64,
                                   P, c_int64, c_int, c_int, c_int, P]),
+    "a2c_rollout_post_u8": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_int, P, c_int64, P, P,
+                                     c_int64, P, c_int64, c_int, c_int, c_int, P]),
     "a2c_rollout_bootstrap": (c_int, [P, c_int64, P, P, P, P, c_int, c_int64, c_int64, c_float, P]),
     "a2c_copy_rows": (c_int, [P, c_int64, P, c_int64, c_int, c_int64, P]),
     "a2c_mask_rows": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P]),
@@ -75,6 +91,12 @@ SIGNATURES = {
     "a2c_compose_heads": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "a2c_a3c_step_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "a2c_a3c_step": (c_int, [PS, P]),
+    "a2c_a3c_rollout": (c_int, [PR, P]),
+    "a2c_rollout_buffer_create": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_void_p)]),
+    "a2c_rollout_buffer_destroy": (c_int, [c_char_p, P, c_size_t]),
+    "a2c_pinned_register": (c_int, [P, c_size_t, POINTER(c_void_p)]),
+    "a2c_pinned_unregister": (c_int, [P]),
+    "a2c_memcpy_async": (c_int, [P, P, c_size_t, c_int, P]),
     "a2c_conv2d_prep_weights": (c_int, [PD, c_int, P, P, P]),
     "a2c_conv2d_fwd": (c_int, [PD, P, c_int64, P, P, c_int, P, c_int64, c_int, P]),
     "a2c_conv2d_bwd_data": (c_int, [PD, P, P, P, P, c_int, P]),

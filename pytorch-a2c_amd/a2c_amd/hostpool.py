@@ -1,0 +1,305 @@
+"""Parallel host env pool: env stepping on host CPUs, one region of pinned host memory between
+the env workers and the MI355X (C layout and protocol: include/a2c_hostpool.h).
+
+Reference: ``n_envs`` OS processes, each with its own gym env, each writing its state / reward /
+done into shared tensors element by element (training.py:109-121, runner.py:199,208,222-226).
+Here ``n_workers`` worker PROCESSES (``python -m a2c_amd.hostpool_worker``; numpy + ctypes only, they
+never touch the GPU runtime) each own a contiguous block of envs.  A worker spins on the 8-byte
+``cmd`` granule of each of its envs, steps the env with the action found there, writes the prepped
+frame (uint8 when the preprocessor yields uint8 -- ``pong_prep`` does --, else fp32) into the env's
+slot of the shared pinned region and publishes an 8-byte ``rec`` granule {step count, done, reward}.
+Who writes ``cmd`` and who reads the frames depends on the ingest mode of the ``Runner``:
+
+  zero-copy  the persistent rollout kernel (a2c_a3c_rollout) itself: it stores the sampled action
+             into ``cmd`` and loads the frame straight from the pinned region over PCIe -- the host
+             process is not in the loop at all during a rollout;
+  memcpy     the GPU process: D2H of the actions -> ``post_actions`` -> ``wait_frames`` ->
+             hipMemcpyAsync of the frames block into HBM.
+
+This module imports neither torch nor the HIP library at import time (workers import it).
+"""
+import ctypes
+import json
+import mmap
+import os
+import pickle
+import subprocess
+import sys
+import time
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+POOL_LIB_PATH = os.path.join(_HERE, "liba2c_hostpool.so")
+IDLE, ROLLOUT, SHUTDOWN = 0, 1, 2
+FRAME_U8, FRAME_F32 = 0, 1
+
+
+class PoolHeader(Structure):
+    """a2c_pool_header"""
+    _fields_ = [("magic", c_uint64), ("version", c_uint32), ("n_envs", c_uint32), ("frame_bytes", c_uint32),
+                ("frame_stride", c_uint32), ("frame_dtype", c_uint32), ("n_workers", c_uint32),
+                ("off_cmd", c_uint64), ("off_rec", c_uint64), ("off_frames", c_uint64), ("total_bytes", c_uint64),
+                ("phase", c_uint32), ("workers_ready", c_uint32), ("worker_error", c_uint32), ("ema_lock", c_uint32),
+                ("rew_ema", c_double), ("episodes", c_uint64)]
+
+
+P = c_void_p
+POOL_SIGNATURES = {   # one entry per prototype in include/a2c_hostpool.h
+    "a2c_pool_bytes": (c_size_t, [c_int, c_int]),
+    "a2c_pool_init": (c_int, [P, c_size_t, c_int, c_int, c_int, c_int, c_double]),
+    "a2c_pool_check": (c_int, [P]),
+    "a2c_pool_set_phase": (None, [P, c_uint32]),
+    "a2c_pool_phase": (c_uint32, [P]),
+    "a2c_pool_poll": (c_int, [P, c_int, c_int, P, c_int64]),
+    "a2c_pool_action": (c_int32, [P, c_int]),
+    "a2c_pool_take": (c_int, [P, c_int, c_int, P, c_int64, P]),
+    "a2c_pool_publish": (None, [P, c_int, P, c_uint32, c_float, c_int]),
+    "a2c_pool_episode": (None, [P, c_double]),
+    "a2c_pool_worker_ready": (None, [P]),
+    "a2c_pool_worker_failed": (None, [P, c_int]),
+    "a2c_pool_post_actions": (None, [P, c_int, c_int, P, c_int64, c_uint32]),
+    "a2c_pool_wait_frames": (c_int, [P, c_int, c_int, c_uint32, c_int64]),
+    "a2c_pool_unpack": (None, [P, c_int, c_int, P, P]),
+    "a2c_pool_rew_ema": (c_double, [P]),
+}
+_pool_lib = None
+
+
+def pool_lib():
+    global _pool_lib
+    if _pool_lib is None:
+        if not os.path.exists(POOL_LIB_PATH):
+            raise ImportError(f"{POOL_LIB_PATH} not found: run make -C pytorch-a2c_amd/csrc (or __graft_entry__.build())")
+        lib = ctypes.CDLL(POOL_LIB_PATH)
+        for name, (res, args) in POOL_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _pool_lib = lib
+    return _pool_lib
+
+
+def shm_path(name):
+    return os.path.join("/dev/shm", name)
+
+
+class Region:
+    """A mapped pool region (creator or attached worker): numpy views of cmd / rec / frames."""
+
+    def __init__(self, name, create_bytes=0):
+        self.name = name
+        path = shm_path(name)
+        if create_bytes:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            os.ftruncate(fd, create_bytes)
+        else:
+            fd = os.open(path, os.O_RDWR)
+        try:
+            self.size = os.fstat(fd).st_size
+            self.mm = mmap.mmap(fd, self.size)
+        finally:
+            os.close(fd)
+        self._buf = (ctypes.c_char * self.size).from_buffer(self.mm)
+        self.base = ctypes.addressof(self._buf)
+        self.created = bool(create_bytes)
+
+    def bind(self):
+        """views that need a formatted header"""
+        h = self.header = PoolHeader.from_buffer(self.mm)
+        arr = np.frombuffer(self.mm, dtype=np.uint8)
+        n = h.n_envs
+        self.cmd = arr[h.off_cmd:h.off_cmd + 8 * n].view(np.uint64)
+        self.rec = arr[h.off_rec:h.off_rec + 8 * n].view(np.uint64)
+        self.frames = arr[h.off_frames:h.off_frames + n * h.frame_stride].reshape(n, h.frame_stride)
+        return self
+
+    def close(self, unlink=False):
+        for k in ("cmd", "rec", "frames", "header", "_buf"):
+            self.__dict__.pop(k, None)
+        try:
+            self.mm.close()
+        except BufferError:      # a numpy view is still alive somewhere: leave the mapping to process exit
+            pass
+        if unlink:
+            try:
+                os.unlink(shm_path(self.name))
+            except FileNotFoundError:
+                pass
+
+
+def _dump_spec(spec):
+    try:
+        import cloudpickle
+        return cloudpickle.dumps(spec)
+    except Exception:      # noqa: BLE001
+        return pickle.dumps(spec)
+
+
+class ProcessEnvPool:
+    """``n_envs`` host envs stepped by ``n_workers`` processes behind one pinned region.
+
+    env_factory(**env_kwargs[j]) -> object with ``reset() -> obs`` and ``step(a) -> (obs, rew, done, info)``
+    returning already prepped frames of shape (1, H, W) / (1, L) (what SequentialEnvironment returns).
+    ``action_shift`` / ``pong`` are the hyps of runner.py:208,212-214 (the Pong done override only affects
+    the episode-reward EMA here; the device applies it to the ``dones`` buffer).
+    """
+
+    device_pool = False
+
+    def __init__(self, env_factory, n_envs, env_kwargs=None, n_workers=None, action_shift=0, pong=False,
+                 frame_shape=None, frame_dtype=None, rew_ema0=-1.0, register=True, spin=True, sys_path=None,
+                 probe_reset=False):
+        self.env_factory, self.n_envs = env_factory, int(n_envs)
+        self.env_kwargs = list(env_kwargs) if env_kwargs is not None else [dict() for _ in range(n_envs)]
+        assert len(self.env_kwargs) == self.n_envs
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if n_workers is None:
+            n_workers = max(1, min(self.n_envs, int(os.environ.get("A2C_ENV_WORKERS", "0")) or min(32, max(1, cores // 2))))
+        self.n_workers = int(n_workers)
+        self.action_shift, self.pong = int(action_shift), bool(pong)
+        # raw env objects: one extra reset() per env right after construction, which is what the reference's
+        # SequentialEnvironment.__init__ does to read raw_shape (runner.py:45); wrappers that already do it pass False
+        self.probe_reset = bool(probe_reset)
+        if frame_shape is None or frame_dtype is None:
+            # one probing env, like training.py:60-65 reads the observation shape from StatsRunner's env
+            obs = np.asarray(env_factory(**self.env_kwargs[0]).reset())
+            frame_shape = obs.shape if frame_shape is None else frame_shape
+            frame_dtype = obs.dtype if frame_dtype is None else frame_dtype
+        self.frame_shape = tuple(int(s) for s in frame_shape)
+        self.frame_dtype = np.dtype(np.uint8 if np.dtype(frame_dtype) in (np.dtype(np.uint8), np.dtype(bool)) else np.float32)
+        self.frame_bytes = int(np.prod(self.frame_shape)) * self.frame_dtype.itemsize
+        self.rew_ema0, self.register, self.spin = float(rew_ema0), bool(register), bool(spin)
+        self.sys_path = list(sys_path) if sys_path is not None else [p for p in sys.path if p]
+        self.region = None
+        self.procs = []
+        self.dev_ptr = 0
+        self.seq = 0            # env steps requested so far (same for every env: lock-step slots)
+
+    def __len__(self):
+        return self.n_envs
+
+    # ------------------------------------------------------------------ life cycle
+    def start(self, timeout=300.0):
+        if self.region is not None:
+            return self
+        lib = pool_lib()
+        nbytes = lib.a2c_pool_bytes(self.n_envs, self.frame_bytes)
+        self.name = f"a2c_pool_{os.getpid()}_{id(self) & 0xffffff:x}_{int(time.time() * 1e3) & 0xffffff:x}"
+        reg = self.region = Region(self.name, create_bytes=nbytes)
+        dt = FRAME_U8 if self.frame_dtype == np.uint8 else FRAME_F32
+        if lib.a2c_pool_init(reg.base, nbytes, self.n_envs, self.frame_bytes, dt, self.n_workers, self.rew_ema0):
+            raise RuntimeError("a2c_pool_init failed")
+        reg.bind()
+        if self.register:       # pin + map into the GPU's address space (no copy): hipHostRegister
+            from . import ops
+            self.dev_ptr = ops.pinned_register(reg.base, nbytes)
+        per = -(-self.n_envs // self.n_workers)
+        blocks = [(w, w * per, min(per, self.n_envs - w * per)) for w in range(self.n_workers) if w * per < self.n_envs]
+        self.n_workers = len(blocks)
+        reg.header.n_workers = self.n_workers
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join(self.sys_path + [os.environ.get("PYTHONPATH", "")]))
+        for w, e0, n in blocks:
+            spec = dict(shm=self.name, worker=w, env0=e0, n=n, factory=self.env_factory,
+                        env_kwargs=self.env_kwargs[e0:e0 + n], action_shift=self.action_shift, pong=self.pong,
+                        frame_shape=self.frame_shape, frame_dtype=self.frame_dtype.str, parent=os.getpid(),
+                        probe_reset=self.probe_reset)
+            p = subprocess.Popen([sys.executable, "-m", "a2c_amd.hostpool_worker"], stdin=subprocess.PIPE, env=env)
+            p.stdin.write(_dump_spec(spec))
+            p.stdin.close()
+            self.procs.append(p)
+        t0 = time.time()
+        while reg.header.workers_ready < self.n_workers:
+            self._check_workers()
+            if time.time() - t0 > timeout:
+                self.close()
+                raise TimeoutError("env workers did not come up")
+            time.sleep(0.005)
+        if not self.spin:
+            self.set_phase(IDLE)
+        return self
+
+    def _check_workers(self):
+        h = self.region.header
+        if h.worker_error:
+            raise RuntimeError(f"env worker {h.worker_error - 1} died with an exception (see its stderr)")
+        for p in self.procs:
+            if p.poll() is not None:
+                raise RuntimeError(f"env worker pid {p.pid} exited with code {p.returncode}")
+
+    def close(self):
+        reg = self.region
+        if reg is None:
+            return
+        pool_lib().a2c_pool_set_phase(reg.base, SHUTDOWN)
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        self.procs = []
+        if self.dev_ptr:
+            from . import ops
+            ops.pinned_unregister(reg.base)
+            self.dev_ptr = 0
+        reg.close(unlink=True)
+        self.region = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass
+
+    # ------------------------------------------------------------------ GPU-process side of the protocol
+    @property
+    def header(self):
+        return self.region.header
+
+    def set_phase(self, phase):
+        pool_lib().a2c_pool_set_phase(self.region.base, phase)
+
+    def post_actions(self, actions, env0=0, seq=None):
+        """cmd[env0+i] = (seq, actions[i]) -- actions: contiguous int64 numpy array (e.g. a pinned staging view)"""
+        a = np.ascontiguousarray(actions, dtype=np.int64)
+        pool_lib().a2c_pool_post_actions(self.region.base, env0, a.shape[0], a.ctypes.data, 1, self.seq if seq is None else seq)
+
+    def wait_frames(self, seq, env0=0, n=None, timeout=30.0):
+        rc = pool_lib().a2c_pool_wait_frames(self.region.base, env0, self.n_envs - env0 if n is None else n, seq,
+                                             int(timeout * 1e9))
+        if rc == -3:
+            self._check_workers()
+            raise RuntimeError("an env worker failed")
+        if rc:
+            self._check_workers()
+            raise TimeoutError(f"env workers did not deliver frame {seq} within {timeout}s")
+
+    def unpack(self, rew, done, env0=0):
+        """rec -> float32 numpy arrays rew[i], done[i] (real done = reset flag)"""
+        pool_lib().a2c_pool_unpack(self.region.base, env0, rew.shape[0], rew.ctypes.data, done.ctypes.data)
+
+    def rew_ema(self):
+        return pool_lib().a2c_pool_rew_ema(self.region.base)
+
+    def frames_view(self):
+        """(n_envs, *frame_shape) numpy view of the current frames (no copy)"""
+        f = self.region.frames[:, :self.frame_bytes]
+        return f.view(self.frame_dtype).reshape((self.n_envs,) + self.frame_shape)
+
+    # device addresses inside the registered region (zero-copy ingest)
+    @property
+    def dev_cmd(self):
+        return self.dev_ptr + self.header.off_cmd
+
+    @property
+    def dev_rec(self):
+        return self.dev_ptr + self.header.off_rec
+
+    @property
+    def dev_frames(self):
+        return self.dev_ptr + self.header.off_frames
+
+    def describe(self):
+        h = self.header
+        return json.dumps(dict(n_envs=h.n_envs, n_workers=h.n_workers, frame_bytes=h.frame_bytes,
+                               frame_dtype="u8" if h.frame_dtype == FRAME_U8 else "f32"))

@@ -155,6 +155,12 @@ def frame_stack_push(frame_new, reset_mask, prev_ptr, prev_stride, out_ptr, out_
                                      B, C, HW, st if st is not None else stream()), "a2c_frame_stack_push")
 
 
+def frame_stack_push_u8(frame_u8_ptr, frame_stride, reset_mask, prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW, st=None):
+    """frame_stack_push with the new frame as uint8 pixels at frame_u8_ptr + b*frame_stride (device address)"""
+    check(lib().a2c_frame_stack_push_u8(frame_u8_ptr, frame_stride, _p(reset_mask), prev_ptr, prev_stride, out_ptr,
+                                        out_stride, B, C, HW, st if st is not None else stream()), "a2c_frame_stack_push_u8")
+
+
 def softmax_sample(logits, u, actions_ptr, act_stride, B, A, probs=None, st=None):
     _chk(logits, "logits", contig=False); _chk(u, "u")
     check(lib().a2c_softmax_sample(_p(logits), logits.stride(0), _p(u), actions_ptr, act_stride, _p(probs), B, A,
@@ -185,6 +191,14 @@ def rollout_post(rew, done, val_ptr, val_stride, val_prev, rewards, dones, delta
                                  st if st is not None else stream()), "a2c_rollout_post")
 
 
+def rollout_post_u8(rew, done, val_ptr, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma, pong, frame_u8_ptr,
+                    frame_stride, reset_mask, prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW, st=None):
+    check(lib().a2c_rollout_post_u8(_p(rew), _p(done), val_ptr, val_stride, _p(val_prev), _p(rewards), _p(dones),
+                                    _p(deltas), T, t, slot0, float(gamma), int(bool(pong)), frame_u8_ptr, frame_stride,
+                                    _p(reset_mask), prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW,
+                                    st if st is not None else stream()), "a2c_rollout_post_u8")
+
+
 def compose_heads(Wh, bh, Wp, bp, Wc, bc, st=None):
     """Wc = Wh . Wp, bc = Wh . bp + bh (inference-only composition of two activation-free linear layers)"""
     for t, n in ((Wh, "Wh"), (bh, "bh"), (Wp, "Wp"), (bp, "bp"), (Wc, "Wc"), (bc, "bc")):
@@ -206,6 +220,34 @@ def a3c_step(st=None, **kw):
     for k, v in kw.items():
         setattr(args, k, v)
     check(lib().a2c_a3c_step(ctypes.byref(args), st if st is not None else stream()), "a2c_a3c_step")
+
+
+def a3c_rollout(st=None, **kw):
+    """A whole rollout slot in one persistent launch fed by the host env pool (a2c_a3c_rollout in the header).
+    Keyword arguments are the fields of a2c_a3c_rollout_args."""
+    args = _lib.A3CRolloutArgs()
+    for k, v in kw.items():
+        setattr(args, k, v)
+    check(lib().a2c_a3c_rollout(ctypes.byref(args), st if st is not None else stream()), "a2c_a3c_rollout")
+
+
+# ---------------------------------------------------------------- pinned staging / async copies
+def pinned_register(host_addr, nbytes):
+    """hipHostRegister(mapped): pins [host_addr, +nbytes) and returns the device address of the range"""
+    dev = ctypes.c_void_p()
+    check(lib().a2c_pinned_register(host_addr, nbytes, ctypes.byref(dev)), "a2c_pinned_register")
+    return int(dev.value)
+
+
+def pinned_unregister(host_addr):
+    check(lib().a2c_pinned_unregister(host_addr), "a2c_pinned_unregister")
+
+
+H2D, D2H, D2D = 1, 2, 3
+
+
+def memcpy_async(dst_ptr, src_ptr, nbytes, kind, st=None):
+    check(lib().a2c_memcpy_async(dst_ptr, src_ptr, nbytes, kind, st if st is not None else stream()), "a2c_memcpy_async")
 
 
 def rollout_bootstrap(val_ptr, val_stride, val_prev, rewards, dones, deltas, B, T, slot0, gamma, st=None):

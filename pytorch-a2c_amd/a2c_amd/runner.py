@@ -10,9 +10,19 @@ write the step's rows of the rollout-major buffers (frame stack -> ``states``, r
 TD deltas, ``h_states``).  The ``shared_data`` layout (training.py:88-101) and the gate/stop
 queue protocol are unchanged, so ``Updater`` and a ``train()``-style driver see the same data.
 
-An env pool may instead be *device resident* (``DeviceEnvPool`` protocol: frames / rewards /
-dones already in HBM, e.g. the synthetic benchmark env); then a whole n_tsteps rollout is
-enqueued without a single host synchronisation and can be captured into one hipGraph.
+Env pools (``env_pool=``):
+  * ``hostpool.ProcessEnvPool`` -- the production path: env worker PROCESSES behind one pinned,
+    device-mapped region (include/a2c_hostpool.h), frames travel as uint8 when the preprocessor
+    yields uint8.  Two ingest modes (``hyps['ingest']`` or ``Runner(..., ingest=)``):
+      "zero-copy"  (A3CModel-shaped nets, uint8 frames) the whole slot is ONE persistent launch
+                   (a2c_a3c_rollout): workgroups and env workers hand actions / frames to each other
+                   through the pinned region, the host process is not in the loop;
+      "memcpy"     (every model) per step: actions D2H -> workers step -> hipMemcpyAsync of the
+                   frames block from the pinned region into HBM -> the step kernels.
+  * ``HostEnvPool`` -- B env objects stepped serially in this process (tests, tiny runs).
+  * a *device resident* pool (``device_step`` protocol: frames / rewards / dones already in HBM,
+    e.g. a synthetic tape): a whole n_tsteps rollout is enqueued without a single host
+    synchronisation and can be captured into one hipGraph.
 """
 import os
 import time
@@ -93,30 +103,48 @@ class HostEnvPool:
         return np.asarray(obs), float(rew), bool(done)
 
 
+class _Frames:
+    """Where the new frames of one env step are on the device: fp32 (B, HW) or uint8 (B, stride bytes)."""
+    __slots__ = ("ptr32", "ptr8", "stride")
+
+    def __init__(self, ptr32=0, ptr8=0, stride=0):
+        self.ptr32, self.ptr8, self.stride = ptr32, ptr8, stride
+
+
 class Runner:
     """Collects rollouts for ALL envs of this process into ``datas`` (reference signature:
     runner.py:110).  ``datas`` tensors should live on the device (``cuda_if`` them like
     training.py:94-101); ``actions`` may stay a host LongTensor like the reference's."""
 
-    def __init__(self, datas, hyps, gate_q, stop_q, rew_q, env_pool=None, uniform_fn=None):
+    def __init__(self, datas, hyps, gate_q, stop_q, rew_q, env_pool=None, uniform_fn=None, ingest=None):
         self.hyps, self.datas = hyps, datas
         self.gate_q, self.stop_q, self.rew_q = gate_q, stop_q, rew_q
         self.obs_deque = deque(maxlen=hyps["n_frame_stack"])     # kept for API parity (single-env helpers)
         self.env_pool = env_pool
         self.uniform_fn = uniform_fn          # (t, B) -> device tensor (B,) of uniforms; default torch.rand
+        self.ingest = ingest or try_key(hyps, "ingest", None)     # None: zero-copy when it applies, else memcpy
         self._ready = False
+        self.error = None                     # exception that ended run() (training.train re-raises it)
 
     # ------------------------------------------------------------------ set-up (body of run())
     def _make_pool(self):
+        """n_envs gym envs like the reference's n_envs processes (training.py:109-121): worker processes
+        behind the pinned pool region; ``hyps['env_pool'] == 'serial'`` keeps them in this process."""
         hyps = self.hyps
         n = int(try_key(hyps, "n_envs", 1))
-        envs = []
+        kws = []
         for j in range(n):
-            kw = dict(hyps)
+            kw = {k: v for k, v in hyps.items() if k not in ("seed",)}
             kw["seed"] = try_key(hyps, "seed", 0) + j
-            envs.append(SequentialEnvironment(**kw))
-        shape = np.asarray(envs[0].prep_obs(np.zeros(envs[0].raw_shape, dtype=np.uint8))).shape
-        return HostEnvPool(envs, frame_shape=shape)
+            kws.append(kw)
+        if try_key(hyps, "env_pool", "process") == "serial":
+            envs = [SequentialEnvironment(**kw) for kw in kws]
+            shape = np.asarray(envs[0].prep_obs(np.zeros(envs[0].raw_shape, dtype=np.uint8))).shape
+            return HostEnvPool(envs, frame_shape=shape)
+        from .hostpool import ProcessEnvPool
+        return ProcessEnvPool(SequentialEnvironment, n, env_kwargs=kws, n_workers=try_key(hyps, "n_env_workers", None),
+                              action_shift=hyps["action_shift"], pong="Pong" in hyps["env_type"],
+                              rew_ema0=-1.0)
 
     def start(self, net):
         """Everything Runner.run does before its loop (runner.py:158-168), for all envs."""
@@ -134,6 +162,7 @@ class Runner:
         self.state_shape = (C,) + fshape[1:]
         self.S = C * self.HW
         self.device_pool = hasattr(pool, "device_step")
+        self.proc_pool = hasattr(pool, "post_actions")
         f32 = dict(dtype=torch.float32, device=dev)
         self.bookmark = torch.zeros((B, self.S), **f32)                  # state_bookmark of every env
         self.val_prev = torch.zeros(B, **f32)
@@ -141,18 +170,40 @@ class Runner:
         self.act_dev = torch.zeros(B, dtype=torch.int64, device=dev)
         self.h = torch.zeros((B, net.h_size), **f32) if net.is_recurrent else None   # h_bookmark
         self.ep_rew = np.zeros(B)
-        if not self.device_pool:
-            pin = torch.cuda.is_available()
-            mk = lambda *s, dt=torch.float32: (torch.zeros(*s, dtype=dt).pin_memory() if pin else torch.zeros(*s, dtype=dt))
+        pin = torch.cuda.is_available()
+        mk = lambda *s, dt=torch.float32: (torch.zeros(*s, dtype=dt).pin_memory() if pin else torch.zeros(*s, dtype=dt))
+        ones = torch.ones(B, **f32)
+        if self.proc_pool:
+            # worker processes behind the pinned region: frame 0 of every env (its env.reset()) is already there
+            pool.start()
+            self.h_rew, self.h_done, self.h_act = mk(B), mk(B), mk(B, dt=torch.int64)
+            self.np_rew, self.np_done, self.np_act = self.h_rew.numpy(), self.h_done.numpy(), self.h_act.numpy()
+            self.d_rew, self.d_done = torch.zeros(B, **f32), torch.zeros(B, **f32)
+            self.u8 = pool.frame_dtype == np.uint8
+            self.fstride = int(pool.header.frame_stride)
+            self.d_frames = torch.zeros((B, self.fstride), dtype=torch.uint8, device=dev)
+            self.rollout_err = torch.zeros(1, dtype=torch.int32, device=dev)
+            pool.set_phase(1)
+            pool.wait_frames(0)
+            fr = self._pool_frames_h2d(pool, 0, B, ops.stream())
+            if fr.ptr8:
+                ops.frame_stack_push_u8(fr.ptr8, fr.stride, ones, self.bookmark.data_ptr(), self.S, self.bookmark.data_ptr(),
+                                        self.S, B, C, self.HW)
+            else:
+                ops.frame_stack_push(_Ptr(fr.ptr32), ones, self.bookmark.data_ptr(), self.S, self.bookmark.data_ptr(), self.S,
+                                     B, C, self.HW)
+            torch.cuda.current_stream().synchronize()
+        elif not self.device_pool:
             self.h_frames, self.h_rew, self.h_done, self.h_reset = mk(B, self.HW), mk(B), mk(B), mk(B)
             self.h_act = mk(B, dt=torch.int64)
+            self.np_frames, self.np_rew, self.np_done, self.np_act = (x.numpy() for x in (self.h_frames, self.h_rew,
+                                                                                             self.h_done, self.h_act))
             self.d_frames = torch.zeros((B, self.HW), **f32)
             self.d_rew, self.d_done, self.d_reset = (torch.zeros(B, **f32) for _ in range(3))
             # initial state: next_state(reset=True) -> [0,..,0, env.reset()] (utils.py:37-42)
             for j in range(B):
-                self.h_frames[j] = torch.from_numpy(np.asarray(pool.reset(j), dtype=np.float32).reshape(-1))
+                self.np_frames[j] = np.asarray(pool.reset(j), dtype=np.float32).reshape(-1)
             self.d_frames.copy_(self.h_frames, non_blocking=True)
-            ones = torch.ones(B, **f32)
             ops.frame_stack_push(self.d_frames, ones, self.bookmark.data_ptr(), self.S, self.bookmark.data_ptr(), self.S,
                                  B, C, self.HW)
         else:
@@ -162,18 +213,52 @@ class Runner:
         self._ready = True
 
     def run(self, net):
-        """Entry point with the reference's protocol: wait on gate_q, roll out, answer on stop_q."""
-        self.start(net)
-        while True:
-            idxs = [self.gate_q.get()]
-            while len(idxs) < self.B:
+        """Entry point with the reference's protocol: wait on gate_q, roll out, answer on stop_q.
+        An exception ends the loop, is kept in ``self.error`` and is answered with ``None`` tokens on
+        stop_q so that the consumer wakes up (the reference's dead runner process deadlocks its
+        ``stop_q.get()`` forever)."""
+        try:
+            self.start(net)
+            while True:
+                idxs = [self.gate_q.get()]
+                if idxs[0] is None:        # shutdown token
+                    return
+                while len(idxs) < self.B:
+                    try:
+                        idxs.append(self.gate_q.get_nowait())
+                    except Exception:
+                        break
+                self.rollout(net, sorted(idxs), self.hyps)
+                self.finish()
+                for i in idxs:
+                    self.stop_q.put(i)
+        except BaseException as e:      # noqa: BLE001
+            self.error = e
+            for _ in range(int(try_key(self.hyps, "n_rollouts", 1))):
                 try:
-                    idxs.append(self.gate_q.get_nowait())
-                except Exception:
+                    self.stop_q.put_nowait(None)
+                except Exception:      # noqa: BLE001
                     break
-            self.rollout(net, sorted(idxs), self.hyps)
-            for i in idxs:
-                self.stop_q.put(i)
+            raise
+
+    def finish(self):
+        """Wait for the enqueued rollout work, surface a host-handshake timeout of the persistent kernel,
+        publish the episode-reward EMA the env workers kept (runner.py:216) and let the workers idle."""
+        torch.cuda.current_stream().synchronize()
+        if getattr(self, "proc_pool", False):
+            self.check()
+            if self.rew_q is not None:
+                self.rew_q.get()
+                self.rew_q.put(self.env_pool.rew_ema())
+
+    def check(self):
+        if getattr(self, "proc_pool", False) and int(self.rollout_err.item()):
+            self.env_pool._check_workers()
+            raise TimeoutError("a2c_a3c_rollout: an env worker did not answer within the time-out")
+
+    def close(self):
+        if getattr(self, "proc_pool", False):
+            self.env_pool.close()
 
     # ------------------------------------------------------------------ the rollout
     def rollout(self, net, idx, hyps):
@@ -182,6 +267,8 @@ class Runner:
         if not self._ready:
             self.start(net)
         idxs = [idx] if isinstance(idx, int) else list(idx)
+        if self.proc_pool and len(idxs) != self.B:
+            raise ValueError("a process env pool advances all its envs in lock-step: roll out all of its slots at once")
         j = 0
         while j < len(idxs):
             k = j
@@ -189,6 +276,8 @@ class Runner:
                 k += 1
             self._rollout_block(net, idxs[j], j, k - j + 1, hyps)
             j = k + 1
+        if self.proc_pool:
+            self.env_pool.seq += int(hyps["n_tsteps"])
 
     def _uniforms(self, t, B, env0):
         if self.uniform_fn is not None:
@@ -201,6 +290,17 @@ class Runner:
         if sampler is not None and getattr(net, "_fused_sampling", False):
             return net._fwd(x_ptr, bstride, B, "roll", st, False, sampler=sampler)
         return net._fwd(x_ptr, bstride, B, "roll", st, False)
+
+    def _zero_copy_ok(self, net):
+        """the persistent one-launch rollout applies: A3CModel-shaped net, process pool with uint8 frames"""
+        if not self.proc_pool or self.h is not None or self.ingest == "memcpy":
+            return False
+        ok = (getattr(net, "_step_supported", lambda: False)() and self.u8 and self.HW % 16 == 0 and self.HW <= 8192
+              and self.env_pool.dev_ptr != 0)
+        if self.ingest == "zero-copy" and not ok:
+            raise ValueError("ingest='zero-copy' needs an A3CModel-shaped net (a2c_a3c_step_supported) and a registered "
+                             "process env pool with uint8 frames")
+        return ok
 
     def _rollout_block(self, net, slot0, env0, B, hyps):
         D, pool = self.datas, self.env_pool
@@ -218,6 +318,8 @@ class Runner:
         val_prev, done_eff = self.val_prev[env0:env0 + B], self.done_eff[env0:env0 + B]
         h = None if self.h is None else self.h[env0:env0 + B]
         acts_host_out = D["actions"] if not D["actions"].is_cuda else None
+        if self._zero_copy_ok(net):
+            return self._rollout_block_persistent(net, slot0, env0, B, hyps, bm, val_prev, acts_host_out, st)
         # The per-step bookkeeping kernel only feeds later bookkeeping, so it CAN run on a side stream
         # next to the frame-stack kernel (two branches in the hipGraph).  Measured on MI355X the
         # fork/join costs more than the 4.8 us it hides (16.0 -> 17.8 ms per 256x128 epoch), so it is
@@ -249,16 +351,18 @@ class Runner:
                 ops.softmax_sample(logits, u, a_ptr, a_stride, B, net.output_space, st=st)
             if h is not None:
                 ops.copy_rows(out["h"].data_ptr(), h.shape[1], h.data_ptr(), h.shape[1], B, h.shape[1], st)
-            if self.device_pool:
-                frames, rew, done, reset = pool.device_step(t, env0, B)
-            else:
-                frames, rew, done, reset = self._host_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift,
-                                                           acts_host_out, pong)
+            fr, rew, done, reset = self._env_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong)
             nxt_ptr, nxt_stride = (sp(t + 1), T * S) if t + 1 < T else (bm.data_ptr(), S)
             if h is None and side is None and HW % 4 == 0 and S % 4 == 0 and os.environ.get("A2C_NO_POST_FUSE") != "1":
                 # feed-forward net: bookkeeping + next frame stack in ONE launch
-                ops.rollout_post(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t, slot0,
-                                 gamma, pong, frames, reset, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
+                if fr.ptr8:
+                    ops.rollout_post_u8(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t,
+                                        slot0, gamma, pong, fr.ptr8, fr.stride, reset, sp(t), T * S, nxt_ptr, nxt_stride, B,
+                                        C, HW, st)
+                else:
+                    ops.rollout_post(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t,
+                                     slot0, gamma, pong, _Ptr(fr.ptr32), reset, sp(t), T * S, nxt_ptr, nxt_stride, B, C,
+                                     HW, st)
                 continue
             if side is not None:
                 side.wait_stream(main)
@@ -269,8 +373,10 @@ class Runner:
                 ops.rollout_record(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, done_eff,
                                    h, B, T, t, slot0, gamma, pong, st)
             # next state (utils.next_state): into states[t+1], or the bookmark after the last step
-            nxt_ptr, nxt_stride = (sp(t + 1), T * S) if t + 1 < T else (bm.data_ptr(), S)
-            ops.frame_stack_push(frames, reset, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
+            if fr.ptr8:
+                ops.frame_stack_push_u8(fr.ptr8, fr.stride, reset, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
+            else:
+                ops.frame_stack_push(_Ptr(fr.ptr32), reset, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
             if side is not None:
                 main.wait_stream(side)     # join before the next forward overwrites the heads buffer
         # bootstrap (runner.py:236-245): value of the state after the last step
@@ -287,15 +393,19 @@ class Runner:
         gamma, pong, shift = hyps["gamma"], "Pong" in hyps["env_type"], hyps["action_shift"]
         rec = dict(val_prev=val_prev.data_ptr(), rewards=D["rewards"].data_ptr(), dones=D["dones"].data_ptr(),
                    deltas=D["deltas"].data_ptr(), T=T, slot0=slot0, gamma=float(gamma), pong=int(pong))
-        frames = rew = done = reset = None
+        fr = rew = done = reset = None
         for t in range(T + 1):
             kw = dict(rec)
             if t == 0:        # state of step 0 = the bookmark left by the previous slot (runner.py:190)
                 kw.update(prev=bm.data_ptr(), prev_stride=S, out=sp(0), out_stride=T * S)
             else:
                 out_ptr, out_stride = (sp(t), T * S) if t < T else (bm.data_ptr(), S)
-                kw.update(prev=sp(t - 1), prev_stride=T * S, frame_new=frames.data_ptr(), reset_mask=reset.data_ptr(),
+                kw.update(prev=sp(t - 1), prev_stride=T * S, reset_mask=reset.data_ptr(),
                           out=out_ptr, out_stride=out_stride, rew=rew.data_ptr(), done=done.data_ptr(), t_rec=t - 1)
+                if fr.ptr8:
+                    kw.update(frame_u8=fr.ptr8, frame_stride=fr.stride)
+                else:
+                    kw.update(frame_new=fr.ptr32)
             if t == T:
                 net._step(B, st, bootstrap=1, **kw)
                 break
@@ -306,25 +416,99 @@ class Runner:
             else:
                 a_ptr, a_stride = act.data_ptr(), 1
             net._step(B, st, u=u.data_ptr(), actions=a_ptr, act_stride=a_stride, **kw)
-            if self.device_pool:
-                frames, rew, done, reset = pool.device_step(t, env0, B)
-            else:
-                frames, rew, done, reset = self._host_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift,
-                                                           acts_host_out, pong)
-            for name, x in (("frames", frames), ("rew", rew), ("done", done), ("reset", reset)):
+            fr, rew, done, reset = self._env_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong)
+            for name, x in (("rew", rew), ("done", done), ("reset", reset)):
                 ops._chk(x, name)
 
-    def _host_step(self, pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong):
-        """actions D2H -> env.step on the host -> frames/rewards/dones H2D through pinned buffers."""
+    def _rollout_block_persistent(self, net, slot0, env0, B, hyps, bm, val_prev, acts_host_out, st):
+        """The whole slot as ONE persistent launch (a2c_a3c_rollout): the workgroups and the env worker
+        processes hand actions and uint8 frames to each other through the pinned pool region; nothing
+        runs on the host of this process until the launch has finished."""
+        D, pool = self.datas, self.env_pool
+        T, S = int(hyps["n_tsteps"]), self.S
+        dev = net._dev
+        if self.uniform_fn is not None:
+            u = torch.stack([self.uniform_fn(t, B, env0).reshape(B) for t in range(T)]).contiguous()
+        else:
+            u = torch.rand((T, B), device=dev, dtype=torch.float32)
+        ops._chk(u, "uniforms")
+        if acts_host_out is None:
+            acts = D["actions"]
+        else:
+            if getattr(self, "_acts_dev", None) is None or self._acts_dev.numel() != D["actions"].numel():
+                self._acts_dev = torch.zeros(D["actions"].numel(), dtype=torch.int64, device=dev)
+            acts = self._acts_dev
+        C, H, W = net.input_space[-3:]
+        hb, _, _ = net._heads("roll", self.B)
+        hb = hb[env0:env0 + B]
+        P = net.P
+        self._u_keep = u          # stays alive until the launch has consumed it
+        timeout_s = float(try_key(hyps, "env_timeout_s", 20.0))
+        ops.a3c_rollout(st, B=B, C=C, H=H, W=W, n_actions=net.output_space, states=D["states"].data_ptr(),
+                        bookmark=bm.data_ptr(), wfrag1=net._c1.wf.data_ptr(), bias1=P("convs.0.0.bias").data_ptr(),
+                        wfrag2=net._c2.wf.data_ptr(), bias2=P("convs.1.0.bias").data_ptr(), Wc=net._Wc.data_ptr(),
+                        bc=net._bc.data_ptr(), heads=hb.data_ptr(), ldh=hb.stride(0), u=u.data_ptr(), u_stride=B,
+                        actions=acts.data_ptr(), val_prev=val_prev.data_ptr(), rewards=D["rewards"].data_ptr(),
+                        dones=D["dones"].data_ptr(), deltas=D["deltas"].data_ptr(), T=T, slot0=slot0,
+                        gamma=float(hyps["gamma"]), pong=int("Pong" in hyps["env_type"]), cmd=pool.dev_cmd, rec=pool.dev_rec,
+                        frames=pool.dev_frames, frame_stride=self.fstride, seq0=pool.seq, env0=env0,
+                        err=self.rollout_err.data_ptr(), timeout_ticks=int(timeout_s * 1e8))
+        if acts_host_out is not None:
+            acts_host_out[slot0 * T:(slot0 + B) * T].copy_(acts[slot0 * T:(slot0 + B) * T])
+
+    # ------------------------------------------------------------------ one env step of B envs
+    def _env_step(self, pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong):
+        """-> (_Frames, rew, done, reset) device views of what the envs returned for the actions just sampled"""
+        if self.device_pool:
+            frames, rew, done, reset = pool.device_step(t, env0, B)
+            ops._chk(frames, "frames")
+            return _Frames(ptr32=frames.data_ptr()), rew, done, reset
+        if self.proc_pool:
+            return self._pool_step(pool, act, a_stride, env0, B, t, slot0, T, acts_host_out)
+        return self._host_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong)
+
+    def _actions_to_host(self, act, a_stride, env0, B, t, slot0, T):
         ha = self.h_act[env0:env0 + B]
         if a_stride == 1:
             ha.copy_(act, non_blocking=True)
         else:
             ha.copy_(self.datas["actions"][slot0 * T + t::T][:B], non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        hf, hr, hd, hz = (x[env0:env0 + B] for x in (self.h_frames, self.h_rew, self.h_done, self.h_reset))
+        return ha
+
+    def _pool_frames_h2d(self, pool, env0, B, st):
+        """hipMemcpyAsync of the frames block of envs env0..env0+B from the pinned region into HBM"""
+        fs = self.fstride
+        dst = self.d_frames.data_ptr() + env0 * fs
+        ops.memcpy_async(dst, pool.region.base + pool.header.off_frames + env0 * fs, B * fs, ops.H2D, st)
+        return _Frames(ptr8=dst, stride=fs) if self.u8 else _Frames(ptr32=dst)
+
+    def _pool_step(self, pool, act, a_stride, env0, B, t, slot0, T, acts_host_out):
+        """memcpy ingest with the process pool: actions D2H -> the workers step their envs in parallel ->
+        frames H2D from the pinned region (uint8 when the pool carries uint8) + rewards / dones."""
+        ha = self._actions_to_host(act, a_stride, env0, B, t, slot0, T)
+        k = pool.seq + t
+        na = self.np_act[env0:env0 + B]
+        pool.post_actions(na, env0=env0, seq=k)
+        if acts_host_out is not None:
+            acts_host_out[slot0 * T + t:(slot0 + B) * T:T] = ha
+        pool.wait_frames(k + 1, env0=env0, n=B, timeout=float(try_key(self.hyps, "env_timeout_s", 20.0)))
+        pool.unpack(self.np_rew[env0:env0 + B], self.np_done[env0:env0 + B], env0=env0)
+        st = ops.stream()
+        fr = self._pool_frames_h2d(pool, env0, B, st)
+        dr, dd = self.d_rew[env0:env0 + B], self.d_done[env0:env0 + B]
+        dr.copy_(self.h_rew[env0:env0 + B], non_blocking=True)
+        dd.copy_(self.h_done[env0:env0 + B], non_blocking=True)
+        return fr, dr, dd, dd
+
+    def _host_step(self, pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong):
+        """serial in-process pool: actions D2H -> env.step one after the other -> frames/rewards/dones H2D
+        through pinned buffers (numpy views of them: no per-element tensor writes)."""
+        self._actions_to_host(act, a_stride, env0, B, t, slot0, T)
+        na = self.np_act[env0:env0 + B]
+        nf, nr, nd = (x[env0:env0 + B] for x in (self.np_frames, self.np_rew, self.np_done))
         for j in range(B):
-            a = int(ha[j])
+            a = int(na[j])
             obs, rew, done = pool.step(env0 + j, a + shift)
             self.ep_rew[env0 + j] += rew
             reset = done
@@ -336,16 +520,26 @@ class Runner:
                 self.ep_rew[env0 + j] = 0
             if reset:
                 obs = pool.reset(env0 + j)
-            hf[j] = torch.from_numpy(np.asarray(obs, dtype=np.float32).reshape(-1))
-            hr[j], hd[j], hz[j] = rew, float(reset), float(reset)
-            if acts_host_out is not None:
-                acts_host_out[(slot0 + j) * T + t] = a
-        df, dr, dd, dz = (x[env0:env0 + B] for x in (self.d_frames, self.d_rew, self.d_done, self.d_reset))
-        df.copy_(hf, non_blocking=True)
-        dr.copy_(hr, non_blocking=True)
-        dd.copy_(hd, non_blocking=True)
-        dz.copy_(hz, non_blocking=True)
-        return df, dr, dd, dz
+            nf[j] = np.asarray(obs, dtype=np.float32).reshape(-1)
+            nr[j], nd[j] = rew, float(reset)
+        if acts_host_out is not None:
+            acts_host_out[slot0 * T + t:(slot0 + B) * T:T] = self.h_act[env0:env0 + B]
+        df, dr, dd = (x[env0:env0 + B] for x in (self.d_frames, self.d_rew, self.d_done))
+        df.copy_(self.h_frames[env0:env0 + B], non_blocking=True)
+        dr.copy_(self.h_rew[env0:env0 + B], non_blocking=True)
+        dd.copy_(self.h_done[env0:env0 + B], non_blocking=True)
+        return _Frames(ptr32=df.data_ptr()), dr, dd, dd
+
+
+class _Ptr:
+    """raw device address with the ``data_ptr()`` the ops wrappers ask for"""
+    __slots__ = ("p",)
+
+    def __init__(self, p):
+        self.p = int(p)
+
+    def data_ptr(self):
+        return self.p
 
 
 class StatsRunner:

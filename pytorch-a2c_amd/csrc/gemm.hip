@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restric
             cs = cs + expf(h[n] - mx) / den;
             if (pick < 0 && cs >= ub) pick = n;
           }
+        if (pick < 0) pick = n_logits - 1;      // fp32 cumsum short of u: the last action (see sample_kernel)
         actions[m * act_stride] = (int64_t)pick;
       }
     }

@@ -1,0 +1,80 @@
+// Host-side entry points of the C ABI that touch the HIP runtime but launch no kernel: the pinned,
+// device-mapped pool region the env workers and the rollout kernels share (include/a2c_hostpool.h) and
+// the async copies of the memcpy ingest.  SURVEY.md section 8(b): a2c_rollout_buffer_{create,destroy}.
+#include "a2c_common.h"
+
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+extern "C" {
+int a2c_pinned_register(void* host, size_t bytes, void** dev_out) {
+  if (!host || !bytes || !dev_out) return A2C_ERR_ARG;
+  if (hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return A2C_ERR_LAUNCH;
+  }
+  if (hipHostGetDevicePointer(dev_out, host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(host);
+    return A2C_ERR_LAUNCH;
+  }
+  return A2C_OK;
+}
+
+int a2c_pinned_unregister(void* host) {
+  if (!host) return A2C_ERR_ARG;
+  if (hipHostUnregister(host) != hipSuccess) {
+    (void)hipGetLastError();
+    return A2C_ERR_LAUNCH;
+  }
+  return A2C_OK;
+}
+
+int a2c_rollout_buffer_create(const char* shm_name, size_t bytes, void** host_out, void** dev_out) {
+  if (!shm_name || !bytes || !host_out || !dev_out) return A2C_ERR_ARG;
+  const int fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) return A2C_ERR_ARG;
+  if (ftruncate(fd, (off_t)bytes) != 0) {
+    close(fd);
+    shm_unlink(shm_name);
+    return A2C_ERR_WORKSPACE;
+  }
+  void* h = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (h == MAP_FAILED) {
+    shm_unlink(shm_name);
+    return A2C_ERR_WORKSPACE;
+  }
+  memset(h, 0, bytes);
+  const int rc = a2c_pinned_register(h, bytes, dev_out);
+  if (rc != A2C_OK) {
+    munmap(h, bytes);
+    shm_unlink(shm_name);
+    return rc;
+  }
+  *host_out = h;
+  return A2C_OK;
+}
+
+int a2c_rollout_buffer_destroy(const char* shm_name, void* host, size_t bytes) {
+  if (!host || !bytes) return A2C_ERR_ARG;
+  int rc = a2c_pinned_unregister(host);
+  munmap(host, bytes);
+  if (shm_name) shm_unlink(shm_name);
+  return rc;
+}
+
+int a2c_memcpy_async(void* dst, const void* src, size_t bytes, int kind, a2c_stream_t stream) {
+  if (!bytes) return A2C_OK;
+  if (!dst || !src || kind < 1 || kind > 3) return A2C_ERR_ARG;
+  const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (hipMemcpyAsync(dst, src, bytes, k, a2c_s(stream)) != hipSuccess) {
+    (void)hipGetLastError();
+    return A2C_ERR_LAUNCH;
+  }
+  return A2C_OK;
+}
+}

@@ -1,0 +1,163 @@
+// liba2c_hostpool.so: host side of the rollout ingest (see include/a2c_hostpool.h).  Plain C,
+// no HIP: env worker processes load it without initialising the GPU runtime.
+#define _GNU_SOURCE
+#include "../../include/a2c_hostpool.h"
+
+#include <string.h>
+#include <time.h>
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+#define cpu_relax() _mm_pause()
+#else
+#define cpu_relax() __asm__ __volatile__("" ::: "memory")
+#endif
+
+static inline int64_t now_ns(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+}
+static inline void sleep_ns(long ns) {
+  struct timespec ts = {0, ns};
+  nanosleep(&ts, NULL);
+}
+static inline a2c_pool_header *hdr(void *base) { return (a2c_pool_header *)base; }
+static inline const a2c_pool_header *chdr(const void *base) { return (const a2c_pool_header *)base; }
+static inline uint64_t *cmd_of(void *base) { return (uint64_t *)((char *)base + hdr(base)->off_cmd); }
+static inline uint64_t *rec_of(void *base) { return (uint64_t *)((char *)base + hdr(base)->off_rec); }
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+/* frame slots are 16 B apart at least (one 16-byte load per lane on the device); fp32 frames whose size is a
+ * multiple of 16 B are therefore dense, which is what the fp32 frame-stack kernels expect */
+static size_t frame_stride_of(int frame_bytes) { return align_up((size_t)frame_bytes, 16); }
+
+size_t a2c_pool_bytes(int n_envs, int frame_bytes) {
+  if (n_envs < 1 || frame_bytes < 1) return 0;
+  const size_t stride = frame_stride_of(frame_bytes);
+  return align_up(4096 + 2 * align_up((size_t)n_envs * 8, 4096) + (size_t)n_envs * stride, 4096);
+}
+
+int a2c_pool_init(void *base, size_t bytes, int n_envs, int frame_bytes, int frame_dtype, int n_workers,
+                  double rew_ema0) {
+  if (!base || n_envs < 1 || frame_bytes < 1 || bytes < a2c_pool_bytes(n_envs, frame_bytes)) return -1;
+  if (frame_dtype != A2C_FRAME_U8 && frame_dtype != A2C_FRAME_F32) return -1;
+  a2c_pool_header *h = hdr(base);
+  memset(h, 0, 4096);
+  h->version = A2C_POOL_VERSION;
+  h->n_envs = (uint32_t)n_envs;
+  h->frame_bytes = (uint32_t)frame_bytes;
+  h->frame_stride = (uint32_t)frame_stride_of(frame_bytes);
+  h->frame_dtype = (uint32_t)frame_dtype;
+  h->n_workers = (uint32_t)n_workers;
+  h->off_cmd = 4096;
+  h->off_rec = h->off_cmd + align_up((size_t)n_envs * 8, 4096);
+  h->off_frames = h->off_rec + align_up((size_t)n_envs * 8, 4096);
+  h->total_bytes = a2c_pool_bytes(n_envs, frame_bytes);
+  h->rew_ema = rew_ema0;
+  uint64_t *c = cmd_of(base), *r = rec_of(base);
+  for (int j = 0; j < n_envs; ++j) {
+    c[j] = ~0ULL;      /* seq 0xffffffff: nothing requested yet */
+    r[j] = ~0ULL;      /* no frame yet                          */
+  }
+  __atomic_store_n(&h->magic, A2C_POOL_MAGIC, __ATOMIC_RELEASE);
+  return 0;
+}
+
+int a2c_pool_check(const void *base) {
+  if (!base) return -1;
+  const a2c_pool_header *h = chdr(base);
+  return (__atomic_load_n(&h->magic, __ATOMIC_ACQUIRE) == A2C_POOL_MAGIC && h->version == A2C_POOL_VERSION) ? 0 : -1;
+}
+
+void a2c_pool_set_phase(void *base, uint32_t phase) { __atomic_store_n(&hdr(base)->phase, phase, __ATOMIC_RELEASE); }
+uint32_t a2c_pool_phase(const void *base) { return __atomic_load_n(&chdr(base)->phase, __ATOMIC_ACQUIRE); }
+
+int a2c_pool_poll(void *base, int env0, int n, const uint32_t *next_seq, int64_t spin_ns) {
+  const uint64_t *c = cmd_of(base) + env0;
+  const int64_t t0 = now_ns();
+  for (unsigned sweep = 0;; ++sweep) {
+    for (int i = 0; i < n; ++i)
+      if ((uint32_t)(__atomic_load_n(c + i, __ATOMIC_ACQUIRE) >> 32) == next_seq[i]) return i;
+    if ((sweep & 15) == 15) {
+      const uint32_t ph = a2c_pool_phase(base);
+      if (ph == A2C_POOL_SHUTDOWN) return -2;
+      if (ph == A2C_POOL_IDLE) sleep_ns(50000);   /* no rollout running: do not burn the core */
+      if (now_ns() - t0 > spin_ns) return -1;
+    }
+    cpu_relax();
+  }
+}
+
+int32_t a2c_pool_action(const void *base, int env) {
+  const uint64_t *c = (const uint64_t *)((const char *)base + chdr(base)->off_cmd);
+  return (int32_t)(uint32_t)__atomic_load_n(c + env, __ATOMIC_ACQUIRE);
+}
+
+int a2c_pool_take(void *base, int env0, int n, const uint32_t *next_seq, int64_t spin_ns, int32_t *action) {
+  const int i = a2c_pool_poll(base, env0, n, next_seq, spin_ns);
+  if (i >= 0) *action = a2c_pool_action(base, env0 + i);
+  return i;
+}
+
+void a2c_pool_publish(void *base, int env, const void *frame, uint32_t seq, float rew, int done) {
+  a2c_pool_header *h = hdr(base);
+  memcpy((char *)base + h->off_frames + (size_t)env * h->frame_stride, frame, h->frame_bytes);
+  uint32_t rb;
+  memcpy(&rb, &rew, 4);
+  const uint64_t g = ((uint64_t)((seq << 1) | (done ? 1u : 0u)) << 32) | rb;
+  __atomic_store_n(rec_of(base) + env, g, __ATOMIC_RELEASE);   /* frame bytes are visible before the tag */
+}
+
+void a2c_pool_episode(void *base, double ep_rew) {
+  a2c_pool_header *h = hdr(base);
+  while (__atomic_exchange_n(&h->ema_lock, 1u, __ATOMIC_ACQUIRE)) cpu_relax();
+  h->rew_ema = .99 * h->rew_ema + .01 * ep_rew;
+  h->episodes += 1;
+  __atomic_store_n(&h->ema_lock, 0u, __ATOMIC_RELEASE);
+}
+
+void a2c_pool_worker_ready(void *base) { __atomic_fetch_add(&hdr(base)->workers_ready, 1u, __ATOMIC_ACQ_REL); }
+void a2c_pool_worker_failed(void *base, int worker_id) {
+  __atomic_store_n(&hdr(base)->worker_error, (uint32_t)worker_id + 1u, __ATOMIC_RELEASE);
+}
+
+void a2c_pool_post_actions(void *base, int env0, int n, const int64_t *actions, int64_t stride, uint32_t seq) {
+  uint64_t *c = cmd_of(base) + env0;
+  for (int i = 0; i < n; ++i)
+    __atomic_store_n(c + i, ((uint64_t)seq << 32) | (uint32_t)(int32_t)actions[(int64_t)i * stride], __ATOMIC_RELEASE);
+}
+
+int a2c_pool_wait_frames(void *base, int env0, int n, uint32_t seq, int64_t timeout_ns) {
+  const uint64_t *r = rec_of(base) + env0;
+  const int64_t t0 = now_ns();
+  int i = 0;
+  for (unsigned sweep = 0; i < n; ++sweep) {
+    while (i < n && (uint32_t)(__atomic_load_n(r + i, __ATOMIC_ACQUIRE) >> 33) == seq) ++i;
+    if (i == n) break;
+    if ((sweep & 63) == 63) {
+      if (__atomic_load_n(&hdr(base)->worker_error, __ATOMIC_ACQUIRE)) return -3;
+      if (now_ns() - t0 > timeout_ns) return -1;
+    }
+    cpu_relax();
+  }
+  return 0;
+}
+
+void a2c_pool_unpack(const void *base, int env0, int n, float *rew, float *done) {
+  const uint64_t *r = (const uint64_t *)((const char *)base + chdr(base)->off_rec) + env0;
+  for (int i = 0; i < n; ++i) {
+    const uint64_t g = __atomic_load_n(r + i, __ATOMIC_ACQUIRE);
+    const uint32_t rb = (uint32_t)g;
+    memcpy(rew + i, &rb, 4);
+    done[i] = (float)((g >> 32) & 1u);
+  }
+}
+
+double a2c_pool_rew_ema(const void *base) {
+  a2c_pool_header *h = (a2c_pool_header *)base;
+  while (__atomic_exchange_n(&h->ema_lock, 1u, __ATOMIC_ACQUIRE)) cpu_relax();
+  const double v = h->rew_ema;
+  __atomic_store_n(&h->ema_lock, 0u, __ATOMIC_RELEASE);
+  return v;
+}

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
     const float lse = logf(se);
     float adv = advs[n];
     if (adv_sums != nullptr) adv = (adv - mean) / den;
-    const int act = (int)actions[n];
+    int act = (int)actions[n];
+    if (act < 0) act += A;      // log_softs[arange, actions] (updater.py:104): a -1 of sample_action indexes the last action
     float plp = 0.f, lp_act = 0.f;
 #pragma unroll
     for (int a = 0; a < MAXA; ++a)

@@ -6,9 +6,23 @@
 
 namespace {
 
+// uint8 frames (the host pool's transport format, preprocessing.py:11-17 yields uint8): 4 pixels per dword,
+// expanded to fp32 on the way into the state (runner.py:199 `FloatTensor(state)`)
+__device__ __forceinline__ float4 u8x4_to_f32(unsigned int w) {
+  return make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+}
+
+// plane C-1 of the new state from a uint8 frame: `fstride` bytes between envs, HW % 4 == 0
+__device__ __forceinline__ void stack_u8_plane(const uint8_t* __restrict__ f, float* __restrict__ o, int HW) {
+  const unsigned int* __restrict__ w = reinterpret_cast<const unsigned int*>(f);
+  const int n4 = HW >> 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) reinterpret_cast<float4*>(o)[i] = u8x4_to_f32(w[i]);
+}
+
 // a1: frame stack.  One workgroup column per (env, plane); 16 B per lane when HW % 4 == 0.
 template <bool VEC4>
 __global__ __launch_bounds__(256) void frame_stack_kernel(const float* __restrict__ frame_new,
+                                                          const uint8_t* __restrict__ frame_u8, long fstride,
                                                           const float* __restrict__ reset_mask,
                                                           const float* __restrict__ prev, long prev_stride,
                                                           float* __restrict__ out, long out_stride, int C,
@@ -18,8 +32,10 @@ __global__ __launch_bounds__(256) void frame_stack_kernel(const float* __restric
   const bool rst = reset_mask != nullptr && reset_mask[b] != 0.f;
   float* o = out + (long)b * out_stride + (long)c * HW;
   const float* src = nullptr;  // nullptr => zeros
-  if (c == C - 1) src = frame_new + (long)b * HW;
-  else if (!rst) src = prev + (long)b * prev_stride + (long)(c + 1) * HW;
+  if (c == C - 1) {
+    if (frame_u8) { stack_u8_plane(frame_u8 + (long)b * fstride, o, HW); return; }
+    src = frame_new + (long)b * HW;
+  } else if (!rst) src = prev + (long)b * prev_stride + (long)(c + 1) * HW;
   if (VEC4) {
     const int n4 = HW >> 2;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
@@ -55,6 +71,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
       cs = __fadd_rn(cs, p);
       if (pick < 0 && cs >= ub) pick = a;
     }
+    // Rounding can leave the fp32 cumsum of a softmax below a uniform close to 1 (utils.py:58 then returns
+    // -1, which indexes the LAST action in the loss, updater.py:104, but is not a valid env action): the
+    // rollout sampler returns that last action.  a2c_sample_probs keeps the reference's -1.
+    if (SOFTMAX && pick < 0) pick = A - 1;
     if (act_i) act_i[b * act_stride] = (int64_t)pick;
     if (act_f) act_f[b] = (float)pick;
   }
@@ -94,6 +114,7 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ rew
                                                    float* __restrict__ dones, float* __restrict__ deltas, long T, long t,
                                                    long slot0, float gamma, int pong,
                                                    const float* __restrict__ frame_new,
+                                                   const uint8_t* __restrict__ frame_u8, long fstride,
                                                    const float* __restrict__ reset_mask, const float* __restrict__ prev,
                                                    long prev_stride, float* __restrict__ out, long out_stride, int B,
                                                    int C, int HW) {
@@ -121,8 +142,10 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ rew
   const bool rst = reset_mask != nullptr && reset_mask[b] != 0.f;
   float* o = out + (long)b * out_stride + (long)c * HW;
   const float* src = nullptr;
-  if (c == C - 1) src = frame_new + (long)b * HW;
-  else if (!rst) src = prev + (long)b * prev_stride + (long)(c + 1) * HW;
+  if (c == C - 1) {
+    if (frame_u8) { stack_u8_plane(frame_u8 + (long)b * fstride, o, HW); return; }
+    src = frame_new + (long)b * HW;
+  } else if (!rst) src = prev + (long)b * prev_stride + (long)(c + 1) * HW;
   const int n4 = HW >> 2;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -156,9 +179,9 @@ __global__ __launch_bounds__(256) void bootstrap_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, long ss,
-                                                        float* __restrict__ dst, long ds, long n) {
-  const int b = blockIdx.y;
-  for (long j = blockIdx.x * 256L + threadIdx.x; j < n; j += gridDim.x * 256L) dst[b * ds + j] = src[b * ss + j];
+                                                        float* __restrict__ dst, long ds, long n, long B) {
+  for (long b = blockIdx.y; b < B; b += gridDim.y)
+    for (long j = blockIdx.x * 256L + threadIdx.x; j < n; j += gridDim.x * 256L) dst[b * ds + j] = src[b * ss + j];
 }
 
 __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, long ld,
@@ -191,23 +214,39 @@ int a2c_permute_rows(const float* src, float* dst, int64_t R, int64_t T, int64_t
   return A2C_OK;
 }
 
-int a2c_frame_stack_push(const float* frame_new, const float* reset_mask, const float* prev, int64_t prev_stride,
-                         float* out, int64_t out_stride, int B, int C, int HW, a2c_stream_t stream) {
+static int frame_stack_push_any(const float* frame_new, const uint8_t* frame_u8, int64_t fstride,
+                                const float* reset_mask, const float* prev, int64_t prev_stride, float* out,
+                                int64_t out_stride, int B, int C, int HW, a2c_stream_t stream) {
   if (B < 0 || C < 1 || HW < 1) return A2C_ERR_ARG;
   if (B == 0) return A2C_OK;
-  if (!frame_new || !out || (C > 1 && !prev)) return A2C_ERR_ARG;
+  if ((!frame_new && !frame_u8) || !out || (C > 1 && !prev)) return A2C_ERR_ARG;
   const bool vec = (HW % 4 == 0) && (prev_stride % 4 == 0) && (out_stride % 4 == 0) &&
                    (((uintptr_t)frame_new | (uintptr_t)prev | (uintptr_t)out) % 16 == 0);
+  if (frame_u8 && (!vec || fstride % 4 || (uintptr_t)frame_u8 % 4 || fstride < HW)) return A2C_ERR_ARG;
   const int work = vec ? HW / 4 : HW;
   dim3 grid((work + 255) / 256 > 8 ? 8 : (work + 255) / 256, B, C);
   if (vec)
-    hipLaunchKernelGGL(frame_stack_kernel<true>, grid, dim3(256), 0, a2c_s(stream), frame_new, reset_mask, prev,
-                       (long)prev_stride, out, (long)out_stride, C, HW);
+    hipLaunchKernelGGL(frame_stack_kernel<true>, grid, dim3(256), 0, a2c_s(stream), frame_new, frame_u8, (long)fstride,
+                       reset_mask, prev, (long)prev_stride, out, (long)out_stride, C, HW);
   else
-    hipLaunchKernelGGL(frame_stack_kernel<false>, grid, dim3(256), 0, a2c_s(stream), frame_new, reset_mask, prev,
-                       (long)prev_stride, out, (long)out_stride, C, HW);
+    hipLaunchKernelGGL(frame_stack_kernel<false>, grid, dim3(256), 0, a2c_s(stream), frame_new, frame_u8, (long)fstride,
+                       reset_mask, prev, (long)prev_stride, out, (long)out_stride, C, HW);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
+}
+
+int a2c_frame_stack_push(const float* frame_new, const float* reset_mask, const float* prev, int64_t prev_stride,
+                         float* out, int64_t out_stride, int B, int C, int HW, a2c_stream_t stream) {
+  if (!frame_new && B > 0) return A2C_ERR_ARG;
+  return frame_stack_push_any(frame_new, nullptr, 0, reset_mask, prev, prev_stride, out, out_stride, B, C, HW, stream);
+}
+
+int a2c_frame_stack_push_u8(const uint8_t* frame_u8, int64_t frame_stride, const float* reset_mask, const float* prev,
+                            int64_t prev_stride, float* out, int64_t out_stride, int B, int C, int HW,
+                            a2c_stream_t stream) {
+  if (!frame_u8 && B > 0) return A2C_ERR_ARG;
+  return frame_stack_push_any(nullptr, frame_u8, frame_stride, reset_mask, prev, prev_stride, out, out_stride, B, C, HW,
+                              stream);
 }
 
 int a2c_softmax_sample(const float* logits, int64_t ld_logits, const float* u, int64_t* actions,
@@ -252,23 +291,44 @@ int a2c_rollout_record(const float* rew, const float* done, const float* val, in
   return A2C_OK;
 }
 
+static int rollout_post_any(const float* rew, const float* done, const float* val, int64_t val_stride, float* val_prev,
+                            float* rewards, float* dones, float* deltas, int64_t T, int64_t t, int64_t slot0, float gamma,
+                            int pong, const float* frame_new, const uint8_t* frame_u8, int64_t fstride,
+                            const float* reset_mask, const float* prev, int64_t prev_stride, float* out,
+                            int64_t out_stride, int B, int C, int HW, a2c_stream_t stream) {
+  if (B < 0 || T < 1 || t < 0 || t >= T || C < 1 || HW < 4 || HW % 4) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!rew || !done || !val || !val_prev || !rewards || !dones || !deltas || (!frame_new && !frame_u8) || !out ||
+      (C > 1 && !prev))
+    return A2C_ERR_ARG;
+  if (prev_stride % 4 || out_stride % 4 || (((uintptr_t)frame_new | (uintptr_t)prev | (uintptr_t)out) % 16))
+    return A2C_ERR_ARG;
+  if (frame_u8 && (fstride % 4 || (uintptr_t)frame_u8 % 4 || fstride < HW)) return A2C_ERR_ARG;
+  const int work = HW / 4;
+  dim3 grid((work + 255) / 256 > 8 ? 8 : (work + 255) / 256, B, C + 1);
+  hipLaunchKernelGGL(post_kernel, grid, dim3(256), 0, a2c_s(stream), rew, done, val, (long)val_stride, val_prev, rewards,
+                     dones, deltas, (long)T, (long)t, (long)slot0, gamma, pong, frame_new, frame_u8, (long)fstride,
+                     reset_mask, prev, (long)prev_stride, out, (long)out_stride, B, C, HW);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
 int a2c_rollout_post(const float* rew, const float* done, const float* val, int64_t val_stride, float* val_prev,
                      float* rewards, float* dones, float* deltas, int64_t T, int64_t t, int64_t slot0, float gamma, int pong,
                      const float* frame_new, const float* reset_mask, const float* prev, int64_t prev_stride, float* out,
                      int64_t out_stride, int B, int C, int HW, a2c_stream_t stream) {
-  if (B < 0 || T < 1 || t < 0 || t >= T || C < 1 || HW < 4 || HW % 4) return A2C_ERR_ARG;
-  if (B == 0) return A2C_OK;
-  if (!rew || !done || !val || !val_prev || !rewards || !dones || !deltas || !frame_new || !out || (C > 1 && !prev))
-    return A2C_ERR_ARG;
-  if (prev_stride % 4 || out_stride % 4 || (((uintptr_t)frame_new | (uintptr_t)prev | (uintptr_t)out) % 16))
-    return A2C_ERR_ARG;
-  const int work = HW / 4;
-  dim3 grid((work + 255) / 256 > 8 ? 8 : (work + 255) / 256, B, C + 1);
-  hipLaunchKernelGGL(post_kernel, grid, dim3(256), 0, a2c_s(stream), rew, done, val, (long)val_stride, val_prev, rewards,
-                     dones, deltas, (long)T, (long)t, (long)slot0, gamma, pong, frame_new, reset_mask, prev,
-                     (long)prev_stride, out, (long)out_stride, B, C, HW);
-  A2C_CHECK_LAUNCH();
-  return A2C_OK;
+  if (!frame_new && B > 0) return A2C_ERR_ARG;
+  return rollout_post_any(rew, done, val, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma, pong, frame_new,
+                          nullptr, 0, reset_mask, prev, prev_stride, out, out_stride, B, C, HW, stream);
+}
+
+int a2c_rollout_post_u8(const float* rew, const float* done, const float* val, int64_t val_stride, float* val_prev,
+                        float* rewards, float* dones, float* deltas, int64_t T, int64_t t, int64_t slot0, float gamma,
+                        int pong, const uint8_t* frame_u8, int64_t frame_stride, const float* reset_mask, const float* prev,
+                        int64_t prev_stride, float* out, int64_t out_stride, int B, int C, int HW, a2c_stream_t stream) {
+  if (!frame_u8 && B > 0) return A2C_ERR_ARG;
+  return rollout_post_any(rew, done, val, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma, pong, nullptr,
+                          frame_u8, frame_stride, reset_mask, prev, prev_stride, out, out_stride, B, C, HW, stream);
 }
 
 int a2c_rollout_bootstrap(const float* val_boot, int64_t val_stride, const float* val_prev, float* rewards,
@@ -288,9 +348,9 @@ int a2c_copy_rows(const float* src, int64_t src_stride, float* dst, int64_t dst_
   if (B < 0 || n < 0) return A2C_ERR_ARG;
   if (B == 0 || n == 0) return A2C_OK;
   if (!src || !dst) return A2C_ERR_ARG;
-  dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), B);
+  dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), B > 32768 ? 32768 : B);
   hipLaunchKernelGGL(copy_rows_kernel, grid, dim3(256), 0, a2c_s(stream), src, (long)src_stride, dst,
-                     (long)dst_stride, (long)n);
+                     (long)dst_stride, (long)n, (long)B);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
 }  // namespace
 
 extern "C" {
-int a2c_version(void) { return 1; }
+int a2c_version(void) { return 2; }
 
 const char* a2c_error_string(int code) {
   switch (code) {

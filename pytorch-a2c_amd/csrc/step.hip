@@ -12,10 +12,20 @@
 //   (32 mod 64: conflict-free ds_read_b64) | a2 flat (c, y, x) | reduction scratch.  conv1's 64
 //   A fragments live in registers; conv2's 32 KB of fragments are prefetched into registers at
 //   kernel start and dropped over the image once conv1 has consumed it.
+//
+// Three instantiation axes of the same kernel body:
+//   U8       the new frame arrives as uint8 pixels (the host pool's transport format) and is expanded
+//            in registers: one 16-byte load per thread brings the whole plane;
+//   PERSIST  the WHOLE slot (T+1 iterations) in one launch (a2c_a3c_rollout): each workgroup loops
+//            over the time steps of its env(s), waits for the env worker's `rec` granule in pinned
+//            host memory, loads the uint8 frame straight from the pinned pool slot (system-scope loads
+//            over PCIe) and hands the sampled action back with one 8-byte system-scope store to `cmd`
+//            (include/a2c_hostpool.h) -- no kernel boundary and no host code between env steps.
 #include "a2c_common.h"
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT = 512;        // threads per workgroup (8 waves, 2 per SIMD)
 constexpr int NCH = 3;         // the state arrives in 3 row chunks; conv1 runs on chunk k while k+1.. are in flight
 constexpr int SL0 = 6, SL1 = 5, SL2 = 5;   // float4 staging registers per thread and chunk
@@ -33,11 +43,33 @@ __device__ int a2c_step_skip;       // debug: bit 0 no row stores, 1 no conv1, 2
 #define SKIP(bit) false
 #endif
 
+struct RolloutX {              // what a2c_a3c_rollout adds to the per-step arguments
+  float* states;
+  float* bookmark;
+  const float* u; long u_stride;
+  int64_t* actions;
+  unsigned long long* cmd;
+  const unsigned long long* rec;
+  unsigned int seq0;
+  int env0;
+  int* err;
+  long timeout_ticks;
+};
+
 struct StepP {
   a2c_a3c_step_args a;
   int OH1, OW1, OH2, OW2, PLANE1, PLANE2, F, F4;
   int row_end[NCH];            // chunk k = input rows [row_end[k-1], row_end[k])
   int tile_end[NCH];           // conv1 16-pixel tiles computable once chunk k is in LDS
+  RolloutX x;
+};
+
+// what one iteration works on (uniform over the workgroup)
+struct It {
+  const float* prev;           // state row the frame is pushed onto (or, without a frame, the state itself)
+  const float* frame32;        // fp32 new frame of this env, or nullptr
+  bool frame8;                 // the new frame is the uint8 one (loaded separately)
+  float* out;                  // row that receives the state (nullptr: none)
 };
 
 // plane c of state_t comes from: the new frame (c == 3) / plane c+1 of the previous state (frame
@@ -46,11 +78,12 @@ struct StepP {
 // Every thread executes the SAME number of global loads/stores (out-of-range slots are clamped onto
 // the chunk's last element: a benign duplicate), so the s_waitcnt vmcnt(n) the compiler derives for
 // "chunk k has landed" is exact and never drains the younger loads and the row stores behind it.
+// With a uint8 frame the plane-3 slots re-load plane 2's bytes (a cache hit) and are dropped at commit.
 template <int N>
-__device__ __forceinline__ void issue_chunk(float4 (&pf)[N], const a2c_a3c_step_args& a, int b, int r0, int q4, int HW,
-                                            int W, int tid) {
-  const float* __restrict__ pb = a.prev + (long)b * a.prev_stride + (a.frame_new ? HW : 0);
-  const float* __restrict__ p3 = a.frame_new ? a.frame_new + (long)b * HW : pb + 3L * HW;
+__device__ __forceinline__ void issue_chunk(float4 (&pf)[N], const It& it, int r0, int q4, int HW, int W, int tid) {
+  const bool has_frame = it.frame32 != nullptr || it.frame8;
+  const float* __restrict__ pb = it.prev + (has_frame ? HW : 0);
+  const float* __restrict__ p3 = it.frame32 ? it.frame32 : pb + (it.frame8 ? 2L : 3L) * HW;
 #pragma unroll
   for (int u = 0; u < N; ++u) {
     const int idx = min(tid + u * NT, 4 * q4 - 1);
@@ -63,9 +96,9 @@ __device__ __forceinline__ void issue_chunk(float4 (&pf)[N], const a2c_a3c_step_
   }
 }
 
-template <bool OUT, int N>
-__device__ __forceinline__ void commit_chunk(const float4 (&pf)[N], const a2c_a3c_step_args& a, int b, int r0, int q4,
-                                             int HW, int W, int tid, bool zero_old, float* __restrict__ img, int PLANE1) {
+template <int N>
+__device__ __forceinline__ void commit_chunk(const float4 (&pf)[N], const It& it, int r0, int q4, int W, int tid,
+                                             bool zero_old, float* __restrict__ img, int PLANE1) {
 #pragma unroll
   for (int u = 0; u < N; ++u) {
     const int idx = min(tid + u * NT, 4 * q4 - 1);
@@ -73,7 +106,7 @@ __device__ __forceinline__ void commit_chunk(const float4 (&pf)[N], const a2c_a3
     const int rem = idx - c * q4;
     float4 v = pf[u];
     if (zero_old && c != 3) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(img + c * PLANE1 + r0 * W + (rem << 2)) = v;
+    if (!(it.frame8 && c == 3)) *reinterpret_cast<float4*>(img + c * PLANE1 + r0 * W + (rem << 2)) = v;
   }
 }
 
@@ -81,8 +114,8 @@ __device__ __forceinline__ void commit_chunk(const float4 (&pf)[N], const a2c_a3
 // the chunk was committed to LDS: at the start of the kernel HBM belongs to the state loads (the
 // critical path); the row stores drain under the conv phases instead of competing with them.
 template <int N>
-__device__ __forceinline__ void store_chunk(const float4 (&pf)[N], const a2c_a3c_step_args& a, int b, int r0, int q4,
-                                            int HW, int W, int tid, bool zero_old) {
+__device__ __forceinline__ void store_chunk(const float4 (&pf)[N], const It& it, int r0, int q4, int HW, int W, int tid,
+                                            bool zero_old) {
 #pragma unroll
   for (int u = 0; u < N; ++u) {
     const int idx = min(tid + u * NT, 4 * q4 - 1);
@@ -92,13 +125,17 @@ __device__ __forceinline__ void store_chunk(const float4 (&pf)[N], const a2c_a3c
     if (zero_old && c != 3) v = make_float4(0.f, 0.f, 0.f, 0.f);
     // streaming store: the rows are not re-read by this kernel, and a write-back line left dirty in
     // the XCD's L2 would have to be flushed at the kernel boundary (serialised after the last wave)
-    if (!SKIP(0))
+    if (!SKIP(0) && !(it.frame8 && c == 3))
       __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w},
-                                  reinterpret_cast<f32x4*>(a.out + (long)b * a.out_stride + (long)c * HW + r0 * W + (rem << 2)));
+                                  reinterpret_cast<f32x4*>(it.out + (long)c * HW + r0 * W + (rem << 2)));
   }
 }
 
-template <bool OUT>
+__device__ __forceinline__ float4 u8x4(unsigned int w) {
+  return make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+}
+
+template <bool OUT, bool U8, bool PERSIST, int HNT = HN>      // HNT: heads kept in registers (n_actions + 1 <= HNT)
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void a3c_step_kernel(StepP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (SKIP(6)) return;
@@ -108,7 +145,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   float* __restrict__ a1 = img + 4 * p.PLANE1;
   float* __restrict__ red = a1 + 16 * p.PLANE2;
   float* __restrict__ a2 = img + NF2;
-  const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int HW = a.H * a.W, W = a.W;
@@ -122,243 +158,363 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                "s"(a.n_actions), "s"(p.PLANE1), "s"(p.row_end[0]), "s"(p.row_end[1]), "s"(p.row_end[2]));
   TS(0);
 
-  // ---- every global load of the kernel is issued here, in the order it is consumed.
-  // Bookkeeping inputs first (oldest in the in-order vmcnt queue), from always-valid addresses.
+  // ---- once per launch: conv1 fragments and the biases
   const float4 b1v = *reinterpret_cast<const float4*>(a.bias1 + 4 * g);
   const float b1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
   const float ld_b2 = a.bias2[tid & 31];
-  const bool rec = a.rew != nullptr;
-  const long bk_e = rec ? (a.slot0 + b) * a.T + a.t_rec : 0;
-  const float* __restrict__ safe = a.heads + (long)b * a.ldh;
-  const float ld_r = *(rec ? a.rew + b : safe);
-  const float ld_d = *(rec ? a.done + b : safe);
-  const float ld_v = safe[a.n_actions];                      // value of the state the env step left
-  const float ld_pr = *((rec && a.t_rec > 0) ? a.rewards + bk_e - 1 : safe);
-  const float ld_pd = *((rec && a.t_rec > 0) ? a.dones + bk_e - 1 : safe);
-  const float ld_vp = *(rec ? a.val_prev + b : safe);
-  const float ld_rst = *((a.frame_new && a.reset_mask) ? a.reset_mask + b : safe);
   const float4* __restrict__ wf1v = reinterpret_cast<const float4*>(a.wfrag1);
-  const float4 f1a = SKIP(5) ? make_float4(0.f, 0.f, 0.f, 0.f) : wf1v[tid], f1b = SKIP(5) ? make_float4(0.f, 0.f, 0.f, 0.f) : wf1v[tid + NT];
   const int q0 = (p.row_end[0] * W) >> 2, q1 = ((p.row_end[1] - p.row_end[0]) * W) >> 2, q2 = ((p.row_end[2] - p.row_end[1]) * W) >> 2;
-  float4 pf0[SL0], pf1[SL1], pf2[SL2];
-  issue_chunk(pf0, a, b, 0, q0, HW, W, tid);
-  issue_chunk(pf1, a, b, p.row_end[0], q1, HW, W, tid);
-  const bool zero_old = a.frame_new != nullptr && a.reset_mask != nullptr && ld_rst != 0.f;
-  TS(1);
-
-  // ---- conv1 (16 x OH1*OW1, K = 256), chunk by chunk as the state lands in LDS.  The loads of
-  // chunk k+2 / the later weights are issued right before the matrix phase of chunk k, so the
-  // vector-memory pipe works while the MFMAs run.
-  {
-    float4* __restrict__ fv = reinterpret_cast<float4*>(fr1);
-    fv[tid] = f1a; fv[tid + NT] = f1b;
-    if (tid < 32) red[HN + tid] = ld_b2;             // conv2 bias for the K-half epilogue
-  }
   const int NP1 = p.OH1 * p.OW1;
   const float* __restrict__ la1 = fr1 + lane;
-  float4 w2a = make_float4(0.f, 0.f, 0.f, 0.f), w2b = w2a, w2c = w2a, w2d = w2a;
-  float4 wc[2][HN];
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    if (k == 0) commit_chunk<OUT>(pf0, a, b, 0, q0, HW, W, tid, zero_old, img, p.PLANE1);
-    else if (k == 1) commit_chunk<OUT>(pf1, a, b, p.row_end[0], q1, HW, W, tid, zero_old, img, p.PLANE1);
-    else commit_chunk<OUT>(pf2, a, b, p.row_end[1], q2, HW, W, tid, zero_old, img, p.PLANE1);
-    __syncthreads();
-    TS(2 + k);
-    if (k == 0) issue_chunk(pf2, a, b, p.row_end[1], q2, HW, W, tid);
-#ifdef A2C_STEP_EARLY_STORES
-    if (OUT && k == 0) store_chunk(pf0, a, b, 0, q0, HW, W, tid, zero_old);
-    if (OUT && k == 1) store_chunk(pf1, a, b, p.row_end[0], q1, HW, W, tid, zero_old);
-    if (OUT && k == 2) store_chunk(pf2, a, b, p.row_end[1], q2, HW, W, tid, zero_old);
-#else
-    if (OUT && k == 1) store_chunk(pf0, a, b, 0, q0, HW, W, tid, zero_old);
-    if (OUT && k == 2) store_chunk(pf1, a, b, p.row_end[0], q1, HW, W, tid, zero_old);
-#endif
-    if (k == 1 && !SKIP(5)) {
-      const float4* __restrict__ wf2v = reinterpret_cast<const float4*>(a.wfrag2);
-      w2a = wf2v[tid]; w2b = wf2v[tid + NT]; w2c = wf2v[tid + 2 * NT]; w2d = wf2v[tid + 3 * NT];
-    }
-    for (int tile = (k ? p.tile_end[k - 1] : 0) + w; tile < p.tile_end[k] && !SKIP(1); tile += NT / 64) {
-      const int idx = tile * 16 + j;
-      const bool ok = idx < NP1;
-      const int i = ok ? idx : 0;
-      const int r = i / p.OW1, c = i - r * p.OW1;
-      const float* __restrict__ l = img + r * 4 * W + c * 4 + g * p.PLANE1;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ky = 0; ky < 8; ++ky) {
-        const float4 t0 = *reinterpret_cast<const float4*>(l + ky * W);
-        const float4 t1 = *reinterpret_cast<const float4*>(l + ky * W + 4);
-        float av[8];
-#pragma unroll
-        for (int kx = 0; kx < 8; ++kx) av[kx] = la1[(ky * 8 + kx) * 64];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], t0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], t0.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], t0.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], t0.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4], t1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[5], t1.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[6], t1.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[7], t1.w, acc, 0, 0, 0);
-      }
-      if (ok) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) a1[(4 * g + rr) * p.PLANE2 + i] = fmaxf(acc[rr] + b1[rr], 0.f);
-      }
-    }
+  if (PERSIST) {
+    float4* __restrict__ fv = reinterpret_cast<float4*>(fr1);
+    fv[tid] = wf1v[tid]; fv[tid + NT] = wf1v[tid + NT];
+    if (tid < 32) red[HN + tid] = ld_b2;
   }
-  __syncthreads();                                   // img consumed, a1 complete
-  TS(5);
-#ifndef A2C_STEP_EARLY_STORES
-  if (OUT) store_chunk(pf2, a, b, p.row_end[1], q2, HW, W, tid, zero_old);
-#endif
-  // head weights for this thread's K slices: issued here (not with conv2's fragments before phase 2:
-  // 16 more float4 per thread on the vector-memory pipe delayed that matrix phase), in flight during conv2
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int kk = (tid << 2) + q * (NT * 4);
-#pragma unroll
-    for (int n = 0; n < HN; ++n)
-      wc[q][n] = *reinterpret_cast<const float4*>(a.Wc + (long)min(n, N - 1) * p.F + min(kk, p.F - 4));
-  }
-  {
-    float4* __restrict__ iv = reinterpret_cast<float4*>(img);
-    iv[tid] = w2a; iv[tid + NT] = w2b; iv[tid + 2 * NT] = w2c; iv[tid + 3 * NT] = w2d;
-  }
-  __syncthreads();
 
-  // ---- conv2: 32 x (OH2*OW2), K = 256 split in two halves so that the 4*ntile units spread
-  // evenly over the 8 waves; unit = (16-pixel tile, 16-channel half m, K half kh) writes its raw
-  // partial sums to LDS, the epilogue adds the halves in a fixed order (+ bias, ReLU).
-  const int NP2 = p.OH2 * p.OW2, ntile2 = (NP2 + 15) >> 4;
-  float* __restrict__ part = a2 + p.F4;              // [2][ntile2*2][256]
-  {
-    const float* __restrict__ la = img + lane;
-    for (int unit = w; unit < ntile2 * 4 && !SKIP(2); unit += NT / 64) {
-      const int kh = unit & 1, m = (unit >> 1) & 1, tile = unit >> 2;
-      const int idx = tile * 16 + j;
-      const int i = idx < NP2 ? idx : 0;
-      const int r = i / p.OW2, c = i - r * p.OW2;
-      const float* __restrict__ l = a1 + r * 2 * p.OW1 + c * 2 + g * p.PLANE2;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        const int c4 = kh * 2 + cc;
-        float bv[16], av[16];
-#pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-          const int off = c4 * 4 * p.PLANE2 + ky * p.OW1;
-          const float2 t0 = *reinterpret_cast<const float2*>(l + off);
-          const float2 t1 = *reinterpret_cast<const float2*>(l + off + 2);
-          bv[ky * 4 + 0] = t0.x; bv[ky * 4 + 1] = t0.y; bv[ky * 4 + 2] = t1.x; bv[ky * 4 + 3] = t1.y;
+  // PERSIST: this workgroup plays envs blockIdx.x, blockIdx.x + gridDim.x, ... in turn, time step by time step
+  const int nb = PERSIST ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+  const int n_it = PERSIST ? ((int)a.T + 1) * nb : 1;
+  const long S = 4L * HW;
+  for (int iter = 0; iter < n_it; ++iter) {
+    const int t = PERSIST ? iter / nb : 0;
+    const int b = PERSIST ? (int)blockIdx.x + (iter - t * nb) * (int)gridDim.x : (int)blockIdx.x;
+    // ---- what this iteration is (uniform)
+    It it;
+    bool rec, boot, sample;
+    long t_rec;
+    const float* u_ptr;
+    int64_t* act_ptr;
+    if (PERSIST) {
+      const long row = (a.slot0 + b) * a.T;
+      it.prev = t == 0 ? p.x.bookmark + (long)b * S : p.x.states + (row + t - 1) * S;
+      it.frame32 = nullptr;
+      it.frame8 = t > 0;
+      it.out = t == (int)a.T ? p.x.bookmark + (long)b * S : p.x.states + (row + t) * S;
+      rec = t > 0; t_rec = t - 1; boot = t == (int)a.T; sample = t < (int)a.T;
+      u_ptr = p.x.u + (long)t * p.x.u_stride + b;
+      act_ptr = p.x.actions + row + t;
+    } else {
+      it.prev = a.prev + (long)b * a.prev_stride;
+      it.frame32 = a.frame_new ? a.frame_new + (long)b * HW : nullptr;
+      it.frame8 = U8 && a.frame_u8 != nullptr;
+      it.out = OUT ? a.out + (long)b * a.out_stride : nullptr;
+      rec = a.rew != nullptr; t_rec = a.t_rec; boot = a.bootstrap != 0; sample = a.u != nullptr;
+      u_ptr = a.u + b;
+      act_ptr = a.actions + (long)b * a.act_stride;
+    }
+    const bool has_frame = it.frame32 != nullptr || it.frame8;
+
+    // ---- every global load of the iteration is issued here, in the order it is consumed.
+    // Bookkeeping inputs first (oldest in the in-order vmcnt queue), from always-valid addresses.
+    const long bk_e = rec ? (a.slot0 + b) * a.T + t_rec : 0;
+    const float* __restrict__ safe = a.heads + (long)b * a.ldh;
+    float ld_r, ld_d, ld_v, ld_pr, ld_pd, ld_vp, ld_rst;
+    float4 f1a, f1b;
+    u32x4 f8 = (u32x4){0u, 0u, 0u, 0u};
+    float4 pf0[SL0], pf1[SL1], pf2[SL2];
+    if (PERSIST) {
+      // values this workgroup stored in its previous iteration (same cache lines, rewritten every step):
+      // agent-scope loads are served by L2, never by a stale line of this CU's vector L1
+      ld_v = __hip_atomic_load(safe + a.n_actions, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ld_pr = __hip_atomic_load((rec && t_rec > 0) ? a.rewards + bk_e - 1 : safe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ld_pd = __hip_atomic_load((rec && t_rec > 0) ? a.dones + bk_e - 1 : safe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ld_vp = __hip_atomic_load(rec ? a.val_prev + b : safe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the 3 planes the state shares with its predecessor do not depend on the host: in flight during the wait
+      issue_chunk(pf0, it, 0, q0, HW, W, tid);
+      issue_chunk(pf1, it, p.row_end[0], q1, HW, W, tid);
+      ld_r = 0.f; ld_d = 0.f; ld_rst = 0.f;
+      if (t > 0) {
+        // wait for the env worker: rec granule = ((seq << 1 | done) << 32) | float_bits(reward), frame written before it
+        if (tid == 0) {
+          const unsigned int want = p.x.seq0 + (unsigned int)t;
+          const unsigned long long t0 = wall_clock64();
+          unsigned long long gr;
+          for (;;) {
+            gr = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned int)(gr >> 33) == want) break;
+            if ((long)(wall_clock64() - t0) > p.x.timeout_ticks) {
+              __hip_atomic_store(p.x.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              gr = ~0ULL;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+          }
+          reinterpret_cast<unsigned int*>(red)[HN + 32] = (unsigned int)gr;
+          reinterpret_cast<unsigned int*>(red)[HN + 33] = (unsigned int)(gr >> 32);
         }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) av[u] = la[((c4 * 16 + u) * 2 + m) * 64];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        __syncthreads();
+        const unsigned int g_lo = reinterpret_cast<const unsigned int*>(red)[HN + 32];
+        const unsigned int g_hi = reinterpret_cast<const unsigned int*>(red)[HN + 33];
+        if (g_hi == 0xffffffffu) break;              // host timeout: the error flag is set, give up on this slot
+        ld_r = __uint_as_float(g_lo);
+        ld_d = (g_hi & 1u) ? 1.f : 0.f;
+        ld_rst = ld_d;
+        // the frame: the whole uint8 plane in one 16-byte system-scope load per thread, over PCIe
+        __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW, 0x00020000);
+        f8 = __builtin_amdgcn_raw_buffer_load_b128(fr, tid * 16, 0, 1 | 16);   // sc0 sc1
       }
-      *reinterpret_cast<float4*>(part + ((kh * ntile2 + tile) * 2 + m) * 256 + lane * 4) = (float4){acc[0], acc[1], acc[2], acc[3]};
+    } else {
+      ld_r = *(rec ? a.rew + b : safe);
+      ld_d = *(rec ? a.done + b : safe);
+      ld_v = safe[a.n_actions];                      // value of the state the env step left
+      ld_pr = *((rec && t_rec > 0) ? a.rewards + bk_e - 1 : safe);
+      ld_pd = *((rec && t_rec > 0) ? a.dones + bk_e - 1 : safe);
+      ld_vp = *(rec ? a.val_prev + b : safe);
+      ld_rst = *((has_frame && a.reset_mask) ? a.reset_mask + b : safe);
+      f1a = SKIP(5) ? make_float4(0.f, 0.f, 0.f, 0.f) : wf1v[tid];
+      f1b = SKIP(5) ? make_float4(0.f, 0.f, 0.f, 0.f) : wf1v[tid + NT];
+      if (U8) {
+        if (it.frame8) {
+          __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.frame_u8 + (long)b * a.frame_stride), 0, HW, 0x00020000);
+          f8 = __builtin_amdgcn_raw_buffer_load_b128(fr, tid * 16, 0, 0);
+        }
+      }
+      issue_chunk(pf0, it, 0, q0, HW, W, tid);
+      issue_chunk(pf1, it, p.row_end[0], q1, HW, W, tid);
     }
-  }
-  __syncthreads();
-  {  // a2 flat (co, pixel) = relu((half0 + half1) + bias): thread = (channel, pixel lane), no division
-    const int co = tid >> 4, pl = tid & 15;
-    const float bias2 = red[HN + co];
-    const int cslot = (co >> 4) * 256 + 16 * ((co & 15) >> 2) * 4 + (co & 3);
-    for (int px = pl; px < NP2; px += 16) {
-      const int slot = (px >> 4) * 512 + (px & 15) * 4 + cslot;
-      a2[co * NP2 + px] = fmaxf((part[slot] + part[ntile2 * 512 + slot]) + bias2, 0.f);
-    }
-  }
-  __syncthreads();
-  TS(6);
+    const bool zero_old = has_frame && (PERSIST || a.reset_mask != nullptr) && ld_rst != 0.f;
+    TS(1);
 
-  // ---- heads: N dot products of length F.  Per-thread partials are transposed through LDS so
-  // that wave n reduces head n with ONE butterfly; summation order is fixed (deterministic).
-  float* __restrict__ hp = part + ntile2 * 1024;      // [HN][NT]
-  {
-    float acc[HN];
+    // ---- conv1 (16 x OH1*OW1, K = 256), chunk by chunk as the state lands in LDS.  The loads of
+    // chunk k+2 / the later weights are issued right before the matrix phase of chunk k, so the
+    // vector-memory pipe works while the MFMAs run.
+    if (!PERSIST) {
+      float4* __restrict__ fv = reinterpret_cast<float4*>(fr1);
+      fv[tid] = f1a; fv[tid + NT] = f1b;
+      if (tid < 32) red[HN + tid] = ld_b2;             // conv2 bias for the K-half epilogue
+    }
+    float4 w2a = make_float4(0.f, 0.f, 0.f, 0.f), w2b = w2a, w2c = w2a, w2d = w2a;
+    float4 wc[2][HNT];
 #pragma unroll
-    for (int n = 0; n < HN; ++n) acc[n] = 0.f;
+    for (int k = 0; k < NCH; ++k) {
+      if (k == 0) {
+        commit_chunk(pf0, it, 0, q0, W, tid, zero_old, img, p.PLANE1);
+        if (U8 && it.frame8 && tid * 16 < HW) {         // plane 3 from the uint8 frame, all rows at once
+          float4* __restrict__ d = reinterpret_cast<float4*>(img + 3 * p.PLANE1 + tid * 16);
+          d[0] = u8x4(f8[0]); d[1] = u8x4(f8[1]); d[2] = u8x4(f8[2]); d[3] = u8x4(f8[3]);
+        }
+      } else if (k == 1) commit_chunk(pf1, it, p.row_end[0], q1, W, tid, zero_old, img, p.PLANE1);
+      else commit_chunk(pf2, it, p.row_end[1], q2, W, tid, zero_old, img, p.PLANE1);
+      __syncthreads();
+      TS(2 + k);
+      if (k == 0) issue_chunk(pf2, it, p.row_end[1], q2, HW, W, tid);
+#ifdef A2C_STEP_EARLY_STORES
+      if (OUT && k == 0) store_chunk(pf0, it, 0, q0, HW, W, tid, zero_old);
+      if (OUT && k == 1) store_chunk(pf1, it, p.row_end[0], q1, HW, W, tid, zero_old);
+      if (OUT && k == 2) store_chunk(pf2, it, p.row_end[1], q2, HW, W, tid, zero_old);
+#else
+      if (OUT && k == 1) {
+        store_chunk(pf0, it, 0, q0, HW, W, tid, zero_old);
+        if (U8 && it.frame8 && tid * 16 < HW && !SKIP(0)) {
+          f32x4* __restrict__ d = reinterpret_cast<f32x4*>(it.out + 3L * HW + tid * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = u8x4(f8[q]);
+            __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, d + q);
+          }
+        }
+      }
+      if (OUT && k == 2) store_chunk(pf1, it, p.row_end[0], q1, HW, W, tid, zero_old);
+#endif
+      if (k == 1 && !SKIP(5)) {
+        const float4* __restrict__ wf2v = reinterpret_cast<const float4*>(a.wfrag2);
+        w2a = wf2v[tid]; w2b = wf2v[tid + NT]; w2c = wf2v[tid + 2 * NT]; w2d = wf2v[tid + 3 * NT];
+      }
+      for (int tile = (k ? p.tile_end[k - 1] : 0) + w; tile < p.tile_end[k] && !SKIP(1); tile += NT / 64) {
+        const int idx = tile * 16 + j;
+        const bool ok = idx < NP1;
+        const int i = ok ? idx : 0;
+        const int r = i / p.OW1, c = i - r * p.OW1;
+        const float* __restrict__ l = img + r * 4 * W + c * 4 + g * p.PLANE1;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 8; ++ky) {
+          const float4 t0 = *reinterpret_cast<const float4*>(l + ky * W);
+          const float4 t1 = *reinterpret_cast<const float4*>(l + ky * W + 4);
+          float av[8];
+#pragma unroll
+          for (int kx = 0; kx < 8; ++kx) av[kx] = la1[(ky * 8 + kx) * 64];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], t0.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], t0.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], t0.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], t0.w, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4], t1.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[5], t1.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[6], t1.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[7], t1.w, acc, 0, 0, 0);
+        }
+        if (ok) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) a1[(4 * g + rr) * p.PLANE2 + i] = fmaxf(acc[rr] + b1[rr], 0.f);
+        }
+      }
+    }
+    __syncthreads();                                   // img consumed, a1 complete
+    TS(5);
+#ifndef A2C_STEP_EARLY_STORES
+    if (OUT) store_chunk(pf2, it, p.row_end[1], q2, HW, W, tid, zero_old);
+#endif
+    // head weights for this thread's K slices: issued here (not with conv2's fragments before phase 2:
+    // 16 more float4 per thread on the vector-memory pipe delayed that matrix phase), in flight during conv2
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int k = (tid << 2) + q * (NT * 4);
-      if (k < p.F && !SKIP(3)) {
-        const float4 x = *reinterpret_cast<const float4*>(a2 + k);
+      const int kk = (tid << 2) + q * (NT * 4);
 #pragma unroll
-        for (int n = 0; n < HN; ++n)
-          if (n < N) acc[n] += x.x * wc[q][n].x + x.y * wc[q][n].y + x.z * wc[q][n].z + x.w * wc[q][n].w;
-      }
+      for (int n = 0; n < HNT; ++n)
+        wc[q][n] = *reinterpret_cast<const float4*>(a.Wc + (long)min(n, N - 1) * p.F + min(kk, p.F - 4));
     }
-#pragma unroll
-    for (int n = 0; n < HN; ++n)
-      if (n < N) hp[n * NT + tid] = acc[n];
-  }
-  __syncthreads();
-  if (w < N) {
-    float v = 0.f;
-#pragma unroll
-    for (int q = 0; q < NT / 64; ++q) v += hp[w * NT + q * 64 + lane];
-    v = wave_sum(v);
-    if (lane == 0) red[w] = v;
-  }
-  __syncthreads();
-  TS(7);
-  if (tail) {
-    // bookkeeping of the env step that produced this state (runner.py:212-232)
-    const float bk_r = ld_r, bk_v = ld_v;
-    float bk_d = ld_d != 0.f ? 1.f : 0.f;
-    if (a.pong && bk_r != 0.f) bk_d = 1.f;
-    if (rec) {
-      a.rewards[bk_e] = bk_r;
-      a.dones[bk_e] = bk_d;
-      if (a.t_rec > 0) {
-        const float gv = a.gamma * bk_v;
-        a.deltas[bk_e - 1] = (ld_pr + gv * (1.f - ld_pd)) - ld_vp;
-      }
-      a.val_prev[b] = bk_v;
+    {
+      float4* __restrict__ iv = reinterpret_cast<float4*>(img);
+      iv[tid] = w2a; iv[tid + NT] = w2b; iv[tid + 2 * NT] = w2c; iv[tid + 3 * NT] = w2d;
     }
-    float h[HN], vboot = 0.f;
+    __syncthreads();
+
+    // ---- conv2: 32 x (OH2*OW2), K = 256 split in two halves so that the 4*ntile units spread
+    // evenly over the 8 waves; unit = (16-pixel tile, 16-channel half m, K half kh) writes its raw
+    // partial sums to LDS, the epilogue adds the halves in a fixed order (+ bias, ReLU).
+    const int NP2 = p.OH2 * p.OW2, ntile2 = (NP2 + 15) >> 4;
+    float* __restrict__ part = a2 + p.F4;              // [2][ntile2*2][256]
+    {
+      const float* __restrict__ la = img + lane;
+      for (int unit = w; unit < ntile2 * 4 && !SKIP(2); unit += NT / 64) {
+        const int kh = unit & 1, m = (unit >> 1) & 1, tile = unit >> 2;
+        const int idx = tile * 16 + j;
+        const int i = idx < NP2 ? idx : 0;
+        const int r = i / p.OW2, c = i - r * p.OW2;
+        const float* __restrict__ l = a1 + r * 2 * p.OW1 + c * 2 + g * p.PLANE2;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int n = 0; n < HN; ++n) {
-      h[n] = 0.f;
-      if (n < N) {
-        h[n] = red[n] + a.bc[n];
-        a.heads[(long)b * a.ldh + n] = h[n];
-        if (n == a.n_actions) vboot = h[n];
-      }
-    }
-    if (a.u != nullptr) {        // same maths as sample_kernel<true>: softmax, running fp32 cumsum, first >= u
-      float mx = -INFINITY;
+        for (int cc = 0; cc < 2; ++cc) {
+          const int c4 = kh * 2 + cc;
+          float bv[16], av[16];
 #pragma unroll
-      for (int n = 0; n < HN; ++n)
-        if (n < a.n_actions) mx = fmaxf(mx, h[n]);
-      float den = 0.f;
+          for (int ky = 0; ky < 4; ++ky) {
+            const int off = c4 * 4 * p.PLANE2 + ky * p.OW1;
+            const float2 t0 = *reinterpret_cast<const float2*>(l + off);
+            const float2 t1 = *reinterpret_cast<const float2*>(l + off + 2);
+            bv[ky * 4 + 0] = t0.x; bv[ky * 4 + 1] = t0.y; bv[ky * 4 + 2] = t1.x; bv[ky * 4 + 3] = t1.y;
+          }
 #pragma unroll
-      for (int n = 0; n < HN; ++n)
-        if (n < a.n_actions) den += expf(h[n] - mx);
-      const float ub = a.u[b];
-      float cs = 0.f;
-      int pick = -1;
+          for (int u = 0; u < 16; ++u) av[u] = la[((c4 * 16 + u) * 2 + m) * 64];
 #pragma unroll
-      for (int n = 0; n < HN; ++n)
-        if (n < a.n_actions) {
-          cs = cs + expf(h[n] - mx) / den;
-          if (pick < 0 && cs >= ub) pick = n;
+          for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
-      a.actions[(long)b * a.act_stride] = (int64_t)pick;
-    }
-    if (a.bootstrap && rec) {  // runner.py:236-245 on the step recorded above (e = slot*T + T-1)
-      float r = bk_r;
-      if (bk_d == 0.f) {
-        r = r + a.gamma * vboot;
-        a.rewards[bk_e] = r;
-        a.dones[bk_e] = 1.f;
+        *reinterpret_cast<float4*>(part + ((kh * ntile2 + tile) * 2 + m) * 256 + lane * 4) = (float4){acc[0], acc[1], acc[2], acc[3]};
       }
-      a.deltas[bk_e] = r - bk_v;
+    }
+    __syncthreads();
+    {  // a2 flat (co, pixel) = relu((half0 + half1) + bias): thread = (channel, pixel lane), no division
+      const int co = tid >> 4, pl = tid & 15;
+      const float bias2 = red[HN + co];
+      const int cslot = (co >> 4) * 256 + 16 * ((co & 15) >> 2) * 4 + (co & 3);
+      for (int px = pl; px < NP2; px += 16) {
+        const int slot = (px >> 4) * 512 + (px & 15) * 4 + cslot;
+        a2[co * NP2 + px] = fmaxf((part[slot] + part[ntile2 * 512 + slot]) + bias2, 0.f);
+      }
+    }
+    __syncthreads();
+    TS(6);
+
+    // ---- heads: N dot products of length F.  Per-thread partials are transposed through LDS so
+    // that wave n reduces head n with ONE butterfly; summation order is fixed (deterministic).
+    float* __restrict__ hp = part + ntile2 * 1024;      // [HN][NT]
+    {
+      float acc[HNT];
+#pragma unroll
+      for (int n = 0; n < HNT; ++n) acc[n] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = (tid << 2) + q * (NT * 4);
+        if (k < p.F && !SKIP(3)) {
+          const float4 x = *reinterpret_cast<const float4*>(a2 + k);
+#pragma unroll
+          for (int n = 0; n < HNT; ++n)
+            if (n < N) acc[n] += x.x * wc[q][n].x + x.y * wc[q][n].y + x.z * wc[q][n].z + x.w * wc[q][n].w;
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < HNT; ++n)
+        if (n < N) hp[n * NT + tid] = acc[n];
+    }
+    __syncthreads();
+    if (w < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < NT / 64; ++q) v += hp[w * NT + q * 64 + lane];
+      v = wave_sum(v);
+      if (lane == 0) red[w] = v;
+    }
+    __syncthreads();
+    TS(7);
+    if (tail) {
+      // bookkeeping of the env step that produced this state (runner.py:212-232)
+      const float bk_r = ld_r, bk_v = ld_v;
+      float bk_d = ld_d != 0.f ? 1.f : 0.f;
+      if (a.pong && bk_r != 0.f) bk_d = 1.f;
+      if (rec) {
+        a.rewards[bk_e] = bk_r;
+        a.dones[bk_e] = bk_d;
+        if (t_rec > 0) {
+          const float gv = a.gamma * bk_v;
+          a.deltas[bk_e - 1] = (ld_pr + gv * (1.f - ld_pd)) - ld_vp;
+        }
+        a.val_prev[b] = bk_v;
+      }
+      float h[HNT], vboot = 0.f;
+#pragma unroll
+      for (int n = 0; n < HNT; ++n) {
+        h[n] = 0.f;
+        if (n < N) {
+          h[n] = red[n] + a.bc[n];
+          a.heads[(long)b * a.ldh + n] = h[n];
+          if (n == a.n_actions) vboot = h[n];
+        }
+      }
+      if (sample) {              // same maths as sample_kernel<true>: softmax, running fp32 cumsum, first >= u
+        float mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < HNT; ++n)
+          if (n < a.n_actions) mx = fmaxf(mx, h[n]);
+        float den = 0.f;
+#pragma unroll
+        for (int n = 0; n < HNT; ++n)
+          if (n < a.n_actions) den += expf(h[n] - mx);
+        const float ub = *u_ptr;
+        float cs = 0.f;
+        int pick = -1;
+#pragma unroll
+        for (int n = 0; n < HNT; ++n)
+          if (n < a.n_actions) {
+            cs = cs + expf(h[n] - mx) / den;
+            if (pick < 0 && cs >= ub) pick = n;
+          }
+        if (pick < 0) pick = a.n_actions - 1;          // fp32 cumsum short of u: the last action (see sample_kernel)
+        *act_ptr = (int64_t)pick;
+        if (PERSIST)     // hand the action to the env worker: one 8-byte granule {step number, action} in pinned host memory
+          __hip_atomic_store(p.x.cmd + p.x.env0 + b,
+                             ((unsigned long long)(p.x.seq0 + (unsigned int)t) << 32) | (unsigned int)pick,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (boot && rec) {  // runner.py:236-245 on the step recorded above (e = slot*T + T-1)
+        float r = bk_r;
+        if (bk_d == 0.f) {
+          r = r + a.gamma * vboot;
+          a.rewards[bk_e] = r;
+          a.dones[bk_e] = 1.f;
+        }
+        a.deltas[bk_e] = r - bk_v;
+      }
+    }
+    TS(8);
+    if (PERSIST) {
+      // the next iteration re-reads what this one stored (state row, heads, records): every wave drains its
+      // stores, then the workgroup meets; this barrier also frees the LDS regions the heads phase read
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
   }
-  TS(8);
 }
 
 static inline int plane_pad(int n, int mod64) {      // smallest p >= n with p % 64 == mod64
@@ -392,7 +548,22 @@ static bool step_shapes(int C, int H, int W, int n_actions, StepP& p) {
   }
   return true;
 }
-static size_t step_lds(const StepP& p) { return 4 * ((size_t)NF1 + (size_t)4 * p.PLANE1 + (size_t)16 * p.PLANE2 + 8 * HN + 16); }
+// uint8 frames: one 16-byte load per thread must cover the plane
+static bool u8_shapes(int H, int W) { return (H * W) % 16 == 0 && H * W <= 16 * NT; }
+static size_t step_lds(const StepP& p) { return 4 * ((size_t)NF1 + (size_t)4 * p.PLANE1 + (size_t)16 * p.PLANE2 + 8 * HN + 16 + 32); }
+
+static bool set_lds_attr() {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* ks[] = {(const void*)a3c_step_kernel<true, false, false>, (const void*)a3c_step_kernel<false, false, false>,
+                        (const void*)a3c_step_kernel<true, true, false>, (const void*)a3c_step_kernel<false, true, false>,
+                        (const void*)a3c_step_kernel<true, true, true, 4>, (const void*)a3c_step_kernel<true, true, true, 8>};
+    for (const void* k : ks)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    attr_set = true;
+  }
+  return true;
+}
 }  // namespace
 
 extern "C" {
@@ -413,6 +584,7 @@ int a2c_a3c_step(const a2c_a3c_step_args* args, a2c_stream_t stream) {
   if (!args) return A2C_ERR_ARG;
   StepP p;
   p.a = *args;
+  p.x = RolloutX{};
   const a2c_a3c_step_args& a = p.a;
   if (a.B < 0) return A2C_ERR_ARG;
   if (a.B == 0) return A2C_OK;
@@ -425,16 +597,54 @@ int a2c_a3c_step(const a2c_a3c_step_args* args, a2c_stream_t stream) {
   if (a.bootstrap && (!a.rew || a.t_rec != a.T - 1)) return A2C_ERR_ARG;
   if (a.prev_stride % 4 || (a.out && a.out_stride % 4) || a.ldh < a.n_actions + 1) return A2C_ERR_ARG;
   if ((((uintptr_t)a.prev | (uintptr_t)a.frame_new | (uintptr_t)a.out | (uintptr_t)a.wfrag2 | (uintptr_t)a.Wc) % 16)) return A2C_ERR_ARG;
+  if (a.frame_u8 && (a.frame_new || !u8_shapes(a.H, a.W) || a.frame_stride % 16 || (uintptr_t)a.frame_u8 % 16 ||
+                     a.frame_stride < a.H * a.W))
+    return A2C_ERR_ARG;
   const size_t lds = step_lds(p);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)a3c_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)a3c_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return A2C_ERR_LAUNCH;
-    attr_set = true;
+  if (!set_lds_attr()) return A2C_ERR_LAUNCH;
+  if (a.frame_u8) {
+    if (a.out) hipLaunchKernelGGL((a3c_step_kernel<true, true, false>), dim3(a.B), dim3(NT), lds, a2c_s(stream), p);
+    else hipLaunchKernelGGL((a3c_step_kernel<false, true, false>), dim3(a.B), dim3(NT), lds, a2c_s(stream), p);
+  } else {
+    if (a.out) hipLaunchKernelGGL((a3c_step_kernel<true, false, false>), dim3(a.B), dim3(NT), lds, a2c_s(stream), p);
+    else hipLaunchKernelGGL((a3c_step_kernel<false, false, false>), dim3(a.B), dim3(NT), lds, a2c_s(stream), p);
   }
-  if (a.out) hipLaunchKernelGGL(a3c_step_kernel<true>, dim3(a.B), dim3(NT), lds, a2c_s(stream), p);
-  else hipLaunchKernelGGL(a3c_step_kernel<false>, dim3(a.B), dim3(NT), lds, a2c_s(stream), p);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
+  if (!r) return A2C_ERR_ARG;
+  if (r->B < 0) return A2C_ERR_ARG;
+  if (r->B == 0) return A2C_OK;
+  StepP p;
+  p.a = a2c_a3c_step_args{};
+  a2c_a3c_step_args& a = p.a;
+  a.B = r->B; a.C = r->C; a.H = r->H; a.W = r->W; a.n_actions = r->n_actions;
+  a.wfrag1 = r->wfrag1; a.bias1 = r->bias1; a.wfrag2 = r->wfrag2; a.bias2 = r->bias2; a.Wc = r->Wc; a.bc = r->bc;
+  a.heads = r->heads; a.ldh = r->ldh;
+  a.val_prev = r->val_prev; a.rewards = r->rewards; a.dones = r->dones; a.deltas = r->deltas;
+  a.T = r->T; a.slot0 = r->slot0; a.gamma = r->gamma; a.pong = r->pong;
+  a.frame_u8 = r->frames; a.frame_stride = r->frame_stride;
+  p.x.states = r->states; p.x.bookmark = r->bookmark; p.x.u = r->u; p.x.u_stride = (long)r->u_stride;
+  p.x.actions = r->actions; p.x.cmd = (unsigned long long*)r->cmd; p.x.rec = (const unsigned long long*)r->rec;
+  p.x.seq0 = r->seq0; p.x.env0 = r->env0; p.x.err = r->err; p.x.timeout_ticks = (long)r->timeout_ticks;
+  if (!step_shapes(a.C, a.H, a.W, a.n_actions, p) || step_lds(p) > 160 * 1024 || !u8_shapes(a.H, a.W)) return A2C_ERR_ARG;
+  if (!r->states || !r->bookmark || !r->u || !r->actions || !r->cmd || !r->rec || !r->frames || !r->err) return A2C_ERR_ARG;
+  if (!a.wfrag1 || !a.bias1 || !a.wfrag2 || !a.bias2 || !a.Wc || !a.bc || !a.heads) return A2C_ERR_ARG;
+  if (!a.val_prev || !a.rewards || !a.dones || !a.deltas || a.T < 1 || a.ldh < a.n_actions + 1) return A2C_ERR_ARG;
+  if (r->frame_stride % 16 || r->frame_stride < a.H * a.W || r->timeout_ticks < 1 || r->env0 < 0) return A2C_ERR_ARG;
+  if ((((uintptr_t)r->states | (uintptr_t)r->bookmark | (uintptr_t)r->frames | (uintptr_t)a.wfrag2 | (uintptr_t)a.Wc) % 16) ||
+      (((uintptr_t)r->cmd | (uintptr_t)r->rec) % 8))
+    return A2C_ERR_ARG;
+  const size_t lds = step_lds(p);
+  if (!set_lds_attr()) return A2C_ERR_LAUNCH;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  // one workgroup per CU at most (157 KB of LDS each): all of them resident, envs beyond that take turns
+  const int grid = a.B < cus ? a.B : cus;
+  if (a.n_actions + 1 <= 4) hipLaunchKernelGGL((a3c_step_kernel<true, true, true, 4>), dim3(grid), dim3(NT), lds, a2c_s(stream), p);
+  else hipLaunchKernelGGL((a3c_step_kernel<true, true, true, 8>), dim3(grid), dim3(NT), lds, a2c_s(stream), p);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -91,3 +91,31 @@ def sample_idx(n):
     return (np.arange(SAMPLE, dtype=np.int64) * 2654435761 % max(n, 1)).astype(np.int64)
 
 
+
+
+class U8FakeEnv(O.FakeEnv):
+    """O.FakeEnv with its (binary) frames as uint8, like pong_prep's output (preprocessing.py:11-17): the
+    host pool then carries uint8 frames; values are identical to FakeEnv's float64 ones."""
+
+    def _frame(self):
+        return super()._frame().astype(np.uint8)
+
+
+class F32FakeEnv(O.FakeEnv):
+    """O.FakeEnv with grey-level frames (b/255, like breakout_prep's rgb2grey floats): fp32 transport"""
+
+    def __init__(self, **kw):
+        super().__init__(binary=False, **kw)
+
+
+class FailingEnv(U8FakeEnv):
+    """raises inside step() after `fail_at` steps (worker-failure propagation tests)"""
+
+    def __init__(self, fail_at=3, **kw):
+        super().__init__(**kw)
+        self.fail_at = fail_at
+
+    def step(self, action):
+        if self.t >= self.fail_at:
+            raise RuntimeError("env crashed (test)")
+        return super().step(action)

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_prototypes():
-    src = open(os.path.join(ROOT, "include", "a2c_mi355x.h")).read()
+def header_prototypes(header="a2c_mi355x.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(a2c_[a-z0-9_]+)\s*\(", src)))
 
@@ -31,8 +31,22 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (a2c_[a-z0-9_]+)", out))
     assert set(names) <= exported, set(names) - exported
-    assert lib.a2c_version() == 1
+    assert lib.a2c_version() == 2
     assert lib.a2c_error_string(-1) == b"invalid argument"
+
+
+def test_hostpool_library_exports_every_declared_symbol():
+    """include/a2c_hostpool.h <-> liba2c_hostpool.so (plain C, loaded by the env worker processes) and it
+    must not depend on the HIP runtime"""
+    from a2c_amd import hostpool
+    hostpool.pool_lib()
+    names = header_prototypes("a2c_hostpool.h")
+    assert sorted(hostpool.POOL_SIGNATURES) == names, set(hostpool.POOL_SIGNATURES) ^ set(names)
+    out = subprocess.run(["nm", "-D", "--defined-only", hostpool.POOL_LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (a2c_[a-z0-9_]+)", out))
+    assert set(names) <= exported, set(names) - exported
+    ldd = subprocess.run(["ldd", hostpool.POOL_LIB_PATH], capture_output=True, text=True).stdout
+    assert "amdhip" not in ldd and "hsa" not in ldd
 
 
 def test_argument_validation_without_gpu():
@@ -54,6 +68,11 @@ def test_argument_validation_without_gpu():
     assert lib.a2c_a3c_step(None, None) == -1
     args = _lib.A3CStepArgs(B=2, C=4, H=84, W=84, n_actions=6)       # all pointers NULL
     assert lib.a2c_a3c_step(ctypes.byref(args), None) == -1
+    assert lib.a2c_a3c_rollout(None, None) == -1
+    rargs = _lib.A3CRolloutArgs(B=2, C=4, H=84, W=84, n_actions=3, T=4)
+    assert lib.a2c_a3c_rollout(ctypes.byref(rargs), None) == -1
+    assert lib.a2c_frame_stack_push_u8(None, 7056, None, None, 0, None, 0, 2, 4, 7056, None) == -1
+    assert lib.a2c_memcpy_async(None, None, 0, 1, None) == 0 and lib.a2c_memcpy_async(None, None, 8, 1, None) == -1
 
 
 def test_product_refuses_cpu_tensors():

@@ -1,0 +1,228 @@
+"""-m gpu: the north-star ingest -- env stepping in host worker processes, frames through ONE pinned,
+device-mapped region (uint8 when the preprocessor yields uint8) -- against the CPU oracle's batch-1
+runners on the same deterministic envs (runner.py:174-248).  Covers both ingest modes of the Runner
+(memcpy: hipMemcpyAsync per step, every model; zero-copy: the persistent one-launch rollout
+a2c_a3c_rollout), rollout -> update -> rollout sequences (stale derived weights would show), more envs
+than CUs, fp32 frames, worker failure and the host time-out of the persistent kernel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import a2c_oracle as O  # noqa: E402
+from cases import F32FakeEnv, FailingEnv, U8FakeEnv, base_hyps, hashf  # noqa: E402
+from test_gpu_kernels import close  # noqa: E402
+from test_gpu_models import _datas, make_net  # noqa: E402
+
+DEV = "cuda"
+
+
+def _pool(cls, ekws, n_workers, **kw):
+    from a2c_amd.hostpool import ProcessEnvPool
+    return ProcessEnvPool(cls, len(ekws), env_kwargs=ekws, n_workers=n_workers, probe_reset=True, **kw)
+
+
+def _oracle_rollouts(kind, onet, hyps, ekws, us, n_rounds, B, T, ss, env_cls=O.FakeEnv, updater=None):
+    """env j plays slot j of every round; `updater` (oracle) runs between rounds when given"""
+    N = B * T
+    Do = dict(states=torch.zeros(N, *ss), deltas=torch.zeros(N), rewards=torch.zeros(N), dones=torch.zeros(N),
+              actions=torch.zeros(N).long())
+    if onet.is_recurrent:
+        Do["h_states"] = torch.zeros(N, onet.h_size)
+    runners = []
+    for j in range(B):
+        seq = iter([float(us[k, t, j]) for k in range(n_rounds) for t in range(T)])
+        sr = O.SlotRunner(env_cls(**ekws[j]), Do, hyps, uniform_fn=lambda seq=seq: next(seq))
+        sr.start(onet)
+        runners.append(sr)
+    outs = []
+    for k in range(n_rounds):
+        for j in range(B):
+            runners[j].rollout(onet, j)
+        outs.append({n: v.clone() for n, v in Do.items()})
+        if updater is not None and k + 1 < n_rounds:
+            outs[-1]["info"] = updater.update_model(Do)
+    return outs
+
+
+def _compare_round(D, ref, recurrent, tol=1e-5):
+    assert torch.equal(D["actions"].cpu(), ref["actions"])
+    assert torch.equal(D["dones"].cpu(), ref["dones"])
+    assert torch.equal(D["states"].cpu(), ref["states"])
+    close("rewards", D["rewards"], ref["rewards"], tol, tol)
+    close("deltas", D["deltas"], ref["deltas"], tol, tol)
+    if recurrent:
+        close("h_states", D["h_states"], ref["h_states"], tol, tol)
+
+
+@pytest.mark.parametrize("kind,ingest,fused", [("A3CModel", "zero-copy", True), ("A3CModel", "memcpy", True),
+                                               ("A3CModel", "memcpy", False), ("GRUModel", "memcpy", False),
+                                               ("ConvModel", "memcpy", False), ("FCModel", "memcpy", False)])
+def test_process_pool_rollouts_match_oracle(kind, ingest, fused, monkeypatch):
+    """two consecutive rounds of B slots (the second continues the envs, bookmarks and hidden states)"""
+    from a2c_amd.runner import Runner
+    if not fused:
+        monkeypatch.setenv("A2C_NO_FUSED_STEP", "1")
+    B, T, A, ss = 5, 6, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=3 + j % 3, done_period=5 + 2 * j) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0" if kind == "A3CModel" else "FakeBreakout", n_tsteps=T, n_rollouts=B,
+                     action_shift=0, n_envs=B, env_timeout_s=20.0)
+    net = make_net(kind, ss, A, 256)
+    onet = O.OracleNet(kind, ss, A, 256)
+    D = _datas(B * T, ss, net.is_recurrent, actions_on_host=(kind == "GRUModel"))
+    us = torch.from_numpy(hashf(2 * T * B, 901, 0, 1).reshape(2, T, B))
+    usd = us.to(DEV)
+    rnd = [0]
+    pool = _pool(U8FakeEnv, ekws, 2, pong="Pong" in hyps["env_type"])
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest,
+               uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+    try:
+        refs = _oracle_rollouts(kind, onet, hyps, ekws, us, 2, B, T, ss)
+        for rnd[0] in range(2):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            _compare_round(D, refs[rnd[0]], net.is_recurrent)
+        assert pool.frame_dtype == np.uint8 and pool.seq == 2 * T
+        if ingest == "zero-copy":
+            assert r._zero_copy_ok(net)
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("kind,ingest", [("A3CModel", "zero-copy"), ("A3CModel", "memcpy"), ("GRUModel", "memcpy")])
+def test_rollout_update_rollout_matches_oracle(kind, ingest):
+    """three rounds with update_model in between (training.py:163-165): the rollout after an optimiser step
+    must use the NEW weights (derived inference weights -- composed heads, conv fragments -- re-built)"""
+    from a2c_amd.runner import Runner
+    from a2c_amd.updater import Updater
+    B, T, A, ss = 4, 5, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-2,
+                     optim_type="RMSprop")
+    net = make_net(kind, ss, A, 256)
+    onet = O.OracleNet(kind, ss, A, 256)
+    D = _datas(B * T, ss, net.is_recurrent, actions_on_host=False)
+    us = torch.from_numpy(hashf(3 * T * B, 977, 0, 1).reshape(3, T, B))
+    usd = us.to(DEV)
+    rnd = [0]
+    pool = _pool(U8FakeEnv, ekws, 2, pong=True)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest,
+               uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+    upd = Updater(net, hyps)
+    try:
+        refs = _oracle_rollouts(kind, onet, hyps, ekws, us, 3, B, T, ss, updater=O.OracleUpdater(onet, hyps))
+        for rnd[0] in range(3):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            # lr = 1e-2 moves the weights by ~1e-2 per step: stale weights would change values by >> tolerance;
+            # after two such steps the nets agree to ~1e-4 relative (RMSprop's 1/sqrt(v) amplifies 1e-7 gradient noise)
+            tol = 1e-5 if rnd[0] == 0 else 2e-3
+            assert torch.equal(D["states"].cpu(), refs[rnd[0]]["states"])
+            assert torch.equal(D["dones"].cpu(), refs[rnd[0]]["dones"])
+            close("deltas", D["deltas"], refs[rnd[0]]["deltas"], tol, tol)
+            mism = (D["actions"].cpu() != refs[rnd[0]]["actions"]).sum().item()
+            assert mism == 0 if rnd[0] == 0 else mism <= 1, mism
+            if rnd[0] < 2:
+                info = upd.update_model(D)
+                oi = refs[rnd[0]]["info"]
+                for k in oi:
+                    assert abs(info[k] - oi[k]) <= 1e-4 + 2e-3 * abs(oi[k]), (rnd[0], k, info[k], oi[k])
+        # and the weights really moved: round 2's values differ from what the ORIGINAL weights give
+        assert not torch.allclose(D["deltas"].cpu(), _oracle_rollouts(kind, O.OracleNet(kind, ss, A, 256), hyps, ekws, us, 3, B,
+                                                                      T, ss)[2]["deltas"], atol=1e-3)
+    finally:
+        r.close()
+
+
+def test_zero_copy_more_envs_than_cus_and_sampled_oracle():
+    """300 envs on 256 CUs: workgroups play several envs in turn (a2c_a3c_rollout); every env's data against
+    the layered per-step path, sampled envs against the oracle"""
+    from a2c_amd.runner import Runner
+    B, T, A, ss = 300, 4, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=2 + j % 3, done_period=3 + j % 7) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    us = torch.from_numpy(hashf(T * B, 31337, 0, 1).reshape(1, T, B))
+    usd = us.to(DEV)
+    out = {}
+    for ingest in ("zero-copy", "memcpy"):
+        net = make_net("A3CModel", ss, A, 256)
+        D = _datas(B * T, ss, False, actions_on_host=False)
+        pool = _pool(U8FakeEnv, ekws, 6, pong=True)
+        r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest,
+                   uniform_fn=lambda t, Bn, env0: usd[0, t, env0:env0 + Bn].contiguous())
+        try:
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+        finally:
+            r.close()
+        out[ingest] = {k: v.cpu() for k, v in D.items()}
+    for k in ("states", "actions", "dones", "rewards", "deltas"):
+        assert torch.equal(out["zero-copy"][k], out["memcpy"][k]), k
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    for j in (0, 137, 255, 256, 299):
+        Do = dict(states=torch.zeros(T, *ss), deltas=torch.zeros(T), rewards=torch.zeros(T), dones=torch.zeros(T),
+                  actions=torch.zeros(T).long())
+        it = iter([float(us[0, t, j]) for t in range(T)])
+        sr = O.SlotRunner(O.FakeEnv(**ekws[j]), Do, hyps, uniform_fn=lambda it=it: next(it))
+        sr.start(onet)
+        sr.rollout(onet, 0)
+        sl = slice(j * T, (j + 1) * T)
+        assert torch.equal(out["zero-copy"]["actions"][sl], Do["actions"]) and torch.equal(out["zero-copy"]["states"][sl], Do["states"])
+        close("deltas", out["zero-copy"]["deltas"][sl], Do["deltas"], 1e-5, 1e-5)
+
+
+def test_fp32_frames_travel_as_fp32():
+    """grey-level float frames (breakout_prep-like) keep the fp32 transport"""
+    from a2c_amd.runner import Runner
+    B, T, A, ss = 3, 5, 4, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=3, done_period=4 + j) for j in range(B)]
+    hyps = base_hyps(env_type="FakeBreakout", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    net = make_net("A3CModel", ss, A, 256)
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    D = _datas(B * T, ss, False)
+    us = torch.from_numpy(hashf(T * B, 77, 0, 1).reshape(1, T, B))
+    usd = us.to(DEV)
+    pool = _pool(F32FakeEnv, ekws, 2)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, uniform_fn=lambda t, Bn, env0: usd[0, t, env0:env0 + Bn].contiguous())
+    try:
+        ref = _oracle_rollouts("A3CModel", onet, hyps, ekws, us, 1, B, T, ss, env_cls=F32FakeEnv)[0]
+        r.rollout(net, list(range(B)), hyps)
+        r.finish()
+        assert pool.frame_dtype == np.float32 and not r._zero_copy_ok(net)
+        _compare_round(D, ref, False)
+    finally:
+        r.close()
+
+
+def test_persistent_rollout_times_out_instead_of_hanging():
+    """an env worker that dies mid-slot: the kernel's bounded wait sets the error flag and the launch ends"""
+    from a2c_amd.runner import Runner
+    B, T, A, ss = 4, 8, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, fail_at=3 if j == 1 else 10 ** 9) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, env_timeout_s=1.0)
+    net = make_net("A3CModel", ss, A, 256)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    pool = _pool(FailingEnv, ekws, 2, pong=True)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy")
+    try:
+        r.rollout(net, list(range(B)), hyps)
+        with pytest.raises((TimeoutError, RuntimeError)):
+            r.finish()
+    finally:
+        r.close()
+
+
+def test_rollout_sampler_never_returns_minus_one():
+    """u = nextafter(1, 0): the fp32 cumsum of a softmax can stay below it; the rollout samplers return the
+    last action (what -1 indexes in the loss, updater.py:104), utils.sample_action keeps the reference's -1"""
+    from a2c_amd import ops, utils
+    A, B = 3, 64
+    logits = torch.from_numpy(hashf(B * A, 5, -3, 3).reshape(B, A)).to(DEV)
+    u = torch.full((B,), float(np.nextafter(np.float32(1), np.float32(0))), device=DEV)
+    acts = torch.zeros(B, dtype=torch.int64, device=DEV)
+    ops.softmax_sample(logits, u, acts.data_ptr(), 1, B, A)
+    torch.cuda.synchronize()
+    assert int(acts.min()) >= 0 and int(acts.max()) == A - 1
+    p = torch.tensor([[.3, .3, .3]])
+    assert float(utils.sample_action(p, rand_nums=torch.tensor([.95]))) == -1.0

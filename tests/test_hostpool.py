@@ -1,0 +1,109 @@
+"""CPU: the host env pool (worker processes + pinned-region protocol, include/a2c_hostpool.h) without a GPU.
+The test process plays the device's part of the protocol (post actions, wait for the rec granules, read
+the frames) and checks every frame byte, reward and done flag against the same envs stepped in-process
+exactly like the reference's loop body does (runner.py:207-227)."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from cases import F32FakeEnv, FailingEnv, U8FakeEnv
+from a2c_amd.hostpool import IDLE, ROLLOUT, ProcessEnvPool, pool_lib
+from a2c_amd.synthetic import TapeEnv
+
+
+def _ref_step(env, a, shift):
+    obs, rew, done, _ = env.step(a + shift)
+    if done:
+        obs = env.reset()
+    return np.asarray(obs), rew, done
+
+
+@pytest.mark.parametrize("cls,dtype", [(U8FakeEnv, np.uint8), (F32FakeEnv, np.float32), (TapeEnv, np.uint8)])
+def test_pool_matches_in_process_envs(cls, dtype):
+    B, W, K, shift = 7, 3, 40, 1
+    if cls is TapeEnv:
+        kws = [dict(env_id=j, length=17, p_done=0.1) for j in range(B)]
+    else:
+        kws = [dict(env_id=j, rew_period=3 + j % 3, done_period=5 + j) for j in range(B)]
+    pool = ProcessEnvPool(cls, B, env_kwargs=kws, n_workers=W, action_shift=shift, pong=True, register=False)
+    try:
+        pool.start()
+        assert pool.frame_dtype == dtype and pool.frame_shape == (1, 84, 84)
+        assert pool.header.n_workers == W and pool.header.frame_stride % 16 == 0
+        pool.set_phase(ROLLOUT)
+        refs = [cls(**kw) for kw in kws]
+        fr = pool.frames_view()
+        rew, done = np.zeros(B, np.float32), np.zeros(B, np.float32)
+        pool.wait_frames(0)
+        pool.unpack(rew, done)
+        assert (done == 1).all() and (rew == 0).all()           # frame 0: env.reset(), frame stack restarts
+        for j in range(B):
+            assert np.array_equal(fr[j], np.asarray(refs[j].reset()).astype(dtype))
+        ema, ep = -1.0, [0.0] * B
+        n_eps = 0
+        for k in range(K):
+            acts = ((np.arange(B) * 7 + k) % 3 - (k % 5 == 0)).astype(np.int64)     # includes the -1 of sample_action
+            pool.post_actions(acts, seq=k)
+            pool.wait_frames(k + 1)
+            pool.unpack(rew, done)
+            for j in range(B):
+                o, r, d = _ref_step(refs[j], int(acts[j]), shift)
+                assert np.array_equal(fr[j], o.astype(dtype)), (k, j)
+                assert rew[j] == np.float32(r) and done[j] == float(d), (k, j)
+                ep[j] += r
+                if d or r != 0:       # Pong: an episode ends whenever a point is scored (runner.py:212-217)
+                    n_eps += 1
+                    ep[j] = 0.0
+        assert pool.header.episodes == n_eps and n_eps > 0
+        # the EMA is order dependent across workers (as across the reference's processes): check its range only
+        assert -1.0 <= pool.rew_ema() <= 1.0
+        pool.set_phase(IDLE)
+    finally:
+        pool.close()
+    assert not os.path.exists("/dev/shm/" + pool.name)
+
+
+def test_pool_worker_exception_reaches_the_gpu_process():
+    B = 4
+    kws = [dict(env_id=j, fail_at=2 if j == 2 else 10 ** 9) for j in range(B)]
+    pool = ProcessEnvPool(FailingEnv, B, env_kwargs=kws, n_workers=2, register=False)
+    try:
+        pool.start()
+        pool.set_phase(ROLLOUT)
+        acts = np.zeros(B, np.int64)
+        with pytest.raises(RuntimeError, match="env worker"):
+            for k in range(5):
+                pool.post_actions(acts, seq=k)
+                pool.wait_frames(k + 1, timeout=20.0)
+    finally:
+        pool.close()
+
+
+def test_pool_workers_do_not_import_torch_or_hip():
+    """the worker program and the pool library must stay free of the GPU runtime"""
+    import subprocess
+    code = ("import sys; sys.argv=['x']; import a2c_amd.hostpool, a2c_amd.hostpool_worker, a2c_amd.synthetic; "
+            "a2c_amd.hostpool.pool_lib(); assert 'torch' not in sys.modules, 'torch imported'; "
+            "assert not any('amdhip' in l for l in open('/proc/self/maps')), 'HIP runtime mapped'; print('clean')")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join(sys.path))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert out.stdout.strip() == "clean", out.stderr
+
+
+def test_pool_idle_phase_does_not_spin():
+    pool = ProcessEnvPool(TapeEnv, 2, env_kwargs=[dict(env_id=j, length=9) for j in range(2)], n_workers=2, register=False)
+    try:
+        pool.start()
+        pool.set_phase(IDLE)
+        time.sleep(0.2)
+        import psutil
+        for p in pool.procs:
+            psutil.Process(p.pid).cpu_percent()
+        time.sleep(0.5)
+        busy = [psutil.Process(p.pid).cpu_percent() for p in pool.procs]
+        assert max(busy) < 50.0, busy
+    finally:
+        pool.close()

@@ -94,6 +94,32 @@ int a2c_pool_wait_frames(void *base, int env0, int n, uint32_t seq, int64_t time
 void a2c_pool_unpack(const void *base, int env0, int n, float *rew, float *done);
 double a2c_pool_rew_ema(const void *base);
 
+/* ---- native env workers (threads of the GPU process) ------------------------------------
+ * For envs implemented in C: n_threads pthreads inside this process play the worker loop above
+ * (a2c_pool_take -> step -> reset on done -> publish) without Python.  The env writes its observation
+ * STRAIGHT into its pinned frame slot (no staging copy).  Python gym envs use worker processes
+ * instead (a2c_amd.hostpool_worker); both speak the same protocol to the device.               */
+typedef struct {
+  /* write the observation of a fresh episode into frame_out */
+  void (*reset)(void *env, void *frame_out);
+  /* one env step: observation into frame_out, reward and real done; on done the pool calls reset() next */
+  void (*step)(void *env, int32_t action, void *frame_out, float *rew, int *done);
+} a2c_env_vtable;
+typedef struct a2c_pool_threads a2c_pool_threads;
+/* starts the threads; they publish frame 0 of every env before the call returns.  NULL on error.  */
+a2c_pool_threads *a2c_pool_threads_start(void *base, int n_threads, const a2c_env_vtable *vt,
+                                         void *const *envs, int action_shift, int pong);
+/* sets the phase to SHUTDOWN, joins the threads, frees the handle                                */
+void a2c_pool_threads_stop(a2c_pool_threads *h);
+
+/* The synthetic benchmark env as a native env: replays a tape of `length` frames /
+ * rewards / dones (copied from the caller's arrays; a2c_amd.synthetic.TapeEnv generates them), ignoring
+ * the action -- step k returns frame (k+1) % length, reward[k % length], done[k % length].       */
+void *a2c_tape_env_create(const void *frames, const double *rews, const uint8_t *dones, int length,
+                          int frame_bytes);
+void a2c_tape_env_destroy(void *env);
+const a2c_env_vtable *a2c_tape_env_vtable(void);
+
 #ifdef __cplusplus
 }
 #endif

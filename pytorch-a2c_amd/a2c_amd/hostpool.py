@@ -63,6 +63,11 @@ POOL_SIGNATURES = {   # one entry per prototype in include/a2c_hostpool.h
     "a2c_pool_wait_frames": (c_int, [P, c_int, c_int, c_uint32, c_int64]),
     "a2c_pool_unpack": (None, [P, c_int, c_int, P, P]),
     "a2c_pool_rew_ema": (c_double, [P]),
+    "a2c_pool_threads_start": (P, [P, c_int, P, P, c_int, c_int]),
+    "a2c_pool_threads_stop": (None, [P]),
+    "a2c_tape_env_create": (P, [P, P, P, c_int, c_int]),
+    "a2c_tape_env_destroy": (None, [P]),
+    "a2c_tape_env_vtable": (P, []),
 }
 _pool_lib = None
 
@@ -78,6 +83,27 @@ def pool_lib():
             fn.restype, fn.argtypes = res, args
         _pool_lib = lib
     return _pool_lib
+
+
+def usable_cpus():
+    """CPUs this process can really burn: the affinity mask, capped by the cgroup CPU quota (cpu.max) --
+    a container may show 256 CPUs and be throttled to 16; spinning workers beyond the quota get descheduled
+    for whole scheduler periods, which stalls the device-side hand-shake."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def shm_path(name):
@@ -136,53 +162,25 @@ def _dump_spec(spec):
         return pickle.dumps(spec)
 
 
-class ProcessEnvPool:
-    """``n_envs`` host envs stepped by ``n_workers`` processes behind one pinned region.
-
-    env_factory(**env_kwargs[j]) -> object with ``reset() -> obs`` and ``step(a) -> (obs, rew, done, info)``
-    returning already prepped frames of shape (1, H, W) / (1, L) (what SequentialEnvironment returns).
-    ``action_shift`` / ``pong`` are the hyps of runner.py:208,212-214 (the Pong done override only affects
-    the episode-reward EMA here; the device applies it to the ``dones`` buffer).
-    """
+class _PinnedPool:
+    """What both pool kinds share: the pinned region and the GPU-process side of the protocol."""
 
     device_pool = False
 
-    def __init__(self, env_factory, n_envs, env_kwargs=None, n_workers=None, action_shift=0, pong=False,
-                 frame_shape=None, frame_dtype=None, rew_ema0=-1.0, register=True, spin=True, sys_path=None,
-                 probe_reset=False):
-        self.env_factory, self.n_envs = env_factory, int(n_envs)
-        self.env_kwargs = list(env_kwargs) if env_kwargs is not None else [dict() for _ in range(n_envs)]
-        assert len(self.env_kwargs) == self.n_envs
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        if n_workers is None:
-            n_workers = max(1, min(self.n_envs, int(os.environ.get("A2C_ENV_WORKERS", "0")) or min(32, max(1, cores // 2))))
-        self.n_workers = int(n_workers)
-        self.action_shift, self.pong = int(action_shift), bool(pong)
-        # raw env objects: one extra reset() per env right after construction, which is what the reference's
-        # SequentialEnvironment.__init__ does to read raw_shape (runner.py:45); wrappers that already do it pass False
-        self.probe_reset = bool(probe_reset)
-        if frame_shape is None or frame_dtype is None:
-            # one probing env, like training.py:60-65 reads the observation shape from StatsRunner's env
-            obs = np.asarray(env_factory(**self.env_kwargs[0]).reset())
-            frame_shape = obs.shape if frame_shape is None else frame_shape
-            frame_dtype = obs.dtype if frame_dtype is None else frame_dtype
+    def _setup(self, n_envs, frame_shape, frame_dtype, n_workers, rew_ema0, register):
+        self.n_envs, self.n_workers = int(n_envs), int(n_workers)
         self.frame_shape = tuple(int(s) for s in frame_shape)
         self.frame_dtype = np.dtype(np.uint8 if np.dtype(frame_dtype) in (np.dtype(np.uint8), np.dtype(bool)) else np.float32)
         self.frame_bytes = int(np.prod(self.frame_shape)) * self.frame_dtype.itemsize
-        self.rew_ema0, self.register, self.spin = float(rew_ema0), bool(register), bool(spin)
-        self.sys_path = list(sys_path) if sys_path is not None else [p for p in sys.path if p]
+        self.rew_ema0, self.register = float(rew_ema0), bool(register)
         self.region = None
-        self.procs = []
         self.dev_ptr = 0
         self.seq = 0            # env steps requested so far (same for every env: lock-step slots)
 
     def __len__(self):
         return self.n_envs
 
-    # ------------------------------------------------------------------ life cycle
-    def start(self, timeout=300.0):
-        if self.region is not None:
-            return self
+    def _create_region(self):
         lib = pool_lib()
         nbytes = lib.a2c_pool_bytes(self.n_envs, self.frame_bytes)
         self.name = f"a2c_pool_{os.getpid()}_{id(self) & 0xffffff:x}_{int(time.time() * 1e3) & 0xffffff:x}"
@@ -194,56 +192,21 @@ class ProcessEnvPool:
         if self.register:       # pin + map into the GPU's address space (no copy): hipHostRegister
             from . import ops
             self.dev_ptr = ops.pinned_register(reg.base, nbytes)
-        per = -(-self.n_envs // self.n_workers)
-        blocks = [(w, w * per, min(per, self.n_envs - w * per)) for w in range(self.n_workers) if w * per < self.n_envs]
-        self.n_workers = len(blocks)
-        reg.header.n_workers = self.n_workers
-        env = dict(os.environ, PYTHONPATH=os.pathsep.join(self.sys_path + [os.environ.get("PYTHONPATH", "")]))
-        for w, e0, n in blocks:
-            spec = dict(shm=self.name, worker=w, env0=e0, n=n, factory=self.env_factory,
-                        env_kwargs=self.env_kwargs[e0:e0 + n], action_shift=self.action_shift, pong=self.pong,
-                        frame_shape=self.frame_shape, frame_dtype=self.frame_dtype.str, parent=os.getpid(),
-                        probe_reset=self.probe_reset)
-            p = subprocess.Popen([sys.executable, "-m", "a2c_amd.hostpool_worker"], stdin=subprocess.PIPE, env=env)
-            p.stdin.write(_dump_spec(spec))
-            p.stdin.close()
-            self.procs.append(p)
-        t0 = time.time()
-        while reg.header.workers_ready < self.n_workers:
-            self._check_workers()
-            if time.time() - t0 > timeout:
-                self.close()
-                raise TimeoutError("env workers did not come up")
-            time.sleep(0.005)
-        if not self.spin:
-            self.set_phase(IDLE)
-        return self
+        return reg
 
-    def _check_workers(self):
-        h = self.region.header
-        if h.worker_error:
-            raise RuntimeError(f"env worker {h.worker_error - 1} died with an exception (see its stderr)")
-        for p in self.procs:
-            if p.poll() is not None:
-                raise RuntimeError(f"env worker pid {p.pid} exited with code {p.returncode}")
-
-    def close(self):
+    def _destroy_region(self):
         reg = self.region
-        if reg is None:
-            return
-        pool_lib().a2c_pool_set_phase(reg.base, SHUTDOWN)
-        for p in self.procs:
-            try:
-                p.wait(timeout=5)
-            except subprocess.TimeoutExpired:
-                p.kill()
-        self.procs = []
         if self.dev_ptr:
             from . import ops
             ops.pinned_unregister(reg.base)
             self.dev_ptr = 0
         reg.close(unlink=True)
         self.region = None
+
+    def _check_workers(self):
+        h = self.region.header
+        if h.worker_error:
+            raise RuntimeError(f"env worker {h.worker_error - 1} died with an exception (see its stderr)")
 
     def __del__(self):
         try:
@@ -303,3 +266,143 @@ class ProcessEnvPool:
         h = self.header
         return json.dumps(dict(n_envs=h.n_envs, n_workers=h.n_workers, frame_bytes=h.frame_bytes,
                                frame_dtype="u8" if h.frame_dtype == FRAME_U8 else "f32"))
+
+
+class ProcessEnvPool(_PinnedPool):
+    """``n_envs`` host envs stepped by ``n_workers`` processes behind one pinned region.
+
+    env_factory(**env_kwargs[j]) -> object with ``reset() -> obs`` and ``step(a) -> (obs, rew, done, info)``
+    returning already prepped frames of shape (1, H, W) / (1, L) (what SequentialEnvironment returns).
+    ``action_shift`` / ``pong`` are the hyps of runner.py:208,212-214 (the Pong done override only affects
+    the episode-reward EMA here; the device applies it to the ``dones`` buffer).
+    """
+
+    def __init__(self, env_factory, n_envs, env_kwargs=None, n_workers=None, action_shift=0, pong=False,
+                 frame_shape=None, frame_dtype=None, rew_ema0=-1.0, register=True, spin=True, sys_path=None,
+                 probe_reset=False):
+        self.env_factory, self.n_envs = env_factory, int(n_envs)
+        self.env_kwargs = list(env_kwargs) if env_kwargs is not None else [dict() for _ in range(n_envs)]
+        assert len(self.env_kwargs) == self.n_envs
+        if n_workers is None:
+            # all usable CPUs but two (the GPU process and the OS); every worker spins during a rollout
+            n_workers = max(1, min(self.n_envs, int(os.environ.get("A2C_ENV_WORKERS", "0")) or min(48, max(1, usable_cpus() - 2))))
+        self.n_workers = int(n_workers)
+        self.action_shift, self.pong = int(action_shift), bool(pong)
+        # raw env objects: one extra reset() per env right after construction, which is what the reference's
+        # SequentialEnvironment.__init__ does to read raw_shape (runner.py:45); wrappers that already do it pass False
+        self.probe_reset = bool(probe_reset)
+        if frame_shape is None or frame_dtype is None:
+            # one probing env, like training.py:60-65 reads the observation shape from StatsRunner's env
+            obs = np.asarray(env_factory(**self.env_kwargs[0]).reset())
+            frame_shape = obs.shape if frame_shape is None else frame_shape
+            frame_dtype = obs.dtype if frame_dtype is None else frame_dtype
+        self._setup(n_envs, frame_shape, frame_dtype, n_workers, rew_ema0, register)
+        self.spin = bool(spin)
+        self.sys_path = list(sys_path) if sys_path is not None else [p for p in sys.path if p]
+        self.procs = []
+
+    # ------------------------------------------------------------------ life cycle
+    def start(self, timeout=300.0):
+        if self.region is not None:
+            return self
+        reg = self._create_region()
+        per = -(-self.n_envs // self.n_workers)
+        blocks = [(w, w * per, min(per, self.n_envs - w * per)) for w in range(self.n_workers) if w * per < self.n_envs]
+        self.n_workers = len(blocks)
+        reg.header.n_workers = self.n_workers
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join(self.sys_path + [os.environ.get("PYTHONPATH", "")]))
+        for w, e0, n in blocks:
+            spec = dict(shm=self.name, worker=w, env0=e0, n=n, factory=self.env_factory,
+                        env_kwargs=self.env_kwargs[e0:e0 + n], action_shift=self.action_shift, pong=self.pong,
+                        frame_shape=self.frame_shape, frame_dtype=self.frame_dtype.str, parent=os.getpid(),
+                        probe_reset=self.probe_reset)
+            p = subprocess.Popen([sys.executable, "-m", "a2c_amd.hostpool_worker"], stdin=subprocess.PIPE, env=env)
+            p.stdin.write(_dump_spec(spec))
+            p.stdin.close()
+            self.procs.append(p)
+        t0 = time.time()
+        while reg.header.workers_ready < self.n_workers:
+            self._check_workers()
+            if time.time() - t0 > timeout:
+                self.close()
+                raise TimeoutError("env workers did not come up")
+            time.sleep(0.005)
+        if not self.spin:
+            self.set_phase(IDLE)
+        return self
+
+    def _check_workers(self):
+        super()._check_workers()
+        for p in self.procs:
+            if p.poll() is not None:
+                raise RuntimeError(f"env worker pid {p.pid} exited with code {p.returncode}")
+
+    def close(self):
+        reg = self.region
+        if reg is None:
+            return
+        pool_lib().a2c_pool_set_phase(reg.base, SHUTDOWN)
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        self.procs = []
+        self._destroy_region()
+
+
+class ThreadEnvPool(_PinnedPool):
+    """Envs implemented natively (a2c_env_vtable, include/a2c_hostpool.h) stepped by ``n_threads`` pthreads
+    of THIS process -- no Python in the loop; the env writes its observation straight into its pinned frame
+    slot.  ``from_tape_envs`` wraps the synthetic benchmark env: the tapes of ``synthetic.TapeEnv`` objects
+    are copied into native tape envs, so it produces byte-identical data to stepping those objects in
+    worker processes.  Same device-facing protocol and API as ProcessEnvPool."""
+
+    def __init__(self, vtable_ptr, env_ptrs, frame_shape, frame_dtype, n_threads=None, action_shift=0, pong=False,
+                 rew_ema0=-1.0, register=True, destroy=None):
+        if n_threads is None:
+            n_threads = max(1, min(len(env_ptrs), int(os.environ.get("A2C_ENV_THREADS", "0")) or min(8, max(1, usable_cpus() - 2))))
+        self._setup(len(env_ptrs), frame_shape, frame_dtype, n_threads, rew_ema0, register)
+        self.vtable_ptr, self.env_ptrs, self._destroy_env = vtable_ptr, list(env_ptrs), destroy
+        self.action_shift, self.pong = int(action_shift), bool(pong)
+        self.handle = None
+
+    @classmethod
+    def from_tape_envs(cls, envs, **kw):
+        lib = pool_lib()
+        ptrs = []
+        for e in envs:
+            fr = np.ascontiguousarray(e.frames)
+            rw = np.ascontiguousarray(e.rews, dtype=np.float64)
+            dn = np.ascontiguousarray(e.dones, dtype=np.uint8)
+            ptr = lib.a2c_tape_env_create(fr.ctypes.data, rw.ctypes.data, dn.ctypes.data, e.length, fr[0].nbytes)
+            if not ptr:
+                raise RuntimeError("a2c_tape_env_create failed")
+            ptrs.append(ptr)
+        e0 = envs[0]
+        return cls(lib.a2c_tape_env_vtable(), ptrs, e0.frames.shape[1:], e0.frames.dtype, destroy=lib.a2c_tape_env_destroy, **kw)
+
+    def start(self, timeout=None):
+        if self.region is not None:
+            return self
+        reg = self._create_region()
+        self._env_array = (c_void_p * self.n_envs)(*self.env_ptrs)
+        self.handle = pool_lib().a2c_pool_threads_start(reg.base, self.n_workers, self.vtable_ptr, self._env_array,
+                                                        self.action_shift, int(self.pong))
+        if not self.handle:
+            self._destroy_region()
+            raise RuntimeError("a2c_pool_threads_start failed")
+        self.n_workers = int(reg.header.n_workers)
+        return self
+
+    def close(self):
+        if self.region is None:
+            return
+        if self.handle:
+            pool_lib().a2c_pool_threads_stop(self.handle)
+            self.handle = None
+        self._destroy_region()
+        if self._destroy_env is not None:
+            for p in self.env_ptrs:
+                self._destroy_env(p)
+        self.env_ptrs = []

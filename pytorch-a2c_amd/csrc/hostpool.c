@@ -3,6 +3,8 @@
 #define _GNU_SOURCE
 #include "../../include/a2c_hostpool.h"
 
+#include <pthread.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 #if defined(__x86_64__) || defined(__i386__)
@@ -161,3 +163,149 @@ double a2c_pool_rew_ema(const void *base) {
   __atomic_store_n(&h->ema_lock, 0u, __ATOMIC_RELEASE);
   return v;
 }
+
+/* ------------------------------------------------------------------ native env worker threads */
+typedef struct {
+  void *base;
+  const a2c_env_vtable *vt;
+  void *const *envs;
+  int env0, n, shift, pong;
+} worker_arg;
+
+struct a2c_pool_threads {
+  int n_threads;
+  pthread_t *threads;
+  worker_arg *args;
+};
+
+static void publish_inplace(void *base, int env, uint32_t seq, float rew, int done) {
+  uint32_t rb;
+  memcpy(&rb, &rew, 4);
+  __atomic_store_n(rec_of(base) + env, ((uint64_t)((seq << 1) | (done ? 1u : 0u)) << 32) | rb, __ATOMIC_RELEASE);
+}
+
+static void *worker_main(void *p) {
+  worker_arg *w = (worker_arg *)p;
+  a2c_pool_header *h = hdr(w->base);
+  char *frames = (char *)w->base + h->off_frames;
+  uint32_t *next_seq = (uint32_t *)calloc((size_t)w->n, sizeof(uint32_t));
+  double *ep_rew = (double *)calloc((size_t)w->n, sizeof(double));
+  for (int i = 0; i < w->n; ++i) {          /* frame 0 = reset observation, done = 1 */
+    w->vt->reset(w->envs[w->env0 + i], frames + (size_t)(w->env0 + i) * h->frame_stride);
+    publish_inplace(w->base, w->env0 + i, 0, 0.f, 1);
+  }
+  a2c_pool_worker_ready(w->base);
+  for (;;) {
+    int32_t action = 0;
+    const int i = a2c_pool_take(w->base, w->env0, w->n, next_seq, 200000000LL, &action);
+    if (i == -2) break;
+    if (i < 0) continue;
+    const int j = w->env0 + i;
+    void *slot = frames + (size_t)j * h->frame_stride;
+    float rew = 0.f;
+    int done = 0;
+    w->vt->step(w->envs[j], action + w->shift, slot, &rew, &done);      /* runner.py:208 */
+    ep_rew[i] += rew;
+    const int reset = done != 0;
+    if (w->pong && rew != 0.f) done = 1;                                 /* runner.py:212-214 */
+    if (done) {                                                          /* runner.py:215-217 */
+      a2c_pool_episode(w->base, ep_rew[i]);
+      ep_rew[i] = 0.0;
+    }
+    if (reset) w->vt->reset(w->envs[j], slot);                           /* utils.py:36-38 */
+    next_seq[i] += 1;
+    publish_inplace(w->base, j, next_seq[i], rew, reset);
+  }
+  free(next_seq);
+  free(ep_rew);
+  return NULL;
+}
+
+a2c_pool_threads *a2c_pool_threads_start(void *base, int n_threads, const a2c_env_vtable *vt, void *const *envs,
+                                         int action_shift, int pong) {
+  if (a2c_pool_check(base) || n_threads < 1 || !vt || !vt->reset || !vt->step || !envs) return NULL;
+  a2c_pool_header *h = hdr(base);
+  const int n_envs = (int)h->n_envs;
+  if (n_threads > n_envs) n_threads = n_envs;
+  a2c_pool_threads *t = (a2c_pool_threads *)calloc(1, sizeof(*t));
+  t->threads = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+  t->args = (worker_arg *)calloc((size_t)n_threads, sizeof(worker_arg));
+  const int per = (n_envs + n_threads - 1) / n_threads;
+  int started = 0;
+  for (int w = 0; w < n_threads && w * per < n_envs; ++w) {
+    worker_arg *a = &t->args[w];
+    a->base = base; a->vt = vt; a->envs = envs; a->env0 = w * per;
+    a->n = per < n_envs - w * per ? per : n_envs - w * per;
+    a->shift = action_shift; a->pong = pong;
+    if (pthread_create(&t->threads[w], NULL, worker_main, a) != 0) break;
+    ++started;
+  }
+  t->n_threads = started;
+  h->n_workers = (uint32_t)started;
+  const int want = (n_envs + per - 1) / per;
+  if (started != want) {
+    a2c_pool_threads_stop(t);
+    return NULL;
+  }
+  while (__atomic_load_n(&h->workers_ready, __ATOMIC_ACQUIRE) < (uint32_t)started) sleep_ns(100000);
+  return t;
+}
+
+void a2c_pool_threads_stop(a2c_pool_threads *t) {
+  if (!t) return;
+  if (t->n_threads > 0) a2c_pool_set_phase(t->args[0].base, A2C_POOL_SHUTDOWN);
+  for (int w = 0; w < t->n_threads; ++w) pthread_join(t->threads[w], NULL);
+  free(t->threads);
+  free(t->args);
+  free(t);
+}
+
+/* the synthetic tape env */
+typedef struct {
+  unsigned char *frames;
+  double *rews;
+  uint8_t *dones;
+  int length, frame_bytes;
+  long t;
+} tape_env;
+
+void *a2c_tape_env_create(const void *frames, const double *rews, const uint8_t *dones, int length, int frame_bytes) {
+  if (!frames || !rews || !dones || length < 1 || frame_bytes < 1) return NULL;
+  tape_env *e = (tape_env *)calloc(1, sizeof(*e));
+  e->frames = (unsigned char *)malloc((size_t)length * frame_bytes);
+  e->rews = (double *)malloc((size_t)length * sizeof(double));
+  e->dones = (uint8_t *)malloc((size_t)length);
+  memcpy(e->frames, frames, (size_t)length * frame_bytes);
+  memcpy(e->rews, rews, (size_t)length * sizeof(double));
+  memcpy(e->dones, dones, (size_t)length);
+  e->length = length;
+  e->frame_bytes = frame_bytes;
+  return e;
+}
+
+void a2c_tape_env_destroy(void *env) {
+  tape_env *e = (tape_env *)env;
+  if (!e) return;
+  free(e->frames);
+  free(e->rews);
+  free(e->dones);
+  free(e);
+}
+
+static void tape_reset(void *env, void *frame_out) {
+  tape_env *e = (tape_env *)env;
+  memcpy(frame_out, e->frames + (size_t)(e->t % e->length) * e->frame_bytes, (size_t)e->frame_bytes);
+}
+
+static void tape_step(void *env, int32_t action, void *frame_out, float *rew, int *done) {
+  (void)action;
+  tape_env *e = (tape_env *)env;
+  const long k = e->t % e->length;
+  e->t += 1;
+  memcpy(frame_out, e->frames + (size_t)(e->t % e->length) * e->frame_bytes, (size_t)e->frame_bytes);
+  *rew = (float)e->rews[k];
+  *done = e->dones[k] != 0;
+}
+
+static const a2c_env_vtable tape_vtable = {tape_reset, tape_step};
+const a2c_env_vtable *a2c_tape_env_vtable(void) { return &tape_vtable; }

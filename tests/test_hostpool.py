@@ -107,3 +107,33 @@ def test_pool_idle_phase_does_not_spin():
         assert max(busy) < 50.0, busy
     finally:
         pool.close()
+
+
+def test_native_thread_pool_is_byte_identical_to_python_tape_envs():
+    """ThreadEnvPool (pthreads + native tape env, no Python in the loop) == stepping synthetic.TapeEnv objects"""
+    from a2c_amd.hostpool import ThreadEnvPool
+    B, K = 9, 120
+    kws = [dict(env_id=j, length=13, p_done=0.07) for j in range(B)]
+    pool = ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=2, register=False, pong=True)
+    try:
+        pool.start()
+        pool.set_phase(ROLLOUT)
+        assert pool.frame_dtype == np.uint8 and pool.header.n_workers == 2
+        refs = [TapeEnv(**k) for k in kws]
+        fr = pool.frames_view()
+        pool.wait_frames(0)
+        for j in range(B):
+            assert np.array_equal(fr[j], refs[j].reset())
+        rew, done = np.zeros(B, np.float32), np.zeros(B, np.float32)
+        n_eps = 0
+        for k in range(K):
+            pool.post_actions(np.full(B, k % 3, np.int64), seq=k)
+            pool.wait_frames(k + 1)
+            pool.unpack(rew, done)
+            for j in range(B):
+                o, r, d = _ref_step(refs[j], k % 3, 0)
+                assert np.array_equal(fr[j], o) and rew[j] == np.float32(r) and done[j] == float(d), (k, j)
+                n_eps += bool(d or r != 0)
+        assert pool.header.episodes == n_eps
+    finally:
+        pool.close()

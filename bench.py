@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the A2C rollout+update hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload a3c|conv|gru|gru_bptt|fc]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload a3c|conv|gru|gru_bptt|fc] [--ingest ...]
 
-One "step" = one pass of the hot path over one batch: a rollout of n_envs x n_tsteps env-steps
-(batched forward, sampling, TD deltas, frame stacking -- all HIP kernels) followed by one
-Updater.update_model (GAE/returns scan, forward, loss, backward, clip + optimiser).  Inputs are
-synthetic and already resident in HBM when the timed region starts (84x84 binary frames,
-rewards, dones and sampling uniforms pre-generated on the device: SURVEY.md section 8d).
-Default workload = the headline config of BASELINE.json: A3CModel, n_envs=256, n_tsteps=128.
-Multi-GPU: weak scaling, every rank plays its own n_envs envs; one RCCL all-reduce of the flat
-gradient arena (+ 2 tiny ones for the whole-batch statistics) per update.
+One "step" = one pass of the hot path over one batch: a rollout of n_envs x n_tsteps env-steps followed
+by one Updater.update_model (GAE/returns scan, forward, loss, backward, clip + optimiser).
+
+Where the frames come from (``--ingest``, default ``host-pinned``): the north star keeps env stepping on
+the host.  The synthetic envs (84x84 binary uint8 frames, rewards, dones: SURVEY.md 8d) therefore run in
+HOST env workers; every env step's frame crosses PCIe from pinned host memory inside the timed region:
+  host-pinned  worker threads/processes behind one pinned, device-mapped region; A3CModel: the persistent
+               one-launch rollout kernel reads the uint8 frames zero-copy (a2c_a3c_rollout); other models:
+               hipMemcpyAsync of the frames block per step ("memcpy" forces that for A3CModel too);
+  device-tape  round-1 style: the same tape pre-generated in HBM, the rollout replayed as a hipGraph --
+               reported as the secondary key ``value_device_tape`` (kernel-side evidence, no ingest).
+``--env-workers native`` (default) steps the tape envs in C threads of liba2c_hostpool (no Python per env
+step); ``process`` steps Python TapeEnv objects in worker processes (a2c_amd.hostpool_worker), reported as
+``host_pinned_process_workers``.
+
+Multi-GPU: weak scaling, every rank plays its own n_envs envs (own pool); one RCCL all-reduce of the flat
+gradient arena (+ 2 tiny ones for the whole-batch statistics) per update.  ``python bench.py --gpus N``
+without a launcher spawns ``torch.distributed.run`` itself (before this process touches the GPU).
 
 Prints ONE JSON line (rank 0): metric/value/... plus
-  "roofline":     the dominant kernel's algorithmic bytes (or flops) / its HIP-event duration,
-  "cpu_baseline": the CPU oracle (restatement of the reference's algorithm) timed on this box's
-                  host cores on a bounded sample of the same workload (N=1 only).
+  "roofline":     the kernel the epoch spends most time in: algorithmic flops (bytes) / HIP-event duration,
+  "cpu_baseline": the CPU oracle (restatement of the reference's algorithm) timed on this box's usable host
+                  cores on a bounded sample of the same workload (N=1 only),
+  "configs":      the other BASELINE.json configs (conv 32x64, gru+BPTT 256x128, a3c at 32 / 2048 envs).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -41,19 +52,22 @@ WORKLOADS = {   # model, n_envs, n_tsteps, use_bptt, n_actions
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # fp32 matrix == fp32 vector peak
+PCIE_PEAK_GBS = 63.0         # host link: PCIe Gen5 x16 (spec)
+SS = (4, 84, 84)
+FRAME_BYTES = 84 * 84        # uint8 transport
 
 
 def hyps_for(model, n_envs, T, use_bptt, optim):
     return dict(gamma=.99, lambda_=.98, n_tsteps=T, n_rollouts=n_envs, n_envs=n_envs, n_frame_stack=4, action_shift=0,
                 render=False, env_type="Pong-synthetic", use_bptt=use_bptt, use_nstep_rets=False, norm_advs=True,
                 entr_coef=.005, pi_coef=1.0, val_coef=.5, max_norm=.5, lr=1e-4, optim_type=optim, is_discrete=True,
-                h_size=256, model=model)
+                h_size=256, model=model, env_timeout_s=30.0)
 
 
 class SyntheticDevicePool:
-    """Device-resident synthetic env pool: i.i.d. binary 84x84 frames, rewards
-    -1/0/+1 with P=(.02,.96,.02), real done with P=1/800; the same T-step tape is replayed every
-    epoch.  Implements the Runner's device-pool protocol (start / device_step)."""
+    """Device-resident synthetic env pool: i.i.d. binary 84x84 frames, rewards -1/0/+1 with P=(.02,.96,.02),
+    real done with P=1/800; the same T-step tape is replayed every epoch.  Implements the Runner's device-pool
+    protocol (start / device_step).  Only behind ``--ingest device-tape`` / the ``value_device_tape`` key."""
 
     def __init__(self, n_envs, T, device, seed, frame_shape=(1, 84, 84)):
         self.B, self.T, self.frame_shape = n_envs, T, frame_shape
@@ -79,17 +93,29 @@ class SyntheticDevicePool:
         return self.frames[t, sl], self.rew[t, sl], self.done[t, sl], self.done[t, sl]
 
 
+def make_host_pool(n_envs, T, kind, n_workers, seed):
+    """host env workers stepping synthetic.TapeEnv tapes (uint8 frames) behind the pinned region"""
+    from a2c_amd.hostpool import ProcessEnvPool, ThreadEnvPool
+    from a2c_amd.synthetic import TapeEnv
+    L = min(T + 1, 33)          # tape length per env: content does not affect cost, keeps host memory small
+    kws = [dict(env_id=seed * 100000 + j, length=L) for j in range(n_envs)]
+    if kind == "native":
+        return ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=n_workers, pong=True)
+    return ProcessEnvPool(TapeEnv, n_envs, env_kwargs=kws, n_workers=n_workers, pong=True, frame_shape=(1, 84, 84),
+                          frame_dtype=np.uint8)
+
+
 # ---------------------------------------------------------------- CPU baseline (oracle, host cores)
 def _cpu_rollout_worker(args):
-    model, T, n_slots, A = args
+    model, T, A, seconds = args
     import torch as th
     th.set_num_threads(1)
     from oracle import a2c_oracle as O
-    ss = (4, 84, 84)
-    net = O.OracleNet(model, ss, A, 256)
+    net = O.OracleNet(model, SS, A, 256)
     hyps = hyps_for(model, 1, T, False, "RMSprop")
+    n_slots = 4
     N = T * n_slots
-    D = dict(states=th.zeros(N, *ss), deltas=th.zeros(N), rewards=th.zeros(N), dones=th.zeros(N),
+    D = dict(states=th.zeros(N, *SS), deltas=th.zeros(N), rewards=th.zeros(N), dones=th.zeros(N),
              actions=th.zeros(N).long())
     if net.is_recurrent:
         D["h_states"] = th.zeros(N, 256)
@@ -108,61 +134,67 @@ def _cpu_rollout_worker(args):
     r.start(net)
     r.rollout(net, 0)                       # warm-up slot
     t0 = time.perf_counter()
-    for i in range(1, n_slots):
-        r.rollout(net, i)
-    return (n_slots - 1) * T, time.perf_counter() - t0
+    done_slots = 0
+    while time.perf_counter() - t0 < seconds:
+        r.rollout(net, 1 + done_slots % (n_slots - 1))
+        done_slots += 1
+    return done_slots * T, time.perf_counter() - t0
 
 
 def cpu_baseline(model, n_envs, T, use_bptt, A, optim):
-    """Oracle timed like the reference runs: rollout = one process per core, batch-1
-    forwards, 1 torch thread each; update = one process, all cores.  Bounded sample, scaled to the
-    workload's env-steps/sec: 1 / (1/rollout_rate + 1/update_rate)."""
+    """Oracle timed like the reference runs on the host cores this container may use: rollout =
+    min(n_envs, cores) processes x batch-1 forwards, 1 torch thread each (no scale-up); update = one process,
+    all cores, on as large a batch as ~12 s allow (full N when it fits).  env-steps/sec of one epoch of the
+    workload = N / (N / rollout_rate + N / update_rate)."""
     import multiprocessing as mp
+    from a2c_amd.hostpool import usable_cpus
     from oracle import a2c_oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    workers = min(cores, n_envs, 32)
-    slots = 3
+    cores = usable_cpus()
+    workers = max(1, min(cores, n_envs))
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(workers) as pool:
-        res = pool.map(_cpu_rollout_worker, [(model, T, slots, A)] * workers)
-    steps = sum(r[0] for r in res)
-    roll_rate = steps / max(r[1] for r in res)          # aggregate env-steps/s of `workers` processes
-    roll_rate *= cores / workers
-    # update on a bounded batch
-    R = 8 if model != "ConvModel" else 2
+        res = pool.map(_cpu_rollout_worker, [(model, T, A, 5.0)] * workers)
+    roll_rate = sum(r[0] / r[1] for r in res)          # aggregate env-steps/s of `workers` processes, measured
     torch.set_num_threads(cores)
-    ss = (4, 84, 84)
-    net = O.OracleNet(model, ss, A, 256)
-    hyps = hyps_for(model, R, T, use_bptt, optim)
-    N = R * T
-    g = torch.Generator().manual_seed(0)
-    D = dict(states=(torch.rand(N, *ss, generator=g) < 0.25).float(), deltas=torch.randn(N, generator=g),
-             rewards=torch.randn(N, generator=g).round(), dones=(torch.rand(N, generator=g) < 0.01).float(),
-             actions=torch.randint(0, A, (N,), generator=g))
-    D["dones"][T - 1::T] = 1
-    if net.is_recurrent:
-        D["h_states"] = torch.randn(N, 256, generator=g)
-    upd = O.OracleUpdater(net, hyps)
-    # torch's CPU kernels do not scale to hundreds of threads on such small batches: time a few
-    # thread counts and keep the BEST one for the baseline (favours the CPU)
-    upd_rate, upd_threads = 0.0, cores
-    for nt in sorted({min(cores, c) for c in (8, 16, 32, 64, cores)}):
-        torch.set_num_threads(nt)
-        upd.update_model(D)
+    net = O.OracleNet(model, SS, A, 256)
+    N_full = n_envs * T
+
+    def time_update(R):
+        hyps = hyps_for(model, R, T, use_bptt, optim)
+        N = R * T
+        g = torch.Generator().manual_seed(0)
+        D = dict(states=(torch.rand(N, *SS, generator=g) < 0.25).float(), deltas=torch.randn(N, generator=g),
+                 rewards=torch.randn(N, generator=g).round(), dones=(torch.rand(N, generator=g) < 0.01).float(),
+                 actions=torch.randint(0, A, (N,), generator=g))
+        D["dones"][T - 1::T] = 1
+        if net.is_recurrent:
+            D["h_states"] = torch.randn(N, 256, generator=g)
+        upd = O.OracleUpdater(net, hyps)
         t1 = time.perf_counter()
         upd.update_model(D)
-        rate = N / (time.perf_counter() - t1)
-        if rate > upd_rate:
-            upd_rate, upd_threads = rate, nt
-        if time.perf_counter() - t0 > 45:
-            break
+        return N, time.perf_counter() - t1
+
+    n_small, dt_small = time_update(4 if model != "ConvModel" else 1)
+    n_small, dt_small = time_update(4 if model != "ConvModel" else 1)          # second call: warm
+    budget = 12.0
+    R_big = int(max(1, min(n_envs, budget / max(dt_small / n_small, 1e-9) / T)))
+    N_upd, dt_upd = time_update(R_big)
+    upd_rate = N_upd / dt_upd
     value = 1.0 / (1.0 / roll_rate + 1.0 / upd_rate)
+    cpu_model = ""
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:      # noqa: BLE001
+        pass
     return dict(value=round(value, 1), unit="env-steps/s", cores=cores, kind="port",
-                sample=f"oracle (CPU restatement of the reference): rollout {workers} procs x {slots - 1} slots x {T} "
-                       f"batch-1 steps, scaled to {cores} cores = {roll_rate:.0f} steps/s; update_model on N={N}, best of "
-                       f"several thread counts ({upd_threads} threads) = {upd_rate:.0f} samples/s; combined as "
-                       f"1/(1/r+1/u); wall {time.perf_counter() - t0:.0f}s")
+                rollout_steps_per_s=round(roll_rate, 1), update_samples_per_s=round(upd_rate, 1),
+                rollout_processes=workers, update_batch=N_upd, extrapolated=bool(N_upd < N_full), cpu_model=cpu_model,
+                sample=f"oracle (CPU restatement of the reference): rollout = {workers} processes x batch-1 forwards for 5 s "
+                       f"each, measured aggregate (no scale-up); update_model on N={N_upd} of {N_full} samples with {cores} "
+                       f"torch threads ({'full batch' if N_upd >= N_full else 'rate assumed flat in N'}); value = "
+                       f"1/(1/rollout_rate + 1/update_rate); usable cores = affinity capped by the cgroup quota; "
+                       f"wall {time.perf_counter() - t0:.0f}s")
 
 
 # ---------------------------------------------------------------- roofline helpers
@@ -175,13 +207,13 @@ def conv_flops(d, B):
 
 
 def step_alg_flops(A):
-    """a2c_a3c_step per env: conv 8x8/s4 4->16 on 84x84, conv 4x4/s2 16->32 on 20x20, (A+1) x 2592 heads"""
+    """one rollout step of A3CModel per env: conv 8x8/s4 4->16 on 84x84, conv 4x4/s2 16->32 on 20x20, (A+1) x 2592 heads"""
     return 2 * 16 * 400 * 256 + 2 * 32 * 81 * 256 + 2 * (A + 1) * 2592
 
 
-def step_alg_bytes():
-    """a2c_a3c_step per env: 3 planes of the previous state + the new frame in, the new state out"""
-    return 2 * 4 * 84 * 84 * 4
+def step_alg_bytes(u8_frame=False):
+    """per env-step: 3 planes of the previous state + the new frame in (fp32 or uint8), the new state out"""
+    return 3 * 84 * 84 * 4 + (84 * 84 if u8_frame else 84 * 84 * 4) + 4 * 84 * 84 * 4
 
 
 def scan_roofline(device):
@@ -210,200 +242,346 @@ def scan_roofline(device):
     return out
 
 
+# ---------------------------------------------------------------- one workload on this rank
+class Bench:
+    """net + rollout buffers + env pool + Runner + Updater of one workload; ``step()`` = rollout + update."""
+
+    def __init__(self, workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, update_graph=True):
+        import a2c_amd
+        from a2c_amd.runner import Runner
+        from a2c_amd.updater import Updater
+        self.model, n0, self.T, self.use_bptt, self.A = WORKLOADS[workload]
+        self.n_envs = n_envs or n0
+        self.hyps = hyps_for(self.model, self.n_envs, self.T, self.use_bptt, optim)
+        self.shard, self.dev, self.ingest, self.optim_name = shard, dev, ingest, optim
+        torch.manual_seed(20260101)                # the reference's default init, identical on every rank
+        self.net = net = getattr(a2c_amd.models, self.model)(list(SS), self.A, h_size=256)
+        self.N = N = self.n_envs * self.T
+        self.D = D = dict(states=torch.zeros(N, *SS, device=dev), deltas=torch.zeros(N, device=dev),
+                          rewards=torch.zeros(N, device=dev), dones=torch.zeros(N, device=dev),
+                          actions=torch.zeros(N, dtype=torch.int64, device=dev))
+        if net.is_recurrent:
+            D["h_states"] = torch.zeros(N, 256, device=dev)
+        self.slots = list(range(self.n_envs))
+        self.graph = self.ugraph = None
+        self.env_workers = env_workers
+        if ingest == "device-tape":
+            self.pool = pool = SyntheticDevicePool(self.n_envs, self.T, dev, seed=shard.rank)
+            self.runner = Runner(D, self.hyps, None, None, None, env_pool=pool,
+                                 uniform_fn=lambda t, B, e0: pool.uniforms[t, e0:e0 + B])
+        else:
+            self.pool = pool = make_host_pool(self.n_envs, self.T, env_workers, n_workers, seed=shard.rank)
+            self.runner = Runner(D, self.hyps, None, None, None, env_pool=pool,
+                                 ingest="memcpy" if ingest == "memcpy" else None)
+        self.updater = Updater(net, self.hyps, shard=shard)
+        self.want_update_graph = update_graph and optim == "RMSprop"
+        self.info = None
+
+    # the rollout: a hipGraph replay (device tape) or the live host-pinned ingest
+    def rollout(self):
+        if self.graph is not None:
+            self.graph.replay()
+            self.net._dirty = False        # the captured rollout re-derived the inference weights (conv fragments, Wc)
+        else:
+            self.runner.rollout(self.net, self.slots, self.hyps)
+
+    def update(self):
+        if self.ugraph is not None:
+            self.ugraph.replay()
+            self.updater.optim._steps += 1
+            self.net.mark_dirty()
+            return self.updater._finish_update(self.udev, self.u_nglobal)
+        return self.updater.update_model(self.D)
+
+    def step(self):
+        self.rollout()
+        self.info = self.update()
+        return self.info
+
+    def capture(self):
+        """after one eager step: the device-tape rollout and (single GPU, RMSprop) the update as hipGraphs"""
+        if self.ingest == "device-tape":
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                self.net.mark_dirty()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.runner.rollout(self.net, self.slots, self.hyps)
+                self.graph = g
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench] rollout hipGraph capture failed ({type(e).__name__}: {e}); eager rollout", file=sys.stderr)
+                self.graph = None
+                torch.cuda.synchronize()
+        # the update as a hipGraph: ~40 dependent launches whose stream gaps shrink to graph-edge gaps.  With a
+        # sharded update the collective sits in the middle: two graphs around it would be needed (not captured).
+        if self.want_update_graph and not self.shard.active:
+            try:
+                torch.cuda.synchronize()
+                ug = torch.cuda.CUDAGraph()
+                dirty = self.net._dirty
+                with torch.cuda.graph(ug, capture_error_mode="thread_local"):
+                    self.udev, self.u_nglobal = self.updater._enqueue_update(self.D)
+                self.ugraph = ug
+                self.net._dirty = dirty          # the capture itself did not run:
+                self.updater.optim._steps -= 1   # ... no optimiser step happened
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench] update hipGraph capture failed ({type(e).__name__}: {e}); eager update", file=sys.stderr)
+                self.ugraph = None
+                torch.cuda.synchronize()
+
+    def timed(self, steps, split=True):
+        """time `steps` steps (barrier + sync on both sides); returns (elapsed_s, rollout_ms, update_ms) with the
+        two halves from HIP events on the launch stream"""
+        ev = []
+        self.shard.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if split:
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record()
+                self.rollout()
+                e[1].record()
+                self.info = self.update()
+                e[2].record()
+                ev.append(e)
+            else:
+                self.step()
+        torch.cuda.synchronize()
+        self.shard.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.ingest != "device-tape":
+            self.runner.check()
+        r_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / max(len(ev), 1)
+        u_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / max(len(ev), 1)
+        return elapsed, r_ms, u_ms
+
+    def site_timers(self, n=2):
+        """HIP events per launch site of the update, `n` EAGER updates (the timed ones may be graph replays)"""
+        from a2c_amd import ops
+        timers = ops.KernelTimers()
+        for _ in range(n):
+            self.rollout()
+            ops.TIMERS = timers
+            self.updater.update_model(self.D)
+            ops.TIMERS = None
+        torch.cuda.synchronize()
+        return timers.summary()
+
+    def describe_ingest(self):
+        if self.ingest == "device-tape":
+            return "device-tape fp32 (frames pre-generated in HBM, rollout replayed as a hipGraph)"
+        mode = "zero-copy persistent rollout kernel" if self.runner._zero_copy_ok(self.net) else "hipMemcpyAsync per step"
+        return (f"host-pinned uint8 ({mode}; {self.pool.n_workers} {'native env threads' if self.env_workers == 'native' else 'env worker processes'}"
+                f" behind one pinned device-mapped region)")
+
+    def close(self):
+        try:
+            self.runner.close()
+        except Exception:      # noqa: BLE001
+            pass
+
+
+def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, steps, warmup):
+    """one extra BASELINE config: ms per step, env-steps/s, its dominant update launch site"""
+    b = Bench(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev)
+    try:
+        b.step()
+        b.capture()
+        for _ in range(max(warmup - 1, 0)):
+            b.step()
+        elapsed, r_ms, u_ms = b.timed(steps)
+        out = dict(workload=f"{b.model} n_envs={b.n_envs} n_tsteps={b.T}{' +BPTT' if b.use_bptt else ''}", steps=steps,
+                   ms_per_step=round(1e3 * elapsed / steps, 3), value=round(b.N * steps / elapsed, 1), unit="env-steps/s",
+                   rollout_ms=round(r_ms, 3), update_ms=round(u_ms, 3), ingest=b.describe_ingest())
+        summ = b.site_timers(1)
+        if summ:
+            dom = max(summ, key=lambda k: summ[k]["total_ms"])
+            out["dominant_update_site"] = dict(site=dom, avg_ms=round(summ[dom]["avg_ms"], 4), launches=summ[dom]["launches"])
+            layers = getattr(b.net, "_cl", None) or ([b.net._c1, b.net._c2] if hasattr(b.net, "_c1") else [])
+            conv = {l.name: l for l in layers}
+            lname, _, what = dom.partition(".")
+            if lname in conv:
+                tf = conv_flops(conv[lname].d, b.N) / (summ[dom]["avg_ms"] * 1e-3) / 1e12
+                out["dominant_update_site"].update(tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / F32_PEAK_TFLOPS, 4))
+        if b.ingest != "device-tape" and r_ms > 0:
+            out["h2d_GBs"] = round(b.N * FRAME_BYTES / (r_ms * 1e-3) / 1e9, 2)
+        return out
+    finally:
+        b.close()
+
+
+def spawn_ranks(args, argv):
+    """``python bench.py --gpus N`` without a launcher: start N ranks with torch.distributed.run as a CHILD
+    process (this process has not touched the GPU and never execs) and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in proc.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if line:
+        print(line)
+    sys.exit(proc.returncode if proc.returncode else (0 if line else 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="a3c", choices=sorted(WORKLOADS))
-    ap.add_argument("--n-envs", type=int, default=None)
+    ap.add_argument("--n-envs", type=int, default=None, help="envs per GPU (default: the workload's)")
+    ap.add_argument("--global-envs", type=int, default=None, help="strong scaling: this many envs over all GPUs")
     ap.add_argument("--optim", default="RMSprop", choices=["RMSprop", "Adam"])
-    ap.add_argument("--no-graph", action="store_true", help="do not capture the rollout into a hipGraph")
+    ap.add_argument("--ingest", default="host-pinned", choices=["host-pinned", "memcpy", "device-tape"])
+    ap.add_argument("--env-workers", default="native", choices=["native", "process"])
+    ap.add_argument("--n-workers", type=int, default=None, help="env worker threads/processes per rank")
+    ap.add_argument("--sustain-steps", type=int, default=200,
+                    help="if --steps is smaller, an additional region of this many steps is timed and reported")
     ap.add_argument("--no-update-graph", action="store_true", help="do not capture the update into a hipGraph")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip value_device_tape / process-worker runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
 
-    import a2c_amd
-    from a2c_amd import ops
-    from a2c_amd.parallel import Shard
-    from a2c_amd.runner import Runner
-    from a2c_amd.updater import Updater
-
+    # the ONE JSON line goes to the real stdout; whatever else prints on the way (the model classes mirror the
+    # reference's "Flat Features Size" print) goes to stderr
+    json_out, sys.stdout = sys.stdout, sys.stderr
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.stdout = json_out
+        spawn_ranks(args, sys.argv[1:])
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    from a2c_amd import ops
+    from a2c_amd.hostpool import usable_cpus
+    from a2c_amd.parallel import Shard
+
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("A2C_BENCH_ONE_DEVICE") == "1":      # test hook: N ranks share cuda:0 (use with A2C_DIST_BACKEND=gloo)
         local = 0
     torch.cuda.set_device(local)
     shard = Shard.from_env()
     dev = torch.device("cuda", local)
+    n_envs = args.n_envs
+    scaling = "weak"
+    if args.global_envs:
+        lo, hi = shard.slot_range(args.global_envs)
+        n_envs, scaling = hi - lo, "strong"
+    # env workers per rank: the usable CPUs are shared by all ranks of the node
+    n_workers = args.n_workers
+    if n_workers is None:
+        per_rank = max(1, (usable_cpus() - 2) // max(shard.world, 1))
+        n_workers = max(1, min(8 if args.env_workers == "native" else 48, per_rank))
 
-    model, n_envs, T, use_bptt, A = WORKLOADS[args.workload]
-    if args.n_envs:
-        n_envs = args.n_envs
-    hyps = hyps_for(model, n_envs, T, use_bptt, args.optim)
-    ss = (4, 84, 84)
-    torch.manual_seed(20260101)                # the reference's default init, identical on every rank
-    net = getattr(a2c_amd.models, model)(list(ss), A, h_size=256)
-    N = n_envs * T
-    D = dict(states=torch.zeros(N, *ss, device=dev), deltas=torch.zeros(N, device=dev),
-             rewards=torch.zeros(N, device=dev), dones=torch.zeros(N, device=dev),
-             actions=torch.zeros(N, dtype=torch.int64, device=dev))
-    if net.is_recurrent:
-        D["h_states"] = torch.zeros(N, 256, device=dev)
-    pool = SyntheticDevicePool(n_envs, T, dev, seed=shard.rank)
-    runner = Runner(D, hyps, None, None, None, env_pool=pool,
-                    uniform_fn=lambda t, B, e0: pool.uniforms[t, e0:e0 + B])
-    updater = Updater(net, hyps, shard=shard)
-    slots = list(range(n_envs))
-
-    graph = None
-
-    def rollout():
-        if graph is not None:
-            graph.replay()
-            net._dirty = False        # the captured rollout re-derived the inference weights (conv fragments, Wc)
-        else:
-            net.mark_dirty()
-            runner.rollout(net, slots, hyps)
-
-    def step():
-        rollout()
-        return updater.update_model(D)
-
-    info = None
-    for i in range(max(args.warmup, 1)):
-        info = step()
-        if i == 0 and not args.no_graph:
-            # capture the whole n_tsteps rollout (T x ~8 launches) into ONE hipGraph: no host
-            # round trip exists inside it because the env tape is device resident
-            try:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                net.mark_dirty()
-                # thread_local: the RCCL watchdog thread of a multi-GPU run may query events while
-                # this thread captures; that must not invalidate the capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    runner.rollout(net, slots, hyps)
-                graph = g
-            except Exception as e:      # noqa: BLE001
-                if shard.rank == 0:
-                    print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); eager rollout", file=sys.stderr)
-                graph = None
-                torch.cuda.synchronize()
-    # the update as a second hipGraph (single GPU, RMSprop: no collective and no per-step scalar
-    # argument inside): ~40 dependent launches whose 5-10 us stream gaps shrink to graph-edge gaps
-    ugraph, udev = None, None
-    if graph is not None and not shard.active and args.optim == "RMSprop" and not args.no_update_graph:
-        try:
-            torch.cuda.synchronize()
-            ug = torch.cuda.CUDAGraph()
-            net._dirty = False
-            with torch.cuda.graph(ug, capture_error_mode="thread_local"):
-                udev, u_nglobal = updater._enqueue_update(D)
-            ugraph = ug
-            net._dirty = True          # the capture itself did not run: the optimiser step has not happened
-        except Exception as e:      # noqa: BLE001
-            print(f"[bench] update hipGraph capture failed ({type(e).__name__}: {e}); eager update", file=sys.stderr)
-            ugraph = None
-            torch.cuda.synchronize()
-
-    def update():
-        if ugraph is not None:
-            ugraph.replay()
-            updater.optim._steps += 1
-            return updater._finish_update(udev, u_nglobal)
-        return updater.update_model(D)
-
-    timers = None
-    if not args.no_kernel_timers and ugraph is None:
-        timers = ops.KernelTimers()
-
-    shard.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    roll_ev = []
-    for _ in range(args.steps):
-        ops.TIMERS = None
-        if not args.no_kernel_timers:  # HIP events on the launch stream around the rollout (one hipGraph replay)
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-            rollout()
-            ev[1].record()
-            roll_ev.append(ev)
-        else:
-            rollout()
-        ops.TIMERS = timers
-        info = update()
-    torch.cuda.synchronize()
-    shard.barrier()
-    elapsed = time.perf_counter() - t0
-    ops.TIMERS = None
-    sites_note = "HIP events per launch site inside the timed region"
-    if ugraph is not None and not args.no_kernel_timers:
-        # per-site timings cannot be taken inside a graph replay: two extra EAGER updates after the
-        # timed region (same kernels, same data) provide them; the rollout is still timed live above
-        timers = ops.KernelTimers()
-        for _ in range(2):
-            rollout()
-            ops.TIMERS = timers
-            updater.update_model(D)
-            ops.TIMERS = None
-        torch.cuda.synchronize()
-        sites_note = "HIP events per launch site, 2 eager updates after the timed region (the timed updates are hipGraph replays)"
+    b = Bench(args.workload, n_envs, args.optim, args.ingest, args.env_workers, n_workers, shard, dev,
+              update_graph=not args.no_update_graph)
+    model, T, A, N = b.model, b.T, b.A, b.N
+    b.step()
+    b.capture()
+    for _ in range(max(args.warmup - 1, 0)):
+        b.step()
+    elapsed, rollout_ms, update_ms = b.timed(args.steps, split=not args.no_kernel_timers)
+    sustained = None
+    if args.steps < args.sustain_steps:
+        e2, r2, u2 = b.timed(args.sustain_steps, split=not args.no_kernel_timers)
+        sustained = dict(steps=args.sustain_steps, seconds=round(e2, 3), ms_per_step=round(1e3 * e2 / args.sustain_steps, 3),
+                         value=None, rollout_ms=round(r2, 3), update_ms=round(u2, 3))
+    allreduce_ms = None
     if shard.active:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, sustained["seconds"] if sustained else 0.0], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if sustained:
+            sustained["seconds"] = round(float(t[1].item()), 3)
+        # cost of the one gradient all-reduce per update, timed on its own
+        g = b.net._arena.train_grads()
+        for _ in range(3):
+            shard.allreduce_(g)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            shard.allreduce_(g)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = e0.elapsed_time(e1) / 10
+    summ = None
+    if not args.no_kernel_timers:
+        summ = b.site_timers(2)
+    ingest_desc = b.describe_ingest()
+    zero_copy = args.ingest != "device-tape" and b.runner._zero_copy_ok(b.net)
+    pool_workers = getattr(b.pool, "n_workers", None)
 
     if shard.rank != 0:
+        b.close()
         return
     total_steps = N * shard.world * args.steps
+    if sustained:
+        sustained["value"] = round(N * shard.world * args.sustain_steps / sustained["seconds"], 1)
+    parallelism = f"dp{shard.world} (rollout shards, 1 RCCL grad all-reduce/update)"
     out = dict(metric="env-steps/sec (rollout+update)", value=round(total_steps / elapsed, 1), unit="env-steps/s",
                n_gpus=shard.world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 3),
-               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=f"{model} n_envs={n_envs} n_tsteps={T} 84x84x4 synthetic frames"
-                                    f"{' +BPTT' if use_bptt else ''}, {args.optim}, per GPU",
-                           n_envs_per_gpu=n_envs, n_tsteps=T, optimizer=args.optim,
-                           rollout="hipGraph" if graph is not None else "eager",
-                           parallelism=f"dp{shard.world} (rollout shards, 1 RCCL grad all-reduce/update)"),
-               last_info={k: round(float(v), 6) for k, v in (info or {}).items()})
+               higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=f"{model} n_envs={b.n_envs} n_tsteps={T} 84x84x4 synthetic frames"
+                                    f"{' +BPTT' if b.use_bptt else ''}, {args.optim}, per GPU",
+                           ingest=ingest_desc, n_envs_per_gpu=b.n_envs, n_tsteps=T, optimizer=args.optim,
+                           env_workers=pool_workers, usable_host_cpus=usable_cpus(),
+                           update="hipGraph" if b.ugraph is not None else "eager", parallelism=parallelism),
+               rollout_ms=round(rollout_ms, 3), update_ms=round(update_ms, 3),
+               last_info={k: round(float(v), 6) for k, v in (b.info or {}).items()})
+    if sustained:
+        out["sustained"] = sustained
+    if args.ingest != "device-tape" and rollout_ms > 0:
+        gbs = b.n_envs * FRAME_BYTES * T / (rollout_ms * 1e-3) / 1e9
+        out["h2d"] = dict(bytes_per_update=b.n_envs * FRAME_BYTES * T, bytes_per_step=b.n_envs * FRAME_BYTES,
+                          achieved_GBs=round(gbs, 2), peak_GBs=PCIE_PEAK_GBS, frac=round(gbs / PCIE_PEAK_GBS, 4),
+                          note="uint8 frames, pinned host memory -> device, inside the timed region; rate over the rollout half")
+    if shard.active:
+        out["rccl_ranks"] = torch.distributed.get_world_size() if torch.distributed.get_backend() == "nccl" else 0
+        out["dist_backend"] = torch.distributed.get_backend()
+        out["allreduce_ms_per_update"] = round(allreduce_ms, 4)
+        out["allreduce_bytes"] = int(b.net._arena.n_train * 4)
 
-    # ---- roofline of the dominant kernel of the update (HIP events on the launch stream)
-    if timers is not None:
-        summ = timers.summary()
+    # ---- rooflines
+    if summ is not None:
         kern = {k: dict(avg_ms=round(v["avg_ms"], 4), launches=v["launches"]) for k, v in
                 sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
         out["update_launch_sites_ms"] = kern
-        out["update_launch_sites_note"] = sites_note
-        if ugraph is not None:
-            out["config"]["update"] = "hipGraph"
-        layers = getattr(net, "_cl", None)
-        if layers is None and hasattr(net, "_c1"):
-            layers = [net._c1, net._c2]
-        conv_layers = {l.name: l for l in (layers or [])}
+        out["update_launch_sites_note"] = "HIP events per launch site, 2 eager updates after the timed region"
+        layers = getattr(b.net, "_cl", None) or ([b.net._c1, b.net._c2] if hasattr(b.net, "_c1") else [])
+        conv_layers = {l.name: l for l in layers}
         dom = next(iter(kern), None)
-        rollout_ms = sum(a.elapsed_time(b) for a, b in roll_ev) / max(len(roll_ev), 1)
-        out["rollout_ms"] = round(rollout_ms, 3)
-        fused_step = graph is not None and getattr(net, "_step_supported", lambda: False)()
-        n_upd = 2 if ugraph is not None else args.steps          # updates the launch-site timers saw
-        dom_ms = summ[dom]["total_ms"] / n_upd if dom is not None else 0.0
+        dom_ms = summ[dom]["total_ms"] / 2 if dom is not None else 0.0
+        fused_step = getattr(b.net, "_step_supported", lambda: False)()
         if fused_step and rollout_ms > dom_ms:
-            # the one-launch rollout step is the kernel the epoch spends most time in: T+1 launches
-            # per hipGraph replay; average launch duration = replay time / (T+1) (includes the
-            # inter-node gaps, so `achieved` is a lower bound; profiles/ holds the rocprofv3 average)
-            us = rollout_ms * 1e3 / (T + 1)
-            fl = step_alg_flops(A) * n_envs
-            by = step_alg_bytes() * n_envs
+            launches = 1 if zero_copy else T + 1
+            us = rollout_ms * 1e3 / launches
+            fl = step_alg_flops(A) * b.n_envs * (T + 1) / launches
+            by = step_alg_bytes(u8_frame=args.ingest != "device-tape") * b.n_envs * (T + 1) / launches
             tf = fl / (us * 1e-6) / 1e12
-            out["roofline"] = dict(kernel=f"a3c_step_kernel (B={n_envs}, {T + 1} launches/rollout)", bound="mfma",
-                                   achieved=round(tf, 2), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
+            name = ("a3c_step_kernel<persistent> = a2c_a3c_rollout (1 launch = %d steps x %d envs, paced by the host env "
+                    "workers and the PCIe frame reads)" % (T + 1, b.n_envs)) if zero_copy else \
+                   f"a3c_step_kernel (B={b.n_envs}, {T + 1} launches/rollout)"
+            out["roofline"] = dict(kernel=name, bound="mfma", achieved=round(tf, 2), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
                                    frac=round(tf / F32_PEAK_TFLOPS, 4), traffic=None, avg_launch_us=round(us, 2),
-                                   hbm_GBs=round(by / (us * 1e-6) / 1e9, 1), hbm_frac=round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                   launches_per_rollout=launches, hbm_GBs=round(by / (us * 1e-6) / 1e9, 1),
+                                   hbm_frac=round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                    alg_flops_per_launch=fl, alg_bytes_per_launch=by)
-            dom = "a3c_step"
+            if zero_copy:
+                out["roofline"]["host_link"] = dict(out["h2d"], note="this launch is bounded by the host hand-shake: "
+                                                    "PCIe frame bytes / launch duration vs the 63 GB/s link")
         elif dom is not None:
             ms = summ[dom]["avg_ms"]
             lname, _, what = dom.partition(".")
@@ -423,14 +601,17 @@ def main():
                                        frac=None, traffic=None)
         # HBM bytes per launch from the PMC passes committed under profiles/ (collected separately:
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/run_kernel.py at this exact size)
-        tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        key = {"conv1.fwd": "conv1_fwd", "conv1.bwd_weight": "conv1_wgrad", "conv2.bwd_data": "conv2_bwd_data",
-               "a3c_step": "a3c_step"}.get(dom)
-        if "roofline" in out and key and args.workload == "a3c" and N == 32768 and os.path.exists(tfile) \
-                and key in json.load(open(tfile)):
-            out["roofline"]["traffic"] = round(json.load(open(tfile))[key]["hbm_bytes_per_launch"])
-            out["roofline"]["traffic_source"] = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KB)"
-        # always report conv1 forward (north star: HBM GB/s on the conv forward) and the scan
+        for tname in ("r2_traffic.json", "r1_traffic.json"):
+            tfile = os.path.join(ROOT, "profiles", tname)
+            key = {"conv1.fwd": "conv1_fwd", "conv1.bwd_weight": "conv1_wgrad", "conv2.bwd_data": "conv2_bwd_data"}.get(dom)
+            if "roofline" in out and out["roofline"].get("traffic") is None and args.workload == "a3c" and N == 32768 \
+                    and os.path.exists(tfile):
+                tj = json.load(open(tfile))
+                k2 = ("a3c_rollout" if zero_copy else "a3c_step") if out["roofline"]["kernel"].startswith("a3c_step") else key
+                if k2 in tj:
+                    out["roofline"]["traffic"] = round(tj[k2]["hbm_bytes_per_launch"])
+                    out["roofline"]["traffic_source"] = f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KB)"
+        # always report conv1 forward (north star: HBM GB/s on the conv forward)
         if "conv1" in conv_layers and "conv1.fwd" in summ:
             d = conv_layers["conv1"].d
             ms = summ["conv1.fwd"]["avg_ms"]
@@ -438,14 +619,66 @@ def main():
             out["conv1_fwd_roofline"] = dict(bound="hbm", avg_ms=round(ms, 4), achieved_GBs=round(ach, 1),
                                              frac=round(ach / HBM_PEAK_GBS, 4),
                                              tflops=round(conv_flops(d, N) / (ms * 1e-3) / 1e12, 2))
+    b.close()
+    del b
+    torch.cuda.empty_cache()
+
     if shard.world == 1:
         out["scan_roofline"] = scan_roofline(dev)
+        if not args.no_secondary and args.workload == "a3c":
+            # kernel-side evidence without the ingest: the round-1 path (frames already in HBM, rollout as a hipGraph of
+            # T+1 a3c_step_kernel launches) -- NOT the north-star number
+            try:
+                d = Bench(args.workload, n_envs, args.optim, "device-tape", "native", 1, shard, dev)
+                d.step(); d.capture(); d.step()
+                e, r_ms, u_ms = d.timed(20)
+                us = r_ms * 1e3 / (T + 1)
+                tf = step_alg_flops(A) * d.n_envs / (us * 1e-6) / 1e12
+                out["value_device_tape"] = dict(value=round(d.N * 20 / e, 1), unit="env-steps/s", steps=20,
+                                                ms_per_step=round(1e3 * e / 20, 3), rollout_ms=round(r_ms, 3),
+                                                update_ms=round(u_ms, 3),
+                                                note="frames pre-generated in HBM (no host ingest), rollout hipGraph")
+                out["step_kernel_roofline"] = dict(kernel=f"a3c_step_kernel (B={d.n_envs}, {T + 1} launches per hipGraph replay)",
+                                                   bound="mfma", achieved=round(tf, 2), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
+                                                   frac=round(tf / F32_PEAK_TFLOPS, 4), avg_launch_us=round(us, 2),
+                                                   hbm_GBs=round(step_alg_bytes() * d.n_envs / (us * 1e-6) / 1e9, 1))
+                d.close()
+                del d
+            except Exception as e:      # noqa: BLE001
+                out["value_device_tape"] = dict(value=None, error=f"{type(e).__name__}: {e}")
+            if args.ingest == "host-pinned" and args.env_workers == "native":
+                try:
+                    nw = max(1, min(48, usable_cpus() - 2))
+                    d = Bench(args.workload, n_envs, args.optim, "host-pinned", "process", nw, shard, dev)
+                    d.step(); d.capture(); d.step()
+                    e, r_ms, u_ms = d.timed(40)
+                    out["host_pinned_process_workers"] = dict(value=round(d.N * 40 / e, 1), unit="env-steps/s", steps=40,
+                                                              ms_per_step=round(1e3 * e / 40, 3), rollout_ms=round(r_ms, 3),
+                                                              update_ms=round(u_ms, 3), env_worker_processes=d.pool.n_workers,
+                                                              note="Python TapeEnv objects stepped in worker processes "
+                                                                   "(a2c_amd.hostpool_worker), same pinned-region protocol")
+                    d.close()
+                    del d
+                except Exception as e:      # noqa: BLE001
+                    out["host_pinned_process_workers"] = dict(value=None, error=f"{type(e).__name__}: {e}")
+        if not args.no_configs and args.workload == "a3c" and not args.n_envs and not args.global_envs:
+            cfgs = {}
+            for key, wl, ne, st_, wu in (("conv_32x64", "conv", None, 5, 2), ("gru_bptt_256x128", "gru_bptt", None, 3, 1),
+                                         ("a3c_32", "a3c", 32, 20, 3), ("a3c_2048", "a3c", 2048, 5, 2)):
+                try:
+                    torch.cuda.empty_cache()
+                    cfgs[key] = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu)
+                except Exception as e:      # noqa: BLE001
+                    cfgs[key] = dict(error=f"{type(e).__name__}: {e}")
+            out["configs"] = cfgs
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(model, n_envs, T, use_bptt, A, args.optim)
+                out["cpu_baseline"] = cpu_baseline(model, WORKLOADS[args.workload][1] if not n_envs else n_envs, T,
+                                                   WORKLOADS[args.workload][3], A, args.optim)
             except Exception as e:      # noqa: BLE001
                 out["cpu_baseline"] = dict(value=None, error=f"{type(e).__name__}: {e}")
-    print(json.dumps(out))
+    print(json.dumps(out), file=json_out)
+    json_out.flush()
 
 
 if __name__ == "__main__":

@@ -38,3 +38,15 @@ __device__ __forceinline__ T block_sum_256(T v, T* sm /* >= 4 */) {
   __syncthreads();
   return r;
 }
+
+// Small device buffers (error flags, reduction sums; <= 256 B, 4-byte multiples) are cleared by a one-wave kernel,
+// not by hipMemsetAsync: as a NODE of a captured hipGraph the memset was observed to leave 0x01010101 in a
+// 4-byte flag on some replays (ROCm 7.2, gfx950), which a kernel node never does.
+namespace {
+__global__ void a2c_zero_words_kernel(unsigned int* p, int n) {
+  for (int i = threadIdx.x; i < n; i += 64) p[i] = 0u;
+}
+}  // namespace
+static inline void a2c_zero_async(void* p, size_t bytes, hipStream_t st) {
+  hipLaunchKernelGGL(a2c_zero_words_kernel, dim3(1), dim3(64), 0, st, (unsigned int*)p, (int)(bytes / 4));
+}

@@ -88,7 +88,7 @@ extern "C" int a2c_loss_fwd_bwd(const float* logits, int64_t ld_logits, const fl
                                 a2c_stream_t stream) {
   if (n_local < 0 || n_global < n_local || A < 1 || A > MAXA || !loss_sums) return A2C_ERR_ARG;
   if (adv_sums && n_global < 2) return A2C_ERR_ARG;
-  (void)hipMemsetAsync(loss_sums, 0, 3 * sizeof(double), a2c_s(stream));
+  a2c_zero_async(loss_sums, 3 * sizeof(double), a2c_s(stream));
   if (n_local == 0) return A2C_OK;
   if (!logits || !vals || !actions || !advs || !returns || !dlogits || !dvals) return A2C_ERR_ARG;
   hipLaunchKernelGGL(loss_kernel, dim3(a2c_grid_1d(n_local, 256, 1024)), dim3(256), 0, a2c_s(stream), logits,

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
 extern "C" {
 int a2c_gradnorm_sq(const float* grads, int64_t n, double* sumsq, a2c_stream_t stream) {
   if (n < 0 || !sumsq || (n > 0 && !grads) || ((uintptr_t)grads % 16)) return A2C_ERR_ARG;
-  (void)hipMemsetAsync(sumsq, 0, sizeof(double), a2c_s(stream));
+  a2c_zero_async(sumsq, sizeof(double), a2c_s(stream));
   if (n == 0) return A2C_OK;
   hipLaunchKernelGGL(sumsq_kernel, dim3(a2c_grid_1d((n + 3) / 4, 256, 1024)), dim3(256), 0, a2c_s(stream), grads,
                      (long)n, sumsq);

@@ -191,7 +191,7 @@ int launch_scan(const float* x0, const float* x1, const float* dn, float* y0, fl
   if (n_seg < 0 || T < 0) return A2C_ERR_ARG;
   if (n_seg == 0 || T == 0) return A2C_OK;
   if (!x0 || !dn || !y0 || (NARR == 2 && (!x1 || !y1))) return A2C_ERR_ARG;
-  if (err) (void)hipMemsetAsync(err, 0, sizeof(int), st);
+  if (err) a2c_zero_async(err, sizeof(int), st);
   const int64_t ld = T | 1;
   const bool al16 = (((uintptr_t)x0 | (uintptr_t)dn | (uintptr_t)y0 | (uintptr_t)(NARR == 2 ? x1 : x0) |
                       (uintptr_t)(NARR == 2 ? y1 : y0)) % 16) == 0;
@@ -282,7 +282,7 @@ int a2c_gae_returns_fused(const float* deltas, const float* rewards, const float
 
 int a2c_moments(const float* x, int64_t n, double* sums, a2c_stream_t stream) {
   if (!sums || n < 0 || (n > 0 && !x)) return A2C_ERR_ARG;
-  (void)hipMemsetAsync(sums, 0, 2 * sizeof(double), a2c_s(stream));
+  a2c_zero_async(sums, 2 * sizeof(double), a2c_s(stream));
   if (n == 0) return A2C_OK;
   hipLaunchKernelGGL(moments_kernel, dim3(a2c_grid_1d(n, 256, 1024)), dim3(256), 0, a2c_s(stream), x, (long)n, sums);
   A2C_CHECK_LAUNCH();

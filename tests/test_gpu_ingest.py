@@ -226,3 +226,73 @@ def test_rollout_sampler_never_returns_minus_one():
     assert int(acts.min()) >= 0 and int(acts.max()) == A - 1
     p = torch.tensor([[.3, .3, .3]])
     assert float(utils.sample_action(p, rand_nums=torch.tensor([.95]))) == -1.0
+
+
+def test_full_size_headline_rollout_properties_and_action_flip_census():
+    """BASELINE headline size (A3CModel, 256 envs x 128 steps) through the headline path (native env threads,
+    zero-copy persistent kernel), checked by size-independent properties and a census of sampled actions:
+      * every slot ends with done == 1; actions in range; rewards in {-1, 0, 1} (+ bootstrap on the last step);
+      * frame stack: plane c of state t+1 == plane c+1 of state t unless the env was reset (utils.py:26-43);
+      * the update's GAE / returns scans bit-exact against the sequential definition on sampled rows;
+      * the oracle forward on 2,048 of the 32,768 states with the SAME uniforms samples the same action;
+        a flip is only tolerated where the fp32 cumsum is within 1e-6 of the uniform (composed heads
+        re-associate the logits), and at most 1e-4 of the samples may flip."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    from a2c_amd.updater import Updater
+    B, T, A, ss = 256, 128, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    net = make_net("A3CModel", ss, A, 256)
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    envs = [TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 100) for j in range(B)]
+    pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=True)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy")
+    try:
+        r.rollout(net, list(range(B)), hyps)
+        r.finish()
+        u = r._u_keep.cpu()                                    # (T, B) uniforms the kernel used
+        st = D["states"].cpu().reshape(B, T, 4, -1)
+        acts = D["actions"].cpu().reshape(B, T)
+        dones, rews = D["dones"].cpu().reshape(B, T), D["rewards"].cpu().reshape(B, T)
+        assert bool((dones[:, -1] == 1).all())
+        assert int(acts.min()) >= 0 and int(acts.max()) <= A - 1
+        assert set(np.unique(rews[:, :-1].numpy())) <= {-1.0, 0.0, 1.0}
+        # env data == the tapes (step k of env j consumed frame k+1, reward k, done k)
+        for j in (0, 17, 255):
+            e = TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 100)
+            for t in range(1, T):
+                assert np.array_equal(st[j, t, 3].numpy(), e.frames[t % (T + 1)].reshape(-1).astype(np.float32)), (j, t)
+        # frame stack property on every env / step
+        real_done = torch.from_numpy(np.stack([e.dones[:T] for e in envs]).astype(np.float32))
+        for c in range(3):
+            same = (st[:, 1:, c] == st[:, :-1, c + 1]).all(-1)
+            zero = (st[:, 1:, c] == 0).all(-1)
+            assert bool((same | (zero & (real_done[:, :T - 1] == 1))).all())
+        # scans: bit-exact against the sequential definition (utils.py:63-79) on sampled rows
+        upd = Updater(net, hyps)
+        deltas = D["deltas"].cpu().reshape(B, T).numpy()
+        rew_np, done_np = rews.numpy(), dones.numpy()
+        info = upd.update_model(D)
+        assert all(np.isfinite(v) for v in info.values())
+        advs, rets = upd._bufs["advs"].cpu().reshape(B, T).numpy(), upd._bufs["rets"].cpu().reshape(B, T).numpy()
+        for j in (0, 31, 128, 255):
+            close("advs", advs[j], O.discount_np(deltas[j], done_np[j], hyps["gamma"] * hyps["lambda_"]), 0, 0)
+            close("rets", rets[j], O.discount_np(rew_np[j], done_np[j], hyps["gamma"]), 0, 0)
+        # action-flip census
+        idx = (np.arange(2048, dtype=np.int64) * 2654435761 % (B * T)).astype(np.int64)
+        with torch.no_grad():
+            _, logits = onet(D["states"].cpu().reshape(B * T, *ss)[idx])
+        p = torch.softmax(logits, -1)
+        cs = torch.cumsum(p, -1)
+        uu = u.t().reshape(-1)[idx]                            # sample e = slot*T + t  <->  u[t, slot]
+        ref = (cs >= uu[:, None]).float().argmax(-1)
+        ref[(cs < uu[:, None]).all(-1)] = A - 1
+        got = acts.reshape(-1)[idx]
+        flips = (ref != got).nonzero().flatten()
+        assert len(flips) <= max(1, int(1e-4 * len(idx))), len(flips)
+        for f in flips.tolist():
+            assert float((cs[f] - uu[f]).abs().min()) < 1e-6, (f, cs[f], uu[f])
+    finally:
+        r.close()

@@ -133,6 +133,7 @@ def test_softmax_sample_vs_oracle(A):
     logits = rnd((B, A + 1), 10 + A, -4, 4)          # strided rows, like the heads buffer
     u = rnd((B,), 30 + A, 0, 1)
     want = O.sample_action(F.softmax(logits[:, :A], dim=-1), u).long()
+    want[want < 0] = A - 1          # the rollout sampler returns the last action where utils.sample_action falls through (-1)
     ld, ud = logits.to(DEV), u.to(DEV)
     acts = torch.full((B, 3), -7, dtype=torch.int64, device=DEV)
     probs = torch.empty(B, A, device=DEV)

@@ -450,3 +450,44 @@ def test_updater_optimizer_state_dict_matches_torch_layout():
         getattr(torch.optim, opt)(onet.parameters(), lr=1e-4).load_state_dict(
             {"state": {k: {s: (v.cpu() if torch.is_tensor(v) else v) for s, v in st.items()}
                        for k, st in sd["state"].items()}, "param_groups": sd["param_groups"]})
+
+
+# ------------------------------------------------------------------ step kernel at scale
+@pytest.mark.parametrize("B", [300, 2048])
+def test_a3c_step_kernel_many_envs_vs_layered_and_oracle(B, monkeypatch):
+    """more workgroups than CUs (BASELINE config 5 runs 2048 envs): the one-launch step kernel against the
+    per-layer path on every env, and against the oracle on sampled envs"""
+    from a2c_amd.runner import Runner
+    T, A, ss = 3, 4, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=2 + j % 3, done_period=3 + j % 5) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    us = torch.from_numpy(hashf(T * B, 4242, 0, 1).reshape(T, B))
+    usd = us.to(DEV)
+
+    out = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("A2C_NO_FUSED_STEP", "1")
+        net = make_net("A3CModel", ss, A, 256)
+        D = _datas(B * T, ss, False, actions_on_host=False)
+        from a2c_amd.runner import HostEnvPool
+        pool = HostEnvPool([O.FakeEnv(**k) for k in ekws])
+        r = Runner(D, hyps, None, None, None, env_pool=pool, uniform_fn=lambda t, Bn, e0: usd[t, e0:e0 + Bn].contiguous())
+        r.rollout(net, list(range(B)), hyps)
+        torch.cuda.synchronize()
+        out[fused] = {k: v.cpu() for k, v in D.items()}
+    for k in ("states", "actions", "dones"):
+        assert torch.equal(out[True][k], out[False][k]), k
+    close("rewards", out[True]["rewards"], out[False]["rewards"], 1e-5, 1e-5)      # last step: + gamma * V(bootstrap)
+    close("deltas", out[True]["deltas"], out[False]["deltas"], 1e-5, 1e-5)
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    for j in (0, 255, 256, B - 1):
+        Do = dict(states=torch.zeros(T, *ss), deltas=torch.zeros(T), rewards=torch.zeros(T), dones=torch.zeros(T),
+                  actions=torch.zeros(T).long())
+        it = iter([float(us[t, j]) for t in range(T)])
+        sr = O.SlotRunner(O.FakeEnv(**ekws[j]), Do, hyps, uniform_fn=lambda it=it: next(it))
+        sr.start(onet)
+        sr.rollout(onet, 0)
+        sl = slice(j * T, (j + 1) * T)
+        assert torch.equal(out[True]["actions"][sl], Do["actions"]) and torch.equal(out[True]["states"][sl], Do["states"])
+        close("deltas", out[True]["deltas"][sl], Do["deltas"], 1e-5, 1e-5)

@@ -28,9 +28,11 @@ def _free_port():
     return p
 
 
-def _shard_worker(rank, world, port, kind, opt, q):
+def _shard_worker(rank, world, port, kind, opt, q, ss=(4, 84, 84), backend="gloo", force=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", A2C_DIST_BACKEND="gloo")
+                      LOCAL_RANK="0", A2C_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if force:
+        os.environ["A2C_FORCE_COLLECTIVES"] = "1"
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "pytorch-a2c_amd"), os.path.join(root, "tests", "golden"),
@@ -41,8 +43,9 @@ def _shard_worker(rank, world, port, kind, opt, q):
     from test_gpu_models import make_net
     from cases import base_hyps, synth_shared
     torch.cuda.set_device(0)
-    ss, A, h, R, T = (4, 84, 84), 3, 256, 4, 6
+    A, h, R, T = 3, 256 if ss[-1] == 84 else 32, 4, 6
     sh = Shard.from_env()
+    assert sh.active and dist.get_backend() == backend
     net = make_net(kind, ss, A, h)
     lo, hi = sh.slot_range(R)
     hyps = base_hyps(n_tsteps=T, n_rollouts=hi - lo, optim_type=opt, h_size=h)
@@ -56,12 +59,14 @@ def _shard_worker(rank, world, port, kind, opt, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,opt", [("A3CModel", "RMSprop"), ("GRUModel", "Adam")])
-def test_sharded_update_equals_single_process(kind, opt):
+@pytest.mark.parametrize("kind,opt,ss", [("A3CModel", "RMSprop", (4, 84, 84)), ("GRUModel", "Adam", (4, 84, 84)),
+                                         ("ConvModel", "RMSprop", (4, 84, 84)), ("ConvModel", "Adam", (4, 20, 20))])
+def test_sharded_update_equals_single_process(kind, opt, ss):
     """world_size 2 (two processes, gloo all-reduce of the CUDA gradient arena) must reproduce
-    the single-process update on the whole batch: losses, GradNorm and every parameter."""
+    the single-process update on the whole batch: losses, GradNorm and every parameter.
+    ConvModel = BASELINE config 5's model (230 MB gradient message at 84x84)."""
     from a2c_amd.updater import Updater
-    ss, A, h, R, T = (4, 84, 84), 3, 256, 4, 6
+    A, h, R, T = 3, 256 if ss[-1] == 84 else 32, 4, 6
     net = make_net(kind, ss, A, h)
     upd = Updater(net, base_hyps(n_tsteps=T, n_rollouts=R, optim_type=opt, h_size=h))
     ref_infos = []
@@ -72,10 +77,10 @@ def test_sharded_update_equals_single_process(kind, opt):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, kind, opt, q)) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, kind, opt, q, ss)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -87,6 +92,33 @@ def test_sharded_update_equals_single_process(kind, opt):
             np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
     for a, b in zip(res[0][2], res[1][2]):          # ranks stay bit-identical without any broadcast
         assert np.array_equal(a, b)
+
+
+def test_rccl_branch_executes_at_world_1():
+    """backend "nccl" (= RCCL on ROCm) with the collectives forced on at world_size 1: the all-reduce of the
+    gradient arena, of the advantage moments and of the loss sums really go through RCCL, and the update equals
+    the plain single-process one."""
+    from a2c_amd.updater import Updater
+    kind, opt, ss, A, h, R, T = "A3CModel", "RMSprop", (4, 84, 84), 3, 256, 4, 6
+    net = make_net(kind, ss, A, h)
+    upd = Updater(net, base_hyps(n_tsteps=T, n_rollouts=R, optim_type=opt, h_size=h))
+    ref_infos = []
+    for u in range(2):
+        D = synth_shared(kind, ss, A, h, R, T, seed=700 + 10 * u, recurrent=False)
+        ref_infos.append(upd.update_model({k: v.cuda() for k, v in D.items()}))
+    ref_params = [p.detach().cpu().numpy() for p in net.parameters()]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_shard_worker, args=(0, 1, _free_port(), kind, opt, q, ss, "nccl", True))
+    p.start()
+    rank, infos, params = q.get(timeout=600)
+    p.join(60)
+    assert p.exitcode == 0
+    for u in range(2):
+        for k in ref_infos[u]:
+            assert infos[u][k] == pytest.approx(ref_infos[u][k], rel=2e-5, abs=1e-7), (u, k)
+    for a, b in zip(params, ref_params):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
 
 
 def test_runner_run_queue_protocol():

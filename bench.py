@@ -264,6 +264,7 @@ class Bench:
             D["h_states"] = torch.zeros(N, 256, device=dev)
         self.slots = list(range(self.n_envs))
         self.graph = self.ugraph = None
+        self.graph_stash = False
         self.env_workers = env_workers
         if ingest == "device-tape":
             self.pool = pool = SyntheticDevicePool(self.n_envs, self.T, dev, seed=shard.rank)
@@ -282,6 +283,8 @@ class Bench:
         if self.graph is not None:
             self.graph.replay()
             self.net._dirty = False        # the captured rollout re-derived the inference weights (conv fragments, Wc)
+            if self.graph_stash:           # ... and stashed the conv activations of every state for the update
+                self.net.stash_commit(self.D["states"], self.N)
         else:
             self.runner.rollout(self.net, self.slots, self.hyps)
 
@@ -308,6 +311,7 @@ class Bench:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self.runner.rollout(self.net, self.slots, self.hyps)
                 self.graph = g
+                self.graph_stash = self.runner._stash_bufs is not None and self.runner._stash_used
             except Exception as e:      # noqa: BLE001
                 print(f"[bench] rollout hipGraph capture failed ({type(e).__name__}: {e}); eager rollout", file=sys.stderr)
                 self.graph = None
@@ -316,14 +320,19 @@ class Bench:
         # sharded update the collective sits in the middle: two graphs around it would be needed (not captured).
         if self.want_update_graph and not self.shard.active:
             try:
+                # an update always follows a rollout: capture it in that state (the rollout's activation stash is
+                # valid, so the captured forward starts behind the two conv layers), then replay it once so that the
+                # rollout that was just played is consumed like any other
+                self.rollout()
                 torch.cuda.synchronize()
                 ug = torch.cuda.CUDAGraph()
-                dirty = self.net._dirty
+                dirty, stash = self.net._dirty, self.net._stash
                 with torch.cuda.graph(ug, capture_error_mode="thread_local"):
                     self.udev, self.u_nglobal = self.updater._enqueue_update(self.D)
                 self.ugraph = ug
-                self.net._dirty = dirty          # the capture itself did not run:
-                self.updater.optim._steps -= 1   # ... no optimiser step happened
+                self.net._dirty, self.net._stash = dirty, stash      # the capture itself did not run:
+                self.updater.optim._steps -= 1                        # ... no optimiser step happened
+                self.info = self.update()
             except Exception as e:      # noqa: BLE001
                 print(f"[bench] update hipGraph capture failed ({type(e).__name__}: {e}); eager update", file=sys.stderr)
                 self.ugraph = None

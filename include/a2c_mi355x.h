@@ -156,6 +156,12 @@ typedef struct {
   int pong, bootstrap;
   const uint8_t *frame_u8;         /* instead of frame_new: uint8 frame (B, frame_stride bytes), */
   int64_t frame_stride;            /* e.g. the pool's frames block after its H2D copy            */
+  /* optional stash of the conv activations of this state (post-ReLU, NCHW): a1 (16, OH1, OW1) and a2
+   * (32, OH2, OW2) of env b go to a1_out + b*a1_stride / a2_out + b*a2_stride.  The weights do not change
+   * between a rollout and the update that consumes it (training.py:150-165), so Updater.update_model's
+   * forward (updater.py:80) would recompute exactly these tensors: it reads the stash instead.           */
+  float *a1_out; int64_t a1_stride;
+  float *a2_out; int64_t a2_stride;
 } a2c_a3c_step_args;
 int a2c_a3c_step_supported(int C, int H, int W, int n_actions);
 int a2c_a3c_step(const a2c_a3c_step_args *args, a2c_stream_t stream);
@@ -194,6 +200,7 @@ typedef struct {
   int env0;                        /* pool index of env b is env0 + b                         */
   int *err;                        /* device int                                              */
   int64_t timeout_ticks;
+  float *a1_rows, *a2_rows;        /* optional activation stash, row e = (slot0+b)*T + t (see a2c_a3c_step_args) */
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
 

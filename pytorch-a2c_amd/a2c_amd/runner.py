@@ -269,6 +269,13 @@ class Runner:
         idxs = [idx] if isinstance(idx, int) else list(idx)
         if self.proc_pool and len(idxs) != self.B:
             raise ValueError("a process env pool advances all its envs in lock-step: roll out all of its slots at once")
+        # one call that fills EVERY row of the rollout buffer: the step kernels may stash the conv activations
+        # of each state for the update that follows (same weights, same states)
+        N = self.datas["states"].shape[0]
+        T_ = int(hyps["n_tsteps"])
+        self._stash_bufs = None
+        if idxs == list(range(N // T_)) and N % T_ == 0 and self.h is None:
+            self._stash_bufs = net.stash_rows(self.datas["states"], N)
         j = 0
         while j < len(idxs):
             k = j
@@ -278,6 +285,8 @@ class Runner:
             j = k + 1
         if self.proc_pool:
             self.env_pool.seq += int(hyps["n_tsteps"])
+        if self._stash_bufs is not None and self._stash_used:
+            net.stash_commit(self.datas["states"], N)
 
     def _uniforms(self, t, B, env0):
         if self.uniform_fn is not None:
@@ -318,6 +327,7 @@ class Runner:
         val_prev, done_eff = self.val_prev[env0:env0 + B], self.done_eff[env0:env0 + B]
         h = None if self.h is None else self.h[env0:env0 + B]
         acts_host_out = D["actions"] if not D["actions"].is_cuda else None
+        self._stash_used = False
         if self._zero_copy_ok(net):
             return self._rollout_block_persistent(net, slot0, env0, B, hyps, bm, val_prev, acts_host_out, st)
         # The per-step bookkeeping kernel only feeds later bookkeeping, so it CAN run on a side stream
@@ -394,8 +404,14 @@ class Runner:
         rec = dict(val_prev=val_prev.data_ptr(), rewards=D["rewards"].data_ptr(), dones=D["dones"].data_ptr(),
                    deltas=D["deltas"].data_ptr(), T=T, slot0=slot0, gamma=float(gamma), pong=int(pong))
         fr = rew = done = reset = None
+        stash = self._stash_bufs
+        self._stash_used = stash is not None
         for t in range(T + 1):
             kw = dict(rec)
+            if stash is not None and t < T:      # conv activations of state (slot, t) -> row slot*T + t of the update's buffers
+                n1, n2 = stash[0][0].numel(), stash[1][0].numel()
+                kw.update(a1_out=stash[0].data_ptr() + 4 * (slot0 * T + t) * n1, a1_stride=T * n1,
+                          a2_out=stash[1].data_ptr() + 4 * (slot0 * T + t) * n2, a2_stride=T * n2)
             if t == 0:        # state of step 0 = the bookmark left by the previous slot (runner.py:190)
                 kw.update(prev=bm.data_ptr(), prev_stride=S, out=sp(0), out_stride=T * S)
             else:
@@ -452,7 +468,10 @@ class Runner:
                         dones=D["dones"].data_ptr(), deltas=D["deltas"].data_ptr(), T=T, slot0=slot0,
                         gamma=float(hyps["gamma"]), pong=int("Pong" in hyps["env_type"]), cmd=pool.dev_cmd, rec=pool.dev_rec,
                         frames=pool.dev_frames, frame_stride=self.fstride, seq0=pool.seq, env0=env0,
-                        err=self.rollout_err.data_ptr(), timeout_ticks=int(timeout_s * 1e8))
+                        err=self.rollout_err.data_ptr(), timeout_ticks=int(timeout_s * 1e8),
+                        a1_rows=0 if self._stash_bufs is None else self._stash_bufs[0].data_ptr(),
+                        a2_rows=0 if self._stash_bufs is None else self._stash_bufs[1].data_ptr())
+        self._stash_used = self._stash_bufs is not None
         if acts_host_out is not None:
             acts_host_out[slot0 * T:(slot0 + B) * T].copy_(acts[slot0 * T:(slot0 + B) * T])
 

@@ -54,6 +54,8 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   int env0;
   int* err;
   long timeout_ticks;
+  float* a1_rows;
+  float* a2_rows;
 };
 
 struct StepP {
@@ -70,6 +72,8 @@ struct It {
   const float* frame32;        // fp32 new frame of this env, or nullptr
   bool frame8;                 // the new frame is the uint8 one (loaded separately)
   float* out;                  // row that receives the state (nullptr: none)
+  float* a1o;                  // stash rows for the conv activations of this state (nullptr: none)
+  float* a2o;
 };
 
 // plane c of state_t comes from: the new frame (c == 3) / plane c+1 of the previous state (frame
@@ -194,6 +198,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       rec = t > 0; t_rec = t - 1; boot = t == (int)a.T; sample = t < (int)a.T;
       u_ptr = p.x.u + (long)t * p.x.u_stride + b;
       act_ptr = p.x.actions + row + t;
+      it.a1o = (p.x.a1_rows && t < (int)a.T) ? p.x.a1_rows + (row + t) * (16L * NP1) : nullptr;
+      it.a2o = (p.x.a2_rows && t < (int)a.T) ? p.x.a2_rows + (row + t) * (long)p.F : nullptr;
     } else {
       it.prev = a.prev + (long)b * a.prev_stride;
       it.frame32 = a.frame_new ? a.frame_new + (long)b * HW : nullptr;
@@ -202,6 +208,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       rec = a.rew != nullptr; t_rec = a.t_rec; boot = a.bootstrap != 0; sample = a.u != nullptr;
       u_ptr = a.u + b;
       act_ptr = a.actions + (long)b * a.act_stride;
+      it.a1o = a.a1_out ? a.a1_out + (long)b * a.a1_stride : nullptr;
+      it.a2o = a.a2_out ? a.a2_out + (long)b * a.a2_stride : nullptr;
     }
     const bool has_frame = it.frame32 != nullptr || it.frame8;
 
@@ -356,6 +364,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #ifndef A2C_STEP_EARLY_STORES
     if (OUT) store_chunk(pf2, it, p.row_end[1], q2, HW, W, tid, zero_old);
 #endif
+    if (it.a1o != nullptr) {       // stash conv1's activations (16 x NP1, dense) for the update: LDS -> HBM, streaming
+      const int n4 = NP1 >> 2;     // float4 per channel
+      for (int q = tid; q < 16 * n4; q += NT) {
+        const int ch = q / n4, o4 = q - ch * n4;
+        const float4 v = *reinterpret_cast<const float4*>(a1 + ch * p.PLANE2 + (o4 << 2));
+        __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(it.a1o) + q);
+      }
+    }
     // head weights for this thread's K slices: issued here (not with conv2's fragments before phase 2:
     // 16 more float4 per thread on the vector-memory pipe delayed that matrix phase), in flight during conv2
 #pragma unroll
@@ -415,6 +431,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
     }
     __syncthreads();
+    if (it.a2o != nullptr) {       // stash conv2's activations (flat (c, y, x) = the proj_matrx input row)
+      for (int q = tid; q < (p.F >> 2); q += NT) {
+        const float4 v = *reinterpret_cast<const float4*>(a2 + (q << 2));
+        __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(it.a2o) + q);
+      }
+    }
     TS(6);
 
     // ---- heads: N dot products of length F.  Per-thread partials are transposed through LDS so
@@ -600,6 +622,9 @@ int a2c_a3c_step(const a2c_a3c_step_args* args, a2c_stream_t stream) {
   if (a.frame_u8 && (a.frame_new || !u8_shapes(a.H, a.W) || a.frame_stride % 16 || (uintptr_t)a.frame_u8 % 16 ||
                      a.frame_stride < a.H * a.W))
     return A2C_ERR_ARG;
+  if ((a.a1_out || a.a2_out) && ((p.OH1 * p.OW1) % 4 || a.a1_stride % 4 || a.a2_stride % 4 ||
+                                 (((uintptr_t)a.a1_out | (uintptr_t)a.a2_out) % 16)))
+    return A2C_ERR_ARG;
   const size_t lds = step_lds(p);
   if (!set_lds_attr()) return A2C_ERR_LAUNCH;
   if (a.frame_u8) {
@@ -629,11 +654,13 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.states = r->states; p.x.bookmark = r->bookmark; p.x.u = r->u; p.x.u_stride = (long)r->u_stride;
   p.x.actions = r->actions; p.x.cmd = (unsigned long long*)r->cmd; p.x.rec = (const unsigned long long*)r->rec;
   p.x.seq0 = r->seq0; p.x.env0 = r->env0; p.x.err = r->err; p.x.timeout_ticks = (long)r->timeout_ticks;
+  p.x.a1_rows = r->a1_rows; p.x.a2_rows = r->a2_rows;
   if (!step_shapes(a.C, a.H, a.W, a.n_actions, p) || step_lds(p) > 160 * 1024 || !u8_shapes(a.H, a.W)) return A2C_ERR_ARG;
   if (!r->states || !r->bookmark || !r->u || !r->actions || !r->cmd || !r->rec || !r->frames || !r->err) return A2C_ERR_ARG;
   if (!a.wfrag1 || !a.bias1 || !a.wfrag2 || !a.bias2 || !a.Wc || !a.bc || !a.heads) return A2C_ERR_ARG;
   if (!a.val_prev || !a.rewards || !a.dones || !a.deltas || a.T < 1 || a.ldh < a.n_actions + 1) return A2C_ERR_ARG;
   if (r->frame_stride % 16 || r->frame_stride < a.H * a.W || r->timeout_ticks < 1 || r->env0 < 0) return A2C_ERR_ARG;
+  if ((r->a1_rows || r->a2_rows) && ((p.OH1 * p.OW1) % 4 || (((uintptr_t)r->a1_rows | (uintptr_t)r->a2_rows) % 16))) return A2C_ERR_ARG;
   if ((((uintptr_t)r->states | (uintptr_t)r->bookmark | (uintptr_t)r->frames | (uintptr_t)a.wfrag2 | (uintptr_t)a.Wc) % 16) ||
       (((uintptr_t)r->cmd | (uintptr_t)r->rec) % 8))
     return A2C_ERR_ARG;

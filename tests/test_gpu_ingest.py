@@ -296,3 +296,41 @@ def test_full_size_headline_rollout_properties_and_action_flip_census():
             assert float((cs[f] - uu[f]).abs().min()) < 1e-6, (f, cs[f], uu[f])
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("ingest", ["zero-copy", "memcpy"])
+def test_update_from_stashed_rollout_activations_equals_recomputed(ingest, monkeypatch):
+    """The one-launch rollout step stashes conv1/conv2 activations of every state; update_model reads them instead
+    of re-running the two conv forwards (same weights, same states: training.py:150-165).  Same update as the
+    recomputed one to fp32 rounding (the step kernel's K-split conv2 re-associates the sums)."""
+    from a2c_amd.runner import Runner
+    from a2c_amd.updater import Updater
+    B, T, A, ss = 6, 5, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3)
+    res = {}
+    for stash in (True, False):
+        if not stash:
+            monkeypatch.setenv("A2C_NO_STASH", "1")
+        net = make_net("A3CModel", ss, A, 256)
+        D = _datas(B * T, ss, False, actions_on_host=False)
+        pool = _pool(U8FakeEnv, ekws, 2, pong=True)
+        r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest)
+        torch.manual_seed(5)          # same sampling uniforms in both runs
+        try:
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            assert (net._stash is not None) == stash
+            info = Updater(net, hyps).update_model(D)
+            assert net._stash is None          # the optimiser step invalidated it
+            res[stash] = (info, net._arena.train_grads().cpu().clone(), {k: v.cpu().clone() for k, v in D.items()})
+        finally:
+            r.close()
+    for k in ("states", "actions", "rewards", "deltas"):
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+    for k in res[True][0]:
+        assert res[True][0][k] == pytest.approx(res[False][0][k], rel=2e-6, abs=1e-8), k
+    # the whole (clipped) gradient arena; parameters after an RMSprop step are NOT compared: g/(sqrt(v)+eps) turns
+    # 1e-9 noise on a near-zero gradient into a visible step
+    ga, gb = res[True][1], res[False][1]
+    close("gradient arena", ga, gb, 2e-6 * float(gb.abs().max()), 1e-5)

@@ -465,6 +465,36 @@ class SlotRunner:
 # updater.py  --  Updater.update_model / bptt (updater.py:33-169)
 # --------------------------------------------------------------------------
 
+def stats_rollout(net, env, hyps, n_episodes, uniform_fn):
+    """Restates StatsRunner.rollout (runner.py:274-314): ``n_episodes`` episodes of ONE env played one after the
+    other with the training sampler (softmax + inverse CDF, ``uniform_fn()`` replaces torch.rand), hidden state
+    reset on done, Pong: an episode ends whenever a point is scored; returns total reward / episodes."""
+    obs_deque = deque(maxlen=hyps["n_frame_stack"])
+    state = next_state(env, obs_deque, obs=None, reset=True)
+    h = torch.zeros(1, net.h_size) if net.is_recurrent else None
+    ep_rew, ep_count = 0.0, 0
+    with torch.no_grad():
+        while ep_count < n_episodes:
+            x = torch.FloatTensor(state)[None]
+            if h is not None:
+                val, logits, h = net(x, h)
+            else:
+                val, logits = net(x)
+            probs = F.softmax(logits, dim=-1)
+            action = int(sample_action(probs, torch.tensor([uniform_fn()], dtype=torch.float32)).item())
+            obs, rew, done, _ = env.step(action + hyps["action_shift"])
+            ep_rew += rew
+            reset = done
+            if "Pong" in hyps["env_type"] and rew != 0:
+                done = True
+            if done:
+                ep_count += 1
+                if h is not None:
+                    h = torch.zeros(1, net.h_size)
+            state = next_state(env, obs_deque, obs=obs, reset=reset)
+    return ep_rew / ep_count
+
+
 def bptt(net, states, h_states, dones, hyps):
     """updater.py:139-169."""
     R, T = hyps["n_rollouts"], hyps["n_tsteps"]

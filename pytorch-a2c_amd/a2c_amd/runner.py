@@ -562,16 +562,103 @@ class _Ptr:
 
 
 class StatsRunner:
-    """Evaluation rollouts (runner.py:250-314): ``n_test_eps`` episodes of one env with the same
-    sampler, run on the device net with batch 1 (not part of the rollout+update metric)."""
+    """Evaluation rollouts (runner.py:250-314) with the training sampler.
 
-    def __init__(self, hyps, env=None):
+    The reference plays ``n_test_eps`` episodes of ONE env one after the other with batch-1 forwards on the main
+    process, every epoch (training.py:167) -- with a millisecond-scale update that serial loop would dominate
+    ``train()``.  Here the ``n_test_eps`` episodes are played by ``n_test_eps`` envs in LOCK-STEP: one batched
+    forward + sampling launch per step for all of them (the one-launch step kernel for A3CModel-shaped nets),
+    each env plays exactly one episode and the result is (sum of the episode rewards) / n_test_eps -- the same
+    estimator over the same number of episodes.  ``StatsRunner(hyps, env=one_env)`` keeps the reference's serial
+    loop (same episodes in the same order as the reference) for callers that own a single env object."""
+
+    def __init__(self, hyps, env=None, envs=None, uniform_fn=None):
         self.hyps = hyps
-        self.env = env if env is not None else SequentialEnvironment(**hyps)
-        self.obs_deque = deque(maxlen=hyps["n_frame_stack"])
         self.n_episodes = try_key(hyps, "n_test_eps", 15)
+        self.uniform_fn = uniform_fn              # (t, E) -> (E,) device uniforms; default torch.rand
+        self.obs_deque = deque(maxlen=hyps["n_frame_stack"])
+        self.envs = list(envs) if envs is not None else None
+        self.env = env
+        if env is None and envs is None:
+            seed = try_key(hyps, "seed", 0)
+            self.envs = [SequentialEnvironment(**dict({k: v for k, v in hyps.items() if k != "seed"}, seed=seed + 10007 + j))
+                         for j in range(self.n_episodes)]
+            self.env = self.envs[0]               # the reference's attribute (training.py:61 reads stats_runner.env)
 
     def rollout(self, net):
+        if self.envs is None:
+            return self._rollout_serial(net)
+        return self._rollout_batched(net)
+
+    # ---- E envs, one episode each, in lock-step on the device
+    def _rollout_batched(self, net, max_steps=None):
+        hyps, envs = self.hyps, self.envs
+        E = len(envs)
+        net._ensure_device()
+        dev = net._dev
+        st = ops.stream()
+        net._refresh(st)
+        C = int(hyps["n_frame_stack"])
+        shift, pong = hyps["action_shift"], "Pong" in hyps["env_type"]
+        first = [np.asarray(e.reset(), dtype=np.float32) for e in envs]
+        HW = first[0].size
+        S = C * HW
+        pin = torch.cuda.is_available()
+        h_frames = torch.zeros(E, HW).pin_memory() if pin else torch.zeros(E, HW)
+        np_frames = h_frames.numpy()
+        for j in range(E):
+            np_frames[j] = first[j].reshape(-1)
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_frames = torch.zeros(E, HW, **f32)
+        cur, nxt = torch.zeros(E, S, **f32), torch.zeros(E, S, **f32)
+        ones, zeros = torch.ones(E, **f32), torch.zeros(E, **f32)
+        act_dev = torch.zeros(E, dtype=torch.int64, device=dev)
+        h = torch.zeros(E, net.h_size, **f32) if net.is_recurrent else None
+        d_frames.copy_(h_frames, non_blocking=True)
+        ops.frame_stack_push(d_frames, ones, cur.data_ptr(), S, cur.data_ptr(), S, E, C, HW, st)      # [0,..,0, env.reset()]
+        fused = (not net.is_recurrent) and getattr(net, "_step_supported", lambda: False)()
+        active = np.ones(E, dtype=bool)
+        ep_rew = np.zeros(E)
+        t = 0
+        max_steps = max_steps or int(try_key(hyps, "max_eval_steps", 10 ** 6))
+        while active.any() and t < max_steps:
+            u = self.uniform_fn(t, E) if self.uniform_fn is not None else torch.rand(E, **f32)
+            if fused:       # state t = push(state t-1, frame) + forward + sample in ONE launch
+                kw = dict(prev=cur.data_ptr(), prev_stride=S) if t == 0 else \
+                    dict(prev=cur.data_ptr(), prev_stride=S, frame_new=d_frames.data_ptr(), reset_mask=zeros.data_ptr(),
+                         out=nxt.data_ptr(), out_stride=S)
+                net._step(E, st, u=u.data_ptr(), actions=act_dev.data_ptr(), act_stride=1, **kw)
+                if t > 0:
+                    cur, nxt = nxt, cur
+            else:
+                if t > 0:
+                    ops.frame_stack_push(d_frames, zeros, cur.data_ptr(), S, nxt.data_ptr(), S, E, C, HW, st)
+                    cur, nxt = nxt, cur
+                if net.is_recurrent:
+                    out = net._fwd(cur.data_ptr(), S, E, "eval", st, False, h_in=h)
+                else:
+                    out = net._fwd(cur.data_ptr(), S, E, "eval", st, False, sampler=(u, act_dev.data_ptr(), 1)) \
+                        if getattr(net, "_fused_sampling", False) else net._fwd(cur.data_ptr(), S, E, "eval", st, False)
+                if not out.get("sampled", False):
+                    ops.softmax_sample(out["logits"], u, act_dev.data_ptr(), 1, E, net.output_space, st=st)
+                if net.is_recurrent:
+                    h.copy_(out["h"])
+            acts = act_dev.cpu().numpy()                       # the one host round trip of the step
+            for j in np.nonzero(active)[0]:
+                obs, rew, done, _ = envs[j].step(int(acts[j]) + shift)
+                ep_rew[j] += rew
+                if pong and rew != 0:
+                    done = True
+                if done:                                        # this env's episode is over: it stops playing
+                    active[j] = False
+                else:
+                    np_frames[j] = np.asarray(obs, dtype=np.float32).reshape(-1)
+            d_frames.copy_(h_frames, non_blocking=True)
+            t += 1
+        return float(ep_rew.sum()) / E
+
+    # ---- the reference's loop, one env, batch 1 (runner.py:274-314)
+    def _rollout_serial(self, net):
         state = next_state(self.env, self.obs_deque, obs=None, reset=True)
         h = cuda_if(torch.zeros(1, net.h_size)) if net.is_recurrent else None
         ep_rew, ep_count = 0, 0

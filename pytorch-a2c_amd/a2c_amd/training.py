@@ -5,9 +5,11 @@ wait for ``n_rollouts`` tokens on ``stop_q`` -> ``updater.update_model(shared_da
 rollout -> re-open the gate -> every 10 epochs save.
 
 Differences forced by the design: ONE ``Runner`` (in a thread of this process) drives all
-``n_envs`` envs in lock-step instead of ``n_envs`` OS processes, and runner and updater share the
-net object, so the weight publish ``net.load_state_dict(updater.net.state_dict())``
-(training.py:165) disappears.  ``ml_utils`` (hyper-search CLI, un-vendored in the reference) is
+``n_envs`` envs in lock-step; the envs themselves are stepped by worker PROCESSES behind the pinned
+pool region (``hostpool.ProcessEnvPool``, the counterpart of the reference's ``n_envs`` runner
+processes, training.py:109-121), and runner and updater share the net object, so the weight publish
+``net.load_state_dict(updater.net.state_dict())`` (training.py:165) disappears.  A failure inside
+the runner thread or an env worker is re-raised here instead of dead-locking ``stop_q.get()``.  ``ml_utils`` (hyper-search CLI, un-vendored in the reference) is
 not mirrored; the two helpers the loop needs (experiment numbering / save folder) are restated.
 """
 import os
@@ -64,15 +66,30 @@ def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None):
         log.write(k + ":" + str(hyps[k]) + "\n")
 
     # environments
+    serial = try_key(hyps, "env_pool", "process") == "serial"
     if env_fn is None:
         hyps["preprocessor"] = getattr(preprocessing, hyps["prep_fxn"])
-        envs = [SequentialEnvironment(**dict(hyps, seed=hyps["seed"] + j)) for j in range(hyps["n_envs"])]
-        frame_shape = np.asarray(envs[0].prep_obs(np.zeros(envs[0].raw_shape, dtype=np.uint8))).shape
-        pool = HostEnvPool(envs, frame_shape=frame_shape)
-        hyps["is_discrete"], n_act = envs[0].is_discrete, envs[0].n
-        eval_env = eval_env or SequentialEnvironment(**hyps)
+        probe = eval_env or SequentialEnvironment(**hyps)             # the probe for shapes (training.py:60-65)
+        hyps["is_discrete"], n_act = probe.is_discrete, probe.n
+        kws = [dict({k: v for k, v in hyps.items() if k != "seed"}, seed=hyps["seed"] + j) for j in range(hyps["n_envs"])]
+        if serial:
+            envs = [SequentialEnvironment(**kw) for kw in kws]
+            frame_shape = np.asarray(envs[0].prep_obs(np.zeros(envs[0].raw_shape, dtype=np.uint8))).shape
+            pool = HostEnvPool(envs, frame_shape=frame_shape)
+        else:
+            from .hostpool import ProcessEnvPool
+            pool = ProcessEnvPool(SequentialEnvironment, hyps["n_envs"], env_kwargs=kws,
+                                  n_workers=try_key(hyps, "n_env_workers", None), pong="Pong" in hyps["env_type"],
+                                  action_shift=1 if hyps["env_type"] == "Pong-v0" else try_key(hyps, "action_shift", 0))
     else:
-        pool = HostEnvPool([env_fn(j) for j in range(hyps["n_envs"])])
+        if serial:
+            pool = HostEnvPool([env_fn(j) for j in range(hyps["n_envs"])])
+        else:
+            from .hostpool import ProcessEnvPool
+            pool = ProcessEnvPool(env_fn, hyps["n_envs"], env_kwargs=[dict(j=j) for j in range(hyps["n_envs"])],
+                                  n_workers=try_key(hyps, "n_env_workers", None), pong="Pong" in hyps["env_type"],
+                                  action_shift=1 if hyps["env_type"] == "Pong-v0" else try_key(hyps, "action_shift", 0),
+                                  probe_reset=True)
         hyps["is_discrete"], n_act = True, hyps["action_size"]
     hyps["state_shape"] = [hyps["n_frame_stack"]] + list(pool.frame_shape[1:])
     if hyps["env_type"] == "Pong-v0":
@@ -89,6 +106,7 @@ def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None):
     if hyps["resume"]:
         net.load_state_dict(torch.load(net_save_file))
     net = cuda_if(net)
+    net._ensure_device()            # the flat parameter arena exists BEFORE the runner thread and the Updater touch it
     shared_data = {"states": cuda_if(torch.zeros((shared_len, *hyps["state_shape"]))),
                    "deltas": cuda_if(torch.zeros(shared_len)), "rewards": cuda_if(torch.zeros(shared_len)),
                    "actions": torch.zeros(shared_len).long(), "dones": cuda_if(torch.zeros(shared_len))}
@@ -100,13 +118,29 @@ def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None):
     runner = Runner(shared_data, hyps, gate_q, stop_q, reward_q, env_pool=pool)
     thread = threading.Thread(target=runner.run, args=(net,), daemon=True)
     thread.start()
-    for i in range(n_rollouts):
-        gate_q.put(i)
 
+    def collect():
+        """stop_q.get() that notices a dead runner: a None token or a stopped thread re-raises its exception"""
+        while True:
+            try:
+                tok = stop_q.get(timeout=1.0)
+            except queue.Empty:
+                if not thread.is_alive():
+                    raise RuntimeError("the rollout thread stopped") from runner.error
+                continue
+            if tok is None:
+                raise RuntimeError("the rollout thread failed") from runner.error
+            return tok
     updater = Updater(net, hyps)
     if hyps["resume"]:
         updater.optim.load_state_dict(torch.load(optim_save_file))
-    stats_runner = StatsRunner(hyps, env=eval_env) if eval_env is not None else None
+    for i in range(n_rollouts):
+        gate_q.put(i)
+    # evaluation: the caller's single env (reference loop), else n_test_eps gym envs in lock-step on the device
+    if eval_env is not None:
+        stats_runner = StatsRunner(hyps, env=eval_env)
+    else:
+        stats_runner = StatsRunner(hyps) if env_fn is None else None
     entr_coef_diff, lr_diff = hyps["entr_coef"] - hyps["entr_coef_low"], hyps["lr"] - hyps["lr_low"]
     past_rews = deque([0] * hyps["n_past_rews"])
     best_eval_rew, epoch, T = -np.inf, 0, 0
@@ -114,7 +148,7 @@ def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None):
         basetime = time.time()
         epoch += 1
         for _i in range(n_rollouts):                                   # barrier: all slots collected
-            stop_q.get()
+            collect()
         T += shared_len
         avg_reward = reward_q.get()
         reward_q.put(avg_reward)
@@ -145,4 +179,9 @@ def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None):
     updater.save_model(net_save_file, optim_save_file)
     log.write("\nBestRew:" + str(best_eval_rew))
     log.close()
+    for _i in range(n_rollouts):        # let the rollout the loop re-opened finish, then stop the thread and the env workers
+        collect()
+    gate_q.put(None)
+    thread.join(timeout=30)
+    runner.close()
     return best_eval_rew

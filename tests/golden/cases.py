@@ -78,6 +78,12 @@ UPDATE_CASES = [
     ("fc_full_adam", "FCModel", (4, 84, 84), 3, 256, 2, 4, "Adam", True, False, False, 1),
     ("grufc_bptt_rms", "GRUFCModel", (4, 4), 2, 64, 3, 7, "RMSprop", True, False, True, 2),
 ]
+# evaluation rollouts (StatsRunner.rollout, runner.py:274-314)
+STATS_CASES = [
+    # name, kind, env_type, n_test_eps, env kwargs, A
+    ("a3c_pong", "A3CModel", "FakePong-v0", 4, dict(env_id=5, rew_period=4, done_period=11), 3),
+    ("gru_brk", "GRUModel", "FakeBreakout", 3, dict(env_id=6, rew_period=3, done_period=5), 4),
+]
 # checkpoints written by the reference's Updater.save_model after one update; resumed for a second one
 CHECKPOINT_CASES = [
     # name, kind, state_shape, A, h, n_rollouts, T, optim, bptt

@@ -91,7 +91,7 @@ def load_reference():
 
 
 R = load_reference()
-from cases import (MODEL_CASES, ROLLOUT_CASES, UPDATE_CASES, CHECKPOINT_CASES, SAMPLE, hashf, base_hyps, synth_shared,  # noqa: E402
+from cases import (MODEL_CASES, ROLLOUT_CASES, UPDATE_CASES, CHECKPOINT_CASES, STATS_CASES, SAMPLE, hashf, base_hyps, synth_shared,  # noqa: E402
                    sample_idx, null_prep)
 
 
@@ -314,9 +314,33 @@ def g7():
     save("g7_checkpoint.npz", **out)
 
 
+# ---------------------------------------------------------------- G8 StatsRunner.rollout
+def g8():
+    out = {}
+    real_rand = torch.rand
+    for (name, kind, env_type, n_eps, ekw, A) in STATS_CASES:
+        _ENV_SPECS[env_type] = dict(env_kwargs=ekw, n_actions=A)
+        hyps = base_hyps(env_type=env_type, n_test_eps=n_eps, action_shift=1 if "Pong" in env_type else 0)
+        net = ref_model(kind, (4, 84, 84), A, 256)
+        sr = R["runner"].StatsRunner(hyps)
+        us = hashf(400, 800 + len(out))
+        used = [0]
+
+        def fake_rand(*shape):
+            used[0] += 1
+            return torch.tensor([us[used[0] - 1]], dtype=torch.float32).reshape(shape)
+        torch.rand = fake_rand
+        with torch.no_grad():
+            avg = sr.rollout(net)
+        torch.rand = real_rand
+        out[f"{name}_uniforms"] = us[:used[0]]
+        out[f"{name}_avg_rew"] = np.array(float(avg))
+    save("g8_stats.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for fn in sys.argv[1:]:
             globals()[fn]()
     else:
-        g1(); g2(); g3(); g4(); g5(); g6(); g7()
+        g1(); g2(); g3(); g4(); g5(); g6(); g7(); g8()

@@ -170,6 +170,60 @@ def test_stats_runner_and_get_action():
         assert np.isfinite(val)
 
 
+def test_stats_runner_serial_matches_reference_golden(golden):
+    """one env: the reference's loop on the device net reproduces the reference's own evaluation (g8)"""
+    from cases import STATS_CASES
+    from a2c_amd.runner import StatsRunner
+    from a2c_amd.utils import sample_action
+    g = golden["g8_stats"]
+    for (name, kind, env_type, n_eps, ekw, A) in STATS_CASES:
+        hyps = base_hyps(env_type=env_type, n_test_eps=n_eps, action_shift=1 if "Pong" in env_type else 0)
+        it = iter(g[f"{name}_uniforms"])
+
+        class Env:          # SequentialEnvironment surface over the fake env, uniforms from the fixture
+            def __init__(self):
+                self.e = O.FakeEnv(**ekw)
+                self.e.reset()
+
+            def reset(self):
+                return self.e.reset()
+
+            def step(self, a):
+                return self.e.step(a)
+
+            def get_action(self, logits):
+                return int(sample_action(torch.softmax(logits, -1), torch.tensor([float(next(it))])).item())
+        net = make_net(kind, (4, 84, 84), A, 256)
+        assert StatsRunner(hyps, env=Env()).rollout(net) == pytest.approx(float(g[f"{name}_avg_rew"]), abs=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["A3CModel", "GRUModel", "FCModel"])
+def test_stats_runner_batched_matches_oracle(kind):
+    """row f3: n_test_eps envs in lock-step on the device, one episode each == the oracle's restatement of the
+    reference loop (runner.py:274-314) run on each env for one episode with the same uniforms"""
+    from a2c_amd.runner import StatsRunner
+    E, A, ss = 6, 3, (4, 84, 84)
+    pong = kind == "A3CModel"
+    hyps = base_hyps(env_type="FakePong-v0" if pong else "FakeBreakout", n_test_eps=E, action_shift=1 if pong else 0)
+    ekws = [dict(env_id=20 + j, rew_period=3 + j % 3, done_period=4 + j) for j in range(E)]
+    # uniforms < 0.999: at u ~ 1 the reference falls through to -1 where the rollout samplers return the last action
+    us = torch.from_numpy(hashf(64 * E, 4711, 0, 0.999).reshape(64, E))
+    usd = us.to(DEV)
+    net = make_net(kind, ss, A, 256)
+    onet = O.OracleNet(kind, ss, A, 256)
+
+    def mk(k):
+        e = O.FakeEnv(**k)
+        e.reset()
+        return e
+    got = StatsRunner(hyps, envs=[mk(k) for k in ekws], uniform_fn=lambda t, n: usd[t, :n].contiguous()).rollout(net)
+    want = 0.0
+    for j in range(E):
+        it = iter([float(us[t, j]) for t in range(64)])
+        want += O.stats_rollout(onet, mk(ekws[j]), hyps, 1, lambda it=it: next(it))
+    assert got == pytest.approx(want / E, abs=1e-12)
+
+
 def test_norm_returns_matches_oracle():
     from a2c_amd.updater import Updater
     kind, ss, A, h, R, T = "A3CModel", (4, 84, 84), 3, 256, 3, 5

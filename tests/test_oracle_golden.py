@@ -184,3 +184,19 @@ def test_c_oracle_matches_golden(golden):
     t = torch.tensor
     want = (t(0.5) + t(0.99) * t(0.3) * (1 - t(0.0)) - t(0.2)).item()
     assert lib.oracle_td_delta(0.5, 0.99, 0.3, 0.0, 0.2) == want
+
+
+def test_stats_rollout_matches_the_reference(golden):
+    """oracle restatement of StatsRunner.rollout (runner.py:274-314) vs the reference's own run (g8)"""
+    from cases import STATS_CASES
+    g = golden["g8_stats"]
+    for (name, kind, env_type, n_eps, ekw, A) in STATS_CASES:
+        hyps = base_hyps(env_type=env_type, n_test_eps=n_eps, action_shift=1 if "Pong" in env_type else 0)
+        net = O.OracleNet(kind, (4, 84, 84), A, 256)
+        us = g[f"{name}_uniforms"]
+        it = iter(us)
+        env = O.FakeEnv(**ekw)
+        env.reset()                       # SequentialEnvironment.__init__'s probing reset (runner.py:45)
+        avg = O.stats_rollout(net, env, hyps, n_eps, lambda: float(next(it)))
+        assert avg == float(g[f"{name}_avg_rew"])
+        assert next(it, None) is None     # consumed exactly the uniforms the reference drew

@@ -18,6 +18,18 @@ def lib():
     return _lib.load()
 
 
+def load_torch_ops():
+    """Registers ``torch.ops.a2c_mi355x.*`` (TORCH_LIBRARY shim over the C ABI, csrc/torch_ops.cpp): discount,
+    gae_returns, softmax_sample, frame_stack_push, loss_fwd_bwd, linear, clip_rmsprop_.  HIP dispatch key only."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liba2c_torch_ops.so")
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: run make -C pytorch-a2c_amd/csrc")
+    _lib.load()
+    torch.ops.load_library(path)
+    return torch.ops.a2c_mi355x
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 

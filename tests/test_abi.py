@@ -93,3 +93,14 @@ def test_product_never_imports_the_oracle():
                 for line in open(os.path.join(dp, f)).read().splitlines():
                     low = line.lower()
                     assert not ("oracle" in low and ("import" in low or "include" in low)), (f, line)
+
+
+def test_torch_library_ops_are_registered_without_cpu_kernels():
+    """torch.ops.a2c_mi355x.* (TORCH_LIBRARY shim over the C ABI): registered, HIP dispatch key only"""
+    import torch
+    from a2c_amd import ops
+    o = ops.load_torch_ops()
+    for name in ("discount", "gae_returns", "softmax_sample", "frame_stack_push", "loss_fwd_bwd", "linear", "clip_rmsprop_"):
+        assert hasattr(o, name), name
+    with pytest.raises(NotImplementedError):
+        o.discount(torch.zeros(4), torch.zeros(4), 0.9, 1)

@@ -611,3 +611,31 @@ def test_clip_optimizer_vs_torch(kind):
         assert norm.item() == pytest.approx(float(tn), rel=2e-6)
         close(f"clipped grad step {step}", gd, ref_p.grad, 1e-10, 2e-6)
         close(f"params step {step}", pd, ref_p.detach(), 2e-7, 1e-6)
+
+
+def test_torch_ops_shim_matches_oracle():
+    """torch.ops.a2c_mi355x.* (custom-op registration over the C ABI) on the HIP dispatch key"""
+    from a2c_amd import ops as aops
+    o = aops.load_torch_ops()
+    n_seg, T, A = 7, 12, 4
+    N = n_seg * T
+    x, r = rnd((N,), 1), rnd((N,), 2)
+    d = (rnd((N,), 3, 0, 1) < 0.2).float()
+    d[T - 1::T] = 1
+    y = o.discount(x.to(DEV), d.to(DEV), 0.99, n_seg)
+    assert torch.equal(y.cpu(), O.discount(x, d, 0.99))
+    adv, ret = o.gae_returns(x.to(DEV), r.to(DEV), d.to(DEV), 0.9702, 0.99, n_seg)
+    assert torch.equal(adv.cpu(), O.discount(x, d, 0.9702)) and torch.equal(ret.cpu(), O.discount(r, d, 0.99))
+    logits, u = rnd((33, A), 4, -3, 3), rnd((33,), 5, 0, 0.999)
+    acts = o.softmax_sample(logits.to(DEV), u.to(DEV))
+    assert torch.equal(acts.cpu(), O.sample_action(F.softmax(logits, -1), u).long())
+    prev = rnd((3, 4, 64), 6)
+    f8 = (rnd((3, 64), 7, 0, 1) * 255).to(torch.uint8)
+    rst = torch.tensor([0., 1., 0.])
+    out = o.frame_stack_push(f8.to(DEV), rst.to(DEV), prev.to(DEV)).cpu()
+    want = torch.cat([prev[:, 1:], f8.float()[:, None]], 1)
+    want[1, :3] = 0
+    assert torch.equal(out, want)
+    assert torch.equal(o.frame_stack_push(f8.float().to(DEV), rst.to(DEV), prev.to(DEV)).cpu(), want)
+    w, b, xin = rnd((5, 16), 8), rnd((5,), 9), rnd((9, 16), 10)
+    close("linear", o.linear(xin.to(DEV), w.to(DEV), b.to(DEV), True), F.relu(F.linear(xin, w, b)), 1e-6, 1e-5)

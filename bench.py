@@ -211,9 +211,10 @@ def step_alg_flops(A):
     return 2 * 16 * 400 * 256 + 2 * 32 * 81 * 256 + 2 * (A + 1) * 2592
 
 
-def step_alg_bytes(u8_frame=False):
-    """per env-step: 3 planes of the previous state + the new frame in (fp32 or uint8), the new state out"""
-    return 3 * 84 * 84 * 4 + (84 * 84 if u8_frame else 84 * 84 * 4) + 4 * 84 * 84 * 4
+def step_alg_bytes(u8_frame=False, stash=True):
+    """per env-step: 3 planes of the previous state + the new frame in (fp32 or uint8), the new state out
+    (+ the conv1 / conv2 activations stashed for the update: 16x20x20 + 32x9x9 floats)"""
+    return 3 * 84 * 84 * 4 + (84 * 84 if u8_frame else 84 * 84 * 4) + 4 * 84 * 84 * 4 + (4 * (6400 + 2592) if stash else 0)
 
 
 def scan_roofline(device):

@@ -107,10 +107,11 @@ class ConvLayer:
         if self.need_bwd_data:
             ops.conv_prep(self.d, 1, weight, self.wb, st)
 
-    def fwd(self, in_ptr, in_bstride, bias, out, B, st, relu=True):
-        in_ptr, in_bstride = self._input(in_ptr, in_bstride, B, out.device, st)
+    def fwd(self, in_ptr, in_bstride, bias, out, B, st, relu=True, out_bstride=None):
+        """out: (B, Cout, OH, OW) tensor, or a raw device address + out_bstride (rows of a larger buffer)"""
+        in_ptr, in_bstride = self._input(in_ptr, in_bstride, B, bias.device, st)
         with ops.span(self.name + ".fwd"):
-            ops.conv_fwd(self.d, in_ptr, in_bstride, self.wf, bias, relu, out, B, st)
+            ops.conv_fwd(self.d, in_ptr, in_bstride, self.wf, bias, relu, out, B, st, out_bstride=out_bstride)
 
     def bwd_weight(self, in_ptr, in_bstride, dout, dW, db, B, ws, st):
         in_ptr, in_bstride = self._input(in_ptr, in_bstride, B, dout.device, st)

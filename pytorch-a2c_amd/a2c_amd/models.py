@@ -375,15 +375,40 @@ class _ConvStackNet(_HipNet):
         for i, l in enumerate(self._cl):
             l.prep(self.P(f"convs.{i}.0.weight"), st)
 
-    def _convs_fwd(self, x_ptr, bstride, B, ws, st):
+    def _convs_fwd(self, x_ptr, bstride, B, ws, st, stash=None):
+        """-> [(ptr, batch stride in floats)] of every layer's activation.  ``stash`` = (bufs, row0, row_stride): the
+        activations of sample b go to row row0 + b*row_stride of the update's (N, ...) buffers instead of the
+        per-tag workspace (a rollout step of all envs fills rows slot*T + t)."""
         acts = []
         ptr, bs = x_ptr, bstride
         for i, l in enumerate(self._cl):
-            a = ws.get(f"a{i}", (B,) + l.out_shape)
-            l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), a, B, st)
-            acts.append(a)
-            ptr, bs = a.data_ptr(), a[0].numel()
+            n = int(np.prod(l.out_shape))
+            if stash is None:
+                a = ws.get(f"a{i}", (B,) + l.out_shape)
+                l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), a, B, st)
+                ptr, bs = a.data_ptr(), n
+            else:
+                bufs, row0, rstride = stash
+                optr = bufs[i].data_ptr() + 4 * row0 * n
+                l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), optr, B, st, out_bstride=rstride * n)
+                ptr, bs = optr, rstride * n
+            acts.append((ptr, bs))
         return acts
+
+    def stash_rows(self, states, n_rows):
+        """per-layer (n_rows, C, H, W) activation buffers of the update's workspace: a rollout that covers all rows
+        writes each state's conv activations straight into them and update_model's forward (updater.py:80; same
+        weights, same states) skips the conv stack."""
+        if os.environ.get("A2C_NO_STASH") == "1":
+            return None
+        ws = self.ws("train")
+        return [ws.get(f"a{i}", (n_rows,) + l.out_shape) for i, l in enumerate(self._cl)]
+
+    def _convs_train(self, x_ptr, bstride, B, ws, st):
+        """conv stack of the update's forward: recomputed, or taken from the rollout's stash"""
+        if self._stash_valid(x_ptr, B):
+            return [(ws.get(f"a{i}", (B,) + l.out_shape).data_ptr(), int(np.prod(l.out_shape))) for i, l in enumerate(self._cl)]
+        return self._convs_fwd(x_ptr, bstride, B, ws, st)
 
     def _convs_bwd(self, x_ptr, bstride, B, ws, st, d_last):
         """d_last: gradient wrt the last conv's pre-activation output (ReLU mask already applied)."""
@@ -436,13 +461,13 @@ class ConvModel(_ConvStackNet):
         t = buf[o:o + rows * (cols or 1)]
         return t.view(rows, cols) if cols else t
 
-    def _fwd(self, x_ptr, bstride, B, tag, st, save):
+    def _fwd(self, x_ptr, bstride, B, tag, st, save, stash=None):
         ws, P = self.ws(tag), self.P
         A, h, ch = self.output_space, self.h_size, self.CONV_H
-        acts = self._convs_fwd(x_ptr, bstride, B, ws, st)
+        acts = self._convs_train(x_ptr, bstride, B, ws, st) if (save and tag == "train") else \
+            self._convs_fwd(x_ptr, bstride, B, ws, st, stash=stash)
         e = ws.get("e", (B, ch))
-        linear_fwd(ws, acts[-1].data_ptr(), self.flat_size, P("resize_emb.0.weight"), P("resize_emb.0.bias"), e, B, st,
-                   relu=True)
+        linear_fwd(ws, acts[-1][0], acts[-1][1], P("resize_emb.0.weight"), P("resize_emb.0.bias"), e, B, st, relu=True)
         hid = ws.get("hid", (B, 2 * h))
         linear_fwd(ws, e.data_ptr(), ch, self._cat(self._arena.params, "pi.0.weight", 2 * h, ch),
                    self._cat(self._arena.params, "pi.0.bias", 2 * h), hid, B, st, relu=True)
@@ -680,11 +705,11 @@ class GRUModel(_ConvStackNet, _GruMixin):
         ar = self._arena
         return (buf[ar.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h), buf[ar.offsets["pi.bias"][0]:][:A + 1])
 
-    def _embed_fwd(self, x_ptr, bstride, B, ws, st):
-        acts = self._convs_fwd(x_ptr, bstride, B, ws, st)
+    def _embed_fwd(self, x_ptr, bstride, B, ws, st, train=False, stash=None):
+        acts = self._convs_train(x_ptr, bstride, B, ws, st) if train else self._convs_fwd(x_ptr, bstride, B, ws, st, stash=stash)
         e = ws.get("e", (B, self.h_size))
-        linear_fwd(ws, acts[-1].data_ptr(), self.flat_size, self.P("resize_emb.0.weight"),
-                   self.P("resize_emb.0.bias"), e, B, st, relu=True)
+        linear_fwd(ws, acts[-1][0], acts[-1][1], self.P("resize_emb.0.weight"), self.P("resize_emb.0.bias"), e, B, st,
+                   relu=True)
         return e
 
     def _embed_bwd(self, x_ptr, bstride, B, ws, st, de):
@@ -697,9 +722,9 @@ class GRUModel(_ConvStackNet, _GruMixin):
         linear_bwd_data(ws, de, self.P("resize_emb.0.weight"), dlast.view(B, -1), B, st, mask=a_last)
         self._convs_bwd(x_ptr, bstride, B, ws, st, dlast)
 
-    def _fwd(self, x_ptr, bstride, B, tag, st, save, h_in):
+    def _fwd(self, x_ptr, bstride, B, tag, st, save, h_in, stash=None):
         ws = self.ws(tag)
-        e = self._embed_fwd(x_ptr, bstride, B, ws, st)
+        e = self._embed_fwd(x_ptr, bstride, B, ws, st, train=(save and tag == "train"), stash=stash)
         bufs = self._cell_bufs(ws, B)
         hin = ws.get("h_in", (B, self.h_size))
         hin.copy_(h_in)
@@ -734,7 +759,7 @@ class GRUModel(_ConvStackNet, _GruMixin):
         ws, h, A = self.ws(tag), self.h_size, self.output_space
         N = R * T
         self._refresh(st)
-        e = self._embed_fwd(states.data_ptr(), states[0].numel(), N, ws, st)          # rollout-major (N,h)
+        e = self._embed_fwd(states.data_ptr(), states[0].numel(), N, ws, st, train=True)          # rollout-major (N,h)
         e_tm = ws.get("e_tm", (T, R, h))
         ops.permute_rows(e, e_tm, R, T, h, st)
         tm = self._bptt_cells_fwd(ws, e_tm, h_states, dones, R, T, st)

@@ -361,9 +361,12 @@ def conv_prep(d, kind, weight, wprep, st=None):
                                         st if st is not None else stream()), "a2c_conv2d_prep_weights")
 
 
-def conv_fwd(d, in_ptr, in_bstride, wprep, bias, relu, out, B, st=None):
-    check(lib().a2c_conv2d_fwd(ctypes.byref(d), in_ptr, in_bstride, _p(wprep), _p(bias), int(bool(relu)), _p(out),
-                               d.Cout * d.OH * d.OW, B, st if st is not None else stream()), "a2c_conv2d_fwd")
+def conv_fwd(d, in_ptr, in_bstride, wprep, bias, relu, out, B, st=None, out_bstride=None):
+    """out: tensor, or a raw device address together with out_bstride (rows of a larger buffer)"""
+    out_ptr = out if isinstance(out, int) else _p(out)
+    check(lib().a2c_conv2d_fwd(ctypes.byref(d), in_ptr, in_bstride, _p(wprep), _p(bias), int(bool(relu)), out_ptr,
+                               d.Cout * d.OH * d.OW if out_bstride is None else out_bstride, B,
+                               st if st is not None else stream()), "a2c_conv2d_fwd")
 
 
 def conv_bwd_data(d, dout, wprep_bwd, mask, din, B, st=None):

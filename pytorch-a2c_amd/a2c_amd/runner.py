@@ -274,7 +274,7 @@ class Runner:
         N = self.datas["states"].shape[0]
         T_ = int(hyps["n_tsteps"])
         self._stash_bufs = None
-        if idxs == list(range(N // T_)) and N % T_ == 0 and self.h is None:
+        if idxs == list(range(N // T_)) and N % T_ == 0:
             self._stash_bufs = net.stash_rows(self.datas["states"], N)
         j = 0
         while j < len(idxs):
@@ -293,12 +293,14 @@ class Runner:
             return self.uniform_fn(t, B, env0)
         return torch.rand(B, device=self.net._dev, dtype=torch.float32)
 
-    def _forward(self, net, x_ptr, bstride, B, env0, st, sampler=None):
+    def _forward(self, net, x_ptr, bstride, B, env0, st, sampler=None, stash=None):
+        """stash = (bufs, row0, row_stride): conv-stack nets write this step's activations into the update's buffers"""
+        kw = dict(stash=stash) if (stash is not None and isinstance(stash[0], list)) else {}
         if net.is_recurrent:
-            return net._fwd(x_ptr, bstride, B, "roll", st, False, h_in=self.h[env0:env0 + B])
+            return net._fwd(x_ptr, bstride, B, "roll", st, False, h_in=self.h[env0:env0 + B], **kw)
         if sampler is not None and getattr(net, "_fused_sampling", False):
             return net._fwd(x_ptr, bstride, B, "roll", st, False, sampler=sampler)
-        return net._fwd(x_ptr, bstride, B, "roll", st, False)
+        return net._fwd(x_ptr, bstride, B, "roll", st, False, **kw)
 
     def _zero_copy_ok(self, net):
         """the persistent one-launch rollout applies: A3CModel-shaped net, process pool with uint8 frames"""
@@ -334,6 +336,8 @@ class Runner:
         # next to the frame-stack kernel (two branches in the hipGraph).  Measured on MI355X the
         # fork/join costs more than the 4.8 us it hides (16.0 -> 17.8 ms per 256x128 epoch), so it is
         # opt-in (A2C_SIDE_STREAM=1).
+        if not self.device_pool and os.environ.get("A2C_NO_STEP_GRAPHS") != "1":
+            return self._rollout_block_segmented(net, slot0, env0, B, hyps, sp, bm, val_prev, done_eff, h, acts_host_out)
         main = torch.cuda.current_stream()
         side = None
         if h is None and os.environ.get("A2C_SIDE_STREAM") == "1":
@@ -435,6 +439,180 @@ class Runner:
             fr, rew, done, reset = self._env_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong)
             for name, x in (("rew", rew), ("done", done), ("reset", reset)):
                 ops._chk(x, name)
+
+    # ------------------------------------------------------------------ host pools: one hipGraph per time step
+    def _rollout_block_segmented(self, net, slot0, env0, B, hyps, sp, bm, val_prev, done_eff, h, acts_host_out):
+        """Host env pools (memcpy ingest): the slot is T+1 device SEGMENTS separated by the one host hand-off of
+        each env step.  Segment k = [H2D of what env step k-1 returned + its bookkeeping + frame stack] followed by
+        [forward + sampling of state k + D2H of the actions] (k < T) or by the bootstrap (k == T).  A segment has
+        no host dependency inside, so each one is captured into a hipGraph the first time it runs (all pointers --
+        rollout buffer rows, workspaces, the pinned pool region, the slot's uniforms buffer -- are stable across
+        epochs) and replayed afterwards: ONE launch per env step instead of 5-30 (runner.py:198-232 per step)."""
+        D, pool = self.datas, self.env_pool
+        T, S = int(hyps["n_tsteps"]), self.S
+        shift, pong = hyps["action_shift"], "Pong" in hyps["env_type"]
+        dev = net._dev
+        # the slot's uniforms in ONE persistent buffer (rows are what the graph nodes read)
+        if getattr(self, "_u_buf", None) is None or self._u_buf.shape != (T, self.B):
+            self._u_buf = torch.zeros((T, self.B), dtype=torch.float32, device=dev)
+        ub = self._u_buf
+        if self.uniform_fn is not None:
+            for t in range(T):
+                ub[t, env0:env0 + B].copy_(self.uniform_fn(t, B, env0).reshape(B))
+        else:
+            ub[:, env0:env0 + B] = torch.rand((T, B), device=dev, dtype=torch.float32)
+        stash = self._stash_bufs
+        fused = h is None and getattr(net, "_step_supported", lambda: False)()
+        if stash is not None and isinstance(stash, list) == fused:      # tuple (a1, a2): step kernel; list: conv-stack nets
+            stash = None
+        self._stash_used = stash is not None
+        ctx = dict(net=net, slot0=slot0, env0=env0, B=B, T=T, hyps=hyps, sp=sp, bm=bm, val_prev=val_prev, done_eff=done_eff,
+                   h=h, acts_host_out=acts_host_out, fused=fused, stash=stash, ub=ub)
+        graphs = None
+        if try_key(hyps, "rollout_graphs", True) and torch.cuda.is_available():
+            key = (id(net), slot0, env0, B, T, fused, stash is not None, acts_host_out is None, pong, float(hyps["gamma"]),
+                   tuple(D[k].data_ptr() for k in sorted(D) if D[k].is_cuda))
+            cache = self.__dict__.setdefault("_seg_graphs", {})
+            graphs = cache.setdefault(key, [None] * (T + 1))
+        for k in range(T + 1):
+            if graphs is None:
+                self._segment(k, ctx)
+            else:
+                if graphs[k] is None:
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            self._segment(k, ctx)
+                        graphs[k] = g
+                    except Exception:      # noqa: BLE001 -- capture not possible here: run this slot eagerly
+                        torch.cuda.synchronize()
+                        graphs[k] = False
+                if graphs[k]:
+                    graphs[k].replay()
+                else:
+                    self._segment(k, ctx)
+            if k < T:
+                torch.cuda.current_stream().synchronize()
+                self._host_env_step(pool, env0, B, k, slot0, T, shift, acts_host_out, pong)
+
+    def _segment(self, k, c):
+        """device work of segment k (see _rollout_block_segmented); only enqueues, never waits on the host"""
+        net, slot0, env0, B, T, hyps = c["net"], c["slot0"], c["env0"], c["B"], c["T"], c["hyps"]
+        D, pool, S, C, HW = self.datas, self.env_pool, self.S, self.C, self.HW
+        sp, bm, val_prev, done_eff, h = c["sp"], c["bm"], c["val_prev"], c["done_eff"], c["h"]
+        gamma, pong = hyps["gamma"], "Pong" in hyps["env_type"]
+        rewards, dones, deltas = D["rewards"], D["dones"], D["deltas"]
+        st = ops.stream()
+        fr = rew = done = None
+        if k > 0:       # what env step k-1 returned: pinned staging -> HBM
+            rew, done = self.d_rew[env0:env0 + B], self.d_done[env0:env0 + B]
+            rew.copy_(self.h_rew[env0:env0 + B], non_blocking=True)
+            done.copy_(self.h_done[env0:env0 + B], non_blocking=True)
+            if self.proc_pool:
+                fr = self._pool_frames_h2d(pool, env0, B, st)
+            else:
+                df = self.d_frames[env0:env0 + B]
+                df.copy_(self.h_frames[env0:env0 + B], non_blocking=True)
+                fr = _Frames(ptr32=df.data_ptr())
+        act = self.act_dev[env0:env0 + B]
+        if c["acts_host_out"] is None:
+            a_ptr, a_stride = D["actions"].data_ptr() + 8 * (slot0 * T + min(k, T - 1)), T
+        else:
+            a_ptr, a_stride = act.data_ptr(), 1
+        if c["fused"]:      # a2c_a3c_step: record(k-1) + frame stack + forward + sample (+ bootstrap) in ONE launch
+            kw = dict(val_prev=val_prev.data_ptr(), rewards=rewards.data_ptr(), dones=dones.data_ptr(), deltas=deltas.data_ptr(),
+                      T=T, slot0=slot0, gamma=float(gamma), pong=int(pong))
+            if k == 0:
+                kw.update(prev=bm.data_ptr(), prev_stride=S, out=sp(0), out_stride=T * S)
+            else:
+                out_ptr, out_stride = (sp(k), T * S) if k < T else (bm.data_ptr(), S)
+                kw.update(prev=sp(k - 1), prev_stride=T * S, reset_mask=done.data_ptr(), out=out_ptr, out_stride=out_stride,
+                          rew=rew.data_ptr(), done=done.data_ptr(), t_rec=k - 1)
+                kw.update(dict(frame_u8=fr.ptr8, frame_stride=fr.stride) if fr.ptr8 else dict(frame_new=fr.ptr32))
+            if c["stash"] is not None and k < T:
+                n1, n2 = c["stash"][0][0].numel(), c["stash"][1][0].numel()
+                kw.update(a1_out=c["stash"][0].data_ptr() + 4 * (slot0 * T + k) * n1, a1_stride=T * n1,
+                          a2_out=c["stash"][1].data_ptr() + 4 * (slot0 * T + k) * n2, a2_stride=T * n2)
+            if k == T:
+                net._step(B, st, bootstrap=1, **kw)
+                return
+            net._step(B, st, u=c["ub"][k, env0:env0 + B].data_ptr(), actions=a_ptr, act_stride=a_stride, **kw)
+        else:
+            hb, logits, vals = net._heads("roll", B)
+            if k == 0:      # state of step 0 = the bookmark left by the previous slot (runner.py:190)
+                ops.copy_rows(bm.data_ptr(), S, sp(0), T * S, B, S, st)
+            else:           # bookkeeping of env step k-1 + the next state (utils.next_state)
+                t = k - 1
+                nxt_ptr, nxt_stride = (sp(k), T * S) if k < T else (bm.data_ptr(), S)
+                if h is None and HW % 4 == 0 and S % 4 == 0:
+                    if fr.ptr8:
+                        ops.rollout_post_u8(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t,
+                                            slot0, gamma, pong, fr.ptr8, fr.stride, done, sp(t), T * S, nxt_ptr, nxt_stride, B,
+                                            C, HW, st)
+                    else:
+                        ops.rollout_post(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t,
+                                         slot0, gamma, pong, _Ptr(fr.ptr32), done, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
+                else:
+                    ops.rollout_record(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, done_eff,
+                                       h, B, T, t, slot0, gamma, pong, st)
+                    if fr.ptr8:
+                        ops.frame_stack_push_u8(fr.ptr8, fr.stride, done, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
+                    else:
+                        ops.frame_stack_push(_Ptr(fr.ptr32), done, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
+            if k == T:      # bootstrap (runner.py:236-245): value of the state after the last step
+                out = self._forward(net, bm.data_ptr(), S, B, env0, st)
+                ops.rollout_bootstrap(out["vals"].data_ptr(), out["vals"].stride(0), val_prev, rewards, dones, deltas, B, T,
+                                      slot0, gamma, st)
+                return
+            if h is not None:                                              # h_states[e] = h (runner.py:201)
+                hs = D["h_states"]
+                ops.copy_rows(h.data_ptr(), h.shape[1], hs.data_ptr() + 4 * (slot0 * T + k) * h.shape[1], T * h.shape[1], B,
+                              h.shape[1], st)
+            u = c["ub"][k, env0:env0 + B]
+            out = self._forward(net, sp(k), T * S, B, env0, st, sampler=(u, a_ptr, a_stride),
+                                stash=None if c["stash"] is None else (c["stash"], slot0 * T + k, T))
+            if not out.get("sampled", False):
+                ops.softmax_sample(out["logits"], u, a_ptr, a_stride, B, net.output_space, st=st)
+            if h is not None:
+                ops.copy_rows(out["h"].data_ptr(), h.shape[1], h.data_ptr(), h.shape[1], B, h.shape[1], st)
+        # the sampled actions go to the host (pinned staging) at the tail of the segment
+        ha = self.h_act[env0:env0 + B]
+        if a_stride == 1:
+            ha.copy_(act, non_blocking=True)
+        else:
+            if getattr(self, "_act_gather", None) is None:
+                self._act_gather = torch.zeros(self.B, dtype=torch.int64, device=net._dev)
+            ag = self._act_gather[env0:env0 + B]
+            ag.copy_(D["actions"][slot0 * T + k::T][:B])
+            ha.copy_(ag, non_blocking=True)
+
+    def _host_env_step(self, pool, env0, B, t, slot0, T, shift, acts_host_out, pong):
+        """host half of env step t (the segment's D2H of the actions has completed): hand the actions to the envs,
+        wait for them, leave rewards / dones (/ frames) in the pinned staging the next segment copies up"""
+        na = self.np_act[env0:env0 + B]
+        if acts_host_out is not None:
+            acts_host_out[slot0 * T + t:(slot0 + B) * T:T] = self.h_act[env0:env0 + B]
+        if self.proc_pool:
+            k = pool.seq + t
+            pool.post_actions(na, env0=env0, seq=k)
+            pool.wait_frames(k + 1, env0=env0, n=B, timeout=float(try_key(self.hyps, "env_timeout_s", 20.0)))
+            pool.unpack(self.np_rew[env0:env0 + B], self.np_done[env0:env0 + B], env0=env0)
+            return
+        nf, nr, nd = (x[env0:env0 + B] for x in (self.np_frames, self.np_rew, self.np_done))
+        for j in range(B):
+            obs, rew, done = pool.step(env0 + j, int(na[j]) + shift)
+            self.ep_rew[env0 + j] += rew
+            reset = done
+            if pong and rew != 0:
+                done = True
+            if done and self.rew_q is not None:                            # runner.py:216-217
+                self.rew_q.put(.99 * self.rew_q.get() + .01 * self.ep_rew[env0 + j])
+            if done:
+                self.ep_rew[env0 + j] = 0
+            if reset:
+                obs = pool.reset(env0 + j)
+            nf[j] = np.asarray(obs, dtype=np.float32).reshape(-1)
+            nr[j], nd[j] = rew, float(reset)
 
     def _rollout_block_persistent(self, net, slot0, env0, B, hyps, bm, val_prev, acts_host_out, st):
         """The whole slot as ONE persistent launch (a2c_a3c_rollout): the workgroups and the env worker

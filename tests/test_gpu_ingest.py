@@ -298,8 +298,9 @@ def test_full_size_headline_rollout_properties_and_action_flip_census():
         r.close()
 
 
-@pytest.mark.parametrize("ingest", ["zero-copy", "memcpy"])
-def test_update_from_stashed_rollout_activations_equals_recomputed(ingest, monkeypatch):
+@pytest.mark.parametrize("kind,ingest", [("A3CModel", "zero-copy"), ("A3CModel", "memcpy"), ("GRUModel", "memcpy"),
+                                         ("ConvModel", "memcpy")])
+def test_update_from_stashed_rollout_activations_equals_recomputed(kind, ingest, monkeypatch):
     """The one-launch rollout step stashes conv1/conv2 activations of every state; update_model reads them instead
     of re-running the two conv forwards (same weights, same states: training.py:150-165).  Same update as the
     recomputed one to fp32 rounding (the step kernel's K-split conv2 re-associates the sums)."""
@@ -307,13 +308,14 @@ def test_update_from_stashed_rollout_activations_equals_recomputed(ingest, monke
     from a2c_amd.updater import Updater
     B, T, A, ss = 6, 5, 3, (4, 84, 84)
     ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
-    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3)
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3,
+                     use_bptt=(kind == "GRUModel"))
     res = {}
     for stash in (True, False):
         if not stash:
             monkeypatch.setenv("A2C_NO_STASH", "1")
-        net = make_net("A3CModel", ss, A, 256)
-        D = _datas(B * T, ss, False, actions_on_host=False)
+        net = make_net(kind, ss, A, 256)
+        D = _datas(B * T, ss, net.is_recurrent, actions_on_host=False)
         pool = _pool(U8FakeEnv, ekws, 2, pong=True)
         r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest)
         torch.manual_seed(5)          # same sampling uniforms in both runs

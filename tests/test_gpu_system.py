@@ -282,3 +282,25 @@ def test_train_driver_two_epochs(tmp_path):
         a, b = net(x), onet(x)
     close("val", a[0], b[0], 1e-5, 1e-5)
     close("pi", a[1], b[1], 1e-5, 1e-5)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver calls it (no launcher): the parent spawns torch.distributed.run
+    before touching the GPU and relays rank 0's JSON line.  The two ranks share cuda:0 here (gloo), each with
+    its own pinned pool region and env threads."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, A2C_BENCH_ONE_DEVICE="1", A2C_DIST_BACKEND="gloo")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--n-envs", "16", "--n-workers", "1", "--sustain-steps", "0", "--no-cpu-baseline", "--no-configs",
+                          "--no-secondary"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["dist_backend"] == "gloo" and d["allreduce_bytes"] > 0 and d["allreduce_ms_per_update"] > 0
+    assert "host-pinned uint8" in d["config"]["ingest"]

@@ -215,6 +215,9 @@ int a2c_rollout_buffer_destroy(const char *shm_name, void *host, size_t bytes);
 /* pin + map an existing host range (page aligned) / undo it                                  */
 int a2c_pinned_register(void *host, size_t bytes, void **dev_out);
 int a2c_pinned_unregister(void *host);
+/* PCI bus id ("0000:c1:00.0") of the current HIP device: the host side places the pinned region and the env
+ * workers on the NUMA node the GPU hangs off (/sys/bus/pci/devices/<id>/numa_node)                */
+int a2c_device_pci_bus_id(char *out, int len);
 /* hipMemcpyAsync on `stream`: kind 1 = host->device, 2 = device->host, 3 = device->device      */
 int a2c_memcpy_async(void *dst, const void *src, size_t bytes, int kind, a2c_stream_t stream);
 /* dst[b*dst_stride + j] = src[b*src_stride + j], j < n  (h_states[e] = h, runner.py:201;

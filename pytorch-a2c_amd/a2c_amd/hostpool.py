@@ -180,11 +180,27 @@ class _PinnedPool:
     def __len__(self):
         return self.n_envs
 
+    def _pin_to_gpu_node(self):
+        """Place this thread -- and with it the first touch of the pinned region and every worker thread / process
+        it starts (they inherit the mask) -- on the NUMA node the GPU hangs off.  On the 2-socket MI355X box the
+        zero-copy rollout runs at 41.8 GB/s of frame bytes from the GPU's node, 37.8 from the other one, and
+        27-36 GB/s with multi-ms outliers when the scheduler is free to migrate the workers."""
+        if not self.register or os.environ.get("A2C_NO_NUMA_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+            return
+        from . import ops
+        cpus = ops.device_numa_cpus()
+        if cpus:
+            allowed = set(cpus) & set(os.sched_getaffinity(0))
+            if allowed:
+                os.sched_setaffinity(0, allowed)
+
     def _create_region(self):
         lib = pool_lib()
+        self._pin_to_gpu_node()
         nbytes = lib.a2c_pool_bytes(self.n_envs, self.frame_bytes)
         self.name = f"a2c_pool_{os.getpid()}_{id(self) & 0xffffff:x}_{int(time.time() * 1e3) & 0xffffff:x}"
         reg = self.region = Region(self.name, create_bytes=nbytes)
+        ctypes.memset(reg.base, 0, nbytes)          # first touch of every page from the (NUMA-placed) creating thread
         dt = FRAME_U8 if self.frame_dtype == np.uint8 else FRAME_F32
         if lib.a2c_pool_init(reg.base, nbytes, self.n_envs, self.frame_bytes, dt, self.n_workers, self.rew_ema0):
             raise RuntimeError("a2c_pool_init failed")

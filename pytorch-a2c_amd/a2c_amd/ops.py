@@ -255,6 +255,25 @@ def pinned_unregister(host_addr):
     check(lib().a2c_pinned_unregister(host_addr), "a2c_pinned_unregister")
 
 
+def device_numa_cpus():
+    """CPUs of the NUMA node the current HIP device hangs off, or None when that cannot be read"""
+    buf = ctypes.create_string_buffer(64)
+    if lib().a2c_device_pci_bus_id(buf, 64) != 0:
+        return None
+    bdf = buf.value.decode().lower()
+    try:
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        return cpus or None
+    except (OSError, ValueError):
+        return None
+
+
 H2D, D2H, D2D = 1, 2, 3
 
 

@@ -67,6 +67,16 @@ int a2c_rollout_buffer_destroy(const char* shm_name, void* host, size_t bytes) {
   return rc;
 }
 
+int a2c_device_pci_bus_id(char* out, int len) {
+  if (!out || len < 16) return A2C_ERR_ARG;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(out, len, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return A2C_ERR_LAUNCH;
+  }
+  return A2C_OK;
+}
+
 int a2c_memcpy_async(void* dst, const void* src, size_t bytes, int kind, a2c_stream_t stream) {
   if (!bytes) return A2C_OK;
   if (!dst || !src || kind < 1 || kind > 3) return A2C_ERR_ARG;

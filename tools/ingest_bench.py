@@ -27,8 +27,13 @@ net = a2c_amd.models.A3CModel(list(ss), A, h_size=256)
 N = B * T
 D = dict(states=torch.zeros(N, *ss, device=dev), deltas=torch.zeros(N, device=dev), rewards=torch.zeros(N, device=dev),
          dones=torch.zeros(N, device=dev), actions=torch.zeros(N, dtype=torch.int64, device=dev))
+from a2c_amd.hostpool import ThreadEnvPool
+native = os.environ.get("NATIVE", "1") == "1"
 for W in workers:
-    pool = ProcessEnvPool(TapeEnv, B, env_kwargs=[dict(env_id=j, length=T + 1) for j in range(B)], n_workers=W, pong=True)
+    if native:
+        pool = ThreadEnvPool.from_tape_envs([TapeEnv(env_id=j, length=33) for j in range(B)], n_threads=W, pong=True)
+    else:
+        pool = ProcessEnvPool(TapeEnv, B, env_kwargs=[dict(env_id=j, length=T + 1) for j in range(B)], n_workers=W, pong=True)
     r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest)
     try:
         t0 = time.perf_counter()

@@ -162,6 +162,7 @@ typedef struct {
    * forward (updater.py:80) would recompute exactly these tensors: it reads the stash instead.           */
   float *a1_out; int64_t a1_stride;
   float *a2_out; int64_t a2_stride;
+  float *heads_out; int64_t heads_out_stride;   /* optional second copy of [logits | value] (same stash) */
 } a2c_a3c_step_args;
 int a2c_a3c_step_supported(int C, int H, int W, int n_actions);
 int a2c_a3c_step(const a2c_a3c_step_args *args, a2c_stream_t stream);
@@ -201,6 +202,7 @@ typedef struct {
   int *err;                        /* device int                                              */
   int64_t timeout_ticks;
   float *a1_rows, *a2_rows;        /* optional activation stash, row e = (slot0+b)*T + t (see a2c_a3c_step_args) */
+  float *heads_rows; int64_t heads_rows_ld;   /* optional [logits | value] of state e, row stride heads_rows_ld */
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
 

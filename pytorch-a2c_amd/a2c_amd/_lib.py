@@ -32,7 +32,8 @@ class A3CStepArgs(Structure):
                 ("rew", P), ("done", P), ("val_prev", P), ("rewards", P), ("dones", P), ("deltas", P),
                 ("T", c_int64), ("t_rec", c_int64), ("slot0", c_int64), ("gamma", c_float),
                 ("pong", c_int), ("bootstrap", c_int), ("frame_u8", P), ("frame_stride", c_int64),
-                ("a1_out", P), ("a1_stride", c_int64), ("a2_out", P), ("a2_stride", c_int64)]
+                ("a1_out", P), ("a1_stride", c_int64), ("a2_out", P), ("a2_stride", c_int64),
+                ("heads_out", P), ("heads_out_stride", c_int64)]
 
 
 class A3CRolloutArgs(Structure):
@@ -44,7 +45,7 @@ class A3CRolloutArgs(Structure):
                 ("val_prev", P), ("rewards", P), ("dones", P), ("deltas", P),
                 ("T", c_int64), ("slot0", c_int64), ("gamma", c_float), ("pong", c_int),
                 ("cmd", P), ("rec", P), ("frames", P), ("frame_stride", c_int64),
-                ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64), ("a1_rows", P), ("a2_rows", P)]
+                ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64), ("a1_rows", P), ("a2_rows", P), ("heads_rows", P), ("heads_rows_ld", c_int64)]
 
 
 PS = POINTER(A3CStepArgs)

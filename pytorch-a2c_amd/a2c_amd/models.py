@@ -270,7 +270,10 @@ class A3CModel(_HipNet):
         if os.environ.get("A2C_NO_STASH") == "1" or not self._step_supported():
             return None
         ws = self.ws("train")
-        return (ws.get("a1", (n_rows,) + self._c1.out_shape), ws.get("a2", (n_rows,) + self._c2.out_shape))
+        # + the heads [logits | value] of every state: the rollout computed them through the composed matrix
+        # Wc = [pi;value].proj_matrx, so the update needs neither the 2592 -> 256 forward GEMM nor the embedding
+        return (ws.get("a1", (n_rows,) + self._c1.out_shape), ws.get("a2", (n_rows,) + self._c2.out_shape),
+                self._heads("train", n_rows)[0])
 
     def _fwd(self, x_ptr, bstride, B, tag, st, save, sampler=None):
         ws, P = self.ws(tag), self.P
@@ -278,10 +281,17 @@ class A3CModel(_HipNet):
         a1 = ws.get("a1", (B,) + self._c1.out_shape)
         a2 = ws.get("a2", (B,) + self._c2.out_shape)
         emb = ws.get("emb", (B, h))
-        if not (save and tag == "train" and self._stash_valid(x_ptr, B)):
+        stashed = save and tag == "train" and self._stash_valid(x_ptr, B)
+        hb, logits, vals = self._heads(tag, B)
+        self._emb_free = False
+        if stashed and os.environ.get("A2C_NO_HEADS_STASH") != "1":
+            # a1, a2 AND [logits | value] of every row were left here by the rollout: no forward work at all; the
+            # backward pass gets dWh = db^T emb without the embedding (see _bwd)
+            self._emb_free = True
+            return dict(logits=logits, vals=vals, sampled=False)
+        if not stashed:
             self._c1.fwd(x_ptr, bstride, P("convs.0.0.bias"), a1, B, st)
             self._c2.fwd(a1.data_ptr(), a1[0].numel(), P("convs.1.0.bias"), a2, B, st)
-        hb, logits, vals = self._heads(tag, B)
         # [pi.weight; value.weight] and [pi.bias | value.bias] are adjacent in the arena: one (A+1)-wide head
         Wh = self._arena.params[self._arena.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
         bh = self._arena.params[self._arena.offsets["pi.bias"][0]:][:A + 1]
@@ -343,7 +353,23 @@ class A3CModel(_HipNet):
         ar = self._arena
         dWh = ar.grads[ar.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
         dbh = ar.grads[ar.offsets["pi.bias"][0]:][:A + 1]
-        linear_bwd_weight(ws, db, emb.data_ptr(), h, dWh, dbh, B, st)
+        if getattr(self, "_emb_free", False):
+            # dWh = db^T emb with emb = a2 Wp^T + 1 bp^T never materialised (models.py:73: no activation behind
+            # proj_matrx):  dWh = (db^T a2) Wp^T + colsum(db) bp^T -- a skinny (A+1) x F product over the batch,
+            # then two tiny GEMMs, instead of the (N x 2592 x 256) forward GEMM
+            F = self.flat_size
+            nch = next(n for n in range(max(1, -(-F // 1024)), F + 1) if F % n == 0 and (F // n) % 4 == 0)
+            Kc = F // nch                    # column chunks the skinny weight-gradient kernel takes (<= 1024 wide)
+            t1 = ws.get("dWh_t1", (nch, A + 1, Kc))
+            Wp = P("proj_matrx.weight")
+            for c in range(nch):
+                linear_bwd_weight(ws, db, a2.data_ptr() + 4 * c * Kc, F, t1[c], dbh if c == 0 else None, B, st)
+                ops.gemm(0, 1, A + 1, h, Kc, t1[c].data_ptr(), Kc, Wp.data_ptr() + 4 * c * Kc, F, dWh.data_ptr(), h,
+                         accumulate=(c > 0), st=st)
+            ops.gemm(0, 0, A + 1, h, 1, dbh.data_ptr(), 1, P("proj_matrx.bias").data_ptr(), h, dWh.data_ptr(), h,
+                     accumulate=True, st=st)
+        else:
+            linear_bwd_weight(ws, db, emb.data_ptr(), h, dWh, dbh, B, st)
         demb = ws.get("demb", (B, h))
         linear_bwd_data(ws, db, P("pi.weight"), demb, B, st, n_cols=A)        # value head is detached
         linear_bwd_weight(ws, demb, a2.data_ptr(), self.flat_size, G("proj_matrx.weight"), G("proj_matrx.bias"), B, st)

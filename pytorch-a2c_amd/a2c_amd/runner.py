@@ -415,7 +415,9 @@ class Runner:
             if stash is not None and t < T:      # conv activations of state (slot, t) -> row slot*T + t of the update's buffers
                 n1, n2 = stash[0][0].numel(), stash[1][0].numel()
                 kw.update(a1_out=stash[0].data_ptr() + 4 * (slot0 * T + t) * n1, a1_stride=T * n1,
-                          a2_out=stash[1].data_ptr() + 4 * (slot0 * T + t) * n2, a2_stride=T * n2)
+                          a2_out=stash[1].data_ptr() + 4 * (slot0 * T + t) * n2, a2_stride=T * n2,
+                          heads_out=stash[2].data_ptr() + 4 * (slot0 * T + t) * stash[2].stride(0),
+                          heads_out_stride=T * stash[2].stride(0))
             if t == 0:        # state of step 0 = the bookmark left by the previous slot (runner.py:190)
                 kw.update(prev=bm.data_ptr(), prev_stride=S, out=sp(0), out_stride=T * S)
             else:
@@ -533,6 +535,8 @@ class Runner:
                 n1, n2 = c["stash"][0][0].numel(), c["stash"][1][0].numel()
                 kw.update(a1_out=c["stash"][0].data_ptr() + 4 * (slot0 * T + k) * n1, a1_stride=T * n1,
                           a2_out=c["stash"][1].data_ptr() + 4 * (slot0 * T + k) * n2, a2_stride=T * n2)
+                hs = c["stash"][2]
+                kw.update(heads_out=hs.data_ptr() + 4 * (slot0 * T + k) * hs.stride(0), heads_out_stride=T * hs.stride(0))
             if k == T:
                 net._step(B, st, bootstrap=1, **kw)
                 return
@@ -648,7 +652,9 @@ class Runner:
                         frames=pool.dev_frames, frame_stride=self.fstride, seq0=pool.seq, env0=env0,
                         err=self.rollout_err.data_ptr(), timeout_ticks=int(timeout_s * 1e8),
                         a1_rows=0 if self._stash_bufs is None else self._stash_bufs[0].data_ptr(),
-                        a2_rows=0 if self._stash_bufs is None else self._stash_bufs[1].data_ptr())
+                        a2_rows=0 if self._stash_bufs is None else self._stash_bufs[1].data_ptr(),
+                        heads_rows=0 if self._stash_bufs is None else self._stash_bufs[2].data_ptr(),
+                        heads_rows_ld=0 if self._stash_bufs is None else self._stash_bufs[2].stride(0))
         self._stash_used = self._stash_bufs is not None
         if acts_host_out is not None:
             acts_host_out[slot0 * T:(slot0 + B) * T].copy_(acts[slot0 * T:(slot0 + B) * T])

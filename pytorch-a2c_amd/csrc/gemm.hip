@@ -343,8 +343,24 @@ __global__ __launch_bounds__(256) void small_n_bwd_weight_kernel(const float* __
   float4 acc[SN_MAX];
 #pragma unroll
   for (int n = 0; n < SN_MAX; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live)
-    for (long m = r0 + rp; m < r1; m += nrp) {
+  if (live) {
+    long m = r0 + rp;
+    // four rows in flight per thread (the loop is latency-bound on its 16-B loads otherwise); rows are still
+    // accumulated in increasing m, so the sums are bit-identical to the one-row-at-a-time loop
+    for (; m + 3L * nrp < r1; m += 4L * nrp) {
+      float4 xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const float4*>(x + (m + (long)u * nrp) * ldx + k);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int n = 0; n < SN_MAX; ++n)
+          if (n < N) {
+            const float g = dy[(m + (long)u * nrp) * ldy + n];
+            acc[n].x += g * xv[u].x; acc[n].y += g * xv[u].y; acc[n].z += g * xv[u].z; acc[n].w += g * xv[u].w;
+          }
+    }
+    for (; m < r1; m += nrp) {
       const float4 xv = *reinterpret_cast<const float4*>(x + m * ldx + k);
 #pragma unroll
       for (int n = 0; n < SN_MAX; ++n)
@@ -353,6 +369,7 @@ __global__ __launch_bounds__(256) void small_n_bwd_weight_kernel(const float* __
           acc[n].x += g * xv.x; acc[n].y += g * xv.y; acc[n].z += g * xv.z; acc[n].w += g * xv.w;
         }
     }
+  }
   // fixed-order sum of the row sub-bands through LDS, one head at a time
 #pragma unroll
   for (int n = 0; n < SN_MAX; ++n) {

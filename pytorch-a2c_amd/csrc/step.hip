@@ -56,6 +56,7 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   long timeout_ticks;
   float* a1_rows;
   float* a2_rows;
+  float* heads_rows; long heads_rows_ld;
 };
 
 struct StepP {
@@ -74,6 +75,7 @@ struct It {
   float* out;                  // row that receives the state (nullptr: none)
   float* a1o;                  // stash rows for the conv activations of this state (nullptr: none)
   float* a2o;
+  float* ho;                   // stash row for [logits | value]
 };
 
 // plane c of state_t comes from: the new frame (c == 3) / plane c+1 of the previous state (frame
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       act_ptr = p.x.actions + row + t;
       it.a1o = (p.x.a1_rows && t < (int)a.T) ? p.x.a1_rows + (row + t) * (16L * NP1) : nullptr;
       it.a2o = (p.x.a2_rows && t < (int)a.T) ? p.x.a2_rows + (row + t) * (long)p.F : nullptr;
+      it.ho = (p.x.heads_rows && t < (int)a.T) ? p.x.heads_rows + (row + t) * p.x.heads_rows_ld : nullptr;
     } else {
       it.prev = a.prev + (long)b * a.prev_stride;
       it.frame32 = a.frame_new ? a.frame_new + (long)b * HW : nullptr;
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       act_ptr = a.actions + (long)b * a.act_stride;
       it.a1o = a.a1_out ? a.a1_out + (long)b * a.a1_stride : nullptr;
       it.a2o = a.a2_out ? a.a2_out + (long)b * a.a2_stride : nullptr;
+      it.ho = a.heads_out ? a.heads_out + (long)b * a.heads_out_stride : nullptr;
     }
     const bool has_frame = it.frame32 != nullptr || it.frame8;
 
@@ -491,6 +495,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (n < N) {
           h[n] = red[n] + a.bc[n];
           a.heads[(long)b * a.ldh + n] = h[n];
+          if (it.ho != nullptr) it.ho[n] = h[n];
           if (n == a.n_actions) vboot = h[n];
         }
       }
@@ -655,6 +660,8 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.actions = r->actions; p.x.cmd = (unsigned long long*)r->cmd; p.x.rec = (const unsigned long long*)r->rec;
   p.x.seq0 = r->seq0; p.x.env0 = r->env0; p.x.err = r->err; p.x.timeout_ticks = (long)r->timeout_ticks;
   p.x.a1_rows = r->a1_rows; p.x.a2_rows = r->a2_rows;
+  p.x.heads_rows = r->heads_rows; p.x.heads_rows_ld = (long)r->heads_rows_ld;
+  if (r->heads_rows && r->heads_rows_ld < r->n_actions + 1) return A2C_ERR_ARG;
   if (!step_shapes(a.C, a.H, a.W, a.n_actions, p) || step_lds(p) > 160 * 1024 || !u8_shapes(a.H, a.W)) return A2C_ERR_ARG;
   if (!r->states || !r->bookmark || !r->u || !r->actions || !r->cmd || !r->rec || !r->frames || !r->err) return A2C_ERR_ARG;
   if (!a.wfrag1 || !a.bias1 || !a.wfrag2 || !a.bias2 || !a.Wc || !a.bc || !a.heads) return A2C_ERR_ARG;

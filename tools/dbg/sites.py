@@ -1,5 +1,5 @@
 import sys, os, json
-ROOT = os.getcwd()
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, ROOT + "/pytorch-a2c_amd"]
 import torch
 import bench

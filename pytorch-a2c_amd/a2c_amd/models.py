@@ -400,6 +400,8 @@ class _ConvStackNet(_HipNet):
     def _prep(self, st):
         for i, l in enumerate(self._cl):
             l.prep(self.P(f"convs.{i}.0.weight"), st)
+        if hasattr(self, "gru"):
+            self._gru_prep(st)
 
     def _convs_fwd(self, x_ptr, bstride, B, ws, st, stash=None):
         """-> [(ptr, batch stride in floats)] of every layer's activation.  ``stash`` = (bufs, row0, row_stride): the
@@ -557,15 +559,36 @@ class _GruMixin:
         buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(M, N, sk)) if sk > 1 else None
         ops.gemm(ta, tb, M, N, K, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, accumulate=accumulate, splitk=sk, ws=buf, st=st)
 
+    def _gru_prep(self, st):
+        """Inference/forward-only derived weights (rebuilt when the parameters change): the gate matrices side by
+        side, [Wx0|Wx1|Wx2] (in, 3h) and [Wh0|Wh1] (h, 2h), so that a cell's x-side and h-side gate products
+        are ONE GEMM each instead of three / two (models.py:472-475 multiplies gate by gate)."""
+        hd, xs = self.h_size, self.gru.x_size
+        Wx, Wh = self.P("gru.W_x"), self.P("gru.W_h")
+        if getattr(self, "_WxC", None) is None:
+            self._WxC = torch.empty(xs, 3 * hd, device=self._dev)
+            self._WhC = torch.empty(hd, 2 * hd, device=self._dev)
+        for g in range(3):
+            ops.copy_rows(Wx[g].data_ptr(), hd, self._WxC.data_ptr() + 4 * g * hd, 3 * hd, xs, hd, st)
+        for g in range(2):
+            ops.copy_rows(Wh[g].data_ptr(), hd, self._WhC.data_ptr() + 4 * g * hd, 2 * hd, hd, hd, st)
+
     def _gru_fwd(self, ws, x, h_in, B, st, bufs):
         hd, xs = self.h_size, self.gru.x_size
         Wx, Wh, b = self.P("gru.W_x"), self.P("gru.W_h"), self.P("gru.b")
         gx, gh, z, r, rh, rhu, c, hn = (bufs[k] for k in ("gx", "gh", "z", "r", "rh", "rhu", "c", "hn"))
+        cat = getattr(self, "_WxC", None) is not None and os.environ.get("A2C_NO_GRU_CAT") != "1"
         if x is not None:   # gx may have been precomputed for all time steps at once
-            for g in range(3):
-                self._mm(ws, 0, 0, B, hd, xs, x.data_ptr(), xs, Wx[g].data_ptr(), hd, gx.data_ptr() + 4 * g * hd, 3 * hd, st)
-        for g in range(2):
-            self._mm(ws, 0, 0, B, hd, hd, h_in.data_ptr(), hd, Wh[g].data_ptr(), hd, gh.data_ptr() + 4 * g * hd, 2 * hd, st)
+            if cat:
+                self._mm(ws, 0, 0, B, 3 * hd, xs, x.data_ptr(), xs, self._WxC.data_ptr(), 3 * hd, gx.data_ptr(), 3 * hd, st)
+            else:
+                for g in range(3):
+                    self._mm(ws, 0, 0, B, hd, xs, x.data_ptr(), xs, Wx[g].data_ptr(), hd, gx.data_ptr() + 4 * g * hd, 3 * hd, st)
+        if cat:
+            self._mm(ws, 0, 0, B, 2 * hd, hd, h_in.data_ptr(), hd, self._WhC.data_ptr(), 2 * hd, gh.data_ptr(), 2 * hd, st)
+        else:
+            for g in range(2):
+                self._mm(ws, 0, 0, B, hd, hd, h_in.data_ptr(), hd, Wh[g].data_ptr(), hd, gh.data_ptr() + 4 * g * hd, 2 * hd, st)
         ops.gru_gates(gx, gh, b, h_in, z, r, rh, st)
         self._mm(ws, 0, 0, B, hd, hd, rh.data_ptr(), hd, Wh[2].data_ptr(), hd, rhu.data_ptr(), hd, st)
         ops.gru_out(gx, rhu, b, h_in, z, c, hn, st)
@@ -619,9 +642,12 @@ class _GruMixin:
         N = R * T
         Wx = self.P("gru.W_x")
         tm = self._tm_bufs(ws, R, T)
-        for g in range(3):   # x-side gate products for all steps at once
-            ops.gemm(0, 0, N, h, xs, x_tm.data_ptr(), xs, Wx[g].data_ptr(), h, tm["gx"].data_ptr() + 4 * g * h, 3 * h,
-                     st=st)
+        if getattr(self, "_WxC", None) is not None and os.environ.get("A2C_NO_GRU_CAT") != "1":
+            ops.gemm(0, 0, N, 3 * h, xs, x_tm.data_ptr(), xs, self._WxC.data_ptr(), 3 * h, tm["gx"].data_ptr(), 3 * h, st=st)
+        else:
+            for g in range(3):   # x-side gate products for all steps at once
+                ops.gemm(0, 0, N, h, xs, x_tm.data_ptr(), xs, Wx[g].data_ptr(), h, tm["gx"].data_ptr() + 4 * g * h, 3 * h,
+                         st=st)
         ops.copy_rows(h_states.data_ptr(), T * h, tm["h_in"][0].data_ptr(), h, R, h, st)   # hs = h_states[:,0]
         for t in range(T):
             bufs = {k: tm[k][t] for k in ("gx", "gh", "z", "r", "rh", "rhu", "c", "hn")}
@@ -876,6 +902,9 @@ class FCModel(_FCBase):
 
 class GRUFCModel(_FCBase, _GruMixin):
     """models.py:483-543."""
+
+    def _prep(self, st):
+        self._gru_prep(st)
 
     def __init__(self, input_shape, output_space, h_size=200, bnorm=False, is_discrete=True, **kwargs):
         super().__init__()

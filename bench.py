@@ -317,9 +317,14 @@ class Bench:
                 print(f"[bench] rollout hipGraph capture failed ({type(e).__name__}: {e}); eager rollout", file=sys.stderr)
                 self.graph = None
                 torch.cuda.synchronize()
-        # the update as a hipGraph: ~40 dependent launches whose stream gaps shrink to graph-edge gaps.  With a
-        # sharded update the collective sits in the middle: two graphs around it would be needed (not captured).
-        if self.want_update_graph and not self.shard.active:
+        # the update as a hipGraph: ~40 dependent launches whose stream gaps shrink to graph-edge gaps.  A sharded
+        # update carries its RCCL all-reduces inside the captured graph (collectives on the capturing stream are
+        # graph nodes like any kernel); gloo collectives are host calls and cannot be captured.
+        # Verified on one GPU (world 1, collectives forced on: tools/dbg/rccl_graph.py); with more than one rank it is
+        # opt-in (A2C_RCCL_GRAPH=1) because no multi-GPU box was available to this build to rule out a capture hang.
+        can = not self.shard.active or (torch.distributed.get_backend() == "nccl" and
+                                        (self.shard.world == 1 or os.environ.get("A2C_RCCL_GRAPH") == "1"))
+        if self.want_update_graph and can:
             try:
                 # an update always follows a rollout: capture it in that state (the rollout's activation stash is
                 # valid, so the captured forward starts behind the two conv layers), then replay it once so that the

@@ -487,6 +487,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("A2C_BENCH_ONE_DEVICE") == "1":      # test hook: N ranks share cuda:0 (use with A2C_DIST_BACKEND=gloo)
         local = 0
+    if usable_cpus() < 4 * max(world, 1):
+        # fewer CPUs than (main thread + env thread + RCCL proxy + slack) per rank: do not let waiting host threads spin
+        from a2c_amd import _lib
+        _lib.load().a2c_set_blocking_sync(1)
     torch.cuda.set_device(local)
     shard = Shard.from_env()
     dev = torch.device("cuda", local)

@@ -217,6 +217,9 @@ int a2c_rollout_buffer_destroy(const char *shm_name, void *host, size_t bytes);
 /* pin + map an existing host range (page aligned) / undo it                                  */
 int a2c_pinned_register(void *host, size_t bytes, void **dev_out);
 int a2c_pinned_unregister(void *host);
+/* host threads waiting in hipStreamSynchronize sleep instead of spinning (hipDeviceScheduleBlockingSync): for
+ * nodes where the ranks of a multi-GPU job have fewer CPUs than busy threads.  Call before any other HIP work. */
+int a2c_set_blocking_sync(int on);
 /* PCI bus id ("0000:c1:00.0") of the current HIP device: the host side places the pinned region and the env
  * workers on the NUMA node the GPU hangs off (/sys/bus/pci/devices/<id>/numa_node)                */
 int a2c_device_pci_bus_id(char *out, int len);

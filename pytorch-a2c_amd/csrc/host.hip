@@ -67,6 +67,15 @@ int a2c_rollout_buffer_destroy(const char* shm_name, void* host, size_t bytes) {
   return rc;
 }
 
+int a2c_set_blocking_sync(int on) {
+  // must run before the first kernel / allocation of the process on the device
+  if (hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto) != hipSuccess) {
+    (void)hipGetLastError();
+    return A2C_ERR_LAUNCH;
+  }
+  return A2C_OK;
+}
+
 int a2c_device_pci_bus_id(char* out, int len) {
   if (!out || len < 16) return A2C_ERR_ARG;
   int dev = 0;

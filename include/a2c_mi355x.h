@@ -46,8 +46,10 @@ const char *a2c_error_string(int code);
  * length T (row r = elements [r*T, (r+1)*T)); the running sum starts at 0 at each row end.
  * With n_seg == 1 this is exactly utils.discount on a flat array of T elements.
  * When n_seg > 1 the rows are only independent if every row ends with dones == 1
- * (Runner guarantees it: runner.py:223,244); err_flag (device int, may be NULL) is set
- * to 1 when a row violates this.                                                       */
+ * (Runner guarantees it: runner.py:223,244).  With err_flag (device int) given, a violation
+ * sets it to 1 AND the call recomputes the array as one flat row on the device, so the
+ * result is the reference's for any data; with err_flag == NULL the rows are taken as
+ * independent without a check.                                                         */
 int a2c_discount_scan(const float *x, const float *dones, float *y, int64_t n_seg,
                       int64_t T, float g, int *err_flag, a2c_stream_t stream);
 /* updater.py:70-71 + 86-88 fused: advs = discount(deltas, dones, g_adv) and
@@ -382,6 +384,11 @@ int a2c_clip_rmsprop(float *params, float *grads, float *square_avg, int64_t n,
 int a2c_clip_adam(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
                   const double *sumsq, double max_norm, double lr, double beta1, double beta2,
                   double eps, int64_t step, float *norm_out, a2c_stream_t stream);
+
+/* out5 = [loss_sums[0..2], grad_norm, err]: the five scalars update_model reads back (updater.py:134-136)
+ * gathered into ONE device buffer for a single D2H copy                                  */
+int a2c_pack_update_scalars(const double *loss_sums, const float *grad_norm, const int *err,
+                            double *out5, a2c_stream_t stream);
 
 #ifdef __cplusplus
 }

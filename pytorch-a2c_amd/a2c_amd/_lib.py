@@ -101,6 +101,7 @@ SIGNATURES = {
     "a2c_memcpy_async": (c_int, [P, P, c_size_t, c_int, P]),
     "a2c_device_pci_bus_id": (c_int, [c_char_p, c_int]),
     "a2c_set_blocking_sync": (c_int, [c_int]),
+    "a2c_pack_update_scalars": (c_int, [P, P, P, P, P]),
     "a2c_conv2d_prep_weights": (c_int, [PD, c_int, P, P, P]),
     "a2c_conv2d_fwd": (c_int, [PD, P, c_int64, P, P, c_int, P, c_int64, c_int, P]),
     "a2c_conv2d_bwd_data": (c_int, [PD, P, P, P, P, c_int, P]),

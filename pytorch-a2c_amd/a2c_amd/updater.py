@@ -26,6 +26,7 @@ class Updater:
         self.shard = shard if shard is not None else Shard()
         self.optim = self.new_optim(hyps["lr"])
         self.info = {}
+        self.flat_scan_fallback = False     # last update: a slot did not end with done == 1 -> flat scans were used
         self.norm = 0
         self.ret_mean = None
         self.ret_std = None
@@ -47,6 +48,7 @@ class Updater:
                      vals_c=torch.empty(N, device=dev),
                      stats=torch.zeros(8, dtype=torch.float64, device=dev),   # [adv sums 0:2 | loss sums 2:5 | ret 5:7]
                      err=torch.zeros(1, dtype=torch.int32, device=dev),
+                     out5=torch.zeros(5, dtype=torch.float64, device=dev),
                      host=torch.zeros(8, dtype=torch.float64).pin_memory() if torch.cuda.is_available() else None)
             self._bufs = b
         return b
@@ -133,14 +135,17 @@ class Updater:
             self.optim.step(max_norm=hyps["max_norm"], st=st)
         self.optim.zero_grad()
 
-        # five scalars for the host (the reference's .item() calls, updater.py:134-136)
-        return torch.cat([stats[2:5], self.optim.grad_norm().double(), b["err"].double()]), n_global
+        # five scalars for the host (the reference's .item() calls, updater.py:134-136), gathered by one kernel
+        ops.check(ops.lib().a2c_pack_update_scalars(stats[2:5].data_ptr(), self.optim.grad_norm().data_ptr(),
+                                                    b["err"].data_ptr(), b["out5"].data_ptr(), st), "a2c_pack_update_scalars")
+        return b["out5"], n_global
 
     def _finish_update(self, dev_vec, n_global):
         hyps = self.hyps
         host = dev_vec.cpu()
-        if int(host[4]):
-            raise ValueError("shared_data['dones']: a slot does not end with done == 1 (runner.py:244 invariant)")
+        # host[4] != 0: a slot did not end with done == 1 (not Runner data, runner.py:244); the scans then ran in
+        # the reference's flat form on the device (a2c_gae_returns_fused), so the update is still the reference's
+        self.flat_scan_fallback = bool(int(host[4]))
         s_pi, s_val, s_ent = (float(host[i]) for i in range(3))
         pi_loss = try_key(hyps, "pi_coef", 1.0) * -(s_pi / n_global)
         val_loss = hyps["val_coef"] * (s_val / n_global)

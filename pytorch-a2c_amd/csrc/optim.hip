@@ -93,7 +93,26 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
 }
 }  // namespace
 
+namespace {
+__global__ void pack_scalars_kernel(const double* __restrict__ loss_sums, const float* __restrict__ norm,
+                                    const int* __restrict__ err, double* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    out[0] = loss_sums[0]; out[1] = loss_sums[1]; out[2] = loss_sums[2];
+    out[3] = (double)norm[0];
+    out[4] = err ? (double)err[0] : 0.0;
+  }
+}
+}  // namespace
+
 extern "C" {
+int a2c_pack_update_scalars(const double* loss_sums, const float* grad_norm, const int* err, double* out5,
+                            a2c_stream_t stream) {
+  if (!loss_sums || !grad_norm || !out5) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(pack_scalars_kernel, dim3(1), dim3(64), 0, a2c_s(stream), loss_sums, grad_norm, err, out5);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
 int a2c_gradnorm_sq(const float* grads, int64_t n, double* sumsq, a2c_stream_t stream) {
   if (n < 0 || !sumsq || (n > 0 && !grads) || ((uintptr_t)grads % 16)) return A2C_ERR_ARG;
   a2c_zero_async(sumsq, sizeof(double), a2c_s(stream));

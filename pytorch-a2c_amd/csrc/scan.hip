@@ -148,9 +148,11 @@ __global__ __launch_bounds__(64) void scan_long_kernel(const float* __restrict__
                                                        const float* __restrict__ x1,
                                                        const float* __restrict__ dn,
                                                        float* __restrict__ y0, float* __restrict__ y1,
-                                                       long n_seg, long T, float g0, float g1, int* err) {
+                                                       long n_seg, long T, float g0, float g1, int* err,
+                                                       const int* __restrict__ run_if) {
   __shared__ float s0[TILE], sd[TILE], s1[NARR == 2 ? TILE : 1];
   const int lane = threadIdx.x;
+  if (run_if != nullptr && *run_if == 0) return;      // flat fall-back pass: only when the row pass flagged a violation
   for (long row = blockIdx.x; row < n_seg; row += gridDim.x) {
     const long base = row * T;
     float r0 = 0.f, r1 = 0.f;
@@ -212,9 +214,17 @@ int launch_scan(const float* x0, const float* x1, const float* dn, float* y0, fl
   } else {
     const int grid = (int)(n_seg < 1024 ? n_seg : 1024);
     hipLaunchKernelGGL(scan_long_kernel<NARR>, dim3(grid), dim3(64), 0, st, x0, x1, dn, y0, y1,
-                       (long)n_seg, (long)T, g0, g1, err);
+                       (long)n_seg, (long)T, g0, g1, err, (const int*)nullptr);
   }
   A2C_CHECK_LAUNCH();
+  if (err && n_seg > 1) {
+    // rows that do not end with done == 1 are not independent: the reference's flat loop (utils.py:73-79) carries
+    // the running sum across them.  The row pass flagged it; redo the array as ONE row, in order, on the device
+    // (a few ms for 32k elements -- the Runner never produces such data, arbitrary callers may).
+    hipLaunchKernelGGL(scan_long_kernel<NARR>, dim3(1), dim3(64), 0, st, x0, x1, dn, y0, y1, 1L, (long)(n_seg * T), g0, g1,
+                       (int*)nullptr, (const int*)err);
+    A2C_CHECK_LAUNCH();
+  }
   return A2C_OK;
 }
 

@@ -73,12 +73,22 @@ def test_discount_row_invariant_flag_and_flat_fallback():
     x = rnd((40,), 4).to(DEV)
     d = torch.zeros(40, device=DEV)
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
-    ops.discount_rows(x, d, 0.9, 4, 10, err=err)
+    flat = O.discount_np(x.cpu().numpy(), d.cpu().numpy(), 0.9)
+    y = ops.discount_rows(x, d, 0.9, 4, 10, err=err)
+    assert int(err.item()) == 1                       # rows do not end with done == 1 ...
+    assert np.array_equal(y.cpu().numpy(), flat)       # ... so the call fell back to the reference's flat scan
+    assert np.array_equal(discount(x, d, 0.9, n_tsteps=10).cpu().numpy(), flat)
+    d2 = d.clone()
+    d2[19] = 1                                         # only one of the four rows ends properly: still flat
+    assert np.array_equal(ops.discount_rows(x, d2, 0.9, 4, 10, err=err).cpu().numpy(),
+                          O.discount_np(x.cpu().numpy(), d2.cpu().numpy(), 0.9))
+    a_, r_ = torch.empty_like(x), torch.empty_like(x)
+    ops.gae_returns(x, -x, d2, 0.9, 0.8, 4, 10, a_, r_, err=err)
     assert int(err.item()) == 1
-    with pytest.raises(ValueError):
-        discount(x, d, 0.9, n_tsteps=10)
+    assert np.array_equal(a_.cpu().numpy(), O.discount_np(x.cpu().numpy(), d2.cpu().numpy(), 0.9))
+    assert np.array_equal(r_.cpu().numpy(), O.discount_np(-x.cpu().numpy(), d2.cpu().numpy(), 0.8))
     y = discount(x, d, 0.9)            # flat: carries across everything, exactly like the reference
-    assert np.array_equal(y.cpu().numpy(), O.discount_np(x.cpu().numpy(), d.cpu().numpy(), 0.9))
+    assert np.array_equal(y.cpu().numpy(), flat)
     assert discount(torch.zeros(0), torch.zeros(0), 0.9).numel() == 0
 
 

@@ -45,7 +45,7 @@ import torch  # noqa: E402
 
 WORKLOADS = {   # model, n_envs, n_tsteps, use_bptt, n_actions
     "a3c": ("A3CModel", 256, 128, False, 3),        # headline: Pong-v0, a3c, 256 x 128
-    "conv": ("ConvModel", 32, 64, False, 3),        # configs[1]
+    "conv": ("ConvModel", 32, 64, False, 3),        # configs[1]; --n-envs 256 with T=128 is the per-GPU shard of configs[4]
     "gru": ("GRUModel", 256, 128, False, 3),
     "gru_bptt": ("GRUModel", 256, 128, True, 3),    # configs[3]
     "fc": ("FCModel", 256, 128, False, 3),
@@ -253,6 +253,8 @@ class Bench:
         from a2c_amd.updater import Updater
         self.model, n0, self.T, self.use_bptt, self.A = WORKLOADS[workload]
         self.n_envs = n_envs or n0
+        if workload == "conv" and self.n_envs >= 256:
+            self.T = 128                               # configs[4]: n_tsteps=128
         self.hyps = hyps_for(self.model, self.n_envs, self.T, self.use_bptt, optim)
         self.shard, self.dev, self.ingest, self.optim_name = shard, dev, ingest, optim
         torch.manual_seed(20260101)                # the reference's default init, identical on every rank
@@ -682,8 +684,11 @@ def main():
                     out["host_pinned_process_workers"] = dict(value=None, error=f"{type(e).__name__}: {e}")
         if not args.no_configs and args.workload == "a3c" and not args.n_envs and not args.global_envs:
             cfgs = {}
+            # BASELINE.json configs[1], [3], the north star's n_envs in {32, 2048} for the headline model, and the
+            # per-GPU shard of configs[4] (ConvModel, 2048 envs over 8 GPUs = 256 envs x 128 steps per GPU)
             for key, wl, ne, st_, wu in (("conv_32x64", "conv", None, 5, 2), ("gru_bptt_256x128", "gru_bptt", None, 3, 1),
-                                         ("a3c_32", "a3c", 32, 20, 3), ("a3c_2048", "a3c", 2048, 5, 2)):
+                                         ("a3c_32", "a3c", 32, 20, 3), ("a3c_2048", "a3c", 2048, 5, 2),
+                                         ("conv_2048x128_per_gpu_shard_256x128", "conv", 256, 2, 1)):
                 try:
                     torch.cuda.empty_cache()
                     cfgs[key] = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu)

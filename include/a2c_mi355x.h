@@ -205,6 +205,14 @@ typedef struct {
   int64_t timeout_ticks;
   float *a1_rows, *a2_rows;        /* optional activation stash, row e = (slot0+b)*T + t (see a2c_a3c_step_args) */
   float *heads_rows; int64_t heads_rows_ld;   /* optional [logits | value] of state e, row stride heads_rows_ld */
+  /* optional single-frame uint8 store (row f4 of SURVEY.md section 8): slot r keeps T+4 frames of H*W bytes,
+   * frame_store_slot_stride bytes apart; the 4 planes of state (r, t) are the CONTIGUOUS window
+   * frames[r][t .. t+3] (the newest frame of state t is frames[r][t+3]; frames[r][0..3] are copied from
+   * frames[r][T..T+3], the state the previous slot ended in).  nvalid_rows[e] = how many of the 4 planes of state
+   * e are real (planes older than the env's last reset are zero, utils.py:37-42); nvalid_carry[b] carries that
+   * count of the bookmark state from slot to slot.  Consumer: a2c_conv2d_bwd_weight_frames.              */
+  uint8_t *frame_store; int64_t frame_store_slot_stride;
+  int32_t *nvalid_rows, *nvalid_carry;
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
 
@@ -344,6 +352,13 @@ size_t a2c_conv2d_bwd_weight_ws_bytes(const a2c_conv_desc *d, int B);
 int a2c_conv2d_bwd_weight(const a2c_conv_desc *d, const float *in, int64_t in_bstride,
                           const float *dout, float *dW, float *db, int B, void *ws,
                           size_t ws_bytes, a2c_stream_t stream);
+/* The same for the first layer of the A3CModel-shaped nets (8x8 / stride 4 on 4 stacked frames) with the
+ * input taken from the single-frame uint8 store a2c_a3c_rollout leaves (stack-on-load: 28 KB of uint8 per
+ * sample instead of the 113 KB fp32 state; identical fp32 values, identical summation order): sample
+ * n = r*T + t reads frames[r][t .. t+3], planes c < 4 - nvalid[n] are zero.                              */
+int a2c_conv2d_bwd_weight_frames(const a2c_conv_desc *d, const uint8_t *frame_store, int64_t slot_stride,
+                                 int64_t T, const int32_t *nvalid, const float *dout, float *dW,
+                                 float *db, int B, void *ws, size_t ws_bytes, a2c_stream_t stream);
 
 /* ------------------------------------------------------------------ a6: GRU cell, LayerNorm
  * models.GRU.forward (models.py:465-476) given the six pre-activation products:

@@ -45,7 +45,8 @@ class A3CRolloutArgs(Structure):
                 ("val_prev", P), ("rewards", P), ("dones", P), ("deltas", P),
                 ("T", c_int64), ("slot0", c_int64), ("gamma", c_float), ("pong", c_int),
                 ("cmd", P), ("rec", P), ("frames", P), ("frame_stride", c_int64),
-                ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64), ("a1_rows", P), ("a2_rows", P), ("heads_rows", P), ("heads_rows_ld", c_int64)]
+                ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64), ("a1_rows", P), ("a2_rows", P), ("heads_rows", P), ("heads_rows_ld", c_int64),
+                ("frame_store", P), ("frame_store_slot_stride", c_int64), ("nvalid_rows", P), ("nvalid_carry", P)]
 
 
 PS = POINTER(A3CStepArgs)
@@ -107,6 +108,7 @@ SIGNATURES = {
     "a2c_conv2d_bwd_data": (c_int, [PD, P, P, P, P, c_int, P]),
     "a2c_conv2d_bwd_weight_ws_bytes": (c_size_t, [PD, c_int]),
     "a2c_conv2d_bwd_weight": (c_int, [PD, P, c_int64, P, P, P, c_int, P, c_size_t, P]),
+    "a2c_conv2d_bwd_weight_frames": (c_int, [PD, P, c_int64, c_int64, P, P, P, P, c_int, P, c_size_t, P]),
     "a2c_gru_gates": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "a2c_gru_out": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "a2c_gru_out_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),

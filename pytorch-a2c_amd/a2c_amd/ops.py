@@ -403,6 +403,14 @@ def conv_bwd_weight(d, in_ptr, in_bstride, dout, dW, db, B, ws, st=None):
                                       st if st is not None else stream()), "a2c_conv2d_bwd_weight")
 
 
+def conv_bwd_weight_frames(d, fstore, slot_stride, T, nvalid, dout, dW, db, B, ws, st=None):
+    """first-layer weight gradient from the rollout's single-frame uint8 store (stack-on-load)"""
+    _chk(fstore, "frame_store", torch.uint8); _chk(nvalid, "nvalid", torch.int32)
+    check(lib().a2c_conv2d_bwd_weight_frames(ctypes.byref(d), _p(fstore), slot_stride, T, _p(nvalid), _p(dout), _p(dW), _p(db),
+                                             B, ws.data_ptr(), ws.numel() * ws.element_size(),
+                                             st if st is not None else stream()), "a2c_conv2d_bwd_weight_frames")
+
+
 # ---------------------------------------------------------------- GRU / LayerNorm
 def gru_gates(gx, gh, b, h, z, r, rh, st=None):
     B, hd = h.shape

@@ -274,6 +274,7 @@ class Runner:
         N = self.datas["states"].shape[0]
         T_ = int(hyps["n_tsteps"])
         self._stash_bufs = None
+        self._frames_written = None
         if idxs == list(range(N // T_)) and N % T_ == 0:
             self._stash_bufs = net.stash_rows(self.datas["states"], N)
         j = 0
@@ -286,7 +287,7 @@ class Runner:
         if self.proc_pool:
             self.env_pool.seq += int(hyps["n_tsteps"])
         if self._stash_bufs is not None and self._stash_used:
-            net.stash_commit(self.datas["states"], N)
+            net.stash_commit(self.datas["states"], N, frames=getattr(self, "_frames_written", None))
 
     def _uniforms(self, t, B, env0):
         if self.uniform_fn is not None:
@@ -336,6 +337,7 @@ class Runner:
         # next to the frame-stack kernel (two branches in the hipGraph).  Measured on MI355X the
         # fork/join costs more than the 4.8 us it hides (16.0 -> 17.8 ms per 256x128 epoch), so it is
         # opt-in (A2C_SIDE_STREAM=1).
+        self._fstore_ok = False          # this slot is not played by the persistent kernel: the frame store goes stale
         if not self.device_pool and os.environ.get("A2C_NO_STEP_GRAPHS") != "1":
             return self._rollout_block_segmented(net, slot0, env0, B, hyps, sp, bm, val_prev, done_eff, h, acts_host_out)
         main = torch.cuda.current_stream()
@@ -642,6 +644,9 @@ class Runner:
         P = net.P
         self._u_keep = u          # stays alive until the launch has consumed it
         timeout_s = float(try_key(hyps, "env_timeout_s", 20.0))
+        # single-frame uint8 store (row f4): T+4 frames per slot, created with the bookmark in start(); the update's
+        # first-layer weight gradient stacks the frames on load instead of reading the 4x duplicated fp32 states
+        fs = self._frame_store(T, D["states"].shape[0] // T, dev)
         ops.a3c_rollout(st, B=B, C=C, H=H, W=W, n_actions=net.output_space, states=D["states"].data_ptr(),
                         bookmark=bm.data_ptr(), wfrag1=net._c1.wf.data_ptr(), bias1=P("convs.0.0.bias").data_ptr(),
                         wfrag2=net._c2.wf.data_ptr(), bias2=P("convs.1.0.bias").data_ptr(), Wc=net._Wc.data_ptr(),
@@ -654,10 +659,38 @@ class Runner:
                         a1_rows=0 if self._stash_bufs is None else self._stash_bufs[0].data_ptr(),
                         a2_rows=0 if self._stash_bufs is None else self._stash_bufs[1].data_ptr(),
                         heads_rows=0 if self._stash_bufs is None else self._stash_bufs[2].data_ptr(),
-                        heads_rows_ld=0 if self._stash_bufs is None else self._stash_bufs[2].stride(0))
+                        heads_rows_ld=0 if self._stash_bufs is None else self._stash_bufs[2].stride(0),
+                        frame_store=0 if fs is None else fs[0].data_ptr(),
+                        frame_store_slot_stride=0 if fs is None else fs[0].stride(0),
+                        nvalid_rows=0 if fs is None else fs[1].data_ptr(),
+                        nvalid_carry=0 if fs is None else fs[2][env0:env0 + B].data_ptr())
+        if fs is not None and self._stash_bufs is not None:
+            self._frames_written = (fs[0], fs[1], T)
         self._stash_used = self._stash_bufs is not None
         if acts_host_out is not None:
             acts_host_out[slot0 * T:(slot0 + B) * T].copy_(acts[slot0 * T:(slot0 + B) * T])
+
+    def _frame_store(self, T, R, dev):
+        """(frames uint8 (R, T+4, HW), nvalid_rows int32 (R*T,), nvalid_carry int32 (B,)) or None.  OPT-IN
+        (hyps['frame_store'] / A2C_FRAME_STORE=1): on MI355X the first-layer weight gradient is matrix-bound, not
+        HBM-bound, and runs 10 % SLOWER from the uint8 store (1.41 vs 1.27 ms at N = 32 768: the uint8 -> fp32
+        expansion sits in the commit phase all waves wait on) although it reads 4x fewer bytes.  Valid only while
+        EVERY env step since start() went through the persistent kernel (it is the only writer): the first slot finds
+        frames[:, T+3] = the reset frame and one valid plane; any other rollout path switches the store off."""
+        on = os.environ.get("A2C_FRAME_STORE") == "1" or bool(try_key(self.hyps, "frame_store", False))
+        if not on or os.environ.get("A2C_NO_FRAME_STORE") == "1" or T < 4 or self.HW % 16 or \
+                not getattr(self, "_fstore_ok", True):
+            return None
+        fs = getattr(self, "_fstore", None)
+        if fs is None:
+            if self.env_pool.seq != 0 or R != self.B:
+                self._fstore_ok = False
+                return None
+            F_ = torch.zeros((R, T + 4, self.HW), dtype=torch.uint8, device=dev)
+            F_[:, T + 3] = self.d_frames[:, :self.HW]          # frame 0 of every env (its env.reset()), still in HBM from start()
+            fs = self._fstore = (F_, torch.zeros(R * T, dtype=torch.int32, device=dev),
+                                 torch.ones(self.B, dtype=torch.int32, device=dev))
+        return fs
 
     # ------------------------------------------------------------------ one env step of B envs
     def _env_step(self, pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong):

@@ -1768,7 +1768,26 @@ struct WstreamP {
   const float* dout;              // (B, Cout, OH, OW) contiguous
   float* slab;                    // [grid][Cout*K + Cout]
   int B, H, W, OH, OW, Cout, K, PLANE1, PLANEo, WP;
+  // U8: the input comes from the single-frame uint8 store of the rollout instead of the stacked fp32 states:
+  // sample n = (slot r, step t) is the CONTIGUOUS window of 4 frames fstore[r][t .. t+3] (T+4 frames per slot),
+  // planes older than the env's last reset (c < 4 - nvalid[n]) are zero (utils.py:37-42)
+  const unsigned char* fstore; long fs_slot_stride; int T; const int* nvalid;
 };
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ws_u8x4(unsigned int w) {
+  return make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+}
+#define WS_LDU(var, u, src) var = *reinterpret_cast<const u32x4w*>((src) + ((long)min(tid + (u) * ST_NT, g16 - 1) << 4));
+#define WS_STU(var, u, nv)                                                                     \
+  {                                                                                            \
+    const int idx_ = min(tid + (u) * ST_NT, g16 - 1);                                           \
+    const int c_ = (idx_ >= gpp) + (idx_ >= 2 * gpp) + (idx_ >= 3 * gpp);                      \
+    float4* d_ = reinterpret_cast<float4*>(img + c_ * p.PLANE1 + ((idx_ - c_ * gpp) << 4));     \
+    const bool z_ = c_ < 4 - (nv);                                                             \
+    const float4 zz_ = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
+    d_[0] = z_ ? zz_ : ws_u8x4(var[0]); d_[1] = z_ ? zz_ : ws_u8x4(var[1]);                    \
+    d_[2] = z_ ? zz_ : ws_u8x4(var[2]); d_[3] = z_ ? zz_ : ws_u8x4(var[3]);                    \
+  }
 #define WS_LDI(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * ST_NT, tot4 - 1) << 2));
 #define WS_LDD(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * ST_NT, dtot4 - 1) << 2));
 #define WS_STI(var, u)                                                                         \
@@ -1787,6 +1806,7 @@ struct WstreamP {
     *reinterpret_cast<float2*>(d_ + 2) = make_float2(var.z, var.w);                            \
   }
 
+template <bool U8>
 __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_stream_kernel(WstreamP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* __restrict__ img = lds;
@@ -1797,6 +1817,7 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   const int HW = p.H * p.W, W = p.W, NP = p.OH * p.OW;
   const int per4 = HW >> 2, tot4 = 4 * per4, w4 = W >> 2;
   const int dper4 = NP >> 2, dtot4 = p.Cout * dper4;
+  const int gpp = HW >> 4, g16 = 4 * gpp;            // U8: 16-pixel groups per plane / per sample
   for (int i = tid; i < 16 * p.PLANEo; i += ST_NT) ldo[i] = 0.f;
   // this lane's weight column group: (ci, ky, kxh), the 4 accumulators are kxl = 0..3
   const int cidx = q * 16 + j;
@@ -1809,13 +1830,22 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   float dbacc = 0.f;
   float4 v0 = {}, v1 = {}, v2 = {}, v3 = {}, v4 = {}, v5 = {}, v6 = {}, v7 = {}, v8 = {}, v9 = {}, v10 = {}, v11 = {}, v12 = {}, v13 = {};
   float4 d0 = {}, d1 = {}, d2 = {}, d3 = {};
+  u32x4w g0 = {}, g1 = {}, g2 = {}, g3 = {};
+  int nv = 4;
+  auto fsrc = [&](long nn_) { const long r_ = nn_ / p.T; return p.fstore + r_ * p.fs_slot_stride + (nn_ - r_ * p.T) * (long)HW; };
   long n = blockIdx.x;
   if (n < p.B) {
     const float* __restrict__ src = p.in + n * p.in_bs;
     const float* __restrict__ dsrc = p.dout + n * (long)p.Cout * NP;
     WS_LDD(d0, 0, dsrc) WS_LDD(d1, 1, dsrc) WS_LDD(d2, 2, dsrc) WS_LDD(d3, 3, dsrc)
+    if (U8) {
+      const unsigned char* __restrict__ us = fsrc(n);
+      nv = p.nvalid[n];
+      WS_LDU(g0, 0, us) WS_LDU(g1, 1, us) WS_LDU(g2, 2, us) WS_LDU(g3, 3, us)
+    } else {
     WS_LDI(v0, 0, src) WS_LDI(v1, 1, src) WS_LDI(v2, 2, src) WS_LDI(v3, 3, src) WS_LDI(v4, 4, src) WS_LDI(v5, 5, src) WS_LDI(v6, 6, src)
     WS_LDI(v7, 7, src) WS_LDI(v8, 8, src) WS_LDI(v9, 9, src) WS_LDI(v10, 10, src) WS_LDI(v11, 11, src) WS_LDI(v12, 12, src) WS_LDI(v13, 13, src)
+    }
   }
   const int nrow = (p.OH - h + 1) >> 1;              // output rows h, h+2, ...
   const int s1 = nrow / 3, s2 = (2 * nrow) / 3;
@@ -1826,8 +1856,12 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const float* __restrict__ ndsrc = p.dout + nn * (long)p.Cout * NP;
     __syncthreads();                                 // everyone is done with the previous sample
     WS_STD(d0, 0) WS_STD(d1, 1) WS_STD(d2, 2) WS_STD(d3, 3)
+    if (U8) {
+      WS_STU(g0, 0, nv) WS_STU(g1, 1, nv) WS_STU(g2, 2, nv) WS_STU(g3, 3, nv)
+    } else {
     WS_STI(v0, 0) WS_STI(v1, 1) WS_STI(v2, 2) WS_STI(v3, 3) WS_STI(v4, 4) WS_STI(v5, 5) WS_STI(v6, 6)
     WS_STI(v7, 7) WS_STI(v8, 8) WS_STI(v9, 9) WS_STI(v10, 10) WS_STI(v11, 11) WS_STI(v12, 12) WS_STI(v13, 13)
+    }
     __syncthreads();
     if (bco < p.Cout) {                              // bias gradient partials from the dOut tile
       const float* __restrict__ pl = ldo + bco * p.PLANEo;
@@ -1856,12 +1890,23 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }                                                                                                   \
       }                                                                                                     \
     }
+    if (U8) {
+      const unsigned char* __restrict__ nus = fsrc(nn);
+      nv = p.nvalid[nn];
+      WS_LDD(d0, 0, ndsrc) WS_LDD(d1, 1, ndsrc) WS_LDD(d2, 2, ndsrc) WS_LDD(d3, 3, ndsrc) WS_LDU(g0, 0, nus)
+      WS_ROWS(0, s1)
+      WS_LDU(g1, 1, nus) WS_LDU(g2, 2, nus)
+      WS_ROWS(s1, s2)
+      WS_LDU(g3, 3, nus)
+      WS_ROWS(s2, nrow)
+    } else {
     WS_LDD(d0, 0, ndsrc) WS_LDD(d1, 1, ndsrc) WS_LDD(d2, 2, ndsrc) WS_LDD(d3, 3, ndsrc) WS_LDI(v0, 0, nsrc) WS_LDI(v1, 1, nsrc)
     WS_ROWS(0, s1)
     WS_LDI(v2, 2, nsrc) WS_LDI(v3, 3, nsrc) WS_LDI(v4, 4, nsrc) WS_LDI(v5, 5, nsrc) WS_LDI(v6, 6, nsrc) WS_LDI(v7, 7, nsrc)
     WS_ROWS(s1, s2)
     WS_LDI(v8, 8, nsrc) WS_LDI(v9, 9, nsrc) WS_LDI(v10, 10, nsrc) WS_LDI(v11, 11, nsrc) WS_LDI(v12, 12, nsrc) WS_LDI(v13, 13, nsrc)
     WS_ROWS(s2, nrow)
+    }
   }
   // epilogue: add the two row parities in a fixed order, write this workgroup's slab
   __syncthreads();
@@ -2334,6 +2379,35 @@ size_t a2c_conv2d_bwd_weight_ws_bytes(const a2c_conv_desc* d, int B) {
   return (size_t)grid * ((size_t)d->Cout * d->Cin * d->ks * d->ks + d->Cout) * sizeof(float);
 }
 
+int a2c_conv2d_bwd_weight_frames(const a2c_conv_desc* d, const uint8_t* fstore, int64_t slot_stride, int64_t T,
+                                 const int* nvalid, const float* dout, float* dW, float* db, int B, void* ws, size_t ws_bytes,
+                                 a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 1 || !fstore || !nvalid || !dout || !dW || T < 1) return A2C_ERR_ARG;
+  WstreamP wp;
+  if (!plan_wstream(d, wp) || (d->H * d->W) % 16 || ((uintptr_t)fstore % 16) || slot_stride % 16 || ((uintptr_t)dout % 16) ||
+      slot_stride < (T + 3) * (int64_t)d->H * d->W)
+    return A2C_ERR_ARG;
+  if (!ws || ws_bytes < a2c_conv2d_bwd_weight_ws_bytes(d, B)) return A2C_ERR_WORKSPACE;
+  hipStream_t st = a2c_s(stream);
+  const int grid = stream_grid();
+  wp.in = nullptr; wp.in_bs = 0; wp.dout = dout; wp.slab = (float*)ws; wp.B = B;
+  wp.fstore = fstore; wp.fs_slot_stride = (long)slot_stride; wp.T = (int)T; wp.nvalid = nvalid;
+  const size_t lds = 4 * (size_t)(4 * wp.PLANE1 + 16 * wp.PLANEo);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)wgrad_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return A2C_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(wgrad_stream_kernel<true>, dim3(grid < B ? grid : B), dim3(ST_NT), lds, st, wp);
+  A2C_CHECK_LAUNCH();
+  const int g = grid < B ? grid : B;
+  const long nWs = (long)wp.Cout * wp.K, pers = nWs + wp.Cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(pers, 256)), dim3(256), 0, st, (const float*)ws, g, pers, nWs, dW, db);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
 int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* dout, float* dW,
                           float* db, int B, void* ws, size_t ws_bytes, a2c_stream_t stream) {
   WgradPlan pl;
@@ -2348,14 +2422,15 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
     if (aligned && B >= 8 * grid && ((uintptr_t)dout % 16 == 0) && !getenv("A2C_NO_STREAM") && !getenv("A2C_NO_PF") &&
         plan_wstream(d, wp)) {
       wp.in = in; wp.in_bs = in_bstride; wp.dout = dout; wp.slab = (float*)ws; wp.B = B;
+      wp.fstore = nullptr; wp.fs_slot_stride = 0; wp.T = 1; wp.nvalid = nullptr;
       const size_t lds = 4 * (size_t)(4 * wp.PLANE1 + 16 * wp.PLANEo);
       static bool attr = false;
       if (!attr) {
-        if (hipFuncSetAttribute((const void*)wgrad_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)wgrad_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
           return A2C_ERR_LAUNCH;
         attr = true;
       }
-      hipLaunchKernelGGL(wgrad_stream_kernel, dim3(grid), dim3(ST_NT), lds, st, wp);
+      hipLaunchKernelGGL(wgrad_stream_kernel<false>, dim3(grid), dim3(ST_NT), lds, st, wp);
       A2C_CHECK_LAUNCH();
       const long nWs = (long)wp.Cout * wp.K, pers = nWs + wp.Cout;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(pers, 256)), dim3(256), 0, st, (const float*)ws, grid, pers, nWs,

@@ -57,6 +57,8 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   float* a1_rows;
   float* a2_rows;
   float* heads_rows; long heads_rows_ld;
+  unsigned char* fstore; long fs_slot_stride;      // single-frame uint8 store (T+4 frames per slot)
+  int* nvalid; int* nvalid_carry;
 };
 
 struct StepP {
@@ -222,6 +224,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const long bk_e = rec ? (a.slot0 + b) * a.T + t_rec : 0;
     const float* __restrict__ safe = a.heads + (long)b * a.ldh;
     float ld_r, ld_d, ld_v, ld_pr, ld_pd, ld_vp, ld_rst;
+    int ld_nvc = 4;
+    unsigned char* __restrict__ fs_slot = nullptr;
     float4 f1a, f1b;
     u32x4 f8 = (u32x4){0u, 0u, 0u, 0u};
     float4 pf0[SL0], pf1[SL1], pf2[SL2];
@@ -232,6 +236,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       ld_pr = __hip_atomic_load((rec && t_rec > 0) ? a.rewards + bk_e - 1 : safe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ld_pd = __hip_atomic_load((rec && t_rec > 0) ? a.dones + bk_e - 1 : safe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ld_vp = __hip_atomic_load(rec ? a.val_prev + b : safe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p.x.fstore != nullptr) {
+        fs_slot = p.x.fstore + (a.slot0 + b) * p.x.fs_slot_stride;
+        ld_nvc = __hip_atomic_load(p.x.nvalid_carry + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) {      // the slot starts in the state the previous one ended in: frames[0..3] = frames[T..T+3]
+          const int g16 = (4 * HW) >> 4;
+          for (int q = tid; q < g16; q += NT)
+            reinterpret_cast<u32x4*>(fs_slot)[q] = reinterpret_cast<const u32x4*>(fs_slot + a.T * (long)HW)[q];
+        }
+      }
       // the 3 planes the state shares with its predecessor do not depend on the host: in flight during the wait
       issue_chunk(pf0, it, 0, q0, HW, W, tid);
       issue_chunk(pf1, it, p.row_end[0], q1, HW, W, tid);
@@ -266,6 +279,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW, 0x00020000);
         f8 = __builtin_amdgcn_raw_buffer_load_b128(fr, tid * 16, 0, 1 | 16);   // sc0 sc1
+        // single-frame store: the newest frame of state t is frames[slot][t + 3]
+        if (fs_slot != nullptr && tid * 16 < HW) *reinterpret_cast<u32x4*>(fs_slot + (long)(t + 3) * HW + tid * 16) = f8;
       }
     } else {
       ld_r = *(rec ? a.rew + b : safe);
@@ -488,6 +503,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         a.val_prev[b] = bk_v;
       }
+      if (PERSIST && p.x.nvalid != nullptr) {     // how many planes of this state are real frames (not pre-reset zeros)
+        const int nvs = t == 0 ? ld_nvc : (ld_rst != 0.f ? 1 : min(ld_nvc + 1, 4));
+        if (t < (int)a.T) p.x.nvalid[(a.slot0 + b) * a.T + t] = nvs;
+        p.x.nvalid_carry[b] = nvs;
+      }
       float h[HNT], vboot = 0.f;
 #pragma unroll
       for (int n = 0; n < HNT; ++n) {
@@ -661,6 +681,11 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.seq0 = r->seq0; p.x.env0 = r->env0; p.x.err = r->err; p.x.timeout_ticks = (long)r->timeout_ticks;
   p.x.a1_rows = r->a1_rows; p.x.a2_rows = r->a2_rows;
   p.x.heads_rows = r->heads_rows; p.x.heads_rows_ld = (long)r->heads_rows_ld;
+  p.x.fstore = r->frame_store; p.x.fs_slot_stride = (long)r->frame_store_slot_stride;
+  p.x.nvalid = r->nvalid_rows; p.x.nvalid_carry = r->nvalid_carry;
+  if (r->frame_store && (!r->nvalid_rows || !r->nvalid_carry || r->T < 4 || ((uintptr_t)r->frame_store % 16) ||
+                         r->frame_store_slot_stride % 16 || r->frame_store_slot_stride < (r->T + 4) * (int64_t)r->H * r->W))
+    return A2C_ERR_ARG;
   if (r->heads_rows && r->heads_rows_ld < r->n_actions + 1) return A2C_ERR_ARG;
   if (!step_shapes(a.C, a.H, a.W, a.n_actions, p) || step_lds(p) > 160 * 1024 || !u8_shapes(a.H, a.W)) return A2C_ERR_ARG;
   if (!r->states || !r->bookmark || !r->u || !r->actions || !r->cmd || !r->rec || !r->frames || !r->err) return A2C_ERR_ARG;

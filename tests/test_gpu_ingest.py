@@ -336,3 +336,45 @@ def test_update_from_stashed_rollout_activations_equals_recomputed(kind, ingest,
     # 1e-9 noise on a near-zero gradient into a visible step
     ga, gb = res[True][1], res[False][1]
     close("gradient arena", ga, gb, 2e-6 * float(gb.abs().max()), 1e-5)
+
+
+def test_first_layer_weight_gradient_from_the_single_frame_store():
+    """row f4: the persistent rollout kernel keeps ONE uint8 frame per env-step (T+4 per slot) + the count of real
+    planes per state; update_model's conv1 weight gradient stacks the 4 frames on load.  Three rollout+update rounds
+    (history copy between slots, resets inside and across slots) against the same run reading the fp32 states."""
+    from a2c_amd.runner import Runner
+    from a2c_amd.updater import Updater
+    B, T, A, ss = 5, 6, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=50, done_period=3 + 2 * j) for j in range(B)]
+    hyps = base_hyps(env_type="FakeBreakout", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-5)
+    res = {}
+    for frames in (True, False):
+        net = make_net("A3CModel", ss, A, 256)
+        D = _datas(B * T, ss, False, actions_on_host=False)
+        pool = _pool(U8FakeEnv, ekws, 2)
+        r = Runner(D, dict(hyps, frame_store=frames), None, None, None, env_pool=pool, ingest="zero-copy")
+        upd = Updater(net, hyps)
+        torch.manual_seed(11)
+        out = []
+        try:
+            for k in range(3):
+                r.rollout(net, list(range(B)), hyps)
+                r.finish()
+                assert (net._stash_frames is not None) == frames
+                if frames:     # the store reproduces the fp32 states exactly: stack-on-load == states
+                    F_, nv, _ = net._stash_frames
+                    st = D["states"].reshape(B, T, 4, -1)
+                    for b in range(B):
+                        for t in range(T):
+                            n = int(nv[b * T + t])
+                            want = F_[b, t:t + 4].float()
+                            want[:4 - n] = 0
+                            assert torch.equal(st[b, t], want), (k, b, t, n)
+                upd.update_model(D)
+                out.append(net._arena.train_grads().cpu().clone())
+            res[frames] = out
+        finally:
+            r.close()
+    for k in range(3):
+        ga, gb = res[True][k], res[False][k]
+        close(f"gradient arena, round {k}", ga, gb, 2e-6 * float(gb.abs().max()), 1e-5)

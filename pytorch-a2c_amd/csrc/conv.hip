@@ -1579,6 +1579,223 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
   }
 }
 
+// Pipelined twin of bwd_band_kernel for the fragment sets that fit LDS (every 3x3 layer of the reference models up
+// to 48 KB of fragments).  Same band / class / step structure and the same (class, tap a, tap b, channel quad)
+// summation order, so the results are bit-identical; what changes is where the time went in the PMC profile of the
+// synchronous kernel (12 VALU instructions per MFMA, 46 % of the wave time parked on staging):
+//   * the A fragments of all classes live in LDS for the whole kernel (were: global loads per chunk and pixel pair),
+//   * the tap walk is three nested loops over (a, b, channel quad) with running LDS addresses (was: a per-lane
+//     counter machine of selects per MFMA step),
+//   * the NEXT band's dOut rows are loaded into registers before the matrix phase of the current band, and the
+//     ReLU-derivative mask of the CURRENT band at its start, so neither the staging nor the flush waits on HBM.
+constexpr int PFB2_MAX = 16;         // dOut prefetch slots per thread (VEC floats each): template parameter PFB2 = 8, 12 or 16
+constexpr int PFM2 = 12;             // mask prefetch slots per thread (float4 each)
+struct BwdBand2P {
+  BwdBandP b;
+  int nfrag;                         // floats of the prepared backward fragments (all classes)
+  int mask_pf;                       // 1: the band's mask fits PFM2 float4 per thread and rows are 16-B multiples
+};
+
+template <int MT, int VEC, int PFB2>
+__global__ __launch_bounds__(256) void bwd_band2_kernel(BwdBand2P pp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const BwdBandP& p = pp.b;
+  float* __restrict__ frag = lds;                          // [nfrag]
+  float* __restrict__ outb = lds + pp.nfrag;                // [Cin][TY*W]
+  float* __restrict__ img = outb + p.out_floats;            // [Cout][PLANE]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int WP = p.st.WP, PLANE = p.st.PLANE;
+  const long total = (long)p.B * p.bands;
+  for (int i = tid; i < pp.nfrag; i += 256) frag[i] = p.wfrag[i];
+  stage_zero(p.st, img);
+  // this thread's slots of the dOut band image: (plane c, image row r, VEC floats at column x)
+  const int nv = p.st.IW / VEC;
+  const int tot_v = p.st.Cp * p.st.TIH * nv;
+  int dst[PFB2], srcoff[PFB2], rrow[PFB2];
+#pragma unroll
+  for (int u = 0; u < PFB2; ++u) {
+    const int idx = tid + u * 256;
+    dst[u] = -1; srcoff[u] = 0; rrow[u] = 0;
+    if (idx < tot_v) {
+      const int rt = idx / nv, x = (idx - rt * nv) * VEC;
+      const int c = rt / p.st.TIH, r = rt - c * p.st.TIH;
+      dst[u] = c * PLANE + r * WP + x - p.st.sx0;
+      srcoff[u] = (c * p.st.IH + r) * p.st.IW + x;
+      rrow[u] = r;
+    }
+  }
+  float pf[PFB2][VEC];
+  auto issue = [&](long tile) {
+    const long b = tile / p.bands;
+    const int Y0 = (int)(tile - b * p.bands) * p.TY;
+    const int oy_lo = fdiv(Y0 + p.P - (p.ks - 1), p.S);
+    const float* __restrict__ base = p.st.src + b * p.st.bstride + (long)oy_lo * p.st.IW;
+#pragma unroll
+    for (int u = 0; u < PFB2; ++u) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) pf[u][e] = 0.f;
+      const int ys = oy_lo + rrow[u];
+      if (dst[u] >= 0 && ys >= 0 && ys < p.st.IH) {
+        const float* q = base + srcoff[u];
+        if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(q); pf[u][0] = t.x; pf[u][1] = t.y; pf[u][2] = t.z; pf[u][3] = t.w; }
+        else if (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(q); pf[u][0] = t.x; pf[u][1] = t.y; }
+        else pf[u][0] = q[0];
+      }
+    }
+  };
+  long tile = blockIdx.x;
+  if (tile < total) issue(tile);
+  for (; tile < total; tile += gridDim.x) {
+    const long b = tile / p.bands;
+    const int Y0 = (int)(tile - b * p.bands) * p.TY;
+    const int rowsY = min(p.TY, p.H - Y0);
+    const int oy_lo = fdiv(Y0 + p.P - (p.ks - 1), p.S);
+    __syncthreads();                       // readers of the previous band (image and dX band) are done
+#pragma unroll
+    for (int u = 0; u < PFB2; ++u)
+      if (dst[u] >= 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) img[dst[u] + e] = pf[u][e];
+      }
+    __syncthreads();
+    if (tile + gridDim.x < total) issue(tile + gridDim.x);
+    // the ReLU-derivative mask of THIS band: in flight during the matrix phase, consumed by the flush
+    const int per = rowsY * p.W;
+    float4 mk[PFM2];
+    if (pp.mask_pf && p.mask) {
+      const int per4 = per >> 2, n4 = p.Cin * per4;
+#pragma unroll
+      for (int u = 0; u < PFM2; ++u) {
+        const int i = tid + u * 256;
+        mk[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (i < n4) {
+          const int ch = i / per4, e = (i - ch * per4) << 2;
+          mk[u] = *reinterpret_cast<const float4*>(p.mask + ((b * p.Cin + ch) * (long)p.H + Y0) * p.W + e);
+        }
+      }
+    }
+    for (int c = 0; c < p.ncls; ++c) {
+      const BandClass& k = p.cls[c];
+      int q_lo = (Y0 + p.P - k.ry + p.S - 1) / p.S;
+      if (q_lo < 0) q_lo = 0;
+      const int y_first = p.S * q_lo + k.ry - p.P;
+      const int rows_c = y_first < Y0 + rowsY ? (Y0 + rowsY - 1 - y_first) / p.S + 1 : 0;
+      const int NP = rows_c * k.PWc;
+      const int npairs = (NP + 31) >> 5;
+      const float* __restrict__ fc = frag + k.frag_off + lane;
+      for (int pr = w; pr < npairs; pr += 4) {
+        const int idx0 = pr * 32 + j, idx1 = idx0 + 16;
+        const bool ok0 = idx0 < NP, ok1 = idx1 < NP;
+        const int i0 = ok0 ? idx0 : 0, i1 = ok1 ? idx1 : 0;
+        const int r0 = i0 / k.PWc, c0 = i0 - r0 * k.PWc;
+        const int r1 = i1 / k.PWc, c1 = i1 - r1 * k.PWc;
+        const float* __restrict__ l0 = img + (q_lo + r0 - oy_lo) * WP + (k.p0 + c0 - p.ox_lo) + g * PLANE;
+        const float* __restrict__ l1 = img + (q_lo + r1 - oy_lo) * WP + (k.p0 + c1 - p.ox_lo) + g * PLANE;
+        f32x4 acc[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const float* __restrict__ fa = fc;                 // fragments of step s = (a*nb + b)*c4n + c4: MT*64 floats each
+        for (int ta = 0; ta < k.na; ++ta)
+          for (int tb = 0; tb < k.nb; ++tb) {
+            const float* __restrict__ t0 = l0 - ta * WP - tb;
+            const float* __restrict__ t1 = l1 - ta * WP - tb;
+            for (int c4 = 0; c4 < p.c4n; c4 += 2) {        // two channel quads per trip (c4n is even): 2*(MT+2) LDS reads in flight
+              float av[2][MT], bv0[2], bv1[2];
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[u][m] = fa[((c4 + u) * MT + m) * 64];
+                bv0[u] = t0[(c4 + u) * 4 * PLANE];
+                bv1[u] = t1[(c4 + u) * 4 * PLANE];
+              }
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                  acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], bv0[u], acc[m][0], 0, 0, 0);
+                  acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], bv1[u], acc[m][1], 0, 0, 0);
+                }
+            }
+            fa += p.c4n * MT * 64;
+          }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if (!(nt ? ok1 : ok0)) continue;
+          const int r = nt ? r1 : r0, cc = nt ? c1 : c0;
+          const int yy = y_first + r * p.S - Y0;
+          const int xx = (k.p0 + cc) * p.S + k.rx - p.P;
+          const int pix = yy * p.W + xx;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int ch = m * 16 + 4 * g + rr;
+              if (ch < p.Cin) outb[ch * p.TY * p.W + pix] = acc[m][nt][rr];
+            }
+        }
+      }
+    }
+    __syncthreads();
+    if (pp.mask_pf) {        // rows are 16-B multiples: one float4 per slot, mask already in registers
+      const int per4 = per >> 2, n4 = p.Cin * per4;
+#pragma unroll
+      for (int u = 0; u < PFM2; ++u) {
+        const int i = tid + u * 256;
+        if (i < n4) {
+          const int ch = i / per4, e = (i - ch * per4) << 2;
+          float4 v = *reinterpret_cast<const float4*>(outb + ch * p.TY * p.W + e);
+          if (p.mask) {
+            if (!(mk[u].x > 0.f)) v.x = 0.f;
+            if (!(mk[u].y > 0.f)) v.y = 0.f;
+            if (!(mk[u].z > 0.f)) v.z = 0.f;
+            if (!(mk[u].w > 0.f)) v.w = 0.f;
+          }
+          *reinterpret_cast<float4*>(p.din + ((b * p.Cin + ch) * (long)p.H + Y0) * p.W + e) = v;
+        }
+      }
+    } else {
+      const int vec = (p.W & 3) == 0 ? 4 : (p.W & 1) == 0 ? 2 : 1;
+      for (int ch = w; ch < p.Cin; ch += 4) {
+        const long o0 = ((b * p.Cin + ch) * (long)p.H + Y0) * p.W;
+        const float* __restrict__ sb = outb + ch * p.TY * p.W;
+        if (vec == 4) {
+          for (int e = lane << 2; e < per; e += 256) {
+            float4 v = *reinterpret_cast<const float4*>(sb + e);
+            if (p.mask) {
+              const float4 m4 = *reinterpret_cast<const float4*>(p.mask + o0 + e);
+              if (!(m4.x > 0.f)) v.x = 0.f;
+              if (!(m4.y > 0.f)) v.y = 0.f;
+              if (!(m4.z > 0.f)) v.z = 0.f;
+              if (!(m4.w > 0.f)) v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(p.din + o0 + e) = v;
+          }
+        } else if (vec == 2) {
+          for (int e = lane << 1; e < per; e += 128) {
+            float2 v = *reinterpret_cast<const float2*>(sb + e);
+            if (p.mask) {
+              const float2 m2 = *reinterpret_cast<const float2*>(p.mask + o0 + e);
+              if (!(m2.x > 0.f)) v.x = 0.f;
+              if (!(m2.y > 0.f)) v.y = 0.f;
+            }
+            *reinterpret_cast<float2*>(p.din + o0 + e) = v;
+          }
+        } else {
+          for (int e = lane; e < per; e += 64) {
+            float v = sb[e];
+            if (p.mask && !(p.mask[o0 + e] > 0.f)) v = 0.f;
+            p.din[o0 + e] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // "Row-run" weight-gradient kernel for the unpadded layers (ks = 2*S: 8x8/s4, 4x4/s2), software
 // pipelined like igemm_run_kernel.  kx = kxh*S + kxl: for a fixed (ci, ky, kxh) the S taps kxl are
 // S contiguous floats at column S*(ox + kxh), so ONE ds_read_b128 (b64) per lane yields the B
@@ -2323,6 +2540,33 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
       k.p0 = (P - rx) > 0 ? ceil_div(P - rx, S) : 0;
       k.PWc = (d->W - 1 + P - rx) >= 0 ? (d->W - 1 + P - rx) / S - k.p0 + 1 : 0;
       if (k.PWc < 0) k.PWc = 0;
+    }
+    {  // pipelined band kernel: fragments in LDS, next band's dOut and this band's mask in registers
+      const size_t nfrag = a2c_conv2d_prep_floats(d, 1);
+      const int vecs = q.st.vec;
+      const long tot_v = (long)d->Cout * TIH * (d->OW / vecs);
+      const size_t lds2 = 4 * (nfrag + (size_t)q.out_floats + (size_t)d->Cout * PLANEo + 64);
+      if (!getenv("A2C_NO_BAND2") && nfrag * 4 <= 64 * 1024 && d->OW % vecs == 0 && tot_v <= 256L * PFB2_MAX && MTb == 1 &&
+          c4n % 2 == 0 && lds2 <= LDS_HARD_MAX) {      // MTb > 1 measured slower: fragments + band leave one workgroup per CU
+        BwdBand2P q2;
+        q2.b = q; q2.nfrag = (int)nfrag;
+        q2.mask_pf = (d->W % 4 == 0 && (long)d->Cin * TY * d->W <= 256L * PFM2 * 4) ? 1 : 0;
+        const void* kf2;
+        hipStream_t st2 = a2c_s(stream);
+        const int pfb = tot_v <= 256L * 8 ? 8 : tot_v <= 256L * 12 ? 12 : 16;      // fewest prefetch registers that hold a band
+#define BAND2_CASE(V_, P_)                                                                                               \
+        if (vecs == V_ && pfb == P_) {                                                                                    \
+          kf2 = (const void*)bwd_band2_kernel<1, V_, P_>;                                                                 \
+          if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(kf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);    \
+          const int grid2 = resident_grid(kf2, lds2, (long)B * q.bands);                                                  \
+          hipLaunchKernelGGL((bwd_band2_kernel<1, V_, P_>), dim3(grid2), dim3(256), lds2, st2, q2);                        \
+          A2C_CHECK_LAUNCH();                                                                                             \
+          return A2C_OK;                                                                                                  \
+        }
+        BAND2_CASE(1, 8) BAND2_CASE(1, 12) BAND2_CASE(1, 16) BAND2_CASE(2, 8) BAND2_CASE(2, 12) BAND2_CASE(2, 16)
+        BAND2_CASE(4, 8) BAND2_CASE(4, 12) BAND2_CASE(4, 16)
+#undef BAND2_CASE
+      }
     }
     const size_t lds = 4 * ((size_t)q.out_floats + (size_t)d->Cout * PLANEo + 64);
     if (lds <= LDS_HARD_MAX && MTb <= 4) {

@@ -1006,8 +1006,16 @@ struct WgradP {
   int dvec;                       // dOut rows are 16 B aligned float4 streams
 };
 
-template <int MT, int KTW>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
+// RS ("row split"): every wave owns ALL KTW = nkt k-tiles and the tile's pixel rows are dealt round-robin
+// to the four waves (one A read feeds KTW MFMAs per 16 channels, no idle wave when nkt % 4 != 0); the
+// per-wave partial sums are added in wave order through LDS once, at the end of the launch.
+// NI > 0 ("prefetch"): the NEXT tile's input rows (NI float4 per thread) and dOut rows (ND float2 per
+// thread) are loaded into registers while the MFMA phase of the current tile runs, so a workgroup hides
+// its own HBM latency; each thread's (plane, row, vector) slots are tile-invariant and decoded once.
+template <int MT, int KTW, bool RS = false, int NI = 0, int ND = 0, bool EX = false>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
+  constexpr bool PF = NI > 0;
+  constexpr bool BR = PF && MT * KTW < 18;      // bias gradient summed from the prefetch registers (when they are to spare)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int kk = lane >> 4, j = lane & 15;
@@ -1021,7 +1029,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
   int koff[KTW];
 #pragma unroll
   for (int q = 0; q < KTW; ++q) {
-    const int k = (w + 4 * q) * 16 + j;
+    const int k = (RS ? q : w + 4 * q) * 16 + j;
     int o = 0;
     if (k < p.K) {
       const int ci = k / (p.ks * p.ks), rem = k - ci * p.ks * p.ks;
@@ -1043,12 +1051,76 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
 
   const long total = (long)p.B * p.tiles;
   const int c4n = p.OWp >> 2;
+  // prefetch slots: (plane << 16) | (row << 8) | vector, -1 = none
+  int di[PF ? NI : 1], dd[PF ? ND : 1];
+  float4 vi[PF ? NI : 1];
+  float2 vd[PF ? ND : 1];
+  float dbs[BR ? ND : 1];         // bias gradient: this thread's dOut slots, summed over its tiles
+#pragma unroll
+  for (int u = 0; u < (BR ? ND : 1); ++u) dbs[u] = 0.f;
+  if (PF) {
+    const int nv = p.st.IW >> 2, nvd = p.OW >> 1;
+    const int toti = p.st.Cp * p.st.TIH * nv, totd = p.Cout * p.TPH * nvd;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int idx = threadIdx.x + u * 256;
+      const int rt = idx / nv, c = rt / p.st.TIH;
+      di[u] = idx < toti ? (c << 16) | ((rt - c * p.st.TIH) << 8) | (idx - rt * nv) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int idx = threadIdx.x + u * 256;
+      const int rt = idx / nvd, co = rt / p.TPH;
+      dd[u] = idx < totd ? (co << 16) | ((rt - co * p.TPH) << 8) | (idx - rt * nvd) : -1;
+    }
+  }
+  auto issue = [&](long tile) {
+    const long b = tile / p.tiles;
+    const int q0 = (int)(tile - b * p.tiles) * p.TPH;
+    const int rows = min(p.TPH, p.OH - q0), y_lo = q0 * p.S + p.sy0;
+    const float* __restrict__ base = p.st.src + b * p.st.bstride;
+    const float* __restrict__ dsrc = p.dout + (b * p.Cout * p.OH + q0) * (long)p.OW;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      vi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ys = y_lo + ((di[u] >> 8) & 255);
+      if (di[u] >= 0 && ys >= 0 && ys < p.st.IH)
+        vi[u] = *reinterpret_cast<const float4*>(base + ((long)(di[u] >> 16) * p.st.IH + ys) * p.st.IW + ((di[u] & 255) << 2));
+    }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      vd[u] = make_float2(0.f, 0.f);
+      const int r = (dd[u] >> 8) & 255;
+      if (dd[u] >= 0 && r < rows)
+        vd[u] = *reinterpret_cast<const float2*>(dsrc + ((long)(dd[u] >> 16) * p.OH + r) * p.OW + ((dd[u] & 255) << 1));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NI; ++u)
+      if (di[u] >= 0) {
+        float* d = lds + (di[u] >> 16) * PLANE + ((di[u] >> 8) & 255) * WP + ((di[u] & 255) << 2) - p.st.sx0;
+        d[0] = vi[u].x; d[1] = vi[u].y; d[2] = vi[u].z; d[3] = vi[u].w;
+      }
+#pragma unroll
+    for (int u = 0; u < ND; ++u)
+      if (dd[u] >= 0) {
+        *reinterpret_cast<float2*>(ldo + (dd[u] >> 16) * p.PLANEo + ((dd[u] >> 8) & 255) * p.OWp + ((dd[u] & 255) << 1)) = vd[u];
+        if (BR) dbs[u] += vd[u].x + vd[u].y;
+      }
+  };
+  if (PF && blockIdx.x < total) issue(blockIdx.x);
   for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
     const long b = tile / p.tiles;
     const int ti = (int)(tile - b * p.tiles);
     const int q0 = ti * p.TPH;
     const int rows = min(p.TPH, p.OH - q0);
     __syncthreads();
+    if (PF) {
+      commit();
+      __syncthreads();
+      if (tile + gridDim.x < total) issue(tile + gridDim.x);
+    } else {
     stage_tile(p.st, lds, b, q0 * p.S + p.sy0);
     {  // dOut rows q0..q0+rows of every channel (a contiguous run per channel) -> ldo[co][r*OWp + c];
        // pad columns stay 0.  Flattened over all threads, 8 independent loads in flight each.
@@ -1120,35 +1192,85 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
       }
     }
     __syncthreads();
+    }
     // bias partial sums over this tile
-    if (bpart < nparts && bco < p.Cout) {
+    if (!BR && bpart < nparts && bco < p.Cout) {
       const float* pl = ldo + bco * p.PLANEo;
       const int n = rows * p.OWp;
-      float s = 0.f;
-      for (int i = bpart; i < n; i += nparts) s += pl[i];
-      dbacc += s;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four reads in flight
+      int i = bpart;
+      for (; i + 3 * nparts < n; i += 4 * nparts) { s0 += pl[i]; s1 += pl[i + nparts]; s2 += pl[i + 2 * nparts]; s3 += pl[i + 3 * nparts]; }
+      for (; i < n; i += nparts) s0 += pl[i];
+      dbacc += (s0 + s1) + (s2 + s3);
     }
     // implicit GEMM over the tile's pixels, 4 pixels per MFMA step
-    for (int r = 0; r < rows; ++r) {
-      const int arow = r * p.OWp + kk;
-      const int brow = r * p.S * WP;
-      for (int c4 = 0; c4 < c4n; ++c4) {
-        float a[MT];
+    // RS: the tile's rows*c4n steps in four contiguous runs, one per wave.  EX: every instantiated
+    // k-tile is real (or its wave would only idle), so the step is one branch-free block and the next
+    // step's operands are read from LDS while this step's MFMAs run.
+    {
+      const int nsteps = rows * c4n;
+      const int s0 = RS ? (nsteps * w) >> 2 : 0, s1 = RS ? (nsteps * (w + 1)) >> 2 : nsteps;
+      int r = s0 / c4n, c4 = s0 - r * c4n;
+      float a[MT], bv[KTW];
+      if (s0 < s1) {
+        const int ao = r * p.OWp + kk + 4 * c4, bo = r * p.S * WP + 4 * c4 * p.S;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = ldo[(m * 16 + j) * p.PLANEo + arow + 4 * c4];
+        for (int m = 0; m < MT; ++m) a[m] = ldo[(m * 16 + j) * p.PLANEo + ao];
 #pragma unroll
-        for (int q = 0; q < KTW; ++q) {
-          if (w + 4 * q < p.nkt) {   // wave-uniform
-            const float bv = lds[koff[q] + brow + 4 * c4 * p.S];
+        for (int q = 0; q < KTW; ++q) bv[q] = lds[koff[q] + bo];
+      }
+      for (int s = s0; s < s1; ++s) {
+        if (++c4 == c4n) { c4 = 0; ++r; }
+        const bool more = s + 1 < s1;                       // last step: re-read valid operands
+        const int rn = more ? r : 0, cn = more ? c4 : 0;
+        const int ao = rn * p.OWp + kk + 4 * cn, bo = rn * p.S * WP + 4 * cn * p.S;
+        float an[MT], bn[KTW];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][q], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) an[m] = ldo[(m * 16 + j) * p.PLANEo + ao];
+#pragma unroll
+        for (int q = 0; q < KTW; ++q) bn[q] = lds[koff[q] + bo];
+        if (EX) __builtin_amdgcn_sched_barrier(0);          // keep the reads ahead of the MFMAs
+#pragma unroll
+        for (int q = 0; q < KTW; ++q)
+          if (EX || (RS ? q : w + 4 * q) < p.nkt) {        // wave-uniform
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[q], acc[m][q], 0, 0, 0);
           }
-        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = an[m];
+#pragma unroll
+        for (int q = 0; q < KTW; ++q) bv[q] = bn[q];
       }
     }
   }
   // write this workgroup's partials: D row (co) = 4*(lane>>4)+reg, col (k) = lane&15
   float* sl = p.slab + (long)blockIdx.x * ((long)p.Cout * p.K + p.Cout);
+  if (RS) {
+    float4* red4 = reinterpret_cast<float4*>(lds);    // [4 waves][KTW][64 lanes], one 16-channel block at a time
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < KTW; ++q)
+        red4[(w * KTW + q) * 64 + lane] = make_float4(acc[m][q][0], acc[m][q][1], acc[m][q][2], acc[m][q][3]);
+      __syncthreads();
+      for (int e = threadIdx.x; e < KTW * 64; e += 256) {
+        float4 s = red4[e];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+          const float4 t = red4[ww * KTW * 64 + e];
+          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const int k = (e >> 6) * 16 + (e & 15), co = m * 16 + 4 * ((e & 63) >> 4);
+        if (k < p.K) {
+          if (co < p.Cout) sl[(long)co * p.K + k] = s.x;
+          if (co + 1 < p.Cout) sl[(long)(co + 1) * p.K + k] = s.y;
+          if (co + 2 < p.Cout) sl[(long)(co + 2) * p.K + k] = s.z;
+          if (co + 3 < p.Cout) sl[(long)(co + 3) * p.K + k] = s.w;
+        }
+      }
+    }
+  } else
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1164,6 +1286,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
     }
   __syncthreads();
   float* red = lds;   // reuse: [nparts][Cm]
+  if (BR) {           // slot index = channel-major: a channel's partial sums are one contiguous run
+#pragma unroll
+    for (int u = 0; u < ND; ++u) red[threadIdx.x + u * 256] = dbs[u];
+    __syncthreads();
+    if (threadIdx.x < p.Cout) {
+      const int per = p.TPH * (p.OW >> 1);
+      float s = 0.f;
+      for (int i = 0; i < per; ++i) s += red[threadIdx.x * per + i];
+      sl[(long)p.Cout * p.K + threadIdx.x] = s;
+    }
+    return;
+  }
   if (bpart < nparts) red[bpart * Cm + bco] = dbacc;
   __syncthreads();
   if (threadIdx.x < p.Cout) {
@@ -1913,9 +2047,11 @@ __global__ __launch_bounds__(256) void wgrad_run_kernel(WrunP p) {
     if (bpart < nparts && bco < p.Cout) {          // bias partial sums over this tile
       const float* pl = ldo + bco * p.PLANEo;
       const int n = rows * p.OWp;
-      float s = 0.f;
-      for (int i = bpart; i < n; i += nparts) s += pl[i];
-      dbacc += s;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four reads in flight
+      int i = bpart;
+      for (; i + 3 * nparts < n; i += 4 * nparts) { s0 += pl[i]; s1 += pl[i + nparts]; s2 += pl[i + 2 * nparts]; s3 += pl[i + 3 * nparts]; }
+      for (; i < n; i += nparts) s0 += pl[i];
+      dbacc += (s0 + s1) + (s2 + s3);
     }
     for (int r = 0; r < rows; ++r) {
       const float* __restrict__ arow = ldo + j * p.PLANEo + r * p.OWp + kk;
@@ -2193,7 +2329,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-struct WgradPlan { SrcTile t; int OWp, PLANEo, MT, KTW, grid, run; size_t lds; };
+struct WgradPlan { SrcTile t; int OWp, PLANEo, MT, KTW, grid, run, rs, pf, ex; size_t lds; };
+
+// prefetching instantiations: <MT, KTW, RS, NI, ND>
+#define WGRAD_PF_A 1, 3, true, 4, 16, true
+#define WGRAD_PF_B 2, 9, true, 8, 8, true
+#define WGRAD_PF_C 2, 4, false, 12, 8, true
+#define WGRAD_VARIANTS(X)                                                                                      \
+  if (pl.pf && pl.KTW == 3) { X(WGRAD_PF_A); }                                                                 \
+  else if (pl.pf && pl.KTW == 9) { X(WGRAD_PF_B); }                                                            \
+  else if (pl.pf) { X(WGRAD_PF_C); }                                                                           \
+  else if (pl.rs && pl.KTW == 3) { X(1, 3, true, 0, 0, true); }                                                \
+  else if (pl.rs) { X(2, 9, true, 0, 0, true); }                                                               \
+  else if (pl.MT == 1 && pl.KTW == 1) { X(1, 1, false, 0, 0, true); }                                         \
+  else if (pl.MT == 1 && pl.KTW == 4) { X(1, 4); }                                                            \
+  else if (pl.MT == 2 && pl.KTW == 4 && pl.ex) { X(2, 4, false, 0, 0, true); }                                \
+  else if (pl.MT == 2 && pl.KTW == 4) { X(2, 4); }                                                            \
+  else if (pl.KTW == 5) { X(4, 5, false, 0, 0, true); }                                                       \
+  else if (pl.ex) { X(4, 7, false, 0, 0, true); }                                                              \
+  else { X(4, 7); }
+
+static const void* wgrad_fn(const WgradPlan& pl) {
+#define WGRAD_FN(...) return (const void*)wgrad_kernel<__VA_ARGS__>
+  WGRAD_VARIANTS(WGRAD_FN)
+#undef WGRAD_FN
+}
 
 // which wgrad_run_kernel instantiation (if any) fits the layer: 1 = <1,4,1,5>, 2 = <2,2,2,3>
 static int wgrad_run_variant(const a2c_conv_desc* d) {
@@ -2241,30 +2401,55 @@ static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl, bool allow_
   const int mt = ceil_div(d->Cout, 16);
   const int nkt = ceil_div(d->Cin * d->ks * d->ks, 16);
   const int ktw = ceil_div(nkt, 4);
-  if (mt == 1 && ktw <= 1) { pl.MT = 1; pl.KTW = 1; }
+  pl.rs = 0;
+  const bool rs_ok = !getenv("A2C_NO_WGRAD_RS");
+  if (rs_ok && mt == 1 && nkt == 3) { pl.MT = 1; pl.KTW = 3; pl.rs = 1; }          // exact: every k-tile is real
+  else if (rs_ok && mt == 2 && nkt == 9) { pl.MT = 2; pl.KTW = 9; pl.rs = 1; }
+  else if (mt == 1 && ktw <= 1) { pl.MT = 1; pl.KTW = 1; }
   else if (mt == 1 && ktw <= 4) { pl.MT = 1; pl.KTW = 4; }
   else if (mt <= 2 && ktw <= 4) { pl.MT = 2; pl.KTW = 4; }
+  else if (mt <= 4 && ktw == 5) { pl.MT = 4; pl.KTW = 5; }
   else if (mt <= 4 && ktw <= 7) { pl.MT = 4; pl.KTW = 7; }
   else return false;
+  pl.ex = (ktw == pl.KTW) ? 1 : 0;
   // dOut tile floats per pixel row: MT*16 planes * OWp (+ plane padding, fixed)
   plan_src(t, pl.MT * 16 * pl.OWp, pl.MT * 16 * 34, WGRAD_LDS_BUDGET);
+  pl.pf = 0;
+  if (allow_run && !getenv("A2C_NO_WGRAD_PF") && d->W % 4 == 0 && d->OW % 2 == 0) {
+    const int ni = (pl.rs && pl.KTW == 3) ? 4 : (pl.rs && pl.KTW == 9) ? 8 : (!pl.rs && pl.MT == 2 && pl.KTW == 4 && pl.ex) ? 12 : 0;
+    const int nd = (pl.rs && pl.KTW == 3) ? 16 : 8;
+    const long budget = env_kb("A2C_WGRAD_PF_LDS_KB", 64);
+    int tph = 0;
+    for (int c = 1; c <= d->OH && ni; ++c) {      // largest band whose loads fit the prefetch registers
+      const int tih = (c - 1) * d->stride + d->ks;
+      const long plane = ((tih * t.WP + 31) / 32) * 32 + 16, planeo = ((c * pl.OWp + 31) / 32) * 32 + 2;
+      if ((long)d->Cin * tih * (d->W / 4) <= 256L * ni && (long)d->Cout * c * (d->OW / 2) <= 256L * nd && tih < 256 &&
+          4 * (d->Cin * plane + pl.MT * 16 * planeo + 64) <= budget) tph = c; else break;
+    }
+    if (tph) {
+      pl.pf = 1;
+      t.TPH = tph; t.TIH = (tph - 1) * d->stride + d->ks;
+      t.PLANE = ((t.TIH * t.WP + 31) / 32) * 32 + 16;
+      t.tiles = ceil_div(t.PH, t.TPH);
+    }
+  }
   pl.PLANEo = ((t.TPH * pl.OWp + 31) / 32) * 32 + 2;
   pl.lds = 4 * ((size_t)t.Cp * t.PLANE + (size_t)pl.MT * 16 * pl.PLANEo + 64);
+  if (pl.rs && pl.lds < (size_t)pl.KTW * 4096) pl.lds = (size_t)pl.KTW * 4096;   // cross-wave reduction scratch
+  if (pl.pf && pl.lds < 256 * 16 * 4) pl.lds = 256 * 16 * 4;                      // bias partials, one per dOut slot
   if (pl.lds > LDS_HARD_MAX) return false;
   const long total = (long)B * t.tiles;
-  const void* k = (pl.MT == 1 && pl.KTW == 1) ? (const void*)wgrad_kernel<1, 1>
-                  : (pl.MT == 1 && pl.KTW == 4) ? (const void*)wgrad_kernel<1, 4>
-                  : (pl.MT == 2 && pl.KTW == 4) ? (const void*)wgrad_kernel<2, 4> : (const void*)wgrad_kernel<4, 7>;
+  const void* k = wgrad_fn(pl);
   if (pl.lds > 64 * 1024) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
   pl.grid = resident_grid(k, pl.lds, total);
   return true;
 }
 
-template <int MT, int KTW>
+template <int MT, int KTW, bool RS = false, int NI = 0, int ND = 0, bool EX = false>
 static void launch_wgrad_t(const WgradP& p, int grid, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<MT, KTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((wgrad_kernel<MT, KTW>), dim3(grid), dim3(256), lds, st, p);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<MT, KTW, RS, NI, ND, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((wgrad_kernel<MT, KTW, RS, NI, ND, EX>), dim3(grid), dim3(256), lds, st, p);
 }
 }  // namespace
 
@@ -2656,7 +2841,7 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
                           float* db, int B, void* ws, size_t ws_bytes, a2c_stream_t stream) {
   WgradPlan pl;
   if (!desc_ok(d) || B < 1 || !in || !dout || !dW) return A2C_ERR_ARG;
-  const bool aligned = (in_bstride % 4 == 0) && ((uintptr_t)in % 16 == 0);
+  const bool aligned = (in_bstride % 4 == 0) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)dout % 8 == 0);
   if (!plan_wgrad(d, B, pl, aligned)) return A2C_ERR_ARG;
   if (!ws || ws_bytes < a2c_conv2d_bwd_weight_ws_bytes(d, B)) return A2C_ERR_WORKSPACE;
   hipStream_t st = a2c_s(stream);
@@ -2705,10 +2890,9 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
   p.S = d->stride; p.sy0 = pl.t.sy0; p.TPH = pl.t.TPH; p.tiles = pl.t.tiles; p.B = B;
   p.PLANEo = pl.PLANEo; p.nkt = ceil_div(p.K, 16);
   p.dvec = ((d->OW % 4 == 0) && ((uintptr_t)dout % 16 == 0)) ? 4 : ((d->OW % 2 == 0) && ((uintptr_t)dout % 8 == 0)) ? 2 : 0;
-  if (pl.MT == 1 && pl.KTW == 1) launch_wgrad_t<1, 1>(p, pl.grid, pl.lds, st);
-  else if (pl.MT == 1 && pl.KTW == 4) launch_wgrad_t<1, 4>(p, pl.grid, pl.lds, st);
-  else if (pl.MT == 2 && pl.KTW == 4) launch_wgrad_t<2, 4>(p, pl.grid, pl.lds, st);
-  else launch_wgrad_t<4, 7>(p, pl.grid, pl.lds, st);
+#define WGRAD_LAUNCH(...) launch_wgrad_t<__VA_ARGS__>(p, pl.grid, pl.lds, st)
+  WGRAD_VARIANTS(WGRAD_LAUNCH)
+#undef WGRAD_LAUNCH
   A2C_CHECK_LAUNCH();
   const long nW = (long)p.Cout * p.K, per = nW + p.Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(per, 256)), dim3(256), 0, st, (const float*)ws, pl.grid, per,

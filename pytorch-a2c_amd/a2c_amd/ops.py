@@ -5,6 +5,7 @@ layout, and enqueues the HIP kernels on torch's current stream.  Nothing here co
 on the CPU: a non-CUDA tensor raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -319,6 +320,7 @@ def loss_fwd_bwd(logits, vals, actions, advs, returns, adv_sums, n_global, pi_co
 
 # ---------------------------------------------------------------- dense
 def pick_splitk(M, N, K, target_wgs=512, min_k=32):
+    min_k = int(os.environ.get("A2C_SPLITK_MIN_K", min_k))
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= target_wgs // 2:
         return 1

@@ -229,6 +229,88 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Skinny-M streaming variant for the rollout batch (M = n_envs <= 64) against a LARGE k-contiguous weight matrix
+// (ConvModel: 32 x 28224 times 2000 x 28224, 226 MB of weights per step): the block-tiled kernel above moves the
+// weights through LDS 16 k-columns (64 B per row) at a time behind two barriers per step and runs at ~2.2 TB/s.
+// Here nothing goes through LDS and nothing synchronises: a wave owns 32 weight rows and one k-split; lane
+// (i = l & 31, h = l >> 5) loads 16 B of ITS row at k + 4h (weights) and of activation row i (L2 resident), and
+// register j of both quads is one v_mfma_f32_32x32x2_f32 (the k-pair {k + j, k + 4 + j} is the same on both
+// operands, which is all the instruction needs).  A row is read as one forward stream of 32 B pieces, SK_U loads
+// in flight per lane.  Partials go to the split-K slabs; splitk_reduce_kernel applies the epilogue as before.
+constexpr int SK_U = 4;
+template <int MB>
+__global__ __launch_bounds__(256) void skinny_stream_kernel(long M, long N, long K, const float* __restrict__ X, long ldx,
+                                                            const float* __restrict__ W, long ldw, long k_per_split,
+                                                            float* __restrict__ slab) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const long n0 = ((long)blockIdx.x * 4 + w) * 32;
+  if (n0 >= N) return;
+  const long kbeg = (long)blockIdx.y * k_per_split, kend = min(K, kbeg + k_per_split);
+  const float* __restrict__ wrow = W + min(n0 + li, N - 1) * ldw + 4 * lk;
+  const float* __restrict__ xrow[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) xrow[b] = X + min((long)b * 32 + li, M - 1) * ldx + 4 * lk;
+  f32x16 acc[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  long k = kbeg;
+  for (; k + 8 * SK_U <= kend; k += 8 * SK_U) {
+    float4 wv[SK_U], xv[MB][SK_U];
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) {
+      wv[u] = *reinterpret_cast<const float4*>(wrow + k + 8 * u);
+#pragma unroll
+      for (int b = 0; b < MB; ++b) xv[b][u] = *reinterpret_cast<const float4*>(xrow[b] + k + 8 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u)
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[b][u].x, wv[u].x, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[b][u].y, wv[u].y, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[b][u].z, wv[u].z, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[b][u].w, wv[u].w, acc[b], 0, 0, 0);
+      }
+  }
+  for (; k < kend; k += 8) {          // K % 8 == 0 and splits start at multiples of 8
+    const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      const float4 xv = *reinterpret_cast<const float4*>(xrow[b] + k);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.x, wv.x, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.y, wv.y, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.z, wv.z, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.w, wv.w, acc[b], 0, 0, 0);
+    }
+  }
+  // D map of the 32x32 tile: col (n) = lane & 31, row (m) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float* __restrict__ out = slab + (long)blockIdx.y * M * N;
+  const long n = n0 + li;
+  if (n < N) {
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = (long)b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m < M) out[m * N + n] = acc[b][r];
+      }
+  }
+}
+
+// the skinny streaming kernel writes the same [split][M][N] slabs as gemm_kernel; true = launched
+static bool launch_skinny_stream(long M, long N, long K, const float* A, long lda, const float* B, long ldb, long kps,
+                                 int splits, float* slab, int vecA, int vecB, hipStream_t st) {
+  if (M > 64 || splits < 2 || !vecA || !vecB || K % 8 || kps % 8 || N * K < (1L << 22) || getenv("A2C_NO_SKINNY_STREAM"))
+    return false;
+  dim3 grid((unsigned)((N + 127) / 128), (unsigned)splits);
+  if (M <= 32) hipLaunchKernelGGL(skinny_stream_kernel<1>, grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
+  else hipLaunchKernelGGL(skinny_stream_kernel<2>, grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
+  return true;
+}
+
 // out[n] = sum_m x[m*ld+n]: stage 1 = per-workgroup partial column sums over a row band,
 // stage 2 = fixed-order sum of the partials.
 constexpr int CS_BANDS = 256;
@@ -613,7 +695,8 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)splitk);
   hipStream_t st = a2c_s(stream);
   const bool a_kc = (transA == 0), b_kc = (transB != 0);
-  if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
+  if (a_kc && b_kc && launch_skinny_stream(M, N, K, A, lda, B, ldb, kps, splitk, slab, vecA, vecB, st)) {}
+  else if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
   else if (a_kc && !b_kc) launch_gemm<true, false>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
   else if (!a_kc && b_kc) launch_gemm<false, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
   else launch_gemm<false, false>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
@@ -649,7 +732,8 @@ int a2c_gemm_f32_partial(int transA, int transB, int64_t M, int64_t N, int64_t K
   hipStream_t st = a2c_s(stream);
   float* slab = (float*)ws;
   const bool a_kc = (transA == 0), b_kc = (transB != 0);
-  if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
+  if (a_kc && b_kc && launch_skinny_stream(M, N, K, A, lda, B, ldb, kps, splits, slab, vecA, vecB, st)) {}
+  else if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
   else if (a_kc && !b_kc) launch_gemm<true, false>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
   else if (!a_kc && b_kc) launch_gemm<false, true>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
   else launch_gemm<false, false>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);

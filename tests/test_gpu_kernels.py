@@ -2,6 +2,8 @@
 the CPU oracle / the same torch CPU operator the reference calls, on seeded inputs.
 Tolerances: bit-exact for the scans, sampler and integer outputs; 1e-5 (fp32, the north-star
 tolerance) for dense arithmetic, scaled by the magnitude of the accumulated terms."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -306,6 +308,30 @@ def test_gemm_f32(tA, tB, M, N, K):
                  relu=True, mask_ptr=mask.data_ptr(), ldmask=N, accumulate=True, splitk=sk, ws=ws)
         ref = torch.relu(C0.cpu().double() + want + bias.cpu().double()) * (mask.cpu() > 0)
         close(f"epilogue sk={sk}", Cx, ref, 5 * scale, 1e-5)
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(32, 2000, 28224, 32), (8, 1030, 4104, 5), (33, 1500, 4096, 7), (64, 2048, 2048, 2)])
+def test_gemm_skinny_stream(M, N, K, sk):
+    """rollout-batch rows against a large k-contiguous weight matrix (ConvModel proj_matrx at n_envs = 32,
+    models.py:246-264): the LDS-free streaming split-K kernel, ragged M / N and a short last split"""
+    ops = _ops()
+    A, B = rnd((M, K), 90), rnd((N, K), 91)
+    want = _gemm_ref(A, B, 0, 1)
+    scale = 1e-6 * K ** 0.5 + 1e-7
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    bias = rnd((N,), 92).to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ws = torch.empty(max(1, ops.gemm_ws_bytes(M, N, sk) // 4), device=DEV)
+    ops.gemm(0, 1, M, N, K, Ad.data_ptr(), K, Bd.data_ptr(), K, C.data_ptr(), N, bias=bias, relu=True, splitk=sk, ws=ws)
+    close("stream", C, torch.relu(want + bias.cpu().double()), 5 * scale, 1e-5)
+    # the block-tiled kernel on the same call (A2C_NO_SKINNY_STREAM): same result up to summation order
+    os.environ["A2C_NO_SKINNY_STREAM"] = "1"
+    try:
+        C2 = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(0, 1, M, N, K, Ad.data_ptr(), K, Bd.data_ptr(), K, C2.data_ptr(), N, bias=bias, relu=True, splitk=sk, ws=ws)
+    finally:
+        del os.environ["A2C_NO_SKINNY_STREAM"]
+    close("tiled", C2, torch.relu(want + bias.cpu().double()), 5 * scale, 1e-5)
 
 
 def test_gemm_skinny_head_paths():

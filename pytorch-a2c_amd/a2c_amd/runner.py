@@ -482,7 +482,14 @@ class Runner:
             if graphs is None:
                 self._segment(k, ctx)
             else:
-                if graphs[k] is None:
+                if graphs[k] is None:          # first visit: eager (the conv tile tuners measure on eager calls only)
+                    graphs[k] = "warm"
+                    self._segment(k, ctx)
+                    if k < T:
+                        torch.cuda.current_stream().synchronize()
+                        self._host_env_step(pool, env0, B, k, slot0, T, shift, acts_host_out, pong)
+                    continue
+                if graphs[k] == "warm":
                     try:
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, capture_error_mode="thread_local"):

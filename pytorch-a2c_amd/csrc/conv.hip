@@ -31,6 +31,10 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int MAX_TAPS = 64;
+struct BandKey {         // (layer, batch, flags) key of the tile-size tuners' caches
+  int v[9];
+  bool operator<(const BandKey& o) const { return std::lexicographical_compare(v, v + 9, o.v, o.v + 9); }
+};
 static int env_kb(const char* name, int dflt_kb) {
   const char* v = getenv(name);
   const int kb = v ? atoi(v) : 0;
@@ -2488,16 +2492,17 @@ int a2c_conv2d_prep_weights(const a2c_conv_desc* d, int kind, const float* weigh
   return A2C_OK;
 }
 
-int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* wprep_fwd,
-                   const float* bias, int relu, float* out, int64_t out_bstride, int B, a2c_stream_t stream) {
-  if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
-  if (B == 0) return A2C_OK;
-  if (!in || !wprep_fwd || !out) return A2C_ERR_ARG;
+}  // extern "C"
+namespace {
+// fwd_kb > 0 replaces the LDS budget (KB) that sizes the forward tiles of the tiled kernels (the tuner below)
+static int conv_fwd_impl(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* wprep_fwd,
+                         const float* bias, int relu, float* out, int64_t out_bstride, int B, int fwd_kb,
+                         a2c_stream_t stream) {
   SrcTile t;
   t.Cp = d->Cin; t.IH = d->H; t.IW = d->W; t.SY = d->stride; t.SX = d->stride;
   t.sy0 = -d->pad; t.sx0 = -d->pad; t.span_y = d->ks; t.span_x = d->ks; t.PH = d->OH; t.PW = d->OW;
   const bool staged_out = !getenv("A2C_NO_OUT_STAGE");
-  plan_src(t, staged_out ? d->Cout * d->OW : 0, 16, IGEMM_LDS_BUDGET);
+  plan_src(t, staged_out ? d->Cout * d->OW : 0, 16, fwd_kb > 0 ? fwd_kb * 1024 : IGEMM_LDS_BUDGET);
   IgemmP p;
   fill_stage(p.st, t, in, in_bstride);
   p.out_stage = 0; p.out_vec = 0;
@@ -2588,7 +2593,7 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   if (run3 && in_bstride % 4 == 0 && ((uintptr_t)in % 16 == 0) && !getenv("A2C_NO_PF") && !getenv("A2C_NO_RUN3")) {
     const int S = d->stride;
     const bool ovec = (d->OW % 4 == 0) && (out_bstride % 4 == 0) && (((long)d->OH * d->OW) % 4 == 0) && ((uintptr_t)out % 16 == 0);
-    const long budget = (long)env_kb("A2C_RUN3_LDS_KB", 80);
+    const long budget = fwd_kb > 0 ? fwd_kb * 1024L : (long)env_kb("A2C_RUN3_LDS_KB", 80);
     int tph = 0, plane_best = 0;
     double best = -1.0;
     for (int c = 1; c <= d->OH; ++c) {
@@ -2638,6 +2643,57 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   }
   p.step_a = t.WP; p.step_c = 4 * t.PLANE;
   return launch_igemm(p, MT, a2c_s(stream));
+}
+
+// Forward tile height by measurement, like bwd_band_tuned: the tile size changes neither the taps nor their order
+// for any output element, so every candidate gives bit-identical results.  At rollout batch sizes (a few hundred
+// tiles for 256 CUs) the best height is a trade of tiles per CU against the per-workgroup prologue that no rule
+// predicted (measured 1.2-1.5x between budgets on the 24- and 32-channel layers at n_envs = 32).
+static int conv_fwd_tuned(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* wprep_fwd,
+                          const float* bias, int relu, float* out, int64_t out_bstride, int B, a2c_stream_t stream) {
+  static std::mutex mu;
+  static std::map<BandKey, int> cache;
+  const long work = (long)B * d->Cout * d->OH * d->OW;
+  if (getenv("A2C_NO_TUNE") || getenv("A2C_IGEMM_LDS_KB") || getenv("A2C_RUN3_LDS_KB") || work < (1L << 16))
+    return conv_fwd_impl(d, in, in_bstride, wprep_fwd, bias, relu, out, out_bstride, B, 0, stream);
+  const BandKey key = {{d->Cin, d->H, d->W, d->Cout, d->ks, d->stride, d->pad, B, (int)(in_bstride % 4 == 0) | ((int)(out_bstride % 4 == 0) << 1)}};
+  hipStream_t st = a2c_s(stream);
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return conv_fwd_impl(d, in, in_bstride, wprep_fwd, bias, relu, out, out_bstride, B, it->second, stream);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+    return conv_fwd_impl(d, in, in_bstride, wprep_fwd, bias, relu, out, out_bstride, B, 0, stream);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return A2C_ERR_LAUNCH;
+  static const int cand[] = {0, 24, 32, 48, 64, 96, 128};
+  const int reps = work < (1L << 22) ? 4 : 1;
+  int best = 0;
+  float best_ms = -1.f;
+  for (int c : cand) {
+    if (conv_fwd_impl(d, in, in_bstride, wprep_fwd, bias, relu, out, out_bstride, B, c, stream) != A2C_OK) { (void)hipGetLastError(); continue; }
+    (void)hipEventRecord(e0, st);
+    int rc = A2C_OK;
+    for (int r = 0; r < reps && rc == A2C_OK; ++r) rc = conv_fwd_impl(d, in, in_bstride, wprep_fwd, bias, relu, out, out_bstride, B, c, stream);
+    (void)hipEventRecord(e1, st);
+    float ms = 0.f;
+    if (rc != A2C_OK || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+    if (getenv("A2C_TUNE_LOG")) fprintf(stderr, "a2c fwd tune (%d,%d,%d)->%d s%d B=%d: budget %d KB %.4f ms\n", d->Cin, d->H, d->W, d->Cout, d->stride, B, c, ms / reps);
+    if (best_ms < 0.f || ms < 0.97f * best_ms) { best = c; best_ms = ms; }      // later candidates must win by 3 %
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  cache[key] = best;
+  return conv_fwd_impl(d, in, in_bstride, wprep_fwd, bias, relu, out, out_bstride, B, best, stream);
+}
+}  // namespace
+extern "C" {
+int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* wprep_fwd,
+                   const float* bias, int relu, float* out, int64_t out_bstride, int B, a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!in || !wprep_fwd || !out) return A2C_ERR_ARG;
+  return conv_fwd_tuned(d, in, in_bstride, wprep_fwd, bias, relu, out, out_bstride, B, stream);
 }
 
 }  // extern "C"
@@ -2732,10 +2788,6 @@ static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const floa
 // between heights on the reference's 3x3 layers: 1.3-1.7x (pixel-pair quantisation of the class rows, workgroups
 // per CU, bands per sample), which no closed-form rule predicted.  Calls made while the stream is being captured
 // into a hipGraph use the cached height, or the LDS-budget rule when the pair has not been seen yet.
-struct BandKey {
-  int v[9];
-  bool operator<(const BandKey& o) const { return std::lexicographical_compare(v, v + 9, o.v, o.v + 9); }
-};
 static int bwd_band_tuned(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask,
                           float* din, int B, a2c_stream_t stream) {
   static std::mutex mu;

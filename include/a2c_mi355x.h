@@ -82,6 +82,27 @@ int a2c_frame_stack_push_u8(const uint8_t *frame_u8, int64_t frame_stride, const
                             const float *prev, int64_t prev_stride, float *out, int64_t out_stride,
                             int B, int C, int HW, a2c_stream_t stream);
 
+/* ------------------------------------------------------------------ g1: device relay of the host env pool
+ * (a2c_hostpool.h) for the per-step rollout of the models without a persistent kernel.  Replaces, per env step, the
+ * host round trip of the memcpy ingest -- D2H of the actions, a2c_pool_post_actions, a2c_pool_wait_frames,
+ * a2c_pool_unpack, H2D of the frames block (runner.py:199,207-226 of the reference did the same hand-off one
+ * element at a time) -- by two launches that stay on the stream:
+ *   a2c_pool_publish_actions   cmd[i] = ((seq_base[0] + seq_off) << 32) | actions[i*act_stride], i < n
+ *                              (system-scope 8-byte stores into the device-mapped pinned region)
+ *   a2c_pool_ingest            waits until rec[i].seq == seq_base[0] + seq_off (every env, bounded by
+ *                              timeout_ticks of the 100 MHz wall clock; on expiry *err = 1 and this and all later
+ *                              calls return without waiting), then rew[i], done[i] <- rec[i] and
+ *                              frames_out[i*out_stride ..] <- frames[i*frame_stride .. +frame_bytes] (16-byte
+ *                              system-scope loads over PCIe).  frame_bytes, strides: multiples of 16.
+ * cmd / rec / frames are the DEVICE addresses of the pool's granules of the first env of the block
+ * (hipHostGetDevicePointer of the registered region); seq_base lives in device memory so that a captured hipGraph
+ * of a segment can be replayed by later rollouts.                                               */
+int a2c_pool_publish_actions(uint64_t *cmd, const int64_t *actions, int64_t act_stride, int n,
+                             const uint32_t *seq_base, uint32_t seq_off, a2c_stream_t stream);
+int a2c_pool_ingest(const uint64_t *rec, const uint8_t *frames, int64_t frame_stride, int frame_bytes, int n,
+                    const uint32_t *seq_base, uint32_t seq_off, int64_t timeout_ticks, int *err, float *rew,
+                    float *done, uint8_t *frames_out, int64_t out_stride, a2c_stream_t stream);
+
 /* ------------------------------------------------------------------ a2: sampler
  * SequentialEnvironment.get_action discrete branch (runner.py:94-97) + utils.sample_action
  * (utils.py:45-60): p = softmax(logits); running fp32 cumsum in index order; first a with

@@ -63,6 +63,8 @@ SIGNATURES = {
     "a2c_add": (c_int, [P, P, P, c_int64, P]),
     "a2c_frame_stack_push": (c_int, [P, P, P, c_int64, P, c_int64, c_int, c_int, c_int, P]),
     "a2c_frame_stack_push_u8": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int, c_int, P]),
+    "a2c_pool_publish_actions": (c_int, [P, P, c_int64, c_int, P, ctypes.c_uint32, P]),
+    "a2c_pool_ingest": (c_int, [P, P, c_int64, c_int, c_int, P, ctypes.c_uint32, c_int64, P, P, P, P, c_int64, P]),
     "a2c_softmax_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int, c_int, P]),
     "a2c_sample_probs": (c_int, [P, P, P, c_int64, c_int, P]),
     "a2c_rollout_record": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_int64, c_int64, c_int64,

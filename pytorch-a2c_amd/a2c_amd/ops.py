@@ -168,6 +168,20 @@ def frame_stack_push(frame_new, reset_mask, prev_ptr, prev_stride, out_ptr, out_
                                      B, C, HW, st if st is not None else stream()), "a2c_frame_stack_push")
 
 
+def pool_publish_actions(cmd_ptr, actions_ptr, act_stride, n, seq_base, seq_off, st=None):
+    """device side of a2c_pool_post_actions: cmd granules of n envs written from the stream (include/a2c_mi355x.h g1)"""
+    check(lib().a2c_pool_publish_actions(cmd_ptr, actions_ptr, act_stride, n, _p(seq_base), seq_off,
+                                         st if st is not None else stream()), "a2c_pool_publish_actions")
+
+
+def pool_ingest(rec_ptr, frames_ptr, frame_stride, frame_bytes, n, seq_base, seq_off, timeout_ticks, err, rew, done,
+                frames_out_ptr, out_stride, st=None):
+    """device side of a2c_pool_wait_frames + unpack + the H2D copy of the frames block"""
+    check(lib().a2c_pool_ingest(rec_ptr, frames_ptr, frame_stride, frame_bytes, n, _p(seq_base), seq_off, timeout_ticks,
+                                _p(err), _p(rew), _p(done), frames_out_ptr, out_stride,
+                                st if st is not None else stream()), "a2c_pool_ingest")
+
+
 def frame_stack_push_u8(frame_u8_ptr, frame_stride, reset_mask, prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW, st=None):
     """frame_stack_push with the new frame as uint8 pixels at frame_u8_ptr + b*frame_stride (device address)"""
     check(lib().a2c_frame_stack_push_u8(frame_u8_ptr, frame_stride, _p(reset_mask), prev_ptr, prev_stride, out_ptr,

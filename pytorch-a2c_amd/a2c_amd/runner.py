@@ -305,7 +305,7 @@ class Runner:
 
     def _zero_copy_ok(self, net):
         """the persistent one-launch rollout applies: A3CModel-shaped net, process pool with uint8 frames"""
-        if not self.proc_pool or self.h is not None or self.ingest == "memcpy":
+        if not self.proc_pool or self.h is not None or self.ingest in ("memcpy", "relay"):
             return False
         ok = (getattr(net, "_step_supported", lambda: False)() and self.u8 and self.HW % 16 == 0 and self.HW <= 8192
               and self.env_pool.dev_ptr != 0)
@@ -465,16 +465,29 @@ class Runner:
                 ub[t, env0:env0 + B].copy_(self.uniform_fn(t, B, env0).reshape(B))
         else:
             ub[:, env0:env0 + B] = torch.rand((T, B), device=dev, dtype=torch.float32)
+        # device relay (a2c_pool_publish_actions / a2c_pool_ingest): the segments hand actions and frames to the env
+        # workers through the pinned region themselves, so the T+1 launches queue back to back with no host in between
+        relay = (self.proc_pool and pool.dev_ptr != 0 and acts_host_out is None and self.ingest != "memcpy"
+                 and self.fstride % 16 == 0 and os.environ.get("A2C_NO_RELAY") != "1")
+        if self.ingest == "relay" and not relay:
+            raise ValueError("ingest='relay' needs a registered process/thread env pool and a device-resident "
+                             "datas['actions'] tensor")
+        if relay:
+            if getattr(self, "_seq_dev", None) is None:
+                self._seq_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+                self._seq_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._seq_pin[0] = pool.seq & 0x7fffffff
+            self._seq_dev.copy_(self._seq_pin, non_blocking=True)
         stash = self._stash_bufs
         fused = h is None and getattr(net, "_step_supported", lambda: False)()
         if stash is not None and isinstance(stash, list) == fused:      # tuple (a1, a2): step kernel; list: conv-stack nets
             stash = None
         self._stash_used = stash is not None
         ctx = dict(net=net, slot0=slot0, env0=env0, B=B, T=T, hyps=hyps, sp=sp, bm=bm, val_prev=val_prev, done_eff=done_eff,
-                   h=h, acts_host_out=acts_host_out, fused=fused, stash=stash, ub=ub)
+                   h=h, acts_host_out=acts_host_out, fused=fused, stash=stash, ub=ub, relay=relay)
         graphs = None
         if try_key(hyps, "rollout_graphs", True) and torch.cuda.is_available():
-            key = (id(net), slot0, env0, B, T, fused, stash is not None, acts_host_out is None, pong, float(hyps["gamma"]),
+            key = (id(net), slot0, env0, B, T, fused, stash is not None, acts_host_out is None, pong, relay, float(hyps["gamma"]),
                    tuple(D[k].data_ptr() for k in sorted(D) if D[k].is_cuda))
             cache = self.__dict__.setdefault("_seg_graphs", {})
             graphs = cache.setdefault(key, [None] * (T + 1))
@@ -485,7 +498,7 @@ class Runner:
                 if graphs[k] is None:          # first visit: eager (the conv tile tuners measure on eager calls only)
                     graphs[k] = "warm"
                     self._segment(k, ctx)
-                    if k < T:
+                    if k < T and not relay:
                         torch.cuda.current_stream().synchronize()
                         self._host_env_step(pool, env0, B, k, slot0, T, shift, acts_host_out, pong)
                     continue
@@ -502,7 +515,7 @@ class Runner:
                     graphs[k].replay()
                 else:
                     self._segment(k, ctx)
-            if k < T:
+            if k < T and not relay:
                 torch.cuda.current_stream().synchronize()
                 self._host_env_step(pool, env0, B, k, slot0, T, shift, acts_host_out, pong)
 
@@ -515,7 +528,14 @@ class Runner:
         rewards, dones, deltas = D["rewards"], D["dones"], D["deltas"]
         st = ops.stream()
         fr = rew = done = None
-        if k > 0:       # what env step k-1 returned: pinned staging -> HBM
+        if k > 0 and c.get("relay"):       # what env step k-1 returned: waited for and fetched by the device itself
+            rew, done = self.d_rew[env0:env0 + B], self.d_done[env0:env0 + B]
+            fs = self.fstride
+            dst = self.d_frames.data_ptr() + env0 * fs
+            ops.pool_ingest(pool.dev_rec + 8 * env0, pool.dev_frames + env0 * fs, fs, fs, B, self._seq_dev, k,
+                            int(float(try_key(hyps, "env_timeout_s", 20.0)) * 1e8), self.rollout_err, rew, done, dst, fs, st)
+            fr = _Frames(ptr8=dst, stride=fs) if self.u8 else _Frames(ptr32=dst)
+        elif k > 0:     # what env step k-1 returned: pinned staging -> HBM
             rew, done = self.d_rew[env0:env0 + B], self.d_done[env0:env0 + B]
             rew.copy_(self.h_rew[env0:env0 + B], non_blocking=True)
             done.copy_(self.h_done[env0:env0 + B], non_blocking=True)
@@ -588,6 +608,9 @@ class Runner:
                 ops.softmax_sample(out["logits"], u, a_ptr, a_stride, B, net.output_space, st=st)
             if h is not None:
                 ops.copy_rows(out["h"].data_ptr(), h.shape[1], h.data_ptr(), h.shape[1], B, h.shape[1], st)
+        if c.get("relay"):      # the sampled actions go to the env workers: cmd granules of env step k
+            ops.pool_publish_actions(pool.dev_cmd + 8 * env0, a_ptr, a_stride, B, self._seq_dev, k, st)
+            return
         # the sampled actions go to the host (pinned staging) at the tail of the segment
         ha = self.h_act[env0:env0 + B]
         if a_stride == 1:

@@ -2421,6 +2421,11 @@ static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl, bool allow_
   pl.ex = (ktw == pl.KTW) ? 1 : 0;
   // dOut tile floats per pixel row: MT*16 planes * OWp (+ plane padding, fixed)
   plan_src(t, pl.MT * 16 * pl.OWp, pl.MT * 16 * 34, WGRAD_LDS_BUDGET);
+  if (t.tiles > 1 && !getenv("A2C_WGRAD_LDS_KB")) {     // a small plane: the whole sample as ONE tile beats two uneven ones
+    SrcTile t1 = t;
+    plan_src(t1, pl.MT * 16 * pl.OWp, pl.MT * 16 * 34, 80 * 1024);
+    if (t1.tiles == 1) t = t1;
+  }
   pl.pf = 0;
   if (allow_run && !getenv("A2C_NO_WGRAD_PF") && d->W % 4 == 0 && d->OW % 2 == 0) {
     const int ni = (pl.rs && pl.KTW == 3) ? 4 : (pl.rs && pl.KTW == 9) ? 8 : (!pl.rs && pl.MT == 2 && pl.KTW == 4 && pl.ex) ? 12 : 0;

@@ -201,6 +201,67 @@ __global__ __launch_bounds__(256) void permute_rows_kernel(const float* __restri
     dst[i] = src[(r * T + t) * n + j];
   }
 }
+
+// ---- device relay of the host env pool (include/a2c_hostpool.h) for the per-step rollout of ANY model -------
+// The persistent A3C kernel talks to the env workers itself; every other model runs one segment of kernels per env
+// step.  With these two kernels the segments need no host in between either: the tail of segment k publishes the
+// sampled actions as cmd granules in the pinned region (system-scope 8-byte stores), the head of segment k+1 waits
+// for the workers' rec granules and pulls the frames over PCIe with 16-byte system-scope loads (what the host's
+// D2H copy / post_actions / wait_frames / H2D copies did, at ~50 us of host round trip + launch gaps per step).
+// The step number comes from device memory (seq_base[0] + seq_off) so that a captured segment can be replayed by
+// later rollouts.  A worker that does not answer within timeout_ticks (100 MHz) sets *err; later waits return at once.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+__global__ __launch_bounds__(256) void pool_publish_kernel(unsigned long long* __restrict__ cmd,
+                                                           const int64_t* __restrict__ actions, long stride, int n,
+                                                           const unsigned int* __restrict__ seq_base, unsigned int seq_off) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long seq = (unsigned long long)(seq_base[0] + seq_off);
+  __hip_atomic_store(cmd + i, (seq << 32) | (unsigned int)actions[i * stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long long* __restrict__ rec,
+                                                          const uint8_t* __restrict__ frames, long fstride, int fbytes,
+                                                          const unsigned int* __restrict__ seq_base, unsigned int seq_off,
+                                                          long timeout_ticks, int* __restrict__ err, float* __restrict__ rew,
+                                                          float* __restrict__ done, uint8_t* __restrict__ out, long ostride) {
+  __shared__ unsigned int sh[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    const unsigned int want = seq_base[0] + seq_off;
+    unsigned long long gr = ~0ULL;
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      const unsigned long long t0 = wall_clock64();
+      for (;;) {
+        gr = __hip_atomic_load(rec + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned int)(gr >> 33) == want) break;
+        if ((long)(wall_clock64() - t0) > timeout_ticks) {
+          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          gr = ~0ULL;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
+    }
+    sh[0] = (unsigned int)gr;
+    sh[1] = (unsigned int)(gr >> 32);
+  }
+  __syncthreads();
+  const unsigned int lo = sh[0], hi = sh[1];
+  if (hi == 0xffffffffu) return;                      // timeout (now or earlier): the error flag is set
+  if (tid == 0) {
+    rew[b] = __uint_as_float(lo);
+    done[b] = (hi & 1u) ? 1.f : 0.f;
+  }
+  // the frame was written before its rec granule (release): 16-byte system-scope loads straight from pinned host memory
+  __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(frames + (long)b * fstride), 0, fbytes, 0x00020000);
+  uint8_t* __restrict__ o = out + (long)b * ostride;
+  for (int off = tid * 16; off < fbytes; off += 256 * 16) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(fr, off, 0, 1 | 16);   // sc0 sc1
+    *reinterpret_cast<u32x4*>(o + off) = v;
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -363,6 +424,31 @@ int a2c_mask_rows(float* x, int64_t ld, const float* dones, int64_t done_stride,
   const long tot = (long)B * n;
   hipLaunchKernelGGL(mask_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, a2c_s(stream), x, (long)ld,
                      dones, (long)done_stride, B, n);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_pool_publish_actions(uint64_t* cmd, const int64_t* actions, int64_t act_stride, int n, const uint32_t* seq_base,
+                             uint32_t seq_off, a2c_stream_t stream) {
+  if (n < 0 || !cmd || !actions || !seq_base || act_stride < 1) return A2C_ERR_ARG;
+  if (n == 0) return A2C_OK;
+  hipLaunchKernelGGL(pool_publish_kernel, dim3((n + 255) / 256), dim3(256), 0, a2c_s(stream), (unsigned long long*)cmd,
+                     actions, (long)act_stride, n, seq_base, seq_off);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_pool_ingest(const uint64_t* rec, const uint8_t* frames, int64_t frame_stride, int frame_bytes, int n,
+                    const uint32_t* seq_base, uint32_t seq_off, int64_t timeout_ticks, int* err, float* rew, float* done,
+                    uint8_t* frames_out, int64_t out_stride, a2c_stream_t stream) {
+  if (n < 0 || !rec || !frames || !seq_base || !err || !rew || !done || !frames_out) return A2C_ERR_ARG;
+  if (frame_bytes < 16 || frame_bytes % 16 || frame_stride % 16 || out_stride % 16 || frame_stride < frame_bytes ||
+      out_stride < frame_bytes || timeout_ticks < 1 || ((uintptr_t)frames % 16) || ((uintptr_t)frames_out % 16))
+    return A2C_ERR_ARG;
+  if (n == 0) return A2C_OK;
+  hipLaunchKernelGGL(pool_ingest_kernel, dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
+                     (long)frame_stride, frame_bytes, seq_base, seq_off, (long)timeout_ticks, err, rew, done, frames_out,
+                     (long)out_stride);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -1,9 +1,12 @@
 """-m gpu: the north-star ingest -- env stepping in host worker processes, frames through ONE pinned,
 device-mapped region (uint8 when the preprocessor yields uint8) -- against the CPU oracle's batch-1
 runners on the same deterministic envs (runner.py:174-248).  Covers both ingest modes of the Runner
-(memcpy: hipMemcpyAsync per step, every model; zero-copy: the persistent one-launch rollout
-a2c_a3c_rollout), rollout -> update -> rollout sequences (stale derived weights would show), more envs
+(memcpy: hipMemcpyAsync per step behind a host hand-off, every model; relay: the same segments with the
+hand-off done by the device, a2c_pool_publish_actions / a2c_pool_ingest; zero-copy: the persistent one-launch
+rollout a2c_a3c_rollout), rollout -> update -> rollout sequences (stale derived weights would show), more envs
 than CUs, fp32 frames, worker failure and the host time-out of the persistent kernel."""
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -58,7 +61,10 @@ def _compare_round(D, ref, recurrent, tol=1e-5):
 
 @pytest.mark.parametrize("kind,ingest,fused", [("A3CModel", "zero-copy", True), ("A3CModel", "memcpy", True),
                                                ("A3CModel", "memcpy", False), ("GRUModel", "memcpy", False),
-                                               ("ConvModel", "memcpy", False), ("FCModel", "memcpy", False)])
+                                               ("ConvModel", "memcpy", False), ("FCModel", "memcpy", False),
+                                               ("A3CModel", "relay", True), ("A3CModel", "relay", False),
+                                               ("GRUModel", "relay", False), ("ConvModel", "relay", False),
+                                               ("FCModel", "relay", False)])
 def test_process_pool_rollouts_match_oracle(kind, ingest, fused, monkeypatch):
     """two consecutive rounds of B slots (the second continues the envs, bookmarks and hidden states)"""
     from a2c_amd.runner import Runner
@@ -70,7 +76,7 @@ def test_process_pool_rollouts_match_oracle(kind, ingest, fused, monkeypatch):
                      action_shift=0, n_envs=B, env_timeout_s=20.0)
     net = make_net(kind, ss, A, 256)
     onet = O.OracleNet(kind, ss, A, 256)
-    D = _datas(B * T, ss, net.is_recurrent, actions_on_host=(kind == "GRUModel"))
+    D = _datas(B * T, ss, net.is_recurrent, actions_on_host=(kind == "GRUModel" and ingest != "relay"))
     us = torch.from_numpy(hashf(2 * T * B, 901, 0, 1).reshape(2, T, B))
     usd = us.to(DEV)
     rnd = [0]
@@ -90,7 +96,8 @@ def test_process_pool_rollouts_match_oracle(kind, ingest, fused, monkeypatch):
         r.close()
 
 
-@pytest.mark.parametrize("kind,ingest", [("A3CModel", "zero-copy"), ("A3CModel", "memcpy"), ("GRUModel", "memcpy")])
+@pytest.mark.parametrize("kind,ingest", [("A3CModel", "zero-copy"), ("A3CModel", "memcpy"), ("GRUModel", "memcpy"),
+                                         ("GRUModel", "relay"), ("ConvModel", "relay")])
 def test_rollout_update_rollout_matches_oracle(kind, ingest):
     """three rounds with update_model in between (training.py:163-165): the rollout after an optimiser step
     must use the NEW weights (derived inference weights -- composed heads, conv fragments -- re-built)"""
@@ -213,6 +220,27 @@ def test_persistent_rollout_times_out_instead_of_hanging():
         r.close()
 
 
+def test_device_relay_rollout_times_out_instead_of_hanging():
+    """the same for the per-step rollout of the other models: the segments wait for the workers on the DEVICE
+    (a2c_pool_ingest); a dead worker ends the first wait after the time-out and every later one at once"""
+    from a2c_amd.runner import Runner
+    B, T, A, ss = 4, 8, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, fail_at=3 if j == 1 else 10 ** 9) for j in range(B)]
+    hyps = base_hyps(env_type="FakeBreakout", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, env_timeout_s=1.0)
+    net = make_net("ConvModel", ss, A, 256)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    pool = _pool(FailingEnv, ekws, 2, pong=False)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="relay")
+    t0 = time.time()
+    try:
+        r.rollout(net, list(range(B)), hyps)
+        with pytest.raises((TimeoutError, RuntimeError)):
+            r.finish()
+        assert time.time() - t0 < 15.0          # one 1 s wait, not one per remaining segment
+    finally:
+        r.close()
+
+
 def test_rollout_sampler_never_returns_minus_one():
     """u = nextafter(1, 0): the fp32 cumsum of a softmax can stay below it; the rollout samplers return the
     last action (what -1 indexes in the loss, updater.py:104), utils.sample_action keeps the reference's -1"""
@@ -299,7 +327,7 @@ def test_full_size_headline_rollout_properties_and_action_flip_census():
 
 
 @pytest.mark.parametrize("kind,ingest", [("A3CModel", "zero-copy"), ("A3CModel", "memcpy"), ("GRUModel", "memcpy"),
-                                         ("ConvModel", "memcpy")])
+                                         ("ConvModel", "memcpy"), ("GRUModel", "relay")])
 def test_update_from_stashed_rollout_activations_equals_recomputed(kind, ingest, monkeypatch):
     """The one-launch rollout step stashes conv1/conv2 activations of every state; update_model reads them instead
     of re-running the two conv forwards (same weights, same states: training.py:150-165).  Same update as the

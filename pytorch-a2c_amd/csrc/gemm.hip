@@ -311,6 +311,101 @@ static bool launch_skinny_stream(long M, long N, long K, const float* A, long ld
   return true;
 }
 
+// Small products (the GRU cell's h x h and x x 3h GEMMs at rollout / BPTT batch, M = n_envs: a handful of
+// 128 x 128 tiles) used to run as split-K + slab reduce: two launches and a few MB of slab traffic for a few
+// MFLOP, 18 us per product, ~9 products per env step.  Here ONE launch: a workgroup owns a 32 x 32 tile of C, its
+// four waves split K into quarters, operands go global -> register -> MFMA with no LDS staging (lane (i, h) reads
+// 16 B of row i at k + 4h when the operand is k-contiguous, else four coalesced dwords), the four partial tiles are
+// added through LDS in wave order (deterministic) and the epilogue (accumulate, bias, ReLU, mask) is applied.
+template <bool B_KC>
+__global__ __launch_bounds__(256) void small_gemm_kernel(long M, long N, long K, const float* __restrict__ A, long lda,
+                                                         const float* __restrict__ B, long ldb, float* __restrict__ C,
+                                                         long ldc, const float* __restrict__ bias, int relu,
+                                                         const float* __restrict__ mask, long ldmask, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float red[4][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const long m0 = (long)blockIdx.y * 32, n0 = (long)blockIdx.x * 32;
+  const long kq = K >> 2;                              // K % 32 == 0: quarters are multiples of 8
+  const long kbeg = w * kq, kend = kbeg + kq;
+  const float* __restrict__ arow = A + min(m0 + li, M - 1) * lda + 4 * lk;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (B_KC) {
+    const float* __restrict__ brow = B + min(n0 + li, N - 1) * ldb + 4 * lk;
+    long k = kbeg;
+    for (; k + 8 <= kend && ((kend - k) & 31); k += 8) {   // head: bring the rest to a multiple of 32
+      const float4 a1 = *reinterpret_cast<const float4*>(arow + k), b1 = *reinterpret_cast<const float4*>(brow + k);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
+    }
+    for (; k < kend; k += 32) {                        // four 8-column groups in flight
+      float4 av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = *reinterpret_cast<const float4*>(arow + k + 8 * u);
+        bv[u] = *reinterpret_cast<const float4*>(brow + k + 8 * u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+      }
+    }
+  } else {
+    const float* __restrict__ bcol = B + min(n0 + li, N - 1) + (long)(4 * lk) * ldb;
+    long k = kbeg;
+    if ((kend - k) & 15) {                             // head: one 8-row group
+      const float4 a1 = *reinterpret_cast<const float4*>(arow + k);
+      const float b0 = bcol[k * ldb], b1 = bcol[(k + 1) * ldb], b2 = bcol[(k + 2) * ldb], b3 = bcol[(k + 3) * ldb];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b3, acc, 0, 0, 0);
+      k += 8;
+    }
+    for (; k < kend; k += 16) {                        // two 8-row groups in flight
+      float4 av[2];
+      float bv[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        av[u] = *reinterpret_cast<const float4*>(arow + k + 8 * u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[u][j] = bcol[(k + 8 * u + j) * ldb];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u][3], acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[w][r][lane] = acc[r];
+  __syncthreads();
+  // thread t finishes register r = t >> 6 .. (4 per thread) of lane t & 63: col n = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = w * 4 + q;
+    float v = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+    const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk, n = n0 + li;
+    if (m < M && n < N) {
+      if (accumulate) v += C[m * ldc + n];
+      if (bias) v += bias[n];
+      if (relu) v = fmaxf(v, 0.f);
+      if (mask && !(mask[m * ldmask + n] > 0.f)) v = 0.f;
+      C[m * ldc + n] = v;
+    }
+  }
+}
+
 // out[n] = sum_m x[m*ld+n]: stage 1 = per-workgroup partial column sums over a row band,
 // stage 2 = fixed-order sum of the partials.
 constexpr int CS_BANDS = 256;
@@ -682,6 +777,18 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
     return A2C_OK;
   }
   (void)al16;
+  {  // small products: one launch, no slabs (see small_gemm_kernel)
+    const long t128 = ((M + 127) / 128) * ((N + 127) / 128), t32 = ((M + 31) / 32) * ((N + 31) / 32);
+    const bool vA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0), vB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
+    if (transA == 0 && K % 32 == 0 && K <= 4096 && t128 < 64 && t32 >= 16 && t32 <= 4096 && vA && (transB == 0 || vB) &&
+        !getenv("A2C_NO_SMALL_GEMM")) {
+      dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
+      if (transB) hipLaunchKernelGGL(small_gemm_kernel<true>, grid, dim3(256), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
+      else hipLaunchKernelGGL(small_gemm_kernel<false>, grid, dim3(256), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
   if (splitk < 1) splitk = 1;
   long kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;  // multiple of BK keeps 16 B alignment of k0
   splitk = (int)((K + kps - 1) / kps);

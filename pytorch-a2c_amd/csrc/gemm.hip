@@ -317,16 +317,16 @@ static bool launch_skinny_stream(long M, long N, long K, const float* A, long ld
 // four waves split K into quarters, operands go global -> register -> MFMA with no LDS staging (lane (i, h) reads
 // 16 B of row i at k + 4h when the operand is k-contiguous, else four coalesced dwords), the four partial tiles are
 // added through LDS in wave order (deterministic) and the epilogue (accumulate, bias, ReLU, mask) is applied.
-template <bool B_KC>
-__global__ __launch_bounds__(256) void small_gemm_kernel(long M, long N, long K, const float* __restrict__ A, long lda,
+template <bool B_KC, int NW>
+__global__ __launch_bounds__(64 * NW) void small_gemm_kernel(long M, long N, long K, const float* __restrict__ A, long lda,
                                                          const float* __restrict__ B, long ldb, float* __restrict__ C,
                                                          long ldc, const float* __restrict__ bias, int relu,
                                                          const float* __restrict__ mask, long ldmask, int accumulate) {
-  __shared__ __attribute__((aligned(16))) float red[4][16][64];
+  __shared__ __attribute__((aligned(16))) float red[NW][16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const long m0 = (long)blockIdx.y * 32, n0 = (long)blockIdx.x * 32;
-  const long kq = K >> 2;                              // K % 32 == 0: quarters are multiples of 8
+  const long kq = K / NW;                              // K % (8 * NW) == 0: the parts are multiples of 8
   const long kbeg = w * kq, kend = kbeg + kq;
   const float* __restrict__ arow = A + min(m0 + li, M - 1) * lda + 4 * lk;
   f32x16 acc;
@@ -342,19 +342,29 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(long M, long N, long K,
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
     }
-    for (; k < kend; k += 32) {                        // four 8-column groups in flight
-      float4 av[4], bv[4];
+    if (k < kend) {                                    // four 8-column groups per trip, the next trip's loads in flight
+      float4 av[4], bv[4], an[4], bn[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         av[u] = *reinterpret_cast<const float4*>(arow + k + 8 * u);
         bv[u] = *reinterpret_cast<const float4*>(brow + k + 8 * u);
       }
+      for (; k < kend; k += 32) {
+        const long kn = (k + 32 < kend) ? k + 32 : k;  // last trip: re-read (valid addresses, values unused)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+          an[u] = *reinterpret_cast<const float4*>(arow + kn + 8 * u);
+          bn[u] = *reinterpret_cast<const float4*>(brow + kn + 8 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
       }
     }
   } else {
@@ -390,11 +400,13 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(long M, long N, long K,
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[w][r][lane] = acc[r];
   __syncthreads();
-  // thread t finishes register r = t >> 6 .. (4 per thread) of lane t & 63: col n = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // wave w finishes registers w*16/NW .. of every lane: col n = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = w * 4 + q;
-    float v = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+  for (int q = 0; q < 16 / NW; ++q) {
+    const int r = w * (16 / NW) + q;
+    float v = red[0][r][lane];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) v += red[ww][r][lane];
     const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk, n = n0 + li;
     if (m < M && n < N) {
       if (accumulate) v += C[m * ldc + n];
@@ -783,8 +795,11 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
     if (transA == 0 && K % 32 == 0 && K <= 4096 && t128 < 64 && t32 >= 16 && t32 <= 4096 && vA && (transB == 0 || vB) &&
         !getenv("A2C_NO_SMALL_GEMM")) {
       dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
-      if (transB) hipLaunchKernelGGL(small_gemm_kernel<true>, grid, dim3(256), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
-      else hipLaunchKernelGGL(small_gemm_kernel<false>, grid, dim3(256), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
+      const bool deep = K >= 1024 && K % 64 == 0 && t32 <= 512;      // long K, few tiles: eight waves share it
+      if (transB && deep) hipLaunchKernelGGL((small_gemm_kernel<true, 8>), grid, dim3(512), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
+      else if (transB) hipLaunchKernelGGL((small_gemm_kernel<true, 4>), grid, dim3(256), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
+      else if (deep) hipLaunchKernelGGL((small_gemm_kernel<false, 8>), grid, dim3(512), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
+      else hipLaunchKernelGGL((small_gemm_kernel<false, 4>), grid, dim3(256), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
       A2C_CHECK_LAUNCH();
       return A2C_OK;
     }

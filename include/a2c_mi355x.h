@@ -367,6 +367,17 @@ int a2c_conv2d_fwd(const a2c_conv_desc *d, const float *in, int64_t in_bstride,
  * (B,Cin,H,W) activation that fed this conv (the ReLU below it)                          */
 int a2c_conv2d_bwd_data(const a2c_conv_desc *d, const float *dout, const float *wprep_bwd,
                         const float *mask, float *din, int B, a2c_stream_t stream);
+/* a2c_conv2d_bwd_data of layer d2 FUSED with a2c_conv2d_bwd_weight of the layer d1 below it, for the case where
+ * nothing but d1's weight gradient reads d2's input gradient (d1 = first conv of the stack: models.py:196-215, its
+ * input needs no gradient): the masked input gradient (the `din` of the call above) is assembled band by band
+ * in LDS, multiplied against the band's rows of d1's input x on the matrix cores and dropped -- it is never
+ * written to HBM.  dW1 (d1.Cout, d1.Cin, 3, 3), db1 (d1.Cout): the same sums as the two separate calls, per-workgroup
+ * partials in ws + fixed-order reduction.  Applies when d1 is 3x3 / stride 1 / pad 1 with d1.Cin*9 <= 48,
+ * d1.Cout == d2.Cin <= 16, d2.W % 4 == 0: _ws_bytes returns 0 when it does not (then use the two calls).         */
+size_t a2c_conv2d_bwd_data_w1_ws_bytes(const a2c_conv_desc *d2, const a2c_conv_desc *d1, int B);
+int a2c_conv2d_bwd_data_w1(const a2c_conv_desc *d2, const float *dout, const float *wprep_bwd,
+                           const float *mask, const a2c_conv_desc *d1, const float *x, int64_t x_bstride,
+                           float *dW1, float *db1, int B, void *ws, size_t ws_bytes, a2c_stream_t stream);
 /* dW (Cout,Cin,ks,ks) and db (Cout) summed over the batch: per-workgroup partial slabs in
  * ws + fixed-order reduction (deterministic).                                            */
 size_t a2c_conv2d_bwd_weight_ws_bytes(const a2c_conv_desc *d, int B);

@@ -109,6 +109,8 @@ SIGNATURES = {
     "a2c_conv2d_fwd": (c_int, [PD, P, c_int64, P, P, c_int, P, c_int64, c_int, P]),
     "a2c_conv2d_bwd_data": (c_int, [PD, P, P, P, P, c_int, P]),
     "a2c_conv2d_bwd_weight_ws_bytes": (c_size_t, [PD, c_int]),
+    "a2c_conv2d_bwd_data_w1_ws_bytes": (c_size_t, [PD, PD, c_int]),
+    "a2c_conv2d_bwd_data_w1": (c_int, [PD, P, P, P, PD, P, c_int64, P, P, c_int, P, c_size_t, P]),
     "a2c_conv2d_bwd_weight": (c_int, [PD, P, c_int64, P, P, P, c_int, P, c_size_t, P]),
     "a2c_conv2d_bwd_weight_frames": (c_int, [PD, P, c_int64, c_int64, P, P, P, P, c_int, P, c_size_t, P]),
     "a2c_gru_gates": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),

@@ -461,6 +461,16 @@ class _ConvStackNet(_HipNet):
             l = self._cl[i]
             in_ptr, in_bs = (x_ptr, bstride) if i == 0 else (acts[i - 1].data_ptr(), acts[i - 1][0].numel())
             l.bwd_weight(in_ptr, in_bs, d, self.G(f"convs.{i}.0.weight"), self.G(f"convs.{i}.0.bias"), B, ws, st)
+            if i == 1 and not self._cl[0].padded and not l.padded and bstride % 4 == 0 and x_ptr % 16 == 0:
+                # layer 2's input gradient only feeds layer 1's weight gradient: one fused pass, da0 never reaches HBM
+                l0 = self._cl[0]
+                nb = ops.conv_bwd_data_w1_ws_bytes(l.d, l0.d, B)
+                if nb:
+                    buf = ws.bytes("conv_w1_ws", nb)
+                    with ops.span("conv2.bwd_data+conv1.bwd_weight"):
+                        ops.conv_bwd_data_w1(l.d, d, l.wb, acts[0], l0.d, x_ptr, bstride, self.G("convs.0.0.weight"),
+                                             self.G("convs.0.0.bias"), B, buf, st)
+                    return
             if i > 0:
                 dprev = ws.get(f"da{i-1}", (B,) + self._cl[i - 1].out_shape)
                 l.bwd_data(d, acts[i - 1], dprev, B, st)

@@ -413,6 +413,17 @@ def conv_bwd_weight_ws_bytes(d, B):
     return lib().a2c_conv2d_bwd_weight_ws_bytes(ctypes.byref(d), B)
 
 
+def conv_bwd_data_w1_ws_bytes(d2, d1, B):
+    """> 0 when layer d2's backward-data can absorb the weight gradient of the first layer d1 below it"""
+    return lib().a2c_conv2d_bwd_data_w1_ws_bytes(ctypes.byref(d2), ctypes.byref(d1), B)
+
+
+def conv_bwd_data_w1(d2, dout, wprep_bwd, mask, d1, x_ptr, x_bstride, dW1, db1, B, ws, st=None):
+    check(lib().a2c_conv2d_bwd_data_w1(ctypes.byref(d2), _p(dout), _p(wprep_bwd), _p(mask), ctypes.byref(d1), x_ptr,
+                                       x_bstride, _p(dW1), _p(db1), B, ws.data_ptr(), ws.numel() * ws.element_size(),
+                                       st if st is not None else stream()), "a2c_conv2d_bwd_data_w1")
+
+
 def conv_bwd_weight(d, in_ptr, in_bstride, dout, dW, db, B, ws, st=None):
     check(lib().a2c_conv2d_bwd_weight(ctypes.byref(d), in_ptr, in_bstride, _p(dout), _p(dW), _p(db), B,
                                       ws.data_ptr(), ws.numel() * ws.element_size(),

@@ -1731,14 +1731,29 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
 //     ReLU-derivative mask of the CURRENT band at its start, so neither the staging nor the flush waits on HBM.
 constexpr int PFB2_MAX = 16;         // dOut prefetch slots per thread (VEC floats each): template parameter PFB2 = 8, 12 or 16
 constexpr int PFM2 = 12;             // mask prefetch slots per thread (float4 each)
+constexpr int PFM2_W1 = 8;           // ... of the fused variant (registers: two workgroups per CU)
 struct BwdBand2P {
   BwdBandP b;
   int nfrag;                         // floats of the prepared backward fragments (all classes)
   int mask_pf;                       // 1: the band's mask fits PFM2 float4 per thread and rows are 16-B multiples
 };
 
-template <int MT, int VEC, int PFB2>
-__global__ __launch_bounds__(256) void bwd_band2_kernel(BwdBand2P pp) {
+// W1 = true fuses the weight gradient of the layer BELOW behind this backward-data pass: when that layer is the first
+// of the stack (3x3 / stride 1 / pad 1, <= 48 weight columns: 4 frames x 9 taps), the dX band this kernel assembles
+// in LDS is exactly the dOut tile its weight gradient needs, and nothing else reads dX.  The band is masked in place,
+// multiplied against the band's input rows (prefetched like dOut: fw.x) on the matrix cores, and never leaves the
+// chip: 2 x Cin*H*W*4 bytes per sample (GRUModel/ConvModel: 903 KB of the 2.1 MB the two separate passes moved)
+// and one launch saved.  Per-workgroup partials of dW / db go to fw.slab for wgrad_reduce_kernel.
+struct FuseW1P {
+  const float* x; long x_bs;                 // the lower layer's input (B, Cin1, H, W) and its sample stride
+  float* slab;                               // [grid][Cout1*K1 + Cout1], Cout1 = this layer's Cin
+  int Cin1, K1, WPx, PLANEx, TIHx, xoff;     // LDS image of the band's input rows (TIHx = TY + 2 rows of W + 2 columns) at lds + xoff
+};
+constexpr int NIX = 4;                       // float4 prefetch slots of the input rows per thread
+
+template <int MT, int VEC, int PFB2, bool W1 = false>
+__global__ __launch_bounds__(256) void bwd_band2_kernel(BwdBand2P pp, FuseW1P fw) {
+  constexpr int PFM = W1 ? PFM2_W1 : PFM2;       // mask prefetch slots per thread
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BwdBandP& p = pp.b;
   float* __restrict__ frag = lds;                          // [nfrag]
@@ -1750,21 +1765,43 @@ __global__ __launch_bounds__(256) void bwd_band2_kernel(BwdBand2P pp) {
   const long total = (long)p.B * p.bands;
   for (int i = tid; i < pp.nfrag; i += 256) frag[i] = p.wfrag[i];
   stage_zero(p.st, img);
+  // ---- fused lower-layer weight gradient: input-row image, prefetch slots, this lane's k offsets, accumulators
+  float* __restrict__ xt = lds + (W1 ? fw.xoff : 0);
+  int dxs[W1 ? NIX : 1];
+  float4 vx[W1 ? NIX : 1];
+  int koff1[3];
+  f32x4 acc1[3];
+  float dbacc1 = 0.f;
+  if (W1) {
+    for (int i = tid; i < fw.Cin1 * fw.PLANEx + 64; i += 256) xt[i] = 0.f;
+    const int nvx = p.W >> 2, totx = fw.Cin1 * fw.TIHx * nvx;
+#pragma unroll
+    for (int u = 0; u < NIX; ++u) {
+      const int idx = tid + u * 256;
+      const int rt = idx / nvx, c = rt / fw.TIHx;
+      dxs[u] = idx < totx ? (c << 16) | ((rt - c * fw.TIHx) << 8) | (idx - rt * nvx) : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int k = q * 16 + j;
+      int o = 0;
+      if (k < fw.K1) {
+        const int ci = k / 9, rem = k - ci * 9, ky = rem / 3;
+        o = ci * fw.PLANEx + ky * fw.WPx + (rem - ky * 3);
+      }
+      koff1[q] = o + g;                                   // + pixel (4*c4 + g) of the step
+      acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
   // this thread's slots of the dOut band image: (plane c, image row r, VEC floats at column x)
   const int nv = p.st.IW / VEC;
   const int tot_v = p.st.Cp * p.st.TIH * nv;
-  int dst[PFB2], srcoff[PFB2], rrow[PFB2];
+  int dsc[PFB2];                  // (plane << 20) | (row << 10) | vector index, -1 = none
 #pragma unroll
   for (int u = 0; u < PFB2; ++u) {
     const int idx = tid + u * 256;
-    dst[u] = -1; srcoff[u] = 0; rrow[u] = 0;
-    if (idx < tot_v) {
-      const int rt = idx / nv, x = (idx - rt * nv) * VEC;
-      const int c = rt / p.st.TIH, r = rt - c * p.st.TIH;
-      dst[u] = c * PLANE + r * WP + x - p.st.sx0;
-      srcoff[u] = (c * p.st.IH + r) * p.st.IW + x;
-      rrow[u] = r;
-    }
+    const int rt = idx / nv, c = rt / p.st.TIH;
+    dsc[u] = idx < tot_v ? (c << 20) | ((rt - c * p.st.TIH) << 10) | (idx - rt * nv) : -1;
   }
   float pf[PFB2][VEC];
   auto issue = [&](long tile) {
@@ -1776,12 +1813,22 @@ __global__ __launch_bounds__(256) void bwd_band2_kernel(BwdBand2P pp) {
     for (int u = 0; u < PFB2; ++u) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) pf[u][e] = 0.f;
-      const int ys = oy_lo + rrow[u];
-      if (dst[u] >= 0 && ys >= 0 && ys < p.st.IH) {
-        const float* q = base + srcoff[u];
+      const int r = (dsc[u] >> 10) & 1023, ys = oy_lo + r;
+      if (dsc[u] >= 0 && ys >= 0 && ys < p.st.IH) {
+        const float* q = base + ((long)(dsc[u] >> 20) * p.st.IH + r) * p.st.IW + (dsc[u] & 1023) * VEC;
         if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(q); pf[u][0] = t.x; pf[u][1] = t.y; pf[u][2] = t.z; pf[u][3] = t.w; }
         else if (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(q); pf[u][0] = t.x; pf[u][1] = t.y; }
         else pf[u][0] = q[0];
+      }
+    }
+    if (W1) {      // the lower layer's input rows Y0-1 .. Y0+TY of every plane
+      const float* __restrict__ xb = fw.x + b * fw.x_bs;
+#pragma unroll
+      for (int u = 0; u < NIX; ++u) {
+        vx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int ys = Y0 - 1 + ((dxs[u] >> 8) & 255);
+        if (dxs[u] >= 0 && ys >= 0 && ys < p.H)
+          vx[u] = *reinterpret_cast<const float4*>(xb + ((long)(dxs[u] >> 16) * p.H + ys) * p.W + ((dxs[u] & 255) << 2));
       }
     }
   };
@@ -1795,19 +1842,28 @@ __global__ __launch_bounds__(256) void bwd_band2_kernel(BwdBand2P pp) {
     __syncthreads();                       // readers of the previous band (image and dX band) are done
 #pragma unroll
     for (int u = 0; u < PFB2; ++u)
-      if (dst[u] >= 0) {
+      if (dsc[u] >= 0) {
+        float* d = img + (dsc[u] >> 20) * PLANE + ((dsc[u] >> 10) & 1023) * WP + (dsc[u] & 1023) * VEC - p.st.sx0;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) img[dst[u] + e] = pf[u][e];
+        for (int e = 0; e < VEC; ++e) d[e] = pf[u][e];
       }
+    if (W1) {
+#pragma unroll
+      for (int u = 0; u < NIX; ++u)
+        if (dxs[u] >= 0) {
+          float* d = xt + (dxs[u] >> 16) * fw.PLANEx + ((dxs[u] >> 8) & 255) * fw.WPx + ((dxs[u] & 255) << 2) + 1;
+          d[0] = vx[u].x; d[1] = vx[u].y; d[2] = vx[u].z; d[3] = vx[u].w;
+        }
+    }
     __syncthreads();
     if (tile + gridDim.x < total) issue(tile + gridDim.x);
     // the ReLU-derivative mask of THIS band: in flight during the matrix phase, consumed by the flush
     const int per = rowsY * p.W;
-    float4 mk[PFM2];
+    float4 mk[PFM];
     if (pp.mask_pf && p.mask) {
       const int per4 = per >> 2, n4 = p.Cin * per4;
 #pragma unroll
-      for (int u = 0; u < PFM2; ++u) {
+      for (int u = 0; u < PFM; ++u) {
         const int i = tid + u * 256;
         mk[u] = make_float4(1.f, 1.f, 1.f, 1.f);
         if (i < n4) {
@@ -1884,7 +1940,7 @@ __global__ __launch_bounds__(256) void bwd_band2_kernel(BwdBand2P pp) {
     if (pp.mask_pf) {        // rows are 16-B multiples: one float4 per slot, mask already in registers
       const int per4 = per >> 2, n4 = p.Cin * per4;
 #pragma unroll
-      for (int u = 0; u < PFM2; ++u) {
+      for (int u = 0; u < PFM; ++u) {
         const int i = tid + u * 256;
         if (i < n4) {
           const int ch = i / per4, e = (i - ch * per4) << 2;
@@ -1895,7 +1951,46 @@ __global__ __launch_bounds__(256) void bwd_band2_kernel(BwdBand2P pp) {
             if (!(mk[u].z > 0.f)) v.z = 0.f;
             if (!(mk[u].w > 0.f)) v.w = 0.f;
           }
-          *reinterpret_cast<float4*>(p.din + ((b * p.Cin + ch) * (long)p.H + Y0) * p.W + e) = v;
+          if (W1) *reinterpret_cast<float4*>(outb + ch * p.TY * p.W + e) = v;         // masked in place: it stays on chip
+          else *reinterpret_cast<float4*>(p.din + ((b * p.Cin + ch) * (long)p.H + Y0) * p.W + e) = v;
+        }
+      }
+      if (W1) {
+        __syncthreads();
+        {  // bias gradient of the lower layer: channel = tid & 15, 16 interleaved parts, four reads in flight
+          const float* __restrict__ pl = outb + (tid & 15) * p.TY * p.W;
+          const int part = tid >> 4;
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+          int i = part;
+          for (; i + 48 < per; i += 64) { s0 += pl[i]; s1 += pl[i + 16]; s2 += pl[i + 32]; s3 += pl[i + 48]; }
+          for (; i < per; i += 16) s0 += pl[i];
+          if ((tid & 15) < p.Cin) dbacc1 += (s0 + s1) + (s2 + s3);
+        }
+        // dW1[co][k] += sum over the band's pixels of dX[co][y][x] * x[ci][y+ky-1][x+kx-1]: 4 pixels per MFMA step,
+        // the band's rowsY * W/4 steps in four contiguous runs (one per wave), operands read one step ahead
+        const int c4n = p.W >> 2, nsteps = rowsY * c4n;
+        const int s0 = (nsteps * w) >> 2, s1 = (nsteps * (w + 1)) >> 2;
+        int r = s0 / c4n, c4 = s0 - r * c4n;
+        float av, bv[3];
+        if (s0 < s1) {
+          av = outb[j * p.TY * p.W + r * p.W + 4 * c4 + g];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bv[q] = xt[koff1[q] + r * fw.WPx + 4 * c4];
+        }
+        for (int s = s0; s < s1; ++s) {
+          if (++c4 == c4n) { c4 = 0; ++r; }
+          const bool more = s + 1 < s1;
+          const int rn = more ? r : 0, cn = more ? c4 : 0;
+          const float an = outb[j * p.TY * p.W + rn * p.W + 4 * cn + g];
+          float bn[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bn[q] = xt[koff1[q] + rn * fw.WPx + 4 * cn];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[q], acc1[q], 0, 0, 0);
+          av = an;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bv[q] = bn[q];
         }
       }
     } else {
@@ -1935,8 +2030,37 @@ __global__ __launch_bounds__(256) void bwd_band2_kernel(BwdBand2P pp) {
       }
     }
   }
+  if (W1) {      // per-workgroup partials: the four waves' tiles added in wave order, then the bias parts
+    __syncthreads();
+    float4* red4 = reinterpret_cast<float4*>(lds);              // [4 waves][3 k-tiles][64 lanes]
+#pragma unroll
+    for (int q = 0; q < 3; ++q) red4[(w * 3 + q) * 64 + lane] = make_float4(acc1[q][0], acc1[q][1], acc1[q][2], acc1[q][3]);
+    float* redb = lds + 4 * 3 * 64 * 4;                         // [16 parts][16 channels]
+    redb[(tid >> 4) * 16 + (tid & 15)] = dbacc1;
+    __syncthreads();
+    float* sl = fw.slab + (long)blockIdx.x * ((long)p.Cin * fw.K1 + p.Cin);
+    if (tid < 3 * 64) {
+      float4 sv = red4[tid];
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) {
+        const float4 t = red4[ww * 3 * 64 + tid];
+        sv.x += t.x; sv.y += t.y; sv.z += t.z; sv.w += t.w;
+      }
+      const int k = (tid >> 6) * 16 + (tid & 15), co = 4 * ((tid & 63) >> 4);
+      if (k < fw.K1) {
+        if (co < p.Cin) sl[(long)co * fw.K1 + k] = sv.x;
+        if (co + 1 < p.Cin) sl[(long)(co + 1) * fw.K1 + k] = sv.y;
+        if (co + 2 < p.Cin) sl[(long)(co + 2) * fw.K1 + k] = sv.z;
+        if (co + 3 < p.Cin) sl[(long)(co + 3) * fw.K1 + k] = sv.w;
+      }
+    }
+    if (tid < p.Cin) {
+      float sb = 0.f;
+      for (int q = 0; q < 16; ++q) sb += redb[q * 16 + tid];
+      sl[(long)p.Cin * fw.K1 + tid] = sb;
+    }
+  }
 }
-
 // "Row-run" weight-gradient kernel for the unpadded layers (ks = 2*S: 8x8/s4, 4x4/s2), software
 // pipelined like igemm_run_kernel.  kx = kxh*S + kxl: for a fixed (ci, ky, kxh) the S taps kxl are
 // S contiguous floats at column S*(ox + kxh), so ONE ds_read_b128 (b64) per lane yields the B
@@ -2703,22 +2827,21 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
 
 }  // extern "C"
 namespace {
-// Band kernels (bwd_band2_kernel / bwd_band_kernel) for one launch; ty_force > 0 fixes the band height (a multiple
-// of the stride), 0 = the tallest band inside the LDS budget.  BAND_NA: no band kernel fits this call.
 constexpr int BAND_NA = -1000;
-static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask,
-                           float* din, int B, int ty_force, a2c_stream_t stream) {
+// fills q for band height ty_force (> 0) or the tallest band inside the LDS budget (0); false: no such band
+static bool band_setup(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask, float* din,
+                       int B, int ty_force, BwdBandP& q, int& TIH, int& PLANEo) {
   const int S = d->stride, P = d->pad;
   // band kernel: all classes fused, dX band assembled in LDS and flushed coalesced
-  const int MTb = ceil_div(d->Cin, 16), c4n = d->Cout / 4;
-  BwdBandP q;
+  const int c4n = d->Cout / 4;
   q.din = din; q.mask = mask; q.wfrag = wprep_bwd;
   q.Cin = d->Cin; q.H = d->H; q.W = d->W; q.S = S; q.P = P; q.ks = d->ks; q.B = B; q.ncls = S * S; q.c4n = c4n;
   const int ox_lo = (P - (d->ks - 1)) >= 0 ? (P - (d->ks - 1)) / S : -((-(P - (d->ks - 1)) + S - 1) / S);
   const int ox_hi = (d->W - 1 + P) / S;
   q.ox_lo = ox_lo;
   const int WPo = ox_hi - ox_lo + 1;
-  int TY = 0, TIH = 0, PLANEo = 0;
+  int TY = 0;
+  TIH = 0; PLANEo = 0;
   for (int ty = S; ty <= ((d->H + S - 1) / S) * S; ty += S) {
     const int tih = (ty - 1 + d->ks - 1) / S + 2;
     const int plane = ((tih * WPo + 31) / 32) * 32 + 16;
@@ -2726,7 +2849,7 @@ static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const floa
     if (ty_force > 0 ? ty == ty_force : (bytes <= IGEMM_LDS_BUDGET || TY == 0)) { TY = ty; TIH = tih; PLANEo = plane; }
     if (ty_force > 0 ? ty >= ty_force : bytes > IGEMM_LDS_BUDGET) break;
   }
-  if (TY == 0) return BAND_NA;
+  if (TY == 0) return false;
   q.TY = TY; q.bands = ceil_div(d->H, TY); q.out_floats = d->Cin * TY * d->W;
   q.st.src = dout; q.st.bstride = (long)d->Cout * d->OH * d->OW; q.st.Cp = d->Cout; q.st.IH = d->OH; q.st.IW = d->OW;
   q.st.TIH = TIH; q.st.WP = WPo; q.st.PLANE = PLANEo; q.st.sx0 = ox_lo; q.st.fast = 0;
@@ -2743,6 +2866,20 @@ static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const floa
     k.PWc = (d->W - 1 + P - rx) >= 0 ? (d->W - 1 + P - rx) / S - k.p0 + 1 : 0;
     if (k.PWc < 0) k.PWc = 0;
   }
+  return true;
+}
+
+// Band kernels (bwd_band2_kernel / bwd_band_kernel) for one launch; ty_force > 0 fixes the band height (a multiple
+// of the stride), 0 = the tallest band inside the LDS budget.  BAND_NA: no band kernel fits this call.
+static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask,
+                           float* din, int B, int ty_force, a2c_stream_t stream) {
+  const int S = d->stride;
+  const int MTb = ceil_div(d->Cin, 16), c4n = d->Cout / 4;
+  BwdBandP q;
+  int TIH = 0, PLANEo = 0;
+  if (!band_setup(d, dout, wprep_bwd, mask, din, B, ty_force, q, TIH, PLANEo)) return BAND_NA;
+  const int TY = q.TY;
+  (void)S;
   {  // pipelined band kernel: fragments in LDS, next band's dOut and this band's mask in registers
     const size_t nfrag = a2c_conv2d_prep_floats(d, 1);
     const int vecs = q.st.vec;
@@ -2761,7 +2898,7 @@ static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const floa
         kf2 = (const void*)bwd_band2_kernel<1, V_, P_>;                                                                 \
         if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(kf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);    \
         const int grid2 = resident_grid(kf2, lds2, (long)B * q.bands);                                                  \
-        hipLaunchKernelGGL((bwd_band2_kernel<1, V_, P_>), dim3(grid2), dim3(256), lds2, st2, q2);                        \
+        hipLaunchKernelGGL((bwd_band2_kernel<1, V_, P_>), dim3(grid2), dim3(256), lds2, st2, q2, FuseW1P());                        \
         A2C_CHECK_LAUNCH();                                                                                             \
         return A2C_OK;                                                                                                  \
       }
@@ -2785,6 +2922,68 @@ static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const floa
     return A2C_OK;
   }
   return BAND_NA;
+}
+
+// ---- backward-data of layer 2 + weight gradient of layer 1 in one pass (bwd_band2_kernel<.., W1 = true>) ----------
+struct BandW1Plan { BwdBand2P q2; FuseW1P fw; int vec, pfb, grid; size_t lds; };
+
+// d2 = the upper layer (its dX is the lower layer's dOut), d1 = the lower (first) layer.  The band height is a fixed
+// rule (tallest band with two workgroups per CU), NOT tuned by timing: it partitions the sums of dW1.
+static bool plan_band_w1(const a2c_conv_desc* d2, const a2c_conv_desc* d1, int B, const float* dout, BandW1Plan& pl) {
+  // OPT-IN (A2C_FUSE_W1=1): measured on MI355X the fused pass is SLOWER than the two separate ones (GRUModel layers at
+  // N = 32 768: 21.7 vs 11.4 + 6.9 ms; ConvModel at N = 2 048: 3.0-4.1 vs 2.35 + 0.47 ms) although it moves 43 % fewer
+  // bytes: with the input-row prefetch, the k offsets and the extra accumulators it needs 250-300 VGPRs (one workgroup
+  // per CU), and the extra per-band phases (mask in place, barrier, bias partials, 3-MFMA steps) are latency-bound.
+  const char* on = getenv("A2C_FUSE_W1");
+  if (!on || on[0] != '1' || !desc_ok(d2) || !desc_ok(d1) || getenv("A2C_NO_BAND2")) return false;
+  if (d1->ks != 3 || d1->stride != 1 || d1->pad != 1 || d1->Cout != d2->Cin || d1->OH != d2->H || d1->OW != d2->W) return false;
+  if (d2->Cin > 16 || d1->Cin * 9 > 48 || d2->W % 4 || d2->stride * d2->stride > MAX_CLS || (d2->Cout / 4) % 2) return false;
+  const size_t nfrag = a2c_conv2d_prep_floats(d2, 1);
+  if (nfrag * 4 > 64 * 1024) return false;
+  const int S = d2->stride;
+  int best = 0;
+  for (int ty = S; ty <= ((d2->H + S - 1) / S) * S; ty += S) {
+    int TIH = 0, PLANEo = 0;
+    BwdBandP q;
+    if (!band_setup(d2, dout, nullptr, nullptr, nullptr, B, ty, q, TIH, PLANEo)) break;
+    const int vec = q.st.vec;
+    if (d2->OW % vec) break;
+    const long tot_v = (long)d2->Cout * TIH * (d2->OW / vec);
+    const int tihx = ty + 2, wpx = d2->W + 2;
+    const long planex = ((tihx * wpx + 31) / 32) * 32 + 16;
+    const long lds = 4L * ((long)nfrag + q.out_floats + (long)d2->Cout * PLANEo + 64 + d1->Cin * planex + 64);
+    if (tot_v > 256L * PFB2_MAX || (long)d2->Cin * ty * d2->W > 256L * PFM2_W1 * 4 ||
+        (long)d1->Cin * tihx * (d2->W / 4) > 256L * NIX || tihx > 255 || lds > env_kb("A2C_W1_LDS_KB", 80)) break;
+    best = ty;
+  }
+  if (!best) return false;
+  int TIH = 0, PLANEo = 0;
+  band_setup(d2, dout, nullptr, nullptr, nullptr, B, best, pl.q2.b, TIH, PLANEo);
+  pl.q2.nfrag = (int)nfrag; pl.q2.mask_pf = 1;
+  pl.vec = pl.q2.b.st.vec;
+  const long tot_v = (long)d2->Cout * TIH * (d2->OW / pl.vec);
+  pl.pfb = tot_v <= 256L * 8 ? 8 : tot_v <= 256L * 12 ? 12 : 16;
+  FuseW1P& fw = pl.fw;
+  fw.Cin1 = d1->Cin; fw.K1 = d1->Cin * 9; fw.TIHx = best + 2; fw.WPx = d2->W + 2;
+  fw.PLANEx = ((fw.TIHx * fw.WPx + 31) / 32) * 32 + 16;
+  fw.xoff = (int)nfrag + pl.q2.b.out_floats + d2->Cout * PLANEo + 64;
+  pl.lds = 4 * ((size_t)fw.xoff + (size_t)fw.Cin1 * fw.PLANEx + 64);
+  if (pl.lds < 4 * (4 * 3 * 64 * 4 + 256)) pl.lds = 4 * (4 * 3 * 64 * 4 + 256);       // end-of-kernel reduction scratch
+  return true;
+}
+
+#define BAND_W1_CASES(X) X(1, 8) X(1, 12) X(1, 16) X(2, 8) X(2, 12) X(2, 16) X(4, 8) X(4, 12) X(4, 16)
+static const void* band_w1_fn(int vec, int pfb) {
+#define W1_FN(V_, P_) if (vec == V_ && pfb == P_) return (const void*)bwd_band2_kernel<1, V_, P_, true>;
+  BAND_W1_CASES(W1_FN)
+#undef W1_FN
+  return nullptr;
+}
+static int band_w1_grid(BandW1Plan& pl, int B) {
+  const void* k = band_w1_fn(pl.vec, pl.pfb);
+  if (!k) return 0;
+  if (pl.lds > 64 * 1024) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  return resident_grid(k, pl.lds, (long)B * pl.q2.b.bands);
 }
 
 // The band height changes the tiling only (every dX element keeps its tap / channel summation order), so the
@@ -2920,6 +3119,46 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
     const int rc = launch_igemm(p, ceil_div(d->Cin, 16), a2c_s(stream));
     if (rc != A2C_OK) return rc;
   }
+  return A2C_OK;
+}
+
+size_t a2c_conv2d_bwd_data_w1_ws_bytes(const a2c_conv_desc* d2, const a2c_conv_desc* d1, int B) {
+  BandW1Plan pl;
+  if (B < 1 || !plan_band_w1(d2, d1, B, nullptr, pl)) return 0;
+  // the vector width of the dOut staging depends on the pointer alignment, known at launch only: size for any of them
+  int grid = 0;
+  for (int v : {1, 2, 4}) {
+    if (d2->OW % v) continue;
+    pl.vec = v;
+    const int g = band_w1_grid(pl, B);
+    if (g > grid) grid = g;
+  }
+  return (size_t)grid * ((size_t)d1->Cout * d1->Cin * 9 + d1->Cout) * sizeof(float);
+}
+
+int a2c_conv2d_bwd_data_w1(const a2c_conv_desc* d2, const float* dout, const float* wprep_bwd, const float* mask,
+                           const a2c_conv_desc* d1, const float* x, int64_t x_bstride, float* dW1, float* db1, int B,
+                           void* ws, size_t ws_bytes, a2c_stream_t stream) {
+  if (B < 1 || !dout || !wprep_bwd || !mask || !x || !dW1 || !db1) return A2C_ERR_ARG;
+  BandW1Plan pl;
+  if (((uintptr_t)mask % 16) || ((uintptr_t)x % 16) || x_bstride % 4 || !plan_band_w1(d2, d1, B, dout, pl)) return A2C_ERR_ARG;
+  pl.q2.b.wfrag = wprep_bwd; pl.q2.b.mask = mask; pl.q2.b.din = nullptr;
+  pl.fw.x = x; pl.fw.x_bs = x_bstride; pl.fw.slab = (float*)ws;
+  const int grid = band_w1_grid(pl, B);
+  const size_t per = (size_t)d1->Cout * pl.fw.K1 + d1->Cout;
+  if (grid < 1) return A2C_ERR_ARG;
+  if (!ws || ws_bytes < (size_t)grid * per * sizeof(float)) return A2C_ERR_WORKSPACE;
+  hipStream_t st = a2c_s(stream);
+#define W1_LAUNCH(V_, P_)                                                                                         \
+  if (pl.vec == V_ && pl.pfb == P_)                                                                               \
+    hipLaunchKernelGGL((bwd_band2_kernel<1, V_, P_, true>), dim3(grid), dim3(256), pl.lds, st, pl.q2, pl.fw);
+  BAND_W1_CASES(W1_LAUNCH)
+#undef W1_LAUNCH
+  A2C_CHECK_LAUNCH();
+  const long nW = (long)d1->Cout * pl.fw.K1;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d((long)per, 256)), dim3(256), 0, st, (const float*)ws, grid,
+                     (long)per, nW, dW1, db1);
+  A2C_CHECK_LAUNCH();
   return A2C_OK;
 }
 

@@ -425,6 +425,51 @@ def test_conv2d_fwd_bwd(spec):
     close("bwd_bias", db, br.grad, 1e-5 * float(br.grad.abs().max()), 1e-5)
 
 
+@pytest.mark.parametrize("s2,hw,B", [(2, (84, 84), 5), (1, (84, 84), 3), (2, (20, 24), 37), (1, (12, 16), 300)])
+def test_conv2d_bwd_data_fused_with_first_layer_weight_gradient(s2, hw, B, monkeypatch):
+    """conv1 (4 -> 16, 3x3/1/1) + ReLU + conv2 (16 -> 24, 3x3/s2 (GRUModel) or s1 (ConvModel)): da1 = conv2's masked
+    input gradient only feeds conv1's weight gradient (models.py:196-215), so a2c_conv2d_bwd_data_w1 keeps it on
+    chip.  Against torch autograd of the two-layer stack in fp64, and against the two separate C-ABI calls.
+    Opt-in (A2C_FUSE_W1=1): measured slower than the two passes on MI355X."""
+    ops = _ops()
+    monkeypatch.setenv("A2C_FUSE_W1", "1")
+    H, W = hw
+    d1 = ops.conv_desc(4, H, W, 16, 3, 1, 1)
+    d2 = ops.conv_desc(16, H, W, 24, 3, s2, 1)
+    nb = ops.conv_bwd_data_w1_ws_bytes(d2, d1, B)
+    assert nb > 0
+    x = rnd((B, 4, H, W), 60, 0, 1)
+    w1 = rnd((16, 4, 3, 3), 61) / 6.0
+    b1 = rnd((16,), 62) * 0.1
+    w2 = rnd((24, 16, 3, 3), 63) / 12.0
+    w1r, b1r = w1.double().requires_grad_(True), b1.double().requires_grad_(True)
+    a1 = F.relu(F.conv2d(x.double(), w1r, b1r, stride=1, padding=1))
+    y = F.conv2d(a1, w2.double(), None, stride=s2, padding=1)
+    gy = rnd(tuple(y.shape), 64)
+    y.backward(gy.double())
+    xd, w2d, dout = x.to(DEV), w2.to(DEV), gy.contiguous().to(DEV)
+    a1d = a1.detach().float().to(DEV)                     # the mask: conv1's ReLU output
+    wb = torch.empty(ops.conv_prep_floats(d2, 1), device=DEV)
+    ops.conv_prep(d2, 1, w2d, wb)
+    dW1 = torch.full((16, 4, 3, 3), float("nan"), device=DEV)
+    db1 = torch.full((16,), float("nan"), device=DEV)
+    ws = torch.empty(nb // 4, device=DEV)
+    ops.conv_bwd_data_w1(d2, dout, wb, a1d, d1, xd.data_ptr(), 4 * H * W, dW1, db1, B, ws)
+    sw, sb = float(w1r.grad.abs().max()), float(b1r.grad.abs().max())
+    close("fused dW1", dW1, w1r.grad, 1e-5 * sw, 1e-5)
+    close("fused db1", db1, b1r.grad, 1e-5 * sb, 1e-5)
+    # the two separate passes
+    da1 = torch.empty(B, 16, H, W, device=DEV)
+    ops.conv_bwd_data(d2, dout, wb, a1d, da1, B)
+    dW1s, db1s = torch.empty_like(dW1), torch.empty_like(db1)
+    ws2 = torch.empty(ops.conv_bwd_weight_ws_bytes(d1, B) // 4, device=DEV)
+    ops.conv_bwd_weight(d1, xd.data_ptr(), 4 * H * W, da1, dW1s, db1s, B, ws2)
+    close("fused vs separate dW1", dW1, dW1s, 2e-6 * sw, 1e-5)
+    close("fused vs separate db1", db1, db1s, 2e-6 * sb, 1e-5)
+    # layers it does not apply to report 0 (callers fall back to the two passes)
+    assert ops.conv_bwd_data_w1_ws_bytes(ops.conv_desc(24, 42, 42, 32, 3, 2, 1), ops.conv_desc(16, 84, 84, 24, 3, 2, 1), B) == 0
+
+
 def test_conv2d_many_samples_persistent_grid():
     """more tiles than workgroups: exercises the grid-stride / persistent accumulation paths"""
     ops = _ops()

@@ -388,7 +388,12 @@ class Bench:
     def describe_ingest(self):
         if self.ingest == "device-tape":
             return "device-tape fp32 (frames pre-generated in HBM, rollout replayed as a hipGraph)"
-        mode = "zero-copy persistent rollout kernel" if self.runner._zero_copy_ok(self.net) else "hipMemcpyAsync per step"
+        if self.runner._zero_copy_ok(self.net):
+            mode = "zero-copy persistent rollout kernel"
+        elif self.ingest == "memcpy" or os.environ.get("A2C_NO_RELAY") == "1":
+            mode = "hipMemcpyAsync per step behind a host hand-off"
+        else:
+            mode = "per-step hipGraph segments; actions published and frames fetched by the device, a2c_pool_publish_actions / a2c_pool_ingest"
         return (f"host-pinned uint8 ({mode}; {self.pool.n_workers} {'native env threads' if self.env_workers == 'native' else 'env worker processes'}"
                 f" behind one pinned device-mapped region)")
 

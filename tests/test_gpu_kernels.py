@@ -470,6 +470,54 @@ def test_conv2d_bwd_data_fused_with_first_layer_weight_gradient(s2, hw, B, monke
     assert ops.conv_bwd_data_w1_ws_bytes(ops.conv_desc(24, 42, 42, 32, 3, 2, 1), ops.conv_desc(16, 84, 84, 24, 3, 2, 1), B) == 0
 
 
+@pytest.mark.parametrize("spec", [(16, 84, 84, 24, 3, 2, 1), (24, 42, 42, 32, 3, 2, 1), (32, 21, 21, 48, 3, 2, 1),
+                                  (16, 84, 84, 24, 3, 1, 1)], ids=str)
+def test_conv2d_tile_height_does_not_change_a_bit(spec, monkeypatch):
+    """The tile tuners (bwd_band_tuned / conv_fwd_tuned) pick band / tile heights by timing.  That is only sound
+    because the height changes the tiling and nothing else: every output element keeps its tap and channel order.
+    Forced heights / LDS budgets must therefore agree BIT FOR BIT (and the tuned call with them)."""
+    ops = _ops()
+    Cin, H, W, Cout, ks, s, p = spec
+    B = 40
+    d = ops.conv_desc(*spec)
+    x = rnd((B, Cin, H, W), 70, 0, 1).to(DEV)
+    w = (rnd((Cout, Cin, ks, ks), 71) / (Cin * ks * ks) ** 0.5).to(DEV)
+    bias = (rnd((Cout,), 72) * 0.1).to(DEV)
+    dout = rnd((B, Cout, d.OH, d.OW), 73).to(DEV)
+    wf = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
+    wb = torch.empty(ops.conv_prep_floats(d, 1), device=DEV)
+    ops.conv_prep(d, 0, w, wf)
+    ops.conv_prep(d, 1, w, wb)
+
+    def bwd():
+        din = torch.full((B, Cin, H, W), float("nan"), device=DEV)
+        ops.conv_bwd_data(d, dout, wb, x - 0.5, din, B)
+        return din
+
+    def fwd():
+        out = torch.full((B, Cout, d.OH, d.OW), float("nan"), device=DEV)
+        ops.conv_fwd(d, x.data_ptr(), Cin * H * W, wf, bias, True, out, B)
+        return out
+
+    monkeypatch.setenv("A2C_NO_TUNE", "1")
+    ref_b, ref_f = bwd(), fwd()
+    assert torch.isfinite(ref_b).all() and torch.isfinite(ref_f).all()
+    for ty in (2, 4, 6, 10, 12):
+        monkeypatch.setenv("A2C_BAND_TY", str(ty))
+        assert torch.equal(bwd(), ref_b), ty
+    monkeypatch.delenv("A2C_BAND_TY")
+    for kb in (24, 32, 48, 96, 128):
+        monkeypatch.setenv("A2C_IGEMM_LDS_KB", str(kb))
+        monkeypatch.setenv("A2C_RUN3_LDS_KB", str(kb))
+        assert torch.equal(fwd(), ref_f), kb
+        assert torch.equal(bwd(), ref_b), kb
+    monkeypatch.delenv("A2C_IGEMM_LDS_KB")
+    monkeypatch.delenv("A2C_RUN3_LDS_KB")
+    monkeypatch.delenv("A2C_NO_TUNE")            # the tuned calls (large enough to be tuned: B * planes >= 2^24 / 2^16)
+    assert torch.equal(fwd(), ref_f) and torch.equal(fwd(), ref_f)
+    assert torch.equal(bwd(), ref_b) and torch.equal(bwd(), ref_b)
+
+
 def test_conv2d_many_samples_persistent_grid():
     """more tiles than workgroups: exercises the grid-stride / persistent accumulation paths"""
     ops = _ops()

@@ -1,6 +1,6 @@
 """print the kernel launch sequence (name, duration us, gap us) of a window of a rocprofv3 kernel trace: kseq.py <dir> <start> <count>"""
-import csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
+import csv, glob, os, sys
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 s, n = int(sys.argv[2]), int(sys.argv[3])
 if s < 0:

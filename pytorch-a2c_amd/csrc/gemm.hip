@@ -326,8 +326,8 @@ __global__ __launch_bounds__(64 * NW) void small_gemm_kernel(long M, long N, lon
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const long m0 = (long)blockIdx.y * 32, n0 = (long)blockIdx.x * 32;
-  const long kq = K / NW;                              // K % (8 * NW) == 0: the parts are multiples of 8
-  const long kbeg = w * kq, kend = kbeg + kq;
+  const long kq = ((K / 8 + NW - 1) / NW) * 8;         // K % 8 == 0: parts of whole 8-column groups, the last ones shorter
+  const long kbeg = min(K, w * kq), kend = min(K, kbeg + kq);
   const float* __restrict__ arow = A + min(m0 + li, M - 1) * lda + 4 * lk;
   f32x16 acc;
 #pragma unroll
@@ -792,10 +792,11 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   {  // small products: one launch, no slabs (see small_gemm_kernel)
     const long t128 = ((M + 127) / 128) * ((N + 127) / 128), t32 = ((M + 31) / 32) * ((N + 31) / 32);
     const bool vA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0), vB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
-    if (transA == 0 && K % 32 == 0 && K <= 4096 && t128 < 64 && t32 >= 16 && t32 <= 4096 && vA && (transB == 0 || vB) &&
+    if (transA == 0 && K % 8 == 0 && K >= 32 && K <= 4096 && t128 < 64 && t32 >= (K > 1024 ? 64 : 16) && t32 <= 4096 && vA &&
+        (transB == 0 || vB) &&
         !getenv("A2C_NO_SMALL_GEMM")) {
       dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
-      const bool deep = K >= 1024 && K % 64 == 0 && t32 <= 512;      // long K, few tiles: eight waves share it
+      const bool deep = K >= 1024 && t32 <= 512;                     // long K, few tiles: eight waves share it
       if (transB && deep) hipLaunchKernelGGL((small_gemm_kernel<true, 8>), grid, dim3(512), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
       else if (transB) hipLaunchKernelGGL((small_gemm_kernel<true, 4>), grid, dim3(256), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);
       else if (deep) hipLaunchKernelGGL((small_gemm_kernel<false, 8>), grid, dim3(512), 0, st0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate);

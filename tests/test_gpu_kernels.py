@@ -286,7 +286,7 @@ def _gemm_ref(A, B, tA, tB):
 
 @pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 3, 7), (128, 128, 16), (130, 257, 100), (256, 256, 2592), (300, 4, 256),
-                                   (3, 256, 1000), (200, 300, 256), (33, 95, 64), (256, 768, 288)])
+                                   (3, 256, 1000), (200, 300, 256), (33, 95, 64), (256, 768, 288), (32, 512, 2000), (70, 130, 40)])
 def test_gemm_f32(tA, tB, M, N, K):
     ops = _ops()
     A = rnd((K, M) if tA else (M, K), 80)

@@ -513,7 +513,27 @@ class ConvModel(_ConvStackNet):
         t = buf[o:o + rows * (cols or 1)]
         return t.view(rows, cols) if cols else t
 
-    def _fwd(self, x_ptr, bstride, B, tag, st, save, stash=None):
+    @property
+    def _fused_sampling(self):
+        """_fwd(..., sampler=(u, actions_ptr, act_stride)) samples inside the heads kernel (up to 7 actions)"""
+        return self.output_space + 1 <= 8 and os.environ.get("A2C_NO_FUSED_TAIL") != "1"
+
+    def _prep(self, st):
+        super()._prep(st)
+        # Inference-only: pi.2 and value.2 read the two halves of ONE hidden row (pi.0 | value.0 run as one GEMM), so
+        # both heads are one (A+1) x 2h skinny layer with zero blocks: [[pi.2.weight, 0], [0, value.2.weight]]
+        A, h = self.output_space, self.h_size
+        if A + 1 > 8:
+            return
+        if getattr(self, "_Whd", None) is None:
+            self._Whd = torch.zeros(A + 1, 2 * h, device=self._dev)
+            self._bhd = torch.zeros(A + 1, device=self._dev)
+        ops.copy_rows(self.P("pi.2.weight").data_ptr(), h, self._Whd.data_ptr(), 2 * h, A, h, st)
+        ops.copy_rows(self.P("value.2.weight").data_ptr(), h, self._Whd.data_ptr() + 4 * (A * 2 * h + h), 2 * h, 1, h, st)
+        ops.copy_rows(self.P("pi.2.bias").data_ptr(), A, self._bhd.data_ptr(), A, 1, A, st)
+        ops.copy_rows(self.P("value.2.bias").data_ptr(), 1, self._bhd.data_ptr() + 4 * A, 1, 1, 1, st)
+
+    def _fwd(self, x_ptr, bstride, B, tag, st, save, stash=None, sampler=None):
         ws, P = self.ws(tag), self.P
         A, h, ch = self.output_space, self.h_size, self.CONV_H
         acts = self._convs_train(x_ptr, bstride, B, ws, st) if (save and tag == "train") else \
@@ -521,9 +541,25 @@ class ConvModel(_ConvStackNet):
         e = ws.get("e", (B, ch))
         linear_fwd(ws, acts[-1][0], acts[-1][1], P("resize_emb.0.weight"), P("resize_emb.0.bias"), e, B, st, relu=True)
         hid = ws.get("hid", (B, 2 * h))
-        linear_fwd(ws, e.data_ptr(), ch, self._cat(self._arena.params, "pi.0.weight", 2 * h, ch),
-                   self._cat(self._arena.params, "pi.0.bias", 2 * h), hid, B, st, relu=True)
+        W0, b0 = self._cat(self._arena.params, "pi.0.weight", 2 * h, ch), self._cat(self._arena.params, "pi.0.bias", 2 * h)
         hb, logits, vals = self._heads(tag, B)
+        if sampler is not None and not save and self._fused_sampling:
+            # rollout step: the split-K slabs of the hidden layer are summed by the heads kernel itself -- slab sum +
+            # bias + ReLU, both heads (block matrix above) and the action sampling in ONE node instead of four
+            u, a_ptr, a_stride = sampler
+            sk = ops.pick_splitk(B, 2 * h, ch)
+            if sk > 1:
+                buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(B, 2 * h, sk))
+                with ops.span(f"linear.fwd {2 * h}x{ch}"):
+                    nslab = ops.gemm_partial(0, 1, B, 2 * h, ch, e.data_ptr(), ch, W0.data_ptr(), ch, sk, buf, st)
+                ops.heads_fused(buf.data_ptr(), nslab, B * 2 * h, 2 * h, b0, True, None, self._Whd, self._bhd, hb, B, u, A,
+                                a_ptr, a_stride, st)
+            else:
+                linear_fwd(ws, e.data_ptr(), ch, W0, b0, hid, B, st, relu=True)
+                ops.heads_fused(hid.data_ptr(), 1, 0, 2 * h, None, False, None, self._Whd, self._bhd, hb, B, u, A, a_ptr,
+                                a_stride, st)
+            return dict(logits=logits, vals=vals, sampled=True)
+        linear_fwd(ws, e.data_ptr(), ch, W0, b0, hid, B, st, relu=True)
         linear_fwd(ws, hid.data_ptr(), 2 * h, P("pi.2.weight"), P("pi.2.bias"), logits, B, st)
         linear_fwd(ws, hid.data_ptr() + 4 * h, 2 * h, P("value.2.weight"), P("value.2.bias"), hb[:, A:], B, st)
         return dict(logits=logits, vals=vals)
@@ -798,7 +834,11 @@ class GRUModel(_ConvStackNet, _GruMixin):
         linear_bwd_data(ws, de, self.P("resize_emb.0.weight"), dlast.view(B, -1), B, st, mask=a_last)
         self._convs_bwd(x_ptr, bstride, B, ws, st, dlast)
 
-    def _fwd(self, x_ptr, bstride, B, tag, st, save, h_in, stash=None):
+    @property
+    def _fused_sampling(self):
+        return self.output_space + 1 <= 8 and os.environ.get("A2C_NO_FUSED_TAIL") != "1"
+
+    def _fwd(self, x_ptr, bstride, B, tag, st, save, h_in, stash=None, sampler=None):
         ws = self.ws(tag)
         e = self._embed_fwd(x_ptr, bstride, B, ws, st, train=(save and tag == "train"), stash=stash)
         bufs = self._cell_bufs(ws, B)
@@ -807,6 +847,11 @@ class GRUModel(_ConvStackNet, _GruMixin):
         self._gru_fwd(ws, e, hin, B, st, bufs)
         hb, logits, vals = self._heads(tag, B)
         Wh, bh = self._head_w(self._arena.params)
+        if sampler is not None and not save and self._fused_sampling:      # rollout step: heads + sampling in one node
+            u, a_ptr, a_stride = sampler
+            ops.heads_fused(bufs["hn"].data_ptr(), 1, 0, self.h_size, None, False, None, Wh, bh, hb, B, u, self.output_space,
+                            a_ptr, a_stride, st)
+            return dict(logits=logits, vals=vals, h=bufs["hn"], sampled=True)
         linear_fwd(ws, bufs["hn"].data_ptr(), self.h_size, Wh, bh, hb, B, st)
         return dict(logits=logits, vals=vals, h=bufs["hn"])
 

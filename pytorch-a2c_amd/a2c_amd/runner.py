@@ -297,10 +297,10 @@ class Runner:
     def _forward(self, net, x_ptr, bstride, B, env0, st, sampler=None, stash=None):
         """stash = (bufs, row0, row_stride): conv-stack nets write this step's activations into the update's buffers"""
         kw = dict(stash=stash) if (stash is not None and isinstance(stash[0], list)) else {}
+        if sampler is not None and getattr(net, "_fused_sampling", False):
+            kw["sampler"] = sampler
         if net.is_recurrent:
             return net._fwd(x_ptr, bstride, B, "roll", st, False, h_in=self.h[env0:env0 + B], **kw)
-        if sampler is not None and getattr(net, "_fused_sampling", False):
-            return net._fwd(x_ptr, bstride, B, "roll", st, False, sampler=sampler)
         return net._fwd(x_ptr, bstride, B, "roll", st, False, **kw)
 
     def _zero_copy_ok(self, net):

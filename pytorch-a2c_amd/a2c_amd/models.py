@@ -842,8 +842,11 @@ class GRUModel(_ConvStackNet, _GruMixin):
         ws = self.ws(tag)
         e = self._embed_fwd(x_ptr, bstride, B, ws, st, train=(save and tag == "train"), stash=stash)
         bufs = self._cell_bufs(ws, B)
-        hin = ws.get("h_in", (B, self.h_size))
-        hin.copy_(h_in)
+        if save or not h_in.is_contiguous():       # the backward pass re-reads h_in from the workspace
+            hin = ws.get("h_in", (B, self.h_size))
+            hin.copy_(h_in)
+        else:                                      # rollout / eval: the caller's rows are read in place
+            hin = h_in
         self._gru_fwd(ws, e, hin, B, st, bufs)
         hb, logits, vals = self._heads(tag, B)
         Wh, bh = self._head_w(self._arena.params)

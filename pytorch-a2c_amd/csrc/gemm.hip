@@ -792,7 +792,7 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   {  // small products: one launch, no slabs (see small_gemm_kernel)
     const long t128 = ((M + 127) / 128) * ((N + 127) / 128), t32 = ((M + 31) / 32) * ((N + 31) / 32);
     const bool vA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0), vB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
-    if (transA == 0 && K % 8 == 0 && K >= 32 && K <= 4096 && t128 < 64 && t32 >= (K > 1024 ? 64 : 16) && t32 <= 4096 && vA &&
+    if (transA == 0 && K % 8 == 0 && K >= 32 && K <= 4096 && t128 < 64 && t32 >= (K > 1024 ? 128 : 16) && t32 <= 4096 && vA &&
         (transB == 0 || vB) &&
         !getenv("A2C_NO_SMALL_GEMM")) {
       dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));

@@ -572,6 +572,7 @@ class Runner:
             net._step(B, st, u=c["ub"][k, env0:env0 + B].data_ptr(), actions=a_ptr, act_stride=a_stride, **kw)
         else:
             hb, logits, vals = net._heads("roll", B)
+            h_row_done = False
             if k == 0:      # state of step 0 = the bookmark left by the previous slot (runner.py:190)
                 ops.copy_rows(bm.data_ptr(), S, sp(0), T * S, B, S, st)
             else:           # bookkeeping of env step k-1 + the next state (utils.next_state)
@@ -585,6 +586,14 @@ class Runner:
                     else:
                         ops.rollout_post(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t,
                                          slot0, gamma, pong, _Ptr(fr.ptr32), done, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
+                elif h is not None and HW % 4 == 0 and S % 4 == 0 and os.environ.get("A2C_NO_FUSED_POST") != "1":
+                    # recurrent nets: bookkeeping + frame stack + hidden-state reset + the h_states row in ONE launch
+                    hs = D["h_states"]
+                    hrow = hs.data_ptr() + 4 * (slot0 * T + k) * h.shape[1] if k < T else 0
+                    ops.rollout_post_rec(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t,
+                                         slot0, gamma, pong, fr.ptr32 or 0, fr.ptr8 or 0, fr.stride if fr.ptr8 else 0, done,
+                                         sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, done_eff, h, hrow, T * h.shape[1], st)
+                    h_row_done = True
                 else:
                     ops.rollout_record(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, done_eff,
                                        h, B, T, t, slot0, gamma, pong, st)
@@ -597,7 +606,7 @@ class Runner:
                 ops.rollout_bootstrap(out["vals"].data_ptr(), out["vals"].stride(0), val_prev, rewards, dones, deltas, B, T,
                                       slot0, gamma, st)
                 return
-            if h is not None:                                              # h_states[e] = h (runner.py:201)
+            if h is not None and not h_row_done:                            # h_states[e] = h (runner.py:201)
                 hs = D["h_states"]
                 ops.copy_rows(h.data_ptr(), h.shape[1], hs.data_ptr() + 4 * (slot0 * T + k) * h.shape[1], T * h.shape[1], B,
                               h.shape[1], st)

@@ -117,7 +117,19 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ rew
                                                    const uint8_t* __restrict__ frame_u8, long fstride,
                                                    const float* __restrict__ reset_mask, const float* __restrict__ prev,
                                                    long prev_stride, float* __restrict__ out, long out_stride, int B,
-                                                   int C, int HW) {
+                                                   int C, int HW, float* __restrict__ done_eff_out, float* __restrict__ h,
+                                                   int hdim, float* __restrict__ h_rows, long h_rows_stride) {
+  if ((int)blockIdx.z == C + 1) {      // recurrent nets (runner.py:201,219-221): h = 0 where the episode ended, then
+    if (blockIdx.x != 0) return;       // h_states[row] = h for the step that follows
+    const int b = blockIdx.y;
+    const bool d = (done[b] != 0.f) || (pong && rew[b] != 0.f);
+    for (int i = threadIdx.x; i < hdim; i += 256) {
+      const float v = d ? 0.f : h[(long)b * hdim + i];
+      if (d) h[(long)b * hdim + i] = 0.f;
+      if (h_rows) h_rows[(long)b * h_rows_stride + i] = v;
+    }
+    return;
+  }
   if ((int)blockIdx.z == C) {
     if (blockIdx.x != 0) return;
     const int b = blockIdx.y * 256 + threadIdx.x;
@@ -128,6 +140,7 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ rew
     if (pong && r != 0.f) d = 1.f;
     rewards[e] = r;
     dones[e] = d;
+    if (done_eff_out) done_eff_out[b] = d;
     const float v = val[b * vstride];
     if (t > 0) {
       const float pr = rewards[e - 1], pd = dones[e - 1];
@@ -356,7 +369,8 @@ static int rollout_post_any(const float* rew, const float* done, const float* va
                             float* rewards, float* dones, float* deltas, int64_t T, int64_t t, int64_t slot0, float gamma,
                             int pong, const float* frame_new, const uint8_t* frame_u8, int64_t fstride,
                             const float* reset_mask, const float* prev, int64_t prev_stride, float* out,
-                            int64_t out_stride, int B, int C, int HW, a2c_stream_t stream) {
+                            int64_t out_stride, int B, int C, int HW, a2c_stream_t stream, float* done_eff_out = nullptr,
+                            float* h = nullptr, int hdim = 0, float* h_rows = nullptr, int64_t h_rows_stride = 0) {
   if (B < 0 || T < 1 || t < 0 || t >= T || C < 1 || HW < 4 || HW % 4) return A2C_ERR_ARG;
   if (B == 0) return A2C_OK;
   if (!rew || !done || !val || !val_prev || !rewards || !dones || !deltas || (!frame_new && !frame_u8) || !out ||
@@ -365,11 +379,13 @@ static int rollout_post_any(const float* rew, const float* done, const float* va
   if (prev_stride % 4 || out_stride % 4 || (((uintptr_t)frame_new | (uintptr_t)prev | (uintptr_t)out) % 16))
     return A2C_ERR_ARG;
   if (frame_u8 && (fstride % 4 || (uintptr_t)frame_u8 % 4 || fstride < HW)) return A2C_ERR_ARG;
+  if (h && hdim < 1) return A2C_ERR_ARG;
   const int work = HW / 4;
-  dim3 grid((work + 255) / 256 > 8 ? 8 : (work + 255) / 256, B, C + 1);
+  dim3 grid((work + 255) / 256 > 8 ? 8 : (work + 255) / 256, B, C + (h ? 2 : 1));
   hipLaunchKernelGGL(post_kernel, grid, dim3(256), 0, a2c_s(stream), rew, done, val, (long)val_stride, val_prev, rewards,
                      dones, deltas, (long)T, (long)t, (long)slot0, gamma, pong, frame_new, frame_u8, (long)fstride,
-                     reset_mask, prev, (long)prev_stride, out, (long)out_stride, B, C, HW);
+                     reset_mask, prev, (long)prev_stride, out, (long)out_stride, B, C, HW, done_eff_out, h, hdim, h_rows,
+                     (long)h_rows_stride);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }
@@ -390,6 +406,18 @@ int a2c_rollout_post_u8(const float* rew, const float* done, const float* val, i
   if (!frame_u8 && B > 0) return A2C_ERR_ARG;
   return rollout_post_any(rew, done, val, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma, pong, nullptr,
                           frame_u8, frame_stride, reset_mask, prev, prev_stride, out, out_stride, B, C, HW, stream);
+}
+
+int a2c_rollout_post_rec(const float* rew, const float* done, const float* val, int64_t val_stride, float* val_prev,
+                         float* rewards, float* dones, float* deltas, int64_t T, int64_t t, int64_t slot0, float gamma,
+                         int pong, const float* frame_new, const uint8_t* frame_u8, int64_t frame_stride,
+                         const float* reset_mask, const float* prev, int64_t prev_stride, float* out, int64_t out_stride,
+                         int B, int C, int HW, float* done_eff_out, float* h, int hdim, float* h_rows,
+                         int64_t h_rows_stride, a2c_stream_t stream) {
+  if (B > 0 && (!h || (!frame_new == !frame_u8))) return A2C_ERR_ARG;
+  return rollout_post_any(rew, done, val, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma, pong, frame_new,
+                          frame_u8, frame_stride, reset_mask, prev, prev_stride, out, out_stride, B, C, HW, stream,
+                          done_eff_out, h, hdim, h_rows, h_rows_stride);
 }
 
 int a2c_rollout_bootstrap(const float* val_boot, int64_t val_stride, const float* val_prev, float* rewards,

@@ -845,8 +845,11 @@ class GRUModel(_ConvStackNet, _GruMixin):
         if save or not h_in.is_contiguous():       # the backward pass re-reads h_in from the workspace
             hin = ws.get("h_in", (B, self.h_size))
             hin.copy_(h_in)
-        else:                                      # rollout / eval: the caller's rows are read in place
+        else:                                      # rollout / eval: the caller's rows are read in place ...
             hin = h_in
+            if sampler is not None:                # ... and UPDATED in place by an action step (gru_out is elementwise
+                bufs = dict(bufs, hn=h_in)         # in h and nothing reads the old h after it); the bootstrap forward
+                                                   # (no sampler) must leave the hidden state alone (runner.py:236-245)
         self._gru_fwd(ws, e, hin, B, st, bufs)
         hb, logits, vals = self._heads(tag, B)
         Wh, bh = self._head_w(self._arena.params)

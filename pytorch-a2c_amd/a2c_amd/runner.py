@@ -365,7 +365,7 @@ class Runner:
             logits, vals = out["logits"], out["vals"]
             if not out.get("sampled", False):
                 ops.softmax_sample(logits, u, a_ptr, a_stride, B, net.output_space, st=st)
-            if h is not None:
+            if h is not None and out["h"].data_ptr() != h.data_ptr():      # (the GRU models update h in place)
                 ops.copy_rows(out["h"].data_ptr(), h.shape[1], h.data_ptr(), h.shape[1], B, h.shape[1], st)
             fr, rew, done, reset = self._env_step(pool, act, a_ptr, a_stride, env0, B, t, slot0, T, shift, acts_host_out, pong)
             nxt_ptr, nxt_stride = (sp(t + 1), T * S) if t + 1 < T else (bm.data_ptr(), S)
@@ -615,7 +615,7 @@ class Runner:
                                 stash=None if c["stash"] is None else (c["stash"], slot0 * T + k, T))
             if not out.get("sampled", False):
                 ops.softmax_sample(out["logits"], u, a_ptr, a_stride, B, net.output_space, st=st)
-            if h is not None:
+            if h is not None and out["h"].data_ptr() != h.data_ptr():      # (the GRU models update h in place)
                 ops.copy_rows(out["h"].data_ptr(), h.shape[1], h.data_ptr(), h.shape[1], B, h.shape[1], st)
         if c.get("relay"):      # the sampled actions go to the env workers: cmd granules of env step k
             ops.pool_publish_actions(pool.dev_cmd + 8 * env0, a_ptr, a_stride, B, self._seq_dev, k, st)

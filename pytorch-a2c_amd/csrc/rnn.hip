@@ -26,9 +26,9 @@ __global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void gru_out_kernel(const float* __restrict__ gx, const float* __restrict__ rhu,
-                                                      const float* __restrict__ b, const float* __restrict__ h,
+                                                      const float* __restrict__ b, const float* h,
                                                       const float* __restrict__ z, float* __restrict__ cnd,
-                                                      float* __restrict__ hn, long B, int hd) {
+                                                      float* hn, long B, int hd) {      // hn may alias h (in-place rollout step)
   const long n = B * hd;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
     const long row = i / hd;

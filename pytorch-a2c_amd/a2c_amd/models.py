@@ -444,7 +444,26 @@ class _ConvStackNet(_HipNet):
         if os.environ.get("A2C_NO_STASH") == "1":
             return None
         ws = self.ws("train")
-        return [ws.get(f"a{i}", (n_rows,) + l.out_shape) for i, l in enumerate(self._cl)]
+        bufs = [ws.get(f"a{i}", (n_rows,) + l.out_shape) for i, l in enumerate(self._cl)]
+        if self._E_STASH and os.environ.get("A2C_NO_EMB_STASH") != "1":
+            # + the embedding e = relu(resize_emb(features)) of every state (the rollout computed it too): the update's
+            # forward then also skips the flat_size -> e GEMM (ConvModel: 28224 -> 2000, 2.6 of its 16 ms)
+            bufs.append(ws.get("e", (n_rows, self._E_STASH())))
+        return bufs
+
+    _E_STASH = None      # subclasses: callable -> width of the "e" workspace rows
+
+    def _e_out(self, ws, B, stash):
+        """(B, width) tensor the rollout writes e into: rows of the update's workspace when the stash carries them"""
+        width = self._E_STASH()
+        if stash is not None and len(stash[0]) > len(self._cl):
+            bufs, row0, rstride = stash
+            return bufs[len(self._cl)][row0::rstride][:B]
+        return ws.get("e", (B, width))
+
+    def _e_stashed(self, x_ptr, B):
+        return (self._E_STASH is not None and os.environ.get("A2C_NO_EMB_STASH") != "1" and os.environ.get("A2C_NO_STASH") != "1"
+                and self._stash_valid(x_ptr, B))
 
     def _convs_train(self, x_ptr, bstride, B, ws, st):
         """conv stack of the update's forward: recomputed, or taken from the rollout's stash"""
@@ -482,6 +501,9 @@ class ConvModel(_ConvStackNet):
     _packed_after = ("value.0.weight", "value.0.bias")
     SPECS = [(16, 3, 1, 1), (24, 3, 1, 1), (32, 3, 2, 1), (64, 3, 2, 1)]
     CONV_H = 2000
+
+    def _E_STASH(self):
+        return self.CONV_H
 
     def __init__(self, input_space, output_space, h_size=288, bnorm=False, is_discrete=True, **kwargs):
         super().__init__()
@@ -538,8 +560,12 @@ class ConvModel(_ConvStackNet):
         A, h, ch = self.output_space, self.h_size, self.CONV_H
         acts = self._convs_train(x_ptr, bstride, B, ws, st) if (save and tag == "train") else \
             self._convs_fwd(x_ptr, bstride, B, ws, st, stash=stash)
-        e = ws.get("e", (B, ch))
-        linear_fwd(ws, acts[-1][0], acts[-1][1], P("resize_emb.0.weight"), P("resize_emb.0.bias"), e, B, st, relu=True)
+        if save and tag == "train" and self._e_stashed(x_ptr, B):
+            e = ws.get("e", (B, ch))                 # left here, row by row, by the rollout
+        else:
+            e = self._e_out(ws, B, stash)
+            linear_fwd(ws, acts[-1][0], acts[-1][1], P("resize_emb.0.weight"), P("resize_emb.0.bias"), e, B, st, relu=True)
+        lde = e.stride(0)
         hid = ws.get("hid", (B, 2 * h))
         W0, b0 = self._cat(self._arena.params, "pi.0.weight", 2 * h, ch), self._cat(self._arena.params, "pi.0.bias", 2 * h)
         hb, logits, vals = self._heads(tag, B)
@@ -551,15 +577,15 @@ class ConvModel(_ConvStackNet):
             if sk > 1:
                 buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(B, 2 * h, sk))
                 with ops.span(f"linear.fwd {2 * h}x{ch}"):
-                    nslab = ops.gemm_partial(0, 1, B, 2 * h, ch, e.data_ptr(), ch, W0.data_ptr(), ch, sk, buf, st)
+                    nslab = ops.gemm_partial(0, 1, B, 2 * h, ch, e.data_ptr(), lde, W0.data_ptr(), ch, sk, buf, st)
                 ops.heads_fused(buf.data_ptr(), nslab, B * 2 * h, 2 * h, b0, True, None, self._Whd, self._bhd, hb, B, u, A,
                                 a_ptr, a_stride, st)
             else:
-                linear_fwd(ws, e.data_ptr(), ch, W0, b0, hid, B, st, relu=True)
+                linear_fwd(ws, e.data_ptr(), lde, W0, b0, hid, B, st, relu=True)
                 ops.heads_fused(hid.data_ptr(), 1, 0, 2 * h, None, False, None, self._Whd, self._bhd, hb, B, u, A, a_ptr,
                                 a_stride, st)
             return dict(logits=logits, vals=vals, sampled=True)
-        linear_fwd(ws, e.data_ptr(), ch, W0, b0, hid, B, st, relu=True)
+        linear_fwd(ws, e.data_ptr(), lde, W0, b0, hid, B, st, relu=True)
         linear_fwd(ws, hid.data_ptr(), 2 * h, P("pi.2.weight"), P("pi.2.bias"), logits, B, st)
         linear_fwd(ws, hid.data_ptr() + 4 * h, 2 * h, P("value.2.weight"), P("value.2.bias"), hb[:, A:], B, st)
         return dict(logits=logits, vals=vals)
@@ -640,10 +666,10 @@ class _GruMixin:
         cat = getattr(self, "_WxC", None) is not None and os.environ.get("A2C_NO_GRU_CAT") != "1"
         if x is not None:   # gx may have been precomputed for all time steps at once
             if cat:
-                self._mm(ws, 0, 0, B, 3 * hd, xs, x.data_ptr(), xs, self._WxC.data_ptr(), 3 * hd, gx.data_ptr(), 3 * hd, st)
+                self._mm(ws, 0, 0, B, 3 * hd, xs, x.data_ptr(), x.stride(0), self._WxC.data_ptr(), 3 * hd, gx.data_ptr(), 3 * hd, st)
             else:
                 for g in range(3):
-                    self._mm(ws, 0, 0, B, hd, xs, x.data_ptr(), xs, Wx[g].data_ptr(), hd, gx.data_ptr() + 4 * g * hd, 3 * hd, st)
+                    self._mm(ws, 0, 0, B, hd, xs, x.data_ptr(), x.stride(0), Wx[g].data_ptr(), hd, gx.data_ptr() + 4 * g * hd, 3 * hd, st)
         if cat:
             self._mm(ws, 0, 0, B, 2 * hd, hd, h_in.data_ptr(), hd, self._WhC.data_ptr(), 2 * hd, gh.data_ptr(), 2 * hd, st)
         else:
@@ -819,10 +845,15 @@ class GRUModel(_ConvStackNet, _GruMixin):
 
     def _embed_fwd(self, x_ptr, bstride, B, ws, st, train=False, stash=None):
         acts = self._convs_train(x_ptr, bstride, B, ws, st) if train else self._convs_fwd(x_ptr, bstride, B, ws, st, stash=stash)
-        e = ws.get("e", (B, self.h_size))
+        if train and self._e_stashed(x_ptr, B):
+            return ws.get("e", (B, self.h_size))     # left here, row by row, by the rollout
+        e = self._e_out(ws, B, None if train else stash)
         linear_fwd(ws, acts[-1][0], acts[-1][1], self.P("resize_emb.0.weight"), self.P("resize_emb.0.bias"), e, B, st,
                    relu=True)
         return e
+
+    def _E_STASH(self):
+        return self.h_size
 
     def _embed_bwd(self, x_ptr, bstride, B, ws, st, de):
         """de: gradient wrt e (ReLU mask already applied)."""

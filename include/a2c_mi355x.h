@@ -143,6 +143,8 @@ int a2c_rollout_post_u8(const float *rew, const float *done, const float *val, i
 /* The same for recurrent nets, with the hidden-state handling of the step folded into the launch (runner.py:201,
  * 219-221): h[b] = 0 where the env step ended an episode (done, or the Pong override), done_eff_out[b] = that flag,
  * and, when h_rows != NULL, h_rows[b*h_rows_stride ..] = h[b] (the h_states row of the step that follows).
+ * h_src (NULL = h): where the previous step's cell left its new hidden rows (B, hdim); h = masked h_src, so a cell
+ * that writes h_new somewhere else (e.g. into the update's time-major buffers) needs no copy back.
  * Exactly one of frame_new (fp32) / frame_u8 is given.                                          */
 int a2c_rollout_post_rec(const float *rew, const float *done, const float *val, int64_t val_stride,
                          float *val_prev, float *rewards, float *dones, float *deltas, int64_t T,
@@ -150,7 +152,7 @@ int a2c_rollout_post_rec(const float *rew, const float *done, const float *val, 
                          const uint8_t *frame_u8, int64_t frame_stride, const float *reset_mask,
                          const float *prev, int64_t prev_stride, float *out, int64_t out_stride, int B,
                          int C, int HW, float *done_eff_out, float *h, int hdim, float *h_rows,
-                         int64_t h_rows_stride, a2c_stream_t stream);
+                         int64_t h_rows_stride, const float *h_src, a2c_stream_t stream);
 /* End of slot (runner.py:236-245): e = slot*T + T-1; if dones[e] == 0:
  * rewards[e] += gamma*val_boot[b], dones[e] = 1; then deltas[e] = rewards[e] - val_prev[b]. */
 int a2c_rollout_bootstrap(const float *val_boot, int64_t val_stride, const float *val_prev, float *rewards,

@@ -72,7 +72,7 @@ SIGNATURES = {
     "a2c_rollout_post": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_int, P, P, P, c_int64,
                                   P, c_int64, c_int, c_int, c_int, P]),
     "a2c_rollout_post_rec": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_int, P, P, c_int64, P, P,
-                             c_int64, P, c_int64, c_int, c_int, c_int, P, P, c_int, P, c_int64, P]),
+                             c_int64, P, c_int64, c_int, c_int, c_int, P, P, c_int, P, c_int64, P, P]),
     "a2c_rollout_post_u8": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_int, P, c_int64, P, P,
                                      c_int64, P, c_int64, c_int, c_int, c_int, P]),
     "a2c_rollout_bootstrap": (c_int, [P, c_int64, P, P, P, P, c_int, c_int64, c_int64, c_float, P]),

@@ -88,9 +88,9 @@ class _HipNet(nn.Module):
         self._stash_frames = None
 
     # ---- rollout -> update activation stash (models with a one-launch rollout step)
-    def stash_rows(self, states, n_rows):
+    def stash_rows(self, states, n_rows, T=None):
         """Buffers a rollout may fill with the conv activations of its states (row e of the rollout buffer ->
-        row e of the "train" workspace), or None when the model has no stash / it is disabled."""
+        row e of the "train" workspace), or None when the model has no stash / it is disabled.  T = n_tsteps."""
         return None
 
     def stash_commit(self, states, n_rows, frames=None):
@@ -268,7 +268,7 @@ class A3CModel(_HipNet):
         """_fwd(..., sampler=(u, actions_ptr, act_stride)) samples inside the heads kernel (up to 7 actions)"""
         return self.output_space + 1 <= 8
 
-    def stash_rows(self, states, n_rows):
+    def stash_rows(self, states, n_rows, T=None):
         """(a1, a2) buffers of the update's workspace for a rollout over all n_rows rows of `states`: the one-launch
         rollout step writes each state's conv activations there, and update_model's forward (updater.py:80; same
         weights, same states: training.py:150-165) reads them instead of recomputing 45 % of its FLOPs."""
@@ -395,6 +395,11 @@ class A3CModel(_HipNet):
             self._c1.bwd_weight(x_ptr, bstride, da1, G("convs.0.0.weight"), G("convs.0.0.bias"), B, ws, st)
 
 
+def h_is_lockstep(stash, B, R, T):
+    """stash = (bufs, row0, row_stride) of a rollout step that plays ALL R slots at once: rows t, t+T, t+2T, ..."""
+    return B == R and stash[2] == T and 0 <= stash[1] < T
+
+
 # ====================================================================== conv-stack models
 class _ConvStackNet(_HipNet):
     """Shared by ConvModel and GRUModel: a stack of 3x3 conv+ReLU blocks."""
@@ -437,7 +442,7 @@ class _ConvStackNet(_HipNet):
             acts.append((ptr, bs))
         return acts
 
-    def stash_rows(self, states, n_rows):
+    def stash_rows(self, states, n_rows, T=None):
         """per-layer (n_rows, C, H, W) activation buffers of the update's workspace: a rollout that covers all rows
         writes each state's conv activations straight into them and update_model's forward (updater.py:80; same
         weights, same states) skips the conv stack."""
@@ -449,6 +454,14 @@ class _ConvStackNet(_HipNet):
             # + the embedding e = relu(resize_emb(features)) of every state (the rollout computed it too): the update's
             # forward then also skips the flat_size -> e GEMM (ConvModel: 28224 -> 2000, 2.6 of its 16 ms)
             bufs.append(ws.get("e", (n_rows, self._E_STASH())))
+        self._cells_T = None
+        if T and hasattr(self, "gru") and hasattr(self, "_tm_bufs") and n_rows % T == 0 and os.environ.get("A2C_NO_CELL_STASH") != "1" \
+                and len(bufs) > len(self._cl) and self.output_space + 1 <= 8:
+            # BPTT (updater.py:139-169) re-runs every GRU cell of the slot with the weights and inputs the rollout
+            # just used: with all R slots played in lock-step the rollout's step t IS row t of the update's time-major
+            # buffers, so the cells (and the heads) write there and bptt_forward has nothing left to compute
+            self._cells_T, self._cells_R, self._cells_done = int(T), n_rows // int(T), -1
+            self._tm_bufs(ws, self._cells_R, int(T))
         return bufs
 
     _E_STASH = None      # subclasses: callable -> width of the "e" workspace rows
@@ -855,6 +868,28 @@ class GRUModel(_ConvStackNet, _GruMixin):
     def _E_STASH(self):
         return self.h_size
 
+    def _cell_stash_step(self, stash, B):
+        """time step whose cells a rollout step of B envs may write into the update's time-major buffers, or None"""
+        T = getattr(self, "_cells_T", None)
+        if T is None or stash is None or not getattr(self, "_cell_stash_ok", True) or not h_is_lockstep(stash, B, self._cells_R, T):
+            return None
+        return stash[1]
+
+    def _roll_outputs(self, stash, B):
+        """(vals_ptr, vals_ld, h_new_ptr) a rollout step with this stash tuple leaves behind, or None: the runner's next
+        segment reads the values / hidden rows from there (pointers are a pure function of the step: graph-safe)"""
+        t = self._cell_stash_step(stash, B)
+        if t is None:
+            return None
+        A, h = self.output_space, self.h_size
+        hb = self._heads("train", self._cells_R * self._cells_T)[0]
+        tm = self._tm_bufs(self.ws("train"), self._cells_R, self._cells_T)
+        return (hb.data_ptr() + 4 * (stash[1] * (A + 1) + A), stash[2] * (A + 1), tm["hn"][t].data_ptr())
+
+    def _cells_stashed(self, states, R, T):
+        return (getattr(self, "_cells_T", None) == T and getattr(self, "_cells_R", None) == R and
+                getattr(self, "_cells_done", -1) == T - 1 and self._stash_valid(states.data_ptr(), R * T))
+
     def _embed_bwd(self, x_ptr, bstride, B, ws, st, de):
         """de: gradient wrt e (ReLU mask already applied)."""
         last = self._cl[-1]
@@ -873,6 +908,19 @@ class GRUModel(_ConvStackNet, _GruMixin):
         ws = self.ws(tag)
         e = self._embed_fwd(x_ptr, bstride, B, ws, st, train=(save and tag == "train"), stash=stash)
         bufs = self._cell_bufs(ws, B)
+        t_cell = self._cell_stash_step(stash, B) if (sampler is not None and not save) else None
+        if t_cell is not None:
+            # this step of ALL slots = row t of the update's time-major buffers (see stash_rows)
+            tm = self._tm_bufs(self.ws("train"), self._cells_R, self._cells_T)
+            bufs = dict(bufs, **{k: tm[k][t_cell] for k in ("z", "r", "rh", "c", "hn")})
+            self._gru_fwd(ws, e, h_in, B, st, bufs)
+            hb_t = self._heads("train", self._cells_R * self._cells_T)[0][stash[1]::stash[2]][:B]
+            Wh, bh = self._head_w(self._arena.params)
+            u, a_ptr, a_stride = sampler
+            ops.heads_fused(bufs["hn"].data_ptr(), 1, 0, self.h_size, None, False, None, Wh, bh, hb_t, B, u, self.output_space,
+                            a_ptr, a_stride, st)
+            return dict(logits=hb_t[:, :self.output_space], vals=hb_t[:, self.output_space], h=bufs["hn"], sampled=True,
+                        h_next_src=bufs["hn"])
         if save or not h_in.is_contiguous():       # the backward pass re-reads h_in from the workspace
             hin = ws.get("h_in", (B, self.h_size))
             hin.copy_(h_in)
@@ -920,6 +968,13 @@ class GRUModel(_ConvStackNet, _GruMixin):
         e = self._embed_fwd(states.data_ptr(), states[0].numel(), N, ws, st, train=True)          # rollout-major (N,h)
         e_tm = ws.get("e_tm", (T, R, h))
         ops.permute_rows(e, e_tm, R, T, h, st)
+        if tag == "train" and self._cells_stashed(states, R, T):
+            # the rollout left z, r, rh, c, hn of every step in the time-major buffers and [logits | value] of every state
+            # in the heads rows; h_in[t] = the masked hidden state the rollout recorded in h_states (runner.py:201)
+            tm = self._tm_bufs(ws, R, T)
+            ops.permute_rows(h_states, tm["h_in"].view(N, h), R, T, h, st)
+            hb, logits, vals = self._heads(tag, N)
+            return vals, logits
         tm = self._bptt_cells_fwd(ws, e_tm, h_states, dones, R, T, st)
         heads_tm = ws.get("heads_tm", (N, A + 1))
         Wh, bh = self._head_w(self._arena.params)

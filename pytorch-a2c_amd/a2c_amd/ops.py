@@ -228,12 +228,12 @@ def rollout_post_u8(rew, done, val_ptr, val_stride, val_prev, rewards, dones, de
 
 def rollout_post_rec(rew, done, val_ptr, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma, pong, frame32_ptr,
                      frame_u8_ptr, frame_stride, reset_mask, prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW, done_eff, h,
-                     h_rows_ptr, h_rows_stride, st=None):
+                     h_rows_ptr, h_rows_stride, h_src_ptr=0, st=None):
     """rollout_post[_u8] + the recurrent nets' hidden-state reset / h_states row in the same launch"""
     check(lib().a2c_rollout_post_rec(_p(rew), _p(done), val_ptr, val_stride, _p(val_prev), _p(rewards), _p(dones), _p(deltas),
                                      T, t, slot0, float(gamma), int(bool(pong)), frame32_ptr, frame_u8_ptr, frame_stride,
                                      _p(reset_mask), prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW, _p(done_eff),
-                                     _p(h), h.shape[1], h_rows_ptr, h_rows_stride,
+                                     _p(h), h.shape[1], h_rows_ptr, h_rows_stride, h_src_ptr,
                                      st if st is not None else stream()), "a2c_rollout_post_rec")
 
 

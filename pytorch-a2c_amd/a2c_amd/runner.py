@@ -276,7 +276,7 @@ class Runner:
         self._stash_bufs = None
         self._frames_written = None
         if idxs == list(range(N // T_)) and N % T_ == 0:
-            self._stash_bufs = net.stash_rows(self.datas["states"], N)
+            self._stash_bufs = net.stash_rows(self.datas["states"], N, T=T_)
         j = 0
         while j < len(idxs):
             k = j
@@ -518,6 +518,10 @@ class Runner:
             if k < T and not relay:
                 torch.cuda.current_stream().synchronize()
                 self._host_env_step(pool, env0, B, k, slot0, T, shift, acts_host_out, pong)
+        ro = getattr(net, "_roll_outputs", None)
+        if ro and stash is not None and h is not None and self.HW % 4 == 0 and S % 4 == 0 and \
+                os.environ.get("A2C_NO_FUSED_POST") != "1" and ro((stash, slot0 * T, T), B) is not None:
+            net._cells_done = T - 1          # every step of every slot went through the cell stash (eagerly or replayed)
 
     def _segment(self, k, c):
         """device work of segment k (see _rollout_block_segmented); only enqueues, never waits on the host"""
@@ -572,6 +576,12 @@ class Runner:
             net._step(B, st, u=c["ub"][k, env0:env0 + B].data_ptr(), actions=a_ptr, act_stride=a_stride, **kw)
         else:
             hb, logits, vals = net._heads("roll", B)
+            # where segment k-1's forward left the values of its states and its new hidden rows: the roll buffers, or
+            # rows of the update's buffers (GRUModel's cell stash) -- a pure function of (net, k), safe under graph replay
+            ro = getattr(net, "_roll_outputs", None)
+            fused_post = h is not None and HW % 4 == 0 and S % 4 == 0 and os.environ.get("A2C_NO_FUSED_POST") != "1"
+            prev = ro((c["stash"], slot0 * T + k - 1, T), B) if (ro and c["stash"] is not None and k > 0 and fused_post) else None
+            v_ptr, v_ld, h_src = prev if prev else (vals.data_ptr(), vals.stride(0), 0)
             h_row_done = False
             if k == 0:      # state of step 0 = the bookmark left by the previous slot (runner.py:190)
                 ops.copy_rows(bm.data_ptr(), S, sp(0), T * S, B, S, st)
@@ -580,22 +590,23 @@ class Runner:
                 nxt_ptr, nxt_stride = (sp(k), T * S) if k < T else (bm.data_ptr(), S)
                 if h is None and HW % 4 == 0 and S % 4 == 0:
                     if fr.ptr8:
-                        ops.rollout_post_u8(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t,
+                        ops.rollout_post_u8(rew, done, v_ptr, v_ld, val_prev, rewards, dones, deltas, T, t,
                                             slot0, gamma, pong, fr.ptr8, fr.stride, done, sp(t), T * S, nxt_ptr, nxt_stride, B,
                                             C, HW, st)
                     else:
-                        ops.rollout_post(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t,
+                        ops.rollout_post(rew, done, v_ptr, v_ld, val_prev, rewards, dones, deltas, T, t,
                                          slot0, gamma, pong, _Ptr(fr.ptr32), done, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
-                elif h is not None and HW % 4 == 0 and S % 4 == 0 and os.environ.get("A2C_NO_FUSED_POST") != "1":
+                elif fused_post:
                     # recurrent nets: bookkeeping + frame stack + hidden-state reset + the h_states row in ONE launch
                     hs = D["h_states"]
                     hrow = hs.data_ptr() + 4 * (slot0 * T + k) * h.shape[1] if k < T else 0
-                    ops.rollout_post_rec(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, T, t,
+                    ops.rollout_post_rec(rew, done, v_ptr, v_ld, val_prev, rewards, dones, deltas, T, t,
                                          slot0, gamma, pong, fr.ptr32 or 0, fr.ptr8 or 0, fr.stride if fr.ptr8 else 0, done,
-                                         sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, done_eff, h, hrow, T * h.shape[1], st)
+                                         sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, done_eff, h, hrow, T * h.shape[1],
+                                         h_src_ptr=h_src, st=st)
                     h_row_done = True
                 else:
-                    ops.rollout_record(rew, done, vals.data_ptr(), vals.stride(0), val_prev, rewards, dones, deltas, done_eff,
+                    ops.rollout_record(rew, done, v_ptr, v_ld, val_prev, rewards, dones, deltas, done_eff,
                                        h, B, T, t, slot0, gamma, pong, st)
                     if fr.ptr8:
                         ops.frame_stack_push_u8(fr.ptr8, fr.stride, done, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
@@ -611,11 +622,14 @@ class Runner:
                 ops.copy_rows(h.data_ptr(), h.shape[1], hs.data_ptr() + 4 * (slot0 * T + k) * h.shape[1], T * h.shape[1], B,
                               h.shape[1], st)
             u = c["ub"][k, env0:env0 + B]
+            net._cell_stash_ok = fused_post            # the cell stash needs the fused post kernel (h_src) of the next segment
             out = self._forward(net, sp(k), T * S, B, env0, st, sampler=(u, a_ptr, a_stride),
                                 stash=None if c["stash"] is None else (c["stash"], slot0 * T + k, T))
             if not out.get("sampled", False):
                 ops.softmax_sample(out["logits"], u, a_ptr, a_stride, B, net.output_space, st=st)
-            if h is not None and out["h"].data_ptr() != h.data_ptr():      # (the GRU models update h in place)
+            if out.get("h_next_src") is not None:      # cell stash: the next segment's post kernel reads h_new from there
+                pass
+            elif h is not None and out["h"].data_ptr() != h.data_ptr():    # (the GRU models update h in place)
                 ops.copy_rows(out["h"].data_ptr(), h.shape[1], h.data_ptr(), h.shape[1], B, h.shape[1], st)
         if c.get("relay"):      # the sampled actions go to the env workers: cmd granules of env step k
             ops.pool_publish_actions(pool.dev_cmd + 8 * env0, a_ptr, a_stride, B, self._seq_dev, k, st)

@@ -117,15 +117,16 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ rew
                                                    const uint8_t* __restrict__ frame_u8, long fstride,
                                                    const float* __restrict__ reset_mask, const float* __restrict__ prev,
                                                    long prev_stride, float* __restrict__ out, long out_stride, int B,
-                                                   int C, int HW, float* __restrict__ done_eff_out, float* __restrict__ h,
-                                                   int hdim, float* __restrict__ h_rows, long h_rows_stride) {
+                                                   int C, int HW, float* __restrict__ done_eff_out, float* h,
+                                                   int hdim, float* __restrict__ h_rows, long h_rows_stride,
+                                                   const float* h_src) {
   if ((int)blockIdx.z == C + 1) {      // recurrent nets (runner.py:201,219-221): h = 0 where the episode ended, then
     if (blockIdx.x != 0) return;       // h_states[row] = h for the step that follows
     const int b = blockIdx.y;
     const bool d = (done[b] != 0.f) || (pong && rew[b] != 0.f);
-    for (int i = threadIdx.x; i < hdim; i += 256) {
-      const float v = d ? 0.f : h[(long)b * hdim + i];
-      if (d) h[(long)b * hdim + i] = 0.f;
+    for (int i = threadIdx.x; i < hdim; i += 256) {      // h_src: where the previous step left its new hidden rows
+      const float v = d ? 0.f : h_src[(long)b * hdim + i];
+      if (d || h_src != h) h[(long)b * hdim + i] = v;
       if (h_rows) h_rows[(long)b * h_rows_stride + i] = v;
     }
     return;
@@ -370,7 +371,8 @@ static int rollout_post_any(const float* rew, const float* done, const float* va
                             int pong, const float* frame_new, const uint8_t* frame_u8, int64_t fstride,
                             const float* reset_mask, const float* prev, int64_t prev_stride, float* out,
                             int64_t out_stride, int B, int C, int HW, a2c_stream_t stream, float* done_eff_out = nullptr,
-                            float* h = nullptr, int hdim = 0, float* h_rows = nullptr, int64_t h_rows_stride = 0) {
+                            float* h = nullptr, int hdim = 0, float* h_rows = nullptr, int64_t h_rows_stride = 0,
+                            const float* h_src = nullptr) {
   if (B < 0 || T < 1 || t < 0 || t >= T || C < 1 || HW < 4 || HW % 4) return A2C_ERR_ARG;
   if (B == 0) return A2C_OK;
   if (!rew || !done || !val || !val_prev || !rewards || !dones || !deltas || (!frame_new && !frame_u8) || !out ||
@@ -385,7 +387,7 @@ static int rollout_post_any(const float* rew, const float* done, const float* va
   hipLaunchKernelGGL(post_kernel, grid, dim3(256), 0, a2c_s(stream), rew, done, val, (long)val_stride, val_prev, rewards,
                      dones, deltas, (long)T, (long)t, (long)slot0, gamma, pong, frame_new, frame_u8, (long)fstride,
                      reset_mask, prev, (long)prev_stride, out, (long)out_stride, B, C, HW, done_eff_out, h, hdim, h_rows,
-                     (long)h_rows_stride);
+                     (long)h_rows_stride, h_src ? h_src : h);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }
@@ -413,11 +415,11 @@ int a2c_rollout_post_rec(const float* rew, const float* done, const float* val, 
                          int pong, const float* frame_new, const uint8_t* frame_u8, int64_t frame_stride,
                          const float* reset_mask, const float* prev, int64_t prev_stride, float* out, int64_t out_stride,
                          int B, int C, int HW, float* done_eff_out, float* h, int hdim, float* h_rows,
-                         int64_t h_rows_stride, a2c_stream_t stream) {
+                         int64_t h_rows_stride, const float* h_src, a2c_stream_t stream) {
   if (B > 0 && (!h || (!frame_new == !frame_u8))) return A2C_ERR_ARG;
   return rollout_post_any(rew, done, val, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma, pong, frame_new,
                           frame_u8, frame_stride, reset_mask, prev, prev_stride, out, out_stride, B, C, HW, stream,
-                          done_eff_out, h, hdim, h_rows, h_rows_stride);
+                          done_eff_out, h, hdim, h_rows, h_rows_stride, h_src);
 }
 
 int a2c_rollout_bootstrap(const float* val_boot, int64_t val_stride, const float* val_prev, float* rewards,

@@ -491,6 +491,30 @@ class Runner:
                    tuple(D[k].data_ptr() for k in sorted(D) if D[k].is_cuda))
             cache = self.__dict__.setdefault("_seg_graphs", {})
             graphs = cache.setdefault(key, [None] * (T + 1))
+        if graphs is not None and relay and os.environ.get("A2C_NO_SLOT_GRAPH") != "1":
+            # device relay: nothing happens on the host between the segments, so the WHOLE slot (T+1 segments, a few
+            # thousand kernel nodes) is ONE hipGraph -- first rollout eager (tuners), second captured, then replayed
+            whole = cache.setdefault(key + ("slot",), [None])
+            if whole[0] is None:
+                whole[0] = "warm"
+                for k in range(T + 1):
+                    self._segment(k, ctx)
+            else:
+                if whole[0] == "warm":
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            for k in range(T + 1):
+                                self._segment(k, ctx)
+                        whole[0] = g
+                    except Exception:      # noqa: BLE001 -- fall back to one graph per segment
+                        torch.cuda.synchronize()
+                        whole[0] = False
+                if whole[0]:
+                    whole[0].replay()
+            if whole[0] is not False:
+                self._mark_cells_done(net, stash, h, slot0, T, S, B)
+                return
         for k in range(T + 1):
             if graphs is None:
                 self._segment(k, ctx)
@@ -518,6 +542,9 @@ class Runner:
             if k < T and not relay:
                 torch.cuda.current_stream().synchronize()
                 self._host_env_step(pool, env0, B, k, slot0, T, shift, acts_host_out, pong)
+        self._mark_cells_done(net, stash, h, slot0, T, S, B)
+
+    def _mark_cells_done(self, net, stash, h, slot0, T, S, B):
         ro = getattr(net, "_roll_outputs", None)
         if ro and stash is not None and h is not None and self.HW % 4 == 0 and S % 4 == 0 and \
                 os.environ.get("A2C_NO_FUSED_POST") != "1" and ro((stash, slot0 * T, T), B) is not None:

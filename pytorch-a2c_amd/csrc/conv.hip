@@ -95,6 +95,9 @@ struct StageP {
   const float* src; long bstride;   // sample stride (floats)
   int Cp, IH, IW, TIH, WP, PLANE, sx0, fast;
   int vec;                          // widest aligned load for a source row: 4, 2 or 1 floats
+  int flat;                         // the tile is the WHOLE sample (one tile per sample): its Cp*IH*IW floats are one
+                                    // contiguous, 16-B aligned run whatever the row width -- float4 loads, scattered to
+                                    // the padded image per element (pad rows keep the zeros of stage_zero)
 };
 
 constexpr int STAGE_U = 8;          // independent loads in flight per thread
@@ -169,6 +172,32 @@ __device__ __forceinline__ void stage_tile(const StageP& s, float* __restrict__ 
 #pragma unroll
       for (int u = 0; u < STAGE_U; ++u)
         if (dst[u] >= 0) *reinterpret_cast<float4*>(lds + dst[u]) = v[u];
+    }
+  } else if (s.flat && s.vec != 4) {
+    const int hw = s.IH * s.IW, total4 = (s.Cp * hw) >> 2;
+    for (int i0 = tid; i0 < total4; i0 += 256 * STAGE_U) {
+      float4 v[STAGE_U];
+#pragma unroll
+      for (int u = 0; u < STAGE_U; ++u) {
+        const int idx = i0 + u * 256;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < total4) v[u] = reinterpret_cast<const float4*>(base)[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < STAGE_U; ++u) {
+        const int idx = i0 + u * 256;
+        if (idx < total4) {
+          const int e = idx << 2;
+          int c = e / hw, rem = e - c * hw;
+          int r = rem / s.IW, x = rem - r * s.IW;
+          const float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            lds[c * s.PLANE + (r - y_lo) * s.WP + x - s.sx0] = f[k];
+            if (++x == s.IW) { x = 0; if (++r == s.IH) { r = 0; ++c; } }
+          }
+        }
+      }
     }
   } else if (s.vec == 4) stage_rows<4>(s, lds, base, y_lo);
   else if (s.vec == 2) stage_rows<2>(s, lds, base, y_lo);
@@ -999,6 +1028,8 @@ static void fill_stage(StageP& s, const SrcTile& t, const float* src, long bstri
   s.fast = (t.sx0 == 0) && (t.sy0 >= 0) && (t.WP == t.IW) && (t.IW % 4 == 0) && (bstride % 4 == 0) &&
            ((uintptr_t)src % 16 == 0);
   s.vec = stage_vec(src, bstride, t.IH, t.IW);
+  s.flat = (t.tiles == 1 && t.sy0 <= 0 && t.TIH + t.sy0 >= t.IH && bstride % 4 == 0 && ((uintptr_t)src % 16 == 0) &&
+            ((long)t.Cp * t.IH * t.IW) % 4 == 0 && !getenv("A2C_NO_FLAT_STAGE")) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ backward-weight
@@ -2852,7 +2883,7 @@ static bool band_setup(const a2c_conv_desc* d, const float* dout, const float* w
   if (TY == 0) return false;
   q.TY = TY; q.bands = ceil_div(d->H, TY); q.out_floats = d->Cin * TY * d->W;
   q.st.src = dout; q.st.bstride = (long)d->Cout * d->OH * d->OW; q.st.Cp = d->Cout; q.st.IH = d->OH; q.st.IW = d->OW;
-  q.st.TIH = TIH; q.st.WP = WPo; q.st.PLANE = PLANEo; q.st.sx0 = ox_lo; q.st.fast = 0;
+  q.st.TIH = TIH; q.st.WP = WPo; q.st.PLANE = PLANEo; q.st.sx0 = ox_lo; q.st.fast = 0; q.st.flat = 0;
   q.st.vec = stage_vec(dout, q.st.bstride, d->OH, d->OW);
   for (int cls = 0; cls < S * S; ++cls) {
     const int ry = cls / S, rx = cls % S;

@@ -1711,7 +1711,33 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
     // coalesced flush of the band: rows Y0 .. Y0+rowsY of every channel are ONE contiguous run of
     // rowsY*W floats per channel; a wave takes a channel at a time (no per-element division), with
     // the widest vector the row pitch allows (W % 4 == 0: 16 B, W % 2 == 0: 8 B, else 4 B)
-    {
+    if (p.st.flat) {
+      // the band is the whole sample and TY == H: the dX block [Cin][H*W] is one contiguous 16-B aligned run in LDS,
+      // in HBM and in the mask, whatever the row width -- float4 everywhere, the mask words of a batch loaded first
+      const int n4 = (p.Cin * p.H * p.W) >> 2;
+      const long o0 = b * (long)p.Cin * p.H * p.W;
+      for (int i0 = tid; i0 < n4; i0 += 256 * STAGE_U) {
+        float4 mk4[STAGE_U];
+#pragma unroll
+        for (int u = 0; u < STAGE_U; ++u) {
+          const int i = i0 + u * 256;
+          mk4[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (p.mask && i < n4) mk4[u] = reinterpret_cast<const float4*>(p.mask + o0)[i];
+        }
+#pragma unroll
+        for (int u = 0; u < STAGE_U; ++u) {
+          const int i = i0 + u * 256;
+          if (i < n4) {
+            float4 v = reinterpret_cast<const float4*>(outb)[i];
+            if (!(mk4[u].x > 0.f)) v.x = 0.f;
+            if (!(mk4[u].y > 0.f)) v.y = 0.f;
+            if (!(mk4[u].z > 0.f)) v.z = 0.f;
+            if (!(mk4[u].w > 0.f)) v.w = 0.f;
+            reinterpret_cast<float4*>(p.din + o0)[i] = v;
+          }
+        }
+      }
+    } else {
       const int per = rowsY * p.W;
       const int vec = (p.W & 3) == 0 ? 4 : (p.W & 1) == 0 ? 2 : 1;
       for (int ch = w; ch < p.Cin; ch += 4) {
@@ -2881,9 +2907,13 @@ static bool band_setup(const a2c_conv_desc* d, const float* dout, const float* w
     if (ty_force > 0 ? ty >= ty_force : bytes > IGEMM_LDS_BUDGET) break;
   }
   if (TY == 0) return false;
+  if (TY > d->H) TY = d->H;        // one band = the whole sample: the dX block in LDS is laid out exactly like HBM
   q.TY = TY; q.bands = ceil_div(d->H, TY); q.out_floats = d->Cin * TY * d->W;
   q.st.src = dout; q.st.bstride = (long)d->Cout * d->OH * d->OW; q.st.Cp = d->Cout; q.st.IH = d->OH; q.st.IW = d->OW;
-  q.st.TIH = TIH; q.st.WP = WPo; q.st.PLANE = PLANEo; q.st.sx0 = ox_lo; q.st.fast = 0; q.st.flat = 0;
+  q.st.TIH = TIH; q.st.WP = WPo; q.st.PLANE = PLANEo; q.st.sx0 = ox_lo; q.st.fast = 0;
+  // one band = the whole sample (TY == H): dOut is staged and dX flushed as contiguous float4 runs (bwd_band_kernel)
+  q.st.flat = (TY == d->H && q.st.vec != 4 && ((long)d->Cout * d->OH * d->OW) % 4 == 0 && ((long)d->Cin * d->H * d->W) % 4 == 0 &&
+               ((uintptr_t)dout % 16 == 0) && !getenv("A2C_NO_FLAT_STAGE")) ? 1 : 0;
   q.st.vec = stage_vec(dout, q.st.bstride, d->OH, d->OW);
   for (int cls = 0; cls < S * S; ++cls) {
     const int ry = cls / S, rx = cls % S;
@@ -3044,8 +3074,9 @@ static int bwd_band_tuned(const a2c_conv_desc* d, const float* dout, const float
     const int S = d->stride;
     int best = 0;
     float best_ms = 0.f;
-    for (int ty = S; ty <= ((d->H + S - 1) / S) * S; ty += S) {
-      if (ty > 16 && ty % (4 * S)) continue;                       // coarser steps for tall bands
+    const int ty_all = ((d->H + S - 1) / S) * S;                    // one band = the whole sample
+    for (int ty = S; ty <= ty_all; ty += S) {
+      if (ty > 16 && ty % (4 * S) && ty != ty_all) continue;       // coarser steps for tall bands
       if (launch_bwd_band(d, dout, wprep_bwd, mask, din, B, ty, stream) != A2C_OK) { (void)hipGetLastError(); continue; }
       (void)hipEventRecord(e0, st);
       const int rc = launch_bwd_band(d, dout, wprep_bwd, mask, din, B, ty, stream);

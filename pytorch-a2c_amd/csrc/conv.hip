@@ -1042,6 +1042,7 @@ struct WgradP {
   int PLANEo;                     // dOut LDS plane stride (= 2 mod 32)
   int nkt;                        // ceil(K/16)
   int dvec;                       // dOut rows are 16 B aligned float4 streams
+  int dflat;                      // the tile is the whole sample: dOut (Cout*OH*OW floats) is ONE 16-B aligned run
 };
 
 // RS ("row split"): every wave owns ALL KTW = nkt k-tiles and the tile's pixel rows are dealt round-robin
@@ -1164,7 +1165,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
        // pad columns stay 0.  Flattened over all threads, 8 independent loads in flight each.
       const int per = rows * p.OW;
       const float* __restrict__ dsrc = p.dout + (b * p.Cout * p.OH + q0) * (long)p.OW;
-      if (p.dvec == 4) {       // OW % 4 == 0, 16 B aligned: a channel's rows are one float4 stream
+      if (p.dflat && p.dvec != 4) {      // whole sample, any row width: float4 loads, scattered to the padded planes
+        const int hw = p.OH * p.OW, tot4 = (p.Cout * hw) >> 2;
+        const float4* __restrict__ d4 = reinterpret_cast<const float4*>(p.dout + b * (long)p.Cout * hw);
+        for (int i0 = threadIdx.x; i0 < tot4; i0 += 256 * STAGE_U) {
+          float4 v[STAGE_U];
+#pragma unroll
+          for (int u = 0; u < STAGE_U; ++u) {
+            const int idx = i0 + u * 256;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < tot4) v[u] = d4[idx];
+          }
+#pragma unroll
+          for (int u = 0; u < STAGE_U; ++u) {
+            const int idx = i0 + u * 256;
+            if (idx < tot4) {
+              const int e = idx << 2;
+              int co = e / hw, rem = e - co * hw;
+              int r = rem / p.OW, x = rem - r * p.OW;
+              const float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                ldo[co * p.PLANEo + r * p.OWp + x] = f[k];
+                if (++x == p.OW) { x = 0; if (++r == p.OH) { r = 0; ++co; } }
+              }
+            }
+          }
+        }
+      } else if (p.dvec == 4) {       // OW % 4 == 0, 16 B aligned: a channel's rows are one float4 stream
         const int per4 = per >> 2, tot4 = p.Cout * per4;
         for (int i0 = threadIdx.x; i0 < tot4; i0 += 256 * STAGE_U) {
           float4 v[STAGE_U];
@@ -2604,7 +2632,7 @@ static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl, bool allow_
   plan_src(t, pl.MT * 16 * pl.OWp, pl.MT * 16 * 34, WGRAD_LDS_BUDGET);
   if (t.tiles > 1 && !getenv("A2C_WGRAD_LDS_KB")) {     // a small plane: the whole sample as ONE tile beats two uneven ones
     SrcTile t1 = t;
-    plan_src(t1, pl.MT * 16 * pl.OWp, pl.MT * 16 * 34, 80 * 1024);
+    plan_src(t1, pl.MT * 16 * pl.OWp, pl.MT * 16 * 34, 128 * 1024);     // (whole samples are staged as float4 runs)
     if (t1.tiles == 1) t = t1;
   }
   pl.pf = 0;
@@ -3315,6 +3343,8 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
   p.S = d->stride; p.sy0 = pl.t.sy0; p.TPH = pl.t.TPH; p.tiles = pl.t.tiles; p.B = B;
   p.PLANEo = pl.PLANEo; p.nkt = ceil_div(p.K, 16);
   p.dvec = ((d->OW % 4 == 0) && ((uintptr_t)dout % 16 == 0)) ? 4 : ((d->OW % 2 == 0) && ((uintptr_t)dout % 8 == 0)) ? 2 : 0;
+  p.dflat = (pl.t.tiles == 1 && ((long)d->Cout * d->OH * d->OW) % 4 == 0 && ((uintptr_t)dout % 16 == 0) &&
+             !getenv("A2C_NO_FLAT_STAGE")) ? 1 : 0;
 #define WGRAD_LAUNCH(...) launch_wgrad_t<__VA_ARGS__>(p, pl.grid, pl.lds, st)
   WGRAD_VARIANTS(WGRAD_LAUNCH)
 #undef WGRAD_LAUNCH

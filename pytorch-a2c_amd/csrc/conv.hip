@@ -334,6 +334,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p) {
       const long chs = (long)p.OHf * p.OWf;
       // a wave takes one channel at a time (no per-element division); 16 B vectors when the
       // launcher found every run aligned, else 4 B
+      if (p.out_vec == 2) {      // the tile is the whole sample: [Mch][OH*OW] is one contiguous 16-B aligned run
+        const int n4 = (p.Mch * NP) >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(ob)[i] = reinterpret_cast<const float4*>(sb)[i];
+      } else
       for (int co = w; co < p.Mch; co += 4) {
         float* __restrict__ oc = ob + co * chs;
         const float* __restrict__ sc = sb + co * p.TPH * p.PW;
@@ -1767,7 +1771,9 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
       }
     } else {
       const int per = rowsY * p.W;
-      const int vec = (p.W & 3) == 0 ? 4 : (p.W & 1) == 0 ? 2 : 1;
+      // a channel's band is one contiguous run: 16-B vectors when the run (not necessarily each row) is 16-B aligned
+      const bool run4 = (per & 3) == 0 && ((Y0 * p.W) & 3) == 0 && ((p.H * p.W) & 3) == 0 && ((p.TY * p.W) & 3) == 0;
+      const int vec = ((p.W & 3) == 0 || run4) ? 4 : (p.W & 1) == 0 ? 2 : 1;
       for (int ch = w; ch < p.Cin; ch += 4) {
         const long o0 = ((b * p.Cin + ch) * (long)p.H + Y0) * p.W;
         const float* __restrict__ sb = outb + ch * p.TY * p.W;
@@ -2849,6 +2855,9 @@ static int conv_fwd_impl(const a2c_conv_desc* d, const float* in, int64_t in_bst
   if (staged_out) {            // generic kernel: output tile assembled in LDS, flushed coalesced
     p.out_stage = t.Cp * t.PLANE + 64;
     p.out_vec = (d->OW % 4 == 0) && (out_bstride % 4 == 0) && (((long)d->OH * d->OW) % 4 == 0) && ((uintptr_t)out % 16 == 0);
+    if (!p.out_vec && t.tiles == 1 && t.TPH == d->OH && out_bstride % 4 == 0 && ((long)d->Cout * d->OH * d->OW) % 4 == 0 &&
+        ((uintptr_t)out % 16 == 0) && (p.out_stage % 4 == 0) && !getenv("A2C_NO_FLAT_STAGE"))
+      p.out_vec = 2;
   }
   if (run || run3) {   // generic kernel on a run-ordered layer: steps walk (c4, ky, kx)
     p.nb = d->ks; p.c4n = d->ks;                      // walker levels: outer c4, mid ky, inner kx

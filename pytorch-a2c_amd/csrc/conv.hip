@@ -1055,7 +1055,9 @@ struct WgradP {
 // NI > 0 ("prefetch"): the NEXT tile's input rows (NI float4 per thread) and dOut rows (ND float2 per
 // thread) are loaded into registers while the MFMA phase of the current tile runs, so a workgroup hides
 // its own HBM latency; each thread's (plane, row, vector) slots are tile-invariant and decoded once.
-template <int MT, int KTW, bool RS = false, int NI = 0, int ND = 0, bool EX = false>
+// VI / VD: floats per input / dOut prefetch slot (the widest load the row width allows: 84-wide rows 4 / 2,
+// 42-wide inputs 2, 21-wide dOut 1).
+template <int MT, int KTW, bool RS = false, int NI = 0, int ND = 0, bool EX = false, int VI = 4, int VD = 2>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   constexpr bool PF = NI > 0;
   constexpr bool BR = PF && MT * KTW < 18;      // bias gradient summed from the prefetch registers (when they are to spare)
@@ -1096,13 +1098,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   const int c4n = p.OWp >> 2;
   // prefetch slots: (plane << 16) | (row << 8) | vector, -1 = none
   int di[PF ? NI : 1], dd[PF ? ND : 1];
-  float4 vi[PF ? NI : 1];
-  float2 vd[PF ? ND : 1];
+  float vi[PF ? NI : 1][VI];
+  float vd[PF ? ND : 1][VD];
   float dbs[BR ? ND : 1];         // bias gradient: this thread's dOut slots, summed over its tiles
 #pragma unroll
   for (int u = 0; u < (BR ? ND : 1); ++u) dbs[u] = 0.f;
   if (PF) {
-    const int nv = p.st.IW >> 2, nvd = p.OW >> 1;
+    const int nv = p.st.IW / VI, nvd = p.OW / VD;
     const int toti = p.st.Cp * p.st.TIH * nv, totd = p.Cout * p.TPH * nvd;
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
@@ -1125,31 +1127,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     const float* __restrict__ dsrc = p.dout + (b * p.Cout * p.OH + q0) * (long)p.OW;
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
-      vi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int e = 0; e < VI; ++e) vi[u][e] = 0.f;
       const int ys = y_lo + ((di[u] >> 8) & 255);
-      if (di[u] >= 0 && ys >= 0 && ys < p.st.IH)
-        vi[u] = *reinterpret_cast<const float4*>(base + ((long)(di[u] >> 16) * p.st.IH + ys) * p.st.IW + ((di[u] & 255) << 2));
+      if (di[u] >= 0 && ys >= 0 && ys < p.st.IH) {
+        const float* q = base + ((long)(di[u] >> 16) * p.st.IH + ys) * p.st.IW + (di[u] & 255) * VI;
+        if (VI == 4) { const float4 t = *reinterpret_cast<const float4*>(q); vi[u][0] = t.x; vi[u][1] = t.y; vi[u][2] = t.z; vi[u][3] = t.w; }
+        else if (VI == 2) { const float2 t = *reinterpret_cast<const float2*>(q); vi[u][0] = t.x; vi[u][1] = t.y; }
+        else vi[u][0] = q[0];
+      }
     }
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
-      vd[u] = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int e = 0; e < VD; ++e) vd[u][e] = 0.f;
       const int r = (dd[u] >> 8) & 255;
-      if (dd[u] >= 0 && r < rows)
-        vd[u] = *reinterpret_cast<const float2*>(dsrc + ((long)(dd[u] >> 16) * p.OH + r) * p.OW + ((dd[u] & 255) << 1));
+      if (dd[u] >= 0 && r < rows) {
+        const float* q = dsrc + ((long)(dd[u] >> 16) * p.OH + r) * p.OW + (dd[u] & 255) * VD;
+        if (VD == 2) { const float2 t = *reinterpret_cast<const float2*>(q); vd[u][0] = t.x; vd[u][1] = t.y; }
+        else vd[u][0] = q[0];
+      }
     }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int u = 0; u < NI; ++u)
       if (di[u] >= 0) {
-        float* d = lds + (di[u] >> 16) * PLANE + ((di[u] >> 8) & 255) * WP + ((di[u] & 255) << 2) - p.st.sx0;
-        d[0] = vi[u].x; d[1] = vi[u].y; d[2] = vi[u].z; d[3] = vi[u].w;
+        float* d = lds + (di[u] >> 16) * PLANE + ((di[u] >> 8) & 255) * WP + (di[u] & 255) * VI - p.st.sx0;
+#pragma unroll
+        for (int e = 0; e < VI; ++e) d[e] = vi[u][e];
       }
 #pragma unroll
     for (int u = 0; u < ND; ++u)
       if (dd[u] >= 0) {
-        *reinterpret_cast<float2*>(ldo + (dd[u] >> 16) * p.PLANEo + ((dd[u] >> 8) & 255) * p.OWp + ((dd[u] & 255) << 1)) = vd[u];
-        if (BR) dbs[u] += vd[u].x + vd[u].y;
+        float* d = ldo + (dd[u] >> 16) * p.PLANEo + ((dd[u] >> 8) & 255) * p.OWp + (dd[u] & 255) * VD;
+#pragma unroll
+        for (int e = 0; e < VD; ++e) {
+          d[e] = vd[u][e];
+          if (BR) dbs[u] += vd[u][e];
+        }
       }
   };
   if (PF && blockIdx.x < total) issue(blockIdx.x);
@@ -1361,7 +1377,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     for (int u = 0; u < ND; ++u) red[threadIdx.x + u * 256] = dbs[u];
     __syncthreads();
     if (threadIdx.x < p.Cout) {
-      const int per = p.TPH * (p.OW >> 1);
+      const int per = p.TPH * (p.OW / VD);
       float s = 0.f;
       for (int i = 0; i < per; ++i) s += red[threadIdx.x * per + i];
       sl[(long)p.Cout * p.K + threadIdx.x] = s;
@@ -2557,8 +2573,10 @@ struct WgradPlan { SrcTile t; int OWp, PLANEo, MT, KTW, grid, run, rs, pf, ex; s
 #define WGRAD_PF_A 1, 3, true, 4, 16, true
 #define WGRAD_PF_B 2, 9, true, 8, 8, true
 #define WGRAD_PF_C 2, 4, false, 12, 8, true
+#define WGRAD_PF_D 2, 4, false, 14, 8, true, 2, 1       /* 42-wide input (8-B slots), 21-wide dOut (4-B slots) */
 #define WGRAD_VARIANTS(X)                                                                                      \
-  if (pl.pf && pl.KTW == 3) { X(WGRAD_PF_A); }                                                                 \
+  if (pl.pf == 2) { X(WGRAD_PF_D); }                                                                           \
+  else if (pl.pf && pl.KTW == 3) { X(WGRAD_PF_A); }                                                            \
   else if (pl.pf && pl.KTW == 9) { X(WGRAD_PF_B); }                                                            \
   else if (pl.pf) { X(WGRAD_PF_C); }                                                                           \
   else if (pl.rs && pl.KTW == 3) { X(1, 3, true, 0, 0, true); }                                                \
@@ -2660,6 +2678,24 @@ static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl, bool allow_
       t.tiles = ceil_div(t.PH, t.TPH);
     }
   }
+  if (!pl.pf && allow_run && !getenv("A2C_NO_WGRAD_PF") && !getenv("A2C_NO_WGRAD_PF2") && d->W % 4 && d->W % 2 == 0 && pl.ex &&
+      !pl.rs && pl.MT == 2 && pl.KTW == 4) {
+    // narrow layers: 8-B input slots, 4-B dOut slots (WGRAD_PF_D / _E)
+    const long budget = env_kb("A2C_WGRAD_PF_LDS_KB", 64);
+    int tph = 0;
+    for (int c = 1; c <= d->OH; ++c) {
+      const int tih = (c - 1) * d->stride + d->ks;
+      const long plane = ((tih * t.WP + 31) / 32) * 32 + 16, planeo = ((c * pl.OWp + 31) / 32) * 32 + 2;
+      if ((long)d->Cin * tih * (d->W / 2) <= 256L * 14 && (long)d->Cout * c * d->OW <= 256L * 8 && tih < 256 &&
+          4 * (d->Cin * plane + pl.MT * 16 * planeo + 64) <= budget) tph = c; else break;
+    }
+    if (tph) {
+      pl.pf = 2;
+      t.TPH = tph; t.TIH = (tph - 1) * d->stride + d->ks;
+      t.PLANE = ((t.TIH * t.WP + 31) / 32) * 32 + 16;
+      t.tiles = ceil_div(t.PH, t.TPH);
+    }
+  }
   pl.PLANEo = ((t.TPH * pl.OWp + 31) / 32) * 32 + 2;
   pl.lds = 4 * ((size_t)t.Cp * t.PLANE + (size_t)pl.MT * 16 * pl.PLANEo + 64);
   if (pl.rs && pl.lds < (size_t)pl.KTW * 4096) pl.lds = (size_t)pl.KTW * 4096;   // cross-wave reduction scratch
@@ -2672,11 +2708,11 @@ static bool plan_wgrad(const a2c_conv_desc* d, int B, WgradPlan& pl, bool allow_
   return true;
 }
 
-template <int MT, int KTW, bool RS = false, int NI = 0, int ND = 0, bool EX = false>
+template <int MT, int KTW, bool RS = false, int NI = 0, int ND = 0, bool EX = false, int VI = 4, int VD = 2>
 static void launch_wgrad_t(const WgradP& p, int grid, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<MT, KTW, RS, NI, ND, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((wgrad_kernel<MT, KTW, RS, NI, ND, EX>), dim3(grid), dim3(256), lds, st, p);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<MT, KTW, RS, NI, ND, EX, VI, VD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((wgrad_kernel<MT, KTW, RS, NI, ND, EX, VI, VD>), dim3(grid), dim3(256), lds, st, p);
 }
 }  // namespace
 

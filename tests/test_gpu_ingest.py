@@ -152,7 +152,7 @@ def test_zero_copy_more_envs_than_cus_and_sampled_oracle():
     us = torch.from_numpy(hashf(T * B, 31337, 0, 1).reshape(1, T, B))
     usd = us.to(DEV)
     out = {}
-    for ingest in ("zero-copy", "memcpy"):
+    for ingest in ("zero-copy", "memcpy", "relay"):
         net = make_net("A3CModel", ss, A, 256)
         D = _datas(B * T, ss, False, actions_on_host=False)
         pool = _pool(U8FakeEnv, ekws, 6, pong=True)
@@ -166,6 +166,7 @@ def test_zero_copy_more_envs_than_cus_and_sampled_oracle():
         out[ingest] = {k: v.cpu() for k, v in D.items()}
     for k in ("states", "actions", "dones", "rewards", "deltas"):
         assert torch.equal(out["zero-copy"][k], out["memcpy"][k]), k
+        assert torch.equal(out["relay"][k], out["memcpy"][k]), k      # the device relay hands over the same bytes
     onet = O.OracleNet("A3CModel", ss, A, 256)
     for j in (0, 137, 255, 256, 299):
         Do = dict(states=torch.zeros(T, *ss), deltas=torch.zeros(T), rewards=torch.zeros(T), dones=torch.zeros(T),

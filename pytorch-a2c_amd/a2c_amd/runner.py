@@ -476,7 +476,8 @@ class Runner:
             if getattr(self, "_seq_dev", None) is None:
                 self._seq_dev = torch.zeros(1, dtype=torch.int32, device=dev)
                 self._seq_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self._seq_pin[0] = pool.seq & 0x7fffffff
+            s32 = pool.seq & 0xffffffff                     # the granules carry the step number modulo 2^32
+            self._seq_pin[0] = s32 - (1 << 32) if s32 >= (1 << 31) else s32
             self._seq_dev.copy_(self._seq_pin, non_blocking=True)
         stash = self._stash_bufs
         fused = h is None and getattr(net, "_step_supported", lambda: False)()

@@ -226,6 +226,45 @@ def test_rollout_record_and_bootstrap():
         assert l2[e].item() == (r - vp[b].cpu()).float().item()
 
 
+@pytest.mark.parametrize("u8,with_src", [(True, False), (True, True), (False, True)])
+def test_rollout_post_rec_equals_the_separate_launches(u8, with_src):
+    """a2c_rollout_post_rec (bookkeeping + frame stack + hidden-state reset + h_states row, runner.py:199-232) against
+    a2c_rollout_record + a2c_frame_stack_push[_u8] + a2c_copy_rows, every output bit for bit; h_src = where the
+    previous step's cell left its new hidden rows"""
+    ops = _ops()
+    B, T, slot0, n_slots, hd, C, HW = 7, 5, 1, 9, 24, 4, 84 * 84
+    gamma, t, S = 0.99, 2, 4 * 84 * 84
+    mk = lambda: dict(rw=rnd((n_slots * T,), 50).to(DEV), dn=(rnd((n_slots * T,), 51, 0, 1) < 0.3).float().to(DEV),
+                      dl=rnd((n_slots * T,), 52).to(DEV), vp=rnd((B,), 53).to(DEV), de=torch.zeros(B, device=DEV),
+                      h=rnd((B, hd), 54).to(DEV), hs=torch.zeros(n_slots * T, hd, device=DEV),
+                      states=rnd((n_slots * T, S), 57, 0, 1).to(DEV))
+    rew = torch.tensor([0., 1, -1, 0, 0, 2, 0]).to(DEV)
+    done = torch.tensor([0., 0, 0, 1, 0, 0, 1]).to(DEV)
+    val = rnd((B, 4), 55).to(DEV)
+    h_new = rnd((B, hd), 58).to(DEV)                         # what the cell of step t left (when with_src)
+    f8 = (rnd((B, HW), 59, 0, 1) < 0.3).to(torch.uint8).to(DEV)
+    f32 = f8.float()
+    sp = lambda D, k: D["states"].data_ptr() + 4 * (slot0 * T + k) * S
+    a, b = mk(), mk()
+    # separate launches
+    if with_src:
+        a["h"].copy_(h_new)
+    ops.rollout_record(rew, done, val.data_ptr() + 12, 4, a["vp"], a["rw"], a["dn"], a["dl"], a["de"], a["h"], B, T, t, slot0,
+                       gamma, True)
+    if u8:
+        ops.frame_stack_push_u8(f8.data_ptr(), HW, done, sp(a, t), T * S, sp(a, t + 1), T * S, B, C, HW)
+    else:
+        ops.frame_stack_push(f32, done, sp(a, t), T * S, sp(a, t + 1), T * S, B, C, HW)
+    ops.copy_rows(a["h"].data_ptr(), hd, a["hs"].data_ptr() + 4 * (slot0 * T + t + 1) * hd, T * hd, B, hd)
+    # one launch
+    ops.rollout_post_rec(rew, done, val.data_ptr() + 12, 4, b["vp"], b["rw"], b["dn"], b["dl"], T, t, slot0, gamma, True,
+                         0 if u8 else f32.data_ptr(), f8.data_ptr() if u8 else 0, HW if u8 else 0, done, sp(b, t), T * S,
+                         sp(b, t + 1), T * S, B, C, HW, b["de"], b["h"], b["hs"].data_ptr() + 4 * (slot0 * T + t + 1) * hd, T * hd,
+                         h_src_ptr=h_new.data_ptr() if with_src else 0)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_copy_mask_permute_rows():
     ops = _ops()
     R, T, n = 5, 7, 12

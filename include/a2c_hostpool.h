@@ -15,7 +15,8 @@
  *           by the GPU process after a D2H copy:   (seq << 32) | (uint32) action
  *           "perform env step number `seq` of env j with this action"  (runner.py:207-208)
  *   rec[j]  8-byte granule written by the env WORKER after the step (release store, after the
- *           frame bytes):   ((seq << 1 | done) << 32) | float_bits(reward)
+ *           frame bytes):   ((seq << 1 | done) << 32) | float_bits(reward)     [seq modulo 2^31 here: readers
+ *           compare (rec >> 33) with (seq & 0x7fffffff); cmd carries seq modulo 2^32]
  *           "frame number `seq` is in frames[j]";  seq counts the env steps taken so far, frame 0 is
  *           the frame of the initial env.reset() (done = 1: the frame stack restarts, utils.py:37-42).
  *           `done` is the env's real done (the worker has already called env.reset() and stored the
@@ -39,12 +40,17 @@ extern "C" {
 #endif
 
 #define A2C_POOL_MAGIC 0x4132435F504F4F4CULL /* "A2C_POOL" */
-#define A2C_POOL_VERSION 1
+#define A2C_POOL_VERSION 2
 #define A2C_POOL_IDLE 0     /* between rollouts: workers sleep-poll                    */
 #define A2C_POOL_ROLLOUT 1  /* a rollout is running: workers spin on their cmd granules */
 #define A2C_POOL_SHUTDOWN 2
 #define A2C_FRAME_U8 0
 #define A2C_FRAME_F32 1
+/* packed transport for BINARY preprocessors (pong_prep yields {0,1}, preprocessing.py:15-16): the worker publishes
+ * one bit per pixel (pixel p = bit p%8 of byte p/8; frame_bytes = ceil(frame_elems / 8)) and the device expands the
+ * bits in registers -- 8x fewer bytes over the host link, results bit-identical to the uint8 transport.  A worker
+ * that meets a pixel other than 0/1 fails loudly (a2c_pool_publish_bits returns -1).                              */
+#define A2C_FRAME_BITS 2
 
 typedef struct {
   uint64_t magic;
@@ -56,6 +62,8 @@ typedef struct {
   volatile uint32_t ema_lock;
   volatile double rew_ema;          /* runner.py:216: .99*ema + .01*episode reward            */
   volatile uint64_t episodes;       /* finished episodes (all envs)                           */
+  uint32_t frame_elems;             /* pixels / values per frame (A2C_FRAME_BITS: frame_bytes = ceil(frame_elems/8)) */
+  uint32_t seq_start;               /* step number of frame 0 (0 unless a2c_pool_set_seq_start was called)     */
 } a2c_pool_header;
 
 /* bytes of the region for n_envs envs with frame_bytes per frame (page aligned)             */
@@ -63,6 +71,11 @@ size_t a2c_pool_bytes(int n_envs, int frame_bytes);
 /* format a zero-filled region (GPU process, before the workers attach); 0 or -1             */
 int a2c_pool_init(void *base, size_t bytes, int n_envs, int frame_bytes, int frame_dtype,
                   int n_workers, double rew_ema0);
+/* optional, after a2c_pool_init and before the workers attach: pixels per frame (needed for A2C_FRAME_BITS; the
+ * default is frame_bytes / sizeof(element), 8 * frame_bytes for bits) and the step number the envs start counting
+ * from (tests of the 31-bit wrap of the rec granule's step counter)                                            */
+void a2c_pool_set_frame_elems(void *base, uint32_t frame_elems);
+void a2c_pool_set_seq_start(void *base, uint32_t seq_start);
 /* 0 when base holds a formatted region                                                      */
 int a2c_pool_check(const void *base);
 void a2c_pool_set_phase(void *base, uint32_t phase);
@@ -79,6 +92,9 @@ int a2c_pool_take(void *base, int env0, int n, const uint32_t *next_seq, int64_t
                   int32_t *action);
 /* frames[env] = frame (frame_bytes), then rec[env] = {seq, done, rew} with release order     */
 void a2c_pool_publish(void *base, int env, const void *frame, uint32_t seq, float rew, int done);
+/* A2C_FRAME_BITS pools: pack the frame_elems uint8 pixels of `frame_u8` (each 0 or 1) into the env's slot, then
+ * publish rec like a2c_pool_publish.  Returns 0, or -1 (nothing published) when a pixel is neither 0 nor 1.   */
+int a2c_pool_publish_bits(void *base, int env, const uint8_t *frame_u8, uint32_t seq, float rew, int done);
 /* episode finished with total reward ep_rew: ema = .99*ema + .01*ep_rew under a spin lock    */
 void a2c_pool_episode(void *base, double ep_rew);
 void a2c_pool_worker_ready(void *base);

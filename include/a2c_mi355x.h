@@ -102,6 +102,15 @@ int a2c_pool_publish_actions(uint64_t *cmd, const int64_t *actions, int64_t act_
 int a2c_pool_ingest(const uint64_t *rec, const uint8_t *frames, int64_t frame_stride, int frame_bytes, int n,
                     const uint32_t *seq_base, uint32_t seq_off, int64_t timeout_ticks, int *err, float *rew,
                     float *done, uint8_t *frames_out, int64_t out_stride, a2c_stream_t stream);
+/* The same for a pool with the PACKED transport (A2C_FRAME_BITS in a2c_hostpool.h: binary preprocessors such as
+ * pong_prep, preprocessing.py:15-16, publish one bit per pixel): n_pixels / 8 bytes per env cross the host link and
+ * frames_out receives the n_pixels uint8 {0,1} pixels the uint8 kernels expect (n_pixels % 16 == 0).
+ * a2c_unpack_bits is the expansion alone, for packed frames a hipMemcpyAsync staged in HBM (memcpy ingest).    */
+int a2c_pool_ingest_bits(const uint64_t *rec, const uint8_t *frames, int64_t frame_stride, int n_pixels, int n,
+                         const uint32_t *seq_base, uint32_t seq_off, int64_t timeout_ticks, int *err, float *rew,
+                         float *done, uint8_t *frames_out, int64_t out_stride, a2c_stream_t stream);
+int a2c_unpack_bits(const uint8_t *src, int64_t src_stride, uint8_t *dst, int64_t dst_stride, int n,
+                    int n_pixels, a2c_stream_t stream);
 
 /* ------------------------------------------------------------------ a2: sampler
  * SequentialEnvironment.get_action discrete branch (runner.py:94-97) + utils.sample_action
@@ -247,6 +256,7 @@ typedef struct {
    * count of the bookmark state from slot to slot.  Consumer: a2c_conv2d_bwd_weight_frames.              */
   uint8_t *frame_store; int64_t frame_store_slot_stride;
   int32_t *nvalid_rows, *nvalid_carry;
+  int frame_bits;                  /* 1: `frames` holds the packed transport (one bit per pixel, frame_stride >= H*W/8) */
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
 

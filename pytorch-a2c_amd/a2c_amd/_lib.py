@@ -46,7 +46,8 @@ class A3CRolloutArgs(Structure):
                 ("T", c_int64), ("slot0", c_int64), ("gamma", c_float), ("pong", c_int),
                 ("cmd", P), ("rec", P), ("frames", P), ("frame_stride", c_int64),
                 ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64), ("a1_rows", P), ("a2_rows", P), ("heads_rows", P), ("heads_rows_ld", c_int64),
-                ("frame_store", P), ("frame_store_slot_stride", c_int64), ("nvalid_rows", P), ("nvalid_carry", P)]
+                ("frame_store", P), ("frame_store_slot_stride", c_int64), ("nvalid_rows", P), ("nvalid_carry", P),
+                ("frame_bits", c_int)]
 
 
 PS = POINTER(A3CStepArgs)
@@ -65,6 +66,8 @@ SIGNATURES = {
     "a2c_frame_stack_push_u8": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int, c_int, P]),
     "a2c_pool_publish_actions": (c_int, [P, P, c_int64, c_int, P, ctypes.c_uint32, P]),
     "a2c_pool_ingest": (c_int, [P, P, c_int64, c_int, c_int, P, ctypes.c_uint32, c_int64, P, P, P, P, c_int64, P]),
+    "a2c_pool_ingest_bits": (c_int, [P, P, c_int64, c_int, c_int, P, ctypes.c_uint32, c_int64, P, P, P, P, c_int64, P]),
+    "a2c_unpack_bits": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P]),
     "a2c_softmax_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int, c_int, P]),
     "a2c_sample_probs": (c_int, [P, P, P, c_int64, c_int, P]),
     "a2c_rollout_record": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_int64, c_int64, c_int64,

@@ -33,7 +33,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 POOL_LIB_PATH = os.path.join(_HERE, "liba2c_hostpool.so")
 IDLE, ROLLOUT, SHUTDOWN = 0, 1, 2
-FRAME_U8, FRAME_F32 = 0, 1
+FRAME_U8, FRAME_F32, FRAME_BITS = 0, 1, 2
 
 
 class PoolHeader(Structure):
@@ -42,13 +42,15 @@ class PoolHeader(Structure):
                 ("frame_stride", c_uint32), ("frame_dtype", c_uint32), ("n_workers", c_uint32),
                 ("off_cmd", c_uint64), ("off_rec", c_uint64), ("off_frames", c_uint64), ("total_bytes", c_uint64),
                 ("phase", c_uint32), ("workers_ready", c_uint32), ("worker_error", c_uint32), ("ema_lock", c_uint32),
-                ("rew_ema", c_double), ("episodes", c_uint64)]
+                ("rew_ema", c_double), ("episodes", c_uint64), ("frame_elems", c_uint32), ("seq_start", c_uint32)]
 
 
 P = c_void_p
 POOL_SIGNATURES = {   # one entry per prototype in include/a2c_hostpool.h
     "a2c_pool_bytes": (c_size_t, [c_int, c_int]),
     "a2c_pool_init": (c_int, [P, c_size_t, c_int, c_int, c_int, c_int, c_double]),
+    "a2c_pool_set_frame_elems": (None, [P, c_uint32]),
+    "a2c_pool_set_seq_start": (None, [P, c_uint32]),
     "a2c_pool_check": (c_int, [P]),
     "a2c_pool_set_phase": (None, [P, c_uint32]),
     "a2c_pool_phase": (c_uint32, [P]),
@@ -56,6 +58,7 @@ POOL_SIGNATURES = {   # one entry per prototype in include/a2c_hostpool.h
     "a2c_pool_action": (c_int32, [P, c_int]),
     "a2c_pool_take": (c_int, [P, c_int, c_int, P, c_int64, P]),
     "a2c_pool_publish": (None, [P, c_int, P, c_uint32, c_float, c_int]),
+    "a2c_pool_publish_bits": (c_int, [P, c_int, P, c_uint32, c_float, c_int]),
     "a2c_pool_episode": (None, [P, c_double]),
     "a2c_pool_worker_ready": (None, [P]),
     "a2c_pool_worker_failed": (None, [P, c_int]),
@@ -167,15 +170,39 @@ class _PinnedPool:
 
     device_pool = False
 
-    def _setup(self, n_envs, frame_shape, frame_dtype, n_workers, rew_ema0, register):
+    def _setup(self, n_envs, frame_shape, frame_dtype, n_workers, rew_ema0, register, frame_bits=False, seq_start=0):
         self.n_envs, self.n_workers = int(n_envs), int(n_workers)
         self.frame_shape = tuple(int(s) for s in frame_shape)
         self.frame_dtype = np.dtype(np.uint8 if np.dtype(frame_dtype) in (np.dtype(np.uint8), np.dtype(bool)) else np.float32)
-        self.frame_bytes = int(np.prod(self.frame_shape)) * self.frame_dtype.itemsize
+        self.frame_elems = int(np.prod(self.frame_shape))
+        # transport: what crosses the host link per frame.  "bits" = one bit per pixel for BINARY uint8 preprocessors
+        # (pong_prep, preprocessing.py:15-16); the frames the kernels see are the same uint8 {0,1} planes
+        self.frame_bits = bool(frame_bits)
+        if self.frame_bits and self.frame_dtype != np.uint8:
+            raise ValueError("frame_bits=True needs uint8 frames with values in {0, 1}")
+        self.transport = "bits" if self.frame_bits else ("u8" if self.frame_dtype == np.uint8 else "f32")
+        self.frame_bytes = (self.frame_elems + 7) // 8 if self.frame_bits else self.frame_elems * self.frame_dtype.itemsize
         self.rew_ema0, self.register = float(rew_ema0), bool(register)
         self.region = None
         self.dev_ptr = 0
-        self.seq = 0            # env steps requested so far (same for every env: lock-step slots)
+        # env steps requested so far, per env (granules carry it modulo 2^32 / 2^31).  Lock-step blocks of envs share
+        # one value; envs fall out of step with each other when n_rollouts is not a multiple of n_envs (runner.rollout)
+        self.seq_start = int(seq_start)
+        self.seq_env = np.full(self.n_envs, self.seq_start, dtype=np.int64)
+
+    @property
+    def seq(self):
+        """the common step count of ALL envs (raises when they are out of step: use seq_of(env0, n))"""
+        return self.seq_of(0, self.n_envs)
+
+    def seq_of(self, env0, n):
+        s = self.seq_env[env0:env0 + n]
+        if not (s == s[0]).all():
+            raise ValueError(f"envs {env0}..{env0 + n - 1} are not in lock-step: {sorted(set(s.tolist()))}")
+        return int(s[0])
+
+    def advance(self, env0, n, steps):
+        self.seq_env[env0:env0 + n] += int(steps)
 
     def __len__(self):
         return self.n_envs
@@ -201,9 +228,11 @@ class _PinnedPool:
         self.name = f"a2c_pool_{os.getpid()}_{id(self) & 0xffffff:x}_{int(time.time() * 1e3) & 0xffffff:x}"
         reg = self.region = Region(self.name, create_bytes=nbytes)
         ctypes.memset(reg.base, 0, nbytes)          # first touch of every page from the (NUMA-placed) creating thread
-        dt = FRAME_U8 if self.frame_dtype == np.uint8 else FRAME_F32
+        dt = FRAME_BITS if self.frame_bits else (FRAME_U8 if self.frame_dtype == np.uint8 else FRAME_F32)
         if lib.a2c_pool_init(reg.base, nbytes, self.n_envs, self.frame_bytes, dt, self.n_workers, self.rew_ema0):
             raise RuntimeError("a2c_pool_init failed")
+        lib.a2c_pool_set_frame_elems(reg.base, self.frame_elems)
+        lib.a2c_pool_set_seq_start(reg.base, self.seq_start & 0xffffffff)
         reg.bind()
         if self.register:       # pin + map into the GPU's address space (no copy): hipHostRegister
             from . import ops
@@ -241,11 +270,13 @@ class _PinnedPool:
     def post_actions(self, actions, env0=0, seq=None):
         """cmd[env0+i] = (seq, actions[i]) -- actions: contiguous int64 numpy array (e.g. a pinned staging view)"""
         a = np.ascontiguousarray(actions, dtype=np.int64)
-        pool_lib().a2c_pool_post_actions(self.region.base, env0, a.shape[0], a.ctypes.data, 1, self.seq if seq is None else seq)
+        if seq is None:
+            seq = self.seq_of(env0, a.shape[0])
+        pool_lib().a2c_pool_post_actions(self.region.base, env0, a.shape[0], a.ctypes.data, 1, int(seq) & 0xffffffff)
 
     def wait_frames(self, seq, env0=0, n=None, timeout=30.0):
-        rc = pool_lib().a2c_pool_wait_frames(self.region.base, env0, self.n_envs - env0 if n is None else n, seq,
-                                             int(timeout * 1e9))
+        rc = pool_lib().a2c_pool_wait_frames(self.region.base, env0, self.n_envs - env0 if n is None else n,
+                                             int(seq) & 0xffffffff, int(timeout * 1e9))
         if rc == -3:
             self._check_workers()
             raise RuntimeError("an env worker failed")
@@ -261,8 +292,10 @@ class _PinnedPool:
         return pool_lib().a2c_pool_rew_ema(self.region.base)
 
     def frames_view(self):
-        """(n_envs, *frame_shape) numpy view of the current frames (no copy)"""
+        """(n_envs, *frame_shape) numpy view of the current frames (no copy; the packed transport is unpacked into a copy)"""
         f = self.region.frames[:, :self.frame_bytes]
+        if self.frame_bits:
+            return np.unpackbits(f, axis=1, bitorder="little")[:, :self.frame_elems].reshape((self.n_envs,) + self.frame_shape)
         return f.view(self.frame_dtype).reshape((self.n_envs,) + self.frame_shape)
 
     # device addresses inside the registered region (zero-copy ingest)
@@ -281,7 +314,7 @@ class _PinnedPool:
     def describe(self):
         h = self.header
         return json.dumps(dict(n_envs=h.n_envs, n_workers=h.n_workers, frame_bytes=h.frame_bytes,
-                               frame_dtype="u8" if h.frame_dtype == FRAME_U8 else "f32"))
+                               frame_dtype={FRAME_U8: "u8", FRAME_F32: "f32", FRAME_BITS: "bits"}[h.frame_dtype]))
 
 
 class ProcessEnvPool(_PinnedPool):
@@ -295,7 +328,7 @@ class ProcessEnvPool(_PinnedPool):
 
     def __init__(self, env_factory, n_envs, env_kwargs=None, n_workers=None, action_shift=0, pong=False,
                  frame_shape=None, frame_dtype=None, rew_ema0=-1.0, register=True, spin=True, sys_path=None,
-                 probe_reset=False):
+                 probe_reset=False, frame_bits=False, seq_start=0):
         self.env_factory, self.n_envs = env_factory, int(n_envs)
         self.env_kwargs = list(env_kwargs) if env_kwargs is not None else [dict() for _ in range(n_envs)]
         assert len(self.env_kwargs) == self.n_envs
@@ -312,7 +345,7 @@ class ProcessEnvPool(_PinnedPool):
             obs = np.asarray(env_factory(**self.env_kwargs[0]).reset())
             frame_shape = obs.shape if frame_shape is None else frame_shape
             frame_dtype = obs.dtype if frame_dtype is None else frame_dtype
-        self._setup(n_envs, frame_shape, frame_dtype, n_workers, rew_ema0, register)
+        self._setup(n_envs, frame_shape, frame_dtype, n_workers, rew_ema0, register, frame_bits=frame_bits, seq_start=seq_start)
         self.spin = bool(spin)
         self.sys_path = list(sys_path) if sys_path is not None else [p for p in sys.path if p]
         self.procs = []
@@ -363,6 +396,7 @@ class ProcessEnvPool(_PinnedPool):
                 p.wait(timeout=5)
             except subprocess.TimeoutExpired:
                 p.kill()
+                p.wait()            # reap it: no zombie outlives the pool
         self.procs = []
         self._destroy_region()
 
@@ -375,10 +409,11 @@ class ThreadEnvPool(_PinnedPool):
     worker processes.  Same device-facing protocol and API as ProcessEnvPool."""
 
     def __init__(self, vtable_ptr, env_ptrs, frame_shape, frame_dtype, n_threads=None, action_shift=0, pong=False,
-                 rew_ema0=-1.0, register=True, destroy=None):
+                 rew_ema0=-1.0, register=True, destroy=None, frame_bits=False, seq_start=0):
         if n_threads is None:
             n_threads = max(1, min(len(env_ptrs), int(os.environ.get("A2C_ENV_THREADS", "0")) or min(8, max(1, usable_cpus() - 2))))
-        self._setup(len(env_ptrs), frame_shape, frame_dtype, n_threads, rew_ema0, register)
+        self._setup(len(env_ptrs), frame_shape, frame_dtype, n_threads, rew_ema0, register, frame_bits=frame_bits,
+                    seq_start=seq_start)
         self.vtable_ptr, self.env_ptrs, self._destroy_env = vtable_ptr, list(env_ptrs), destroy
         self.action_shift, self.pong = int(action_shift), bool(pong)
         self.handle = None

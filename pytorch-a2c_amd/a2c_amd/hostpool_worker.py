@@ -32,11 +32,13 @@ def main():
 
 
 def run(spec, lib, reg, base, env0, n):
+    from a2c_amd import hostpool as hp
     shift, pong = int(spec["action_shift"]), bool(spec["pong"])
     fdt = np.dtype(spec["frame_dtype"])
     fshape = tuple(spec["frame_shape"])
+    bits = reg.header.frame_dtype == hp.FRAME_BITS      # packed transport: the frame is packed 8 pixels to a byte
     fbytes = int(np.prod(fshape)) * fdt.itemsize
-    assert fbytes == reg.header.frame_bytes
+    assert (fbytes + 7) // 8 == reg.header.frame_bytes if bits else fbytes == reg.header.frame_bytes
     parent = int(spec["parent"])
     envs = [spec["factory"](**kw) for kw in spec["env_kwargs"]]
     if spec.get("probe_reset"):
@@ -49,12 +51,19 @@ def run(spec, lib, reg, base, env0, n):
             raise ValueError(f"env returned a frame of {f.nbytes} bytes, the pool was sized for {fbytes}")
         return f
 
-    publish, take, episode = lib.a2c_pool_publish, lib.a2c_pool_take, lib.a2c_pool_episode
+    take, episode = lib.a2c_pool_take, lib.a2c_pool_episode
+    if bits:
+        def publish(b, j, ptr, s, rew, done):
+            if lib.a2c_pool_publish_bits(b, j, ptr, s, rew, done):
+                raise ValueError("frame_bits transport: the env returned a pixel that is neither 0 nor 1")
+    else:
+        publish = lib.a2c_pool_publish
+    seq0 = int(reg.header.seq_start)
     for i, env in enumerate(envs):          # frame 0 = env.reset(); done = 1: the frame stack starts from zeros
         f = as_frame(env.reset())
-        publish(base, env0 + i, f.ctypes.data, 0, 0.0, 1)
+        publish(base, env0 + i, f.ctypes.data, seq0, 0.0, 1)
     lib.a2c_pool_worker_ready(base)
-    next_seq = np.zeros(n, dtype=np.uint32)  # the env step each env waits for
+    next_seq = np.full(n, seq0, dtype=np.uint32)  # the env step each env waits for (cmd granules: modulo 2^32)
     nsp = next_seq.ctypes.data
     ep_rew = [0.0] * n
     act = ctypes.c_int32(0)
@@ -79,7 +88,7 @@ def run(spec, lib, reg, base, env0, n):
         if reset:
             obs = envs[i].reset()
         f = as_frame(obs)
-        s = int(next_seq[i]) + 1
+        s = (int(next_seq[i]) + 1) & 0xffffffff
         next_seq[i] = s
         publish(base, env0 + i, f.__array_interface__["data"][0], s, rew, 1 if reset else 0)
 

@@ -182,6 +182,20 @@ def pool_ingest(rec_ptr, frames_ptr, frame_stride, frame_bytes, n, seq_base, seq
                                 st if st is not None else stream()), "a2c_pool_ingest")
 
 
+def pool_ingest_bits(rec_ptr, frames_ptr, frame_stride, n_pixels, n, seq_base, seq_off, timeout_ticks, err, rew, done,
+                     frames_out_ptr, out_stride, st=None):
+    """pool_ingest for the packed transport (one bit per pixel over the host link; uint8 pixels land in HBM)"""
+    check(lib().a2c_pool_ingest_bits(rec_ptr, frames_ptr, frame_stride, n_pixels, n, _p(seq_base), seq_off, timeout_ticks,
+                                     _p(err), _p(rew), _p(done), frames_out_ptr, out_stride,
+                                     st if st is not None else stream()), "a2c_pool_ingest_bits")
+
+
+def unpack_bits(src_ptr, src_stride, dst_ptr, dst_stride, n, n_pixels, st=None):
+    """packed frames staged in HBM -> uint8 frames (memcpy ingest of a frame_bits pool)"""
+    check(lib().a2c_unpack_bits(src_ptr, src_stride, dst_ptr, dst_stride, n, n_pixels,
+                                st if st is not None else stream()), "a2c_unpack_bits")
+
+
 def frame_stack_push_u8(frame_u8_ptr, frame_stride, reset_mask, prev_ptr, prev_stride, out_ptr, out_stride, B, C, HW, st=None):
     """frame_stack_push with the new frame as uint8 pixels at frame_u8_ptr + b*frame_stride (device address)"""
     check(lib().a2c_frame_stack_push_u8(frame_u8_ptr, frame_stride, _p(reset_mask), prev_ptr, prev_stride, out_ptr,

@@ -25,6 +25,7 @@ Env pools (``env_pool=``):
     synchronisation and can be captured into one hipGraph.
 """
 import os
+import queue
 import time
 from collections import deque
 
@@ -180,11 +181,20 @@ class Runner:
             self.np_rew, self.np_done, self.np_act = self.h_rew.numpy(), self.h_done.numpy(), self.h_act.numpy()
             self.d_rew, self.d_done = torch.zeros(B, **f32), torch.zeros(B, **f32)
             self.u8 = pool.frame_dtype == np.uint8
-            self.fstride = int(pool.header.frame_stride)
-            self.d_frames = torch.zeros((B, self.fstride), dtype=torch.uint8, device=dev)
+            self.bits = bool(getattr(pool, "frame_bits", False))      # packed transport: one bit per pixel over the link
+            self.fstride = int(pool.header.frame_stride)              # bytes between the envs' slots in the pinned region
+            if self.bits and self.HW % 16:
+                raise ValueError("frame_bits transport: the frame size must be a multiple of 16 pixels")
+            # HBM staging of one env step's frames: uint8 pixels (expanded from the packed slots on the way in), or fp32
+            self.dstride = -(-self.HW // 16) * 16 if self.bits else self.fstride
+            self.d_frames = torch.zeros((B, self.dstride), dtype=torch.uint8, device=dev)
+            self.d_packed = torch.zeros((B, self.fstride), dtype=torch.uint8, device=dev) if self.bits else None
+            # fp32 frames whose size is not a multiple of 16 B sit `fstride` bytes apart; the fp32 frame-stack kernels
+            # read dense (B, HW) rows: compact them with one strided row copy
+            self.d_dense = torch.zeros((B, self.HW), **f32) if (not self.u8 and self.fstride != 4 * self.HW) else None
             self.rollout_err = torch.zeros(1, dtype=torch.int32, device=dev)
             pool.set_phase(1)
-            pool.wait_frames(0)
+            pool.wait_frames(pool.seq_start)
             fr = self._pool_frames_h2d(pool, 0, B, ops.stream())
             if fr.ptr8:
                 ops.frame_stack_push_u8(fr.ptr8, fr.stride, ones, self.bookmark.data_ptr(), self.S, self.bookmark.data_ptr(),
@@ -223,15 +233,26 @@ class Runner:
                 idxs = [self.gate_q.get()]
                 if idxs[0] is None:        # shutdown token
                     return
-                while len(idxs) < self.B:
+                # the driver re-opens the gate with ALL n_rollouts tokens in one go (training.py:122-123, 174-175): take
+                # the whole epoch, so that the slot -> env assignment below is the same every epoch.  Fewer tokens
+                # (a caller that trickles them) still work: whatever arrived is played in lock-step rounds.
+                n_tok = int(try_key(self.hyps, "n_rollouts", None) or self.B)
+                stop = False
+                while len(idxs) < n_tok:
                     try:
-                        idxs.append(self.gate_q.get_nowait())
-                    except Exception:
+                        tok = self.gate_q.get(timeout=0.05)
+                    except queue.Empty:
                         break
+                    if tok is None:
+                        stop = True
+                        break
+                    idxs.append(tok)
                 self.rollout(net, sorted(idxs), self.hyps)
                 self.finish()
                 for i in idxs:
                     self.stop_q.put(i)
+                if stop:
+                    return
         except BaseException as e:      # noqa: BLE001
             self.error = e
             for _ in range(int(try_key(self.hyps, "n_rollouts", 1))):
@@ -262,31 +283,42 @@ class Runner:
 
     # ------------------------------------------------------------------ the rollout
     def rollout(self, net, idx, hyps):
-        """Fill slot(s) ``idx`` (an int like the reference, or a list of slots: slot k of the list
-        is played by env k).  Non-contiguous lists are split into contiguous runs."""
+        """Fill slot(s) ``idx``: an int like the reference (runner.py:174), or a list of slots of ANY length.  The
+        list is played in lock-step ROUNDS of at most n_envs slots: slot k of a round is played by env k (the
+        reference hands slots to whichever of its n_envs runner processes is free, runner.py:169-172; n_rollouts
+        need not be a multiple of n_envs -- its shipped hyperparams.json has 45 / 11).  Inside a round, runs of
+        contiguous slots whose envs have taken the same number of steps go through ONE batched block."""
         if not self._ready:
             self.start(net)
         idxs = [idx] if isinstance(idx, int) else list(idx)
-        if self.proc_pool and len(idxs) != self.B:
-            raise ValueError("a process env pool advances all its envs in lock-step: roll out all of its slots at once")
-        # one call that fills EVERY row of the rollout buffer: the step kernels may stash the conv activations
-        # of each state for the update that follows (same weights, same states)
         N = self.datas["states"].shape[0]
         T_ = int(hyps["n_tsteps"])
+        # whatever an earlier rollout stashed in the net describes states this call overwrites
+        net._stash = None
+        net._stash_frames = None
+        if hasattr(net, "_cells_done"):
+            net._cells_done = -1
+        # a call that fills EVERY row of the rollout buffer: the step kernels may stash the conv activations
+        # of each state for the update that follows (same weights, same states)
         self._stash_bufs = None
         self._frames_written = None
         if idxs == list(range(N // T_)) and N % T_ == 0:
             self._stash_bufs = net.stash_rows(self.datas["states"], N, T=T_)
-        j = 0
-        while j < len(idxs):
-            k = j
-            while k + 1 < len(idxs) and idxs[k + 1] == idxs[k] + 1:
-                k += 1
-            self._rollout_block(net, idxs[j], j, k - j + 1, hyps)
-            j = k + 1
-        if self.proc_pool:
-            self.env_pool.seq += int(hyps["n_tsteps"])
-        if self._stash_bufs is not None and self._stash_used:
+        stash_all = self._stash_bufs is not None
+        seqs = self.env_pool.seq_env if self.proc_pool else None
+        for r0 in range(0, len(idxs), self.B):
+            rnd = idxs[r0:r0 + self.B]
+            j = 0
+            while j < len(rnd):
+                k = j
+                while k + 1 < len(rnd) and rnd[k + 1] == rnd[k] + 1 and (seqs is None or seqs[k + 1] == seqs[j]):
+                    k += 1
+                self._rollout_block(net, rnd[j], j, k - j + 1, hyps)
+                stash_all = stash_all and self._stash_used
+                if self.proc_pool:
+                    self.env_pool.advance(j, k - j + 1, T_)
+                j = k + 1
+        if stash_all:
             net.stash_commit(self.datas["states"], N, frames=getattr(self, "_frames_written", None))
 
     def _uniforms(self, t, B, env0):
@@ -475,10 +507,15 @@ class Runner:
         if relay:
             if getattr(self, "_seq_dev", None) is None:
                 self._seq_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-                self._seq_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
-            s32 = pool.seq & 0xffffffff                     # the granules carry the step number modulo 2^32
-            self._seq_pin[0] = s32 - (1 << 32) if s32 >= (1 << 31) else s32
-            self._seq_dev.copy_(self._seq_pin, non_blocking=True)
+                self._seq_pin = torch.zeros(64, dtype=torch.int32).pin_memory()      # ring: one entry per block in flight
+                self._seq_i = 0
+            i = self._seq_i % 64
+            if i == 0 and self._seq_i:
+                torch.cuda.current_stream().synchronize()       # the ring wraps: every earlier copy has been consumed
+            self._seq_i += 1
+            s32 = pool.seq_of(env0, B) & 0xffffffff               # the granules carry the step number modulo 2^32
+            self._seq_pin[i] = s32 - (1 << 32) if s32 >= (1 << 31) else s32
+            self._seq_dev.copy_(self._seq_pin[i:i + 1], non_blocking=True)
         stash = self._stash_bufs
         fused = h is None and getattr(net, "_step_supported", lambda: False)()
         if stash is not None and isinstance(stash, list) == fused:      # tuple (a1, a2): step kernel; list: conv-stack nets
@@ -562,11 +599,16 @@ class Runner:
         fr = rew = done = None
         if k > 0 and c.get("relay"):       # what env step k-1 returned: waited for and fetched by the device itself
             rew, done = self.d_rew[env0:env0 + B], self.d_done[env0:env0 + B]
-            fs = self.fstride
-            dst = self.d_frames.data_ptr() + env0 * fs
-            ops.pool_ingest(pool.dev_rec + 8 * env0, pool.dev_frames + env0 * fs, fs, fs, B, self._seq_dev, k,
-                            int(float(try_key(hyps, "env_timeout_s", 20.0)) * 1e8), self.rollout_err, rew, done, dst, fs, st)
-            fr = _Frames(ptr8=dst, stride=fs) if self.u8 else _Frames(ptr32=dst)
+            fs, ds = self.fstride, self.dstride
+            dst = self.d_frames.data_ptr() + env0 * ds
+            ticks = int(float(try_key(hyps, "env_timeout_s", 20.0)) * 1e8)
+            if self.bits:
+                ops.pool_ingest_bits(pool.dev_rec + 8 * env0, pool.dev_frames + env0 * fs, fs, HW, B, self._seq_dev, k,
+                                     ticks, self.rollout_err, rew, done, dst, ds, st)
+            else:
+                ops.pool_ingest(pool.dev_rec + 8 * env0, pool.dev_frames + env0 * fs, fs, fs, B, self._seq_dev, k,
+                                ticks, self.rollout_err, rew, done, dst, ds, st)
+            fr = self._staged_frames(dst, env0, B, st)
         elif k > 0:     # what env step k-1 returned: pinned staging -> HBM
             rew, done = self.d_rew[env0:env0 + B], self.d_done[env0:env0 + B]
             rew.copy_(self.h_rew[env0:env0 + B], non_blocking=True)
@@ -680,7 +722,7 @@ class Runner:
         if acts_host_out is not None:
             acts_host_out[slot0 * T + t:(slot0 + B) * T:T] = self.h_act[env0:env0 + B]
         if self.proc_pool:
-            k = pool.seq + t
+            k = pool.seq_of(env0, B) + t
             pool.post_actions(na, env0=env0, seq=k)
             pool.wait_frames(k + 1, env0=env0, n=B, timeout=float(try_key(self.hyps, "env_timeout_s", 20.0)))
             pool.unpack(self.np_rew[env0:env0 + B], self.np_done[env0:env0 + B], env0=env0)
@@ -735,7 +777,8 @@ class Runner:
                         actions=acts.data_ptr(), val_prev=val_prev.data_ptr(), rewards=D["rewards"].data_ptr(),
                         dones=D["dones"].data_ptr(), deltas=D["deltas"].data_ptr(), T=T, slot0=slot0,
                         gamma=float(hyps["gamma"]), pong=int("Pong" in hyps["env_type"]), cmd=pool.dev_cmd, rec=pool.dev_rec,
-                        frames=pool.dev_frames, frame_stride=self.fstride, seq0=pool.seq, env0=env0,
+                        frames=pool.dev_frames, frame_stride=self.fstride, frame_bits=int(self.bits),
+                        seq0=pool.seq_of(env0, B) & 0xffffffff, env0=env0,
                         err=self.rollout_err.data_ptr(), timeout_ticks=int(timeout_s * 1e8),
                         a1_rows=0 if self._stash_bufs is None else self._stash_bufs[0].data_ptr(),
                         a2_rows=0 if self._stash_bufs is None else self._stash_bufs[1].data_ptr(),
@@ -764,7 +807,7 @@ class Runner:
             return None
         fs = getattr(self, "_fstore", None)
         if fs is None:
-            if self.env_pool.seq != 0 or R != self.B:
+            if (self.env_pool.seq_env != self.env_pool.seq_start).any() or R != self.B:
                 self._fstore_ok = False
                 return None
             F_ = torch.zeros((R, T + 4, self.HW), dtype=torch.uint8, device=dev)
@@ -793,18 +836,35 @@ class Runner:
         torch.cuda.current_stream().synchronize()
         return ha
 
+    def _staged_frames(self, dst, env0, B, st):
+        """_Frames of the B frames staged at ``dst`` (stride self.dstride): uint8 pixels, or fp32 (compacted to dense
+        rows first when the pool's slots are padded: frame sizes that are not a multiple of 16 B)"""
+        if self.u8:
+            return _Frames(ptr8=dst, stride=self.dstride)
+        if self.d_dense is None:
+            return _Frames(ptr32=dst)
+        dense = self.d_dense.data_ptr() + 4 * env0 * self.HW
+        ops.copy_rows(dst, self.dstride // 4, dense, self.HW, B, self.HW, st)
+        return _Frames(ptr32=dense)
+
     def _pool_frames_h2d(self, pool, env0, B, st):
         """hipMemcpyAsync of the frames block of envs env0..env0+B from the pinned region into HBM"""
-        fs = self.fstride
-        dst = self.d_frames.data_ptr() + env0 * fs
-        ops.memcpy_async(dst, pool.region.base + pool.header.off_frames + env0 * fs, B * fs, ops.H2D, st)
-        return _Frames(ptr8=dst, stride=fs) if self.u8 else _Frames(ptr32=dst)
+        fs, ds = self.fstride, self.dstride
+        dst = self.d_frames.data_ptr() + env0 * ds
+        src = pool.region.base + pool.header.off_frames + env0 * fs
+        if self.bits:       # the packed slots cross the link, one kernel expands them to the uint8 pixels the step kernels read
+            pk = self.d_packed.data_ptr() + env0 * fs
+            ops.memcpy_async(pk, src, B * fs, ops.H2D, st)
+            ops.unpack_bits(pk, fs, dst, ds, B, self.HW, st)
+        else:
+            ops.memcpy_async(dst, src, B * fs, ops.H2D, st)
+        return self._staged_frames(dst, env0, B, st)
 
     def _pool_step(self, pool, act, a_stride, env0, B, t, slot0, T, acts_host_out):
         """memcpy ingest with the process pool: actions D2H -> the workers step their envs in parallel ->
         frames H2D from the pinned region (uint8 when the pool carries uint8) + rewards / dones."""
         ha = self._actions_to_host(act, a_stride, env0, B, t, slot0, T)
-        k = pool.seq + t
+        k = pool.seq_of(env0, B) + t
         na = self.np_act[env0:env0 + B]
         pool.post_actions(na, env0=env0, seq=k)
         if acts_host_out is not None:

@@ -9,7 +9,9 @@
 #include <time.h>
 #if defined(__x86_64__) || defined(__i386__)
 #include <immintrin.h>
+#include <emmintrin.h>
 #define cpu_relax() _mm_pause()
+#define A2C_HAVE_SSE2 1
 #else
 #define cpu_relax() __asm__ __volatile__("" ::: "memory")
 #endif
@@ -43,7 +45,7 @@ size_t a2c_pool_bytes(int n_envs, int frame_bytes) {
 int a2c_pool_init(void *base, size_t bytes, int n_envs, int frame_bytes, int frame_dtype, int n_workers,
                   double rew_ema0) {
   if (!base || n_envs < 1 || frame_bytes < 1 || bytes < a2c_pool_bytes(n_envs, frame_bytes)) return -1;
-  if (frame_dtype != A2C_FRAME_U8 && frame_dtype != A2C_FRAME_F32) return -1;
+  if (frame_dtype != A2C_FRAME_U8 && frame_dtype != A2C_FRAME_F32 && frame_dtype != A2C_FRAME_BITS) return -1;
   a2c_pool_header *h = hdr(base);
   memset(h, 0, 4096);
   h->version = A2C_POOL_VERSION;
@@ -57,6 +59,9 @@ int a2c_pool_init(void *base, size_t bytes, int n_envs, int frame_bytes, int fra
   h->off_frames = h->off_rec + align_up((size_t)n_envs * 8, 4096);
   h->total_bytes = a2c_pool_bytes(n_envs, frame_bytes);
   h->rew_ema = rew_ema0;
+  h->frame_elems = frame_dtype == A2C_FRAME_F32 ? (uint32_t)frame_bytes / 4u
+                   : frame_dtype == A2C_FRAME_BITS ? (uint32_t)frame_bytes * 8u : (uint32_t)frame_bytes;
+  h->seq_start = 0;
   uint64_t *c = cmd_of(base), *r = rec_of(base);
   for (int j = 0; j < n_envs; ++j) {
     c[j] = ~0ULL;      /* seq 0xffffffff: nothing requested yet */
@@ -65,6 +70,9 @@ int a2c_pool_init(void *base, size_t bytes, int n_envs, int frame_bytes, int fra
   __atomic_store_n(&h->magic, A2C_POOL_MAGIC, __ATOMIC_RELEASE);
   return 0;
 }
+
+void a2c_pool_set_frame_elems(void *base, uint32_t frame_elems) { hdr(base)->frame_elems = frame_elems; }
+void a2c_pool_set_seq_start(void *base, uint32_t seq_start) { hdr(base)->seq_start = seq_start; }
 
 int a2c_pool_check(const void *base) {
   if (!base) return -1;
@@ -111,6 +119,48 @@ void a2c_pool_publish(void *base, int env, const void *frame, uint32_t seq, floa
   __atomic_store_n(rec_of(base) + env, g, __ATOMIC_RELEASE);   /* frame bytes are visible before the tag */
 }
 
+/* n uint8 pixels (each 0 / 1) -> ceil(n/8) bytes, pixel p = bit p%8 of byte p/8; returns the OR of all pixels */
+static unsigned pack_bits(const uint8_t *src, uint8_t *dst, size_t n) {
+  size_t p = 0;
+  unsigned any = 0;
+#ifdef A2C_HAVE_SSE2
+  __m128i acc = _mm_setzero_si128();
+  for (; p + 16 <= n; p += 16) {
+    const __m128i x = _mm_loadu_si128((const __m128i *)(src + p));
+    acc = _mm_or_si128(acc, x);
+    const unsigned m = (unsigned)_mm_movemask_epi8(_mm_slli_epi16(x, 7));   /* bit 0 of every byte -> its sign bit */
+    dst[p >> 3] = (uint8_t)m;
+    dst[(p >> 3) + 1] = (uint8_t)(m >> 8);
+  }
+  acc = _mm_or_si128(acc, _mm_srli_si128(acc, 8));
+  acc = _mm_or_si128(acc, _mm_srli_si128(acc, 4));
+  acc = _mm_or_si128(acc, _mm_srli_si128(acc, 2));
+  acc = _mm_or_si128(acc, _mm_srli_si128(acc, 1));
+  any = (unsigned)_mm_cvtsi128_si32(acc) & 0xffu;
+#endif
+  for (; p < n; p += 8) {
+    unsigned b = 0;
+    for (size_t q = 0; q < 8 && p + q < n; ++q) {
+      any |= src[p + q];
+      b |= (unsigned)(src[p + q] & 1u) << q;
+    }
+    dst[p >> 3] = (uint8_t)b;
+  }
+  return any;
+}
+
+int a2c_pool_publish_bits(void *base, int env, const uint8_t *frame_u8, uint32_t seq, float rew, int done) {
+  a2c_pool_header *h = hdr(base);
+  if (h->frame_dtype != A2C_FRAME_BITS) return -1;
+  uint8_t *slot = (uint8_t *)base + h->off_frames + (size_t)env * h->frame_stride;
+  if (pack_bits(frame_u8, slot, h->frame_elems) > 1u) return -1;       /* not a binary frame: refuse, do not mangle */
+  uint32_t rb;
+  memcpy(&rb, &rew, 4);
+  const uint64_t g = ((uint64_t)((seq << 1) | (done ? 1u : 0u)) << 32) | rb;
+  __atomic_store_n(rec_of(base) + env, g, __ATOMIC_RELEASE);
+  return 0;
+}
+
 void a2c_pool_episode(void *base, double ep_rew) {
   a2c_pool_header *h = hdr(base);
   while (__atomic_exchange_n(&h->ema_lock, 1u, __ATOMIC_ACQUIRE)) cpu_relax();
@@ -135,7 +185,7 @@ int a2c_pool_wait_frames(void *base, int env0, int n, uint32_t seq, int64_t time
   const int64_t t0 = now_ns();
   int i = 0;
   for (unsigned sweep = 0; i < n; ++sweep) {
-    while (i < n && (uint32_t)(__atomic_load_n(r + i, __ATOMIC_ACQUIRE) >> 33) == seq) ++i;
+    while (i < n && (uint32_t)(__atomic_load_n(r + i, __ATOMIC_ACQUIRE) >> 33) == (seq & 0x7fffffffu)) ++i;
     if (i == n) break;
     if ((sweep & 63) == 63) {
       if (__atomic_load_n(&hdr(base)->worker_error, __ATOMIC_ACQUIRE)) return -3;
@@ -190,10 +240,19 @@ static void *worker_main(void *p) {
   char *frames = (char *)w->base + h->off_frames;
   uint32_t *next_seq = (uint32_t *)calloc((size_t)w->n, sizeof(uint32_t));
   double *ep_rew = (double *)calloc((size_t)w->n, sizeof(double));
+  /* packed transport: the env writes its uint8 observation into this thread's scratch (cache resident), the
+   * pixels are packed 8 to a byte into the pinned slot */
+  const int bits = h->frame_dtype == A2C_FRAME_BITS;
+  uint8_t *scratch = bits ? (uint8_t *)calloc((size_t)h->frame_elems + 64, 1) : NULL;
+  int bad = 0;
   for (int i = 0; i < w->n; ++i) {          /* frame 0 = reset observation, done = 1 */
-    w->vt->reset(w->envs[w->env0 + i], frames + (size_t)(w->env0 + i) * h->frame_stride);
-    publish_inplace(w->base, w->env0 + i, 0, 0.f, 1);
+    void *slot0 = frames + (size_t)(w->env0 + i) * h->frame_stride;
+    w->vt->reset(w->envs[w->env0 + i], bits ? (void *)scratch : slot0);
+    if (bits && pack_bits(scratch, (uint8_t *)slot0, h->frame_elems) > 1u) bad = 1;
+    next_seq[i] = h->seq_start;
+    publish_inplace(w->base, w->env0 + i, h->seq_start, 0.f, 1);
   }
+  if (bad) a2c_pool_worker_failed(w->base, w->env0);
   a2c_pool_worker_ready(w->base);
   for (;;) {
     int32_t action = 0;
@@ -201,7 +260,8 @@ static void *worker_main(void *p) {
     if (i == -2) break;
     if (i < 0) continue;
     const int j = w->env0 + i;
-    void *slot = frames + (size_t)j * h->frame_stride;
+    void *pinned = frames + (size_t)j * h->frame_stride;
+    void *slot = bits ? (void *)scratch : pinned;
     float rew = 0.f;
     int done = 0;
     w->vt->step(w->envs[j], action + w->shift, slot, &rew, &done);      /* runner.py:208 */
@@ -213,11 +273,16 @@ static void *worker_main(void *p) {
       ep_rew[i] = 0.0;
     }
     if (reset) w->vt->reset(w->envs[j], slot);                           /* utils.py:36-38 */
+    if (bits && pack_bits(scratch, (uint8_t *)pinned, h->frame_elems) > 1u) {
+      a2c_pool_worker_failed(w->base, j);                                /* not a binary frame */
+      break;
+    }
     next_seq[i] += 1;
     publish_inplace(w->base, j, next_seq[i], rew, reset);
   }
   free(next_seq);
   free(ep_rew);
+  free(scratch);
   return NULL;
 }
 

@@ -235,6 +235,28 @@ __global__ __launch_bounds__(256) void pool_publish_kernel(unsigned long long* _
   __hip_atomic_store(cmd + i, (seq << 32) | (unsigned int)actions[i * stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// 16 packed pixels (bit q = pixel q) -> 16 uint8 pixels
+__device__ __forceinline__ u32x4 expand_bits16(unsigned int b) {
+  u32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned int w = b >> (4 * q);
+    v[q] = (w & 1u) | ((w & 2u) << 7) | ((w & 4u) << 14) | ((w & 8u) << 21);
+  }
+  return v;
+}
+
+// packed frames (A2C_FRAME_BITS transport, staged in HBM by a memcpy) -> uint8 frames; n_pixels % 16 == 0
+__global__ __launch_bounds__(256) void unpack_bits_kernel(const uint8_t* __restrict__ src, long sstride,
+                                                          uint8_t* __restrict__ dst, long dstride, int n_pixels) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;           // group of 16 pixels
+  if (i * 16 >= n_pixels) return;
+  const unsigned int bits = reinterpret_cast<const unsigned short*>(src + (long)b * sstride)[i];
+  *reinterpret_cast<u32x4*>(dst + (long)b * dstride + i * 16) = expand_bits16(bits);
+}
+
+template <bool BITS>
 __global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long long* __restrict__ rec,
                                                           const uint8_t* __restrict__ frames, long fstride, int fbytes,
                                                           const unsigned int* __restrict__ seq_base, unsigned int seq_off,
@@ -243,7 +265,7 @@ __global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long lo
   __shared__ unsigned int sh[2];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {
-    const unsigned int want = seq_base[0] + seq_off;
+    const unsigned int want = (seq_base[0] + seq_off) & 0x7fffffffu;      // rec carries the step number modulo 2^31
     unsigned long long gr = ~0ULL;
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       const unsigned long long t0 = wall_clock64();
@@ -271,6 +293,13 @@ __global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long lo
   // the frame was written before its rec granule (release): 16-byte system-scope loads straight from pinned host memory
   __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(frames + (long)b * fstride), 0, fbytes, 0x00020000);
   uint8_t* __restrict__ o = out + (long)b * ostride;
+  if (BITS) {     // fbytes = ceil(n_pixels / 8) packed bytes: 2 bytes per lane -> 16 uint8 pixels in HBM
+    for (int off = tid * 2; off < fbytes; off += 256 * 2) {
+      const unsigned int bits = __builtin_amdgcn_raw_buffer_load_b16(fr, off, 0, 1 | 16);
+      *reinterpret_cast<u32x4*>(o + off * 8) = expand_bits16(bits);
+    }
+    return;
+  }
   for (int off = tid * 16; off < fbytes; off += 256 * 16) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(fr, off, 0, 1 | 16);   // sc0 sc1
     *reinterpret_cast<u32x4*>(o + off) = v;
@@ -476,9 +505,36 @@ int a2c_pool_ingest(const uint64_t* rec, const uint8_t* frames, int64_t frame_st
       out_stride < frame_bytes || timeout_ticks < 1 || ((uintptr_t)frames % 16) || ((uintptr_t)frames_out % 16))
     return A2C_ERR_ARG;
   if (n == 0) return A2C_OK;
-  hipLaunchKernelGGL(pool_ingest_kernel, dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
+  hipLaunchKernelGGL(pool_ingest_kernel<false>, dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
                      (long)frame_stride, frame_bytes, seq_base, seq_off, (long)timeout_ticks, err, rew, done, frames_out,
                      (long)out_stride);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_pool_ingest_bits(const uint64_t* rec, const uint8_t* frames, int64_t frame_stride, int n_pixels, int n,
+                         const uint32_t* seq_base, uint32_t seq_off, int64_t timeout_ticks, int* err, float* rew, float* done,
+                         uint8_t* frames_out, int64_t out_stride, a2c_stream_t stream) {
+  if (n < 0 || !rec || !frames || !seq_base || !err || !rew || !done || !frames_out) return A2C_ERR_ARG;
+  if (n_pixels < 16 || n_pixels % 16 || frame_stride % 16 || out_stride % 16 || frame_stride * 8 < n_pixels ||
+      out_stride < n_pixels || timeout_ticks < 1 || ((uintptr_t)frames % 16) || ((uintptr_t)frames_out % 16))
+    return A2C_ERR_ARG;
+  if (n == 0) return A2C_OK;
+  hipLaunchKernelGGL(pool_ingest_kernel<true>, dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
+                     (long)frame_stride, n_pixels / 8, seq_base, seq_off, (long)timeout_ticks, err, rew, done, frames_out,
+                     (long)out_stride);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_unpack_bits(const uint8_t* src, int64_t src_stride, uint8_t* dst, int64_t dst_stride, int n, int n_pixels,
+                    a2c_stream_t stream) {
+  if (n < 0 || !src || !dst || n_pixels < 16 || n_pixels % 16 || src_stride % 2 || src_stride * 8 < n_pixels ||
+      dst_stride % 16 || dst_stride < n_pixels || ((uintptr_t)src % 2) || ((uintptr_t)dst % 16))
+    return A2C_ERR_ARG;
+  if (n == 0) return A2C_OK;
+  hipLaunchKernelGGL(unpack_bits_kernel, dim3((n_pixels / 16 + 255) / 256, n), dim3(256), 0, a2c_s(stream), src,
+                     (long)src_stride, dst, (long)dst_stride, n_pixels);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -59,6 +59,7 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   float* heads_rows; long heads_rows_ld;
   unsigned char* fstore; long fs_slot_stride;      // single-frame uint8 store (T+4 frames per slot)
   int* nvalid; int* nvalid_carry;
+  int frame_bits;                                  // the pool publishes one bit per pixel (A2C_FRAME_BITS)
 };
 
 struct StepP {
@@ -276,9 +277,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         ld_d = (g_hi & 1u) ? 1.f : 0.f;
         ld_rst = ld_d;
         // the frame: the whole uint8 plane in one 16-byte system-scope load per thread, over PCIe
-        __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW, 0x00020000);
-        f8 = __builtin_amdgcn_raw_buffer_load_b128(fr, tid * 16, 0, 1 | 16);   // sc0 sc1
+        if (p.x.frame_bits) {
+          // packed transport: this thread's 16 pixels are 2 bytes of the slot (HW / 8 bytes per env cross PCIe)
+          __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW >> 3, 0x00020000);
+          const unsigned int bits = __builtin_amdgcn_raw_buffer_load_b16(fr, tid * 2, 0, 1 | 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned int wq = bits >> (4 * q);
+            f8[q] = (wq & 1u) | ((wq & 2u) << 7) | ((wq & 4u) << 14) | ((wq & 8u) << 21);
+          }
+        } else {
+          __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW, 0x00020000);
+          f8 = __builtin_amdgcn_raw_buffer_load_b128(fr, tid * 16, 0, 1 | 16);   // sc0 sc1
+        }
         // single-frame store: the newest frame of state t is frames[slot][t + 3]
         if (fs_slot != nullptr && tid * 16 < HW) *reinterpret_cast<u32x4*>(fs_slot + (long)(t + 3) * HW + tid * 16) = f8;
       }
@@ -683,6 +696,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.heads_rows = r->heads_rows; p.x.heads_rows_ld = (long)r->heads_rows_ld;
   p.x.fstore = r->frame_store; p.x.fs_slot_stride = (long)r->frame_store_slot_stride;
   p.x.nvalid = r->nvalid_rows; p.x.nvalid_carry = r->nvalid_carry;
+  p.x.frame_bits = r->frame_bits ? 1 : 0;
   if (r->frame_store && (!r->nvalid_rows || !r->nvalid_carry || r->T < 4 || ((uintptr_t)r->frame_store % 16) ||
                          r->frame_store_slot_stride % 16 || r->frame_store_slot_stride < (r->T + 4) * (int64_t)r->H * r->W))
     return A2C_ERR_ARG;
@@ -691,7 +705,9 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   if (!r->states || !r->bookmark || !r->u || !r->actions || !r->cmd || !r->rec || !r->frames || !r->err) return A2C_ERR_ARG;
   if (!a.wfrag1 || !a.bias1 || !a.wfrag2 || !a.bias2 || !a.Wc || !a.bc || !a.heads) return A2C_ERR_ARG;
   if (!a.val_prev || !a.rewards || !a.dones || !a.deltas || a.T < 1 || a.ldh < a.n_actions + 1) return A2C_ERR_ARG;
-  if (r->frame_stride % 16 || r->frame_stride < a.H * a.W || r->timeout_ticks < 1 || r->env0 < 0) return A2C_ERR_ARG;
+  if (r->frame_stride % 16 || r->frame_stride < (r->frame_bits ? (a.H * a.W + 7) / 8 : a.H * a.W) || r->timeout_ticks < 1 ||
+      r->env0 < 0)
+    return A2C_ERR_ARG;
   if ((r->a1_rows || r->a2_rows) && ((p.OH1 * p.OW1) % 4 || (((uintptr_t)r->a1_rows | (uintptr_t)r->a2_rows) % 16))) return A2C_ERR_ARG;
   if ((((uintptr_t)r->states | (uintptr_t)r->bookmark | (uintptr_t)r->frames | (uintptr_t)a.wfrag2 | (uintptr_t)a.Wc) % 16) ||
       (((uintptr_t)r->cmd | (uintptr_t)r->rec) % 8))

@@ -108,7 +108,9 @@ class U8FakeEnv(O.FakeEnv):
 
 
 class F32FakeEnv(O.FakeEnv):
-    """O.FakeEnv with grey-level frames (b/255, like breakout_prep's rgb2grey floats): fp32 transport"""
+    """O.FakeEnv with float grey-level frames in [0, 1): the fp32 transport of the host pool.  (NOT what the reference's
+    breakout_prep yields: its rgb2grey acts on an already 2-D uint8 slice and returns it unchanged -- uint8 0..255, see
+    a2c_amd/preprocessing.py; this env only exercises the fp32 path.)"""
 
     def __init__(self, **kw):
         super().__init__(binary=False, **kw)

@@ -137,3 +137,92 @@ def test_native_thread_pool_is_byte_identical_to_python_tape_envs():
         assert pool.header.episodes == n_eps
     finally:
         pool.close()
+
+
+@pytest.mark.parametrize("kind", ["process", "thread"])
+def test_packed_bits_transport_carries_the_same_frames(kind):
+    """A2C_FRAME_BITS (binary preprocessors, preprocessing.py:15-16): one bit per pixel in the pinned slots; unpacked
+    they are byte for byte the uint8 frames of the same envs, rewards / dones unchanged"""
+    from a2c_amd.hostpool import FRAME_BITS, ThreadEnvPool
+    B, K = 5, 30
+    if kind == "process":
+        kws = [dict(env_id=j, rew_period=3 + j % 3, done_period=5 + j) for j in range(B)]
+        pool = ProcessEnvPool(U8FakeEnv, B, env_kwargs=kws, n_workers=2, pong=True, register=False, frame_bits=True)
+        refs = [U8FakeEnv(**kw) for kw in kws]
+    else:
+        kws = [dict(env_id=j, length=13, p_done=0.07) for j in range(B)]
+        pool = ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=2, register=False, pong=True, frame_bits=True)
+        refs = [TapeEnv(**k) for k in kws]
+    try:
+        pool.start()
+        pool.set_phase(ROLLOUT)
+        h = pool.header
+        assert h.frame_dtype == FRAME_BITS and h.frame_bytes == 882 and h.frame_stride == 896 and h.frame_elems == 7056
+        assert pool.transport == "bits" and pool.frame_dtype == np.uint8
+        pool.wait_frames(0)
+        for j in range(B):
+            assert np.array_equal(pool.frames_view()[j], np.asarray(refs[j].reset()).astype(np.uint8))
+        rew, done = np.zeros(B, np.float32), np.zeros(B, np.float32)
+        for k in range(K):
+            pool.post_actions(np.full(B, k % 3, np.int64), seq=k)
+            pool.wait_frames(k + 1)
+            pool.unpack(rew, done)
+            fr = pool.frames_view()
+            for j in range(B):
+                o, r, d = _ref_step(refs[j], k % 3, 0)
+                assert np.array_equal(fr[j], np.asarray(o).astype(np.uint8)), (k, j)
+                assert rew[j] == np.float32(r) and done[j] == float(d), (k, j)
+    finally:
+        pool.close()
+
+
+class _GreyEnv(U8FakeEnv):
+    """uint8 frames that are NOT binary"""
+
+    def _frame(self):
+        return (super()._frame() * 7).astype(np.uint8)
+
+
+def test_packed_bits_transport_refuses_non_binary_frames():
+    pool = ProcessEnvPool(_GreyEnv, 2, env_kwargs=[dict(env_id=j) for j in range(2)], n_workers=1, register=False,
+                          frame_bits=True, frame_shape=(1, 84, 84), frame_dtype=np.uint8)
+    try:
+        with pytest.raises(RuntimeError, match="env worker"):
+            pool.start(timeout=30.0)
+            pool.wait_frames(0, timeout=10.0)
+    finally:
+        pool.close()
+
+
+@pytest.mark.parametrize("kind", ["process", "thread"])
+def test_step_counter_wraps_at_2_31_on_the_rec_side(kind):
+    """rec carries (seq << 1 | done) in 32 bits = seq modulo 2^31, cmd carries seq modulo 2^32: an env that has taken
+    more than 2^31 steps must keep answering (the host side compares modulo 2^31, like the kernels do)"""
+    from a2c_amd.hostpool import ThreadEnvPool
+    B, s0 = 3, (1 << 31) - 3
+    if kind == "process":
+        kws = [dict(env_id=j, rew_period=3, done_period=5 + j) for j in range(B)]
+        pool = ProcessEnvPool(U8FakeEnv, B, env_kwargs=kws, n_workers=2, register=False, seq_start=s0)
+        refs = [U8FakeEnv(**kw) for kw in kws]
+    else:
+        kws = [dict(env_id=j, length=13, p_done=0.07) for j in range(B)]
+        pool = ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=2, register=False, seq_start=s0)
+        refs = [TapeEnv(**k) for k in kws]
+    try:
+        pool.start()
+        pool.set_phase(ROLLOUT)
+        assert pool.seq == s0
+        pool.wait_frames(s0, timeout=10.0)
+        for j in range(B):
+            refs[j].reset()
+        rew, done = np.zeros(B, np.float32), np.zeros(B, np.float32)
+        for k in range(8):                                    # crosses 2^31 - 1 -> 2^31
+            pool.post_actions(np.zeros(B, np.int64), seq=s0 + k)
+            pool.wait_frames(s0 + k + 1, timeout=10.0)
+            pool.unpack(rew, done)
+            fr = pool.frames_view()
+            for j in range(B):
+                o, r, d = _ref_step(refs[j], 0, 0)
+                assert np.array_equal(fr[j], np.asarray(o).astype(np.uint8)) and rew[j] == np.float32(r) and done[j] == float(d)
+    finally:
+        pool.close()

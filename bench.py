@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # fp32 matrix == fp32 vector peak
 PCIE_PEAK_GBS = 63.0         # host link: PCIe Gen5 x16 (spec)
 SS = (4, 84, 84)
-FRAME_BYTES = 84 * 84        # uint8 transport
+FRAME_BYTES = {"u8": 84 * 84, "bits": 84 * 84 // 8}      # bytes per frame over the host link, by transport
 
 
 def hyps_for(model, n_envs, T, use_bptt, optim):
@@ -93,16 +93,18 @@ class SyntheticDevicePool:
         return self.frames[t, sl], self.rew[t, sl], self.done[t, sl], self.done[t, sl]
 
 
-def make_host_pool(n_envs, T, kind, n_workers, seed):
-    """host env workers stepping synthetic.TapeEnv tapes (uint8 frames) behind the pinned region"""
+def make_host_pool(n_envs, T, kind, n_workers, seed, transport="bits"):
+    """host env workers stepping synthetic.TapeEnv tapes (binary uint8 frames, like pong_prep's) behind the pinned
+    region; transport "bits": the workers pack every frame to one bit per pixel on its way into the pinned slot"""
     from a2c_amd.hostpool import ProcessEnvPool, ThreadEnvPool
     from a2c_amd.synthetic import TapeEnv
     L = min(T + 1, 33)          # tape length per env: content does not affect cost, keeps host memory small
     kws = [dict(env_id=seed * 100000 + j, length=L) for j in range(n_envs)]
+    bits = transport == "bits"
     if kind == "native":
-        return ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=n_workers, pong=True)
+        return ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=n_workers, pong=True, frame_bits=bits)
     return ProcessEnvPool(TapeEnv, n_envs, env_kwargs=kws, n_workers=n_workers, pong=True, frame_shape=(1, 84, 84),
-                          frame_dtype=np.uint8)
+                          frame_dtype=np.uint8, frame_bits=bits)
 
 
 # ---------------------------------------------------------------- CPU baseline (oracle, host cores)
@@ -247,7 +249,8 @@ def scan_roofline(device):
 class Bench:
     """net + rollout buffers + env pool + Runner + Updater of one workload; ``step()`` = rollout + update."""
 
-    def __init__(self, workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, update_graph=True):
+    def __init__(self, workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, update_graph=True,
+                 transport="bits"):
         import a2c_amd
         from a2c_amd.runner import Runner
         from a2c_amd.updater import Updater
@@ -268,17 +271,17 @@ class Bench:
         self.slots = list(range(self.n_envs))
         self.graph = self.ugraph = None
         self.graph_stash = False
-        self.env_workers = env_workers
+        self.env_workers, self.transport = env_workers, transport
         if ingest == "device-tape":
             self.pool = pool = SyntheticDevicePool(self.n_envs, self.T, dev, seed=shard.rank)
             self.runner = Runner(D, self.hyps, None, None, None, env_pool=pool,
                                  uniform_fn=lambda t, B, e0: pool.uniforms[t, e0:e0 + B])
         else:
-            self.pool = pool = make_host_pool(self.n_envs, self.T, env_workers, n_workers, seed=shard.rank)
+            self.pool = pool = make_host_pool(self.n_envs, self.T, env_workers, n_workers, seed=shard.rank, transport=transport)
             self.runner = Runner(D, self.hyps, None, None, None, env_pool=pool,
                                  ingest="memcpy" if ingest == "memcpy" else None)
         self.updater = Updater(net, self.hyps, shard=shard)
-        self.want_update_graph = update_graph and optim == "RMSprop"
+        self.want_update_graph = update_graph
         self.info = None
 
     # the rollout: a hipGraph replay (device tape) or the live host-pinned ingest
@@ -293,10 +296,7 @@ class Bench:
 
     def update(self):
         if self.ugraph is not None:
-            self.ugraph.replay()
-            self.updater.optim._steps += 1
-            self.net.mark_dirty()
-            return self.updater._finish_update(self.udev, self.u_nglobal)
+            return self.ugraph.replay()
         return self.updater.update_model(self.D)
 
     def step(self):
@@ -319,27 +319,17 @@ class Bench:
                 print(f"[bench] rollout hipGraph capture failed ({type(e).__name__}: {e}); eager rollout", file=sys.stderr)
                 self.graph = None
                 torch.cuda.synchronize()
-        # the update as a hipGraph: ~40 dependent launches whose stream gaps shrink to graph-edge gaps.  A sharded
-        # update carries its RCCL all-reduces inside the captured graph (collectives on the capturing stream are
-        # graph nodes like any kernel); gloo collectives are host calls and cannot be captured.
-        # Verified on one GPU (world 1, collectives forced on: tools/dbg/rccl_graph.py); with more than one rank it is
-        # opt-in (A2C_RCCL_GRAPH=1) because no multi-GPU box was available to this build to rule out a capture hang.
-        can = not self.shard.active or (torch.distributed.get_backend() == "nccl" and
-                                        (self.shard.world == 1 or os.environ.get("A2C_RCCL_GRAPH") == "1"))
-        if self.want_update_graph and can:
+        # the update as hipGraph(s): ~40 dependent launches whose stream gaps shrink to graph-edge gaps.  A sharded
+        # update is cut at its two collectives (advantage moments, gradient arena): graph, all-reduce on the stream,
+        # graph, all-reduce, graph -- no collective inside a capture (Updater.capture_update).  Adam's step count is a
+        # kernel argument, so its update stays eager.
+        if self.want_update_graph and self.optim_name == "RMSprop" and os.environ.get("A2C_NO_UPDATE_GRAPH") != "1":
             try:
                 # an update always follows a rollout: capture it in that state (the rollout's activation stash is
-                # valid, so the captured forward starts behind the two conv layers), then replay it once so that the
+                # valid, so the captured forward starts behind the conv layers), then replay it once so that the
                 # rollout that was just played is consumed like any other
                 self.rollout()
-                torch.cuda.synchronize()
-                ug = torch.cuda.CUDAGraph()
-                dirty, stash = self.net._dirty, self.net._stash
-                with torch.cuda.graph(ug, capture_error_mode="thread_local"):
-                    self.udev, self.u_nglobal = self.updater._enqueue_update(self.D)
-                self.ugraph = ug
-                self.net._dirty, self.net._stash = dirty, stash      # the capture itself did not run:
-                self.updater.optim._steps -= 1                        # ... no optimiser step happened
+                self.ugraph = self.updater.capture_update(self.D)
                 self.info = self.update()
             except Exception as e:      # noqa: BLE001
                 print(f"[bench] update hipGraph capture failed ({type(e).__name__}: {e}); eager update", file=sys.stderr)
@@ -385,6 +375,23 @@ class Bench:
         torch.cuda.synchronize()
         return timers.summary()
 
+    def rollout_site_timers(self):
+        """HIP events per launch site of ONE eager rollout (per-layer models: the timed rollouts replay a whole-slot
+        hipGraph, which has no per-site events); tuners are warm, so these are the kernels the graph replays"""
+        from a2c_amd import ops
+        if self.ingest == "device-tape" or self.runner._zero_copy_ok(self.net):
+            return None
+        timers = ops.KernelTimers()
+        hy = dict(self.hyps, rollout_graphs=False)
+        ops.TIMERS = timers
+        try:
+            self.runner.rollout(self.net, self.slots, hy)
+            self.runner.finish()
+        finally:
+            ops.TIMERS = None
+        self.update()                      # consume the rollout like any other
+        return timers.summary()
+
     def describe_ingest(self):
         if self.ingest == "device-tape":
             return "device-tape fp32 (frames pre-generated in HBM, rollout replayed as a hipGraph)"
@@ -394,7 +401,9 @@ class Bench:
             mode = "hipMemcpyAsync per step behind a host hand-off"
         else:
             mode = "per-step hipGraph segments; actions published and frames fetched by the device, a2c_pool_publish_actions / a2c_pool_ingest"
-        return (f"host-pinned uint8 ({mode}; {self.pool.n_workers} {'native env threads' if self.env_workers == 'native' else 'env worker processes'}"
+        tr = ("packed 1 bit/pixel (binary preprocessor, 882 B/frame over the link, expanded to uint8 {0,1} on the device)"
+              if self.transport == "bits" else "uint8 (7056 B/frame over the link)")
+        return (f"host-pinned {tr} ({mode}; {self.pool.n_workers} {'native env threads' if self.env_workers == 'native' else 'env worker processes'}"
                 f" behind one pinned device-mapped region)")
 
     def close(self):
@@ -404,9 +413,24 @@ class Bench:
             pass
 
 
-def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, steps, warmup):
-    """one extra BASELINE config: ms per step, env-steps/s, its dominant update launch site"""
-    b = Bench(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev)
+def site_roofline(name, site, conv_layers, batch, launches_note=""):
+    """roofline entry of one conv launch site: algorithmic in+out bytes and flops / its average HIP-event duration"""
+    lname, _, what = name.partition(".")
+    out = dict(site=name, avg_ms=round(site["avg_ms"], 4), launches=site["launches"])
+    if lname in conv_layers:
+        d = conv_layers[lname].d
+        sec = site["avg_ms"] * 1e-3
+        tf = conv_flops(d, batch) / sec / 1e12
+        gbs = conv_alg_bytes(d, batch) / sec / 1e9
+        out.update(batch=batch, tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / F32_PEAK_TFLOPS, 4),
+                   hbm_GBs=round(gbs, 1), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4),
+                   alg_bytes=conv_alg_bytes(d, batch), alg_flops=conv_flops(d, batch))
+    return out
+
+
+def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, steps, warmup, transport="bits"):
+    """one extra BASELINE config: ms per step, env-steps/s, its dominant update and rollout launch sites"""
+    b = Bench(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, transport=transport)
     try:
         b.step()
         b.capture()
@@ -415,19 +439,24 @@ def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, d
         elapsed, r_ms, u_ms = b.timed(steps)
         out = dict(workload=f"{b.model} n_envs={b.n_envs} n_tsteps={b.T}{' +BPTT' if b.use_bptt else ''}", steps=steps,
                    ms_per_step=round(1e3 * elapsed / steps, 3), value=round(b.N * steps / elapsed, 1), unit="env-steps/s",
-                   rollout_ms=round(r_ms, 3), update_ms=round(u_ms, 3), ingest=b.describe_ingest())
+                   rollout_ms=round(r_ms, 3), update_ms=round(u_ms, 3), ingest=b.describe_ingest(),
+                   update="hipGraph" if b.ugraph is not None else "eager")
+        layers = getattr(b.net, "_cl", None) or ([b.net._c1, b.net._c2] if hasattr(b.net, "_c1") else [])
+        conv = {l.name: l for l in layers}
         summ = b.site_timers(1)
         if summ:
             dom = max(summ, key=lambda k: summ[k]["total_ms"])
-            out["dominant_update_site"] = dict(site=dom, avg_ms=round(summ[dom]["avg_ms"], 4), launches=summ[dom]["launches"])
-            layers = getattr(b.net, "_cl", None) or ([b.net._c1, b.net._c2] if hasattr(b.net, "_c1") else [])
-            conv = {l.name: l for l in layers}
-            lname, _, what = dom.partition(".")
-            if lname in conv:
-                tf = conv_flops(conv[lname].d, b.N) / (summ[dom]["avg_ms"] * 1e-3) / 1e12
-                out["dominant_update_site"].update(tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / F32_PEAK_TFLOPS, 4))
+            out["dominant_update_site"] = site_roofline(dom, summ[dom], conv, b.N)
+            out["update_conv_sites"] = {k: site_roofline(k, v, conv, b.N) for k, v in summ.items() if k.split(".")[0] in conv}
+        rs = b.rollout_site_timers()
+        if rs:
+            # the rollout's forwards run at batch n_envs, T+1 times per slot (north star: HBM GB/s on the conv forward)
+            dom = max(rs, key=lambda k: rs[k]["total_ms"])
+            out["dominant_rollout_site"] = site_roofline(dom, rs[dom], conv, b.n_envs)
+            out["rollout_conv_fwd_sites"] = {k: site_roofline(k, v, conv, b.n_envs) for k, v in rs.items() if k.endswith(".fwd") and k.split(".")[0] in conv}
+            out["rollout_sites_total_ms"] = round(sum(v["total_ms"] for v in rs.values()), 3)
         if b.ingest != "device-tape" and r_ms > 0:
-            out["h2d_GBs"] = round(b.N * FRAME_BYTES / (r_ms * 1e-3) / 1e9, 2)
+            out["h2d_GBs"] = round(b.N * FRAME_BYTES[transport] / (r_ms * 1e-3) / 1e9, 2)
         return out
     finally:
         b.close()
@@ -466,6 +495,9 @@ def main():
     ap.add_argument("--global-envs", type=int, default=None, help="strong scaling: this many envs over all GPUs")
     ap.add_argument("--optim", default="RMSprop", choices=["RMSprop", "Adam"])
     ap.add_argument("--ingest", default="host-pinned", choices=["host-pinned", "memcpy", "device-tape"])
+    ap.add_argument("--transport", default="bits", choices=["bits", "u8"],
+                    help="what crosses the host link per frame: bits = 1 bit/pixel (the synthetic frames are binary like "
+                         "pong_prep's, preprocessing.py:15-16), u8 = one byte per pixel (any uint8 preprocessor)")
     ap.add_argument("--env-workers", default="native", choices=["native", "process"])
     ap.add_argument("--n-workers", type=int, default=None, help="env worker threads/processes per rank")
     ap.add_argument("--sustain-steps", type=int, default=200,
@@ -509,11 +541,16 @@ def main():
     # env workers per rank: the usable CPUs are shared by all ranks of the node
     n_workers = args.n_workers
     if n_workers is None:
-        per_rank = max(1, (usable_cpus() - 2) // max(shard.world, 1))
-        n_workers = max(1, min(8 if args.env_workers == "native" else 48, per_rank))
+        # this rank's share of the usable CPUs (the quota is shared by all ranks of the node), but never fewer than 4
+        # env threads: below that the hand-shake of 256 envs serialises behind one thread (the threads sleep-poll
+        # between rollouts, so over-subscription costs little while another rank's rollout is not running)
+        per_rank = max(4, (usable_cpus() - 2) // max(shard.world, 1))
+        n_workers = max(1, min(12 if args.env_workers == "native" else 48, per_rank))
+    print(f"[bench] rank {shard.rank}/{shard.world}: env_workers={n_workers} ({args.env_workers}), usable_cpus={usable_cpus()}",
+          file=sys.stderr)
 
     b = Bench(args.workload, n_envs, args.optim, args.ingest, args.env_workers, n_workers, shard, dev,
-              update_graph=not args.no_update_graph)
+              update_graph=not args.no_update_graph, transport=args.transport)
     model, T, A, N = b.model, b.T, b.A, b.N
     b.step()
     b.capture()
@@ -563,17 +600,20 @@ def main():
                config=dict(workload=f"{model} n_envs={b.n_envs} n_tsteps={T} 84x84x4 synthetic frames"
                                     f"{' +BPTT' if b.use_bptt else ''}, {args.optim}, per GPU",
                            ingest=ingest_desc, n_envs_per_gpu=b.n_envs, n_tsteps=T, optimizer=args.optim,
-                           env_workers=pool_workers, usable_host_cpus=usable_cpus(),
-                           update="hipGraph" if b.ugraph is not None else "eager", parallelism=parallelism),
+                           transport=args.transport, env_workers=pool_workers, usable_host_cpus=usable_cpus(),
+                           update=("hipGraph" if len(b.ugraph.graphs) == 1 else f"{len(b.ugraph.graphs)} hipGraphs around "
+                                   f"{len(b.ugraph.colls)} collectives") if b.ugraph is not None else "eager",
+                           parallelism=parallelism),
                rollout_ms=round(rollout_ms, 3), update_ms=round(update_ms, 3),
                last_info={k: round(float(v), 6) for k, v in (b.info or {}).items()})
     if sustained:
         out["sustained"] = sustained
     if args.ingest != "device-tape" and rollout_ms > 0:
-        gbs = b.n_envs * FRAME_BYTES * T / (rollout_ms * 1e-3) / 1e9
-        out["h2d"] = dict(bytes_per_update=b.n_envs * FRAME_BYTES * T, bytes_per_step=b.n_envs * FRAME_BYTES,
+        fb = FRAME_BYTES[args.transport]
+        gbs = b.n_envs * fb * T / (rollout_ms * 1e-3) / 1e9
+        out["h2d"] = dict(transport=args.transport, bytes_per_update=b.n_envs * fb * T, bytes_per_step=b.n_envs * fb,
                           achieved_GBs=round(gbs, 2), peak_GBs=PCIE_PEAK_GBS, frac=round(gbs / PCIE_PEAK_GBS, 4),
-                          note="uint8 frames, pinned host memory -> device, inside the timed region; rate over the rollout half")
+                          note="frames, pinned host memory -> device, inside the timed region; rate over the rollout half")
     if shard.active:
         out["rccl_ranks"] = torch.distributed.get_world_size() if torch.distributed.get_backend() == "nccl" else 0
         out["dist_backend"] = torch.distributed.get_backend()
@@ -595,7 +635,8 @@ def main():
             launches = 1 if zero_copy else T + 1
             us = rollout_ms * 1e3 / launches
             fl = step_alg_flops(A) * b.n_envs * (T + 1) / launches
-            by = step_alg_bytes(u8_frame=args.ingest != "device-tape") * b.n_envs * (T + 1) / launches
+            by = (step_alg_bytes(u8_frame=args.ingest != "device-tape") - (84 * 84 - FRAME_BYTES[args.transport] if args.ingest != "device-tape" else 0)) \
+                * b.n_envs * (T + 1) / launches
             tf = fl / (us * 1e-6) / 1e12
             name = ("a3c_step_kernel<persistent> = a2c_a3c_rollout (1 launch = %d steps x %d envs, paced by the host env "
                     "workers and the PCIe frame reads)" % (T + 1, b.n_envs)) if zero_copy else \
@@ -606,8 +647,12 @@ def main():
                                    hbm_frac=round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                    alg_flops_per_launch=fl, alg_bytes_per_launch=by)
             if zero_copy:
-                out["roofline"]["host_link"] = dict(out["h2d"], note="this launch is bounded by the host hand-shake: "
-                                                    "PCIe frame bytes / launch duration vs the 63 GB/s link")
+                link = dict(out["h2d"], note="PCIe frame bytes / launch duration vs the 63 GB/s link")
+                if link["frac"] > out["roofline"]["frac"]:
+                    # the launch is paced by the host link (uint8 transport): that fraction is the primary figure
+                    out["roofline"].update(bound="host_link", achieved=link["achieved_GBs"], peak=PCIE_PEAK_GBS, unit="GB/s",
+                                           frac=link["frac"], mfma_TFLOPs=round(tf, 2), mfma_frac=round(tf / F32_PEAK_TFLOPS, 4))
+                out["roofline"]["host_link"] = link
         elif dom is not None:
             ms = summ[dom]["avg_ms"]
             lname, _, what = dom.partition(".")
@@ -627,7 +672,7 @@ def main():
                                        frac=None, traffic=None)
         # HBM bytes per launch from the PMC passes committed under profiles/ (collected separately:
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/run_kernel.py at this exact size)
-        for tname in ("r2_traffic.json", "r1_traffic.json"):
+        for tname in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             tfile = os.path.join(ROOT, "profiles", tname)
             key = {"conv1.fwd": "conv1_fwd", "conv1.bwd_weight": "conv1_wgrad", "conv2.bwd_data": "conv2_bwd_data"}.get(dom)
             if "roofline" in out and out["roofline"].get("traffic") is None and args.workload == "a3c" and N == 32768 \
@@ -672,10 +717,28 @@ def main():
                 del d
             except Exception as e:      # noqa: BLE001
                 out["value_device_tape"] = dict(value=None, error=f"{type(e).__name__}: {e}")
+            if args.ingest == "host-pinned" and args.transport == "bits":
+                # the same headline with the generic uint8 transport (any uint8 preprocessor): host-link bound
+                try:
+                    d = Bench(args.workload, n_envs, args.optim, "host-pinned", args.env_workers, n_workers, shard, dev,
+                              transport="u8")
+                    d.step(); d.capture(); d.step()
+                    e, r_ms, u_ms = d.timed(40)
+                    gbs = d.N * FRAME_BYTES["u8"] / (r_ms * 1e-3) / 1e9
+                    out["host_pinned_u8_transport"] = dict(value=round(d.N * 40 / e, 1), unit="env-steps/s", steps=40,
+                                                           ms_per_step=round(1e3 * e / 40, 3), rollout_ms=round(r_ms, 3),
+                                                           update_ms=round(u_ms, 3),
+                                                           h2d=dict(transport="u8", achieved_GBs=round(gbs, 2), peak_GBs=PCIE_PEAK_GBS,
+                                                                    frac=round(gbs / PCIE_PEAK_GBS, 4)),
+                                                           note="one byte per pixel over the link (round 2's headline transport)")
+                    d.close()
+                    del d
+                except Exception as e:      # noqa: BLE001
+                    out["host_pinned_u8_transport"] = dict(value=None, error=f"{type(e).__name__}: {e}")
             if args.ingest == "host-pinned" and args.env_workers == "native":
                 try:
                     nw = max(1, min(48, usable_cpus() - 2))
-                    d = Bench(args.workload, n_envs, args.optim, "host-pinned", "process", nw, shard, dev)
+                    d = Bench(args.workload, n_envs, args.optim, "host-pinned", "process", nw, shard, dev, transport=args.transport)
                     d.step(); d.capture(); d.step()
                     e, r_ms, u_ms = d.timed(40)
                     out["host_pinned_process_workers"] = dict(value=round(d.N * 40 / e, 1), unit="env-steps/s", steps=40,
@@ -691,12 +754,13 @@ def main():
             cfgs = {}
             # BASELINE.json configs[1], [3], the north star's n_envs in {32, 2048} for the headline model, and the
             # per-GPU shard of configs[4] (ConvModel, 2048 envs over 8 GPUs = 256 envs x 128 steps per GPU)
-            for key, wl, ne, st_, wu in (("conv_32x64", "conv", None, 5, 2), ("gru_bptt_256x128", "gru_bptt", None, 3, 1),
-                                         ("a3c_32", "a3c", 32, 20, 3), ("a3c_2048", "a3c", 2048, 5, 2),
-                                         ("conv_2048x128_per_gpu_shard_256x128", "conv", 256, 2, 1)):
+            for key, wl, ne, st_, wu in (("conv_32x64", "conv", None, 20, 3), ("gru_bptt_256x128", "gru_bptt", None, 10, 2),
+                                         ("a3c_32", "a3c", 32, 40, 3), ("a3c_2048", "a3c", 2048, 10, 2),
+                                         ("conv_2048x128_per_gpu_shard_256x128", "conv", 256, 10, 2)):
                 try:
                     torch.cuda.empty_cache()
-                    cfgs[key] = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu)
+                    cfgs[key] = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu,
+                                           transport=args.transport)
                 except Exception as e:      # noqa: BLE001
                     cfgs[key] = dict(error=f"{type(e).__name__}: {e}")
             out["configs"] = cfgs

@@ -32,6 +32,9 @@ class Arena:
                 off = (end + ALIGN - 1) // ALIGN * ALIGN
             if group is train:
                 self.n_train = off
+                # ALIGN floats right behind the trainable prefix that travel WITH the gradient all-reduce of a sharded
+                # update (the three loss sums the reference reports, updater.py:134-136): one collective fewer
+                off += ALIGN
                 end = off
         self.size = off
         self.params = torch.zeros(off, dtype=torch.float32, device=device)
@@ -61,6 +64,13 @@ class Arena:
 
     def train_grads(self):
         return self.grads[:self.n_train]
+
+    def reduce_span(self):
+        """what one sharded update all-reduces: the gradients + the tail slot"""
+        return self.grads[:self.n_train + ALIGN]
+
+    def grad_tail(self):
+        return self.grads[self.n_train:self.n_train + ALIGN]
 
 
 class ConvLayer:

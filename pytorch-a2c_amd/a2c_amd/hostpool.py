@@ -158,11 +158,19 @@ class Region:
 
 
 def _dump_spec(spec):
+    """the worker's spec, env factory included.  cloudpickle (optional dependency) carries lambdas / closures / classes
+    of __main__; plain pickle only module-level callables"""
     try:
         import cloudpickle
+    except ImportError:
+        cloudpickle = None
+    if cloudpickle is not None:
         return cloudpickle.dumps(spec)
-    except Exception:      # noqa: BLE001
+    try:
         return pickle.dumps(spec)
+    except Exception as e:      # noqa: BLE001
+        raise TypeError("the env factory cannot be pickled for the env worker processes: install cloudpickle, pass a "
+                        "module-level callable, or keep the envs in this process (hyps['env_pool'] = 'serial')") from e
 
 
 class _PinnedPool:

@@ -1,8 +1,17 @@
 """Host-side per-frame preprocessing with the reference's names (a2c/preprocessing.py).  These
 run on the CPU next to the env: pure slicing / thresholding of
 one raw frame, no device work.  ``snake_prep`` is out of scope (gym-snake is not in any
-BASELINE config); ``breakout_prep``'s ``rgb2grey`` acts on an already single-channel slice, for
-which skimage's rgb2grey is the identity (2-D input), so it is restated as such."""
+BASELINE config).
+
+``breakout_prep`` (preprocessing.py:19-23) calls ``skimage.color.rgb2grey`` on ``pic[::2, ::2, 0]``, which is already a
+2-D uint8 array.  scikit-image is unpinned in the reference (requirements.txt:7) and absent from this image, so the
+behaviour mirrored here is stated, not measured: ``rgb2grey`` exists in scikit-image <= 0.18 (alias of ``rgb2gray``,
+removed in 0.19), and in every one of those releases ``rgb2gray`` starts with ``if rgb.ndim == 2: return
+np.ascontiguousarray(rgb)`` -- a 2-D input is returned UNCHANGED (uint8, values 0..255, no division by 255, no
+float conversion).  With scikit-image >= 0.19 the reference's import fails outright.  ``breakout_prep`` is therefore the
+crop + stride-2 slice of channel 0 as uint8, and its frames travel as uint8 (0..255, not binary: the packed one-bit
+transport does not apply).  Parity for this function is pinned by that statement and by tests/test_preprocessing.py
+(dtype, shape, values against the slice), not by a golden vector."""
 import numpy as np
 
 
@@ -26,4 +35,4 @@ def pong_prep(pic):                            # preprocessing.py:11-17
 def breakout_prep(pic):                        # preprocessing.py:19-23
     pic = pic[35:195, 8:-8]
     pic = pic[::2, ::2, 0]
-    return np.asarray(pic)[None]
+    return np.ascontiguousarray(pic)[None]

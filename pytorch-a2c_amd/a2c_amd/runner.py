@@ -145,7 +145,8 @@ class Runner:
         from .hostpool import ProcessEnvPool
         return ProcessEnvPool(SequentialEnvironment, n, env_kwargs=kws, n_workers=try_key(hyps, "n_env_workers", None),
                               action_shift=hyps["action_shift"], pong="Pong" in hyps["env_type"],
-                              rew_ema0=-1.0)
+                              rew_ema0=-1.0,
+                              frame_bits=bool(try_key(hyps, "frame_bits", try_key(hyps, "prep_fxn", None) == "pong_prep")))
 
     def start(self, net):
         """Everything Runner.run does before its loop (runner.py:158-168), for all envs."""

@@ -46,10 +46,25 @@ def get_save_folder(hyps):
     return folder
 
 
-def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None):
-    """``hyps``: the reference's flat dict.  ``env_fn(j)`` (optional) builds env j as an object with
-    ``reset()/step(a)`` returning already prepped frames -- otherwise gym envs are made from
-    ``env_type`` / ``prep_fxn`` like the reference.  Returns the best evaluation reward."""
+class _PositionalFactory:
+    """env worker processes build env j as ``env_fn(j)`` whatever the callable names its parameter (the pool calls
+    factories with keyword arguments)"""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, j):
+        return self.fn(j)
+
+
+def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None, uniform_fn=None, on_epoch=None):
+    """``hyps``: the reference's flat dict (training_scripts/hyperparams.json; ``n_rollouts`` need not be a multiple of
+    ``n_envs``).  ``env_fn(j)`` (optional) builds env j as an object with ``reset()/step(a)`` returning already
+    prepped frames -- otherwise gym envs are made from ``env_type`` / ``prep_fxn`` like the reference.  With the
+    default process env pool ``env_fn`` travels to the worker processes pickled: lambdas and closures need
+    ``cloudpickle`` (else pass a module-level callable, or ``hyps['env_pool'] = 'serial'``).  ``uniform_fn`` /
+    ``on_epoch(epoch, updater, shared_data)`` are test hooks (sampler uniforms; called after every update).
+    Returns the best evaluation reward."""
     hyps = dict(DEFAULTS, **hyps)
     if hyps["n_rollouts"] is None:
         hyps["n_rollouts"] = hyps["n_envs"]
@@ -78,18 +93,21 @@ def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None):
             pool = HostEnvPool(envs, frame_shape=frame_shape)
         else:
             from .hostpool import ProcessEnvPool
+            # pong_prep yields {0,1} uint8 planes (preprocessing.py:15-16): one bit per pixel crosses the host link
+            bits = try_key(hyps, "frame_bits", hyps["prep_fxn"] == "pong_prep")
             pool = ProcessEnvPool(SequentialEnvironment, hyps["n_envs"], env_kwargs=kws,
                                   n_workers=try_key(hyps, "n_env_workers", None), pong="Pong" in hyps["env_type"],
-                                  action_shift=1 if hyps["env_type"] == "Pong-v0" else try_key(hyps, "action_shift", 0))
+                                  action_shift=1 if hyps["env_type"] == "Pong-v0" else try_key(hyps, "action_shift", 0),
+                                  frame_bits=bool(bits))
     else:
         if serial:
             pool = HostEnvPool([env_fn(j) for j in range(hyps["n_envs"])])
         else:
             from .hostpool import ProcessEnvPool
-            pool = ProcessEnvPool(env_fn, hyps["n_envs"], env_kwargs=[dict(j=j) for j in range(hyps["n_envs"])],
+            pool = ProcessEnvPool(_PositionalFactory(env_fn), hyps["n_envs"], env_kwargs=[dict(j=j) for j in range(hyps["n_envs"])],
                                   n_workers=try_key(hyps, "n_env_workers", None), pong="Pong" in hyps["env_type"],
                                   action_shift=1 if hyps["env_type"] == "Pong-v0" else try_key(hyps, "action_shift", 0),
-                                  probe_reset=True)
+                                  probe_reset=True, frame_bits=bool(try_key(hyps, "frame_bits", False)))
         hyps["is_discrete"], n_act = True, hyps["action_size"]
     hyps["state_shape"] = [hyps["n_frame_stack"]] + list(pool.frame_shape[1:])
     if hyps["env_type"] == "Pong-v0":
@@ -109,13 +127,15 @@ def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None):
     net._ensure_device()            # the flat parameter arena exists BEFORE the runner thread and the Updater touch it
     shared_data = {"states": cuda_if(torch.zeros((shared_len, *hyps["state_shape"]))),
                    "deltas": cuda_if(torch.zeros(shared_len)), "rewards": cuda_if(torch.zeros(shared_len)),
-                   "actions": torch.zeros(shared_len).long(), "dones": cuda_if(torch.zeros(shared_len))}
+                   # (the reference keeps `actions` on the host, training.py:90,97; device resident here so that the
+                   # rollout's device relay can write it -- nothing outside this function sees the dict)
+                   "actions": cuda_if(torch.zeros(shared_len).long()), "dones": cuda_if(torch.zeros(shared_len))}
     if net.is_recurrent:
         shared_data["h_states"] = cuda_if(torch.zeros(shared_len, net.h_size))
     n_rollouts = hyps["n_rollouts"]
     gate_q, stop_q, reward_q = queue.Queue(n_rollouts), queue.Queue(n_rollouts), queue.Queue(1)
     reward_q.put(-1)
-    runner = Runner(shared_data, hyps, gate_q, stop_q, reward_q, env_pool=pool)
+    runner = Runner(shared_data, hyps, gate_q, stop_q, reward_q, env_pool=pool, uniform_fn=uniform_fn)
     thread = threading.Thread(target=runner.run, args=(net,), daemon=True)
     thread.start()
 
@@ -153,6 +173,8 @@ def train(_, hyps, verbose=True, env_fn=None, eval_env=None, max_epochs=None):
         avg_reward = reward_q.get()
         reward_q.put(avg_reward)
         updater.update_model(shared_data)
+        if on_epoch is not None:
+            on_epoch(epoch, updater, shared_data)
         eval_rew = stats_runner.rollout(net) if stats_runner is not None else avg_reward
         if eval_rew > best_eval_rew:
             best_eval_rew = eval_rew

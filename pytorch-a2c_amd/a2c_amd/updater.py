@@ -16,6 +16,86 @@ from .parallel import Shard
 from .utils import try_key
 
 
+class _CutShard:
+    """Shard stand-in used while capturing: every collective ends the graph being captured and starts the next"""
+
+    def __init__(self, owner, real):
+        self.o, self.real = owner, real
+        self.rank, self.world, self.group = real.rank, real.world, real.group
+
+    @property
+    def active(self):
+        return self.real.active
+
+    def global_count(self, n):
+        return self.real.global_count(n)
+
+    def barrier(self):
+        self.real.barrier()
+
+    def allreduce_(self, t):
+        if self.real.active:
+            self.o._cut(t)
+        return t
+
+
+class _GraphedUpdate:
+    def __init__(self, upd, shared_data):
+        self.upd, self.graphs, self.colls = upd, [], []
+        net = upd.net
+        torch.cuda.synchronize()
+        dirty, stash, cells = net._dirty, net._stash, getattr(net, "_cells_done", None)
+        real = upd.shard
+        upd.shard = _CutShard(self, real)
+        self._ctx = None
+        try:
+            self._begin()
+            self.dev, self.n_global = upd._enqueue_update(shared_data)
+            self._end()
+        except BaseException:
+            if self._ctx is not None:
+                try:
+                    self._ctx.__exit__(None, None, None)
+                except Exception:      # noqa: BLE001
+                    pass
+            torch.cuda.synchronize()
+            raise
+        finally:
+            upd.shard = real
+        # the capture itself executed nothing: the net is still in the state the rollout left it in
+        net._dirty, net._stash = dirty, stash
+        if cells is not None:
+            net._cells_done = cells
+        upd.optim._steps -= 1
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(g, capture_error_mode="thread_local")
+        self._ctx.__enter__()
+        self.graphs.append(g)
+
+    def _end(self):
+        self._ctx.__exit__(None, None, None)
+        self._ctx = None
+
+    def _cut(self, t):
+        self._end()
+        self.colls.append(t)
+        self._begin()
+
+    def replay(self):
+        upd = self.upd
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.colls):
+                upd.shard.allreduce_(self.colls[i])
+        upd.optim._steps += 1
+        upd.net.mark_dirty()
+        return upd._finish_update(self.dev, self.n_global)
+
+    __call__ = replay
+
+
 class Updater:
     def __init__(self, net, hyps, shard=None):
         self.net = net
@@ -126,9 +206,11 @@ class Updater:
         else:
             net._bwd(states.data_ptr(), states[0].numel(), N, "train", st)
         net._arena.attach_grads()
-        if sh.active:                   # ONE all-reduce over xGMI per update
-            sh.allreduce_(net._arena.train_grads())
-            sh.allreduce_(stats[2:5])
+        if sh.active:                   # ONE all-reduce over xGMI per update: gradients + the three loss sums in its tail
+            tail = net._arena.grad_tail()
+            tail[:3].copy_(stats[2:5])                      # reporting only (updater.py:134-136): fp32 is plenty
+            sh.allreduce_(net._arena.reduce_span())
+            stats[2:5].copy_(tail[:3])
 
         # clip_grad_norm_ + optimiser step (updater.py:129-132), fused
         with ops.span("clip_optimizer"):
@@ -139,6 +221,14 @@ class Updater:
         ops.check(ops.lib().a2c_pack_update_scalars(stats[2:5].data_ptr(), self.optim.grad_norm().data_ptr(),
                                                     b["err"].data_ptr(), b["out5"].data_ptr(), st), "a2c_pack_update_scalars")
         return b["out5"], n_global
+
+    def capture_update(self, shared_data):
+        """The enqueue half of update_model as hipGraphs: ONE graph on a single GPU; with a sharded update the captured
+        stream is cut at every collective (advantage moments, gradient arena) -- graph, RCCL all-reduce on the stream,
+        graph, ... -- so that N-GPU updates are not ~40 eager launches either and no collective sits inside a capture.
+        Returns a callable ``replay() -> info`` (same effect as update_model on the same buffers); the caller must
+        have run one eager update_model on these buffers first (workspaces, tuners)."""
+        return _GraphedUpdate(self, shared_data)
 
     def _finish_update(self, dev_vec, n_global):
         hyps = self.hyps

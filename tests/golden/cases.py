@@ -107,6 +107,13 @@ class U8FakeEnv(O.FakeEnv):
         return super()._frame().astype(np.uint8)
 
 
+class PongLikeEnv(U8FakeEnv):
+    """80x80 binary uint8 frames = what pong_prep hands on (preprocessing.py:11-17); built as env_fn(j)"""
+
+    def __init__(self, j=0):
+        super().__init__(env_id=j, frame_shape=(1, 80, 80), rew_period=3 + j % 4, done_period=9 + j)
+
+
 class F32FakeEnv(O.FakeEnv):
     """O.FakeEnv with float grey-level frames in [0, 1): the fp32 transport of the host pool.  (NOT what the reference's
     breakout_prep yields: its rgb2grey acts on an already 2-D uint8 slice and returns it unchanged -- uint8 0..255, see

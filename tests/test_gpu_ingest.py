@@ -96,38 +96,53 @@ def test_process_pool_rollouts_match_oracle(kind, ingest, fused, monkeypatch):
         r.close()
 
 
-@pytest.mark.parametrize("kind,ingest", [("A3CModel", "zero-copy"), ("A3CModel", "memcpy"), ("GRUModel", "memcpy"),
-                                         ("GRUModel", "relay"), ("ConvModel", "relay")])
-def test_rollout_update_rollout_matches_oracle(kind, ingest):
+@pytest.mark.parametrize("kind,ingest,bptt", [("A3CModel", "zero-copy", False), ("A3CModel", "memcpy", False),
+                                              ("GRUModel", "memcpy", False), ("GRUModel", "relay", False),
+                                              ("ConvModel", "relay", False), ("GRUModel", "relay", True),
+                                              ("GRUFCModel", "relay", True)])
+def test_rollout_update_rollout_matches_oracle(kind, ingest, bptt):
     """three rounds with update_model in between (training.py:163-165): the rollout after an optimiser step
-    must use the NEW weights (derived inference weights -- composed heads, conv fragments -- re-built)"""
+    must use the NEW weights (derived inference weights -- composed heads, conv fragments -- re-built).
+    With use_bptt the update is Updater.bptt (updater.py:139-169); for GRUModel behind the relay that is the path the
+    benchmark's config 4 runs: every GRU cell, embedding row and heads row of the update comes from the rollout's stash
+    (models.py bptt_forward "has nothing left to compute") -- compared here with the oracle directly."""
     from a2c_amd.runner import Runner
     from a2c_amd.updater import Updater
-    B, T, A, ss = 4, 5, 3, (4, 84, 84)
-    ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
+    B, T = 4, 5
+    if kind == "GRUFCModel":
+        A, ss, h, env_cls = 2, (4, 4), 64, O.FakeEnv
+        ekws = [dict(env_id=j, frame_shape=(1, 4), binary=False, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
+    else:
+        A, ss, h, env_cls = 3, (4, 84, 84), 256, U8FakeEnv
+        ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
     hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-2,
-                     optim_type="RMSprop")
-    net = make_net(kind, ss, A, 256)
-    onet = O.OracleNet(kind, ss, A, 256)
-    D = _datas(B * T, ss, net.is_recurrent, actions_on_host=False)
+                     optim_type="RMSprop", use_bptt=bptt, h_size=h)
+    net = make_net(kind, ss, A, h)
+    onet = O.OracleNet(kind, ss, A, h)
+    D = _datas(B * T, ss, net.is_recurrent, h=h, actions_on_host=False)
     us = torch.from_numpy(hashf(3 * T * B, 977, 0, 1).reshape(3, T, B))
     usd = us.to(DEV)
     rnd = [0]
-    pool = _pool(U8FakeEnv, ekws, 2, pong=True)
+    pool = _pool(env_cls, ekws, 2, pong=True)
     r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest,
                uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
     upd = Updater(net, hyps)
     try:
-        refs = _oracle_rollouts(kind, onet, hyps, ekws, us, 3, B, T, ss, updater=O.OracleUpdater(onet, hyps))
+        refs = _oracle_rollouts(kind, onet, hyps, ekws, us, 3, B, T, ss, env_cls=O.FakeEnv,
+                                updater=O.OracleUpdater(onet, hyps))
         for rnd[0] in range(3):
             r.rollout(net, list(range(B)), hyps)
             r.finish()
+            if kind == "GRUModel" and bptt and ingest == "relay":
+                assert net._cells_stashed(D["states"], B, T)      # the update below takes its cells from the rollout
             # lr = 1e-2 moves the weights by ~1e-2 per step: stale weights would change values by >> tolerance;
             # after two such steps the nets agree to ~1e-4 relative (RMSprop's 1/sqrt(v) amplifies 1e-7 gradient noise)
             tol = 1e-5 if rnd[0] == 0 else 2e-3
             assert torch.equal(D["states"].cpu(), refs[rnd[0]]["states"])
             assert torch.equal(D["dones"].cpu(), refs[rnd[0]]["dones"])
             close("deltas", D["deltas"], refs[rnd[0]]["deltas"], tol, tol)
+            if net.is_recurrent:
+                close("h_states", D["h_states"], refs[rnd[0]]["h_states"], tol, tol)
             mism = (D["actions"].cpu() != refs[rnd[0]]["actions"]).sum().item()
             assert mism == 0 if rnd[0] == 0 else mism <= 1, mism
             if rnd[0] < 2:
@@ -136,7 +151,7 @@ def test_rollout_update_rollout_matches_oracle(kind, ingest):
                 for k in oi:
                     assert abs(info[k] - oi[k]) <= 1e-4 + 2e-3 * abs(oi[k]), (rnd[0], k, info[k], oi[k])
         # and the weights really moved: round 2's values differ from what the ORIGINAL weights give
-        assert not torch.allclose(D["deltas"].cpu(), _oracle_rollouts(kind, O.OracleNet(kind, ss, A, 256), hyps, ekws, us, 3, B,
+        assert not torch.allclose(D["deltas"].cpu(), _oracle_rollouts(kind, O.OracleNet(kind, ss, A, h), hyps, ekws, us, 3, B,
                                                                       T, ss)[2]["deltas"], atol=1e-3)
     finally:
         r.close()

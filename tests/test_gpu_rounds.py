@@ -1,0 +1,256 @@
+"""-m gpu: what round 3 added on the host-ingest side, against the CPU oracle:
+  * the PACKED transport (one bit per pixel for binary preprocessors, include/a2c_hostpool.h A2C_FRAME_BITS) through
+    every ingest mode -- the kernels must see exactly the uint8 {0,1} planes of the uint8 transport;
+  * fp32 frames whose size is not a multiple of 16 B (padded pool slots, dense kernel rows);
+  * any number of slots per rollout: n_rollouts that is not a multiple of n_envs is played in lock-step rounds with
+    envs falling out of step with each other (the reference's shipped hyperparams.json: 45 slots on 11 envs);
+  * train() on that key set, two epochs, weights and losses against oracle SlotRunner + OracleUpdater."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import a2c_oracle as O  # noqa: E402
+from cases import PongLikeEnv, U8FakeEnv, base_hyps, hashf  # noqa: E402
+from test_gpu_kernels import close  # noqa: E402
+from test_gpu_models import _datas, make_net  # noqa: E402
+from test_gpu_ingest import _compare_round, _oracle_rollouts, _pool  # noqa: E402
+
+DEV = "cuda"
+
+
+# ---------------------------------------------------------------------------------------------- packed transport
+@pytest.mark.parametrize("kind,ingest", [("A3CModel", "zero-copy"), ("A3CModel", "relay"), ("A3CModel", "memcpy"),
+                                         ("GRUModel", "relay"), ("ConvModel", "memcpy"), ("FCModel", "relay")])
+def test_packed_bits_rollouts_match_oracle(kind, ingest):
+    """binary uint8 envs behind a frame_bits pool: two consecutive rounds, every buffer against the oracle"""
+    from a2c_amd.runner import Runner
+    B, T, A, ss = 5, 6, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=3 + j % 3, done_period=5 + 2 * j) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0" if kind == "A3CModel" else "FakeBreakout", n_tsteps=T, n_rollouts=B,
+                     action_shift=0, n_envs=B, env_timeout_s=20.0)
+    net = make_net(kind, ss, A, 256)
+    onet = O.OracleNet(kind, ss, A, 256)
+    D = _datas(B * T, ss, net.is_recurrent, actions_on_host=False)
+    us = torch.from_numpy(hashf(2 * T * B, 4242, 0, 1).reshape(2, T, B))
+    usd = us.to(DEV)
+    rnd = [0]
+    pool = _pool(U8FakeEnv, ekws, 2, pong="Pong" in hyps["env_type"], frame_bits=True)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest,
+               uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+    try:
+        refs = _oracle_rollouts(kind, onet, hyps, ekws, us, 2, B, T, ss)
+        for rnd[0] in range(2):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            _compare_round(D, refs[rnd[0]], net.is_recurrent)
+        assert pool.transport == "bits" and pool.header.frame_bytes == 882 and r.bits and pool.seq == 2 * T
+        if ingest == "zero-copy":
+            assert r._zero_copy_ok(net)
+    finally:
+        r.close()
+
+
+def test_packed_bits_equals_uint8_transport_more_envs_than_cus():
+    """native env threads, 300 envs x 4 steps, persistent kernel: the packed and the uint8 transport leave bit-identical
+    rollout buffers (states, actions, rewards, dones, deltas)"""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    B, T, A, ss = 300, 4, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    usd = torch.from_numpy(hashf(2 * T * B, 99, 0, 1).reshape(2, T, B)).to(DEV)
+    out = {}
+    for bits in (False, True):
+        net = make_net("A3CModel", ss, A, 256)
+        D = _datas(B * T, ss, False, actions_on_host=False)
+        envs = [TapeEnv(env_id=j, length=2 * T + 1, p_done=0.1) for j in range(B)]
+        pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=True, frame_bits=bits)
+        rnd = [0]
+        r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy",
+                   uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+        try:
+            res = []
+            for rnd[0] in range(2):
+                r.rollout(net, list(range(B)), hyps)
+                r.finish()
+                res.append({k: v.cpu().clone() for k, v in D.items()})
+            out[bits] = res
+        finally:
+            r.close()
+    for k in range(2):
+        for name in ("states", "actions", "rewards", "dones", "deltas"):
+            assert torch.equal(out[True][k][name], out[False][k][name]), (k, name)
+    assert float(out[True][1]["states"].sum()) > 0
+
+
+# ---------------------------------------------------------------------------------------------- padded fp32 slots
+@pytest.mark.parametrize("ingest", ["memcpy", "relay"])
+def test_fp32_vector_frames_with_padded_pool_slots(ingest):
+    """vector observations of 3 floats (12 B): the pool's slots are 16 B apart, the fp32 frame-stack kernels read
+    dense rows -- every env b > 0 would read misplaced frames without the compaction"""
+    from a2c_amd.runner import Runner
+    B, T, A, L = 5, 7, 2, 3
+    ss = (4, L)
+    ekws = [dict(env_id=j, frame_shape=(1, L), rew_period=3, done_period=4 + j, binary=False) for j in range(B)]
+    hyps = base_hyps(env_type="FakeCart", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, h_size=64)
+    net = make_net("FCModel", ss, A, 64)
+    onet = O.OracleNet("FCModel", ss, A, 64)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    us = torch.from_numpy(hashf(2 * T * B, 31, 0, 1).reshape(2, T, B))
+    usd = us.to(DEV)
+    rnd = [0]
+    pool = _pool(O.FakeEnv, ekws, 2)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest,
+               uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+    try:
+        refs = _oracle_rollouts("FCModel", onet, hyps, ekws, us, 2, B, T, ss)
+        for rnd[0] in range(2):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            _compare_round(D, refs[rnd[0]], False)
+        assert pool.frame_dtype == np.float32 and r.fstride == 16 and r.d_dense is not None
+    finally:
+        r.close()
+
+
+# ---------------------------------------------------------------------------------------------- lock-step rounds
+class _EnvCounterUniforms:
+    """uniform_fn of a Runner whose envs fall out of step: env e's n-th sampled action uses table[e, n], whatever slot
+    and round it is played in (the oracle's per-env SlotRunner draws from the same row in the same order)"""
+
+    def __init__(self, table):
+        self.table = table                      # (n_envs, K) cpu float32
+        self.dev = table.to(DEV)
+        self.cnt = np.zeros(table.shape[0], dtype=np.int64)
+
+    def __call__(self, t, B, env0):
+        idx = torch.from_numpy(self.cnt[env0:env0 + B].copy()).to(DEV)
+        u = self.dev[env0:env0 + B].gather(1, idx[:, None]).reshape(B).contiguous()
+        self.cnt[env0:env0 + B] += 1
+        return u
+
+
+def _oracle_rounds(kind, onet, hyps, envs, table, R, T, ss, n_epochs, updater=None):
+    """epoch: the sorted slot list 0..R-1 in rounds of len(envs); slot k of a round is played by env k"""
+    B, N = len(envs), R * T
+    Do = dict(states=torch.zeros(N, *ss), deltas=torch.zeros(N), rewards=torch.zeros(N), dones=torch.zeros(N),
+              actions=torch.zeros(N).long())
+    if onet.is_recurrent:
+        Do["h_states"] = torch.zeros(N, onet.h_size)
+    runners = []
+    for j, env in enumerate(envs):
+        it = iter(table[j].tolist())
+        sr = O.SlotRunner(env, Do, hyps, uniform_fn=lambda it=it: float(next(it)))
+        sr.start(onet)
+        runners.append(sr)
+    outs = []
+    for ep in range(n_epochs):
+        for slot in range(R):
+            runners[slot % B].rollout(onet, slot)
+        outs.append({n: v.clone() for n, v in Do.items()})
+        if updater is not None:
+            outs[-1]["info"] = updater.update_model(Do)
+            outs[-1]["params"] = [p.detach().clone() for p in onet.parameters()]
+    return outs
+
+
+@pytest.mark.parametrize("kind,ingest", [("A3CModel", "zero-copy"), ("A3CModel", "relay"), ("GRUModel", "relay"),
+                                         ("ConvModel", "memcpy")])
+def test_rollout_rounds_when_n_rollouts_is_not_a_multiple_of_n_envs(kind, ingest):
+    """7 slots on 3 envs, two epochs: rounds (0,1,2) (3,4,5) (6); in the second epoch env 0 is one slot ahead of the
+    others, so round 1 splits into the blocks [env 0] and [envs 1, 2]"""
+    from a2c_amd.runner import Runner
+    B, R, T, A, ss = 3, 7, 4, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=2 + j, done_period=5 + 2 * j) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=R, action_shift=0, n_envs=B)
+    net = make_net(kind, ss, A, 256)
+    onet = O.OracleNet(kind, ss, A, 256)
+    D = _datas(R * T, ss, net.is_recurrent, actions_on_host=False)
+    table = torch.from_numpy(hashf(B * 8 * T, 515, 0, 1).reshape(B, 8 * T))
+    uf = _EnvCounterUniforms(table)
+    pool = _pool(U8FakeEnv, ekws, 2, pong=True, frame_bits=(ingest != "memcpy"))
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest, uniform_fn=uf)
+    try:
+        refs = _oracle_rounds(kind, onet, hyps, [O.FakeEnv(**kw) for kw in ekws], table, R, T, ss, 2)
+        for ep in range(2):
+            r.rollout(net, list(range(R)), hyps)
+            r.finish()
+            _compare_round(D, refs[ep], net.is_recurrent)
+        assert pool.seq_env.tolist() == [6 * T, 4 * T, 4 * T]
+        with pytest.raises(ValueError):
+            pool.seq                                   # the envs are out of step with each other
+    finally:
+        r.close()
+
+
+# ---------------------------------------------------------------------------------------------- train(), reference key set
+# the key set of the reference's shipped training_scripts/hyperparams.json (values that matter to the path unchanged:
+# FCModel, 12 steps, 11 envs, 45 rollouts, 3 stacked frames, RMSprop); env_type is a Pong-named fake
+REFERENCE_HYPS = dict(exp_name="fcmodel", seed=0, model="FCModel", env_type="FakePong-v0", prep_fxn="pong_prep",
+                      optim_type="RMSprop", max_tsteps=4e7, n_tsteps=12, n_test_eps=21, n_envs=11, n_frame_stack=3,
+                      n_rollouts=45, n_past_rews=25, h_size=256, grid_size=15, unit_size=4, n_foods=2, lr=0.0001,
+                      lr_low=1e-12, lambda_=0.98, gamma=0.99, gamma_high=0.995, val_coef=0.5, entr_coef=0.005,
+                      entr_coef_low=0.001, max_norm=0.5, resume=False, render=False, decay_lr=False, decay_entr=False,
+                      use_nstep_rets=False, norm_advs=True, use_bnorm=False, use_bptt=False)
+
+
+def test_train_on_the_reference_hyperparams_matches_oracle(tmp_path):
+    """row f1: two epochs of train() with n_envs = 11, n_rollouts = 45 (process env pool, packed transport) against two
+    epochs of oracle SlotRunners (env j plays slots j, 11+j, 22+j, 33+j, and env 0 slot 44) + OracleUpdater"""
+    from a2c_amd.training import train
+    hyps = dict(REFERENCE_HYPS, main_path=str(tmp_path), action_size=3, action_shift=0, frame_bits=True, n_env_workers=3)
+    B, R, T, C, A, h = 11, 45, 12, 3, 3, 256
+    ss = (C, 80, 80)
+    table = torch.from_numpy(hashf(B * 16 * T, 2024, 0, 1).reshape(B, 16 * T))
+    uf = _EnvCounterUniforms(table)
+    got = []
+
+    def on_epoch(epoch, updater, shared):
+        got.append((dict(updater.info), {k: v.detach().cpu().clone() for k, v in shared.items()},
+                    [p.detach().cpu().clone() for p in updater.net.parameters()]))
+
+    import a2c_amd.models as M
+    sd = O.formula_state_dict("FCModel", ss, A, h)
+    orig = M.FCModel.__init__
+
+    def patched(self, *a, **k):          # train() builds the net itself: start it from the formula weights
+        orig(self, *a, **k)
+        self.load_state_dict(sd)
+    M.FCModel.__init__ = patched
+    try:
+        train(None, hyps, verbose=False, env_fn=PongLikeEnv, max_epochs=2, uniform_fn=uf, on_epoch=on_epoch)
+    finally:
+        M.FCModel.__init__ = orig
+    assert len(got) == 2
+    ohyps = base_hyps(**{k: v for k, v in hyps.items() if k in ("gamma", "lambda_", "n_tsteps", "n_rollouts", "n_frame_stack",
+                                                                "val_coef", "entr_coef", "max_norm", "lr", "optim_type",
+                                                                "norm_advs", "use_nstep_rets", "use_bptt", "env_type")},
+                      action_shift=0, pi_coef=1.0)
+    onet = O.OracleNet("FCModel", ss, A, h)
+    envs = []
+    for j in range(B):
+        e = PongLikeEnv(j)
+        envs.append(e)
+    refs = _oracle_rounds("FCModel", onet, ohyps, envs, table, R, T, ss, 2, updater=O.OracleUpdater(onet, ohyps))
+    for ep in range(2):
+        info, D, params = got[ep]
+        ref = refs[ep]
+        tol = 1e-5 if ep == 0 else 2e-4          # epoch 2 plays with weights that went through one RMSprop step
+        assert torch.equal(D["states"], ref["states"])
+        assert torch.equal(D["dones"], ref["dones"])
+        mism = int((D["actions"] != ref["actions"]).sum())
+        assert mism == 0 if ep == 0 else mism <= 1, mism
+        close("deltas", D["deltas"], ref["deltas"], tol, tol)
+        for k in ref["info"]:
+            assert abs(info[k] - ref["info"][k]) <= 1e-5 + (3e-5 if ep == 0 else 2e-3) * abs(ref["info"][k]), (ep, k, info[k], ref["info"][k])
+        pm = max(float((p - q).abs().max()) for p, q in zip(params, ref["params"]))
+        assert pm < (5e-5 if ep == 0 else 3e-4), (ep, pm)
+    folder = os.path.join(str(tmp_path), "fcmodel", "fcmodel_0")
+    assert sorted(os.listdir(folder)) == ["best_net.p", "log.txt", "net.p", "optim.p"]
+    log = open(os.path.join(folder, "log.txt")).read()
+    assert f"Step:{R * T}" in log and f"Step:{2 * R * T}" in log

@@ -303,4 +303,25 @@ def test_bench_spawns_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["dist_backend"] == "gloo" and d["allreduce_bytes"] > 0 and d["allreduce_ms_per_update"] > 0
-    assert "host-pinned uint8" in d["config"]["ingest"]
+    assert "host-pinned packed 1 bit/pixel" in d["config"]["ingest"] and d["config"]["transport"] == "bits"
+    assert "hipGraphs around 2 collectives" in d["config"]["update"]      # the sharded update is not eager
+
+
+def test_bench_strong_scaling_conv_world2():
+    """--global-envs over two ranks (contiguous slot shards of ONE global batch) with ConvModel: the 230 MB gradient
+    arena as one message per update, loss means over the global batch; gloo, both ranks on cuda:0"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, A2C_BENCH_ONE_DEVICE="1", A2C_DIST_BACKEND="gloo")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", "conv", "--global-envs", "16", "--n-workers", "1", "--sustain-steps", "0",
+                          "--no-cpu-baseline", "--no-configs", "--no-secondary"], capture_output=True, text=True, env=env,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["n_envs_per_gpu"] == 8 and d["allreduce_bytes"] > 200e6
+    assert all(np.isfinite(v) for v in d["last_info"].values())

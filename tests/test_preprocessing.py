@@ -28,7 +28,8 @@ def test_null_and_breakout_prep():
     f = _frame(5)
     assert P.null_prep(f).shape == (1, 210, 160, 3)
     b = P.breakout_prep(f)
-    assert b.shape == (1, 80, 72)
+    # skimage <= 0.18 rgb2grey returns a 2-D input unchanged (see a2c_amd/preprocessing.py): uint8 0..255, not floats
+    assert b.shape == (1, 80, 72) and b.dtype == np.uint8 and b.max() > 1
     assert np.array_equal(b[0], f[35:195, 8:-8][::2, ::2, 0])
     n = P.normalize_prep(np.array([[0.0, 255.0]]))
     assert np.allclose(n, [[[-3.0, 3.0]]])

@@ -171,7 +171,7 @@ def test_rollout_rounds_when_n_rollouts_is_not_a_multiple_of_n_envs(kind, ingest
     net = make_net(kind, ss, A, 256)
     onet = O.OracleNet(kind, ss, A, 256)
     D = _datas(R * T, ss, net.is_recurrent, actions_on_host=False)
-    table = torch.from_numpy(hashf(B * 8 * T, 515, 0, 1).reshape(B, 8 * T))
+    table = torch.from_numpy(hashf(B * 8 * T, 515, 0, 0.999).reshape(B, 8 * T))     # (u = 1.0 is the sampler's -1 fall-through)
     uf = _EnvCounterUniforms(table)
     pool = _pool(U8FakeEnv, ekws, 2, pong=True, frame_bits=(ingest != "memcpy"))
     r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest, uniform_fn=uf)
@@ -206,7 +206,7 @@ def test_train_on_the_reference_hyperparams_matches_oracle(tmp_path):
     hyps = dict(REFERENCE_HYPS, main_path=str(tmp_path), action_size=3, action_shift=0, frame_bits=True, n_env_workers=3)
     B, R, T, C, A, h = 11, 45, 12, 3, 3, 256
     ss = (C, 80, 80)
-    table = torch.from_numpy(hashf(B * 16 * T, 2024, 0, 1).reshape(B, 16 * T))
+    table = torch.from_numpy(hashf(B * 16 * T, 2024, 0, 0.999).reshape(B, 16 * T))   # (u = 1.0 is the sampler's -1 fall-through)
     uf = _EnvCounterUniforms(table)
     got = []
 

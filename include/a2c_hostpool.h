@@ -120,6 +120,10 @@ typedef struct {
   void (*reset)(void *env, void *frame_out);
   /* one env step: observation into frame_out, reward and real done; on done the pool calls reset() next */
   void (*step)(void *env, int32_t action, void *frame_out, float *rew, int *done);
+  /* optional (may be NULL): pointer to the observation the last reset()/step() produced, valid until the next call.
+   * A pool with the packed transport then calls reset()/step() with frame_out == NULL and packs straight from this
+   * pointer into the pinned slot (no staging copy).                                                        */
+  const void *(*peek)(void *env);
 } a2c_env_vtable;
 typedef struct a2c_pool_threads a2c_pool_threads;
 /* starts the threads; they publish frame 0 of every env before the call returns.  NULL on error.  */

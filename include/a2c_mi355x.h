@@ -224,7 +224,7 @@ int a2c_a3c_step(const a2c_a3c_step_args *args, a2c_stream_t stream);
  *     t < T: sample with u[t*u_stride + b] -> actions[(slot0+b)*T + t], and publish
  *            cmd[env0+b] = (seq0+t) << 32 | action with one 8-byte system-scope store: the worker
  *            that owns the env steps it as soon as it sees the granule;  t == T: bootstrap.
- * Results are identical to T+1 calls of a2c_a3c_step.  Every wait on the host is bounded by
+ * Results are identical to T+1 calls of a2c_a3c_step (see conv1_weight below for the one exception).  Every wait on the host is bounded by
  * timeout_ticks (100 MHz ticks); on a timeout *err is set to 1 and the workgroup stops.
  * Shapes as a2c_a3c_step_supported, uint8 frames, (H*W) % 16 == 0.                          */
 typedef struct {
@@ -257,6 +257,11 @@ typedef struct {
   uint8_t *frame_store; int64_t frame_store_slot_stride;
   int32_t *nvalid_rows, *nvalid_carry;
   int frame_bits;                  /* 1: `frames` holds the packed transport (one bit per pixel, frame_stride >= H*W/8) */
+  /* optional: the first conv layer's weight tensor (16, 4, 8, 8) as the model stores it.  When given, B <= the CU count
+   * and no frame_store is requested, every env gets a workgroup that keeps its state in LDS for the whole slot and
+   * overlaps the env worker's turn-around with the part of the next forward that does not depend on the new frame
+   * (conv1's sum is then ordered plane-major: results equal a2c_a3c_step's up to fp32 re-association).          */
+  const float *conv1_weight;
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
 
@@ -277,6 +282,10 @@ int a2c_set_blocking_sync(int on);
 /* PCI bus id ("0000:c1:00.0") of the current HIP device: the host side places the pinned region and the env
  * workers on the NUMA node the GPU hangs off (/sys/bus/pci/devices/<id>/numa_node)                */
 int a2c_device_pci_bus_id(char *out, int len);
+/* *dev_ptr = value with one system-scope 4-byte store from the stream (e.g. the phase word of the host pool header,
+ * a2c_hostpool.h: the stream itself tells the env workers when a rollout starts and ends, so that they spin only
+ * while one is running)                                                                                        */
+int a2c_store_u32_system(uint32_t *dev_ptr, uint32_t value, a2c_stream_t stream);
 /* hipMemcpyAsync on `stream`: kind 1 = host->device, 2 = device->host, 3 = device->device      */
 int a2c_memcpy_async(void *dst, const void *src, size_t bytes, int kind, a2c_stream_t stream);
 /* dst[b*dst_stride + j] = src[b*src_stride + j], j < n  (h_states[e] = h, runner.py:201;

@@ -47,7 +47,7 @@ class A3CRolloutArgs(Structure):
                 ("cmd", P), ("rec", P), ("frames", P), ("frame_stride", c_int64),
                 ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64), ("a1_rows", P), ("a2_rows", P), ("heads_rows", P), ("heads_rows_ld", c_int64),
                 ("frame_store", P), ("frame_store_slot_stride", c_int64), ("nvalid_rows", P), ("nvalid_carry", P),
-                ("frame_bits", c_int)]
+                ("frame_bits", c_int), ("conv1_weight", P)]
 
 
 PS = POINTER(A3CStepArgs)
@@ -68,6 +68,7 @@ SIGNATURES = {
     "a2c_pool_ingest": (c_int, [P, P, c_int64, c_int, c_int, P, ctypes.c_uint32, c_int64, P, P, P, P, c_int64, P]),
     "a2c_pool_ingest_bits": (c_int, [P, P, c_int64, c_int, c_int, P, ctypes.c_uint32, c_int64, P, P, P, P, c_int64, P]),
     "a2c_unpack_bits": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P]),
+    "a2c_store_u32_system": (c_int, [P, ctypes.c_uint32, P]),
     "a2c_softmax_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int, c_int, P]),
     "a2c_sample_probs": (c_int, [P, P, P, c_int64, c_int, P]),
     "a2c_rollout_record": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_int64, c_int64, c_int64,

@@ -312,6 +312,10 @@ class _PinnedPool:
         return self.dev_ptr + self.header.off_cmd
 
     @property
+    def dev_phase(self):
+        return self.dev_ptr + PoolHeader.phase.offset if self.dev_ptr else 0
+
+    @property
     def dev_rec(self):
         return self.dev_ptr + self.header.off_rec
 

@@ -190,6 +190,11 @@ def pool_ingest_bits(rec_ptr, frames_ptr, frame_stride, n_pixels, n, seq_base, s
                                      st if st is not None else stream()), "a2c_pool_ingest_bits")
 
 
+def store_u32_system(dev_ptr, value, st=None):
+    """one system-scope 4-byte store from the stream (the host pool's phase word)"""
+    check(lib().a2c_store_u32_system(dev_ptr, value, st if st is not None else stream()), "a2c_store_u32_system")
+
+
 def unpack_bits(src_ptr, src_stride, dst_ptr, dst_stride, n, n_pixels, st=None):
     """packed frames staged in HBM -> uint8 frames (memcpy ingest of a frame_bits pool)"""
     check(lib().a2c_unpack_bits(src_ptr, src_stride, dst_ptr, dst_stride, n, n_pixels,

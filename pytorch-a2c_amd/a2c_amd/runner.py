@@ -268,6 +268,8 @@ class Runner:
         publish the episode-reward EMA the env workers kept (runner.py:216) and let the workers idle."""
         torch.cuda.current_stream().synchronize()
         if getattr(self, "proc_pool", False):
+            if not (self.env_pool.dev_phase and self.datas["actions"].is_cuda):
+                self.env_pool.set_phase(0)
             self.check()
             if self.rew_q is not None:
                 self.rew_q.get()
@@ -307,6 +309,14 @@ class Runner:
             self._stash_bufs = net.stash_rows(self.datas["states"], N, T=T_)
         stash_all = self._stash_bufs is not None
         seqs = self.env_pool.seq_env if self.proc_pool else None
+        # the env workers spin on their cmd granules only while a rollout is running: the phase word of the pool is
+        # written FROM THE STREAM (in order with the rollout kernels -- the host may be enqueueing this rollout while the
+        # previous update still runs), by the host when the region is not device mapped
+        dev_phase = self.env_pool.dev_phase if (self.proc_pool and self.datas["actions"].is_cuda) else 0
+        if dev_phase:
+            ops.store_u32_system(dev_phase, 1)
+        elif self.proc_pool:
+            self.env_pool.set_phase(1)
         for r0 in range(0, len(idxs), self.B):
             rnd = idxs[r0:r0 + self.B]
             j = 0
@@ -319,6 +329,8 @@ class Runner:
                 if self.proc_pool:
                     self.env_pool.advance(j, k - j + 1, T_)
                 j = k + 1
+        if dev_phase:       # ... the last env step has been played: the workers sleep-poll through the update
+            ops.store_u32_system(dev_phase, 0)
         if stash_all:
             net.stash_commit(self.datas["states"], N, frames=getattr(self, "_frames_written", None))
 
@@ -779,6 +791,7 @@ class Runner:
                         dones=D["dones"].data_ptr(), deltas=D["deltas"].data_ptr(), T=T, slot0=slot0,
                         gamma=float(hyps["gamma"]), pong=int("Pong" in hyps["env_type"]), cmd=pool.dev_cmd, rec=pool.dev_rec,
                         frames=pool.dev_frames, frame_stride=self.fstride, frame_bits=int(self.bits),
+                        conv1_weight=P("convs.0.0.weight").data_ptr(),
                         seq0=pool.seq_of(env0, B) & 0xffffffff, env0=env0,
                         err=self.rollout_err.data_ptr(), timeout_ticks=int(timeout_s * 1e8),
                         a1_rows=0 if self._stash_bufs is None else self._stash_bufs[0].data_ptr(),

@@ -4,6 +4,7 @@
 #include "../../include/a2c_hostpool.h"
 
 #include <pthread.h>
+#include <sys/prctl.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -92,7 +93,7 @@ int a2c_pool_poll(void *base, int env0, int n, const uint32_t *next_seq, int64_t
     if ((sweep & 15) == 15) {
       const uint32_t ph = a2c_pool_phase(base);
       if (ph == A2C_POOL_SHUTDOWN) return -2;
-      if (ph == A2C_POOL_IDLE) sleep_ns(50000);   /* no rollout running: do not burn the core */
+      if (ph == A2C_POOL_IDLE) sleep_ns(20000);   /* no rollout running: do not burn the core */
       if (now_ns() - t0 > spin_ns) return -1;
     }
     cpu_relax();
@@ -119,12 +120,36 @@ void a2c_pool_publish(void *base, int env, const void *frame, uint32_t seq, floa
   __atomic_store_n(rec_of(base) + env, g, __ATOMIC_RELEASE);   /* frame bytes are visible before the tag */
 }
 
+#ifdef A2C_HAVE_SSE2
+__attribute__((target("avx2"))) static unsigned pack_bits_avx2(const uint8_t *src, uint8_t *dst, size_t n, size_t *done) {
+  __m256i acc = _mm256_setzero_si256();
+  size_t p = 0;
+  for (; p + 32 <= n; p += 32) {
+    const __m256i x = _mm256_loadu_si256((const __m256i *)(src + p));
+    acc = _mm256_or_si256(acc, x);
+    const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(x, 7));
+    memcpy(dst + (p >> 3), &m, 4);
+  }
+  const __m128i a = _mm_or_si128(_mm256_castsi256_si128(acc), _mm256_extracti128_si256(acc, 1));
+  uint64_t lo = (uint64_t)_mm_cvtsi128_si64(a) | (uint64_t)_mm_cvtsi128_si64(_mm_srli_si128(a, 8));
+  lo |= lo >> 32; lo |= lo >> 16; lo |= lo >> 8;
+  *done = p;
+  return (unsigned)(lo & 0xffu);
+}
+#endif
+
 /* n uint8 pixels (each 0 / 1) -> ceil(n/8) bytes, pixel p = bit p%8 of byte p/8; returns the OR of all pixels */
 static unsigned pack_bits(const uint8_t *src, uint8_t *dst, size_t n) {
   size_t p = 0;
   unsigned any = 0;
 #ifdef A2C_HAVE_SSE2
+  static int have_avx2 = -1;
+  if (have_avx2 < 0) have_avx2 = __builtin_cpu_supports("avx2") ? 1 : 0;
+  if (have_avx2) any = pack_bits_avx2(src, dst, n, &p);
+#endif
+#ifdef A2C_HAVE_SSE2
   __m128i acc = _mm_setzero_si128();
+  const unsigned any_wide = any;
   for (; p + 16 <= n; p += 16) {
     const __m128i x = _mm_loadu_si128((const __m128i *)(src + p));
     acc = _mm_or_si128(acc, x);
@@ -136,7 +161,7 @@ static unsigned pack_bits(const uint8_t *src, uint8_t *dst, size_t n) {
   acc = _mm_or_si128(acc, _mm_srli_si128(acc, 4));
   acc = _mm_or_si128(acc, _mm_srli_si128(acc, 2));
   acc = _mm_or_si128(acc, _mm_srli_si128(acc, 1));
-  any = (unsigned)_mm_cvtsi128_si32(acc) & 0xffu;
+  any = any_wide | ((unsigned)_mm_cvtsi128_si32(acc) & 0xffu);
 #endif
   for (; p < n; p += 8) {
     unsigned b = 0;
@@ -238,6 +263,7 @@ static void *worker_main(void *p) {
   worker_arg *w = (worker_arg *)p;
   a2c_pool_header *h = hdr(w->base);
   char *frames = (char *)w->base + h->off_frames;
+  prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);   /* the idle-phase sleeps of a2c_pool_poll really are ~20 us, not 20 + 50 */
   uint32_t *next_seq = (uint32_t *)calloc((size_t)w->n, sizeof(uint32_t));
   double *ep_rew = (double *)calloc((size_t)w->n, sizeof(double));
   /* packed transport: the env writes its uint8 observation into this thread's scratch (cache resident), the
@@ -245,10 +271,12 @@ static void *worker_main(void *p) {
   const int bits = h->frame_dtype == A2C_FRAME_BITS;
   uint8_t *scratch = bits ? (uint8_t *)calloc((size_t)h->frame_elems + 64, 1) : NULL;
   int bad = 0;
+  const int peek = bits && w->vt->peek != NULL;     /* pack straight from the env's own observation buffer */
   for (int i = 0; i < w->n; ++i) {          /* frame 0 = reset observation, done = 1 */
     void *slot0 = frames + (size_t)(w->env0 + i) * h->frame_stride;
-    w->vt->reset(w->envs[w->env0 + i], bits ? (void *)scratch : slot0);
-    if (bits && pack_bits(scratch, (uint8_t *)slot0, h->frame_elems) > 1u) bad = 1;
+    w->vt->reset(w->envs[w->env0 + i], bits ? (peek ? NULL : (void *)scratch) : slot0);
+    const uint8_t *obs0 = peek ? (const uint8_t *)w->vt->peek(w->envs[w->env0 + i]) : scratch;
+    if (bits && pack_bits(obs0, (uint8_t *)slot0, h->frame_elems) > 1u) bad = 1;
     next_seq[i] = h->seq_start;
     publish_inplace(w->base, w->env0 + i, h->seq_start, 0.f, 1);
   }
@@ -261,7 +289,7 @@ static void *worker_main(void *p) {
     if (i < 0) continue;
     const int j = w->env0 + i;
     void *pinned = frames + (size_t)j * h->frame_stride;
-    void *slot = bits ? (void *)scratch : pinned;
+    void *slot = bits ? (peek ? NULL : (void *)scratch) : pinned;
     float rew = 0.f;
     int done = 0;
     w->vt->step(w->envs[j], action + w->shift, slot, &rew, &done);      /* runner.py:208 */
@@ -273,7 +301,7 @@ static void *worker_main(void *p) {
       ep_rew[i] = 0.0;
     }
     if (reset) w->vt->reset(w->envs[j], slot);                           /* utils.py:36-38 */
-    if (bits && pack_bits(scratch, (uint8_t *)pinned, h->frame_elems) > 1u) {
+    if (bits && pack_bits(peek ? (const uint8_t *)w->vt->peek(w->envs[j]) : scratch, (uint8_t *)pinned, h->frame_elems) > 1u) {
       a2c_pool_worker_failed(w->base, j);                                /* not a binary frame */
       break;
     }
@@ -359,7 +387,12 @@ void a2c_tape_env_destroy(void *env) {
 
 static void tape_reset(void *env, void *frame_out) {
   tape_env *e = (tape_env *)env;
-  memcpy(frame_out, e->frames + (size_t)(e->t % e->length) * e->frame_bytes, (size_t)e->frame_bytes);
+  if (frame_out) memcpy(frame_out, e->frames + (size_t)(e->t % e->length) * e->frame_bytes, (size_t)e->frame_bytes);
+}
+
+static const void *tape_peek(void *env) {
+  tape_env *e = (tape_env *)env;
+  return e->frames + (size_t)(e->t % e->length) * e->frame_bytes;
 }
 
 static void tape_step(void *env, int32_t action, void *frame_out, float *rew, int *done) {
@@ -367,10 +400,10 @@ static void tape_step(void *env, int32_t action, void *frame_out, float *rew, in
   tape_env *e = (tape_env *)env;
   const long k = e->t % e->length;
   e->t += 1;
-  memcpy(frame_out, e->frames + (size_t)(e->t % e->length) * e->frame_bytes, (size_t)e->frame_bytes);
+  if (frame_out) memcpy(frame_out, e->frames + (size_t)(e->t % e->length) * e->frame_bytes, (size_t)e->frame_bytes);
   *rew = (float)e->rews[k];
   *done = e->dones[k] != 0;
 }
 
-static const a2c_env_vtable tape_vtable = {tape_reset, tape_step};
+static const a2c_env_vtable tape_vtable = {tape_reset, tape_step, tape_peek};
 const a2c_env_vtable *a2c_tape_env_vtable(void) { return &tape_vtable; }

@@ -256,6 +256,10 @@ __global__ __launch_bounds__(256) void unpack_bits_kernel(const uint8_t* __restr
   *reinterpret_cast<u32x4*>(dst + (long)b * dstride + i * 16) = expand_bits16(bits);
 }
 
+__global__ void store_u32_system_kernel(unsigned int* p, unsigned int v) {
+  if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <bool BITS>
 __global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long long* __restrict__ rec,
                                                           const uint8_t* __restrict__ frames, long fstride, int fbytes,
@@ -523,6 +527,13 @@ int a2c_pool_ingest_bits(const uint64_t* rec, const uint8_t* frames, int64_t fra
   hipLaunchKernelGGL(pool_ingest_kernel<true>, dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
                      (long)frame_stride, n_pixels / 8, seq_base, seq_off, (long)timeout_ticks, err, rew, done, frames_out,
                      (long)out_stride);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_store_u32_system(uint32_t* dev_ptr, uint32_t value, a2c_stream_t stream) {
+  if (!dev_ptr || ((uintptr_t)dev_ptr % 4)) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(store_u32_system_kernel, dim3(1), dim3(64), 0, a2c_s(stream), (unsigned int*)dev_ptr, (unsigned int)value);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -21,6 +21,7 @@
 //            host memory, loads the uint8 frame straight from the pinned pool slot (system-scope loads
 //            over PCIe) and hands the sampled action back with one 8-byte system-scope store to `cmd`
 //            (include/a2c_hostpool.h) -- no kernel boundary and no host code between env steps.
+#include <stdlib.h>
 #include "a2c_common.h"
 
 namespace {
@@ -60,6 +61,8 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   unsigned char* fstore; long fs_slot_stride;      // single-frame uint8 store (T+4 frames per slot)
   int* nvalid; int* nvalid_carry;
   int frame_bits;                                  // the pool publishes one bit per pixel (A2C_FRAME_BITS)
+  unsigned long long* dbg;                         // phase stamps of workgroup 0 (a2c_debug_ring_timing), or nullptr
+  int poll_gap;                                    // 64-cycle sleeps between two polls of the rec granule
 };
 
 struct StepP {
@@ -577,6 +580,415 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The persistent rollout when every env has a workgroup of its own (B <= CU count): the "ring" kernel.
+//
+// What the per-step body above cannot do -- it is also the one-launch-per-step kernel, so every iteration starts from
+// HBM -- and this one does:
+//   * the state lives in LDS for the WHOLE slot as a ring of 4 uint8 planes (28 KB): a new state is the previous one
+//     with its oldest plane replaced by the frame the env worker just published (utils.py:26-43).  No plane is ever
+//     re-read from HBM (85 KB per env-step), the fp32 state row of the rollout buffer is written from the ring;
+//   * conv1's K is ordered PLANE-major (plane p, tap row quad, tap column): the three planes a state shares with
+//     its predecessor are 3/4 of the sum and do not depend on the host.  Their partial sums for state t+1 (48 of
+//     the 64 MFMA steps per tile, accumulators kept in registers), the state-row / stash stores of state t and the
+//     env worker's turn-around (cmd granule over PCIe -> env.step -> rec granule + frame back) all run CONCURRENTLY;
+//     when the frame lands only the newest plane's 16 steps, conv2, the heads and the sampler are left;
+//   * two 16-pixel tiles per wave run as two interleaved accumulator chains sharing the A operand
+//     (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency), A fragments as ds_read_b128 of 4 steps;
+//   * conv2's fragments (32 KB), the head weights and conv1's fragments are loaded ONCE per launch (LDS / registers),
+//     and the values the bookkeeping carries from step to step stay in registers.
+// An env reset (real done) zeroes the older planes of the ring and the partial sums (a sum over zero planes is 0).
+// Results equal the per-step kernel's up to the fp32 re-association of conv1's sum (plane-major instead of tap-major).
+template <int HNT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void a3c_ring_kernel(StepP p, const float* __restrict__ w1raw) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const a2c_a3c_step_args& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int HW = a.H * a.W, W = a.W;
+  const int N = a.n_actions + 1;
+  const int NP1 = p.OH1 * p.OW1, ntile1 = (NP1 + 15) >> 4;
+  const int NP2 = p.OH2 * p.OW2, ntile2 = (NP2 + 15) >> 4;
+  const bool tail = tid == NT - 64;
+  float* __restrict__ fr1 = lds;                        // conv1 fragments, [step/4][lane][step%4]
+  float* __restrict__ fr2 = fr1 + NF1;                  // conv2 fragments (the per-step kernel's layout)
+  float* __restrict__ a1 = fr2 + NF2;                   // 16 x PLANE2
+  float* __restrict__ a2 = a1 + 16 * p.PLANE2;          // flat (c, y, x)
+  float* __restrict__ part = a2 + p.F4;                 // [2][ntile2*2][256] conv2 K-half partials
+  float* __restrict__ hp = part + ntile2 * 1024;        // [HNT][NT] head partials
+  float* __restrict__ red = hp + HNT * NT;              // heads | conv2 bias | granule
+  unsigned char* __restrict__ ring = reinterpret_cast<unsigned char*>(red + HN + 32 + 8);   // 4 planes of HW bytes
+  const int b = blockIdx.x;
+  const long S = 4L * HW, row = (a.slot0 + b) * a.T;
+  const int T = (int)a.T;
+
+  // ---- once per launch
+  for (int q = tid; q < NF1; q += NT) {                 // fragment element (step s, lane l) <- W1[co = l&15][p][ky = 4*kyq + (l>>4)][kx]
+    const int sq = q >> 8, l = (q >> 2) & 63, s = sq * 4 + (q & 3);
+    const int pl = s >> 4, kyq = (s >> 3) & 1, kx = s & 7;
+    fr1[q] = w1raw[(((l & 15) * 4 + pl) * 8 + 4 * kyq + (l >> 4)) * 8 + kx];
+  }
+  {
+    const float4* __restrict__ wf2v = reinterpret_cast<const float4*>(a.wfrag2);
+    float4* __restrict__ f2 = reinterpret_cast<float4*>(fr2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f2[tid + q * NT] = wf2v[tid + q * NT];
+  }
+  if (tid < 32) red[HN + tid] = a.bias2[tid];
+  const float4 b1v = *reinterpret_cast<const float4*>(a.bias1 + 4 * g);
+  const float b1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
+  float4 wc[2][HNT];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int kk = (tid << 2) + q * (NT * 4);
+#pragma unroll
+    for (int n = 0; n < HNT; ++n)
+      wc[q][n] = *reinterpret_cast<const float4*>(a.Wc + (long)min(n, N - 1) * p.F + min(kk, p.F - 4));
+  }
+  float bcv[HNT];
+#pragma unroll
+  for (int n = 0; n < HNT; ++n) bcv[n] = a.bc[min(n, N - 1)];
+  // this wave's conv1 tiles: w, w+8, w+16, w+24 (16 pixels each); byte offset of pixel j's window row g in a plane
+  int boff[4], pix[4];
+  bool okp[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = (w + 8 * q) * 16 + j;
+    okp[q] = (w + 8 * q) < ntile1 && idx < NP1;
+    const int i = okp[q] ? idx : 0;
+    const int r = i / p.OW1, c = i - r * p.OW1;
+    pix[q] = i;
+    boff[q] = (4 * r + g) * W + 4 * c;
+  }
+  const bool three = (w + 16) < ntile1, four = (w + 24) < ntile1;   // tiles beyond the first pair (wave-uniform)
+  f32x4 acc[4];
+
+  // steps of planes [p0, p1) of the state whose plane 0 sits in ring slot `base`, added to acc[]: per (plane, tap
+  // row quad) ONE 8-byte LDS read per tile gives the 8 tap columns of this lane's window row, two ds_read_b128 the
+  // A operands of the 8 steps; the two tiles of a pair are two independent accumulator chains
+  auto conv1_planes = [&](int base, int p0, int p1) {
+    for (int pl = p0; pl < p1; ++pl) {
+      const unsigned char* __restrict__ plane = ring + ((base + pl) & 3) * HW;
+#pragma unroll
+      for (int kyq = 0; kyq < 2; ++kyq) {
+        const float4* __restrict__ fa = reinterpret_cast<const float4*>(fr1) + ((pl * 2 + kyq) * 2) * 64 + lane;
+        const float4 av0 = fa[0], av1 = fa[64];
+        const float av[8] = {av0.x, av0.y, av0.z, av0.w, av1.x, av1.y, av1.z, av1.w};
+        {
+          const unsigned int* __restrict__ q0 = reinterpret_cast<const unsigned int*>(plane + boff[0] + 4 * kyq * W);
+          const unsigned int* __restrict__ q1 = reinterpret_cast<const unsigned int*>(plane + boff[1] + 4 * kyq * W);
+          const float4 f0 = u8x4(q0[0]), f1 = u8x4(q0[1]), h0 = u8x4(q1[0]), h1 = u8x4(q1[1]);
+          const float bx[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+          const float by[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+          for (int kx = 0; kx < 8; ++kx) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kx], bx[kx], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kx], by[kx], acc[1], 0, 0, 0);
+          }
+        }
+        if (four) {
+          const unsigned int* __restrict__ q0 = reinterpret_cast<const unsigned int*>(plane + boff[2] + 4 * kyq * W);
+          const unsigned int* __restrict__ q1 = reinterpret_cast<const unsigned int*>(plane + boff[3] + 4 * kyq * W);
+          const float4 f0 = u8x4(q0[0]), f1 = u8x4(q0[1]), h0 = u8x4(q1[0]), h1 = u8x4(q1[1]);
+          const float bx[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+          const float by[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+          for (int kx = 0; kx < 8; ++kx) {
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kx], bx[kx], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kx], by[kx], acc[3], 0, 0, 0);
+          }
+        } else if (three) {
+          const unsigned int* __restrict__ q0 = reinterpret_cast<const unsigned int*>(plane + boff[2] + 4 * kyq * W);
+          const float4 f0 = u8x4(q0[0]), f1 = u8x4(q0[1]);
+          const float bx[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+          for (int kx = 0; kx < 8; ++kx) acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kx], bx[kx], acc[2], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // ---- state 0 = the bookmark (fp32 rows in HBM) -> ring slots 0..3
+  {
+    const float4* __restrict__ bm = reinterpret_cast<const float4*>(p.x.bookmark + (long)b * S);
+    unsigned int* __restrict__ r32 = reinterpret_cast<unsigned int*>(ring);
+    for (int q = tid; q < (int)(S >> 2); q += NT) {
+      const float4 v = bm[q];
+      r32[q] = (unsigned int)v.x | ((unsigned int)v.y << 8) | ((unsigned int)v.z << 16) | ((unsigned int)v.w << 24);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int base = 0;
+  conv1_planes(base, 0, 3);
+  // values the bookkeeping carries from iteration to iteration (tail lane only)
+  float c_val = 0.f, c_rew = 0.f, c_done = 0.f, c_vprev = 0.f;
+  // phase stamps (debug): wave 1's view of workgroup 0, summed over the iterations, 100 MHz ticks
+  const bool stamp = p.x.dbg != nullptr && b == 0 && tid == 64;
+  unsigned long long ts_prev = 0, ts_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define RING_TS(i) do { if (stamp) { const unsigned long long n_ = wall_clock64(); ts_sum[i] += n_ - ts_prev; ts_prev = n_; } } while (0)
+  if (stamp) ts_prev = wall_clock64();
+
+  for (int t = 0; t <= T; ++t) {
+    float ld_r = 0.f, ld_d = 0.f;
+    if (t > 0) {
+      // ---- wait for the env worker: rec granule = ((seq << 1 | done) << 32) | float_bits(reward), frame written before it
+      if (tid == 64) {           // (lane 0 of a wave with three conv1 tiles: it reaches the poll before wave 0 does)
+        const unsigned int want = (p.x.seq0 + (unsigned int)t) & 0x7fffffffu;
+        const unsigned long long t0 = wall_clock64();
+        unsigned long long gr;
+        for (;;) {
+          gr = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (stamp) ts_sum[9] += 1;
+          if ((unsigned int)(gr >> 33) == want) break;
+          if ((long)(wall_clock64() - t0) > p.x.timeout_ticks) {
+            __hip_atomic_store(p.x.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            gr = ~0ULL;
+            break;
+          }
+          for (int q = 0; q < p.x.poll_gap; ++q) __builtin_amdgcn_s_sleep(1);
+        }
+        reinterpret_cast<unsigned int*>(red)[HN + 32] = (unsigned int)gr;
+        reinterpret_cast<unsigned int*>(red)[HN + 33] = (unsigned int)(gr >> 32);
+        RING_TS(0);               // waiting for the env worker
+        if (stamp) {              // turn-around: cmd store (tail lane's stamp, in LDS) -> rec seen
+          const unsigned long long tc = (unsigned long long)reinterpret_cast<const unsigned int*>(red)[HN + 34] |
+                                        ((unsigned long long)reinterpret_cast<const unsigned int*>(red)[HN + 35] << 32);
+          ts_sum[8] += ts_prev - tc;
+        }
+      }
+      __syncthreads();          // (also: every read of the ring's oldest plane by the stores of state t-1 has returned)
+      RING_TS(1);
+      const unsigned int g_lo = reinterpret_cast<const unsigned int*>(red)[HN + 32];
+      const unsigned int g_hi = reinterpret_cast<const unsigned int*>(red)[HN + 33];
+      if (g_hi == 0xffffffffu) break;                   // host timeout: the error flag is set, give up on this slot
+      ld_r = __uint_as_float(g_lo);
+      ld_d = (g_hi & 1u) ? 1.f : 0.f;
+      // the frame: packed (2 bytes = this thread's 16 pixels) or uint8 (16 bytes), system-scope loads over PCIe
+      u32x4 f8 = (u32x4){0u, 0u, 0u, 0u};
+      if (p.x.frame_bits) {
+        __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW >> 3, 0x00020000);
+        const unsigned int bits = __builtin_amdgcn_raw_buffer_load_b16(fr, tid * 2, 0, 1 | 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned int wq = bits >> (4 * q);
+          f8[q] = (wq & 1u) | ((wq & 2u) << 7) | ((wq & 4u) << 14) | ((wq & 8u) << 21);
+        }
+      } else {
+        __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW, 0x00020000);
+        f8 = __builtin_amdgcn_raw_buffer_load_b128(fr, tid * 16, 0, 1 | 16);
+      }
+      // state t: planes 0..2 = planes 1..3 of state t-1 (already in place: base advanced), plane 3 = the frame
+      if (tid * 16 < HW) *reinterpret_cast<u32x4*>(ring + ((base + 3) & 3) * HW + tid * 16) = f8;
+      if (ld_d != 0.f) {        // real done: the frame stack restarts from zeros (utils.py:37-42)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int pl = 0; pl < 3; ++pl)
+          if (tid * 16 < HW) *reinterpret_cast<u32x4*>(ring + ((base + pl) & 3) * HW + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+      }
+      __syncthreads();
+      RING_TS(2);                 // frame over PCIe into the ring
+    }
+    // ---- conv1: the newest plane's 16 steps on top of the partial sums, then bias + ReLU -> a1
+    conv1_planes(base, 3, 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (okp[q]) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) a1[(4 * g + rr) * p.PLANE2 + pix[q]] = fmaxf(acc[q][rr] + b1[rr], 0.f);
+      }
+    __syncthreads();
+    RING_TS(3);                   // conv1, newest plane
+    // ---- conv2: 32 x (OH2*OW2), K = 256 split in two halves (see the per-step kernel)
+    {
+      const float* __restrict__ la = fr2 + lane;
+      for (int unit = w; unit < ntile2 * 4; unit += NT / 64) {
+        const int kh = unit & 1, m = (unit >> 1) & 1, tile = unit >> 2;
+        const int idx = tile * 16 + j;
+        const int i = idx < NP2 ? idx : 0;
+        const int r = i / p.OW2, c = i - r * p.OW2;
+        const float* __restrict__ l = a1 + r * 2 * p.OW1 + c * 2 + g * p.PLANE2;
+        f32x4 ac2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int c4 = kh * 2 + cc;
+          float bv[16], av[16];
+#pragma unroll
+          for (int ky = 0; ky < 4; ++ky) {
+            const int off = c4 * 4 * p.PLANE2 + ky * p.OW1;
+            const float2 t0 = *reinterpret_cast<const float2*>(l + off);
+            const float2 t1 = *reinterpret_cast<const float2*>(l + off + 2);
+            bv[ky * 4 + 0] = t0.x; bv[ky * 4 + 1] = t0.y; bv[ky * 4 + 2] = t1.x; bv[ky * 4 + 3] = t1.y;
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) av[u] = la[((c4 * 16 + u) * 2 + m) * 64];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) ac2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], ac2, 0, 0, 0);
+        }
+        *reinterpret_cast<float4*>(part + ((kh * ntile2 + tile) * 2 + m) * 256 + lane * 4) = (float4){ac2[0], ac2[1], ac2[2], ac2[3]};
+      }
+    }
+    __syncthreads();
+    {
+      const int co = tid >> 4, pl = tid & 15;
+      const float bias2 = red[HN + co];
+      const int cslot = (co >> 4) * 256 + 16 * ((co & 15) >> 2) * 4 + (co & 3);
+      for (int px = pl; px < NP2; px += 16) {
+        const int slot = (px >> 4) * 512 + (px & 15) * 4 + cslot;
+        a2[co * NP2 + px] = fmaxf((part[slot] + part[ntile2 * 512 + slot]) + bias2, 0.f);
+      }
+    }
+    __syncthreads();
+    RING_TS(4);                   // conv2 + epilogue
+    // ---- heads (same summation order as the per-step kernel)
+    {
+      float hacc[HNT];
+#pragma unroll
+      for (int n = 0; n < HNT; ++n) hacc[n] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = (tid << 2) + q * (NT * 4);
+        if (k < p.F) {
+          const float4 x = *reinterpret_cast<const float4*>(a2 + k);
+#pragma unroll
+          for (int n = 0; n < HNT; ++n)
+            if (n < N) hacc[n] += x.x * wc[q][n].x + x.y * wc[q][n].y + x.z * wc[q][n].z + x.w * wc[q][n].w;
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < HNT; ++n)
+        if (n < N) hp[n * NT + tid] = hacc[n];
+    }
+    __syncthreads();
+    if (w < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < NT / 64; ++q) v += hp[w * NT + q * 64 + lane];
+      v = wave_sum(v);
+      if (lane == 0) red[w] = v;
+    }
+    __syncthreads();
+    RING_TS(5);                   // heads
+    if (tail) {
+      // bookkeeping of the env step that produced this state (runner.py:212-232), like the per-step kernel's tail
+      const bool rec = t > 0;
+      const long bk_e = row + t - 1;
+      const float bk_r = ld_r, bk_v = c_val;            // c_val: value of state t-1
+      float bk_d = ld_d != 0.f ? 1.f : 0.f;
+      if (a.pong && bk_r != 0.f) bk_d = 1.f;
+      if (rec) {
+        a.rewards[bk_e] = bk_r;
+        a.dones[bk_e] = bk_d;
+        if (t > 1) a.deltas[bk_e - 1] = (c_rew + (a.gamma * bk_v) * (1.f - c_done)) - c_vprev;
+        c_vprev = bk_v;
+        c_rew = bk_r;
+        c_done = bk_d;
+      }
+      float h[HNT], vboot = 0.f;
+      float* __restrict__ ho = (p.x.heads_rows && t < T) ? p.x.heads_rows + (row + t) * p.x.heads_rows_ld : nullptr;
+#pragma unroll
+      for (int n = 0; n < HNT; ++n) {
+        h[n] = 0.f;
+        if (n < N) {
+          h[n] = red[n] + bcv[n];
+          a.heads[(long)b * a.ldh + n] = h[n];
+          if (ho != nullptr) ho[n] = h[n];
+          if (n == a.n_actions) vboot = h[n];
+        }
+      }
+      c_val = vboot;
+      if (t < T) {               // softmax + running fp32 cumsum, first >= u (utils.py:45-60)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < HNT; ++n)
+          if (n < a.n_actions) mx = fmaxf(mx, h[n]);
+        float den = 0.f;
+#pragma unroll
+        for (int n = 0; n < HNT; ++n)
+          if (n < a.n_actions) den += expf(h[n] - mx);
+        const float ub = p.x.u[(long)t * p.x.u_stride + b];
+        float cs = 0.f;
+        int pick = -1;
+#pragma unroll
+        for (int n = 0; n < HNT; ++n)
+          if (n < a.n_actions) {
+            cs = cs + expf(h[n] - mx) / den;
+            if (pick < 0 && cs >= ub) pick = n;
+          }
+        if (pick < 0) pick = a.n_actions - 1;
+        // the action goes to the env worker FIRST (its turn-around is the critical path), then to the rollout buffer
+        __hip_atomic_store(p.x.cmd + p.x.env0 + b,
+                           ((unsigned long long)(p.x.seq0 + (unsigned int)t) << 32) | (unsigned int)pick,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.x.dbg != nullptr && b == 0) {
+          const unsigned long long tc = wall_clock64();
+          reinterpret_cast<unsigned int*>(red)[HN + 34] = (unsigned int)tc;
+          reinterpret_cast<unsigned int*>(red)[HN + 35] = (unsigned int)(tc >> 32);
+        }
+        p.x.actions[row + t] = (int64_t)pick;
+      } else if (rec) {          // t == T: bootstrap on the step recorded above (runner.py:236-245)
+        float r = bk_r;
+        if (bk_d == 0.f) {
+          r = r + a.gamma * vboot;
+          a.rewards[bk_e] = r;
+          a.dones[bk_e] = 1.f;
+        }
+        a.deltas[bk_e] = r - bk_v;
+        a.val_prev[b] = bk_v;
+      }
+    }
+    // ---- off the critical path (the env worker is stepping): state row + stash of state t, partial sums of state t+1
+    if (t < T) {
+      base = (base + 1) & 3;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      conv1_planes(base, 0, 3);          // planes 0..2 of state t+1 = planes 1..3 of state t
+    }
+    RING_TS(6);                   // partial sums of the next state
+    {
+      // state t: plane pl sits in slot (bt + pl) & 3, bt = the base the state was computed with
+      const int bt = t < T ? (base + 3) & 3 : base;
+      float* __restrict__ out = t == T ? p.x.bookmark + (long)b * S : p.x.states + (row + t) * S;
+      const int hw4 = HW >> 2;
+      for (int q = tid; q < 4 * hw4; q += NT) {
+        const int pl = q / hw4, o = q - pl * hw4;
+        const unsigned int x = reinterpret_cast<const unsigned int*>(ring + ((bt + pl) & 3) * HW)[o];
+        const float4 v = u8x4(x);
+        __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out) + q);
+      }
+    }
+    if (p.x.a1_rows != nullptr && t < T) {
+      float* __restrict__ a1o = p.x.a1_rows + (row + t) * (16L * NP1);
+      const int n4 = NP1 >> 2;
+      for (int q = tid; q < 16 * n4; q += NT) {
+        const int ch = q / n4, o4 = q - ch * n4;
+        const float4 v = *reinterpret_cast<const float4*>(a1 + ch * p.PLANE2 + (o4 << 2));
+        __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a1o) + q);
+      }
+    }
+    if (p.x.a2_rows != nullptr && t < T) {
+      float* __restrict__ a2o = p.x.a2_rows + (row + t) * (long)p.F;
+      for (int q = tid; q < (p.F >> 2); q += NT) {
+        const float4 v = *reinterpret_cast<const float4*>(a2 + (q << 2));
+        __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a2o) + q);
+      }
+    }
+    RING_TS(7);                   // state row + stash stores issued
+  }
+  if (stamp)
+    for (int q = 0; q < 10; ++q) p.x.dbg[q] = ts_sum[q];
+#undef RING_TS
+}
+
+static size_t ring_lds(const StepP& p, int hnt) {
+  const int ntile2 = (p.OH2 * p.OW2 + 15) / 16;
+  return 4 * ((size_t)NF1 + NF2 + (size_t)16 * p.PLANE2 + p.F4 + (size_t)ntile2 * 1024 + (size_t)hnt * NT + HN + 32 + 8) +
+         (size_t)4 * p.a.H * p.a.W + 64;
+}
+
 static inline int plane_pad(int n, int mod64) {      // smallest p >= n with p % 64 == mod64
   int p = ((n + 63) / 64) * 64 + mod64;
   if (p - 64 >= n) p -= 64;
@@ -617,7 +1029,8 @@ static bool set_lds_attr() {
   if (!attr_set) {
     const void* ks[] = {(const void*)a3c_step_kernel<true, false, false>, (const void*)a3c_step_kernel<false, false, false>,
                         (const void*)a3c_step_kernel<true, true, false>, (const void*)a3c_step_kernel<false, true, false>,
-                        (const void*)a3c_step_kernel<true, true, true, 4>, (const void*)a3c_step_kernel<true, true, true, 8>};
+                        (const void*)a3c_step_kernel<true, true, true, 4>, (const void*)a3c_step_kernel<true, true, true, 8>,
+                        (const void*)a3c_ring_kernel<4>, (const void*)a3c_ring_kernel<8>};
     for (const void* k : ks)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
     attr_set = true;
@@ -626,7 +1039,14 @@ static bool set_lds_attr() {
 }
 }  // namespace
 
+static unsigned long long* g_ring_dbg = nullptr;
 extern "C" {
+/* debug: device buffer of 10 x uint64 that receives the summed phase stamps (100 MHz ticks) of workgroup 0 of every
+ * following ring-kernel launch (see a3c_ring_kernel); NULL switches it off.  Not part of the drop-in boundary. */
+int a2c_debug_ring_timing(unsigned long long* dev_buf) {
+  g_ring_dbg = dev_buf;
+  return A2C_OK;
+}
 #ifdef A2C_STEP_TIMING
 int a2c_debug_step_skip(int mask) {
   return hipMemcpyToSymbol(HIP_SYMBOL(a2c_step_skip), &mask, sizeof(int)) == hipSuccess ? 0 : -1;
@@ -697,6 +1117,11 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.fstore = r->frame_store; p.x.fs_slot_stride = (long)r->frame_store_slot_stride;
   p.x.nvalid = r->nvalid_rows; p.x.nvalid_carry = r->nvalid_carry;
   p.x.frame_bits = r->frame_bits ? 1 : 0;
+  p.x.dbg = g_ring_dbg;
+  {
+    static const int gap = getenv("A2C_RING_POLL") ? atoi(getenv("A2C_RING_POLL")) : 4;
+    p.x.poll_gap = gap > 0 ? gap : 1;
+  }
   if (r->frame_store && (!r->nvalid_rows || !r->nvalid_carry || r->T < 4 || ((uintptr_t)r->frame_store % 16) ||
                          r->frame_store_slot_stride % 16 || r->frame_store_slot_stride < (r->T + 4) * (int64_t)r->H * r->W))
     return A2C_ERR_ARG;
@@ -712,10 +1137,21 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   if ((((uintptr_t)r->states | (uintptr_t)r->bookmark | (uintptr_t)r->frames | (uintptr_t)a.wfrag2 | (uintptr_t)a.Wc) % 16) ||
       (((uintptr_t)r->cmd | (uintptr_t)r->rec) % 8))
     return A2C_ERR_ARG;
-  const size_t lds = step_lds(p);
   if (!set_lds_attr()) return A2C_ERR_LAUNCH;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  // every env has a CU to itself: the state stays in LDS for the whole slot (a3c_ring_kernel)
+  const int hnt = a.n_actions + 1 <= 4 ? 4 : 8;
+  static const bool no_ring = getenv("A2C_NO_RING") != nullptr && getenv("A2C_NO_RING")[0] == '1';
+  if (!no_ring && r->conv1_weight && a.B <= cus && !r->frame_store && ring_lds(p, hnt) <= 160 * 1024 && (p.OH1 * p.OW1 + 15) / 16 <= 32 &&
+      ((uintptr_t)r->conv1_weight % 4) == 0) {
+    const size_t rl = ring_lds(p, hnt);
+    if (hnt == 4) hipLaunchKernelGGL((a3c_ring_kernel<4>), dim3(a.B), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
+    else hipLaunchKernelGGL((a3c_ring_kernel<8>), dim3(a.B), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
+    A2C_CHECK_LAUNCH();
+    return A2C_OK;
+  }
+  const size_t lds = step_lds(p);
   // one workgroup per CU at most (157 KB of LDS each): all of them resident, envs beyond that take turns
   const int grid = a.B < cus ? a.B : cus;
   if (a.n_actions + 1 <= 4) hipLaunchKernelGGL((a3c_step_kernel<true, true, true, 4>), dim3(grid), dim3(NT), lds, a2c_s(stream), p);

@@ -615,9 +615,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   float* __restrict__ a1 = fr2 + NF2;                   // 16 x PLANE2
   float* __restrict__ a2 = a1 + 16 * p.PLANE2;          // flat (c, y, x)
   float* __restrict__ part = a2 + p.F4;                 // [2][ntile2*2][256] conv2 K-half partials
-  float* __restrict__ hp = part + ntile2 * 1024;        // [HNT][NT] head partials
-  float* __restrict__ red = hp + HNT * NT;              // heads | conv2 bias | granule
-  unsigned char* __restrict__ ring = reinterpret_cast<unsigned char*>(red + HN + 32 + 8);   // 4 planes of HW bytes
+  float* __restrict__ hp = part;                        // [HNT][NT] head partials: over the K-half partials (dead by then)
+  float* __restrict__ red = part + max(ntile2 * 1024, HNT * NT);   // heads | conv2 bias | granule, flags
+  // the state: a ring of FIVE uint8 plane slots.  State t owns slots base .. base+3 (mod 5); the fifth receives the
+  // frame of state t+1 while state t's row is still being written out
+  unsigned char* __restrict__ ring = reinterpret_cast<unsigned char*>(red + HN + 32 + 8);
   const int b = blockIdx.x;
   const long S = 4L * HW, row = (a.slot0 + b) * a.T;
   const int T = (int)a.T;
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // A operands of the 8 steps; the two tiles of a pair are two independent accumulator chains
   auto conv1_planes = [&](int base, int p0, int p1) {
     for (int pl = p0; pl < p1; ++pl) {
-      const unsigned char* __restrict__ plane = ring + ((base + pl) & 3) * HW;
+      const unsigned char* __restrict__ plane = ring + ((base + pl) % 5) * HW;
 #pragma unroll
       for (int kyq = 0; kyq < 2; ++kyq) {
         const float4* __restrict__ fa = reinterpret_cast<const float4*>(fr1) + ((pl * 2 + kyq) * 2) * 64 + lane;
@@ -730,11 +732,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define RING_TS(i) do { if (stamp) { const unsigned long long n_ = wall_clock64(); ts_sum[i] += n_ - ts_prev; ts_prev = n_; } } while (0)
   if (stamp) ts_prev = wall_clock64();
 
+  bool pre_ok = false;            // wave 1: granule and frame of the coming state are already in LDS (prefetched)
   for (int t = 0; t <= T; ++t) {
     float ld_r = 0.f, ld_d = 0.f;
+    // the sampler's uniform of this step: in flight from here, consumed by the tail lane behind the heads
+    const float ub = (tail && t < T) ? p.x.u[(long)t * p.x.u_stride + b] : 0.f;
     if (t > 0) {
-      // ---- wait for the env worker: rec granule = ((seq << 1 | done) << 32) | float_bits(reward), frame written before it
-      if (tid == 64) {           // (lane 0 of a wave with three conv1 tiles: it reaches the poll before wave 0 does)
+      // ---- the env worker's answer: rec granule = ((seq << 1 | done) << 32) | float_bits(reward), frame written before it.
+      // Usually wave 1 fetched both during the previous iteration's off-critical-path phase (below); otherwise it
+      // polls here and every thread then loads its part of the frame.
+      if (w == 1 && !pre_ok) {
         const unsigned int want = (p.x.seq0 + (unsigned int)t) & 0x7fffffffu;
         const unsigned long long t0 = wall_clock64();
         unsigned long long gr;
@@ -749,48 +756,54 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           }
           for (int q = 0; q < p.x.poll_gap; ++q) __builtin_amdgcn_s_sleep(1);
         }
-        reinterpret_cast<unsigned int*>(red)[HN + 32] = (unsigned int)gr;
-        reinterpret_cast<unsigned int*>(red)[HN + 33] = (unsigned int)(gr >> 32);
-        RING_TS(0);               // waiting for the env worker
-        if (stamp) {              // turn-around: cmd store (tail lane's stamp, in LDS) -> rec seen
-          const unsigned long long tc = (unsigned long long)reinterpret_cast<const unsigned int*>(red)[HN + 34] |
-                                        ((unsigned long long)reinterpret_cast<const unsigned int*>(red)[HN + 35] << 32);
-          ts_sum[8] += ts_prev - tc;
+        if (lane == 0) {
+          reinterpret_cast<unsigned int*>(red)[HN + 32] = (unsigned int)gr;
+          reinterpret_cast<unsigned int*>(red)[HN + 33] = (unsigned int)(gr >> 32);
+          reinterpret_cast<unsigned int*>(red)[HN + 36] = 0u;        // the frame is still to be loaded
         }
       }
-      __syncthreads();          // (also: every read of the ring's oldest plane by the stores of state t-1 has returned)
+      if (stamp) {                // turn-around: cmd store (tail lane's stamp, in LDS) -> answer in hand
+        RING_TS(0);
+        const unsigned long long tc = (unsigned long long)reinterpret_cast<const unsigned int*>(red)[HN + 34] |
+                                      ((unsigned long long)reinterpret_cast<const unsigned int*>(red)[HN + 35] << 32);
+        ts_sum[8] += ts_prev - tc;
+      }
+      __syncthreads();          // (also: every read of the slot the NEXT frame will go to has returned)
       RING_TS(1);
       const unsigned int g_lo = reinterpret_cast<const unsigned int*>(red)[HN + 32];
       const unsigned int g_hi = reinterpret_cast<const unsigned int*>(red)[HN + 33];
+      const bool in_ring = reinterpret_cast<const unsigned int*>(red)[HN + 36] != 0u;
       if (g_hi == 0xffffffffu) break;                   // host timeout: the error flag is set, give up on this slot
       ld_r = __uint_as_float(g_lo);
       ld_d = (g_hi & 1u) ? 1.f : 0.f;
-      // the frame: packed (2 bytes = this thread's 16 pixels) or uint8 (16 bytes), system-scope loads over PCIe
-      u32x4 f8 = (u32x4){0u, 0u, 0u, 0u};
-      if (p.x.frame_bits) {
-        __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW >> 3, 0x00020000);
-        const unsigned int bits = __builtin_amdgcn_raw_buffer_load_b16(fr, tid * 2, 0, 1 | 16);
+      if (!in_ring) {
+        // the frame: packed (2 bytes = this thread's 16 pixels) or uint8 (16 bytes), system-scope loads over PCIe
+        u32x4 f8 = (u32x4){0u, 0u, 0u, 0u};
+        if (p.x.frame_bits) {
+          __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW >> 3, 0x00020000);
+          const unsigned int bits = __builtin_amdgcn_raw_buffer_load_b16(fr, tid * 2, 0, 1 | 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned int wq = bits >> (4 * q);
-          f8[q] = (wq & 1u) | ((wq & 2u) << 7) | ((wq & 4u) << 14) | ((wq & 8u) << 21);
+          for (int q = 0; q < 4; ++q) {
+            const unsigned int wq = bits >> (4 * q);
+            f8[q] = (wq & 1u) | ((wq & 2u) << 7) | ((wq & 4u) << 14) | ((wq & 8u) << 21);
+          }
+        } else {
+          __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW, 0x00020000);
+          f8 = __builtin_amdgcn_raw_buffer_load_b128(fr, tid * 16, 0, 1 | 16);
         }
-      } else {
-        __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, HW, 0x00020000);
-        f8 = __builtin_amdgcn_raw_buffer_load_b128(fr, tid * 16, 0, 1 | 16);
+        // state t: planes 0..2 = planes 1..3 of state t-1 (in place: base advanced), plane 3 = the frame
+        if (tid * 16 < HW) *reinterpret_cast<u32x4*>(ring + ((base + 3) % 5) * HW + tid * 16) = f8;
       }
-      // state t: planes 0..2 = planes 1..3 of state t-1 (already in place: base advanced), plane 3 = the frame
-      if (tid * 16 < HW) *reinterpret_cast<u32x4*>(ring + ((base + 3) & 3) * HW + tid * 16) = f8;
       if (ld_d != 0.f) {        // real done: the frame stack restarts from zeros (utils.py:37-42)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int pl = 0; pl < 3; ++pl)
-          if (tid * 16 < HW) *reinterpret_cast<u32x4*>(ring + ((base + pl) & 3) * HW + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+          if (tid * 16 < HW) *reinterpret_cast<u32x4*>(ring + ((base + pl) % 5) * HW + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
       }
-      __syncthreads();
-      RING_TS(2);                 // frame over PCIe into the ring
+      if (!in_ring) __syncthreads();
+      RING_TS(2);                 // frame over PCIe into the ring (when it was not prefetched)
     }
     // ---- conv1: the newest plane's 16 steps on top of the partial sums, then bias + ReLU -> a1
     conv1_planes(base, 3, 4);
@@ -873,6 +886,46 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __syncthreads();
     RING_TS(5);                   // heads
     if (tail) {
+      // The action goes to the env worker FIRST: its turn-around is the critical path of the step, and this lane shares
+      // its SIMD with a wave that is already computing the next state's partial sums (hence the priority).
+      __builtin_amdgcn_s_setprio(3);
+      float h[HNT], vboot = 0.f;
+#pragma unroll
+      for (int n = 0; n < HNT; ++n) {
+        h[n] = 0.f;
+        if (n < N) {
+          h[n] = red[n] + bcv[n];
+          if (n == a.n_actions) vboot = h[n];
+        }
+      }
+      int pick = -1;
+      if (t < T) {               // softmax + running fp32 cumsum, first >= u (utils.py:45-60)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < HNT; ++n)
+          if (n < a.n_actions) mx = fmaxf(mx, h[n]);
+        float den = 0.f;
+#pragma unroll
+        for (int n = 0; n < HNT; ++n)
+          if (n < a.n_actions) den += expf(h[n] - mx);
+        float cs = 0.f;
+#pragma unroll
+        for (int n = 0; n < HNT; ++n)
+          if (n < a.n_actions) {
+            cs = cs + expf(h[n] - mx) / den;
+            if (pick < 0 && cs >= ub) pick = n;
+          }
+        if (pick < 0) pick = a.n_actions - 1;
+        __hip_atomic_store(p.x.cmd + p.x.env0 + b,
+                           ((unsigned long long)(p.x.seq0 + (unsigned int)t) << 32) | (unsigned int)pick,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.x.dbg != nullptr && b == 0) {
+          const unsigned long long tc = wall_clock64();
+          reinterpret_cast<unsigned int*>(red)[HN + 34] = (unsigned int)tc;
+          reinterpret_cast<unsigned int*>(red)[HN + 35] = (unsigned int)(tc >> 32);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
       // bookkeeping of the env step that produced this state (runner.py:212-232), like the per-step kernel's tail
       const bool rec = t > 0;
       const long bk_e = row + t - 1;
@@ -887,47 +940,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         c_rew = bk_r;
         c_done = bk_d;
       }
-      float h[HNT], vboot = 0.f;
       float* __restrict__ ho = (p.x.heads_rows && t < T) ? p.x.heads_rows + (row + t) * p.x.heads_rows_ld : nullptr;
 #pragma unroll
-      for (int n = 0; n < HNT; ++n) {
-        h[n] = 0.f;
+      for (int n = 0; n < HNT; ++n)
         if (n < N) {
-          h[n] = red[n] + bcv[n];
           a.heads[(long)b * a.ldh + n] = h[n];
           if (ho != nullptr) ho[n] = h[n];
-          if (n == a.n_actions) vboot = h[n];
         }
-      }
       c_val = vboot;
-      if (t < T) {               // softmax + running fp32 cumsum, first >= u (utils.py:45-60)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int n = 0; n < HNT; ++n)
-          if (n < a.n_actions) mx = fmaxf(mx, h[n]);
-        float den = 0.f;
-#pragma unroll
-        for (int n = 0; n < HNT; ++n)
-          if (n < a.n_actions) den += expf(h[n] - mx);
-        const float ub = p.x.u[(long)t * p.x.u_stride + b];
-        float cs = 0.f;
-        int pick = -1;
-#pragma unroll
-        for (int n = 0; n < HNT; ++n)
-          if (n < a.n_actions) {
-            cs = cs + expf(h[n] - mx) / den;
-            if (pick < 0 && cs >= ub) pick = n;
-          }
-        if (pick < 0) pick = a.n_actions - 1;
-        // the action goes to the env worker FIRST (its turn-around is the critical path), then to the rollout buffer
-        __hip_atomic_store(p.x.cmd + p.x.env0 + b,
-                           ((unsigned long long)(p.x.seq0 + (unsigned int)t) << 32) | (unsigned int)pick,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (p.x.dbg != nullptr && b == 0) {
-          const unsigned long long tc = wall_clock64();
-          reinterpret_cast<unsigned int*>(red)[HN + 34] = (unsigned int)tc;
-          reinterpret_cast<unsigned int*>(red)[HN + 35] = (unsigned int)(tc >> 32);
-        }
+      if (t < T) {
         p.x.actions[row + t] = (int64_t)pick;
       } else if (rec) {          // t == T: bootstrap on the step recorded above (runner.py:236-245)
         float r = bk_r;
@@ -940,42 +961,84 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         a.val_prev[b] = bk_v;
       }
     }
-    // ---- off the critical path (the env worker is stepping): state row + stash of state t, partial sums of state t+1
+    // ---- off the critical path (the env worker is stepping): partial sums of state t+1, state row + stash of state t,
+    // and -- wave 1 -- the env worker's answer: ONE early poll issued between the partial sums (its PCIe round trip runs
+    // under the MFMAs), then the packed frame (one 16-byte load per lane covers it) under the stores
+    const bool pf = w == 1 && t < T && p.x.frame_bits != 0;
+    const unsigned int want_n = (p.x.seq0 + (unsigned int)(t + 1)) & 0x7fffffffu;
+    unsigned long long gr_pf = ~0ULL;
+    u32x4 f_pf = (u32x4){0u, 0u, 0u, 0u};
+    pre_ok = false;
+    const int nbase = (base + 1) % 5;
     if (t < T) {
-      base = (base + 1) & 3;
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      conv1_planes(base, 0, 3);          // planes 0..2 of state t+1 = planes 1..3 of state t
+      conv1_planes(nbase, 0, 2);         // planes 0..2 of state t+1 = planes 1..3 of state t
+      // ONE early poll of the env worker's answer, issued where its PCIe round trip runs under the last plane's MFMAs
+      // (earlier the answer cannot have landed; later -- behind this CU's row stores -- it queues behind them)
+      if (pf) gr_pf = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      conv1_planes(nbase, 2, 3);
     }
     RING_TS(6);                   // partial sums of the next state
-    {
-      // state t: plane pl sits in slot (bt + pl) & 3, bt = the base the state was computed with
-      const int bt = t < T ? (base + 3) & 3 : base;
+    if (pf) {
+      // wave 1 issues no store here: loads and stores retire through ONE in-order counter, a frame load behind the
+      // row stores would wait for their HBM acknowledgements.  The packed frame is one 16-byte load per lane.
+      pre_ok = (unsigned int)(gr_pf >> 33) == want_n;
+      if (pre_ok) {
+        __amdgpu_buffer_rsrc_t fr_pf = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, (int)a.frame_stride, 0x00020000);
+        f_pf = __builtin_amdgcn_raw_buffer_load_b128(fr_pf, lane * 16, 0, 1 | 16);      // pixels 128*lane .. +127
+      }
+    } else {
+      // state t: plane pl sits in slot (base + pl) % 5.  The stores are dealt to the waves other than the fetching one.
+      const bool dealt = t < T && p.x.frame_bits != 0;          // wave 1 is busy with the env worker's answer
+      const int sid = dealt ? (w == 0 ? tid : tid - 64) : tid, sn = dealt ? NT - 64 : NT;
       float* __restrict__ out = t == T ? p.x.bookmark + (long)b * S : p.x.states + (row + t) * S;
       const int hw4 = HW >> 2;
-      for (int q = tid; q < 4 * hw4; q += NT) {
+      for (int q = sid; q < 4 * hw4; q += sn) {
         const int pl = q / hw4, o = q - pl * hw4;
-        const unsigned int x = reinterpret_cast<const unsigned int*>(ring + ((bt + pl) & 3) * HW)[o];
+        const unsigned int x = reinterpret_cast<const unsigned int*>(ring + ((base + pl) % 5) * HW)[o];
         const float4 v = u8x4(x);
         __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out) + q);
       }
-    }
-    if (p.x.a1_rows != nullptr && t < T) {
-      float* __restrict__ a1o = p.x.a1_rows + (row + t) * (16L * NP1);
-      const int n4 = NP1 >> 2;
-      for (int q = tid; q < 16 * n4; q += NT) {
-        const int ch = q / n4, o4 = q - ch * n4;
-        const float4 v = *reinterpret_cast<const float4*>(a1 + ch * p.PLANE2 + (o4 << 2));
-        __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a1o) + q);
+      if (p.x.a1_rows != nullptr && t < T) {
+        float* __restrict__ a1o = p.x.a1_rows + (row + t) * (16L * NP1);
+        const int n4 = NP1 >> 2;
+        for (int q = sid; q < 16 * n4; q += sn) {
+          const int ch = q / n4, o4 = q - ch * n4;
+          const float4 v = *reinterpret_cast<const float4*>(a1 + ch * p.PLANE2 + (o4 << 2));
+          __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a1o) + q);
+        }
+      }
+      if (p.x.a2_rows != nullptr && t < T) {
+        float* __restrict__ a2o = p.x.a2_rows + (row + t) * (long)p.F;
+        for (int q = sid; q < (p.F >> 2); q += sn) {
+          const float4 v = *reinterpret_cast<const float4*>(a2 + (q << 2));
+          __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a2o) + q);
+        }
       }
     }
-    if (p.x.a2_rows != nullptr && t < T) {
-      float* __restrict__ a2o = p.x.a2_rows + (row + t) * (long)p.F;
-      for (int q = tid; q < (p.F >> 2); q += NT) {
-        const float4 v = *reinterpret_cast<const float4*>(a2 + (q << 2));
-        __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a2o) + q);
+    if (pf && pre_ok) {
+      // the prefetched frame -> plane 3 of state t+1 = the ring's free fifth slot, 128 pixels per lane
+      unsigned char* __restrict__ dst = ring + ((nbase + 3) % 5) * HW + lane * 128;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned int bits = f_pf[q >> 1] >> (16 * (q & 1));
+        u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned int wq = bits >> (4 * e);
+          v[e] = (wq & 1u) | ((wq & 2u) << 7) | ((wq & 4u) << 14) | ((wq & 8u) << 21);
+        }
+        if (lane * 128 + q * 16 < HW) *reinterpret_cast<u32x4*>(dst + q * 16) = v;
+      }
+      if (lane == 0) {
+        reinterpret_cast<unsigned int*>(red)[HN + 32] = (unsigned int)gr_pf;
+        reinterpret_cast<unsigned int*>(red)[HN + 33] = (unsigned int)(gr_pf >> 32);
+        reinterpret_cast<unsigned int*>(red)[HN + 36] = 1u;
       }
     }
+    if (t < T) base = nbase;
     RING_TS(7);                   // state row + stash stores issued
   }
   if (stamp)
@@ -985,8 +1048,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 static size_t ring_lds(const StepP& p, int hnt) {
   const int ntile2 = (p.OH2 * p.OW2 + 15) / 16;
-  return 4 * ((size_t)NF1 + NF2 + (size_t)16 * p.PLANE2 + p.F4 + (size_t)ntile2 * 1024 + (size_t)hnt * NT + HN + 32 + 8) +
-         (size_t)4 * p.a.H * p.a.W + 64;
+  const size_t part = (size_t)ntile2 * 1024 > (size_t)hnt * NT ? (size_t)ntile2 * 1024 : (size_t)hnt * NT;
+  return 4 * ((size_t)NF1 + NF2 + (size_t)16 * p.PLANE2 + p.F4 + part + HN + 32 + 8) + (size_t)5 * p.a.H * p.a.W + 64;
 }
 
 static inline int plane_pad(int n, int mod64) {      // smallest p >= n with p % 64 == mod64

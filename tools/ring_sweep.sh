@@ -1,8 +1,8 @@
 #!/bin/bash
-# sweep of the ring kernel's poll gap (64-cycle sleeps between polls of the rec granule): tools/ring_sweep.sh [threads]
-for g in 1 4 16 64; do
-  A2C_RING_POLL=$g python tools/ring_timing.py ${1:-16} bits 2>/dev/null | python -c "
-import json,sys,os
+# the ring kernel's phase stamps at several env thread counts: tools/ring_sweep.sh
+for n in 8 12 16 24; do
+  python tools/ring_timing.py $n bits 2>/dev/null | python -c "
+import json,sys
 d=json.load(sys.stdin)
-print('gap', os.environ.get('G'), d['rollout_ms_timed'], {k[:12]: v for k,v in d.items() if isinstance(v,float) and k[0] in 'wbfTp'})" 
+print(d['env_threads'], 'threads', d['rollout_ms_timed'], 'ms', {k[:12]: v for k,v in d.items() if isinstance(v,float) and k[0] in 'wbfTpsc'})"
 done

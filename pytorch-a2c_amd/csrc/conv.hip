@@ -27,6 +27,16 @@
 #include <mutex>
 #include "a2c_common.h"
 
+// conv3.hip: shape-specialised channel-chunk streaming kernels for the 3x3 layers at 84x84 (fragments appended to the
+// prepared-weight buffers of this file's layouts)
+bool c3_supported(const a2c_conv_desc* d, int kind);
+size_t c3_prep_floats(const a2c_conv_desc* d, int kind);
+int c3_prep(const a2c_conv_desc* d, int kind, const float* weight, float* out, hipStream_t st);
+int c3_fwd(const a2c_conv_desc* d, const float* in, long in_bs, const float* frag, const float* bias, int relu, float* out,
+           long out_bs, int B, hipStream_t st);
+int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, const float* mask, float* din, int B,
+                hipStream_t st);
+
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -2717,19 +2727,23 @@ static void launch_wgrad_t(const WgradP& p, int grid, size_t lds, hipStream_t st
 }  // namespace
 
 extern "C" {
-size_t a2c_conv2d_prep_floats(const a2c_conv_desc* d, int kind) {
-  if (!desc_ok(d)) return 0;
+static size_t prep_floats_base(const a2c_conv_desc* d, int kind) {
   if (kind == 0) return (size_t)pad_steps(d->ks * d->ks * (d->Cin / 4)) * ceil_div(d->Cout, 16) * 64;
   return bwd_class_offset(d, d->stride * d->stride);
+}
+size_t a2c_conv2d_prep_floats(const a2c_conv_desc* d, int kind) {
+  if (!desc_ok(d)) return 0;
+  return prep_floats_base(d, kind) + c3_prep_floats(d, kind);      // [this file's fragments | conv3.hip's]
 }
 
 int a2c_conv2d_prep_weights(const a2c_conv_desc* d, int kind, const float* weight, float* wprep,
                             a2c_stream_t stream) {
   if (!desc_ok(d) || !weight || !wprep) return A2C_ERR_ARG;
   hipStream_t st = a2c_s(stream);
+  if (c3_prep(d, kind, weight, wprep + prep_floats_base(d, kind), st) != A2C_OK) return A2C_ERR_LAUNCH;
   if (kind == 0) {
     const int MT = ceil_div(d->Cout, 16);
-    const long total = (long)a2c_conv2d_prep_floats(d, 0);
+    const long total = (long)prep_floats_base(d, 0);
     hipLaunchKernelGGL(prep_fwd_kernel, dim3(a2c_grid_1d(total, 256)), dim3(256), 0, st, weight, wprep, d->Cin, d->Cout,
                        d->ks, MT, (run_layout(d) || run3_layout(d)) ? 1 : 0, total);
     A2C_CHECK_LAUNCH();
@@ -2952,6 +2966,8 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
   if (B == 0) return A2C_OK;
   if (!in || !wprep_fwd || !out) return A2C_ERR_ARG;
+  if (c3_supported(d, 0) && in_bstride % 4 == 0 && out_bstride % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0)
+    return c3_fwd(d, in, (long)in_bstride, wprep_fwd + prep_floats_base(d, 0), bias, relu, out, (long)out_bstride, B, a2c_s(stream));
   return conv_fwd_tuned(d, in, in_bstride, wprep_fwd, bias, relu, out, out_bstride, B, stream);
 }
 
@@ -3172,6 +3188,8 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
   if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
   if (B == 0) return A2C_OK;
   if (!dout || !wprep_bwd || !din) return A2C_ERR_ARG;
+  if (c3_supported(d, 1) && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)din % 16) == 0 && (!mask || ((uintptr_t)mask % 16) == 0))
+    return c3_bwd_data(d, dout, wprep_bwd + prep_floats_base(d, 1), mask, din, B, a2c_s(stream));
   const int S = d->stride, P = d->pad;
   {  // fused-class pipelined path (unpadded ks = 2S layers whose dOut sample fits the prefetch registers)
     const int MTb = ceil_div(d->Cin, 16), c4n = d->Cout / 4;

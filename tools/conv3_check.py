@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""3x3 conv layers of ConvModel / GRUModel through the C ABI: max error against torch (CPU, fp32) at a small batch and
+HIP-event timings at rollout / update batch sizes.  Run twice to compare the kernel families:
+    python tools/conv3_check.py            # shape-specialised streaming kernels (conv3.hip) where they apply
+    A2C_NO_C3=1 python tools/conv3_check.py    # conv.hip's generic kernels"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-a2c_amd")]
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from a2c_amd import ops  # noqa: E402
+
+LAYERS = [  # Cin, H, W, Cout, stride, has bwd-data
+    (4, 84, 84, 16, 1, False), (16, 84, 84, 24, 1, True), (24, 84, 84, 32, 2, True), (32, 42, 42, 64, 2, True),
+    (16, 84, 84, 24, 2, True), (24, 42, 42, 32, 2, True), (32, 21, 21, 48, 2, True), (48, 11, 11, 64, 2, True)]
+dev = torch.device("cuda")
+only = [int(a) for a in sys.argv[1:]]
+tag = "generic (A2C_NO_C3=1)" if os.environ.get("A2C_NO_C3") == "1" else "conv3 where supported"
+print("kernels:", tag)
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+for li, (Cin, H, W, Cout, S, has_bwd) in enumerate(LAYERS):
+    if only and li not in only:
+        continue
+    d = ops.conv_desc(Cin, H, W, Cout, 3, S, 1)
+    g = torch.Generator().manual_seed(li)
+    wt = (torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * 0.4
+    bias = (torch.rand(Cout, generator=g) - 0.5) * 0.2
+    wf = torch.empty(ops.conv_prep_floats(d, 0), device=dev)
+    ops.conv_prep(d, 0, wt.to(dev), wf)
+    wb = None
+    if has_bwd:
+        wb = torch.empty(ops.conv_prep_floats(d, 1), device=dev)
+        ops.conv_prep(d, 1, wt.to(dev), wb)
+    # ---- correctness at B = 3
+    B = 3
+    x = torch.rand(B, Cin, H, W, generator=g) - 0.3
+    out = torch.empty(B, Cout, d.OH, d.OW, device=dev)
+    xd = x.to(dev)
+    ops.conv_fwd(d, xd.data_ptr(), Cin * H * W, wf, bias.to(dev), True, out, B)
+    ref = F.relu(F.conv2d(x, wt, bias, stride=S, padding=1))
+    err_f = float((out.cpu() - ref).abs().max())
+    err_b = float("nan")
+    if has_bwd:
+        dout = torch.rand(B, Cout, d.OH, d.OW, generator=g) - 0.5
+        mask = torch.rand(B, Cin, H, W, generator=g) - 0.4
+        din = torch.empty(B, Cin, H, W, device=dev)
+        ops.conv_bwd_data(d, dout.to(dev), wb, mask.to(dev), din, B)
+        refb = F.conv_transpose2d(dout, wt, stride=S, padding=1, output_padding=(H + 2 - 3) % S) * (mask > 0)
+        err_b = float((din.cpu() - refb).abs().max())
+    line = f"L{li} {Cin}->{Cout} {H}x{W} s{S}: max|err| fwd {err_f:.2e} bwd_data {err_b:.2e}"
+    # ---- timings
+    for Bt in (256, 4096):
+        xb = torch.rand(Bt, Cin, H, W, device=dev) - 0.3
+        ob = torch.empty(Bt, Cout, d.OH, d.OW, device=dev)
+        bd = bias.to(dev)
+        ms = timeit(lambda: ops.conv_fwd(d, xb.data_ptr(), Cin * H * W, wf, bd, True, ob, Bt), 20 if Bt == 256 else 3)
+        fl = 2.0 * Bt * Cout * d.OH * d.OW * Cin * 9
+        by = 4.0 * Bt * (Cin * H * W + Cout * d.OH * d.OW)
+        line += f" | fwd B={Bt}: {ms * 1e3:.1f} us {fl / ms / 1e9:.1f} TF {by / ms / 1e6:.0f} GB/s"
+        if has_bwd and Bt == 4096:
+            do = torch.rand(Bt, Cout, d.OH, d.OW, device=dev) - 0.5
+            di = torch.empty(Bt, Cin, H, W, device=dev)
+            ms = timeit(lambda: ops.conv_bwd_data(d, do, wb, xb, di, Bt), 3)
+            by = 4.0 * Bt * (2 * Cin * H * W + Cout * d.OH * d.OW)
+            line += f" | bwd_data B={Bt}: {ms * 1e3:.1f} us {fl / ms / 1e9:.1f} TF {by / ms / 1e6:.0f} GB/s"
+        del xb, ob
+    print(line, flush=True)

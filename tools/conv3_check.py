@@ -78,5 +78,17 @@ for li, (Cin, H, W, Cout, S, has_bwd) in enumerate(LAYERS):
             ms = timeit(lambda: ops.conv_bwd_data(d, do, wb, xb, di, Bt), 3)
             by = 4.0 * Bt * (2 * Cin * H * W + Cout * d.OH * d.OW)
             line += f" | bwd_data B={Bt}: {ms * 1e3:.1f} us {fl / ms / 1e9:.1f} TF {by / ms / 1e6:.0f} GB/s"
+            if S == 2 and hasattr(ops.lib(), "a2c_debug_c3_timing"):      # phase stamps of workgroup 0 / wave 0
+                import ctypes
+                lib = ops.lib()
+                lib.a2c_debug_c3_timing.argtypes = [ctypes.c_void_p]
+                buf = torch.zeros(4, dtype=torch.int64, device=dev)
+                lib.a2c_debug_c3_timing(buf.data_ptr())
+                ops.conv_bwd_data(d, do, wb, xb, di, Bt)
+                torch.cuda.synchronize()
+                lib.a2c_debug_c3_timing(None)
+                t = buf.cpu().tolist()
+                if t[3]:
+                    line += f" [wg0: compute {t[0] / 100:.0f} us, epilogue {t[1] / 100:.0f} us, barrier wait {t[2] / 100:.0f} us over {t[3]} chunks]"
         del xb, ob
     print(line, flush=True)

@@ -36,6 +36,10 @@ int c3_fwd(const a2c_conv_desc* d, const float* in, long in_bs, const float* fra
            long out_bs, int B, hipStream_t st);
 int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, const float* mask, float* din, int B,
                 hipStream_t st);
+bool c3w_supported(const a2c_conv_desc* d);
+size_t c3w_ws_bytes(const a2c_conv_desc* d);
+int c3w_bwd_weight(const a2c_conv_desc* d, const float* in, long in_bs, const float* dout, float* dW, float* db, int B, void* ws,
+                   size_t ws_bytes, hipStream_t st);
 
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -3321,7 +3325,9 @@ size_t a2c_conv2d_bwd_weight_ws_bytes(const a2c_conv_desc* d, int B) {
   int grid = pl.grid > pg.grid ? pl.grid : pg.grid;           // any of the kernels may be picked at launch
   WstreamP wp;
   if (plan_wstream(d, wp) && stream_grid() > grid) grid = stream_grid();
-  return (size_t)grid * ((size_t)d->Cout * d->Cin * d->ks * d->ks + d->Cout) * sizeof(float);
+  const size_t base = (size_t)grid * ((size_t)d->Cout * d->Cin * d->ks * d->ks + d->Cout) * sizeof(float);
+  const size_t c3 = c3w_ws_bytes(d);                           // conv3.hip's streaming kernel: one slab per pixel group
+  return c3 > base ? c3 : base;
 }
 
 int a2c_conv2d_bwd_weight_frames(const a2c_conv_desc* d, const uint8_t* fstore, int64_t slot_stride, int64_t T,
@@ -3361,6 +3367,8 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
   if (!plan_wgrad(d, B, pl, aligned)) return A2C_ERR_ARG;
   if (!ws || ws_bytes < a2c_conv2d_bwd_weight_ws_bytes(d, B)) return A2C_ERR_WORKSPACE;
   hipStream_t st = a2c_s(stream);
+  if (c3w_supported(d) && aligned && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dW % 16 == 0) && ((uintptr_t)ws % 16 == 0))
+    return c3w_bwd_weight(d, in, (long)in_bstride, dout, dW, db, B, ws, ws_bytes, st);
   {  // streaming kernel: A3C conv1 class at large batch
     WstreamP wp;
     const int grid = stream_grid();

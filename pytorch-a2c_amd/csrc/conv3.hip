@@ -57,13 +57,14 @@ struct C3Geo {
   static constexpr int NL = 2;
   static constexpr int TPW = (NT + NW - 1) / NW;      // tiles per computing wave
   static constexpr int SR = (R - 1) * S + 3;          // source rows per band (with halo)
-  static constexpr int WP = W + 4;                    // 4 floats of pad + the row
+  static constexpr int PB = W % 4 == 0 ? 4 : 1;       // floats per LDS-DMA piece: 16-byte pieces need 16-byte aligned rows
+  static constexpr int WP = W + PB;                   // one piece of pad + the row
   static constexpr int PL0 = SR * WP;
   // planes 16 (mod 32) floats apart: the two k-groups of a 32-lane LDS access fall on disjoint banks (stride 1)
   static constexpr int PLANE = S == 1 ? ((PL0 + 15) / 32) * 32 + 16 : PL0;
-  static constexpr int PP = PL0 / 4;                  // 16-byte pieces per plane
+  static constexpr int PP = PL0 / PB;                 // pieces per plane
   static constexpr int NQ = (PP + 63) / 64;           // DMA instructions per plane
-  static constexpr int IMG = KC * PLANE + 8;          // + zeros behind the last plane (right halo of its last row)
+  static constexpr int IMG = ((KC * PLANE + 3) / 4) * 4 + 8;   // + zeros behind the last plane (right halo of its last row)
   static constexpr int FRAGC = C4 * 9 * MT * 64;      // fragment floats per chunk
   static constexpr int NFQ = (FRAGC / 4 + 63) / 64;
   static constexpr int BUF = ((IMG + FRAGC + 255) / 256) * 256;
@@ -71,7 +72,8 @@ struct C3Geo {
   static constexpr int MASKF = CD * MROW;              // backward-data: the ReLU-mask band, staged in LDS by the loaders
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * 4;
   static constexpr size_t LDS_BYTES_BWD = (2 * (size_t)BUF + MASKF) * 4;
-  static_assert(W % 4 == 0 && CS % KC == 0 && PL0 % 4 == 0 && MROW % 4 == 0, "shape");
+  static constexpr bool VEC = (OH * OW) % 4 == 0 && MROW % 4 == 0;     // 16-byte output stores
+  static_assert(CS % KC == 0 && PL0 % PB == 0 && (KC * PLANE) % 4 == 0, "shape");
   static_assert(S == 2 || PLANE == PL0, "stride 1 reads the right halo of a plane's last row from the next plane's pad piece");
 };
 
@@ -112,8 +114,12 @@ __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
   const long nwork = nmine * G::NCH;              // work item k = (tile k / NCH, chunk k % NCH)
   // the zeros that never change: behind each buffer's last plane
   if (tid < 16) {
-    lds[G::KC * G::PLANE + (tid & 7)] = 0.f;
-    lds[G::BUF + G::KC * G::PLANE + (tid & 7)] = 0.f;
+    lds[G::IMG - 8 + (tid & 7)] = 0.f;
+    lds[G::BUF + G::IMG - 8 + (tid & 7)] = 0.f;
+    if (G::KC * G::PLANE < G::IMG - 8) {                  // (plane sizes that are not a multiple of 4 floats)
+      lds[G::KC * G::PLANE + (tid & 3)] = 0.f;
+      lds[G::BUF + G::KC * G::PLANE + (tid & 3)] = 0.f;
+    }
   }
   if (w >= G::NW) {
     // ------------------------------------------------------------------ loader waves (planes / fragment pieces dealt round robin)
@@ -122,9 +128,9 @@ __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q) {
       const int pi = q * 64 + lane;
-      const int r = pi / (G::WP / 4), i = pi - r * (G::WP / 4);
+      const int r = pi / (G::WP / G::PB), i = pi - r * (G::WP / G::PB);
       rrow[q] = (pi < G::PP) ? (i == 0 ? -100000 : r) : -200000;      // pad piece: zeros; beyond the plane: no lane
-      roff[q] = r * W + 4 * (i - 1);
+      roff[q] = r * W + G::PB * (i - 1);
     }
     auto dma = [&](long k) {
       const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
           if (rrow[q] > -200000) {
             const int y = y0 + rrow[q];
             const float* gsrc = (rrow[q] >= 0 && y >= 0 && y < H) ? sb + (long)c * H * W + roff[q] : p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(buf + c * G::PLANE + q * 256), 16, 0, 0);
+            if (G::PB == 4) __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(buf + c * G::PLANE + q * 256), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(buf + c * G::PLANE + q * 64), 4, 0, 0);
           }
         }
       }
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
     const bool ok = t < G::NT && pp < G::NPIX;
     const int px = ok ? pp : 0;
     const int r = px / G::OW, x = px - r * G::OW;
-    base[u] = g * G::PLANE + r * S * G::WP + x * S + 3;
+    base[u] = g * G::PLANE + r * S * G::WP + x * S + G::PB - 1;
   }
   f32x4 acc[G::TPW][G::MT];
 #pragma unroll
@@ -255,11 +262,12 @@ __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
           }
           float* __restrict__ o = p.out + o0 + (long)cd * G::OH * G::OW + p0;
           if (cd < CD) {
-            if (p0 + 3 < npix_ok) *reinterpret_cast<float4*>(o) = v;
-            else {                                             // the band's ragged end (partial last band)
+            if (G::VEC && p0 + 3 < npix_ok) *reinterpret_cast<float4*>(o) = v;
+            else {                                             // rows that are not 16-byte aligned / the band's ragged end
               if (p0 < npix_ok) o[0] = v.x;
               if (p0 + 1 < npix_ok) o[1] = v.y;
               if (p0 + 2 < npix_ok) o[2] = v.z;
+              if (p0 + 3 < npix_ok) o[3] = v.w;
             }
           }
           acc[u][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -534,6 +542,253 @@ int c3b_launch(const C3P& p, hipStream_t st) {
   return A2C_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient: dW[co][ci][ky][kx] = sum over samples and output pixels of dOut[co][oy][ox] * X[ci][S*oy+ky-1][S*ox+kx-1],
+// db[co] = sum dOut.  The same streaming skeleton with the PIXELS as the GEMM's K: one MFMA step = 4 consecutive
+// output pixels of a row; A operand = the input seen through the (ci, ky, kx) window of row n = ci*9 + ky*3 + kx
+// (16 such rows per tile, a chunk of KC input channels = ceil(9*KC/16) tiles), B operand = dOut (16 output channels per
+// tile).  D = [n][co]: a lane ends with 4 consecutive n of one co -- a 16-byte run of the (co, ci, ky, kx) gradient.
+// All accumulators (every chunk's tiles) stay in registers for the whole launch; the 8 computing waves split into
+// NCG groups over the output channels and 8/NCG groups over the pixel steps, each wave writes its partial sums to
+// its own slab once, at the end; a fixed-order reduction adds the slabs (deterministic).
+template <int CS, int CD, int H, int W, int S, int R, int KC, int NCG>
+struct C3WGeo {
+  static constexpr int NW = 8, NL = 2, NPG = NW / NCG;
+  static constexpr int NCH = CS / KC;
+  static constexpr int NTC = (KC * 9 + 15) / 16;       // n-tiles per chunk
+  static constexpr int MT = ((CD + 15) / 16 + NCG - 1) / NCG * NCG;
+  static constexpr int MTW = MT / NCG;
+  static constexpr int OH = (H - 1) / S + 1, OW = (W - 1) / S + 1;
+  static constexpr int NBAND = (OH + R - 1) / R;
+  static constexpr int OWP = (OW + 3) / 4 * 4;
+  static constexpr int KSR = OWP / 4, KS = R * KSR;    // MFMA steps per row / band
+  static constexpr int SR = (R - 1) * S + 3;
+  static constexpr int PB = W % 4 == 0 ? 4 : 1;
+  static constexpr int WP = W + PB;
+  static constexpr int PL0 = SR * WP, PLANE = PL0;
+  static constexpr int PP = PL0 / PB, NQ = (PP + 63) / 64;
+  static constexpr int XB = ((KC * PLANE + 3) / 4) * 4 + 64;      // (+ slack: the last step of a row may read past it)
+  static constexpr int DPB = OW % 4 == 0 ? 4 : 1;                 // dOut pieces: whole 16-byte runs when rows are 16-byte multiples
+  static constexpr int DPL0 = R * OWP;
+  static constexpr int DPLANE = (DPL0 - 4 + 31) / 32 * 32 + 4;    // 4 (mod 32) floats apart: channels spread over the banks
+  static constexpr int DPP = DPL0 / DPB, DNQ = (DPP + 63) / 64;
+  static constexpr int DB = CD * DPLANE;
+  static constexpr int K = CS * 9;
+  static constexpr long PER = (long)CD * K + CD;                  // floats per slab: dW | db
+  static constexpr size_t LDS_BYTES = (2 * (size_t)XB + 2 * (size_t)DB) * 4;
+  static_assert(CS % KC == 0 && NW % NCG == 0 && PL0 % PB == 0 && DPLANE >= DPL0 && DPLANE % 4 == 0, "shape");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+struct C3WP {
+  const float* x; long x_bs;          // layer input (B, CS, H, W)
+  const float* dout;                  // (B, CD, OH, OW) dense
+  float* slab;                        // [grid * NPG][CD*CS*9 + CD]
+  const float* zero;
+  int B;
+};
+
+__global__ __launch_bounds__(256) void c3w_reduce_kernel(const float* __restrict__ slab, int nslab, long per, long nW,
+                                                         float* __restrict__ dW, float* __restrict__ db) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += gridDim.x * 256L) {
+    float s = 0.f;
+    int z = 0;
+    for (; z + 8 <= nslab; z += 8) {       // 8 independent loads in flight, fixed summation order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = slab[(long)(z + u) * per + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; z < nslab; ++z) s += slab[(long)z * per + i];
+    if (i < nW) dW[i] = s;
+    else if (db) db[i - nW] = s;
+  }
+}
+
+template <int CS, int CD, int H, int W, int S, int R, int KC, int NCG>
+__global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
+  using G = C3WGeo<CS, CD, H, W, S, R, KC, NCG>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const long ntile = (long)p.B * G::NBAND;
+  long nmine = 0;
+  if ((long)blockIdx.x < ntile) nmine = (ntile - 1 - blockIdx.x) / gridDim.x + 1;
+  const long nwork = nmine * G::NCH;
+  float* __restrict__ xbuf = lds;                      // 2 x XB
+  float* __restrict__ dbuf = lds + 2 * G::XB;          // 2 x DB
+  // whatever the DMAs never write (pad columns, slack behind the planes) must read as finite numbers: zeros
+  for (int i = tid; i < 2 * G::XB + 2 * G::DB; i += 640) lds[i] = 0.f;
+  __syncthreads();
+  if (w >= G::NW) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = w - G::NW;
+    int roff[G::NQ], rrow[G::NQ];
+#pragma unroll
+    for (int q = 0; q < G::NQ; ++q) {
+      const int pi = q * 64 + lane;
+      const int r = pi / (G::WP / G::PB), i = pi - r * (G::WP / G::PB);
+      rrow[q] = (pi < G::PP) ? (i == 0 ? -100000 : r) : -200000;
+      roff[q] = r * W + G::PB * (i - 1);
+    }
+    int doff[G::DNQ], drow[G::DNQ];                   // dOut pieces: band row and source offset of this lane's piece
+#pragma unroll
+    for (int q = 0; q < G::DNQ; ++q) {
+      const int pi = q * 64 + lane;
+      const int f = pi * G::DPB;                       // first float of the piece in the (row, OWP) band image
+      const int r = f / G::OWP, x = f - r * G::OWP;
+      drow[q] = (pi < G::DPP) ? (x < G::OW ? r : -100000) : -200000;      // pad column: zeros
+      doff[q] = r * G::OW + x;
+    }
+    auto dma = [&](long k) {
+      const long it = k / G::NCH;
+      const long tile = blockIdx.x + it * gridDim.x;
+      const int ch = (int)(k % G::NCH);
+      const long b = tile / G::NBAND;
+      const int band = (int)(tile - b * G::NBAND);
+      const int y0 = band * R * S - 1;
+      float* __restrict__ xb = xbuf + (k & 1) * G::XB;
+      const float* __restrict__ sb = p.x + b * p.x_bs + ((long)ch * KC * H + y0) * W;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        if (c % G::NL != lw) continue;
+#pragma unroll
+        for (int q = 0; q < G::NQ; ++q) {
+          if (rrow[q] > -200000) {
+            const int y = y0 + rrow[q];
+            const float* gsrc = (rrow[q] >= 0 && y >= 0 && y < H) ? sb + (long)c * H * W + roff[q] : p.zero;
+            if (G::PB == 4) __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(xb + c * G::PLANE + q * 256), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(xb + c * G::PLANE + q * 64), 4, 0, 0);
+          }
+        }
+      }
+      if (ch == 0) {        // the band's dOut rows, all output channels
+        float* __restrict__ db_ = dbuf + (it & 1) * G::DB;
+        const float* __restrict__ ds = p.dout + (b * CD * G::OH + (long)band * R) * G::OW;
+#pragma unroll 1
+        for (int c = lw; c < CD; c += G::NL) {
+#pragma unroll
+          for (int q = 0; q < G::DNQ; ++q) {
+            if (drow[q] > -200000) {
+              const float* gsrc = (drow[q] >= 0 && band * R + drow[q] < G::OH) ? ds + (long)c * G::OH * G::OW + doff[q] : p.zero;
+              if (G::DPB == 4) __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(db_ + c * G::DPLANE + q * 256), 16, 0, 0);
+              else __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(db_ + c * G::DPLANE + q * 64), 4, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    if (nwork > 0) dma(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (long k = 0; k < nwork; ++k) {
+      if (k + 1 < nwork) dma(k + 1);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- computing waves
+  const int cg = w % NCG, pg = w / NCG;
+  int aoff[G::NTC];                                   // A operand: window offset of row n = nt*16 + j (ci_local, ky, kx) + pixel g
+#pragma unroll
+  for (int nt = 0; nt < G::NTC; ++nt) {
+    const int n = nt * 16 + j;
+    const int nn = n < KC * 9 ? n : 0;
+    const int cl = nn / 9, tap = nn - cl * 9;
+    aoff[nt] = cl * G::PLANE + (tap / 3) * G::WP + (tap % 3) + g * S + G::PB - 1;
+  }
+  int boff[G::MTW];                                   // B operand: dOut channel (cg*MTW + m)*16 + j, pixel g
+#pragma unroll
+  for (int m = 0; m < G::MTW; ++m) {
+    const int co = (cg * G::MTW + m) * 16 + j;
+    boff[m] = (co < CD ? co : 0) * G::DPLANE + g;
+  }
+  f32x4 acc[G::NCH][G::NTC][G::MTW];
+#pragma unroll
+  for (int c = 0; c < G::NCH; ++c)
+#pragma unroll
+    for (int nt = 0; nt < G::NTC; ++nt)
+#pragma unroll
+      for (int m = 0; m < G::MTW; ++m) acc[c][nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dbs[G::MTW];
+#pragma unroll
+  for (int m = 0; m < G::MTW; ++m) dbs[m] = 0.f;
+  __syncthreads();
+  for (long it = 0; it < nmine; ++it) {
+    const float* __restrict__ dimg = dbuf + (it & 1) * G::DB;
+#pragma unroll
+    for (int ch = 0; ch < G::NCH; ++ch) {
+      const float* __restrict__ ximg = xbuf + ((it * G::NCH + ch) & 1) * G::XB;
+      int r = 0, xq = pg;
+      while (xq >= G::KSR) { xq -= G::KSR; ++r; }
+      for (int s = pg; s < G::KS; s += G::NPG) {
+        const int xo = r * S * G::WP + xq * 4 * S, dofs = r * G::OWP + xq * 4;
+        float av[G::NTC], bv[G::MTW];
+#pragma unroll
+        for (int nt = 0; nt < G::NTC; ++nt) av[nt] = ximg[aoff[nt] + xo];
+#pragma unroll
+        for (int m = 0; m < G::MTW; ++m) bv[m] = dimg[boff[m] + dofs];
+#pragma unroll
+        for (int nt = 0; nt < G::NTC; ++nt)
+#pragma unroll
+          for (int m = 0; m < G::MTW; ++m) acc[ch][nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv[m], acc[ch][nt][m], 0, 0, 0);
+        if (ch == 0) {
+#pragma unroll
+          for (int m = 0; m < G::MTW; ++m) dbs[m] += bv[m];
+        }
+        xq += G::NPG;
+        while (xq >= G::KSR) { xq -= G::KSR; ++r; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- this wave's partial sums -> its slab (dW as [co][ci*9 + tap], then db)
+  float* __restrict__ sl = p.slab + ((long)blockIdx.x * G::NPG + pg) * G::PER;
+#pragma unroll
+  for (int m = 0; m < G::MTW; ++m) {
+    const int co = (cg * G::MTW + m) * 16 + j;
+#pragma unroll
+    for (int ch = 0; ch < G::NCH; ++ch)
+#pragma unroll
+      for (int nt = 0; nt < G::NTC; ++nt) {
+        const int n = nt * 16 + 4 * g;                 // 4 consecutive window rows of this chunk
+        if (co < CD && n < KC * 9)
+          *reinterpret_cast<float4*>(sl + (long)co * G::K + ch * KC * 9 + n) =
+              make_float4(acc[ch][nt][m][0], acc[ch][nt][m][1], acc[ch][nt][m][2], acc[ch][nt][m][3]);
+      }
+    float v = dbs[m];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0 && co < CD) sl[(long)CD * G::K + co] = v;
+  }
+}
+
+template <int CS, int CD, int H, int W, int S, int R, int KC, int NCG>
+int c3w_launch(const C3WP& p0, float* dW, float* db, size_t ws_bytes, hipStream_t st, size_t* need) {
+  using G = C3WGeo<CS, CD, H, W, S, R, KC, NCG>;
+  const void* k = (const void*)c3w_kernel<CS, CD, H, W, S, R, KC, NCG>;
+  static int cus = 0;
+  if (!cus) {
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess) return A2C_ERR_LAUNCH;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const long total = (long)p0.B * G::NBAND;
+  const int grid = (int)(total < cus ? total : cus);
+  const size_t bytes = (size_t)grid * G::NPG * G::PER * 4;
+  if (need) { *need = (size_t)cus * G::NPG * G::PER * 4; return A2C_OK; }
+  if (ws_bytes < bytes) return A2C_ERR_WORKSPACE;
+  hipLaunchKernelGGL((c3w_kernel<CS, CD, H, W, S, R, KC, NCG>), dim3(grid), dim3(640), G::LDS_BYTES, st, p0);
+  if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
+  hipLaunchKernelGGL(c3w_reduce_kernel, dim3(a2c_grid_1d(G::PER, 256)), dim3(256), 0, st, (const float*)p0.slab, grid * G::NPG,
+                     G::PER, (long)CD * G::K, dW, db);
+  if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
+  return A2C_OK;
+}
+
 const float* zero_page() {
   static float* z = nullptr;
   static std::once_flag once;
@@ -581,7 +836,10 @@ bool c3_supported(const a2c_conv_desc* d, int kind) {
   static const bool off = getenv("A2C_NO_C3") != nullptr && getenv("A2C_NO_C3")[0] == '1';
   if (off) return false;
   if (kind == 1 && d->stride == 2) return c3b_shape(d);
-  if (d->ks != 3 || d->pad != 1 || d->H != 84 || d->W != 84) return false;
+  if (d->ks != 3 || d->pad != 1) return false;
+  if (kind == 0 && d->stride == 2 && d->H == 42 && d->W == 42) return (d->Cin == 32 && d->Cout == 64) || (d->Cin == 24 && d->Cout == 32);
+  if (kind == 0 && d->stride == 2 && d->H == 21 && d->W == 21) return d->Cin == 32 && d->Cout == 48;
+  if (d->H != 84 || d->W != 84) return false;
   if (kind == 0) {
     if (d->stride == 1) return (d->Cin == 4 && d->Cout == 16) || (d->Cin == 16 && d->Cout == 24);
     if (d->stride == 2) return (d->Cin == 24 && d->Cout == 32) || (d->Cin == 16 && d->Cout == 24);
@@ -624,10 +882,13 @@ int c3_fwd(const a2c_conv_desc* d, const float* in, long in_bs, const float* fra
            long out_bs, int B, hipStream_t st) {
   C3P p{in, in_bs, frag, bias, nullptr, out, out_bs, zero_page(), B, relu, g_c3_dbg};
   if (!p.zero) return A2C_ERR_LAUNCH;
-  if (d->stride == 1 && d->Cin == 4) return c3_launch<4, 16, 84, 84, 1, 12, false>(p, st);
-  if (d->stride == 1 && d->Cin == 16) return c3_launch<16, 24, 84, 84, 1, 12, false>(p, st);
-  if (d->stride == 2 && d->Cin == 24) return c3_launch<24, 32, 84, 84, 2, 6, false>(p, st);
-  if (d->stride == 2 && d->Cin == 16) return c3_launch<16, 24, 84, 84, 2, 6, false>(p, st);
+  if (d->stride == 1 && d->H == 84 && d->Cin == 4) return c3_launch<4, 16, 84, 84, 1, 12, false>(p, st);
+  if (d->stride == 1 && d->H == 84 && d->Cin == 16) return c3_launch<16, 24, 84, 84, 1, 12, false>(p, st);
+  if (d->stride == 2 && d->H == 84 && d->Cin == 24) return c3_launch<24, 32, 84, 84, 2, 6, false>(p, st);
+  if (d->stride == 2 && d->H == 84 && d->Cin == 16) return c3_launch<16, 24, 84, 84, 2, 6, false>(p, st);
+  if (d->stride == 2 && d->H == 42 && d->Cin == 32) return c3_launch<32, 64, 42, 42, 2, 11, false>(p, st);
+  if (d->stride == 2 && d->H == 42 && d->Cin == 24) return c3_launch<24, 32, 42, 42, 2, 11, false>(p, st);
+  if (d->stride == 2 && d->H == 21 && d->Cin == 32) return c3_launch<32, 48, 21, 21, 2, 11, false>(p, st);
   return A2C_ERR_ARG;
 }
 
@@ -641,4 +902,51 @@ int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, co
   if (d->stride == 2 && d->H == 42 && d->Cin == 32) return c3b_launch<64, 32, 21, 21, 11, 8>(p, st);
   if (d->stride == 2 && d->H == 42 && d->Cin == 24) return c3b_launch<32, 24, 21, 21, 11, 8>(p, st);
   return A2C_ERR_ARG;
+}
+
+// weight gradient: instantiations and their workspace
+#define C3W_CASES(X)                                                                           \
+  X(4, 16, 84, 84, 1, 8, 4, 1)   /* conv1 of both models                                    */ \
+  X(16, 24, 84, 84, 1, 4, 16, 1) /* ConvModel conv2                                         */ \
+  X(24, 32, 84, 84, 2, 6, 8, 2)  /* ConvModel conv3                                         */ \
+  X(32, 64, 42, 42, 2, 7, 8, 4)  /* ConvModel conv4                                         */ \
+  X(16, 24, 84, 84, 2, 6, 8, 1)  /* GRUModel conv2                                          */ \
+  X(24, 32, 42, 42, 2, 7, 8, 2)  /* GRUModel conv3                                          */
+
+bool c3w_supported(const a2c_conv_desc* d) {
+  static const bool off = (getenv("A2C_NO_C3") != nullptr && getenv("A2C_NO_C3")[0] == '1') ||
+                          (getenv("A2C_NO_C3W") != nullptr && getenv("A2C_NO_C3W")[0] == '1');
+  static const bool all = getenv("A2C_C3W_ALL") != nullptr && getenv("A2C_C3W_ALL")[0] == '1';
+  if (off || d->ks != 3 || d->pad != 1) return false;
+  // Measured against conv.hip's wgrad_kernel at N = 4096 (tools/conv3_check.py): this kernel wins on the first layer
+  // (4 -> 16: 0.92 vs 1.01 ms) and on ConvModel's conv4 (32 -> 64 @42: 1.29 vs 1.55 ms); the 84-wide 16/24-channel
+  // layers are matrix-bound in both (67 TF with a quarter of the 24-channel tiles empty) and stay where they were.
+  if (!all && !((d->Cin == 4 && d->Cout == 16) || (d->Cin == 32 && d->Cout == 64 && d->H == 42))) return false;
+#define C3W_MATCH(cs, cd, h, w_, s_, r, kc, ncg) if (d->Cin == cs && d->Cout == cd && d->H == h && d->W == w_ && d->stride == s_) return true;
+  C3W_CASES(C3W_MATCH)
+#undef C3W_MATCH
+  return false;
+}
+
+static int c3w_dispatch(const a2c_conv_desc* d, const C3WP& p, float* dW, float* db, size_t ws_bytes, hipStream_t st, size_t* need) {
+#define C3W_RUN(cs, cd, h, w_, s_, r, kc, ncg) \
+  if (d->Cin == cs && d->Cout == cd && d->H == h && d->W == w_ && d->stride == s_) return c3w_launch<cs, cd, h, w_, s_, r, kc, ncg>(p, dW, db, ws_bytes, st, need);
+  C3W_CASES(C3W_RUN)
+#undef C3W_RUN
+  return A2C_ERR_ARG;
+}
+
+size_t c3w_ws_bytes(const a2c_conv_desc* d) {
+  if (!c3w_supported(d)) return 0;
+  size_t need = 0;
+  C3WP p{};
+  p.B = 1;
+  return c3w_dispatch(d, p, nullptr, nullptr, 0, nullptr, &need) == A2C_OK ? need : 0;
+}
+
+int c3w_bwd_weight(const a2c_conv_desc* d, const float* in, long in_bs, const float* dout, float* dW, float* db, int B, void* ws,
+                   size_t ws_bytes, hipStream_t st) {
+  C3WP p{in, in_bs, dout, (float*)ws, zero_page(), B};
+  if (!p.zero) return A2C_ERR_LAUNCH;
+  return c3w_dispatch(d, p, dW, db, ws_bytes, st, nullptr);
 }

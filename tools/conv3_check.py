@@ -62,7 +62,20 @@ for li, (Cin, H, W, Cout, S, has_bwd) in enumerate(LAYERS):
         ops.conv_bwd_data(d, dout.to(dev), wb, mask.to(dev), din, B)
         refb = F.conv_transpose2d(dout, wt, stride=S, padding=1, output_padding=(H + 2 - 3) % S) * (mask > 0)
         err_b = float((din.cpu() - refb).abs().max())
-    line = f"L{li} {Cin}->{Cout} {H}x{W} s{S}: max|err| fwd {err_f:.2e} bwd_data {err_b:.2e}"
+    # weight gradient against autograd
+    xg = x.clone().requires_grad_(False)
+    wt_g = wt.clone().requires_grad_(True)
+    bias_g = bias.clone().requires_grad_(True)
+    dout_w = torch.rand(B, Cout, d.OH, d.OW, generator=g) - 0.5
+    F.conv2d(xg, wt_g, bias_g, stride=S, padding=1).backward(dout_w)
+    dW = torch.empty(Cout, Cin, 3, 3, device=dev)
+    dbv = torch.empty(Cout, device=dev)
+    ws = torch.empty(max(ops.conv_bwd_weight_ws_bytes(d, B), 4) // 4, device=dev)
+    ops.conv_bwd_weight(d, xd.data_ptr(), Cin * H * W, dout_w.to(dev), dW, dbv, B, ws)
+    sc = float(wt_g.grad.abs().max())
+    err_w = float((dW.cpu() - wt_g.grad).abs().max()) / sc
+    err_db = float((dbv.cpu() - bias_g.grad).abs().max()) / float(bias_g.grad.abs().max())
+    line = f"L{li} {Cin}->{Cout} {H}x{W} s{S}: max|err| fwd {err_f:.2e} bwd_data {err_b:.2e} wgrad(rel) {err_w:.2e} db(rel) {err_db:.2e}"
     # ---- timings
     for Bt in (256, 4096):
         xb = torch.rand(Bt, Cin, H, W, device=dev) - 0.3
@@ -90,5 +103,13 @@ for li, (Cin, H, W, Cout, S, has_bwd) in enumerate(LAYERS):
                 t = buf.cpu().tolist()
                 if t[3]:
                     line += f" [wg0: compute {t[0] / 100:.0f} us, epilogue {t[1] / 100:.0f} us, barrier wait {t[2] / 100:.0f} us over {t[3]} chunks]"
+        if Bt == 4096:
+            do = torch.rand(Bt, Cout, d.OH, d.OW, device=dev) - 0.5
+            dWt = torch.empty(Cout, Cin, 3, 3, device=dev)
+            dbt = torch.empty(Cout, device=dev)
+            wst = torch.empty(max(ops.conv_bwd_weight_ws_bytes(d, Bt), 4) // 4, device=dev)
+            ms = timeit(lambda: ops.conv_bwd_weight(d, xb.data_ptr(), Cin * H * W, do, dWt, dbt, Bt, wst), 3)
+            by = 4.0 * Bt * (Cin * H * W + Cout * d.OH * d.OW)
+            line += f" | wgrad B={Bt}: {ms * 1e3:.1f} us {fl / ms / 1e9:.1f} TF {by / ms / 1e6:.0f} GB/s"
         del xb, ob
     print(line, flush=True)

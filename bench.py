@@ -213,9 +213,13 @@ def step_alg_flops(A):
     return 2 * 16 * 400 * 256 + 2 * 32 * 81 * 256 + 2 * (A + 1) * 2592
 
 
-def step_alg_bytes(u8_frame=False, stash=True):
+def step_alg_bytes(u8_frame=False, stash=True, ring=False):
     """per env-step: 3 planes of the previous state + the new frame in (fp32 or uint8), the new state out
-    (+ the conv1 / conv2 activations stashed for the update: 16x20x20 + 32x9x9 floats)"""
+    (+ the conv1 / conv2 activations stashed for the update: 16x20x20 + 32x9x9 floats).  ring: the persistent ring
+    kernel keeps the state in LDS -- HBM sees the state row and the stash going out, nothing coming in (the frame
+    crosses PCIe)"""
+    if ring:
+        return 4 * 84 * 84 * 4 + (4 * (6400 + 2592) if stash else 0)
     return 3 * 84 * 84 * 4 + (84 * 84 if u8_frame else 84 * 84 * 4) + 4 * 84 * 84 * 4 + (4 * (6400 + 2592) if stash else 0)
 
 
@@ -417,6 +421,16 @@ def site_roofline(name, site, conv_layers, batch, launches_note=""):
     """roofline entry of one conv launch site: algorithmic in+out bytes and flops / its average HIP-event duration"""
     lname, _, what = name.partition(".")
     out = dict(site=name, avg_ms=round(site["avg_ms"], 4), launches=site["launches"])
+    if lname == "linear":            # "linear.<pass> NxK": a dense fp32 GEMM over `batch` rows
+        try:
+            n_, k_ = (int(v) for v in what.split(" ")[1].split("x"))
+            tf = 2.0 * batch * n_ * k_ / (site["avg_ms"] * 1e-3) / 1e12
+            out.update(batch=batch, tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / F32_PEAK_TFLOPS, 4))
+            if batch <= 64:          # skinny: the weights are the traffic
+                gbs = 4.0 * n_ * k_ / (site["avg_ms"] * 1e-3) / 1e9
+                out.update(weight_GBs=round(gbs, 1), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
+        except (ValueError, IndexError):
+            pass
     if lname in conv_layers:
         d = conv_layers[lname].d
         sec = site["avg_ms"] * 1e-3
@@ -545,7 +559,7 @@ def main():
         # env threads: below that the hand-shake of 256 envs serialises behind one thread (the threads sleep-poll
         # between rollouts, so over-subscription costs little while another rank's rollout is not running)
         per_rank = max(4, (usable_cpus() - 2) // max(shard.world, 1))
-        n_workers = max(1, min(12 if args.env_workers == "native" else 48, per_rank))
+        n_workers = max(1, min(14 if args.env_workers == "native" else 48, per_rank))
     print(f"[bench] rank {shard.rank}/{shard.world}: env_workers={n_workers} ({args.env_workers}), usable_cpus={usable_cpus()}",
           file=sys.stderr)
 
@@ -635,11 +649,14 @@ def main():
             launches = 1 if zero_copy else T + 1
             us = rollout_ms * 1e3 / launches
             fl = step_alg_flops(A) * b.n_envs * (T + 1) / launches
-            by = (step_alg_bytes(u8_frame=args.ingest != "device-tape") - (84 * 84 - FRAME_BYTES[args.transport] if args.ingest != "device-tape" else 0)) \
+            ring = zero_copy and b.n_envs <= torch.cuda.get_device_properties(dev).multi_processor_count and \
+                os.environ.get("A2C_NO_RING") != "1"
+            by = (step_alg_bytes(u8_frame=args.ingest != "device-tape", ring=ring) -
+                  (0 if ring else (84 * 84 - FRAME_BYTES[args.transport] if args.ingest != "device-tape" else 0))) \
                 * b.n_envs * (T + 1) / launches
             tf = fl / (us * 1e-6) / 1e12
-            name = ("a3c_step_kernel<persistent> = a2c_a3c_rollout (1 launch = %d steps x %d envs, paced by the host env "
-                    "workers and the PCIe frame reads)" % (T + 1, b.n_envs)) if zero_copy else \
+            name = ("%s = a2c_a3c_rollout (1 launch = %d steps x %d envs, paced by the host env workers' turn-around)"
+                    % ("a3c_ring_kernel" if ring else "a3c_step_kernel<persistent>", T + 1, b.n_envs)) if zero_copy else \
                    f"a3c_step_kernel (B={b.n_envs}, {T + 1} launches/rollout)"
             out["roofline"] = dict(kernel=name, bound="mfma", achieved=round(tf, 2), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
                                    frac=round(tf / F32_PEAK_TFLOPS, 4), traffic=None, avg_launch_us=round(us, 2),
@@ -678,7 +695,8 @@ def main():
             if "roofline" in out and out["roofline"].get("traffic") is None and args.workload == "a3c" and N == 32768 \
                     and os.path.exists(tfile):
                 tj = json.load(open(tfile))
-                k2 = ("a3c_rollout" if zero_copy else "a3c_step") if out["roofline"]["kernel"].startswith("a3c_step") else key
+                k2 = (("a3c_ring" if out["roofline"]["kernel"].startswith("a3c_ring") else "a3c_rollout") if zero_copy else "a3c_step") \
+                    if out["roofline"]["kernel"].startswith("a3c_") else key
                 if k2 in tj:
                     out["roofline"]["traffic"] = round(tj[k2]["hbm_bytes_per_launch"])
                     out["roofline"]["traffic_source"] = f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KB)"

@@ -2585,13 +2585,13 @@ struct WgradPlan { SrcTile t; int OWp, PLANEo, MT, KTW, grid, run, rs, pf, ex; s
 
 // prefetching instantiations: <MT, KTW, RS, NI, ND>
 #define WGRAD_PF_A 1, 3, true, 4, 16, true
-#define WGRAD_PF_B 2, 9, true, 8, 8, true
+/* (the <2, 9, true, 8, 8, true> prefetching instance of the 84-wide 16-channel layers is gone: it needed 20 B/lane of
+ * scratch at two workgroups per CU; those layers run conv3.hip's c3w_kernel, the RS variant below is their fallback) */
 #define WGRAD_PF_C 2, 4, false, 12, 8, true
 #define WGRAD_PF_D 2, 4, false, 14, 8, true, 2, 1       /* 42-wide input (8-B slots), 21-wide dOut (4-B slots) */
 #define WGRAD_VARIANTS(X)                                                                                      \
   if (pl.pf == 2) { X(WGRAD_PF_D); }                                                                           \
   else if (pl.pf && pl.KTW == 3) { X(WGRAD_PF_A); }                                                            \
-  else if (pl.pf && pl.KTW == 9) { X(WGRAD_PF_B); }                                                            \
   else if (pl.pf) { X(WGRAD_PF_C); }                                                                           \
   else if (pl.rs && pl.KTW == 3) { X(1, 3, true, 0, 0, true); }                                                \
   else if (pl.rs) { X(2, 9, true, 0, 0, true); }                                                               \

@@ -452,6 +452,7 @@ __global__ __launch_bounds__(640) void c3b_kernel(C3P p) {
           acc[u][3][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s01, wv[6][m], acc[u][3][m], 0, 0, 0);
           acc[u][3][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s00, wv[8][m], acc[u][3][m], 0, 0, 0);
         }
+        if (G::MT > 1) __builtin_amdgcn_sched_barrier(0);      // (registers: keep the next position's reads behind these MFMAs)
       }
     }
     C3_TS(0);
@@ -472,6 +473,8 @@ __global__ __launch_bounds__(640) void c3b_kernel(C3P p) {
 #pragma unroll
         for (int m = 0; m < G::MT; ++m) {
           const int ci = m * 16 + j;
+          const float* __restrict__ mc = mb + ci * G::MROW;                               // this channel's mask band (LDS)
+          float* __restrict__ oc = p.out + o0 + ((long)ci * G::H + 2 * q0) * G::W;          // ... and its dX band (HBM)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int c = c0 + 2 * h;
@@ -479,29 +482,27 @@ __global__ __launch_bounds__(640) void c3b_kernel(C3P p) {
             const bool okA = ci < CI && c < npix_ok, okB = ci < CI && c + 1 < npix_ok, split = pc + 1 >= WO;
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
-              const int lrow = (2 * qr + py) * G::W;              // band-relative row offset
-              const int la = ci * G::MROW + lrow + 2 * pc, lbo = split ? ci * G::MROW + lrow + 2 * G::W : la + 2;
-              const long offA = o0 + ((long)ci * G::H + 2 * q0) * G::W + lrow + 2 * pc;
-              const long offB = split ? o0 + ((long)ci * G::H + 2 * q0) * G::W + lrow + 2 * G::W : offA + 2;
+              const int la = (2 * qr + py) * G::W + 2 * pc;                               // band-relative offsets of the two pixels
+              const int lb = split ? (2 * qr + py + 2) * G::W : la + 2;
               float4 v = make_float4(acc[u][py * 2][m][2 * h], acc[u][py * 2 + 1][m][2 * h], acc[u][py * 2][m][2 * h + 1],
                                      acc[u][py * 2 + 1][m][2 * h + 1]);
               if (p.mask != nullptr) {
                 if (okA) {
-                  const float2 q2 = *reinterpret_cast<const float2*>(mb + la);
+                  const float2 q2 = *reinterpret_cast<const float2*>(mc + la);
                   if (!(q2.x > 0.f)) v.x = 0.f;
                   if (!(q2.y > 0.f)) v.y = 0.f;
                 }
                 if (okB) {
-                  const float2 q2 = *reinterpret_cast<const float2*>(mb + lbo);
+                  const float2 q2 = *reinterpret_cast<const float2*>(mc + lb);
                   if (!(q2.x > 0.f)) v.z = 0.f;
                   if (!(q2.y > 0.f)) v.w = 0.f;
                 }
               }
               if (okA) {
-                if (okB && !split) *reinterpret_cast<float4*>(p.out + offA) = v;
+                if (okB && !split) *reinterpret_cast<float4*>(oc + la) = v;
                 else {
-                  *reinterpret_cast<float2*>(p.out + offA) = make_float2(v.x, v.y);
-                  if (okB) *reinterpret_cast<float2*>(p.out + offB) = make_float2(v.z, v.w);
+                  *reinterpret_cast<float2*>(oc + la) = make_float2(v.x, v.y);
+                  if (okB) *reinterpret_cast<float2*>(oc + lb) = make_float2(v.z, v.w);
                 }
               }
             }
@@ -919,9 +920,10 @@ bool c3w_supported(const a2c_conv_desc* d) {
   static const bool all = getenv("A2C_C3W_ALL") != nullptr && getenv("A2C_C3W_ALL")[0] == '1';
   if (off || d->ks != 3 || d->pad != 1) return false;
   // Measured against conv.hip's wgrad_kernel at N = 4096 (tools/conv3_check.py): this kernel wins on the first layer
-  // (4 -> 16: 0.92 vs 1.01 ms) and on ConvModel's conv4 (32 -> 64 @42: 1.29 vs 1.55 ms); the 84-wide 16/24-channel
-  // layers are matrix-bound in both (67 TF with a quarter of the 24-channel tiles empty) and stay where they were.
-  if (!all && !((d->Cin == 4 && d->Cout == 16) || (d->Cin == 32 && d->Cout == 64 && d->H == 42))) return false;
+  // (4 -> 16: 0.92 vs 1.01 ms) and on ConvModel's conv4 (32 -> 64 @42: 1.29 vs 1.55 ms), ties on the 84-wide
+  // 16 -> 24 layers (2.87-2.95 vs 3.00 ms, 1.15 vs 1.11 ms: matrix-bound in both, 67 TF with a quarter of the 24-channel
+  // tiles empty -- and the generic instance for them spilled registers), and loses on the 24 -> 32 layers, which stay.
+  if (!all && d->Cin == 24) return false;
 #define C3W_MATCH(cs, cd, h, w_, s_, r, kc, ncg) if (d->Cin == cs && d->Cout == cd && d->H == h && d->W == w_ && d->stride == s_) return true;
   C3W_CASES(C3W_MATCH)
 #undef C3W_MATCH

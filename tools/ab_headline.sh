@@ -1,10 +1,11 @@
 #!/bin/bash
-# headline A/B on ONE box: old persistent kernel vs ring kernel, several env thread counts
-for nw in 8 12 16; do
-  for mode in ring noring; do
-    if [ $mode = noring ]; then export A2C_NO_RING=1; else unset A2C_NO_RING; fi
-    python bench.py --steps 60 --warmup 5 --sustain-steps 0 --no-configs --no-cpu-baseline --no-secondary --no-kernel-timers --n-workers $nw 2>/dev/null | python -c "
+# headline on ONE box, three repeats per setting: ring kernel at 8 / 12 / 14 env threads, old persistent kernel at 12
+for rep in 1 2 3; do
+for cfg in "ring 8" "ring 12" "ring 14" "noring 12"; do
+  set -- $cfg
+  if [ $1 = noring ]; then export A2C_NO_RING=1; else unset A2C_NO_RING; fi
+  python bench.py --steps 100 --warmup 5 --sustain-steps 0 --no-configs --no-cpu-baseline --no-secondary --no-kernel-timers --n-workers $2 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$mode', 'threads', $nw, 'value', d['value'], 'ms', d['ms_per_step'])"
-  done
-done
+d=json.loads(sys.stdin.read()); print('$1', 'threads', $2, 'value', d['value'], 'ms', d['ms_per_step'])"
+done; done
+nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; lscpu | grep -i "numa\|model name\|socket" | head

@@ -399,6 +399,19 @@ int a2c_conv2d_fwd(const a2c_conv_desc *d, const float *in, int64_t in_bstride,
  * (B,Cin,H,W) activation that fed this conv (the ReLU below it)                          */
 int a2c_conv2d_bwd_data(const a2c_conv_desc *d, const float *dout, const float *wprep_bwd,
                         const float *mask, float *din, int B, a2c_stream_t stream);
+/* The ReLU mask as SIGN WORDS.  For the 3x3 layers of the conv-stack models the forward can leave, next to `out`, one
+ * bit per activation: bit (x & 31) of word signs[b*signs_bstride + (c*OH + y)*ceil(OW/32) + (x >> 5)] = (out[b][c][y][x] > 0).
+ * a2c_conv2d_bwd_data_signs of the layer ABOVE takes them in place of the float mask (din *= bit): 1/32 of the mask's
+ * HBM reads, same result bit for bit.  a2c_conv2d_sign_words(d) = words per sample of d's output, 0 when d's forward
+ * cannot write them (then use a2c_conv2d_fwd and the float mask); a2c_conv2d_bwd_data_signs_supported(d) = 1 when d's
+ * backward-data can read the sign words of ITS INPUT ([Cin][H][ceil(W/32)] words per sample); signs == NULL: no mask. */
+int64_t a2c_conv2d_sign_words(const a2c_conv_desc *d);
+int a2c_conv2d_fwd_signs(const a2c_conv_desc *d, const float *in, int64_t in_bstride, const float *wprep_fwd,
+                         const float *bias, int relu, float *out, int64_t out_bstride, uint32_t *signs,
+                         int64_t signs_bstride, int B, a2c_stream_t stream);
+int a2c_conv2d_bwd_data_signs_supported(const a2c_conv_desc *d);
+int a2c_conv2d_bwd_data_signs(const a2c_conv_desc *d, const float *dout, const float *wprep_bwd, const uint32_t *signs,
+                              int64_t signs_bstride, float *din, int B, a2c_stream_t stream);
 /* a2c_conv2d_bwd_data of layer d2 FUSED with a2c_conv2d_bwd_weight of the layer d1 below it, for the case where
  * nothing but d1's weight gradient reads d2's input gradient (d1 = first conv of the stack: models.py:196-215, its
  * input needs no gradient): the masked input gradient (the `din` of the call above) is assembled band by band

@@ -114,6 +114,10 @@ SIGNATURES = {
     "a2c_conv2d_prep_weights": (c_int, [PD, c_int, P, P, P]),
     "a2c_conv2d_fwd": (c_int, [PD, P, c_int64, P, P, c_int, P, c_int64, c_int, P]),
     "a2c_conv2d_bwd_data": (c_int, [PD, P, P, P, P, c_int, P]),
+    "a2c_conv2d_sign_words": (c_int64, [PD]),
+    "a2c_conv2d_fwd_signs": (c_int, [PD, P, c_int64, P, P, c_int, P, c_int64, P, c_int64, c_int, P]),
+    "a2c_conv2d_bwd_data_signs_supported": (c_int, [PD]),
+    "a2c_conv2d_bwd_data_signs": (c_int, [PD, P, P, P, c_int64, P, c_int, P]),
     "a2c_conv2d_bwd_weight_ws_bytes": (c_size_t, [PD, c_int]),
     "a2c_conv2d_bwd_data_w1_ws_bytes": (c_size_t, [PD, PD, c_int]),
     "a2c_conv2d_bwd_data_w1": (c_int, [PD, P, P, P, PD, P, c_int64, P, P, c_int, P, c_size_t, P]),

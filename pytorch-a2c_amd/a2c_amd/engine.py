@@ -117,11 +117,37 @@ class ConvLayer:
         if self.need_bwd_data:
             ops.conv_prep(self.d, 1, weight, self.wb, st)
 
-    def fwd(self, in_ptr, in_bstride, bias, out, B, st, relu=True, out_bstride=None):
-        """out: (B, Cout, OH, OW) tensor, or a raw device address + out_bstride (rows of a larger buffer)"""
+    def fwd(self, in_ptr, in_bstride, bias, out, B, st, relu=True, out_bstride=None, signs=None):
+        """out: (B, Cout, OH, OW) tensor, or a raw device address + out_bstride (rows of a larger buffer).
+        signs = (device address, row stride in words): also leave the sign words of the output there (sign_words > 0)"""
         in_ptr, in_bstride = self._input(in_ptr, in_bstride, B, bias.device, st)
         with ops.span(self.name + ".fwd"):
+            optr = out if isinstance(out, int) else out.data_ptr()
+            obs = self.d.Cout * self.d.OH * self.d.OW if out_bstride is None else out_bstride
+            if signs is not None and in_bstride % 4 == 0 and in_ptr % 16 == 0 and obs % 4 == 0 and optr % 16 == 0:
+                ops.conv_fwd_signs(self.d, in_ptr, in_bstride, self.wf, bias, relu, out, signs[0], signs[1], B, st,
+                                   out_bstride=out_bstride)
+                return True
             ops.conv_fwd(self.d, in_ptr, in_bstride, self.wf, bias, relu, out, B, st, out_bstride=out_bstride)
+        return False
+
+    @property
+    def sign_words(self):
+        """uint32 words per sample of the output's sign-word image; 0: this layer's forward cannot write one"""
+        if self.padded:
+            return 0
+        if not hasattr(self, "_sw"):
+            self._sw = ops.conv_sign_words(self.d)
+        return self._sw
+
+    @property
+    def bwd_reads_signs(self):
+        if not hasattr(self, "_brs"):
+            # stride 2 only: measured (tools/conv3_check.py, N = 4096) the staged sign-word kernels beat the float-mask
+            # ones by 12-41 % on the stride-2 layers and lose 15 % on the 84-wide stride-1 layer (16 <- 24)
+            self._brs = ((not self.padded) and self.need_bwd_data and self.d.stride == 2
+                         and ops.conv_bwd_data_signs_supported(self.d))
+        return self._brs
 
     def bwd_weight(self, in_ptr, in_bstride, dout, dW, db, B, ws, st):
         in_ptr, in_bstride = self._input(in_ptr, in_bstride, B, dout.device, st)
@@ -136,11 +162,15 @@ class ConvLayer:
         if self.padded:
             dW.copy_(dst[:, :self.cin])
 
-    def bwd_data(self, dout, mask, din, B, st):
+    def bwd_data(self, dout, mask, din, B, st, signs=None):
+        """mask: the float activation below; signs: its sign words (B, words) when its forward left them (preferred)"""
         if self.padded:
             raise NotImplementedError("a2c_amd: input gradient of a channel-padded conv layer (only first layers are padded)")
         with ops.span(self.name + ".bwd_data"):
-            ops.conv_bwd_data(self.d, dout, self.wb, mask, din, B, st)
+            if signs is not None:
+                ops.conv_bwd_data_signs(self.d, dout, self.wb, signs, din, B, st)
+            else:
+                ops.conv_bwd_data(self.d, dout, self.wb, mask, din, B, st)
 
 
 def linear_fwd(ws, x_ptr, ldx, W, b, out, M, st, relu=False):

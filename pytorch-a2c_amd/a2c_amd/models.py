@@ -422,22 +422,50 @@ class _ConvStackNet(_HipNet):
         if hasattr(self, "gru"):
             self._gru_prep(st)
 
-    def _convs_fwd(self, x_ptr, bstride, B, ws, st, stash=None):
+    def _sign_layers(self):
+        """{i: words per sample}: layers whose forward leaves the SIGN WORDS of its output (one bit per activation) for the
+        backward-data of layer i + 1, which then reads those instead of the float activation as its ReLU mask
+        (a2c_conv2d_fwd_signs / a2c_conv2d_bwd_data_signs): 1/32 of the mask's HBM reads in the update."""
+        sl = getattr(self, "_sign_l", None)
+        if sl is None:
+            sl = {}
+            if os.environ.get("A2C_NO_SIGNS") != "1":
+                for i in range(len(self._cl) - 1):
+                    if self._cl[i].sign_words and self._cl[i + 1].bwd_reads_signs:
+                        sl[i] = self._cl[i].sign_words
+            self._sign_l = sl
+            self._signs_ok = {}
+        return sl
+
+    def _convs_fwd(self, x_ptr, bstride, B, ws, st, stash=None, train=False):
         """-> [(ptr, batch stride in floats)] of every layer's activation.  ``stash`` = (bufs, row0, row_stride): the
         activations of sample b go to row row0 + b*row_stride of the update's (N, ...) buffers instead of the
-        per-tag workspace (a rollout step of all envs fills rows slot*T + t)."""
+        per-tag workspace (a rollout step of all envs fills rows slot*T + t).  With a stash, or train=True (the update's
+        own forward), the sign words of _sign_layers go beside them (rows of the "train" workspace's sg{i})."""
         acts = []
         ptr, bs = x_ptr, bstride
+        sl = self._sign_layers() if (stash is not None or train) else {}
         for i, l in enumerate(self._cl):
             n = int(np.prod(l.out_shape))
             if stash is None:
                 a = ws.get(f"a{i}", (B,) + l.out_shape)
-                l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), a, B, st)
+                sg = None
+                if i in sl:
+                    sg = (ws.get(f"sg{i}", (B, sl[i]), dtype=torch.int32).data_ptr(), sl[i])
+                done = l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), a, B, st, signs=sg)
+                if i in sl:
+                    self._signs_ok[i] = bool(done)
                 ptr, bs = a.data_ptr(), n
             else:
                 bufs, row0, rstride = stash
                 optr = bufs[i].data_ptr() + 4 * row0 * n
-                l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), optr, B, st, out_bstride=rstride * n)
+                sg = None
+                if i in sl:
+                    sgb = self._sign_bufs[i]
+                    sg = (sgb.data_ptr() + 4 * row0 * sl[i], rstride * sl[i])
+                done = l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), optr, B, st, out_bstride=rstride * n, signs=sg)
+                if i in sl:
+                    self._signs_ok[i] = bool(done) and self._signs_ok.get(i, True) if row0 else bool(done)
                 ptr, bs = optr, rstride * n
             acts.append((ptr, bs))
         return acts
@@ -450,6 +478,7 @@ class _ConvStackNet(_HipNet):
             return None
         ws = self.ws("train")
         bufs = [ws.get(f"a{i}", (n_rows,) + l.out_shape) for i, l in enumerate(self._cl)]
+        self._sign_bufs = {i: ws.get(f"sg{i}", (n_rows, nw), dtype=torch.int32) for i, nw in self._sign_layers().items()}
         if self._E_STASH and os.environ.get("A2C_NO_EMB_STASH") != "1":
             # + the embedding e = relu(resize_emb(features)) of every state (the rollout computed it too): the update's
             # forward then also skips the flat_size -> e GEMM (ConvModel: 28224 -> 2000, 2.6 of its 16 ms)
@@ -482,7 +511,7 @@ class _ConvStackNet(_HipNet):
         """conv stack of the update's forward: recomputed, or taken from the rollout's stash"""
         if self._stash_valid(x_ptr, B):
             return [(ws.get(f"a{i}", (B,) + l.out_shape).data_ptr(), int(np.prod(l.out_shape))) for i, l in enumerate(self._cl)]
-        return self._convs_fwd(x_ptr, bstride, B, ws, st)
+        return self._convs_fwd(x_ptr, bstride, B, ws, st, train=True)
 
     def _convs_bwd(self, x_ptr, bstride, B, ws, st, d_last):
         """d_last: gradient wrt the last conv's pre-activation output (ReLU mask already applied)."""
@@ -505,7 +534,11 @@ class _ConvStackNet(_HipNet):
                     return
             if i > 0:
                 dprev = ws.get(f"da{i-1}", (B,) + self._cl[i - 1].out_shape)
-                l.bwd_data(d, acts[i - 1], dprev, B, st)
+                sl = self._sign_layers()
+                if (i - 1) in sl and self._signs_ok.get(i - 1, False):     # the forward that filled acts[i-1] left its sign words
+                    l.bwd_data(d, None, dprev, B, st, signs=ws.get(f"sg{i-1}", (B, sl[i - 1]), dtype=torch.int32))
+                else:
+                    l.bwd_data(d, acts[i - 1], dprev, B, st)
                 d = dprev
 
 

@@ -439,6 +439,30 @@ def conv_bwd_data(d, dout, wprep_bwd, mask, din, B, st=None):
                                     st if st is not None else stream()), "a2c_conv2d_bwd_data")
 
 
+def conv_sign_words(d):
+    """words per sample of the sign-word image of d's OUTPUT (0: d's forward cannot write one)"""
+    return int(lib().a2c_conv2d_sign_words(ctypes.byref(d)))
+
+
+def conv_fwd_signs(d, in_ptr, in_bstride, wprep, bias, relu, out, signs_ptr, signs_bstride, B, st=None, out_bstride=None):
+    """conv_fwd that also leaves (out > 0) as one bit per activation at signs_ptr (rows of signs_bstride uint32 words)"""
+    out_ptr = out if isinstance(out, int) else _p(out)
+    check(lib().a2c_conv2d_fwd_signs(ctypes.byref(d), in_ptr, in_bstride, _p(wprep), _p(bias), int(bool(relu)), out_ptr,
+                                     d.Cout * d.OH * d.OW if out_bstride is None else out_bstride, signs_ptr, signs_bstride,
+                                     B, st if st is not None else stream()), "a2c_conv2d_fwd_signs")
+
+
+def conv_bwd_data_signs_supported(d):
+    return bool(lib().a2c_conv2d_bwd_data_signs_supported(ctypes.byref(d)))
+
+
+def conv_bwd_data_signs(d, dout, wprep_bwd, signs, din, B, st=None):
+    """conv_bwd_data with the ReLU mask given as the sign words of the layer's input: (B, words) int32 tensor or None"""
+    check(lib().a2c_conv2d_bwd_data_signs(ctypes.byref(d), _p(dout), _p(wprep_bwd), _p(signs),
+                                          0 if signs is None else signs.stride(0), _p(din), B,
+                                          st if st is not None else stream()), "a2c_conv2d_bwd_data_signs")
+
+
 def conv_bwd_weight_ws_bytes(d, B):
     return lib().a2c_conv2d_bwd_weight_ws_bytes(ctypes.byref(d), B)
 

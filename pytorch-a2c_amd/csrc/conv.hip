@@ -33,9 +33,11 @@ bool c3_supported(const a2c_conv_desc* d, int kind);
 size_t c3_prep_floats(const a2c_conv_desc* d, int kind);
 int c3_prep(const a2c_conv_desc* d, int kind, const float* weight, float* out, hipStream_t st);
 int c3_fwd(const a2c_conv_desc* d, const float* in, long in_bs, const float* frag, const float* bias, int relu, float* out,
-           long out_bs, int B, hipStream_t st);
-int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, const float* mask, float* din, int B,
-                hipStream_t st);
+           long out_bs, unsigned* signs, long signs_bs, int B, hipStream_t st);
+int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, const float* mask, const unsigned* signs,
+                long signs_bs, float* din, int B, hipStream_t st);
+long c3_sign_words(const a2c_conv_desc* d);
+bool c3_bwd_signs_supported(const a2c_conv_desc* d);
 bool c3w_supported(const a2c_conv_desc* d);
 size_t c3w_ws_bytes(const a2c_conv_desc* d);
 int c3w_bwd_weight(const a2c_conv_desc* d, const float* in, long in_bs, const float* dout, float* dW, float* db, int B, void* ws,
@@ -2971,8 +2973,24 @@ int a2c_conv2d_fwd(const a2c_conv_desc* d, const float* in, int64_t in_bstride, 
   if (B == 0) return A2C_OK;
   if (!in || !wprep_fwd || !out) return A2C_ERR_ARG;
   if (c3_supported(d, 0) && in_bstride % 4 == 0 && out_bstride % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0)
-    return c3_fwd(d, in, (long)in_bstride, wprep_fwd + prep_floats_base(d, 0), bias, relu, out, (long)out_bstride, B, a2c_s(stream));
+    return c3_fwd(d, in, (long)in_bstride, wprep_fwd + prep_floats_base(d, 0), bias, relu, out, (long)out_bstride, nullptr, 0, B, a2c_s(stream));
   return conv_fwd_tuned(d, in, in_bstride, wprep_fwd, bias, relu, out, out_bstride, B, stream);
+}
+
+int64_t a2c_conv2d_sign_words(const a2c_conv_desc* d) {
+  if (!desc_ok(d)) return 0;
+  return (int64_t)c3_sign_words(d);
+}
+
+int a2c_conv2d_fwd_signs(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* wprep_fwd, const float* bias,
+                         int relu, float* out, int64_t out_bstride, uint32_t* signs, int64_t signs_bstride, int B,
+                         a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!in || !wprep_fwd || !out || !signs || c3_sign_words(d) == 0 || signs_bstride < c3_sign_words(d)) return A2C_ERR_ARG;
+  if (in_bstride % 4 || out_bstride % 4 || ((uintptr_t)in % 16) || ((uintptr_t)out % 16)) return A2C_ERR_ARG;
+  return c3_fwd(d, in, (long)in_bstride, wprep_fwd + prep_floats_base(d, 0), bias, relu, out, (long)out_bstride, signs,
+                (long)signs_bstride, B, a2c_s(stream));
 }
 
 }  // extern "C"
@@ -3185,6 +3203,8 @@ static int bwd_band_tuned(const a2c_conv_desc* d, const float* dout, const float
     return launch_bwd_band(d, dout, wprep_bwd, mask, din, B, best, stream);
   }
 }
+int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask, float* din, int B,
+                          a2c_stream_t stream);
 }  // namespace
 extern "C" {
 int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask,
@@ -3193,7 +3213,25 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
   if (B == 0) return A2C_OK;
   if (!dout || !wprep_bwd || !din) return A2C_ERR_ARG;
   if (c3_supported(d, 1) && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)din % 16) == 0 && (!mask || ((uintptr_t)mask % 16) == 0))
-    return c3_bwd_data(d, dout, wprep_bwd + prep_floats_base(d, 1), mask, din, B, a2c_s(stream));
+    return c3_bwd_data(d, dout, wprep_bwd + prep_floats_base(d, 1), mask, nullptr, 0, din, B, a2c_s(stream));
+  return conv_bwd_data_generic(d, dout, wprep_bwd, mask, din, B, stream);
+}
+
+int a2c_conv2d_bwd_data_signs_supported(const a2c_conv_desc* d) { return desc_ok(d) && c3_bwd_signs_supported(d) ? 1 : 0; }
+
+int a2c_conv2d_bwd_data_signs(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const uint32_t* signs,
+                              int64_t signs_bstride, float* din, int B, a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!dout || !wprep_bwd || !din || !c3_bwd_signs_supported(d)) return A2C_ERR_ARG;
+  if (((uintptr_t)dout % 16) || ((uintptr_t)din % 16)) return A2C_ERR_ARG;
+  if (signs && signs_bstride < (int64_t)d->Cin * d->H * ((d->W + 31) / 32)) return A2C_ERR_ARG;
+  return c3_bwd_data(d, dout, wprep_bwd + prep_floats_base(d, 1), nullptr, signs, (long)signs_bstride, din, B, a2c_s(stream));
+}
+}  // extern "C"
+namespace {
+int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask, float* din, int B,
+                          a2c_stream_t stream) {
   const int S = d->stride, P = d->pad;
   {  // fused-class pipelined path (unpadded ks = 2S layers whose dOut sample fits the prefetch registers)
     const int MTb = ceil_div(d->Cin, 16), c4n = d->Cout / 4;
@@ -3278,6 +3316,8 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
   }
   return A2C_OK;
 }
+}  // namespace
+extern "C" {
 
 size_t a2c_conv2d_bwd_data_w1_ws_bytes(const a2c_conv_desc* d2, const a2c_conv_desc* d1, int B) {
   BandW1Plan pl;

@@ -41,11 +41,15 @@ struct C3P {
   const float* zero;                  // >= 64 B of zeros in HBM (16-B aligned)
   int B, relu;
   unsigned long long* dbg;            // debug: phase stamps of workgroup 0 / wave 0 (a2c_debug_c3_timing), or nullptr
+  // sign words (staged kernels): bit x & 31 of word [c][y][x >> 5] of a sample = (activation[c][y][x] > 0)
+  unsigned* sg_out;                   // forward: written for the output, or nullptr
+  const unsigned* sg_in;              // backward-data: the ReLU mask of the layer below as sign words, or nullptr
+  long sg_bs;                         // sample stride of the sign words (in words)
 };
 
-template <int CS, int CD, int H, int W, int S, int R>
+template <int CS, int CD, int H, int W, int S, int R, int KCO = 0>
 struct C3Geo {
-  static constexpr int KC = CS >= 8 ? 8 : 4;          // source channels per chunk
+  static constexpr int KC = KCO ? KCO : (CS >= 8 ? 8 : 4);      // source channels per chunk (c3_kc() tells c3_prep the same)
   static constexpr int NCH = CS / KC;
   static constexpr int C4 = KC / 4;
   static constexpr int MT = (CD + 15) / 16;
@@ -74,7 +78,9 @@ struct C3Geo {
   static constexpr size_t LDS_BYTES_BWD = (2 * (size_t)BUF + MASKF) * 4;
   static constexpr bool VEC = (OH * OW) % 4 == 0 && MROW % 4 == 0;     // 16-byte output stores
   static_assert(CS % KC == 0 && PL0 % PB == 0 && (KC * PLANE) % 4 == 0, "shape");
-  static_assert(S == 2 || PLANE == PL0, "stride 1 reads the right halo of a plane's last row from the next plane's pad piece");
+  // stride 1 reads the right halo of a plane's last row from the next plane's pad piece: PLANE == PL0, or the kernel
+  // zeroes the gap between the planes once (GAP floats per plane, never written by the DMA)
+  static constexpr int GAP = PLANE - PL0;
 };
 
 // weights -> fragments.  forward: A[m*16 + i][k] = W[co = m*16+i][ci = ch*KC + c4*4 + g][ty][tx];
@@ -102,9 +108,9 @@ __global__ __launch_bounds__(256) void c3_prep_kernel(const float* __restrict__ 
   }
 }
 
-template <int CS, int CD, int H, int W, int S, int R, bool BWD>
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO = 0>
 __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
-  using G = C3Geo<CS, CD, H, W, S, R>;
+  using G = C3Geo<CS, CD, H, W, S, R, KCO>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
@@ -119,6 +125,13 @@ __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
     if (G::KC * G::PLANE < G::IMG - 8) {                  // (plane sizes that are not a multiple of 4 floats)
       lds[G::KC * G::PLANE + (tid & 3)] = 0.f;
       lds[G::BUF + G::KC * G::PLANE + (tid & 3)] = 0.f;
+    }
+  }
+  if (S == 1 && G::GAP > 0) {                     // (stride 1 reads one float past a plane's last row)
+    constexpr int GP = G::GAP > 0 ? G::GAP : 1;
+    for (int i = tid; i < 2 * G::KC * GP; i += 640) {
+      const int bsel = i / (G::KC * GP), r = i - bsel * (G::KC * GP);
+      lds[bsel * G::BUF + (r / GP) * G::PLANE + G::PL0 + (r % GP)] = 0.f;
     }
   }
   if (w >= G::NW) {
@@ -544,6 +557,762 @@ int c3b_launch(const C3P& p, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// STAGED variants of the two kernels above: the finished band does not leave through the computing waves.
+//
+// Measured on the kernels above (in-kernel stamps, profiles/README.md round 3): a workgroup's band ends with all eight
+// computing waves pushing 32-97 KB through the CU's store path (7-10 B/clk) while its matrix cores idle, then the
+// matrix phase of the next band runs while the store path idles -- conv1's forward spends 4.6k cycles per band in
+// MFMAs and 8k in the epilogue.  Here the computing waves write the band (bias + ReLU, or the ReLU mask, applied) into
+// an LDS image [channel][band pixels] (ds_write_b128, < 1k cycles) and go on with the next band; two more waves -- the
+// STORERS -- copy that image to HBM (ds_read_b128 -> global_store_dwordx4, full 1 KB wave stores) under the next band's
+// MFMAs, a slice of the channels per chunk interval.  Barriers per band: one per chunk as before, plus one (X) between
+// the last chunk's MFMAs and the write of the image (the storers have read the previous band out of it by then).
+// Store-bound layers now run at the store path's rate, matrix-bound ones lose the epilogue.
+//
+// The ReLU mask of backward-data arrives as SIGN WORDS (one bit per activation, rows padded to 32-bit words) produced
+// by the forward of the layer below -- by its storers, from the image they copy anyway: 1/32 of the mask's HBM reads,
+// and the LDS the float mask band took is what the output image lives in.
+// Workgroup barrier of the staged kernels: LDS traffic of this wave done (lgkmcnt), then s_barrier -- NOT __syncthreads(),
+// whose fence also drains vmcnt: a storer would sit at every barrier until its global stores are acknowledged (microseconds
+// under load) and hold up the computing waves with it.  Loaders wait for their LDS-DMA (vmcnt) themselves before they arrive.
+__device__ __forceinline__ void c3_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CS, int CD, int H, int W, int S, int R>
+struct C3SGeo : C3Geo<CS, CD, H, W, S, R> {
+  using G0 = C3Geo<CS, CD, H, W, S, R>;
+  static constexpr int NS = 2;                                     // storer waves
+  static constexpr int MROWP = ((G0::MROW + 3) / 8) * 8 + 4;        // channel pitch of the image: 4 (mod 8) floats, so the 8
+                                                                   // channels of a ds_write_b128 lane group hit 8 distinct slots
+  static constexpr int STAGE = CD * MROWP;
+  static constexpr int RW = (G0::OW + 31) / 32;                     // sign words per row
+  static constexpr int BITC = R * RW;                              // ... per channel band
+  static constexpr int BITB = ((CD * BITC + 3) / 4) * 4;
+  static constexpr size_t LDS_BYTES_S = (2 * (size_t)G0::BUF + STAGE + BITB) * 4;
+  static constexpr int NTHR = 64 * (G0::NW + G0::NL + NS);
+  static_assert(MROWP >= ((G0::MROW + 3) / 4) * 4, "pitch");
+};
+
+struct C3Drain { const float* s; float* o; unsigned* bb; unsigned* go; bool ok; };
+
+// LDS accesses of the STORER waves go through inline asm.  hipcc's waitcnt insertion treats every LDS access of a kernel
+// that also issues LDS-DMA as a possible reader of an in-flight DMA and puts `s_waitcnt vmcnt(0)` in front of it -- in a
+// storer that is a wait for the acknowledgement of every global store it has issued so far (2-4 us under load) before
+// each batch of reads: 8 KB per round trip.  (The storers never touch what the DMA writes.)
+__device__ __forceinline__ unsigned c3_lds_addr(const void* p) { return (unsigned)(unsigned long)(lptr_t)p; }
+__device__ __forceinline__ f32x4 c3_lds_read128(const float* p) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(c3_lds_addr(p)));
+  return v;
+}
+__device__ __forceinline__ float c3_lds_read32(const void* p) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(c3_lds_addr(p)));
+  return v;
+}
+__device__ __forceinline__ void c3_lds_zero32(void* p) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(c3_lds_addr(p)), "v"(0u) : "memory");
+}
+// all LDS reads issued so far have returned; the values are tied to the wait so that no use can move above it
+__device__ __forceinline__ void c3_lds_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+__device__ __forceinline__ void c3_lds_wait(float& a, float& b, float& c, float& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
+// NH (1 or 2) channel bands: LDS image -> HBM.  Straight-line code with the pieces in named registers: all LDS reads
+// first, then the stores -- a storer is ONE wave, it cannot afford a wait per piece (and a private array here ends up
+// in scratch memory in the instances at the register cap).
+// d.s / d.o: the channel's row of the image / its band in HBM (npx floats, contiguous).  At most 4 pieces per lane.
+template <int MROW, bool VEC, int NH = 2>
+__device__ __forceinline__ void c3_drain_pair(const C3Drain d0, const C3Drain d1, int npx, int lane) {
+  const bool on1 = NH > 1 && d1.ok;
+  if constexpr (VEC) {
+    constexpr int NIT = (MROW / 4 + 63) / 64;
+    static_assert(NIT <= 4, "pieces per lane");
+    const int nf = npx >> 2;                                 // (npx % 4 == 0: OW even and whole rows, see C3Geo::VEC)
+    const int f0 = lane, f1 = 64 + lane, f2 = 128 + lane, f3 = 192 + lane;
+    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define C3_LD(D, F) c3_lds_read128((D).s + 4 * min((F), nf - 1))
+    f32x4 a0 = C3_LD(d0, f0), a1 = NIT > 1 ? C3_LD(d0, f1) : z, a2 = NIT > 2 ? C3_LD(d0, f2) : z, a3 = NIT > 3 ? C3_LD(d0, f3) : z;
+    f32x4 b0 = NH > 1 ? C3_LD(d1, f0) : z, b1 = (NH > 1 && NIT > 1) ? C3_LD(d1, f1) : z,
+          b2 = (NH > 1 && NIT > 2) ? C3_LD(d1, f2) : z, b3 = (NH > 1 && NIT > 3) ? C3_LD(d1, f3) : z;
+#undef C3_LD
+    c3_lds_wait(a0, a1, a2, a3);
+    if (NH > 1) c3_lds_wait(b0, b1, b2, b3);
+#define C3_ST(D, F, V, ON) do { if ((ON) && (F) < nf) *reinterpret_cast<f32x4*>((D).o + 4 * (F)) = (V); } while (0)
+    C3_ST(d0, f0, a0, true);
+    if (NIT > 1) C3_ST(d0, f1, a1, true);
+    if (NIT > 2) C3_ST(d0, f2, a2, true);
+    if (NIT > 3) C3_ST(d0, f3, a3, true);
+    if (NH > 1) {
+      C3_ST(d1, f0, b0, on1);
+      if (NIT > 1) C3_ST(d1, f1, b1, on1);
+      if (NIT > 2) C3_ST(d1, f2, b2, on1);
+      if (NIT > 3) C3_ST(d1, f3, b3, on1);
+    }
+#undef C3_ST
+  } else {                                                   // channel bands that do not start on 16-byte boundaries: dwords
+    constexpr int NIT = (MROW + 63) / 64;
+    static_assert(NIT <= 4, "pieces per lane");
+    const int q0 = lane, q1 = 64 + lane, q2 = 128 + lane, q3 = 192 + lane;
+#define C3_LD(D, Q) c3_lds_read32((D).s + min((Q), npx - 1))
+    float a0 = C3_LD(d0, q0), a1 = NIT > 1 ? C3_LD(d0, q1) : 0.f, a2 = NIT > 2 ? C3_LD(d0, q2) : 0.f, a3 = NIT > 3 ? C3_LD(d0, q3) : 0.f;
+    float b0 = NH > 1 ? C3_LD(d1, q0) : 0.f, b1 = (NH > 1 && NIT > 1) ? C3_LD(d1, q1) : 0.f,
+          b2 = (NH > 1 && NIT > 2) ? C3_LD(d1, q2) : 0.f, b3 = (NH > 1 && NIT > 3) ? C3_LD(d1, q3) : 0.f;
+#undef C3_LD
+    c3_lds_wait(a0, a1, a2, a3);
+    if (NH > 1) c3_lds_wait(b0, b1, b2, b3);
+#define C3_ST(D, Q, V, ON) do { if ((ON) && (Q) < npx) (D).o[(Q)] = (V); } while (0)
+    C3_ST(d0, q0, a0, true);
+    if (NIT > 1) C3_ST(d0, q1, a1, true);
+    if (NIT > 2) C3_ST(d0, q2, a2, true);
+    if (NIT > 3) C3_ST(d0, q3, a3, true);
+    if (NH > 1) {
+      C3_ST(d1, q0, b0, on1);
+      if (NIT > 1) C3_ST(d1, q1, b1, on1);
+      if (NIT > 2) C3_ST(d1, q2, b2, on1);
+      if (NIT > 3) C3_ST(d1, q3, b3, on1);
+    }
+#undef C3_ST
+  }
+}
+
+// a channel band's sign words (set by the computing waves while they wrote the image): LDS -> HBM, and back to zero
+__device__ __forceinline__ void c3_drain_signs(const C3Drain d, int nwords, int lane) {
+  for (int i = lane; i < nwords; i += 64) {
+    float w0 = c3_lds_read32(d.bb + i), z1 = 0.f, z2 = 0.f, z3 = 0.f;
+    c3_lds_wait(w0, z1, z2, z3);
+    d.go[i] = __float_as_uint(w0);
+    c3_lds_zero32(d.bb + i);
+  }
+}
+
+// computing waves, forward: the sign bits of four consecutive band pixels p0 .. p0+3 of one channel -> its sign words
+template <int OW, int RW>
+__device__ __forceinline__ void c3_sign4(unsigned* __restrict__ bbc, int p0, int npix, const float4 q4) {
+  if (OW % 4 == 0) {                                   // the four pixels share a row and a word
+    const unsigned nib = (q4.x > 0.f ? 1u : 0u) | (q4.y > 0.f ? 2u : 0u) | (q4.z > 0.f ? 4u : 0u) | (q4.w > 0.f ? 8u : 0u);
+    const int r = p0 / OW, x = p0 - r * OW;
+    if (p0 < npix && nib) atomicOr(&bbc[r * RW + (x >> 5)], nib << (x & 31));
+  } else {
+    const float e[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = p0 + i, r = q / OW, x = q - r * OW;
+      if (q < npix && e[i] > 0.f) atomicOr(&bbc[r * RW + (x >> 5)], 1u << (x & 31));
+    }
+  }
+}
+
+template <int CS, int CD, int H, int W, int S, int R, bool BWD>
+__global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
+  using G = C3SGeo<CS, CD, H, W, S, R>;
+  static_assert(!BWD || G::OW % 4 == 0, "backward-data reads a lane's four mask bits from one word");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const stage = lds + 2 * G::BUF;
+  unsigned* const bitb = reinterpret_cast<unsigned*>(stage + G::STAGE);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const long ntile = (long)p.B * G::NBAND;
+  long nmine = 0;
+  if ((long)blockIdx.x < ntile) nmine = (ntile - 1 - blockIdx.x) / gridDim.x + 1;
+  const long nwork = nmine * G::NCH;              // work item k = (tile k / NCH, chunk k % NCH)
+  if (tid < 16) {
+    lds[G::IMG - 8 + (tid & 7)] = 0.f;
+    lds[G::BUF + G::IMG - 8 + (tid & 7)] = 0.f;
+    if (G::KC * G::PLANE < G::IMG - 8) {
+      lds[G::KC * G::PLANE + (tid & 3)] = 0.f;
+      lds[G::BUF + G::KC * G::PLANE + (tid & 3)] = 0.f;
+    }
+  }
+  if (S == 1 && G::GAP > 0) {                     // (stride 1 reads one float past a plane's last row)
+    constexpr int GP = G::GAP > 0 ? G::GAP : 1;
+    for (int i = tid; i < 2 * G::KC * GP; i += G::NTHR) {
+      const int bsel = i / (G::KC * GP), r = i - bsel * (G::KC * GP);
+      lds[bsel * G::BUF + (r / GP) * G::PLANE + G::PL0 + (r % GP)] = 0.f;
+    }
+  }
+  if (w >= G::NW + G::NL) {
+    // ------------------------------------------------------------------ storer waves
+    const int sw = w - G::NW - G::NL;
+    if (!BWD && sw == 0)
+      for (int i = lane; i < G::BITB; i += 64) bitb[i] = 0u;
+    c3_bar();
+    const bool signs = !BWD && p.sg_out != nullptr;
+    auto drain = [&](long tile, int part) {
+      const long b = tile / G::NBAND;
+      const int band = (int)(tile - b * G::NBAND);
+      const int nrows = min(R, G::OH - band * R), npx = nrows * G::OW;
+      constexpr int CPP = (CD + G::NCH - 1) / G::NCH;
+      constexpr int CMAX = (CPP + G::NS - 1) / G::NS;         // channels of one storer in one slice (at most)
+      const int cend = min(CD, (part + 1) * CPP);
+#pragma unroll
+      for (int i0 = 0; i0 < CMAX; i0 += 2) {
+        auto chan = [&](int i) {
+          const int c = part * CPP + sw + G::NS * i;
+          C3Drain d;
+          d.ok = i < CMAX && c < cend;
+          const int cc = d.ok ? c : 0;
+          d.s = stage + cc * G::MROWP;
+          d.o = p.out + b * p.out_bs + (long)cc * G::OH * G::OW + (long)band * R * G::OW;
+          d.bb = bitb + cc * G::BITC;
+          d.go = signs ? p.sg_out + b * p.sg_bs + ((long)cc * G::OH + band * R) * G::RW : nullptr;
+          return d;
+        };
+        const C3Drain d0 = chan(i0), d1 = chan(i0 + 1);
+        if (d0.ok) c3_drain_pair<G::MROW, G::VEC>(d0, d1, npx, lane);
+        if (signs) {
+          if (d0.ok) c3_drain_signs(d0, nrows * G::RW, lane);
+          if (d1.ok) c3_drain_signs(d1, nrows * G::RW, lane);
+        }
+      }
+    };
+    long pend = -1;
+    for (long k = 0; k < nwork; ++k) {
+      const int ch = (int)(k % G::NCH);
+      if (pend >= 0) drain(pend, ch);             // the previous band leaves under this band's chunks, a slice per chunk
+      if (ch == G::NCH - 1) c3_bar();      // X
+      c3_bar();
+      if (ch == G::NCH - 1) pend = blockIdx.x + (k / G::NCH) * gridDim.x;
+    }
+    if (pend >= 0)
+      for (int part = 0; part < G::NCH; ++part) drain(pend, part);
+    return;
+  }
+  if (w >= G::NW) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = w - G::NW;
+    int roff[G::NQ], rrow[G::NQ];
+#pragma unroll
+    for (int q = 0; q < G::NQ; ++q) {
+      const int pi = q * 64 + lane;
+      const int r = pi / (G::WP / G::PB), i = pi - r * (G::WP / G::PB);
+      rrow[q] = (pi < G::PP) ? (i == 0 ? -100000 : r) : -200000;
+      roff[q] = r * W + G::PB * (i - 1);
+    }
+    auto dma = [&](long k) {
+      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
+      const int ch = (int)(k % G::NCH);
+      const long b = tile / G::NBAND;
+      const int band = (int)(tile - b * G::NBAND);
+      const int y0 = band * R * S - 1;
+      float* __restrict__ buf = lds + (k & 1) * G::BUF;
+      const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * G::KC * H + y0) * W;
+#pragma unroll
+      for (int c = 0; c < G::KC; ++c) {
+        if (c % G::NL != lw) continue;
+#pragma unroll
+        for (int q = 0; q < G::NQ; ++q) {
+          if (rrow[q] > -200000) {
+            const int y = y0 + rrow[q];
+            const float* gsrc = (rrow[q] >= 0 && y >= 0 && y < H) ? sb + (long)c * H * W + roff[q] : p.zero;
+            if (G::PB == 4) __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(buf + c * G::PLANE + q * 256), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(buf + c * G::PLANE + q * 64), 4, 0, 0);
+          }
+        }
+      }
+      const float* __restrict__ fg = p.frag + (long)ch * G::FRAGC;
+#pragma unroll
+      for (int q = 0; q < G::NFQ; ++q) {
+        const int pi = q * 64 + lane;
+        if (q % G::NL == lw && pi < G::FRAGC / 4)
+          __builtin_amdgcn_global_load_lds((gptr_t)(fg + pi * 4), (lptr_t)(buf + G::IMG + q * 256), 16, 0, 0);
+      }
+    };
+    // backward-data: the band's mask as sign words, R * RW words per channel (contiguous in HBM)
+    auto dma_signs = [&](long tile) {
+      const long b = tile / G::NBAND;
+      const int band = (int)(tile - b * G::NBAND);
+      const int nw = min(R, G::OH - band * R) * G::RW;
+#pragma unroll 1
+      for (int c = lw; c < CD; c += G::NL) {
+        const unsigned* __restrict__ src = p.sg_in + b * p.sg_bs + ((long)c * G::OH + band * R) * G::RW;
+        for (int i0 = 0; i0 < nw; i0 += 64)
+          if (i0 + lane < nw)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + i0 + lane), (lptr_t)(bitb + c * G::BITC + i0), 4, 0, 0);
+      }
+    };
+    const bool msk = BWD && p.sg_in != nullptr;
+    if (nwork > 0) {
+      dma(0);
+      if (msk) dma_signs(blockIdx.x);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the chunk has landed in LDS
+    c3_bar();
+    for (long k = 0; k < nwork; ++k) {
+      const int ch = (int)(k % G::NCH);
+      if (k + 1 < nwork) dma(k + 1);
+      if (msk && ch == 0 && k > 0) dma_signs(blockIdx.x + (k / G::NCH) * gridDim.x);     // (the previous band is done with them)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (ch == G::NCH - 1) c3_bar();       // X
+      c3_bar();
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- computing waves
+  int base[G::TPW];
+#pragma unroll
+  for (int u = 0; u < G::TPW; ++u) {
+    const int t = w + G::NW * u;
+    const int pp = t * 16 + j;
+    const bool ok = t < G::NT && pp < G::NPIX;
+    const int px = ok ? pp : 0;
+    const int r = px / G::OW, x = px - r * G::OW;
+    base[u] = g * G::PLANE + r * S * G::WP + x * S + G::PB - 1;
+  }
+  f32x4 acc[G::TPW][G::MT];
+#pragma unroll
+  for (int u = 0; u < G::TPW; ++u)
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) acc[u][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float biasv[G::MT];
+#pragma unroll
+  for (int m = 0; m < G::MT; ++m) biasv[m] = (!BWD && p.bias && m * 16 + j < CD) ? p.bias[m * 16 + j] : 0.f;
+  const bool msk = BWD && p.sg_in != nullptr;
+  const bool sgn = !BWD && p.sg_out != nullptr;
+  c3_bar();
+  for (long k = 0; k < nwork; ++k) {
+    const float* __restrict__ img = lds + (k & 1) * G::BUF;
+    const float* __restrict__ fr = img + G::IMG + lane;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int c4 = 0; c4 < G::C4; ++c4) {
+        float av[G::MT];
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) av[m] = fr[((tap * G::C4 + c4) * G::MT + m) * 64];
+#pragma unroll
+        for (int u = 0; u < G::TPW; ++u) {
+          const float bv = img[base[u] + c4 * 4 * G::PLANE + (tap / 3) * G::WP + (tap % 3)];
+#pragma unroll
+          for (int m = 0; m < G::MT; ++m) acc[u][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[m], acc[u][m], 0, 0, 0);
+        }
+        if (G::TPW * G::MT >= 12) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if ((int)(k % G::NCH) == G::NCH - 1) {
+      c3_bar();                                       // X: the image is free, this band's sign words are in
+      // ---- accumulators -> the image.  D tile [pixel][channel]: lane (j, g) holds pixels 4g .. 4g+3 of channel j
+#pragma unroll
+      for (int u = 0; u < G::TPW; ++u) {
+        const int t = w + G::NW * u;
+        const int p0 = t * 16 + 4 * g;
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) {
+          const int cd = m * 16 + j;
+          float4 v = make_float4(acc[u][m][0], acc[u][m][1], acc[u][m][2], acc[u][m][3]);
+          if (BWD) {
+            if (msk && cd < CD && p0 < G::NPIX) {
+              const int r = p0 / G::OW, x = p0 - r * G::OW;
+              const unsigned nib = bitb[cd * G::BITC + r * G::RW + (x >> 5)] >> (x & 31);
+              if (!(nib & 1u)) v.x = 0.f;
+              if (!(nib & 2u)) v.y = 0.f;
+              if (!(nib & 4u)) v.z = 0.f;
+              if (!(nib & 8u)) v.w = 0.f;
+            }
+          } else {
+            const float bs = biasv[m];
+            v.x += bs; v.y += bs; v.z += bs; v.w += bs;
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (sgn && cd < CD) c3_sign4<G::OW, G::RW>(bitb + cd * G::BITC, p0, G::NPIX, v);
+          }
+          if (cd < CD && p0 + 3 < G::MROWP) *reinterpret_cast<float4*>(stage + cd * G::MROWP + p0) = v;
+          acc[u][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    c3_bar();
+  }
+}
+
+// ---- stride-2 backward-data, staged.  The chunk images live in a ring of D buffers and the loaders run D - 1 chunks
+// ahead (a chunk's MFMAs take ~1 us, an LDS-DMA issued under load comes back after 2-3: one chunk of lookahead leaves
+// every interval waiting on its barrier); they wait with COUNTED vmcnt -- every chunk is the same number of DMA
+// instructions per loader wave -- so the younger chunks stay in flight across the barrier.  FRES: the weight fragments
+// of ALL chunks stay resident in LDS (loaded once per workgroup) instead of travelling with every chunk.
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES>
+struct C3BSGeo {
+  static constexpr int H = 2 * HO, W = 2 * WO;
+  static constexpr int NCH = CO / KC, C4 = KC / 4, MT = (CI + 15) / 16;
+  static constexpr int NBAND = (HO + RQ - 1) / RQ;
+  static constexpr int NPIX = RQ * WO;                 // class pixels per band
+  static constexpr int NT = (NPIX + 15) / 16;
+  static constexpr int NW = 8, NL = 2, NS = 2;
+  static constexpr int TP = (NT + NW - 1) / NW;        // tile positions per wave
+  // dOut band image.  PB16: planes and band starts are 16-byte aligned in HBM -> the band's rows of a plane come in as ONE
+  // linear run of 16-byte pieces (row pitch WO, no zero column: the right halo is a lane select in the MFMA loop, the
+  // rows below the plane are pieces read from the zero page) -- 2 DMA instructions per plane instead of 5: the loaders
+  // of the 4-byte version spent most of their time ISSUING.  Otherwise 4-byte pieces and a zero column per row.
+  static constexpr bool PB16 = WO % 2 == 0 && (HO * WO) % 4 == 0 && (RQ * WO) % 4 == 0;
+  static constexpr int WP = PB16 ? WO : WO + 1;
+  static constexpr int PL0 = PB16 ? (((RQ + 1) * WO + 3) / 4) * 4 : (RQ + 1) * WP;
+  static constexpr int PLANE = ((PL0 + 15) / 32) * 32 + 16;
+  static constexpr int NQ = PB16 ? (PL0 / 4 + 63) / 64 : (PL0 + 63) / 64;      // DMA instructions per plane
+  static constexpr int IMG = ((KC * PLANE + 3) / 4) * 4 + 4;                   // (+ the float a last-row right-halo read may touch)
+  static constexpr int FRAGC = C4 * 9 * MT * 64;
+  static constexpr int NFQ = (FRAGC / 4 + 63) / 64;
+  static constexpr int BUF = ((IMG + FRAGC + 255) / 256) * 256;
+  static constexpr int MROW = 2 * RQ * W;              // floats of one channel's dX band (rows are contiguous in HBM)
+  static constexpr int LOOK = D - 1;                               // chunks in flight ahead of the one being computed
+  static constexpr int SLOT = FRES ? ((IMG + 63) / 64) * 64 : BUF;              // floats per ring slot
+  static constexpr int FRAG_ALL = FRES ? NCH * FRAGC : 0;
+  static constexpr int MROWP = ((MROW + 3) / 8) * 8 + 4;
+  static constexpr int STAGE = CI * MROWP;
+  static constexpr int RW = (W + 31) / 32;
+  static constexpr int BITC = 2 * RQ * RW;
+  static constexpr int BITB = ((CI * BITC + 3) / 4) * 4;
+  static constexpr size_t LDS_BYTES_S = ((size_t)D * SLOT + FRAG_ALL + STAGE + BITB) * 4;
+  static constexpr bool VEC = (H * W) % 4 == 0 && MROW % 4 == 0;
+  // DMA instructions of one chunk per loader wave (constant by construction: planes and fragment pieces are dealt
+  // round robin, a partly filled instruction still issues)
+  static constexpr int NI0 = (KC / NL) * NQ + (FRES ? 0 : (NFQ + 1) / 2);     // loader 0 / loader 1
+  static constexpr int NI1 = (KC / NL) * NQ + (FRES ? 0 : NFQ / 2);
+  static_assert(CO % KC == 0 && KC % NL == 0 && NL == 2, "every chunk is the same number of DMA instructions per loader");
+  static_assert(LOOK >= 1 && LOOK <= NCH && (LOOK - 1) * NI0 <= 63, "lookahead: sign words land before X; vmcnt is 6 bits");
+};
+
+// per-role phase stamps of workgroup 0 in the staged stride-2 backward kernel (a2c_debug_c3_timing): compiled in with
+// -DA2C_C3_STAMPS only -- their registers push the two instances at the register cap into scratch
+#ifdef A2C_C3_STAMPS
+constexpr bool C3_STAMPS = true;
+#else
+constexpr bool C3_STAMPS = false;
+#endif
+template <int N>
+__device__ __forceinline__ void c3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES>
+__global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
+  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const fres = lds + D * G::SLOT;                     // resident fragments (FRES)
+  float* const stage = fres + G::FRAG_ALL;
+  unsigned* const bitb = reinterpret_cast<unsigned*>(stage + G::STAGE);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const long ntile = (long)p.B * G::NBAND;
+  long nmine = 0;
+  if ((long)blockIdx.x < ntile) nmine = (ntile - 1 - blockIdx.x) / gridDim.x + 1;
+  const long nwork = nmine * G::NCH;
+  if (w >= G::NW + G::NL) {
+    // ------------------------------------------------------------------ storer waves
+    const int sw = w - G::NW - G::NL;
+    c3_bar();
+    auto drain = [&](long tile, int part) {
+      const long b = tile / G::NBAND;
+      const int q0 = (int)(tile - b * G::NBAND) * RQ;
+      const int nrows = 2 * min(RQ, HO - q0), npx = nrows * G::W;
+      constexpr int CPP = (CI + G::NCH - 1) / G::NCH;
+      constexpr int CMAX = (CPP + G::NS - 1) / G::NS;
+      const int cend = min(CI, (part + 1) * CPP);
+      constexpr int NH = (G::MT > 1 && G::TP > 1) ? 1 : 2;      // (the computing waves of those instances sit at the register cap)
+#pragma unroll
+      for (int i0 = 0; i0 < CMAX; i0 += NH) {
+        auto chan = [&](int i) {
+          const int c = part * CPP + sw + G::NS * i;
+          C3Drain d;
+          d.ok = i < CMAX && c < cend;
+          const int cc = d.ok ? c : 0;
+          d.s = stage + cc * G::MROWP;
+          d.o = p.out + b * p.out_bs + ((long)cc * G::H + 2 * q0) * G::W;
+          d.bb = nullptr;
+          d.go = nullptr;
+          return d;
+        };
+        const C3Drain d0 = chan(i0), d1 = chan(i0 + 1);
+        if (d0.ok) c3_drain_pair<G::MROW, G::VEC, NH>(d0, d1, npx, lane);
+      }
+    };
+    long pend = -1;
+    const bool stamp = C3_STAMPS && p.dbg != nullptr && blockIdx.x == 0 && sw == 0 && lane == 0;
+    unsigned long long tdr = 0;
+    for (long k = 0; k < nwork; ++k) {
+      const int ch = (int)(k % G::NCH);
+      const unsigned long long t0 = stamp ? wall_clock64() : 0;
+      if (pend >= 0) drain(pend, ch);
+      if (stamp) tdr += wall_clock64() - t0;
+      if (ch == G::NCH - 1) c3_bar();      // X
+      c3_bar();
+      if (ch == G::NCH - 1) pend = blockIdx.x + (k / G::NCH) * gridDim.x;
+    }
+    if (pend >= 0)
+      for (int part = 0; part < G::NCH; ++part) drain(pend, part);
+    if (stamp) p.dbg[4] = tdr;
+    return;
+  }
+  if (w >= G::NW) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = w - G::NW;
+    int roff[G::NQ], rrow[G::NQ];
+#pragma unroll
+    for (int q = 0; q < G::NQ; ++q) {
+      const int pi = q * 64 + lane;
+      if (G::PB16) {                                     // piece pi = floats 4 pi .. 4 pi + 3 of the plane's band rows
+        rrow[q] = (4 * pi < G::PL0) ? 0 : -200000;
+        roff[q] = 4 * pi;
+      } else {
+        const int r = pi / G::WP, x = pi - r * G::WP;
+        rrow[q] = (pi < G::PL0) ? (x == WO ? -100000 : r) : -200000;
+        roff[q] = r * WO + x;
+      }
+    }
+    auto dma = [&](long k) {
+      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
+      const int ch = (int)(k % G::NCH);
+      const long b = tile / G::NBAND;
+      const int q0 = (int)(tile - b * G::NBAND) * RQ;
+      float* __restrict__ buf = lds + (k % D) * G::SLOT;
+      const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * KC * HO + q0) * WO;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        if (c % G::NL != lw) continue;
+#pragma unroll
+        for (int q = 0; q < G::NQ; ++q) {
+          if (rrow[q] > -200000) {
+            if (G::PB16) {                                // (the plane ends on a piece boundary: HO * WO % 4 == 0)
+              const float* gsrc = (q0 * WO + roff[q] < HO * WO) ? sb + (long)c * HO * WO + roff[q] : p.zero;
+              __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(buf + c * G::PLANE + q * 256), 16, 0, 0);
+            } else {
+              const float* gsrc = (rrow[q] >= 0 && q0 + rrow[q] < HO) ? sb + (long)c * HO * WO + roff[q] : p.zero;
+              __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(buf + c * G::PLANE + q * 64), 4, 0, 0);
+            }
+          }
+        }
+      }
+      if (!FRES) {
+        const float* __restrict__ fg = p.frag + (long)ch * G::FRAGC;
+#pragma unroll
+        for (int q = 0; q < G::NFQ; ++q) {
+          const int pi = q * 64 + lane;
+          if (q % G::NL == lw && pi < G::FRAGC / 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(fg + pi * 4), (lptr_t)(buf + G::IMG + q * 256), 16, 0, 0);
+        }
+      }
+    };
+    auto dma_signs = [&](long tile) {
+      const long b = tile / G::NBAND;
+      const int q0 = (int)(tile - b * G::NBAND) * RQ;
+      const int nw = 2 * min(RQ, HO - q0) * G::RW;
+#pragma unroll 1
+      for (int c = lw; c < CI; c += G::NL) {
+        const unsigned* __restrict__ src = p.sg_in + b * p.sg_bs + ((long)c * G::H + 2 * q0) * G::RW;
+        for (int i0 = 0; i0 < nw; i0 += 64)
+          if (i0 + lane < nw)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + i0 + lane), (lptr_t)(bitb + c * G::BITC + i0), 4, 0, 0);
+      }
+    };
+    // before the barrier that opens chunk k1: everything up to chunk k1 has landed, the m younger chunks stay in flight
+    auto wait_for = [&](long k1) {
+      long m = min(k1 + G::LOOK - 1, nwork - 1) - k1;
+      if (m < 0) m = 0;
+      if (lw == 0) {
+        if (G::LOOK >= 4 && m >= 3) c3_wait_vm<(G::LOOK >= 4 ? 3 : 0) * G::NI0>();
+        else if (G::LOOK >= 3 && m == 2) c3_wait_vm<(G::LOOK >= 3 ? 2 : 0) * G::NI0>();
+        else if (G::LOOK >= 2 && m == 1) c3_wait_vm<(G::LOOK >= 2 ? 1 : 0) * G::NI0>();
+        else c3_wait_vm<0>();
+      } else {
+        if (G::LOOK >= 4 && m >= 3) c3_wait_vm<(G::LOOK >= 4 ? 3 : 0) * G::NI1>();
+        else if (G::LOOK >= 3 && m == 2) c3_wait_vm<(G::LOOK >= 3 ? 2 : 0) * G::NI1>();
+        else if (G::LOOK >= 2 && m == 1) c3_wait_vm<(G::LOOK >= 2 ? 1 : 0) * G::NI1>();
+        else c3_wait_vm<0>();
+      }
+    };
+    static_assert(G::LOOK <= 4, "wait_for");
+    const bool msk = p.sg_in != nullptr;
+    if (nwork > 0) {
+      if (FRES) {                                            // all chunks' fragments, once
+        constexpr int NFA = (G::FRAG_ALL / 4 + 63) / 64;
+#pragma unroll 1
+        for (int q = lw; q < NFA; q += G::NL) {
+          const int pi = q * 64 + lane;
+          if (pi < G::FRAG_ALL / 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.frag + pi * 4), (lptr_t)(fres + q * 256), 16, 0, 0);
+        }
+      }
+      if (msk) dma_signs(blockIdx.x);
+      for (int k = 0; k < G::LOOK; ++k)
+        if (k < nwork) dma(k);
+    }
+    wait_for(0);
+    c3_bar();
+    const bool stamp = C3_STAMPS && p.dbg != nullptr && blockIdx.x == 0 && lw == 0 && lane == 0;
+    unsigned long long tld = 0;
+    for (long k = 0; k < nwork; ++k) {
+      const int ch = (int)(k % G::NCH);
+      const unsigned long long t0 = stamp ? wall_clock64() : 0;
+      if (msk && ch == 0 && k > 0) dma_signs(blockIdx.x + (k / G::NCH) * gridDim.x);     // (the previous band is done with them)
+      if (k + G::LOOK < nwork) dma(k + G::LOOK);            // into the slot chunk k - 1 left
+      wait_for(k + 1);
+      if (stamp) tld += wall_clock64() - t0;
+      if (ch == G::NCH - 1) c3_bar();       // X
+      c3_bar();
+    }
+    if (stamp) p.dbg[5] = tld;
+    return;
+  }
+  // -------------------------------------------------------------------- computing waves
+  int base[G::TP];
+  bool redge[G::TP];                             // PB16: the pixel is the last of its row (its right neighbour is the halo: 0)
+#pragma unroll
+  for (int u = 0; u < G::TP; ++u) {
+    const int t = w + G::NW * u;
+    const int pp = t * 16 + j;
+    const int px = (t < G::NT && pp < G::NPIX) ? pp : 0;
+    const int r = px / WO, x = px - r * WO;
+    base[u] = g * G::PLANE + r * G::WP + x;
+    redge[u] = G::PB16 && x == WO - 1;
+  }
+  f32x4 acc[G::TP][4][G::MT];                    // [tile position][class py*2+px][channel tile]
+#pragma unroll
+  for (int u = 0; u < G::TP; ++u)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < G::MT; ++m) acc[u][c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool msk = p.sg_in != nullptr;
+  c3_bar();
+  const bool stamp = C3_STAMPS && p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+  unsigned long long ts = stamp ? wall_clock64() : 0, tsum[4] = {0, 0, 0, 0};      // MFMAs | wait at X | image write | wait at the chunk barrier
+#define C3_TS(i) do { if (stamp) { const unsigned long long n_ = wall_clock64(); tsum[i] += n_ - ts; ts = n_; } } while (0)
+  for (long k = 0; k < nwork; ++k) {
+    const float* __restrict__ img = lds + (k % D) * G::SLOT;
+    const float* __restrict__ fr = (FRES ? fres + (k % G::NCH) * G::FRAGC : img + G::IMG) + lane;
+#pragma unroll
+    for (int c4 = 0; c4 < G::C4; ++c4) {
+      float wv[9][G::MT];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) wv[tap][m] = fr[((c4 * 9 + tap) * G::MT + m) * 64];
+#pragma unroll
+      for (int u = 0; u < G::TP; ++u) {
+        const float* __restrict__ s = img + base[u] + c4 * 4 * G::PLANE;
+        const float s00 = s[0], s10 = s[G::WP];
+        float s01 = s[1], s11 = s[G::WP + 1];
+        if (G::PB16) {
+          s01 = redge[u] ? 0.f : s01;
+          s11 = redge[u] ? 0.f : s11;
+        }
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) {
+          acc[u][0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s00, wv[4][m], acc[u][0][m], 0, 0, 0);
+          acc[u][1][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s01, wv[3][m], acc[u][1][m], 0, 0, 0);
+          acc[u][2][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s10, wv[1][m], acc[u][2][m], 0, 0, 0);
+          acc[u][3][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s11, wv[0][m], acc[u][3][m], 0, 0, 0);
+          acc[u][1][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s00, wv[5][m], acc[u][1][m], 0, 0, 0);
+          acc[u][2][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s00, wv[7][m], acc[u][2][m], 0, 0, 0);
+          acc[u][3][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s10, wv[2][m], acc[u][3][m], 0, 0, 0);
+          acc[u][3][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s01, wv[6][m], acc[u][3][m], 0, 0, 0);
+          acc[u][3][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s00, wv[8][m], acc[u][3][m], 0, 0, 0);
+        }
+        if (G::MT > 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    C3_TS(0);
+    if ((int)(k % G::NCH) == G::NCH - 1) {
+      c3_bar();                                       // X
+      C3_TS(1);
+      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
+      const long b = tile / G::NBAND;
+      const int q0 = (int)(tile - b * G::NBAND) * RQ;
+      const int npix_ok = min(RQ, HO - q0) * WO;
+#pragma unroll
+      for (int u = 0; u < G::TP; ++u) {
+        const int t = w + G::NW * u;
+        const int c0 = t * 16 + 4 * g;
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) {
+          const int ci = m * 16 + j;
+          float* __restrict__ sc = stage + ci * G::MROWP;
+          const unsigned* __restrict__ bc = bitb + ci * G::BITC;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c = c0 + 2 * h;
+            const int qr = c / WO, pc = c - qr * WO;
+            const bool okA = ci < CI && c < npix_ok, okB = ci < CI && c + 1 < npix_ok, split = pc + 1 >= WO;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+              const int ra = 2 * qr + py, xa = 2 * pc;                                    // band row / column of the first pair
+              const int rb = split ? ra + 2 : ra, xb = split ? 0 : xa + 2;
+              const int la = ra * G::W + xa, lb = rb * G::W + xb;
+              float4 v = make_float4(acc[u][py * 2][m][2 * h], acc[u][py * 2 + 1][m][2 * h], acc[u][py * 2][m][2 * h + 1],
+                                     acc[u][py * 2 + 1][m][2 * h + 1]);
+              if (msk) {
+                if (okA) {
+                  const unsigned q2 = bc[ra * G::RW + (xa >> 5)] >> (xa & 31);
+                  if (!(q2 & 1u)) v.x = 0.f;
+                  if (!(q2 & 2u)) v.y = 0.f;
+                }
+                if (okB) {
+                  const unsigned q2 = bc[rb * G::RW + (xb >> 5)] >> (xb & 31);
+                  if (!(q2 & 1u)) v.z = 0.f;
+                  if (!(q2 & 2u)) v.w = 0.f;
+                }
+              }
+              if (okA) {
+                if (WO % 2 == 0 && okB) *reinterpret_cast<float4*>(sc + la) = v;
+                else {
+                  *reinterpret_cast<float2*>(sc + la) = make_float2(v.x, v.y);
+                  if (okB) *reinterpret_cast<float2*>(sc + lb) = make_float2(v.z, v.w);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[u][c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      C3_TS(2);
+    }
+    c3_bar();
+    C3_TS(3);
+  }
+  if (stamp) {
+    p.dbg[0] = tsum[0]; p.dbg[1] = tsum[1]; p.dbg[2] = tsum[2]; p.dbg[3] = tsum[3]; p.dbg[6] = (unsigned long long)nwork;
+  }
+#undef C3_TS
+}
+
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES>
+int c3bs_launch(const C3P& p, hipStream_t st) {
+  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES>;
+  static_assert(G::LDS_BYTES_S <= 160 * 1024, "LDS");
+  const void* k = (const void*)c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES>;
+  static int cus = 0;
+  if (!cus) {
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES_S) != hipSuccess) return A2C_ERR_LAUNCH;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const long total = (long)p.B * G::NBAND;
+  const int grid = (int)(total < cus ? total : cus);
+  hipLaunchKernelGGL((c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES>), dim3(grid), dim3(768), G::LDS_BYTES_S, st, p);
+  if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
+  return A2C_OK;
+}
+
+template <int CS, int CD, int H, int W, int S, int R, bool BWD>
+int c3s_launch(const C3P& p, hipStream_t st) {
+  using G = C3SGeo<CS, CD, H, W, S, R>;
+  static_assert(G::LDS_BYTES_S <= 160 * 1024, "LDS");
+  const void* k = (const void*)c3s_kernel<CS, CD, H, W, S, R, BWD>;
+  static int cus = 0;
+  if (!cus) {
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES_S) != hipSuccess) return A2C_ERR_LAUNCH;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const long total = (long)p.B * G::NBAND;
+  const int grid = (int)(total < cus ? total : cus);
+  hipLaunchKernelGGL((c3s_kernel<CS, CD, H, W, S, R, BWD>), dim3(grid), dim3(768), G::LDS_BYTES_S, st, p);
+  if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
+  return A2C_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Weight gradient: dW[co][ci][ky][kx] = sum over samples and output pixels of dOut[co][oy][ox] * X[ci][S*oy+ky-1][S*ox+kx-1],
 // db[co] = sum dOut.  The same streaming skeleton with the PIXELS as the GEMM's K: one MFMA step = 4 consecutive
 // output pixels of a row; A operand = the input seen through the (ci, ky, kx) window of row n = ci*9 + ky*3 + kx
@@ -799,10 +1568,10 @@ const float* zero_page() {
   return z;
 }
 
-template <int CS, int CD, int H, int W, int S, int R, bool BWD>
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO = 0>
 int c3_launch(const C3P& p, hipStream_t st) {
-  using G = C3Geo<CS, CD, H, W, S, R>;
-  const void* k = (const void*)c3_kernel<CS, CD, H, W, S, R, BWD>;
+  using G = C3Geo<CS, CD, H, W, S, R, KCO>;
+  const void* k = (const void*)c3_kernel<CS, CD, H, W, S, R, BWD, KCO>;
   constexpr size_t LDSB = BWD ? G::LDS_BYTES_BWD : G::LDS_BYTES;
   static_assert(LDSB <= 160 * 1024, "LDS");
   static_assert(!BWD || G::NCH >= 2, "the mask band is staged one chunk ahead of its use");
@@ -818,7 +1587,7 @@ int c3_launch(const C3P& p, hipStream_t st) {
   const long total = (long)p.B * G::NBAND;
   const long cap = (long)per_cu * cus;
   const int grid = (int)(total < cap ? total : cap);
-  hipLaunchKernelGGL((c3_kernel<CS, CD, H, W, S, R, BWD>), dim3(grid), dim3(640), LDSB, st, p);
+  hipLaunchKernelGGL((c3_kernel<CS, CD, H, W, S, R, BWD, KCO>), dim3(grid), dim3(640), LDSB, st, p);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   return A2C_OK;
 }
@@ -840,6 +1609,7 @@ bool c3_supported(const a2c_conv_desc* d, int kind) {
   if (d->ks != 3 || d->pad != 1) return false;
   if (kind == 0 && d->stride == 2 && d->H == 42 && d->W == 42) return (d->Cin == 32 && d->Cout == 64) || (d->Cin == 24 && d->Cout == 32);
   if (kind == 0 && d->stride == 2 && d->H == 21 && d->W == 21) return d->Cin == 32 && d->Cout == 48;
+  if (kind == 0 && d->stride == 2 && d->H == 11 && d->W == 11) return d->Cin == 48 && d->Cout == 64;
   if (d->H != 84 || d->W != 84) return false;
   if (kind == 0) {
     if (d->stride == 1) return (d->Cin == 4 && d->Cout == 16) || (d->Cin == 16 && d->Cout == 24);
@@ -857,6 +1627,13 @@ static bool c3b_shape(const a2c_conv_desc* d) {
          (d->H == 42 && d->W == 42 && ((d->Cin == 32 && d->Cout == 64) || (d->Cin == 24 && d->Cout == 32)));
 }
 
+// source channels per chunk of the layer's kernel (the fragment layout is [chunk][tap][c4][m][64])
+static int c3_kc(const a2c_conv_desc* d, int kind) {
+  const int CS = kind ? d->Cout : d->Cin;
+  if (kind == 0 && d->H == 11 && d->Cin == 48) return 24;      // GRUModel conv5: 6 x 6 outputs, one band per sample, two big chunks
+  return CS >= 8 ? 8 : 4;
+}
+
 size_t c3_prep_floats(const a2c_conv_desc* d, int kind) {
   if (!c3_supported(d, kind)) return 0;
   const int CS = kind ? d->Cout : d->Cin, CD = kind ? d->Cin : d->Cout;
@@ -866,7 +1643,7 @@ size_t c3_prep_floats(const a2c_conv_desc* d, int kind) {
 int c3_prep(const a2c_conv_desc* d, int kind, const float* weight, float* out, hipStream_t st) {
   const long total = (long)c3_prep_floats(d, kind);
   if (!total) return A2C_OK;
-  const int CS = kind ? d->Cout : d->Cin, CD = kind ? d->Cin : d->Cout;
+  const int CD = kind ? d->Cin : d->Cout;
   if (kind == 1 && d->stride == 2) {
     hipLaunchKernelGGL(c3b_prep_kernel, dim3(a2c_grid_1d(total, 256)), dim3(256), 0, st, weight, out, d->Cin, d->Cout, 8,
                        (CD + 15) / 16, total);
@@ -874,34 +1651,72 @@ int c3_prep(const a2c_conv_desc* d, int kind, const float* weight, float* out, h
     return A2C_OK;
   }
   hipLaunchKernelGGL(c3_prep_kernel, dim3(a2c_grid_1d(total, 256)), dim3(256), 0, st, weight, out, d->Cin, d->Cout, kind,
-                     CS >= 8 ? 8 : 4, (CD + 15) / 16, total);
+                     c3_kc(d, kind), (CD + 15) / 16, total);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   return A2C_OK;
 }
 
+// sign words per sample of the layer's OUTPUT ([Cout][OH][ceil(OW/32)]), 0 when its forward cannot write them
+long c3_sign_words(const a2c_conv_desc* d) {
+  if (!c3_supported(d, 0) || d->H == 11) return 0;
+  return (long)d->Cout * d->OH * ((d->OW + 31) / 32);
+}
+// backward-data with the mask given as the sign words of the layer's INPUT ([Cin][H][ceil(W/32)])
+bool c3_bwd_signs_supported(const a2c_conv_desc* d) { return c3_supported(d, 1); }
+
 int c3_fwd(const a2c_conv_desc* d, const float* in, long in_bs, const float* frag, const float* bias, int relu, float* out,
-           long out_bs, int B, hipStream_t st) {
-  C3P p{in, in_bs, frag, bias, nullptr, out, out_bs, zero_page(), B, relu, g_c3_dbg};
+           long out_bs, unsigned* signs, long signs_bs, int B, hipStream_t st) {
+  C3P p{in, in_bs, frag, bias, nullptr, out, out_bs, zero_page(), B, relu, g_c3_dbg, signs, nullptr, signs_bs};
   if (!p.zero) return A2C_ERR_LAUNCH;
-  if (d->stride == 1 && d->H == 84 && d->Cin == 4) return c3_launch<4, 16, 84, 84, 1, 12, false>(p, st);
-  if (d->stride == 1 && d->H == 84 && d->Cin == 16) return c3_launch<16, 24, 84, 84, 1, 12, false>(p, st);
-  if (d->stride == 2 && d->H == 84 && d->Cin == 24) return c3_launch<24, 32, 84, 84, 2, 6, false>(p, st);
-  if (d->stride == 2 && d->H == 84 && d->Cin == 16) return c3_launch<16, 24, 84, 84, 2, 6, false>(p, st);
-  if (d->stride == 2 && d->H == 42 && d->Cin == 32) return c3_launch<32, 64, 42, 42, 2, 11, false>(p, st);
+  if (signs != nullptr) {        // the staged kernels: their storers also carry the sign words
+    if (d->stride == 1 && d->H == 84 && d->Cin == 4) return c3s_launch<4, 16, 84, 84, 1, 12, false>(p, st);
+    if (d->stride == 1 && d->H == 84 && d->Cin == 16) return c3s_launch<16, 24, 84, 84, 1, 6, false>(p, st);
+    if (d->stride == 2 && d->H == 84 && d->Cin == 24) return c3s_launch<24, 32, 84, 84, 2, 6, false>(p, st);
+    if (d->stride == 2 && d->H == 84 && d->Cin == 16) return c3s_launch<16, 24, 84, 84, 2, 6, false>(p, st);
+    if (d->stride == 2 && d->H == 42 && d->Cin == 32) return c3s_launch<32, 64, 42, 42, 2, 11, false>(p, st);
+    if (d->stride == 2 && d->H == 42 && d->Cin == 24) return c3s_launch<24, 32, 42, 42, 2, 11, false>(p, st);
+    if (d->stride == 2 && d->H == 21 && d->Cin == 32) return c3s_launch<32, 48, 21, 21, 2, 11, false>(p, st);
+    return A2C_ERR_ARG;
+  }
+  // Without sign words the direct-store kernels: measured (tools/conv3_check.py, bench.py's rollout site timers) the staged
+  // forward gains 10-20 % only on the store-bound first layer at B >= 256 and loses where a workgroup sees one band (B = 32).
+  // Small batches (one band or less per CU with the tall bands): shorter bands, more workgroups, two per CU.
+  const bool small = B <= 64;
+  if (d->stride == 1 && d->H == 84 && d->Cin == 4)
+    return small ? c3_launch<4, 16, 84, 84, 1, 6, false>(p, st) : c3s_launch<4, 16, 84, 84, 1, 12, false>(p, st);
+  if (d->stride == 1 && d->H == 84 && d->Cin == 16)
+    return small ? c3_launch<16, 24, 84, 84, 1, 6, false>(p, st) : c3_launch<16, 24, 84, 84, 1, 12, false>(p, st);
+  if (d->stride == 2 && d->H == 84 && d->Cin == 24)
+    return small ? c3_launch<24, 32, 84, 84, 2, 3, false>(p, st) : c3_launch<24, 32, 84, 84, 2, 6, false>(p, st);
+  if (d->stride == 2 && d->H == 84 && d->Cin == 16)
+    return small ? c3_launch<16, 24, 84, 84, 2, 3, false>(p, st) : c3_launch<16, 24, 84, 84, 2, 6, false>(p, st);
+  if (d->stride == 2 && d->H == 42 && d->Cin == 32)
+    return small ? c3_launch<32, 64, 42, 42, 2, 3, false>(p, st) : c3_launch<32, 64, 42, 42, 2, 11, false>(p, st);
   if (d->stride == 2 && d->H == 42 && d->Cin == 24) return c3_launch<24, 32, 42, 42, 2, 11, false>(p, st);
   if (d->stride == 2 && d->H == 21 && d->Cin == 32) return c3_launch<32, 48, 21, 21, 2, 11, false>(p, st);
+  if (d->stride == 2 && d->H == 11 && d->Cin == 48) return c3_launch<48, 64, 11, 11, 2, 6, false, 24>(p, st);
   return A2C_ERR_ARG;
 }
 
-int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, const float* mask, float* din, int B,
-                hipStream_t st) {
-  C3P p{dout, (long)d->Cout * d->OH * d->OW, frag, nullptr, mask, din, (long)d->Cin * d->H * d->W, zero_page(), B, 0, g_c3_dbg};
+// mask: the float activation below (the kernels that keep its band in LDS) -- or signs: its sign words (the staged kernels)
+int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, const float* mask, const unsigned* signs,
+                long signs_bs, float* din, int B, hipStream_t st) {
+  C3P p{dout, (long)d->Cout * d->OH * d->OW, frag, nullptr, mask, din, (long)d->Cin * d->H * d->W, zero_page(), B, 0, g_c3_dbg,
+        nullptr, signs, signs_bs};
   if (!p.zero) return A2C_ERR_LAUNCH;
-  if (d->stride == 1 && d->Cin == 16 && d->Cout == 24) return c3_launch<24, 16, 84, 84, 1, 12, true>(p, st);
-  if (d->stride == 2 && d->H == 84 && d->Cin == 24) return c3b_launch<32, 24, 42, 42, 6, 8>(p, st);
-  if (d->stride == 2 && d->H == 84 && d->Cin == 16) return c3b_launch<24, 16, 42, 42, 6, 8>(p, st);
-  if (d->stride == 2 && d->H == 42 && d->Cin == 32) return c3b_launch<64, 32, 21, 21, 11, 8>(p, st);
-  if (d->stride == 2 && d->H == 42 && d->Cin == 24) return c3b_launch<32, 24, 21, 21, 11, 8>(p, st);
+  if (mask != nullptr) {
+    if (d->stride == 1 && d->Cin == 16 && d->Cout == 24) return c3_launch<24, 16, 84, 84, 1, 12, true>(p, st);
+    if (d->stride == 2 && d->H == 84 && d->Cin == 24) return c3b_launch<32, 24, 42, 42, 6, 8>(p, st);
+    if (d->stride == 2 && d->H == 84 && d->Cin == 16) return c3b_launch<24, 16, 42, 42, 6, 8>(p, st);
+    if (d->stride == 2 && d->H == 42 && d->Cin == 32) return c3b_launch<64, 32, 21, 21, 11, 8>(p, st);
+    if (d->stride == 2 && d->H == 42 && d->Cin == 24) return c3b_launch<32, 24, 21, 21, 11, 8>(p, st);
+    return A2C_ERR_ARG;
+  }
+  if (d->stride == 1 && d->Cin == 16 && d->Cout == 24) return c3s_launch<24, 16, 84, 84, 1, 6, true>(p, st);
+  if (d->stride == 2 && d->H == 84 && d->Cin == 24) return c3bs_launch<32, 24, 42, 42, 6, 8, 3, false>(p, st);
+  if (d->stride == 2 && d->H == 84 && d->Cin == 16) return c3bs_launch<24, 16, 42, 42, 6, 8, 4, true>(p, st);
+  if (d->stride == 2 && d->H == 42 && d->Cin == 32) return c3bs_launch<64, 32, 21, 21, 11, 8, 2, false>(p, st);
+  if (d->stride == 2 && d->H == 42 && d->Cin == 24) return c3bs_launch<32, 24, 21, 21, 11, 8, 3, true>(p, st);
   return A2C_ERR_ARG;
 }
 

@@ -464,6 +464,66 @@ def test_conv2d_fwd_bwd(spec):
     close("bwd_bias", db, br.grad, 1e-5 * float(br.grad.abs().max()), 1e-5)
 
 
+def _sign_words(t):
+    """(B, C, H, W) bool -> (B, C*H*ceil(W/32)) int32: bit x & 31 of word [c][y][x >> 5] (a2c_conv2d_fwd_signs' layout)"""
+    B, C, H, W = t.shape
+    RW = (W + 31) // 32
+    pad = torch.zeros(B, C, H, RW * 32, dtype=torch.bool)
+    pad[..., :W] = t
+    words = (pad.reshape(B, C, H, RW, 32).long() * (2 ** torch.arange(32, dtype=torch.int64))).sum(-1)
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).int().reshape(B, -1).contiguous()
+
+
+SIGN_SPECS = [s for s in CONV_SPECS if s[4] == 3 and s[1] in (84, 42, 21)]
+
+
+@pytest.mark.parametrize("spec", SIGN_SPECS, ids=[str(s) for s in SIGN_SPECS])
+@pytest.mark.parametrize("B", [3, 300])
+def test_conv2d_sign_words(spec, B):
+    """The ReLU mask as one bit per activation: a2c_conv2d_fwd_signs leaves (out > 0) next to the output (which is the
+    plain forward's, bit for bit), a2c_conv2d_bwd_data_signs masks with those bits exactly as a2c_conv2d_bwd_data does
+    with the float activation.  B = 300: several bands per workgroup (the staged kernels' pipeline), rows of a wider
+    sign buffer (whatever lies between the rows is not touched)."""
+    ops = _ops()
+    Cin, H, W, Cout, ks, s, p = spec
+    d = ops.conv_desc(*spec)
+    x = rnd((B, Cin, H, W), 190, 0, 1)
+    w = rnd((Cout, Cin, ks, ks), 191) / (Cin * ks * ks) ** 0.5
+    bias = rnd((Cout,), 192) * 0.1
+    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+    wf = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
+    wb = torch.empty(ops.conv_prep_floats(d, 1), device=DEV)
+    ops.conv_prep(d, 0, wd, wf)
+    ops.conv_prep(d, 1, wd, wb)
+    nsw = ops.conv_sign_words(d)
+    assert nsw == Cout * d.OH * ((d.OW + 31) // 32)
+    ref = torch.empty(B, Cout, d.OH, d.OW, device=DEV)
+    ops.conv_fwd(d, xd.data_ptr(), Cin * H * W, wf, bd, True, ref, B)
+    close("fwd", ref, F.relu(F.conv2d(x, w, bias, stride=s, padding=p)), 2e-6, 1e-5)
+    out = torch.full_like(ref, float("nan"))
+    sg = torch.full((B, nsw + 5), -7, dtype=torch.int32, device=DEV)
+    ops.conv_fwd_signs(d, xd.data_ptr(), Cin * H * W, wf, bd, True, out, sg.data_ptr(), nsw + 5, B)
+    assert torch.equal(out, ref)
+    assert torch.equal(sg[:, :nsw].cpu(), _sign_words(ref.cpu() > 0)) and bool((sg[:, nsw:] == -7).all())
+    if not ops.conv_bwd_data_signs_supported(d):
+        return
+    dout = rnd((B, Cout, d.OH, d.OW), 193).to(DEV)
+    mask = rnd((B, Cin, H, W), 194)
+    words = _sign_words(mask > 0).to(DEV)
+    din_f = torch.full((B, Cin, H, W), float("nan"), device=DEV)
+    din_s = torch.full((B, Cin, H, W), float("nan"), device=DEV)
+    ops.conv_bwd_data(d, dout, wb, mask.to(DEV), din_f, B)
+    ops.conv_bwd_data_signs(d, dout, wb, words, din_s, B)
+    assert torch.equal(din_s, din_f)
+    if B == 3:
+        want = F.conv_transpose2d(dout.cpu(), w, stride=s, padding=p, output_padding=(H + 2 * p - ks) % s)
+        close("bwd_data", din_s, want * (mask > 0), 2e-6, 1e-5)
+        ops.conv_bwd_data(d, dout, wb, None, din_f, B)
+        ops.conv_bwd_data_signs(d, dout, wb, None, din_s, B)
+        assert torch.equal(din_s, din_f)
+        close("bwd_data no mask", din_s, want, 2e-6, 1e-5)
+
+
 @pytest.mark.parametrize("s2,hw,B", [(2, (84, 84), 5), (1, (84, 84), 3), (2, (20, 24), 37), (1, (12, 16), 300)])
 def test_conv2d_bwd_data_fused_with_first_layer_weight_gradient(s2, hw, B, monkeypatch):
     """conv1 (4 -> 16, 3x3/1/1) + ReLU + conv2 (16 -> 24, 3x3/s2 (GRUModel) or s1 (ConvModel)): da1 = conv2's masked

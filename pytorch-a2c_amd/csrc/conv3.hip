@@ -32,6 +32,25 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
+// Global stores of the kernels below go through inline asm: in a kernel that issues LDS-DMA hipcc's waitcnt insertion puts
+// `s_waitcnt vmcnt(0)` in front of an LDS read whenever the wave has a vector-memory operation of its own in flight -- after
+// an epilogue that is a wait for the acknowledgement of every output store (2-4 us under load) in front of the next band's
+// first MFMA operand.  Stores it cannot see, it does not wait for (nothing here ever reads back what it stored).
+// (s_nop 1: the hazard recognizer does not see them either -- a store of more than 8 bytes needs 2 wait states before a
+// VALU instruction may overwrite its data registers.)
+__device__ __forceinline__ void c3_gstore128(float* p, const float4 v) {
+  const f32x4 q = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ void c3_gstore64(float* p, const float2 v) {
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+  const f32x2 q = {v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ void c3_gstore32(float* p, const float v) {
+  asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
 struct C3P {
   const float* src; long src_bs;      // source tensor (B, CS, H, W) and its sample stride (floats)
   const float* frag;                  // [chunk][tap][c4][m][64] weight fragments (c3_prep_kernel)
@@ -275,12 +294,12 @@ __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
           }
           float* __restrict__ o = p.out + o0 + (long)cd * G::OH * G::OW + p0;
           if (cd < CD) {
-            if (G::VEC && p0 + 3 < npix_ok) *reinterpret_cast<float4*>(o) = v;
+            if (G::VEC && p0 + 3 < npix_ok) c3_gstore128(o, v);
             else {                                             // rows that are not 16-byte aligned / the band's ragged end
-              if (p0 < npix_ok) o[0] = v.x;
-              if (p0 + 1 < npix_ok) o[1] = v.y;
-              if (p0 + 2 < npix_ok) o[2] = v.z;
-              if (p0 + 3 < npix_ok) o[3] = v.w;
+              if (p0 < npix_ok) c3_gstore32(o, v.x);
+              if (p0 + 1 < npix_ok) c3_gstore32(o + 1, v.y);
+              if (p0 + 2 < npix_ok) c3_gstore32(o + 2, v.z);
+              if (p0 + 3 < npix_ok) c3_gstore32(o + 3, v.w);
             }
           }
           acc[u][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -512,10 +531,10 @@ __global__ __launch_bounds__(640) void c3b_kernel(C3P p) {
                 }
               }
               if (okA) {
-                if (okB && !split) *reinterpret_cast<float4*>(oc + la) = v;
+                if (okB && !split) c3_gstore128(oc + la, v);
                 else {
-                  *reinterpret_cast<float2*>(oc + la) = make_float2(v.x, v.y);
-                  if (okB) *reinterpret_cast<float2*>(oc + lb) = make_float2(v.z, v.w);
+                  c3_gstore64(oc + la, make_float2(v.x, v.y));
+                  if (okB) c3_gstore64(oc + lb, make_float2(v.z, v.w));
                 }
               }
             }

@@ -365,6 +365,7 @@ def loss_fwd_bwd(logits, vals, actions, advs, returns, adv_sums, n_global, pi_co
 # ---------------------------------------------------------------- dense
 def pick_splitk(M, N, K, target_wgs=512, min_k=32):
     min_k = int(os.environ.get("A2C_SPLITK_MIN_K", min_k))
+    target_wgs = int(os.environ.get("A2C_SPLITK_TARGET", target_wgs))
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= target_wgs // 2:
         return 1

@@ -237,8 +237,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // register j of both quads is one v_mfma_f32_32x32x2_f32 (the k-pair {k + j, k + 4 + j} is the same on both
 // operands, which is all the instruction needs).  A row is read as one forward stream of 32 B pieces, SK_U loads
 // in flight per lane.  Partials go to the split-K slabs; splitk_reduce_kernel applies the epilogue as before.
-constexpr int SK_U = 4;
-template <int MB>
+template <int MB, int SK_U>
 __global__ __launch_bounds__(256) void skinny_stream_kernel(long M, long N, long K, const float* __restrict__ X, long ldx,
                                                             const float* __restrict__ W, long ldw, long k_per_split,
                                                             float* __restrict__ slab) {
@@ -306,8 +305,156 @@ static bool launch_skinny_stream(long M, long N, long K, const float* A, long ld
   if (M > 64 || splits < 2 || !vecA || !vecB || K % 8 || kps % 8 || N * K < (1L << 22) || getenv("A2C_NO_SKINNY_STREAM"))
     return false;
   dim3 grid((unsigned)((N + 127) / 128), (unsigned)splits);
-  if (M <= 32) hipLaunchKernelGGL(skinny_stream_kernel<1>, grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
-  else hipLaunchKernelGGL(skinny_stream_kernel<2>, grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
+  static const int sku = getenv("A2C_SK_U") ? atoi(getenv("A2C_SK_U")) : 4;
+  if (M <= 32) {
+    if (sku == 8) hipLaunchKernelGGL((skinny_stream_kernel<1, 8>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
+    else hipLaunchKernelGGL((skinny_stream_kernel<1, 4>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
+  } else hipLaunchKernelGGL((skinny_stream_kernel<2, 4>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
+  return true;
+}
+
+// Rollout-batch forward of the big dense layers (64 < M <= 256 rows against a k-contiguous weight matrix: ConvModel's
+// 256 x 28224 times 2000 x 28224 is 29 GFLOP per env step): matrix-bound, and the block-tiled kernel above spends its
+// time between two barriers per 16-deep step with register staging (83 TF).  Here:
+//   * a workgroup owns ALL rows (256 x 128 tile: the weights are read once), K split over the grid (slabs as above);
+//   * both operands arrive k-contiguous, so a lane's MFMA operands for FOUR instructions are one 16-byte LDS read: lane
+//     (i, h) holds row i, columns k0 + 4h .. k0 + 4h + 3, and component j of both operands is the k-pair
+//     {k0 + j, k0 + 4 + j} of one v_mfma_f32_32x32x2_f32 -- no transposing stores, 4 ds_read_b128 per 16 MFMAs;
+//   * 32-deep K tiles come in by LDS-DMA (global_load_lds_dwordx4, full 128-byte lines, 8 rows per instruction) from
+//     two loader waves into a ring of three 48 KB stages, two tiles ahead of the eight computing waves, counted vmcnt,
+//     one raw barrier per tile; the 16-byte pieces of a row are XOR-swizzled by (row >> 1) & 7 on the SOURCE address, so
+//     the LDS image is lane-linear for the DMA and conflict-free for the ds_read_b128 lane groups;
+//   * sums per output element: k ascending inside a slab, slabs in fixed order -- the order of gemm_kernel's split-K.
+// Measured at 256 x 28224 x 2000, 16 slabs (tools/gemm_check.py): 307 us with the reduce (94 TF) against gemm_kernel's 337;
+// with the DMA switched off after the first tiles (wrong sums, same MFMA stream) 259 us -- the fp32 matrix rate this
+// chip sustains (111 TF of the nominal 157) -- and no faster with every DMA reading one cache-resident tile: what is left
+// is what 48 LDS-DMA instructions per tile cost the CU beside 128 MFMAs per wave, not memory.  Four loader waves at raised
+// priority instead of two at default: 337 -> 307 us.
+namespace nt {
+constexpr int TM = 256, TN = 128, BKT = 32, NW = 8, NL = 4, DEPTH = 3;
+constexpr int AF = TM * BKT, BF = TN * BKT, STG = AF + BF;     // floats per stage
+constexpr size_t LDS_BYTES = (size_t)DEPTH * STG * 4;
+constexpr int NIA = TM / 8, NIB = TN / 8;                      // DMA instructions per tile (8 rows x 128 B each)
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+template <int N_>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+__device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+}  // namespace nt
+
+__global__ __launch_bounds__(64 * (nt::NW + nt::NL)) void gemm_nt_kernel(long M, long N, long K, const float* __restrict__ X, long ldx,
+                                                      const float* __restrict__ W, long ldw, long k_per_split,
+                                                      float* __restrict__ slab, const float* __restrict__ zero) {
+  using namespace nt;
+  constexpr int NI = (NIA + NIB) / NL;                           // DMA instructions per tile per loader wave
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long n0 = (long)blockIdx.x * TN;
+  const long kbeg = (long)blockIdx.y * k_per_split, kend = min(K, kbeg + k_per_split);
+  const int nt_ = (int)((kend - kbeg + BKT - 1) / BKT);          // K tiles of this split
+  if (w >= NW) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = w - NW;
+    __builtin_amdgcn_s_setprio(3);                               // (the computing waves never wait on anything but these)
+    const int r8 = lane >> 3, s8 = lane & 7;
+    // piece s8 of LDS row r holds the row's 16-byte piece s8 ^ ((r >> 1) & 7); r = 8 q + r8: (r >> 1) & 7 = ((q & 1) * 4 + (r8 >> 1)) & 7
+    const int ce = s8 ^ (r8 >> 1), co = s8 ^ (4 + (r8 >> 1));    // source piece for even / odd q
+    auto dma = [&](int t) {
+      float* __restrict__ st = lds + (t % DEPTH) * STG;
+      const long k0 = kbeg + (long)t * BKT;
+      const int kval = (int)min((long)BKT, kend - k0);           // valid columns of this tile (a multiple of 4)
+#pragma unroll
+      for (int q = 0; q < NIA + NIB; ++q) {
+        if (q % NL != lw) continue;
+        const bool isA = q < NIA;
+        const int qq = isA ? q : q - NIA;
+        const long row = (isA ? 0 : n0) + 8 * qq + r8;
+        const int c = (qq & 1) ? co : ce;
+        const bool ok = row < (isA ? M : N) && 4 * c + 4 <= kval;
+        const float* gsrc = ok ? (isA ? X + row * ldx : W + row * ldw) + k0 + 4 * c : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(st + (isA ? 0 : AF) + qq * 256), 16, 0, 0);
+      }
+    };
+    if (nt_ > 0) dma(0);
+    if (nt_ > 1) dma(1);
+    if (nt_ > 1) wait_vm<NI>(); else wait_vm<0>();
+    bar();
+    for (int t = 0; t < nt_; ++t) {
+      if (t + 2 < nt_) dma(t + 2);                               // into the stage tile t - 1 left
+      if (t + 2 < nt_) wait_vm<NI>(); else wait_vm<0>();         // tile t + 1 has landed, t + 2 stays in flight
+      bar();
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- computing waves: 4 (M) x 2 (N), 64 x 64 each
+  const int wm = w >> 1, wn = w & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  int aoff[2], boff[2], asw[2], bsw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wm * 64 + i * 32 + li, rb = wn * 64 + i * 32 + li;
+    aoff[i] = ra * BKT; asw[i] = (ra >> 1) & 7;
+    boff[i] = AF + rb * BKT; bsw[i] = (rb >> 1) & 7;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bar();
+  for (int t = 0; t < nt_; ++t) {
+    const float* __restrict__ st = lds + (t % DEPTH) * STG;
+#pragma unroll
+    for (int q = 0; q < BKT / 8; ++q) {
+      const int c = 2 * q + lh;
+      const float4 a0 = *reinterpret_cast<const float4*>(st + aoff[0] + 4 * (c ^ asw[0]));
+      const float4 a1 = *reinterpret_cast<const float4*>(st + aoff[1] + 4 * (c ^ asw[1]));
+      const float4 b0 = *reinterpret_cast<const float4*>(st + boff[0] + 4 * (c ^ bsw[0]));
+      const float4 b1 = *reinterpret_cast<const float4*>(st + boff[1] + 4 * (c ^ bsw[1]));
+#define NT_STEP(J)                                                                              \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.J, b0.J, acc[0][0], 0, 0, 0);           \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.J, b1.J, acc[0][1], 0, 0, 0);           \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.J, b0.J, acc[1][0], 0, 0, 0);           \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.J, b1.J, acc[1][1], 0, 0, 0);
+      NT_STEP(x) NT_STEP(y) NT_STEP(z) NT_STEP(w)
+#undef NT_STEP
+    }
+    bar();
+  }
+  // D map of a 32x32 tile: col (n) = lane & 31, row (m) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float* __restrict__ out = slab + (long)blockIdx.y * M * N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long n = n0 + wn * 64 + j * 32 + li;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M) out[m * N + n] = acc[i][j][r];
+      }
+    }
+}
+
+// the same [split][M][N] slabs as gemm_kernel; true = launched
+static bool launch_gemm_nt(long M, long N, long K, const float* A, long lda, const float* B, long ldb, long kps, int splits,
+                           float* slab, int vecA, int vecB, hipStream_t st) {
+  if (M <= 64 || M > nt::TM || splits < 2 || !vecA || !vecB || K % 4 || kps % 4 || N * K < (1L << 22) || getenv("A2C_NO_GEMM_NT"))
+    return false;
+  static float* zero = nullptr;
+  static bool ready = false;
+  if (!ready) {
+    if (hipMalloc(&zero, 256) != hipSuccess || hipMemset(zero, 0, 256) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nt::LDS_BYTES) != hipSuccess)
+      return false;
+    ready = true;
+  }
+  dim3 grid((unsigned)((N + nt::TN - 1) / nt::TN), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(64 * (nt::NW + nt::NL)), nt::LDS_BYTES, st, M, N, K, A, lda, B, ldb, kps, slab,
+                     (const float*)zero);
   return true;
 }
 
@@ -819,6 +966,7 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   hipStream_t st = a2c_s(stream);
   const bool a_kc = (transA == 0), b_kc = (transB != 0);
   if (a_kc && b_kc && launch_skinny_stream(M, N, K, A, lda, B, ldb, kps, splitk, slab, vecA, vecB, st)) {}
+  else if (a_kc && b_kc && launch_gemm_nt(M, N, K, A, lda, B, ldb, kps, splitk, slab, vecA, vecB, st)) {}
   else if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
   else if (a_kc && !b_kc) launch_gemm<true, false>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
   else if (!a_kc && b_kc) launch_gemm<false, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
@@ -856,6 +1004,7 @@ int a2c_gemm_f32_partial(int transA, int transB, int64_t M, int64_t N, int64_t K
   float* slab = (float*)ws;
   const bool a_kc = (transA == 0), b_kc = (transB != 0);
   if (a_kc && b_kc && launch_skinny_stream(M, N, K, A, lda, B, ldb, kps, splits, slab, vecA, vecB, st)) {}
+  else if (a_kc && b_kc && launch_gemm_nt(M, N, K, A, lda, B, ldb, kps, splits, slab, vecA, vecB, st)) {}
   else if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
   else if (a_kc && !b_kc) launch_gemm<true, false>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
   else if (!a_kc && b_kc) launch_gemm<false, true>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);

@@ -398,6 +398,28 @@ def test_gemm_skinny_head_paths():
     close("heads bwd_weight", dW, want, 1e-5 * float(want.abs().max()), 1e-5)
 
 
+@pytest.mark.parametrize("M", [65, 100, 256])
+def test_gemm_rollout_batch_forward_against_long_k_contiguous_weights(M, monkeypatch):
+    """64 < M <= 256 rows against a big k-contiguous weight matrix (ConvModel's resize_emb at the rollout batch of
+    configs 4 / 5): the LDS-DMA kernel (gemm_nt_kernel: all rows in one tile, split K, ragged last column tile, K tail
+    shorter than a 32-deep tile) against fp64 and against the block-tiled kernel it replaces."""
+    ops = _ops()
+    N, K = 300, 14008                    # 3 column tiles (the last 44 wide); N * K >= 2^22; K % 32 == 24
+    x = rnd((M, K + 4), 300).to(DEV)     # lda > K
+    W = (rnd((N, K), 301) * 0.05).to(DEV)
+    b = rnd((N,), 302).to(DEV)
+    sk = 6
+    ws = torch.empty(ops.gemm_ws_bytes(M, N, sk) // 4, device=DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(0, 1, M, N, K, x.data_ptr(), K + 4, W.data_ptr(), K, out.data_ptr(), N, bias=b, relu=True, splitk=sk, ws=ws)
+    want = torch.relu(x[:, :K].cpu().double() @ W.cpu().double().t() + b.cpu().double())
+    close("gemm_nt", out, want, 1e-5 * float(want.abs().max()), 1e-5)
+    monkeypatch.setenv("A2C_NO_GEMM_NT", "1")
+    ref = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(0, 1, M, N, K, x.data_ptr(), K + 4, W.data_ptr(), K, ref.data_ptr(), N, bias=b, relu=True, splitk=sk, ws=ws)
+    close("gemm_nt vs tiled", out, ref, 1e-5 * float(want.abs().max()), 1e-5)
+
+
 def test_gemm_strided_views_and_colsum():
     ops = _ops()
     M, N, K = 70, 5, 33

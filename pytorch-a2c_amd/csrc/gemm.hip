@@ -329,27 +329,42 @@ static bool launch_skinny_stream(long M, long N, long K, const float* A, long ld
 // with the DMA switched off after the first tiles (wrong sums, same MFMA stream) 259 us -- the fp32 matrix rate this
 // chip sustains (111 TF of the nominal 157) -- and no faster with every DMA reading one cache-resident tile: what is left
 // is what 48 LDS-DMA instructions per tile cost the CU beside 128 MFMAs per wave, not memory.  Four loader waves at raised
-// priority instead of two at default: 337 -> 307 us.
+// priority instead of two at default: 337 -> 307 us.  M <= 32 (the 32 x 256 shape, 226 MB of weights per step): 61 us against
+// skinny_stream_kernel's 64 on the same box, 3.7 TB/s; reading the same bytes from a tile-major copy of the weights (32 KB
+// contiguous per tile instead of 256 rows x 128 B) changed nothing -- it is not the access pattern.
 namespace nt {
-constexpr int TM = 256, TN = 128, BKT = 32, NW = 8, NL = 4, DEPTH = 3;
-constexpr int AF = TM * BKT, BF = TN * BKT, STG = AF + BF;     // floats per stage
-constexpr size_t LDS_BYTES = (size_t)DEPTH * STG * 4;
-constexpr int NIA = TM / 8, NIB = TN / 8;                      // DMA instructions per tile (8 rows x 128 B each)
+constexpr int BKT = 32, NW = 8, NL = 4;
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 template <int N_>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 __device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// TM x TN block tile, the 8 computing waves WM (M) x WN (N): 256 x 128 as 4 x 2 (64 x 64 per wave) for the rollout batch of
+// configs 4 / 5; 32 x 256 as 1 x 8 (one 32 x 32 tile per wave) for M <= 32, where the product is the weight STREAM
+// (ConvModel at 32 envs: 226 MB per env step) and the x rows ride in the same ring (4 KB per tile).
+template <int TM_, int TN_, int WM_, int DEPTH_>
+struct Shape {
+  static constexpr int TM = TM_, TN = TN_, WM = WM_, WN = NW / WM_, DEPTH = DEPTH_;
+  static constexpr int IM = TM / WM / 32, JN = TN / WN / 32;            // 32 x 32 tiles per wave
+  static constexpr int AF = TM * BKT, BF = TN * BKT, STG = AF + BF;     // floats per stage
+  static constexpr size_t LDS_BYTES = (size_t)DEPTH * STG * 4;
+  static constexpr int NIA = TM / 8, NIB = TN / 8;                      // DMA instructions per tile (8 rows x 128 B each)
+  static constexpr int NI = (NIA + NIB) / NL;                           // ... per loader wave
+  static_assert((NIA + NIB) % NL == 0 && (DEPTH - 2) * NI <= 63 && DEPTH >= 3 && DEPTH <= 4 && LDS_BYTES <= 160 * 1024, "shape");
+};
+using Big = Shape<256, 128, 4, 3>;
+using Skinny = Shape<32, 256, 1, 4>;
 }  // namespace nt
 
+template <class S>
 __global__ __launch_bounds__(64 * (nt::NW + nt::NL)) void gemm_nt_kernel(long M, long N, long K, const float* __restrict__ X, long ldx,
-                                                      const float* __restrict__ W, long ldw, long k_per_split,
-                                                      float* __restrict__ slab, const float* __restrict__ zero) {
+                                                                        const float* __restrict__ W, long ldw, long k_per_split,
+                                                                        float* __restrict__ slab, const float* __restrict__ zero) {
   using namespace nt;
-  constexpr int NI = (NIA + NIB) / NL;                           // DMA instructions per tile per loader wave
+  constexpr int LOOK = S::DEPTH - 1;                             // tiles in flight ahead of the one being computed
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const long n0 = (long)blockIdx.x * TN;
+  const long n0 = (long)blockIdx.x * S::TN;
   const long kbeg = (long)blockIdx.y * k_per_split, kend = min(K, kbeg + k_per_split);
   const int nt_ = (int)((kend - kbeg + BKT - 1) / BKT);          // K tiles of this split
   if (w >= NW) {
@@ -360,64 +375,75 @@ __global__ __launch_bounds__(64 * (nt::NW + nt::NL)) void gemm_nt_kernel(long M,
     // piece s8 of LDS row r holds the row's 16-byte piece s8 ^ ((r >> 1) & 7); r = 8 q + r8: (r >> 1) & 7 = ((q & 1) * 4 + (r8 >> 1)) & 7
     const int ce = s8 ^ (r8 >> 1), co = s8 ^ (4 + (r8 >> 1));    // source piece for even / odd q
     auto dma = [&](int t) {
-      float* __restrict__ st = lds + (t % DEPTH) * STG;
+      float* __restrict__ st = lds + (t % S::DEPTH) * S::STG;
       const long k0 = kbeg + (long)t * BKT;
       const int kval = (int)min((long)BKT, kend - k0);           // valid columns of this tile (a multiple of 4)
 #pragma unroll
-      for (int q = 0; q < NIA + NIB; ++q) {
+      for (int q = 0; q < S::NIA + S::NIB; ++q) {
         if (q % NL != lw) continue;
-        const bool isA = q < NIA;
-        const int qq = isA ? q : q - NIA;
+        const bool isA = q < S::NIA;
+        const int qq = isA ? q : q - S::NIA;
         const long row = (isA ? 0 : n0) + 8 * qq + r8;
         const int c = (qq & 1) ? co : ce;
         const bool ok = row < (isA ? M : N) && 4 * c + 4 <= kval;
         const float* gsrc = ok ? (isA ? X + row * ldx : W + row * ldw) + k0 + 4 * c : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(st + (isA ? 0 : AF) + qq * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(st + (isA ? 0 : S::AF) + qq * 256), 16, 0, 0);
       }
     };
-    if (nt_ > 0) dma(0);
-    if (nt_ > 1) dma(1);
-    if (nt_ > 1) wait_vm<NI>(); else wait_vm<0>();
+    // before the barrier that opens tile t1: everything up to t1 has landed, the younger tiles stay in flight
+    auto wait_for = [&](int t1) {
+      int m = min(t1 + LOOK - 1, nt_ - 1) - t1;
+      if (LOOK >= 3 && m >= 2) wait_vm<(LOOK >= 3 ? 2 : 0) * S::NI>();
+      else if (m >= 1) wait_vm<S::NI>();
+      else wait_vm<0>();
+    };
+    for (int t = 0; t < LOOK; ++t)
+      if (t < nt_) dma(t);
+    wait_for(0);
     bar();
     for (int t = 0; t < nt_; ++t) {
-      if (t + 2 < nt_) dma(t + 2);                               // into the stage tile t - 1 left
-      if (t + 2 < nt_) wait_vm<NI>(); else wait_vm<0>();         // tile t + 1 has landed, t + 2 stays in flight
+      if (t + LOOK < nt_) dma(t + LOOK);                         // into the stage tile t - 1 left
+      wait_for(t + 1);
       bar();
     }
     return;
   }
-  // -------------------------------------------------------------------- computing waves: 4 (M) x 2 (N), 64 x 64 each
-  const int wm = w >> 1, wn = w & 1;
+  // -------------------------------------------------------------------- computing waves: WM (M) x WN (N)
+  const int wm = w / S::WN, wn = w % S::WN;
   const int li = lane & 31, lh = lane >> 5;
-  int aoff[2], boff[2], asw[2], bsw[2];
+  int aoff[S::IM], asw[S::IM], boff[S::JN], bsw[S::JN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ra = wm * 64 + i * 32 + li, rb = wn * 64 + i * 32 + li;
+  for (int i = 0; i < S::IM; ++i) {
+    const int ra = (wm * S::IM + i) * 32 + li;
     aoff[i] = ra * BKT; asw[i] = (ra >> 1) & 7;
-    boff[i] = AF + rb * BKT; bsw[i] = (rb >> 1) & 7;
   }
-  f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < S::JN; ++j) {
+    const int rb = (wn * S::JN + j) * 32 + li;
+    boff[j] = S::AF + rb * BKT; bsw[j] = (rb >> 1) & 7;
+  }
+  f32x16 acc[S::IM][S::JN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+  for (int i = 0; i < S::IM; ++i)
+#pragma unroll
+    for (int j = 0; j < S::JN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   bar();
   for (int t = 0; t < nt_; ++t) {
-    const float* __restrict__ st = lds + (t % DEPTH) * STG;
+    const float* __restrict__ st = lds + (t % S::DEPTH) * S::STG;
 #pragma unroll
     for (int q = 0; q < BKT / 8; ++q) {
       const int c = 2 * q + lh;
-      const float4 a0 = *reinterpret_cast<const float4*>(st + aoff[0] + 4 * (c ^ asw[0]));
-      const float4 a1 = *reinterpret_cast<const float4*>(st + aoff[1] + 4 * (c ^ asw[1]));
-      const float4 b0 = *reinterpret_cast<const float4*>(st + boff[0] + 4 * (c ^ bsw[0]));
-      const float4 b1 = *reinterpret_cast<const float4*>(st + boff[1] + 4 * (c ^ bsw[1]));
-#define NT_STEP(J)                                                                              \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.J, b0.J, acc[0][0], 0, 0, 0);           \
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.J, b1.J, acc[0][1], 0, 0, 0);           \
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.J, b0.J, acc[1][0], 0, 0, 0);           \
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.J, b1.J, acc[1][1], 0, 0, 0);
+      float4 a[S::IM], b[S::JN];
+#pragma unroll
+      for (int i = 0; i < S::IM; ++i) a[i] = *reinterpret_cast<const float4*>(st + aoff[i] + 4 * (c ^ asw[i]));
+#pragma unroll
+      for (int j = 0; j < S::JN; ++j) b[j] = *reinterpret_cast<const float4*>(st + boff[j] + 4 * (c ^ bsw[j]));
+#define NT_STEP(J)                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < S::IM; ++i)                                                \
+        _Pragma("unroll") for (int j = 0; j < S::JN; ++j)                                              \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].J, b[j].J, acc[i][j], 0, 0, 0);
       NT_STEP(x) NT_STEP(y) NT_STEP(z) NT_STEP(w)
 #undef NT_STEP
     }
@@ -426,36 +452,44 @@ __global__ __launch_bounds__(64 * (nt::NW + nt::NL)) void gemm_nt_kernel(long M,
   // D map of a 32x32 tile: col (n) = lane & 31, row (m) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* __restrict__ out = slab + (long)blockIdx.y * M * N;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < S::IM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long n = n0 + wn * 64 + j * 32 + li;
+    for (int j = 0; j < S::JN; ++j) {
+      const long n = n0 + (wn * S::JN + j) * 32 + li;
       if (n >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long m = (wm * S::IM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m < M) out[m * N + n] = acc[i][j][r];
       }
     }
 }
 
 // the same [split][M][N] slabs as gemm_kernel; true = launched
-static bool launch_gemm_nt(long M, long N, long K, const float* A, long lda, const float* B, long ldb, long kps, int splits,
-                           float* slab, int vecA, int vecB, hipStream_t st) {
-  if (M <= 64 || M > nt::TM || splits < 2 || !vecA || !vecB || K % 4 || kps % 4 || N * K < (1L << 22) || getenv("A2C_NO_GEMM_NT"))
-    return false;
+template <class S>
+static bool launch_gemm_nt_shape(long M, long N, long K, const float* A, long lda, const float* B, long ldb, long kps, int splits,
+                                 float* slab, hipStream_t st) {
   static float* zero = nullptr;
   static bool ready = false;
   if (!ready) {
     if (hipMalloc(&zero, 256) != hipSuccess || hipMemset(zero, 0, 256) != hipSuccess) return false;
-    if (hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nt::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_nt_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES) != hipSuccess)
       return false;
     ready = true;
   }
-  dim3 grid((unsigned)((N + nt::TN - 1) / nt::TN), (unsigned)splits);
-  hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(64 * (nt::NW + nt::NL)), nt::LDS_BYTES, st, M, N, K, A, lda, B, ldb, kps, slab,
+  dim3 grid((unsigned)((N + S::TN - 1) / S::TN), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_nt_kernel<S>, grid, dim3(64 * (nt::NW + nt::NL)), S::LDS_BYTES, st, M, N, K, A, lda, B, ldb, kps, slab,
                      (const float*)zero);
   return true;
+}
+
+static bool launch_gemm_nt(long M, long N, long K, const float* A, long lda, const float* B, long ldb, long kps, int splits,
+                           float* slab, int vecA, int vecB, hipStream_t st) {
+  if (M > nt::Big::TM || splits < 2 || !vecA || !vecB || K % 4 || kps % 4 || N * K < (1L << 22) || getenv("A2C_NO_GEMM_NT"))
+    return false;
+  if (M <= nt::Skinny::TM) return launch_gemm_nt_shape<nt::Skinny>(M, N, K, A, lda, B, ldb, kps, splits, slab, st);
+  if (M <= 64) return false;                       // (33 .. 64 rows: skinny_stream_kernel<2>)
+  return launch_gemm_nt_shape<nt::Big>(M, N, K, A, lda, B, ldb, kps, splits, slab, st);
 }
 
 // Small products (the GRU cell's h x h and x x 3h GEMMs at rollout / BPTT batch, M = n_envs: a handful of
@@ -965,8 +999,8 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)splitk);
   hipStream_t st = a2c_s(stream);
   const bool a_kc = (transA == 0), b_kc = (transB != 0);
-  if (a_kc && b_kc && launch_skinny_stream(M, N, K, A, lda, B, ldb, kps, splitk, slab, vecA, vecB, st)) {}
-  else if (a_kc && b_kc && launch_gemm_nt(M, N, K, A, lda, B, ldb, kps, splitk, slab, vecA, vecB, st)) {}
+  if (a_kc && b_kc && launch_gemm_nt(M, N, K, A, lda, B, ldb, kps, splitk, slab, vecA, vecB, st)) {}
+  else if (a_kc && b_kc && launch_skinny_stream(M, N, K, A, lda, B, ldb, kps, splitk, slab, vecA, vecB, st)) {}
   else if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
   else if (a_kc && !b_kc) launch_gemm<true, false>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
   else if (!a_kc && b_kc) launch_gemm<false, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);
@@ -1003,8 +1037,8 @@ int a2c_gemm_f32_partial(int transA, int transB, int64_t M, int64_t N, int64_t K
   hipStream_t st = a2c_s(stream);
   float* slab = (float*)ws;
   const bool a_kc = (transA == 0), b_kc = (transB != 0);
-  if (a_kc && b_kc && launch_skinny_stream(M, N, K, A, lda, B, ldb, kps, splits, slab, vecA, vecB, st)) {}
-  else if (a_kc && b_kc && launch_gemm_nt(M, N, K, A, lda, B, ldb, kps, splits, slab, vecA, vecB, st)) {}
+  if (a_kc && b_kc && launch_gemm_nt(M, N, K, A, lda, B, ldb, kps, splits, slab, vecA, vecB, st)) {}
+  else if (a_kc && b_kc && launch_skinny_stream(M, N, K, A, lda, B, ldb, kps, splits, slab, vecA, vecB, st)) {}
   else if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
   else if (a_kc && !b_kc) launch_gemm<true, false>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);
   else if (!a_kc && b_kc) launch_gemm<false, true>(grid, st, M, N, K, A, lda, B, ldb, nullptr, 0, nullptr, 0, nullptr, 0, 0, kps, slab, vecA, vecB);

@@ -398,7 +398,7 @@ def test_gemm_skinny_head_paths():
     close("heads bwd_weight", dW, want, 1e-5 * float(want.abs().max()), 1e-5)
 
 
-@pytest.mark.parametrize("M", [65, 100, 256])
+@pytest.mark.parametrize("M", [7, 32, 65, 100, 256])
 def test_gemm_rollout_batch_forward_against_long_k_contiguous_weights(M, monkeypatch):
     """64 < M <= 256 rows against a big k-contiguous weight matrix (ConvModel's resize_emb at the rollout batch of
     configs 4 / 5): the LDS-DMA kernel (gemm_nt_kernel: all rows in one tile, split K, ragged last column tile, K tail

@@ -51,6 +51,42 @@ __device__ __forceinline__ void c3_gstore32(float* p, const float v) {
   asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
+// (sign words: see the staged kernels below)  LDS accesses of a wave that also has global stores in flight go through
+// inline asm for the same reason the stores above do.
+__device__ __forceinline__ unsigned c3_lds_addr(const void* p) { return (unsigned)(unsigned long)(lptr_t)p; }
+__device__ __forceinline__ float c3_lds_read32(const void* p) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(c3_lds_addr(p)));
+  return v;
+}
+__device__ __forceinline__ void c3_lds_zero32(void* p) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(c3_lds_addr(p)), "v"(0u) : "memory");
+}
+__device__ __forceinline__ void c3_lds_wait(float& a, float& b, float& c, float& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+// computing waves, forward: the sign bits of four consecutive band pixels p0 .. p0+3 of one channel -> its sign words
+template <int OW, int RW>
+__device__ __forceinline__ void c3_sign4(unsigned* __restrict__ bbc, int p0, int npix, const float4 q4) {
+  if (OW % 4 == 0) {                                   // the four pixels share a row and a word
+    const unsigned nib = (q4.x > 0.f ? 1u : 0u) | (q4.y > 0.f ? 2u : 0u) | (q4.z > 0.f ? 4u : 0u) | (q4.w > 0.f ? 8u : 0u);
+    const int r = p0 / OW, x = p0 - r * OW;
+    if (p0 < npix && nib) atomicOr(&bbc[r * RW + (x >> 5)], nib << (x & 31));
+  } else {
+    const float e[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = p0 + i, r = q / OW, x = q - r * OW;
+      if (q < npix && e[i] > 0.f) atomicOr(&bbc[r * RW + (x >> 5)], 1u << (x & 31));
+    }
+  }
+}
+
+// Workgroup barrier of the staged kernels: LDS traffic of this wave done (lgkmcnt), then s_barrier -- NOT __syncthreads(),
+// whose fence also drains vmcnt: a storer would sit at every barrier until its global stores are acknowledged (microseconds
+// under load) and hold up the computing waves with it.  Loaders wait for their LDS-DMA (vmcnt) themselves before they arrive.
+__device__ __forceinline__ void c3_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct C3P {
   const float* src; long src_bs;      // source tensor (B, CS, H, W) and its sample stride (floats)
   const float* frag;                  // [chunk][tap][c4][m][64] weight fragments (c3_prep_kernel)
@@ -95,6 +131,9 @@ struct C3Geo {
   static constexpr int MASKF = CD * MROW;              // backward-data: the ReLU-mask band, staged in LDS by the loaders
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * 4;
   static constexpr size_t LDS_BYTES_BWD = (2 * (size_t)BUF + MASKF) * 4;
+  static constexpr int SRW = (OW + 31) / 32, SBITC = R * SRW;          // forward with sign words: words per row / channel band
+  static constexpr int SBITB = ((CD * SBITC + 3) / 4) * 4;
+  static constexpr size_t LDS_BYTES_SG = (2 * (size_t)BUF + SBITB) * 4;
   static constexpr bool VEC = (OH * OW) % 4 == 0 && MROW % 4 == 0;     // 16-byte output stores
   static_assert(CS % KC == 0 && PL0 % PB == 0 && (KC * PLANE) % 4 == 0, "shape");
   // stride 1 reads the right halo of a plane's last row from the next plane's pad piece: PLANE == PL0, or the kernel
@@ -127,10 +166,15 @@ __global__ __launch_bounds__(256) void c3_prep_kernel(const float* __restrict__ 
   }
 }
 
-template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO = 0>
-__global__ __launch_bounds__(640) void c3_kernel(C3P p) {
+// SG (forward only): the epilogue also sets the sign bits of what it stores in an LDS band of sign words, and an ELEVENTH
+// wave carries the finished band's words to HBM under the next band's first chunk (needs NCH >= 2: a barrier between its
+// copy-and-clear and the next epilogue).  The computing waves and the stores are the direct-store kernel's.
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO = 0, bool SG = false>
+__global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
   using G = C3Geo<CS, CD, H, W, S, R, KCO>;
+  static_assert(!SG || (!BWD && G::NCH >= 2), "sign words: forward, two chunks or more");
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned* const sbits = reinterpret_cast<unsigned*>(lds + 2 * G::BUF);      // (SG)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
   const long ntile = (long)p.B * G::NBAND;
@@ -148,10 +192,47 @@ __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
   }
   if (S == 1 && G::GAP > 0) {                     // (stride 1 reads one float past a plane's last row)
     constexpr int GP = G::GAP > 0 ? G::GAP : 1;
-    for (int i = tid; i < 2 * G::KC * GP; i += 640) {
+    for (int i = tid; i < 2 * G::KC * GP; i += (SG ? 704 : 640)) {
       const int bsel = i / (G::KC * GP), r = i - bsel * (G::KC * GP);
       lds[bsel * G::BUF + (r / GP) * G::PLANE + G::PL0 + (r % GP)] = 0.f;
     }
+  }
+  if (SG && w == G::NW + G::NL) {
+    // ------------------------------------------------------------------ sign-word writer
+    for (int i = lane; i < G::SBITB; i += 64) sbits[i] = 0u;
+    c3_bar();
+    for (long k = 0; k < nwork; ++k) {
+      c3_bar();                                   // (raw: this wave must not wait for its stores' acknowledgements here)
+      if ((int)(k % G::NCH) == G::NCH - 1 && p.sg_out != nullptr) {      // the band's epilogue is behind that barrier
+        const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
+        const long b = tile / G::NBAND;
+        const int band = (int)(tile - b * G::NBAND);
+        const int nw = min(R, G::OH - band * R) * G::SRW;
+        unsigned* __restrict__ gb = p.sg_out + b * p.sg_bs + (long)band * R * G::SRW;
+        // all channels' words as one list, four per lane and pass: this wave is at the next barrier late by whatever this takes
+        constexpr int TOT = CD * G::SBITC;
+#pragma unroll 1
+        for (int i0 = lane; i0 < TOT; i0 += 256) {
+          int idx[4];
+          float wv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            idx[e] = min(i0 + 64 * e, TOT - 1);
+            wv[e] = c3_lds_read32(sbits + idx[e]);
+          }
+          c3_lds_wait(wv[0], wv[1], wv[2], wv[3]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = idx[e] / G::SBITC, i = idx[e] - c * G::SBITC;
+            if (i0 + 64 * e < TOT && i < nw) {
+              c3_gstore32(reinterpret_cast<float*>(gb + (long)c * G::OH * G::SRW + i), wv[e]);
+              c3_lds_zero32(sbits + idx[e]);
+            }
+          }
+        }
+      }
+    }
+    return;
   }
   if (w >= G::NW) {
     // ------------------------------------------------------------------ loader waves (planes / fragment pieces dealt round robin)
@@ -291,6 +372,7 @@ __global__ __launch_bounds__(640) void c3_kernel(C3P p) {
             const float bs = biasv[m];
             v.x += bs; v.y += bs; v.z += bs; v.w += bs;
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (SG && p.sg_out != nullptr && cd < CD) c3_sign4<G::OW, G::SRW>(sbits + cd * G::SBITC, p0, npix_ok, v);
           }
           float* __restrict__ o = p.out + o0 + (long)cd * G::OH * G::OW + p0;
           if (cd < CD) {
@@ -591,11 +673,6 @@ int c3b_launch(const C3P& p, hipStream_t st) {
 // The ReLU mask of backward-data arrives as SIGN WORDS (one bit per activation, rows padded to 32-bit words) produced
 // by the forward of the layer below -- by its storers, from the image they copy anyway: 1/32 of the mask's HBM reads,
 // and the LDS the float mask band took is what the output image lives in.
-// Workgroup barrier of the staged kernels: LDS traffic of this wave done (lgkmcnt), then s_barrier -- NOT __syncthreads(),
-// whose fence also drains vmcnt: a storer would sit at every barrier until its global stores are acknowledged (microseconds
-// under load) and hold up the computing waves with it.  Loaders wait for their LDS-DMA (vmcnt) themselves before they arrive.
-__device__ __forceinline__ void c3_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <int CS, int CD, int H, int W, int S, int R>
 struct C3SGeo : C3Geo<CS, CD, H, W, S, R> {
   using G0 = C3Geo<CS, CD, H, W, S, R>;
@@ -617,25 +694,13 @@ struct C3Drain { const float* s; float* o; unsigned* bb; unsigned* go; bool ok; 
 // that also issues LDS-DMA as a possible reader of an in-flight DMA and puts `s_waitcnt vmcnt(0)` in front of it -- in a
 // storer that is a wait for the acknowledgement of every global store it has issued so far (2-4 us under load) before
 // each batch of reads: 8 KB per round trip.  (The storers never touch what the DMA writes.)
-__device__ __forceinline__ unsigned c3_lds_addr(const void* p) { return (unsigned)(unsigned long)(lptr_t)p; }
 __device__ __forceinline__ f32x4 c3_lds_read128(const float* p) {
   f32x4 v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(c3_lds_addr(p)));
   return v;
 }
-__device__ __forceinline__ float c3_lds_read32(const void* p) {
-  float v;
-  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(c3_lds_addr(p)));
-  return v;
-}
-__device__ __forceinline__ void c3_lds_zero32(void* p) {
-  asm volatile("ds_write_b32 %0, %1" ::"v"(c3_lds_addr(p)), "v"(0u) : "memory");
-}
 // all LDS reads issued so far have returned; the values are tied to the wait so that no use can move above it
 __device__ __forceinline__ void c3_lds_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
-}
-__device__ __forceinline__ void c3_lds_wait(float& a, float& b, float& c, float& d) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 
@@ -704,23 +769,6 @@ __device__ __forceinline__ void c3_drain_signs(const C3Drain d, int nwords, int 
     c3_lds_wait(w0, z1, z2, z3);
     d.go[i] = __float_as_uint(w0);
     c3_lds_zero32(d.bb + i);
-  }
-}
-
-// computing waves, forward: the sign bits of four consecutive band pixels p0 .. p0+3 of one channel -> its sign words
-template <int OW, int RW>
-__device__ __forceinline__ void c3_sign4(unsigned* __restrict__ bbc, int p0, int npix, const float4 q4) {
-  if (OW % 4 == 0) {                                   // the four pixels share a row and a word
-    const unsigned nib = (q4.x > 0.f ? 1u : 0u) | (q4.y > 0.f ? 2u : 0u) | (q4.z > 0.f ? 4u : 0u) | (q4.w > 0.f ? 8u : 0u);
-    const int r = p0 / OW, x = p0 - r * OW;
-    if (p0 < npix && nib) atomicOr(&bbc[r * RW + (x >> 5)], nib << (x & 31));
-  } else {
-    const float e[4] = {q4.x, q4.y, q4.z, q4.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = p0 + i, r = q / OW, x = q - r * OW;
-      if (q < npix && e[i] > 0.f) atomicOr(&bbc[r * RW + (x >> 5)], 1u << (x & 31));
-    }
   }
 }
 
@@ -1587,18 +1635,19 @@ const float* zero_page() {
   return z;
 }
 
-template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO = 0>
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO = 0, bool SG = false>
 int c3_launch(const C3P& p, hipStream_t st) {
   using G = C3Geo<CS, CD, H, W, S, R, KCO>;
-  const void* k = (const void*)c3_kernel<CS, CD, H, W, S, R, BWD, KCO>;
-  constexpr size_t LDSB = BWD ? G::LDS_BYTES_BWD : G::LDS_BYTES;
+  const void* k = (const void*)c3_kernel<CS, CD, H, W, S, R, BWD, KCO, SG>;
+  constexpr size_t LDSB = BWD ? G::LDS_BYTES_BWD : (SG ? G::LDS_BYTES_SG : G::LDS_BYTES);
+  constexpr int NTHR = SG ? 704 : 640;
   static_assert(LDSB <= 160 * 1024, "LDS");
   static_assert(!BWD || G::NCH >= 2, "the mask band is staged one chunk ahead of its use");
   static int per_cu = 0, cus = 0;
   if (!per_cu) {
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB) != hipSuccess) return A2C_ERR_LAUNCH;
     int n = 0, dev = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 640, LDSB) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, NTHR, LDSB) != hipSuccess || n < 1) n = 1;
     hipDeviceProp_t prop;
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     per_cu = n;
@@ -1606,7 +1655,7 @@ int c3_launch(const C3P& p, hipStream_t st) {
   const long total = (long)p.B * G::NBAND;
   const long cap = (long)per_cu * cus;
   const int grid = (int)(total < cap ? total : cap);
-  hipLaunchKernelGGL((c3_kernel<CS, CD, H, W, S, R, BWD, KCO>), dim3(grid), dim3(640), LDSB, st, p);
+  hipLaunchKernelGGL((c3_kernel<CS, CD, H, W, S, R, BWD, KCO, SG>), dim3(grid), dim3(NTHR), LDSB, st, p);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   return A2C_OK;
 }
@@ -1687,6 +1736,13 @@ int c3_fwd(const a2c_conv_desc* d, const float* in, long in_bs, const float* fra
            long out_bs, unsigned* signs, long signs_bs, int B, hipStream_t st) {
   C3P p{in, in_bs, frag, bias, nullptr, out, out_bs, zero_page(), B, relu, g_c3_dbg, signs, nullptr, signs_bs};
   if (!p.zero) return A2C_ERR_LAUNCH;
+  if (signs != nullptr && B > 64) {   // the direct-store kernels with the sign-word writer wave, where they have one (two chunks or more)
+    if (d->stride == 1 && d->H == 84 && d->Cin == 16) return c3_launch<16, 24, 84, 84, 1, 12, false, 0, true>(p, st);
+    if (d->stride == 2 && d->H == 84 && d->Cin == 24) return c3_launch<24, 32, 84, 84, 2, 6, false, 0, true>(p, st);
+    if (d->stride == 2 && d->H == 84 && d->Cin == 16) return c3_launch<16, 24, 84, 84, 2, 6, false, 0, true>(p, st);
+    if (d->stride == 2 && d->H == 42 && d->Cin == 32) return c3_launch<32, 64, 42, 42, 2, 11, false, 0, true>(p, st);
+    if (d->stride == 2 && d->H == 42 && d->Cin == 24) return c3_launch<24, 32, 42, 42, 2, 11, false, 0, true>(p, st);
+  }
   if (signs != nullptr) {        // the staged kernels: their storers also carry the sign words
     if (d->stride == 1 && d->H == 84 && d->Cin == 4) return c3s_launch<4, 16, 84, 84, 1, 12, false>(p, st);
     if (d->stride == 1 && d->H == 84 && d->Cin == 16) return c3s_launch<16, 24, 84, 84, 1, 6, false>(p, st);

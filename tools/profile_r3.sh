@@ -27,3 +27,6 @@ rocprofv3 --pmc $SQ1 --output-format csv -d $O/pmc_gru_sq1 -- python3 $R/bench.p
 rocprofv3 --pmc $SQ2 --output-format csv -d $O/pmc_gru_sq2 -- python3 $R/bench.py --workload gru_bptt --steps 2 --warmup 2 $COMMON --no-kernel-timers > $O/pmc_gru_sq2.log 2>&1
 python3 $R/tools/profile_r3_fold.py $O $O/folded
 ls $O/folded
+# only the folded summaries travel back (gpurun_out is capped at 64 MiB)
+mkdir -p $R/gpurun_out/prof_r3_folded && cp $O/folded/* $R/gpurun_out/prof_r3_folded/ && cp $O/*.json $O/*.err $R/gpurun_out/prof_r3_folded/ 2>/dev/null
+rm -rf $O

@@ -7,7 +7,7 @@
                               MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads
   r3_pmc_sq.json              SQ counters per kernel (two passes), with the derived shares the guide names:
                               parked = WAIT_ANY / WAVE_CYCLES, issue_stall = WAIT_INST_ANY / WAVE_CYCLES,
-                              mfma_busy = VALU_MFMA_BUSY_CYCLES / (4 x BUSY_CYCLES ... per SIMD), lds_conflict =
+                              mfma_busy = VALU_MFMA_BUSY_CYCLES / (32 x BUSY_CYCLES: SIMD cycles), lds_conflict =
                               LDS_BANK_CONFLICT / LDS_IDX_ACTIVE, valu_per_mfma = INSTS_VALU / MFMA instructions"""
 import csv
 import glob
@@ -89,7 +89,11 @@ for cfg in ("a3c", "gru"):
         if c.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 3)
         if c.get("SQ_BUSY_CYCLES") and c.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
-            d["mfma_busy_share_of_simd_cycles"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CYCLES"]), 3)
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 CUs = 32 SIMDs each), SQ_VALU_MFMA_BUSY_CYCLES over the SIMDs
+            # (= 8 cycles per 512-flop MFMA op: check against SQ_INSTS_VALU_MFMA_MOPS_F32): busy share of the SIMD cycles
+            d["mfma_busy_share_of_simd_cycles"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * c["SQ_BUSY_CYCLES"]), 3)
+            if c.get("SQ_INSTS_VALU") and c.get("SQ_INSTS_VALU_MFMA_MOPS_F32"):
+                d["valu_per_mfma_op"] = round(c["SQ_INSTS_VALU"] / c["SQ_INSTS_VALU_MFMA_MOPS_F32"], 2)
         sq[f"{cfg}:{kn}"] = d
 json.dump(sq, open(os.path.join(out, "r3_pmc_sq.json"), "w"), indent=1)
 print("kernels with traffic:", len(traffic), "with SQ counters:", len(sq))

@@ -20,9 +20,19 @@
 //   * outputs go straight from the accumulators to HBM (D layout: 16 consecutive pixels of one channel per 16 lanes =
 //     64-B segments, adjacent tiles of a wave complete the 128-B lines in L2): bias + ReLU (forward) or the ReLU mask of
 //     the layer below (backward-data) applied in registers.
-// v_mfma_f32_16x16x4_f32: M = 16 destination channels, N = 16 pixels, K-step = 4 source channels at one tap; a wave
-// owns TPW pixel tiles x MT channel tiles of accumulators and reads every A fragment once per step for all of them.
+// v_mfma_f32_16x16x4_f32: M = 16 pixels (A operand), N = 16 destination channels, K-step = 4 source channels at one tap;
+// a wave owns TPW pixel tiles x MT channel tiles of accumulators and reads every fragment once per step for all of them.
 // Sums are ordered (chunk, tap, channel quad): fixed, deterministic, a re-association of conv.hip's (tap, quad) order.
+//
+// What is in this file, in order:
+//   c3_kernel    forward / stride-1 backward-data, outputs stored straight from the accumulators (inline-asm stores, see
+//                c3_gstore128); SG = forward that also leaves the ReLU mask as SIGN WORDS (an eleventh wave writes them out)
+//   c3b_kernel   stride-2 backward-data with the float mask band staged in LDS
+//   c3s_kernel   / c3bs_kernel: the STAGED variants -- output through an LDS image to two storer waves, the mask read as
+//                sign words, (c3bs) a ring of chunk images with counted vmcnt, resident fragments, 16-byte dOut pieces
+//   c3w_kernel   weight gradient (pixels as K)
+// and the dispatch (c3_fwd, c3_bwd_data, c3w_bwd_weight) that conv.hip's entry points call.  Which kernel runs where, and
+// the measurements behind each choice: DESIGN.md section 4.
 #include <stdlib.h>
 #include <mutex>
 #include "a2c_common.h"

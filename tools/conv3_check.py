@@ -70,7 +70,8 @@ for li, (Cin, H, W, Cout, S, has_bwd) in enumerate(LAYERS):
         xs = torch.rand(Bs, Cin, H, W, generator=g) - 0.3
         outs = torch.empty(Bs, Cout, d.OH, d.OW, device=dev)
         sg = torch.full((Bs, nsw + 3), -1, dtype=torch.int32, device=dev)
-        ops.conv_fwd_signs(d, xs.to(dev).data_ptr(), Cin * H * W, wf, bias.to(dev), True, outs, sg.data_ptr(), nsw + 3, Bs)
+        xsd, bsd = xs.to(dev), bias.to(dev)
+        ops.conv_fwd_signs(d, xsd.data_ptr(), Cin * H * W, wf, bsd, True, outs, sg.data_ptr(), nsw + 3, Bs)
         refs = F.relu(F.conv2d(xs, wt, bias, stride=S, padding=1))
         e1 = float((outs.cpu() - refs).abs().max())
         RW = (d.OW + 31) // 32

@@ -715,14 +715,36 @@ __global__ __launch_bounds__(256) void small_n_bwd_weight_kernel(const float* __
   for (int n = 0; n < SN_MAX; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
     long m = r0 + rp;
-    // four rows in flight per thread (the loop is latency-bound on its 16-B loads otherwise); rows are still
-    // accumulated in increasing m, so the sums are bit-identical to the one-row-at-a-time loop
-    for (; m + 3L * nrp < r1; m += 4L * nrp) {
-      float4 xv[4];
+    // eight rows in flight per thread (the loop is latency-bound on its 16-B loads otherwise: 2.0 TB/s with four); rows are
+    // still accumulated in increasing m, so the sums are bit-identical to the one-row-at-a-time loop
+    constexpr int RU = 8;
+    if (nrp == 1) {
+      // every live thread walks the SAME rows: the RU x N gradient values of a pass are ONE coalesced load per wave
+      // (lane l holds row l / N, head l % N) handed out by v_readlane, instead of RU x N same-address vector loads that
+      // kept the load pipe busier than the x rows themselves did
+      const int lane = threadIdx.x & 63;
+      const int ur = lane / N, un = lane - ur * N;
+      for (; m + (long)(RU - 1) < r1; m += RU) {
+        float4 xv[RU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const float4*>(x + (m + (long)u * nrp) * ldx + k);
+        for (int u = 0; u < RU; ++u) xv[u] = *reinterpret_cast<const float4*>(x + (m + u) * ldx + k);
+        const float dyv = ur < RU ? dy[(m + ur) * ldy + un] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+          for (int n = 0; n < SN_MAX; ++n)
+            if (n < N) {
+              const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dyv), u * N + n));
+              acc[n].x += g * xv[u].x; acc[n].y += g * xv[u].y; acc[n].z += g * xv[u].z; acc[n].w += g * xv[u].w;
+            }
+      }
+    }
+    for (; m + (long)(RU - 1) * nrp < r1; m += (long)RU * nrp) {
+      float4 xv[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) xv[u] = *reinterpret_cast<const float4*>(x + (m + (long)u * nrp) * ldx + k);
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
 #pragma unroll
         for (int n = 0; n < SN_MAX; ++n)
           if (n < N) {
@@ -973,7 +995,7 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   {  // small products: one launch, no slabs (see small_gemm_kernel)
     const long t128 = ((M + 127) / 128) * ((N + 127) / 128), t32 = ((M + 31) / 32) * ((N + 31) / 32);
     const bool vA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0), vB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
-    if (transA == 0 && K % 8 == 0 && K >= 32 && K <= 4096 && t128 < 64 && t32 >= (K > 1024 ? 128 : 16) && t32 <= 4096 && vA &&
+    if (transA == 0 && K % 8 == 0 && K >= 32 && K <= 4096 && t128 < 64 && (t32 >= (K > 1024 ? 128 : 16) || (M <= 32 && t32 >= 4 && K <= 1024)) && t32 <= 4096 && vA &&
         (transB == 0 || vB) &&
         !getenv("A2C_NO_SMALL_GEMM")) {
       dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));

@@ -68,6 +68,9 @@ for cfg in ("a3c", "gru"):
             continue
         traffic[f"{cfg}:{kn}"] = dict(fetch_KB_per_launch=round(f_ / nf, 1), write_KB_per_launch=round(w_ / nw, 1),
                                      hbm_bytes_per_launch=round(hbm), launches_averaged=[nf, nw])
+for k in list(traffic):                 # the key bench.py looks the headline kernel's traffic up by
+    if "a3c_ring_kernel" in k:
+        traffic["a3c_ring"] = dict(traffic[k], alias_of=k)
 json.dump(traffic, open(os.path.join(out, "r3_traffic_raw.json"), "w"), indent=1)
 
 sq = {}

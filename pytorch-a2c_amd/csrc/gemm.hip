@@ -305,11 +305,8 @@ static bool launch_skinny_stream(long M, long N, long K, const float* A, long ld
   if (M > 64 || splits < 2 || !vecA || !vecB || K % 8 || kps % 8 || N * K < (1L << 22) || getenv("A2C_NO_SKINNY_STREAM"))
     return false;
   dim3 grid((unsigned)((N + 127) / 128), (unsigned)splits);
-  static const int sku = getenv("A2C_SK_U") ? atoi(getenv("A2C_SK_U")) : 4;
-  if (M <= 32) {
-    if (sku == 8) hipLaunchKernelGGL((skinny_stream_kernel<1, 8>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
-    else hipLaunchKernelGGL((skinny_stream_kernel<1, 4>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
-  } else hipLaunchKernelGGL((skinny_stream_kernel<2, 4>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
+  if (M <= 32) hipLaunchKernelGGL((skinny_stream_kernel<1, 4>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
+  else hipLaunchKernelGGL((skinny_stream_kernel<2, 4>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, kps, slab);
   return true;
 }
 

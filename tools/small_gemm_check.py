@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""The small dense products of the conv-stack models' rollout step through a2c_gemm_f32 (error against fp64, HIP-event time):
+    python tools/small_gemm_check.py            # the dispatch as shipped
+    A2C_NO_SMALL_GEMM=1 python tools/small_gemm_check.py   # block-tiled kernel + split-K reduce instead of the one-launch kernel"""
 import os, sys
 sys.path[:0]=['/root/repo','/root/repo/pytorch-a2c_amd']
 import torch

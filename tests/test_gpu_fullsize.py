@@ -144,3 +144,43 @@ def test_full_size_conv_stack_rollout_properties_and_action_census(kind, B, T, b
             close("rets", rets[j], O.discount_np(rew_np[j], done_np[j], hyps["gamma"]), 0, 0)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("kind,bptt", [("ConvModel", False), ("GRUModel", True)])
+def test_update_with_sign_word_masks_equals_float_masks_bit_for_bit(kind, bptt, monkeypatch):
+    """The conv stacks carry the ReLU mask of the stride-2 layers' backward-data as sign words (one bit per activation,
+    written by the rollout's forward next to the activation stash).  The same rollout + update with A2C_NO_SIGNS=1 (float
+    masks read from the stashed activations) must leave the same weights, bit for bit: masking with a bit or with
+    (activation > 0) is the same selection and the kernels keep the same summation order."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    from a2c_amd.updater import Updater
+    B, T, A, ss = 96, 8, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, use_bptt=bptt)
+    us = torch.from_numpy(hashf(2 * T * B, 771, 0, 0.999).reshape(2, T, B)).to(DEV)
+    res = {}
+    for signs in (True, False):
+        if not signs:
+            monkeypatch.setenv("A2C_NO_SIGNS", "1")
+        net = make_net(kind, ss, A, 256)
+        assert bool(net._sign_layers()) == signs
+        D = _datas(B * T, ss, net.is_recurrent, actions_on_host=False)
+        envs = [TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 20) for j in range(B)]
+        pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=True, frame_bits=True)
+        rnd = [0]
+        r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="relay",
+                   uniform_fn=lambda t, Bn, env0: us[rnd[0], t, env0:env0 + Bn].contiguous())
+        upd = Updater(net, hyps)
+        try:
+            infos = []
+            for rnd[0] in range(2):
+                r.rollout(net, list(range(B)), hyps)
+                r.finish()
+                infos.append(upd.update_model(D))
+        finally:
+            r.close()
+        res[signs] = ({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, infos)
+    for k in res[True][0]:
+        assert torch.equal(res[True][0][k], res[False][0][k]), k
+    assert res[True][1] == res[False][1]

@@ -157,8 +157,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   float* __restrict__ a1 = img + 4 * p.PLANE1;
   float* __restrict__ red = a1 + 16 * p.PLANE2;
   float* __restrict__ a2 = img + NF2;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int g = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63;       // (the loop body works on its own copies, see there)
+  const int g = lane >> 4;
   const int HW = a.H * a.W, W = a.W;
   const int N = a.n_actions + 1;
   const bool tail = tid == NT - 64;                  // lane 0 of the last wave (fewest conv tiles): bookkeeping + sampling
@@ -191,6 +191,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int iter = 0; iter < n_it; ++iter) {
     const int t = PERSIST ? iter / nb : 0;
     const int b = PERSIST ? (int)blockIdx.x + (iter - t * nb) * (int)gridDim.x : (int)blockIdx.x;
+    // The persistent body with more than 4 heads sits at the 256-register cap: the compiler hoists a dozen LDS addresses
+    // derived from the thread index out of this loop and then spills them (60 B/lane of scratch).  Behind an opaque copy
+    // of the index they are three VALU instructions per use and stay in the loop.
+    int tid_op = tid;
+    if (PERSIST && HNT > 4) asm volatile("" : "+v"(tid_op));      // (4 heads: fits without; measured the same either way)
+    const int tid = tid_op, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
     // ---- what this iteration is (uniform)
     It it;
     bool rec, boot, sample;

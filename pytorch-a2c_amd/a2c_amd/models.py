@@ -359,28 +359,46 @@ class A3CModel(_HipNet):
         ar = self._arena
         dWh = ar.grads[ar.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
         dbh = ar.grads[ar.offsets["pi.bias"][0]:][:A + 1]
-        if getattr(self, "_emb_free", False):
-            # dWh = db^T emb with emb = a2 Wp^T + 1 bp^T never materialised (models.py:73: no activation behind
-            # proj_matrx):  dWh = (db^T a2) Wp^T + colsum(db) bp^T -- a skinny (A+1) x F product over the batch,
-            # then two tiny GEMMs, instead of the (N x 2592 x 256) forward GEMM
-            F = self.flat_size
+        F = self.flat_size
+        Wp = P("proj_matrx.weight")
+        emb_free = getattr(self, "_emb_free", False)
+        # Rank-A backward.  proj_matrx has no activation (models.py:73) and the value head reads a DETACHED embedding
+        # (models.py:85), so demb = dl . W_pi has rank <= A and neither N x 256 x 2592 GEMM of the textbook backward is
+        # needed:   G(proj_matrx.weight) = demb^T a2 = W_pi^T . S[:A]       with S = db^T a2 ((A+1) x F, skinny reduction)
+        #           G(proj_matrx.bias)   = colsum(demb) = W_pi^T . colsum(dl)
+        #           da2 = (demb . Wp) * (a2 > 0) = (dl . Wc[:A]) * (a2 > 0)  with Wc = [pi; value] . proj_matrx (_prep)
+        # The same fp32 products as the reference's, re-associated.  A + 1 > 8 keeps the two GEMMs.
+        rank_bwd = A + 1 <= 8 and getattr(self, "_Wc", None) is not None and os.environ.get("A2C_NO_RANK_BWD") != "1"
+        if emb_free or rank_bwd:
             nch = next(n for n in range(max(1, -(-F // 1024)), F + 1) if F % n == 0 and (F // n) % 4 == 0)
             Kc = F // nch                    # column chunks the skinny weight-gradient kernel takes (<= 1024 wide)
             t1 = ws.get("dWh_t1", (nch, A + 1, Kc))
-            Wp = P("proj_matrx.weight")
+            for c in range(nch):             # S = db^T a2, in column chunks
+                linear_bwd_weight(ws, db, a2.data_ptr() + 4 * c * Kc, F, t1[c], dbh if (c == 0 and emb_free) else None, B, st)
+        if emb_free:
+            # dWh = db^T emb with emb = a2 Wp^T + 1 bp^T never materialised:  dWh = S Wp^T + colsum(db) bp^T
             for c in range(nch):
-                linear_bwd_weight(ws, db, a2.data_ptr() + 4 * c * Kc, F, t1[c], dbh if c == 0 else None, B, st)
                 ops.gemm(0, 1, A + 1, h, Kc, t1[c].data_ptr(), Kc, Wp.data_ptr() + 4 * c * Kc, F, dWh.data_ptr(), h,
                          accumulate=(c > 0), st=st)
             ops.gemm(0, 0, A + 1, h, 1, dbh.data_ptr(), 1, P("proj_matrx.bias").data_ptr(), h, dWh.data_ptr(), h,
                      accumulate=True, st=st)
         else:
             linear_bwd_weight(ws, db, emb.data_ptr(), h, dWh, dbh, B, st)
-        demb = ws.get("demb", (B, h))
-        linear_bwd_data(ws, db, P("pi.weight"), demb, B, st, n_cols=A)        # value head is detached
-        linear_bwd_weight(ws, demb, a2.data_ptr(), self.flat_size, G("proj_matrx.weight"), G("proj_matrx.bias"), B, st)
         da2 = ws.get("da2", (B,) + self._c2.out_shape)
-        linear_bwd_data(ws, demb, P("proj_matrx.weight"), da2.view(B, -1), B, st, mask=a2)
+        if rank_bwd:
+            Wpi, dWp = P("pi.weight"), G("proj_matrx.weight")
+            with ops.span("rank_bwd proj_matrx grads"):
+                for c in range(nch):
+                    ops.gemm(1, 0, h, Kc, A, Wpi.data_ptr(), h, t1[c].data_ptr(), Kc, dWp.data_ptr() + 4 * c * Kc, F, st=st)
+                ops.gemm(1, 0, h, 1, A, Wpi.data_ptr(), h, dbh.data_ptr(), 1, G("proj_matrx.bias").data_ptr(), 1, st=st)
+            with ops.span("rank_bwd da2"):
+                ops.gemm(0, 0, B, F, A, dl.data_ptr(), dl.stride(0), self._Wc.data_ptr(), F, da2.data_ptr(), F,
+                         mask_ptr=a2.data_ptr(), ldmask=F, st=st)
+        else:
+            demb = ws.get("demb", (B, h))
+            linear_bwd_data(ws, db, P("pi.weight"), demb, B, st, n_cols=A)        # value head is detached
+            linear_bwd_weight(ws, demb, a2.data_ptr(), F, G("proj_matrx.weight"), G("proj_matrx.bias"), B, st)
+            linear_bwd_data(ws, demb, Wp, da2.view(B, -1), B, st, mask=a2)
         self._c2.bwd_weight(a1.data_ptr(), a1[0].numel(), da2, G("convs.1.0.weight"), G("convs.1.0.bias"), B, ws, st)
         da1 = ws.get("da1", (B,) + self._c1.out_shape)
         self._c2.bwd_data(da2, a1, da1, B, st)

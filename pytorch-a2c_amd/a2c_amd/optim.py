@@ -15,6 +15,7 @@ from . import ops
 
 class _Fused(torch.optim.Optimizer):
     _state_names = ()
+    capture_safe = False
 
     def __init__(self, net, lr, defaults):
         net._ensure_device()
@@ -86,6 +87,7 @@ class _Fused(torch.optim.Optimizer):
 
 class RMSprop(_Fused):
     _state_names = ("square_avg",)
+    capture_safe = True          # every argument of the step kernel is step-independent (hipGraph replays are exact)
 
     def __init__(self, net, lr=1e-2, alpha=0.99, eps=1e-8):
         super().__init__(net, lr, dict(alpha=alpha, eps=eps, weight_decay=0, momentum=0, centered=False,

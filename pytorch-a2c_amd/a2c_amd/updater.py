@@ -227,7 +227,15 @@ class Updater:
         stream is cut at every collective (advantage moments, gradient arena) -- graph, RCCL all-reduce on the stream,
         graph, ... -- so that N-GPU updates are not ~40 eager launches either and no collective sits inside a capture.
         Returns a callable ``replay() -> info`` (same effect as update_model on the same buffers); the caller must
-        have run one eager update_model on these buffers first (workspaces, tuners)."""
+        have run one eager update_model on these buffers first (workspaces, tuners, one-time hipMalloc / hipMemset of
+        the GEMM and conv launchers: none of that is legal inside a capture)."""
+        if not getattr(self.optim, "capture_safe", False):
+            # Adam's bias correction takes the step count as a KERNEL ARGUMENT: a replay would apply the captured
+            # step's correction for ever
+            raise RuntimeError(f"a2c_amd: {type(self.optim).__name__}.step cannot be captured into a hipGraph "
+                               "(its step count is a kernel argument); use update_model")
+        if self._bufs is None:
+            raise RuntimeError("a2c_amd: capture_update needs one eager update_model on these buffers first")
         return _GraphedUpdate(self, shared_data)
 
     def _finish_update(self, dev_vec, n_global):

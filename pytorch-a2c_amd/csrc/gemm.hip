@@ -10,6 +10,7 @@
 // global loads are issued before the current tile's MFMAs (register prefetch).
 // Split-K writes partial slabs that a second kernel sums in fixed order (deterministic), which
 // also applies the epilogue (bias, ReLU, ReLU-derivative mask of the layer below).
+#include <mutex>
 #include "a2c_common.h"
 
 namespace {
@@ -468,16 +469,18 @@ static bool launch_gemm_nt_shape(long M, long N, long K, const float* A, long ld
                                  float* slab, hipStream_t st) {
   static float* zero = nullptr;
   static bool ready = false;
-  if (!ready) {
-    if (hipMalloc(&zero, 256) != hipSuccess || hipMemset(zero, 0, 256) != hipSuccess) return false;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (hipMalloc(&zero, 256) != hipSuccess || hipMemset(zero, 0, 256) != hipSuccess) return;
     if (hipFuncSetAttribute((const void*)gemm_nt_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES) != hipSuccess)
-      return false;
+      return;
     ready = true;
-  }
+  });
+  if (!ready) return false;                         // the caller falls back to gemm_kernel
   dim3 grid((unsigned)((N + S::TN - 1) / S::TN), (unsigned)splits);
   hipLaunchKernelGGL(gemm_nt_kernel<S>, grid, dim3(64 * (nt::NW + nt::NL)), S::LDS_BYTES, st, M, N, K, A, lda, B, ldb, kps, slab,
                      (const float*)zero);
-  return true;
+  return hipGetLastError() == hipSuccess;           // a refused launch (LDS attribute, block size) -> gemm_kernel, not garbage slabs
 }
 
 static bool launch_gemm_nt(long M, long N, long K, const float* A, long lda, const float* B, long ldb, long kps, int splits,
@@ -710,32 +713,36 @@ __global__ __launch_bounds__(256) void small_n_bwd_weight_kernel(const float* __
   float4 acc[SN_MAX];
 #pragma unroll
   for (int n = 0; n < SN_MAX; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live) {
-    long m = r0 + rp;
-    // eight rows in flight per thread (the loop is latency-bound on its 16-B loads otherwise: 2.0 TB/s with four); rows are
-    // still accumulated in increasing m, so the sums are bit-identical to the one-row-at-a-time loop
-    constexpr int RU = 8;
-    if (nrp == 1) {
-      // every live thread walks the SAME rows: the RU x N gradient values of a pass are ONE coalesced load per wave
-      // (lane l holds row l / N, head l % N) handed out by v_readlane, instead of RU x N same-address vector loads that
-      // kept the load pipe busier than the x rows themselves did
-      const int lane = threadIdx.x & 63;
-      const int ur = lane / N, un = lane - ur * N;
-      for (; m + (long)(RU - 1) < r1; m += RU) {
-        float4 xv[RU];
+  long m = r0 + rp;
+  // eight rows in flight per thread (the loop is latency-bound on its 16-B loads otherwise: 2.0 TB/s with four); rows are
+  // still accumulated in increasing m, so the sums are bit-identical to the one-row-at-a-time loop
+  constexpr int RU = 8;
+  if (nrp == 1 && (int)(threadIdx.x & ~63u) < kq4) {
+    // every live thread walks the SAME rows: the RU x N gradient values of a pass are ONE coalesced load per wave
+    // (lane l holds row l / N, head l % N) handed out by v_readlane, instead of RU x N same-address vector loads that
+    // kept the load pipe busier than the x rows themselves did.  v_readlane ignores EXEC, so this block is entered per
+    // WAVE (the predicate above is wave-uniform) and ALL 64 lanes load their gradient value: in a partly live wave
+    // (K/4 not a multiple of 64) the dead lanes carry gradient values too, read x from column 0 and never write a result.
+    const int lane = threadIdx.x & 63;
+    const int ur = lane / N, un = lane - ur * N;
+    const int kx = live ? k : 0;
+    m = r0;                                // (dead lanes have rp == 1: same trip count for all 64 lanes)
+    for (; m + (long)(RU - 1) < r1; m += RU) {
+      float4 xv[RU];
 #pragma unroll
-        for (int u = 0; u < RU; ++u) xv[u] = *reinterpret_cast<const float4*>(x + (m + u) * ldx + k);
-        const float dyv = ur < RU ? dy[(m + ur) * ldy + un] : 0.f;
+      for (int u = 0; u < RU; ++u) xv[u] = *reinterpret_cast<const float4*>(x + (m + u) * ldx + kx);
+      const float dyv = ur < RU ? dy[(m + ur) * ldy + un] : 0.f;
 #pragma unroll
-        for (int u = 0; u < RU; ++u)
+      for (int u = 0; u < RU; ++u)
 #pragma unroll
-          for (int n = 0; n < SN_MAX; ++n)
-            if (n < N) {
-              const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dyv), u * N + n));
-              acc[n].x += g * xv[u].x; acc[n].y += g * xv[u].y; acc[n].z += g * xv[u].z; acc[n].w += g * xv[u].w;
-            }
-      }
+        for (int n = 0; n < SN_MAX; ++n)
+          if (n < N) {
+            const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dyv), u * N + n));
+            acc[n].x += g * xv[u].x; acc[n].y += g * xv[u].y; acc[n].z += g * xv[u].z; acc[n].w += g * xv[u].w;
+          }
     }
+  }
+  if (live) {
     for (; m + (long)(RU - 1) * nrp < r1; m += (long)RU * nrp) {
       float4 xv[RU];
 #pragma unroll
@@ -790,6 +797,40 @@ __global__ __launch_bounds__(256) void small_n_bwd_weight_reduce(const float* __
     }
     for (; z < bands; ++z) v += part[(long)z * per + i];
     dW[i] = v;
+  }
+}
+
+// C[m, n] (+)= sum_{k < K <= 8} A[k, m] B[k, n]: both operands k-major (rank-K outer-product sum).  A3CModel's rank-A
+// backward (models.py:73, 85: no activation behind proj_matrx and a detached value head make the embedding gradient
+// demb = dl . W_pi a rank-A matrix): G(proj_matrx.weight) = W_pi^T . (dl^T a2) with K = A actions.  Memory-bound on C.
+template <int VEC>
+__global__ __launch_bounds__(256) void small_k_tn_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                         long ldb, float* __restrict__ C, long ldc, long M, long N, int K,
+                                                         int accumulate) {
+  const long nq = (N + VEC - 1) / VEC, tot = M * nq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < tot; i += gridDim.x * 256L) {
+    const long m = i / nq;
+    const long n = (i - m * nq) * VEC;
+    float a[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a[v] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float g = A[k * lda + m];
+      if (VEC == 4) {
+        const float4 bv = *reinterpret_cast<const float4*>(B + k * ldb + n);
+        a[0] += g * bv.x; a[1 % VEC] += g * bv.y; a[2 % VEC] += g * bv.z; a[3 % VEC] += g * bv.w;
+      } else {
+        a[0] += g * B[k * ldb + n];
+      }
+    }
+    if (VEC == 4) {
+      float4* o = reinterpret_cast<float4*>(C + m * ldc + n);
+      float4 r = make_float4(a[0], a[1 % VEC], a[2 % VEC], a[3 % VEC]);
+      if (accumulate) { const float4 c = *o; r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w; }
+      *o = r;
+    } else {
+      C[m * ldc + n] = accumulate ? C[m * ldc + n] + a[0] : a[0];
+    }
   }
 }
 
@@ -985,6 +1026,17 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
     A2C_CHECK_LAUNCH();
     hipLaunchKernelGGL(small_n_bwd_weight_reduce, dim3(a2c_grid_1d(M * N, 256)), dim3(256), 0, st0, (const float*)ws,
                        bands, (long)(M * N), C);
+    A2C_CHECK_LAUNCH();
+    return A2C_OK;
+  }
+  if (transA == 1 && transB == 0 && K <= SN_MAX && !relu && !bias && !mask) {      // rank-K outer-product sum
+    const bool v4 = N % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0);
+    if (v4)
+      hipLaunchKernelGGL((small_k_tn_kernel<4>), dim3(a2c_grid_1d(M * (N / 4), 256)), dim3(256), 0, st0, A, (long)lda, B,
+                         (long)ldb, C, (long)ldc, (long)M, (long)N, (int)K, accumulate);
+    else
+      hipLaunchKernelGGL((small_k_tn_kernel<1>), dim3(a2c_grid_1d(M * N, 256)), dim3(256), 0, st0, A, (long)lda, B, (long)ldb,
+                         C, (long)ldc, (long)M, (long)N, (int)K, accumulate);
     A2C_CHECK_LAUNCH();
     return A2C_OK;
   }

@@ -1,0 +1,404 @@
+"""-m gpu: parity tests ON THE PATH bench.py TIMES and at the sizes BASELINE.json names.
+
+bench.py's timed step is `rollout -> Updater.capture_update(...).replay()` (hipGraph replays of the update, cut at the
+collectives when sharded), at A3CModel 256 x 128 (headline), ConvModel 32 x 64, GRUModel + BPTT 256 x 128 and
+ConvModel 256 x 128 (the per-GPU shard of config 5).  Here:
+  * a replayed update == the eager update BIT FOR BIT over consecutive epochs (twin engines on the same envs / uniforms),
+    and both == the oracle's SlotRunner + OracleUpdater (updater.py:63-137, training.py:150-175) within fp32 tolerance;
+  * the sharded form (graph, all-reduce, graph, all-reduce, graph) at world 2 == the single-process eager update;
+  * the full-size updates (N = 32,768 for A3CModel; N = 2,048 for ConvModel) against OracleUpdater on the recorded
+    buffers: the five infos, per-parameter gradient norms, sampled gradients and sampled post-step weights;
+  * ConvModel 256 x 128 (config 5's per-GPU workload) through the size-independent properties;
+  * GradNorm against the fp64 norm rebuilt from the reference's own per-tensor gradient norms (g6) at 1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import a2c_oracle as O  # noqa: E402
+from cases import UPDATE_CASES, U8FakeEnv, base_hyps, hashf, sample_idx, synth_shared  # noqa: E402
+from test_gpu_kernels import close  # noqa: E402
+from test_gpu_models import _datas, make_net  # noqa: E402
+from test_gpu_ingest import _oracle_rollouts, _pool  # noqa: E402
+
+DEV = "cuda"
+
+
+class _Engine:
+    def __init__(self, kind, ingest, hyps, ekws, usd, B, T, A, ss, h):
+        from a2c_amd.runner import Runner
+        from a2c_amd.updater import Updater
+        self.net = make_net(kind, ss, A, h)
+        self.D = _datas(B * T, ss, self.net.is_recurrent, h=h, actions_on_host=False)
+        self.rnd = [0]
+        self.pool = _pool(U8FakeEnv, ekws, 2, pong=True)
+        self.r = Runner(self.D, hyps, None, None, None, env_pool=self.pool, ingest=ingest,
+                        uniform_fn=lambda t, Bn, env0: usd[self.rnd[0], t, env0:env0 + Bn].contiguous())
+        self.upd = Updater(self.net, hyps)
+        self.hyps, self.B = hyps, B
+        self.g = None
+
+    def rollout(self, k):
+        self.rnd[0] = k
+        self.r.rollout(self.net, list(range(self.B)), self.hyps)
+        self.r.finish()
+
+    def close(self):
+        self.r.close()
+
+
+@pytest.mark.parametrize("kind,ingest,bptt", [("A3CModel", "zero-copy", False), ("GRUModel", "relay", True),
+                                              ("ConvModel", "relay", False)])
+def test_graphed_update_replays_equal_eager_updates_and_the_oracle(kind, ingest, bptt):
+    """epoch 0: rollout + eager update (workspaces, tuners); epoch 1: rollout, capture_update, replay; epochs 2, 3:
+    rollout + replay -- what bench.py's Bench.capture / Bench.step do.  A twin engine runs the same epochs with
+    update_model.  Replay == eager bit for bit (same kernels, same order; the capture's bookkeeping -- stash / dirty
+    flags / optimiser step count -- must leave the net exactly where an eager update leaves it); both against the oracle."""
+    B, T, A, ss, h = 4, 5, 3, (4, 84, 84), 256
+    n_ep = 4
+    ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3,
+                     optim_type="RMSprop", use_bptt=bptt, h_size=h)
+    us = torch.from_numpy(hashf((n_ep + 1) * T * B, 4177, 0, 1).reshape(n_ep + 1, T, B))
+    usd = us.to(DEV)
+    onet = O.OracleNet(kind, ss, A, h)
+    refs = _oracle_rollouts(kind, onet, hyps, ekws, us, n_ep + 1, B, T, ss, env_cls=O.FakeEnv,
+                            updater=O.OracleUpdater(onet, hyps))       # updates after rounds 0 .. n_ep - 1
+    eg = _Engine(kind, ingest, hyps, ekws, usd, B, T, A, ss, h)         # graphed
+    ee = _Engine(kind, ingest, hyps, ekws, usd, B, T, A, ss, h)         # eager twin
+    try:
+        for k in range(n_ep):
+            eg.rollout(k)
+            ee.rollout(k)
+            for n in ("states", "actions", "dones", "rewards", "deltas"):
+                assert torch.equal(eg.D[n], ee.D[n]), (k, n)
+            assert torch.equal(eg.D["states"].cpu(), refs[k]["states"]), k
+            # after an RMSprop step the nets agree to ~1e-4 of a tensor's scale (1/sqrt(v) amplifies 1e-7 gradient noise;
+            # ConvModel's values under the formula weights are ~160)
+            tol = 1e-5 if k == 0 else 5e-4
+            close("deltas", eg.D["deltas"], refs[k]["deltas"], tol * max(1.0, float(refs[k]["deltas"].abs().max())), tol)
+            if k == 0:
+                gi = eg.upd.update_model(eg.D)
+            else:
+                if eg.g is None:
+                    steps0 = eg.upd.optim._steps
+                    eg.g = eg.upd.capture_update(eg.D)
+                    assert len(eg.g.graphs) == 1 and not eg.g.colls        # one GPU: ONE graph, no cut
+                    assert eg.upd.optim._steps == steps0                   # the capture executed nothing
+                gi = eg.g.replay()
+            ei = ee.upd.update_model(ee.D)
+            assert gi == ei, (k, gi, ei)
+            assert eg.upd.optim._steps == ee.upd.optim._steps == k + 1
+            for (n, p), (_, q) in zip(eg.net.named_parameters(), ee.net.named_parameters()):
+                assert torch.equal(p, q), (k, n)
+            oi = refs[k]["info"]
+            for name in oi:
+                assert abs(gi[name] - oi[name]) <= 2e-5 + 5e-4 * abs(oi[name]), (k, name, gi[name], oi[name])
+        # lr = 1e-3: RMSprop's first steps move every weight by ~1e-2 .. 1e-3 whatever |g| (1/sqrt(v) normalises), so the
+        # direction of noise-level gradients is not pinned by fp32; 4 updates -> 4 steps of lr * 10 at most per weight
+        for (n, p), (n2, q) in zip(eg.net.named_parameters(), onet.named_parameters()):
+            assert n == n2
+            d = (p.detach().cpu() - q.detach()).abs()
+            assert float(d.max()) <= 4e-2 and float(d.mean()) <= 2e-4, (n, float(d.max()), float(d.mean()))
+        # the optimiser state the replays left is the eager twin's, bit for bit
+        for a, b in zip(eg.upd.optim._flat.values(), ee.upd.optim._flat.values()):
+            assert torch.equal(a, b)
+    finally:
+        eg.close()
+        ee.close()
+
+
+def test_capture_update_refuses_adam_and_cold_buffers():
+    from a2c_amd.updater import Updater
+    kind, ss, A, h, R, T = "A3CModel", (4, 84, 84), 3, 256, 2, 4
+    D = {k: v.to(DEV) for k, v in synth_shared(kind, ss, A, h, R, T, seed=5, recurrent=False).items()}
+    upd = Updater(make_net(kind, ss, A, h), base_hyps(n_tsteps=T, n_rollouts=R, optim_type="Adam"))
+    upd.update_model(D)
+    with pytest.raises(RuntimeError, match="step count"):
+        upd.capture_update(D)
+    upd = Updater(make_net(kind, ss, A, h), base_hyps(n_tsteps=T, n_rollouts=R, optim_type="RMSprop"))
+    with pytest.raises(RuntimeError, match="eager"):
+        upd.capture_update(D)
+
+
+def _graphed_shard_worker(rank, world, port, kind, q, ss):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", A2C_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "pytorch-a2c_amd"), os.path.join(root, "tests", "golden"),
+                    os.path.join(root, "tests")]
+    import torch.distributed as dist
+    from a2c_amd.parallel import Shard
+    from a2c_amd.updater import Updater
+    from test_gpu_models import make_net
+    from cases import base_hyps, synth_shared
+    torch.cuda.set_device(0)
+    A, h, R, T = 3, 256, 4, 6
+    sh = Shard.from_env()
+    net = make_net(kind, ss, A, h)
+    lo, hi = sh.slot_range(R)
+    hyps = base_hyps(n_tsteps=T, n_rollouts=hi - lo, optim_type="RMSprop", h_size=h)
+    upd = Updater(net, hyps, shard=sh)
+    infos, Dl, g = [], None, None
+    for u in range(4):
+        D = synth_shared(kind, ss, A, h, R, T, seed=700 + 10 * u, recurrent=net.is_recurrent)
+        new = {k: v[lo * T:hi * T].cuda() for k, v in D.items()}
+        if Dl is None:
+            Dl = new
+        else:
+            for k in Dl:                       # a captured update replays on the SAME buffers
+                Dl[k].copy_(new[k])
+        if u == 0:
+            infos.append(upd.update_model(Dl))
+        else:
+            if g is None:
+                g = upd.capture_update(Dl)
+            infos.append(g.replay())
+    q.put((rank, infos, [p.detach().cpu().numpy() for p in net.parameters()], len(g.graphs), len(g.colls)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["A3CModel", "GRUModel"])
+def test_sharded_graphed_update_equals_single_process_eager(kind):
+    """world 2 (gloo all-reduce of CUDA tensors): update 0 eager, then capture_update and three replays on new data --
+    3 graphs around 2 collectives (advantage moments; gradient arena + loss sums) -- against four single-process eager
+    updates on the whole batch."""
+    from a2c_amd.updater import Updater
+    from test_gpu_system import _free_port
+    ss, A, h, R, T = (4, 84, 84), 3, 256, 4, 6
+    net = make_net(kind, ss, A, h)
+    upd = Updater(net, base_hyps(n_tsteps=T, n_rollouts=R, optim_type="RMSprop", h_size=h))
+    ref_infos = []
+    for u in range(4):
+        D = synth_shared(kind, ss, A, h, R, T, seed=700 + 10 * u, recurrent=net.is_recurrent)
+        ref_infos.append(upd.update_model({k: v.cuda() for k, v in D.items()}))
+    ref_params = [p.detach().cpu().numpy() for p in net.parameters()]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graphed_shard_worker, args=(r, 2, port, kind, q, ss)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, infos, params, n_graphs, n_colls in res:
+        assert (n_graphs, n_colls) == (3, 2)
+        for u in range(4):
+            for k in ref_infos[u]:
+                assert infos[u][k] == pytest.approx(ref_infos[u][k], rel=2e-5, abs=1e-7), (rank, u, k)
+        for a, b in zip(params, ref_params):
+            np.testing.assert_allclose(a, b, rtol=0, atol=4e-6)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b)
+
+
+def _compare_full_update(net, upd, info, onet, oinfo, g_tol=2e-5):
+    """five infos at rel 3e-5; per-parameter gradient norms; sampled gradients and sampled post-step weights"""
+    for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy"):
+        assert info[k] == pytest.approx(oinfo[k], rel=3e-5, abs=2e-6), (k, info[k], oinfo[k])
+    # GradNorm against the fp64 norm of the oracle's gradients (torch's fp32 clip_grad_norm_ is itself ~1e-4 low)
+    g64 = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in onet.parameters() if q.grad is not None)))
+    assert info["GradNorm"] == pytest.approx(g64, rel=2e-5), (info["GradNorm"], g64, oinfo["GradNorm"])
+    for (n, p), (n2, q) in zip(net.named_parameters(), onet.named_parameters()):
+        assert n == n2
+        if q.grad is None:
+            assert n in net._unused_params, n
+            continue
+        gr = net.G(n)
+        want_n = float(q.grad.double().norm())
+        assert float(gr.double().norm()) == pytest.approx(want_n, rel=1e-4, abs=1e-6 * g64 + 1e-12), n
+        idx = torch.from_numpy(np.unique(sample_idx(p.numel())))
+        rms = max(want_n / max(p.numel(), 1) ** 0.5, 1e-9)
+        close(f"grad samples {n}", gr.reshape(-1)[idx.to(DEV)], q.grad.reshape(-1)[idx], g_tol * rms + 1e-10, 4e-4)
+        # a first RMSprop step moves a weight by lr * g / (sqrt(0.01 g^2) + 1e-8) ~ lr * 10 whatever |g|: weights whose
+        # gradient is noise-level are pinned by the bound only
+        close(f"param samples {n}", p.detach().reshape(-1)[idx.to(DEV)], q.detach().reshape(-1)[idx], 3e-5, 1e-5)
+
+
+def test_full_size_headline_update_matches_the_oracle_updater():
+    """A3CModel, 256 envs x 128 steps (N = 32,768: the stash-only forward, wgrad_stream / bwd_stream / wgrad_run kernels,
+    the rank-A backward and the skinny reductions at their full row counts), rollout through the headline path
+    (zero-copy ring kernel, packed frames), then update_model from the stash vs OracleUpdater on the SAME recorded
+    buffers (updater.py:63-137).  Then a second epoch as a hipGraph replay, against the oracle's second update."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    from a2c_amd.updater import Updater
+    torch.set_num_threads(max(4, min(16, len(os.sched_getaffinity(0)))))
+    B, T, A, ss = 256, 128, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    net = make_net("A3CModel", ss, A, 256)
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    envs = [TapeEnv(env_id=j, length=2 * T + 1, p_done=1.0 / 100) for j in range(B)]
+    pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=True, frame_bits=True)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy")
+    upd, oupd = Updater(net, hyps), O.OracleUpdater(onet, hyps)
+    try:
+        g = None
+        for ep in range(2):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            assert net._stash_valid(D["states"].data_ptr(), B * T)          # the update below starts behind the convs
+            Do = {k: v.cpu().clone() for k, v in D.items()}
+            if ep == 0:
+                info = upd.update_model(D)
+            else:
+                g = upd.capture_update(D)
+                info = g.replay()
+            assert not upd.flat_scan_fallback
+            oinfo = oupd.update_model(Do)
+            if ep == 0:
+                _compare_full_update(net, upd, info, onet, oinfo)
+            else:
+                # second update: the nets differ by the first step's fp32 noise (RMSprop, see _compare_full_update) and the
+                # rollouts by what that did to a few sampled actions; the scalars still agree to ~1e-3
+                for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy", "GradNorm"):
+                    assert info[k] == pytest.approx(oinfo[k], rel=5e-3, abs=2e-5), (ep, k, info[k], oinfo[k])
+            del Do
+    finally:
+        r.close()
+    torch.set_num_threads(4)
+
+
+def test_full_size_conv_32x64_update_matches_the_oracle_updater():
+    """ConvModel 32 x 64 (BASELINE configs[1]; N = 2,048): relay rollout with every layer + embedding stashed, update vs
+    OracleUpdater on the recorded buffers."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    from a2c_amd.updater import Updater
+    torch.set_num_threads(max(4, min(16, len(os.sched_getaffinity(0)))))
+    B, T, A, ss = 32, 64, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    net = make_net("ConvModel", ss, A, 256)
+    onet = O.OracleNet("ConvModel", ss, A, 256)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    envs = [TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 100) for j in range(B)]
+    pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=True, frame_bits=True)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="relay")
+    try:
+        r.rollout(net, list(range(B)), hyps)
+        r.finish()
+        Do = {k: v.cpu().clone() for k, v in D.items()}
+        upd = Updater(net, hyps)
+        info = upd.update_model(D)
+        oinfo = O.OracleUpdater(onet, hyps).update_model(Do)
+        _compare_full_update(net, upd, info, onet, oinfo)
+    finally:
+        r.close()
+    torch.set_num_threads(4)
+
+
+def test_config5_per_gpu_shard_conv_256x128_properties():
+    """BASELINE configs[4] per GPU: ConvModel, 256 envs x 128 steps (N = 32,768; the 28,224 x 2,000 GEMMs at M = 32,768,
+    ~100 GB of activations resident).  The oracle cannot run this size in a test (77 samples/s), so: size-independent
+    properties of the rollout, the action census against the oracle forward on 512 recorded states, scans bit-exact,
+    and the update's scalars against OracleUpdater-free identities: Loss = Pi + Val - Entropy, GradNorm = the fp64 norm of
+    the gradient arena, and the gradient of the LAST layers (pi / value heads: closed form from the recorded heads)."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    from a2c_amd.updater import Updater
+    free, total = torch.cuda.mem_get_info()
+    if free < 130 * 2 ** 30:
+        pytest.skip(f"needs ~125 GB of HBM, {free / 2 ** 30:.0f} GB free")
+    B, T, A, ss = 256, 128, 4, (4, 84, 84)
+    hyps = base_hyps(env_type="Breakout-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    net = make_net("ConvModel", ss, A, 256)
+    onet = O.OracleNet("ConvModel", ss, A, 256)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    envs = [TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 100) for j in range(B)]
+    pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=False, frame_bits=True)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="relay")
+    try:
+        r.rollout(net, list(range(B)), hyps)
+        r.finish()
+        u = r._u_buf.cpu()
+        acts = D["actions"].cpu().reshape(B, T)
+        dones, rews = D["dones"].cpu().reshape(B, T), D["rewards"].cpu().reshape(B, T)
+        assert bool((dones[:, -1] == 1).all())
+        assert int(acts.min()) >= 0 and int(acts.max()) <= A - 1
+        real_done = torch.from_numpy(np.stack([e.dones[:T] for e in envs]).astype(np.float32))
+        for j0 in range(0, B, 32):                                  # frame stack (utils.py:26-43), 32 envs at a time
+            st = D["states"][j0 * T:(j0 + 32) * T].reshape(32, T, 4, -1)
+            for c in range(3):
+                same = (st[:, 1:, c] == st[:, :-1, c + 1]).all(-1)
+                zero = (st[:, 1:, c] == 0).all(-1)
+                assert bool((same | (zero & (real_done[j0:j0 + 32, :T - 1].to(DEV) == 1))).all())
+            del st
+        idx = (np.arange(512, dtype=np.int64) * 2654435761 % (B * T)).astype(np.int64)
+        with torch.no_grad():
+            ovals, logits = onet(D["states"][torch.from_numpy(idx).to(DEV)].cpu())
+        cs = torch.cumsum(torch.softmax(logits, -1), -1)
+        uu = u.t().reshape(-1)[idx]
+        ref = (cs >= uu[:, None]).float().argmax(-1)
+        ref[(cs < uu[:, None]).all(-1)] = A - 1
+        got = acts.reshape(-1)[idx]
+        flips = (ref != got).nonzero().flatten()
+        assert len(flips) <= 1, len(flips)
+        for f in flips.tolist():
+            assert float((cs[f] - uu[f]).abs().min()) < 1e-6
+        upd = Updater(net, hyps)
+        deltas = D["deltas"].cpu().reshape(B, T).numpy()
+        info = upd.update_model(D)
+        assert all(np.isfinite(v) for v in info.values()), info
+        assert info["Loss"] == pytest.approx(info["Pi_Loss"] + info["ValLoss"] - info["Entropy"], rel=1e-6, abs=1e-9)
+        advs, rets = upd._bufs["advs"].cpu().reshape(B, T).numpy(), upd._bufs["rets"].cpu().reshape(B, T).numpy()
+        for j in (0, B // 3, B - 1):
+            close("advs", advs[j], O.discount_np(deltas[j], dones.numpy()[j], hyps["gamma"] * hyps["lambda_"]), 0, 0)
+            close("rets", rets[j], O.discount_np(rews.numpy()[j], dones.numpy()[j], hyps["gamma"]), 0, 0)
+        # the update's forward at the sampled rows == the oracle's forward (the heads the loss saw)
+        hb = net._heads("train", B * T)[0][torch.from_numpy(idx).to(DEV)].cpu()
+        close("logits at N=32768", hb[:, :A], logits, 2e-5, 1e-5)
+        close("values at N=32768", hb[:, A], ovals.reshape(-1), 2e-5, 1e-5)
+        # losses from the recorded heads, in fp64 on the host (updater.py:100-127)
+        H = net._heads("train", B * T)[0].double().cpu()
+        lsm = torch.log_softmax(H[:, :A], -1)
+        a64 = torch.from_numpy(advs.reshape(-1)).double()
+        a64 = (a64 - a64.mean()) / (a64.std() + 1e-6)
+        lp = lsm.gather(1, D["actions"].cpu().reshape(-1, 1)).reshape(-1)
+        pi_loss = float(-(lp * a64).mean())
+        val_loss = float(hyps["val_coef"] * ((H[:, A] - torch.from_numpy(rets.reshape(-1)).double()) ** 2).mean())
+        entr = float(-hyps["entr_coef"] * (lsm * lsm.exp()).sum(-1).mean())
+        assert info["Pi_Loss"] == pytest.approx(pi_loss, rel=3e-5, abs=2e-6)
+        assert info["ValLoss"] == pytest.approx(val_loss, rel=3e-5, abs=2e-6)
+        assert info["Entropy"] == pytest.approx(entr, rel=3e-5, abs=2e-6)
+        g64 = float(net._arena.train_grads().double().norm())
+        assert info["GradNorm"] == pytest.approx(g64, rel=1e-6)
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("case", UPDATE_CASES, ids=[c[0] for c in UPDATE_CASES])
+def test_gradnorm_against_fp64_norm_rebuilt_from_the_reference_grads(golden, case):
+    """g6 stores the fp64 norm of every parameter gradient the REFERENCE's optimiser saw (`grad_norms`: AFTER
+    clip_grad_norm_, updater.py:129) and the GradNorm it reported: torch's fp32 reduction, up to 1.4e-4 low on
+    multi-million-element tensors -- which is why test_updater_golden compares GradNorm with rel 3e-4.  The quantity
+    itself is recoverable from the recording: post = sqrt(sum grad_norms^2) is the fp64 norm of the clipped gradients,
+    and the clip multiplied every element by c = max_norm / (GradNorm_ref + 1e-6) when GradNorm_ref > max_norm, so the
+    true pre-clip norm is post / c.  The HIP path's GradNorm (fp64 reduction) is matched against THAT at 2e-5 (first
+    update of each case: identical weights on both sides)."""
+    from a2c_amd.updater import Updater
+    g = golden["g6_update"]
+    name, kind, ss, A, h, R_, T, opt, norm_advs, nstep, use_bptt, n_upd = case
+    net = make_net(kind, ss, A, h)
+    hyps = base_hyps(n_tsteps=T, n_rollouts=R_, optim_type=opt, norm_advs=norm_advs, use_nstep_rets=nstep,
+                     use_bptt=use_bptt, h_size=h)
+    D = synth_shared(kind, ss, A, h, R_, T, seed=700, recurrent=net.is_recurrent)
+    info = Updater(net, hyps).update_model({k: v.to(DEV) for k, v in D.items()})
+    gn = np.asarray(g[f"{name}_u0_grad_norms"], dtype=np.float64)
+    has = np.asarray(g[f"{name}_u0_has_grad"]).astype(bool)
+    post = float(np.sqrt((gn[has] ** 2).sum()))
+    ref32 = float(g[f"{name}_u0_GradNorm"])
+    mx = hyps["max_norm"]
+    # torch clips when its (fp32) norm exceeds max_norm: clip_coef = max_norm / (norm + 1e-6), clamped to 1
+    want = post * (ref32 + 1e-6) / mx if mx / (ref32 + 1e-6) < 1.0 else post
+    assert info["GradNorm"] == pytest.approx(want, rel=2e-5), (info["GradNorm"], want, ref32)

@@ -199,30 +199,47 @@ def test_sharded_graphed_update_equals_single_process_eager(kind):
         assert np.array_equal(a, b)
 
 
-def _compare_full_update(net, upd, info, onet, oinfo, g_tol=2e-5):
-    """five infos at rel 3e-5; per-parameter gradient norms; sampled gradients and sampled post-step weights"""
+def _oracle_updates_fp32_and_fp64(kind, ss, A, h, oupd, Do, hyps, monkeypatch):
+    """OracleUpdater on the recorded buffers in fp32 (= the reference's arithmetic) and in fp64 (the same update
+    evaluated exactly enough to MEASURE fp32 noise; the scans stay the reference's fp32 scans in both)."""
+    oinfo, extra = oupd.update_model(Do, keep=True)
+    o64 = O.OracleNet(kind, ss, A, h, state_dict={k: v.double() for k, v in O.formula_state_dict(kind, ss, A, h).items()})
+    d32 = O.discount
+    monkeypatch.setattr(O, "discount", lambda a, d, f: d32(a.float(), d.float(), f).to(a.dtype))
+    D64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in Do.items()}
+    oinfo64, extra64 = O.OracleUpdater(o64, hyps).update_model(D64, keep=True)
+    monkeypatch.setattr(O, "discount", d32)
+    return oinfo, extra["grads"], oinfo64, extra64["grads"]
+
+
+def _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, max_norm):
+    """The five infos at rel 3e-5 (and no further from the fp64 evaluation than the reference's fp32 path is); GradNorm
+    against the fp64 norm; every gradient tensor: rms deviation from the fp64 gradients <= 2 x the deviation of the
+    reference's own fp32 arithmetic + 5e-5 of the tensor's rms (the floor covers ReLU decisions of activations within
+    fp32 noise of zero: measured 1.4e-5 on ConvModel's 2048 x 2000 embedding); sampled post-step weights.
+    fp32 conv gradients at these sizes are sums of 1e7-1e8 cancelling terms: torch's own deviate by ~1e-3 of the
+    tensor's rms from fp64 (tools/dbg/fullsize_grad_stats.py), so an element-wise 1e-5 comparison with them would test noise."""
     for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy"):
         assert info[k] == pytest.approx(oinfo[k], rel=3e-5, abs=2e-6), (k, info[k], oinfo[k])
-    # GradNorm against the fp64 norm of the oracle's gradients (torch's fp32 clip_grad_norm_ is itself ~1e-4 low)
-    g64 = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in onet.parameters() if q.grad is not None)))
-    assert info["GradNorm"] == pytest.approx(g64, rel=2e-5), (info["GradNorm"], g64, oinfo["GradNorm"])
+        assert abs(info[k] - oinfo64[k]) <= 2 * abs(oinfo[k] - oinfo64[k]) + 1e-6 * abs(oinfo64[k]) + 1e-9, k
+    assert oinfo64["GradNorm"] <= max_norm          # (no clipping at these sizes: the recorded grads are the raw ones)
+    assert info["GradNorm"] == pytest.approx(oinfo64["GradNorm"], rel=5e-6), (info["GradNorm"], oinfo64["GradNorm"])
     for (n, p), (n2, q) in zip(net.named_parameters(), onet.named_parameters()):
         assert n == n2
-        if q.grad is None:
+        if g64[n] is None:
             assert n in net._unused_params, n
             continue
-        gr = net.G(n)
-        want_n = float(q.grad.double().norm())
-        assert float(gr.double().norm()) == pytest.approx(want_n, rel=1e-4, abs=1e-6 * g64 + 1e-12), n
+        gh, gr, gx = net.G(n).cpu().double(), g32[n].double(), g64[n]
+        rms = float(gx.pow(2).mean().sqrt())
+        e_hip, e_ref = float((gh - gx).pow(2).mean().sqrt()), float((gr - gx).pow(2).mean().sqrt())
+        assert e_hip <= 2 * e_ref + 5e-5 * rms, (n, e_hip / rms, e_ref / rms)
+        assert float((gh - gx).abs().max()) <= 4 * float((gr - gx).abs().max()) + 5e-3 * rms, n
         idx = torch.from_numpy(np.unique(sample_idx(p.numel())))
-        rms = max(want_n / max(p.numel(), 1) ** 0.5, 1e-9)
-        close(f"grad samples {n}", gr.reshape(-1)[idx.to(DEV)], q.grad.reshape(-1)[idx], g_tol * rms + 1e-10, 4e-4)
-        # a first RMSprop step moves a weight by lr * g / (sqrt(0.01 g^2) + 1e-8) ~ lr * 10 whatever |g|: weights whose
-        # gradient is noise-level are pinned by the bound only
+        # a first RMSprop step moves a weight by lr * g / (sqrt(0.01 g^2) + 1e-8) ~ lr * 10 whatever |g|
         close(f"param samples {n}", p.detach().reshape(-1)[idx.to(DEV)], q.detach().reshape(-1)[idx], 3e-5, 1e-5)
 
 
-def test_full_size_headline_update_matches_the_oracle_updater():
+def test_full_size_headline_update_matches_the_oracle_updater(monkeypatch):
     """A3CModel, 256 envs x 128 steps (N = 32,768: the stash-only forward, wgrad_stream / bwd_stream / wgrad_run kernels,
     the rank-A backward and the skinny reductions at their full row counts), rollout through the headline path
     (zero-copy ring kernel, packed frames), then update_model from the stash vs OracleUpdater on the SAME recorded
@@ -254,10 +271,11 @@ def test_full_size_headline_update_matches_the_oracle_updater():
                 g = upd.capture_update(D)
                 info = g.replay()
             assert not upd.flat_scan_fallback
-            oinfo = oupd.update_model(Do)
             if ep == 0:
-                _compare_full_update(net, upd, info, onet, oinfo)
+                oinfo, g32, oinfo64, g64 = _oracle_updates_fp32_and_fp64("A3CModel", ss, A, 256, oupd, Do, hyps, monkeypatch)
+                _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, hyps["max_norm"])
             else:
+                oinfo = oupd.update_model(Do)
                 # second update: the nets differ by the first step's fp32 noise (RMSprop, see _compare_full_update) and the
                 # rollouts by what that did to a few sampled actions; the scalars still agree to ~1e-3
                 for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy", "GradNorm"):
@@ -268,7 +286,7 @@ def test_full_size_headline_update_matches_the_oracle_updater():
     torch.set_num_threads(4)
 
 
-def test_full_size_conv_32x64_update_matches_the_oracle_updater():
+def test_full_size_conv_32x64_update_matches_the_oracle_updater(monkeypatch):
     """ConvModel 32 x 64 (BASELINE configs[1]; N = 2,048): relay rollout with every layer + embedding stashed, update vs
     OracleUpdater on the recorded buffers."""
     from a2c_amd.hostpool import ThreadEnvPool
@@ -290,8 +308,9 @@ def test_full_size_conv_32x64_update_matches_the_oracle_updater():
         Do = {k: v.cpu().clone() for k, v in D.items()}
         upd = Updater(net, hyps)
         info = upd.update_model(D)
-        oinfo = O.OracleUpdater(onet, hyps).update_model(Do)
-        _compare_full_update(net, upd, info, onet, oinfo)
+        oinfo, g32, oinfo64, g64 = _oracle_updates_fp32_and_fp64("ConvModel", ss, A, 256, O.OracleUpdater(onet, hyps), Do, hyps,
+                                                                 monkeypatch)
+        _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, hyps["max_norm"])
     finally:
         r.close()
     torch.set_num_threads(4)

@@ -139,6 +139,15 @@ def pong_prep(pic):
     return pic[None]
 
 
+def breakout_prep(pic):
+    """preprocessing.py:19-23: crop 35:195 x 8:-8, 2x downsample of channel 0, then skimage's rgb2grey -- which, for the
+    2-D slice it is handed, returns the array unchanged in every scikit-image release that still has the name
+    (<= 0.18; pinned by tests/golden/g9_preprocessing.npz under exactly that stub)."""
+    pic = pic[35:195, 8:-8]
+    pic = pic[::2, ::2, 0]
+    return np.ascontiguousarray(pic)[None]
+
+
 # --------------------------------------------------------------------------
 # models.py  --  parameter shapes and functional forwards
 # --------------------------------------------------------------------------

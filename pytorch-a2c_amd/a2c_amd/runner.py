@@ -239,9 +239,13 @@ class Runner:
                 # (a caller that trickles them) still work: whatever arrived is played in lock-step rounds.
                 n_tok = int(try_key(self.hyps, "n_rollouts", None) or self.B)
                 stop = False
+                # The rest of the epoch's tokens: block for them (a partial batch would be played with a different
+                # slot -> env mapping, which defeats the activation stash and captures a second set of slot graphs); a
+                # caller that really trickles fewer tokens than n_rollouts says so with hyps["gate_timeout_s"]
+                gate_to = try_key(self.hyps, "gate_timeout_s", None)
                 while len(idxs) < n_tok:
                     try:
-                        tok = self.gate_q.get(timeout=0.05)
+                        tok = self.gate_q.get(timeout=gate_to)
                     except queue.Empty:
                         break
                     if tok is None:
@@ -317,18 +321,28 @@ class Runner:
             ops.store_u32_system(dev_phase, 1)
         elif self.proc_pool:
             self.env_pool.set_phase(1)
-        for r0 in range(0, len(idxs), self.B):
-            rnd = idxs[r0:r0 + self.B]
-            j = 0
-            while j < len(rnd):
-                k = j
-                while k + 1 < len(rnd) and rnd[k + 1] == rnd[k] + 1 and (seqs is None or seqs[k + 1] == seqs[j]):
-                    k += 1
-                self._rollout_block(net, rnd[j], j, k - j + 1, hyps)
-                stash_all = stash_all and self._stash_used
-                if self.proc_pool:
-                    self.env_pool.advance(j, k - j + 1, T_)
-                j = k + 1
+        try:
+            for r0 in range(0, len(idxs), self.B):
+                rnd = idxs[r0:r0 + self.B]
+                j = 0
+                while j < len(rnd):
+                    k = j
+                    while k + 1 < len(rnd) and rnd[k + 1] == rnd[k] + 1 and (seqs is None or seqs[k + 1] == seqs[j]):
+                        k += 1
+                    self._rollout_block(net, rnd[j], j, k - j + 1, hyps)
+                    stash_all = stash_all and self._stash_used
+                    if self.proc_pool:
+                        self.env_pool.advance(j, k - j + 1, T_)
+                    j = k + 1
+        except BaseException:
+            # an env time-out, a lock-step violation or a failed capture must not leave the workers spinning on their cmd
+            # granules until close(): back to the sleeping phase from the HOST (the stream may be unusable)
+            if self.proc_pool:
+                try:
+                    self.env_pool.set_phase(0)
+                except Exception:      # noqa: BLE001
+                    pass
+            raise
         if dev_phase:       # ... the last env step has been played: the workers sleep-poll through the update
             ops.store_u32_system(dev_phase, 0)
         if stash_all:

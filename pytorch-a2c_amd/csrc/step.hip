@@ -182,6 +182,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float4* __restrict__ fv = reinterpret_cast<float4*>(fr1);
     fv[tid] = wf1v[tid]; fv[tid + NT] = wf1v[tid + NT];
     if (tid < 32) red[HN + tid] = ld_b2;
+    if (tid == 0) reinterpret_cast<unsigned int*>(red)[HN + 37] = 0u;      // "the env worker timed out" flag of the polls below
   }
 
   // PERSIST: this workgroup plays envs blockIdx.x, blockIdx.x + gridDim.x, ... in turn, time step by time step
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       if (t > 0) {
         // wait for the env worker: rec granule = ((seq << 1 | done) << 32) | float_bits(reward), frame written before it
         if (tid == 0) {
-          const unsigned int want = p.x.seq0 + (unsigned int)t;
+          const unsigned int want = (p.x.seq0 + (unsigned int)t) & 0x7fffffffu;     // rec carries seq modulo 2^31
           const unsigned long long t0 = wall_clock64();
           unsigned long long gr;
           for (;;) {
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if ((unsigned int)(gr >> 33) == want) break;
             if ((long)(wall_clock64() - t0) > p.x.timeout_ticks) {
               __hip_atomic_store(p.x.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              gr = ~0ULL;
+              reinterpret_cast<unsigned int*>(red)[HN + 37] = 1u;      // its own flag: every granule value is a legal answer
               break;
             }
             __builtin_amdgcn_s_sleep(16);
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __syncthreads();
         const unsigned int g_lo = reinterpret_cast<const unsigned int*>(red)[HN + 32];
         const unsigned int g_hi = reinterpret_cast<const unsigned int*>(red)[HN + 33];
-        if (g_hi == 0xffffffffu) break;              // host timeout: the error flag is set, give up on this slot
+        if (reinterpret_cast<const unsigned int*>(red)[HN + 37] != 0u) break;   // host timeout: the error flag is set, give up on this slot
         ld_r = __uint_as_float(g_lo);
         ld_d = (g_hi & 1u) ? 1.f : 0.f;
         ld_rst = ld_d;
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int q = 0; q < 4; ++q) f2[tid + q * NT] = wf2v[tid + q * NT];
   }
   if (tid < 32) red[HN + tid] = a.bias2[tid];
+  if (tid == 0) reinterpret_cast<unsigned int*>(red)[HN + 37] = 0u;        // "the env worker timed out" flag of the polls below
   const float4 b1v = *reinterpret_cast<const float4*>(a.bias1 + 4 * g);
   const float b1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
   float4 wc[2][HNT];
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           if ((unsigned int)(gr >> 33) == want) break;
           if ((long)(wall_clock64() - t0) > p.x.timeout_ticks) {
             __hip_atomic_store(p.x.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            gr = ~0ULL;
+            if (lane == 0) reinterpret_cast<unsigned int*>(red)[HN + 37] = 1u;   // its own flag: every granule value is a legal answer
             break;
           }
           for (int q = 0; q < p.x.poll_gap; ++q) __builtin_amdgcn_s_sleep(1);
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const unsigned int g_lo = reinterpret_cast<const unsigned int*>(red)[HN + 32];
       const unsigned int g_hi = reinterpret_cast<const unsigned int*>(red)[HN + 33];
       const bool in_ring = reinterpret_cast<const unsigned int*>(red)[HN + 36] != 0u;
-      if (g_hi == 0xffffffffu) break;                   // host timeout: the error flag is set, give up on this slot
+      if (reinterpret_cast<const unsigned int*>(red)[HN + 37] != 0u) break;   // host timeout: the error flag is set, give up on this slot
       ld_r = __uint_as_float(g_lo);
       ld_d = (g_hi & 1u) ? 1.f : 0.f;
       if (!in_ring) {

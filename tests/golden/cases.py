@@ -99,6 +99,21 @@ def sample_idx(n):
 
 
 
+def atari_frame(seed):
+    """210 x 160 x 3 uint8 frame shaped like ALE's: random pixels + patches of Pong's two background colours
+    (144, 109: preprocessing.py:14-15) + black / white runs, so that every branch of pong_prep is exercised"""
+    rng = np.random.default_rng(9000 + seed)
+    f = rng.integers(0, 256, size=(210, 160, 3), dtype=np.uint8)
+    f[35 + 2 * seed:75, 10:60, 0] = 144
+    f[90:130, 40 + 4 * seed:120, 0] = 109
+    f[140:150, :, 0] = 0
+    f[150:160, 30:90] = 255
+    return f
+
+
+PREP_SEEDS = (0, 1, 2, 3)
+
+
 class U8FakeEnv(O.FakeEnv):
     """O.FakeEnv with its (binary) frames as uint8, like pong_prep's output (preprocessing.py:11-17): the
     host pool then carries uint8 frames; values are identical to FakeEnv's float64 ones."""

@@ -338,9 +338,36 @@ def g8():
     save("g8_stats.npz", **out)
 
 
+def g9():
+    """The reference's own pong_prep / breakout_prep / null_prep (preprocessing.py:8-23) on Atari-shaped frames.
+    preprocessing.py imports skimage.color.rgb2grey, which is not installed: it is stubbed with the documented behaviour
+    of scikit-image <= 0.18 for the ONLY call the file makes (a 2-D array is returned unchanged, `rgb2gray`:
+    "if rgb.ndim == 2: return np.ascontiguousarray(rgb)"); a non-2-D input raises, so a change of the call would show.
+    pong_prep and null_prep do not touch the stub: those vectors are the reference's, unconditionally."""
+    from cases import atari_frame, PREP_SEEDS
+
+    def rgb2grey(a):
+        a = np.asarray(a)
+        if a.ndim != 2:
+            raise AssertionError("stub: the reference only ever passes a 2-D slice")
+        return np.ascontiguousarray(a)
+    _stub("skimage")
+    _stub("skimage.color", rgb2grey=rgb2grey)
+    spec = importlib.util.spec_from_file_location("a2c.preprocessing", os.path.join(REF, "preprocessing.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    out = {}
+    for s_ in PREP_SEEDS:
+        out[f"pong{s_}"] = np.array(m.pong_prep(atari_frame(s_)))
+        out[f"breakout{s_}"] = np.array(m.breakout_prep(atari_frame(s_)))
+        out[f"null{s_}_shape"] = np.array(m.null_prep(atari_frame(s_)).shape)
+        assert out[f"pong{s_}"].dtype == np.uint8 and out[f"breakout{s_}"].dtype == np.uint8
+    save("g9_preprocessing.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for fn in sys.argv[1:]:
             globals()[fn]()
     else:
-        g1(); g2(); g3(); g4(); g5(); g6(); g7(); g8()
+        g1(); g2(); g3(); g4(); g5(); g6(); g7(); g8(); g9()

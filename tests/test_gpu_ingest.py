@@ -422,3 +422,37 @@ def test_first_layer_weight_gradient_from_the_single_frame_store():
     for k in range(3):
         ga, gb = res[True][k], res[False][k]
         close(f"gradient arena, round {k}", ga, gb, 2e-6 * float(gb.abs().max()), 1e-5)
+
+
+@pytest.mark.parametrize("ingest,no_ring", [("zero-copy", False), ("zero-copy", True), ("relay", False)])
+def test_device_side_polls_across_the_2_31_step_counter_wrap(ingest, no_ring, monkeypatch):
+    """rec carries the step number modulo 2^31 (a2c_hostpool.h): the ring kernel, the persistent per-step kernel
+    (A2C_NO_RING=1; also what runs with more envs than CUs) and the relay's a2c_pool_ingest must all compare modulo
+    2^31 -- an env that has taken 2^31 - 3 steps keeps being served across the wrap, and the granule value
+    0xffffffff'xxxxxxxx (seq = 2^31 - 1 with done = 1) is an answer, not a time-out."""
+    from a2c_amd.runner import Runner
+    if no_ring:
+        monkeypatch.setenv("A2C_NO_RING", "1")
+    B, T, A, ss = 3, 4, 3, (4, 84, 84)
+    s0 = (1 << 31) - 6
+    # done_period 5: env step number 5 (granule seq 2^31 - 1) reports done = 1 -> high word 0xffffffff
+    ekws = [dict(env_id=j, rew_period=2 + j, done_period=5) for j in range(B)]
+    hyps = base_hyps(env_type="FakeBreakout", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, env_timeout_s=20.0)
+    net = make_net("A3CModel", ss, A, 256)
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    us = torch.from_numpy(hashf(3 * T * B, 2231, 0, 1).reshape(3, T, B))
+    usd = us.to(DEV)
+    rnd = [0]
+    pool = _pool(U8FakeEnv, ekws, 2, pong=False, seq_start=s0)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest,
+               uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+    try:
+        refs = _oracle_rollouts("A3CModel", onet, hyps, ekws, us, 3, B, T, ss)
+        for rnd[0] in range(3):                       # 12 env steps: seq 2^31 - 6 ... 2^31 + 6
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            _compare_round(D, refs[rnd[0]], False)
+        assert pool.seq == s0 + 3 * T
+    finally:
+        r.close()

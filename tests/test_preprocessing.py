@@ -1,5 +1,6 @@
-"""CPU: host-side frame preprocessing against the oracle's restatement
-on hand-made Atari-shaped frames (the reference's own file needs skimage, which is not installed)."""
+"""CPU: host-side frame preprocessing against the oracle's restatement on hand-made
+Atari-shaped frames, and both against the REFERENCE's own outputs (tests/golden/g9_preprocessing.npz, recorded by
+make_golden.py g9 from /root/reference/a2c/preprocessing.py with skimage.color stubbed)."""
 import numpy as np
 
 from a2c_amd import preprocessing as P
@@ -33,3 +34,16 @@ def test_null_and_breakout_prep():
     assert np.array_equal(b[0], f[35:195, 8:-8][::2, ::2, 0])
     n = P.normalize_prep(np.array([[0.0, 255.0]]))
     assert np.allclose(n, [[[-3.0, 3.0]]])
+
+
+def test_preprocessors_match_the_reference_recorded_outputs(golden):
+    from cases import PREP_SEEDS, atari_frame
+    g = golden["g9_preprocessing"]
+    for s in PREP_SEEDS:
+        for mod in (P, O):
+            out = mod.pong_prep(atari_frame(s))
+            assert out.dtype == g[f"pong{s}"].dtype and np.array_equal(out, g[f"pong{s}"]), (mod.__name__, s)
+            out = mod.breakout_prep(atari_frame(s))
+            assert out.dtype == g[f"breakout{s}"].dtype and np.array_equal(out, g[f"breakout{s}"]), (mod.__name__, s)
+            assert tuple(mod.null_prep(atari_frame(s)).shape) == tuple(g[f"null{s}_shape"])
+        assert int(g[f"pong{s}"].sum()) > 0 and int((g[f"pong{s}"] == 0).sum()) > 1000       # both branches present

@@ -112,6 +112,34 @@ int a2c_pool_ingest_bits(const uint64_t *rec, const uint8_t *frames, int64_t fra
 int a2c_unpack_bits(const uint8_t *src, int64_t src_stride, uint8_t *dst, int64_t dst_stride, int n,
                     int n_pixels, a2c_stream_t stream);
 
+/* ------------------------------------------------------------------ f4: preprocessing on the device, single-frame store
+ * a2c_frame_prep_u8 = pong_prep / breakout_prep (preprocessing.py:11-23) on n raw (H, W, C) uint8 frames, raw_stride
+ * bytes apart: out[oy][ox] = raw[y0 + oy*step][x0 + ox*step][0] for the crop y0:y1, x0:x1; binarise != 0 applies
+ * pong_prep's "144 and 109 -> 0, everything else that is not 0 -> 1" (preprocessing.py:14-16); binarise == 0 keeps the
+ * byte (breakout_prep: skimage <= 0.18's rgb2grey returns a 2-D slice unchanged).  pong_prep = (35, 195, 0, W, 2, 1),
+ * breakout_prep = (35, 195, 8, W - 8, 2, 0).  Output rows out_stride bytes apart, OW % 4 == 0.                      */
+int a2c_frame_prep_u8(const uint8_t *raw, int64_t raw_stride, int H, int W, int C, int y0, int y1, int x0, int x1,
+                      int step, int binarise, uint8_t *out, int64_t out_stride, int n, a2c_stream_t stream);
+/* Single-frame uint8 store (utils.py:26-43, runner.py:199 behind the boundary): slot r keeps T + C frames of HW bytes,
+ * slot_stride bytes apart; state (r, t) = the window frames[r][t .. t+C-1], planes c < C - nvalid are zero (frames from
+ * before the env's last reset).  a2c_frame_store_begin: start of a slot -- frames[r][0..C-1] = frames[r][T..T+C-1]
+ * (the state the previous slot ended in), nvalid_rows[r*T] = nvalid_carry[r].  a2c_rollout_post_frames: the bookkeeping
+ * of a2c_rollout_post[_rec] for env step t WITHOUT a frame-stack copy (the ingest wrote the new frame straight into
+ * frames[r][t+C]): rewards / dones / deltas / val_prev [/ hidden-state reset and h_states row], and the valid-plane
+ * count of state t+1 (1 after a real done, else min(count + 1, C)) into nvalid_rows[(slot0+b)*T + t+1] / nvalid_carry.
+ * a2c_frames_to_states: the reference's fp32 `states` rows from the store, on demand: state k (< nt) of slot r (< R)
+ * -> out + r*out_slot_stride + k*C*HW floats, valid-plane counts nvalid[r*nvalid_slot_stride + k] (NULL: all valid). */
+int a2c_frame_store_begin(uint8_t *frame_store, int64_t slot_stride, int64_t T, int C, int HW, int32_t *nvalid_rows,
+                          const int32_t *nvalid_carry, int B, a2c_stream_t stream);
+int a2c_rollout_post_frames(const float *rew, const float *done, const float *val, int64_t val_stride, float *val_prev,
+                            float *rewards, float *dones, float *deltas, int64_t T, int64_t t, int64_t slot0,
+                            float gamma, int pong, int B, float *done_eff, float *h, int hdim, float *h_rows,
+                            int64_t h_rows_stride, const float *h_src, int32_t *nvalid_rows, int32_t *nvalid_carry,
+                            a2c_stream_t stream);
+int a2c_frames_to_states(const uint8_t *frame_store, int64_t slot_stride, const int32_t *nvalid,
+                         int64_t nvalid_slot_stride, float *out, int64_t out_slot_stride, int R, int nt, int C, int HW,
+                         a2c_stream_t stream);
+
 /* ------------------------------------------------------------------ a2: sampler
  * SequentialEnvironment.get_action discrete branch (runner.py:94-97) + utils.sample_action
  * (utils.py:45-60): p = softmax(logits); running fp32 cumsum in index order; first a with
@@ -436,6 +464,17 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc *d, const float *in, int64_t in_bs
 int a2c_conv2d_bwd_weight_frames(const a2c_conv_desc *d, const uint8_t *frame_store, int64_t slot_stride,
                                  int64_t T, const int32_t *nvalid, const float *dout, float *dW,
                                  float *db, int B, void *ws, size_t ws_bytes, a2c_stream_t stream);
+/* ... and, with the same signature, for the first layer of the 3x3 stacks (ConvModel / GRUModel: 4 -> 16 channels at
+ * 84 x 84, models.py:201-207, 570-576).  Their FORWARD with the input stacked on load (rollout step: sample b reads the
+ * window frame_store + b * sample_stride, T = 1, nvalid[b * nvalid_stride]; in general sample n reads
+ * frame_store + (n / T) * sample_stride + (n % T) * H * W): the loader waves of the streaming kernel expand the bytes to
+ * the fp32 image, planes c < 4 - nvalid are zero; everything else is a2c_conv2d_fwd[_signs] (signs may be NULL).
+ * a2c_conv2d_fwd_frames_supported: 1 when the layer has such a kernel (else: a2c_frames_to_states + a2c_conv2d_fwd).  */
+int a2c_conv2d_fwd_frames_supported(const a2c_conv_desc *d);
+int a2c_conv2d_fwd_frames(const a2c_conv_desc *d, const uint8_t *frame_store, int64_t sample_stride, int64_t T,
+                          const int32_t *nvalid, int64_t nvalid_stride, const float *wprep_fwd, const float *bias,
+                          int relu, float *out, int64_t out_bstride, uint32_t *signs, int64_t signs_bstride, int B,
+                          a2c_stream_t stream);
 
 /* ------------------------------------------------------------------ a6: GRU cell, LayerNorm
  * models.GRU.forward (models.py:465-476) given the six pre-activation products:

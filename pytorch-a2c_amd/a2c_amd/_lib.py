@@ -123,6 +123,13 @@ SIGNATURES = {
     "a2c_conv2d_bwd_data_w1": (c_int, [PD, P, P, P, PD, P, c_int64, P, P, c_int, P, c_size_t, P]),
     "a2c_conv2d_bwd_weight": (c_int, [PD, P, c_int64, P, P, P, c_int, P, c_size_t, P]),
     "a2c_conv2d_bwd_weight_frames": (c_int, [PD, P, c_int64, c_int64, P, P, P, P, c_int, P, c_size_t, P]),
+    "a2c_conv2d_fwd_frames_supported": (c_int, [PD]),
+    "a2c_conv2d_fwd_frames": (c_int, [PD, P, c_int64, c_int64, P, c_int64, P, P, c_int, P, c_int64, P, c_int64, c_int, P]),
+    "a2c_frame_prep_u8": (c_int, [P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, c_int, P]),
+    "a2c_frame_store_begin": (c_int, [P, c_int64, c_int64, c_int, c_int, P, P, c_int, P]),
+    "a2c_rollout_post_frames": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_int, c_int, P, P,
+                                        c_int, P, c_int64, P, P, P, P]),
+    "a2c_frames_to_states": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, P]),
     "a2c_gru_gates": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "a2c_gru_out": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "a2c_gru_out_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),

@@ -493,6 +493,58 @@ def conv_bwd_weight_frames(d, fstore, slot_stride, T, nvalid, dout, dW, db, B, w
                                              st if st is not None else stream()), "a2c_conv2d_bwd_weight_frames")
 
 
+def conv_fwd_frames_supported(d):
+    return bool(lib().a2c_conv2d_fwd_frames_supported(ctypes.byref(d)))
+
+
+def conv_fwd_frames(d, fstore_ptr, sample_stride, T, nvalid_ptr, nvalid_stride, wprep, bias, relu, out, B, st=None,
+                    out_bstride=None, signs=None):
+    """first-layer forward with the input stacked on load from the single-frame uint8 store (raw device addresses:
+    the window of sample b starts at fstore_ptr + (b // T) * sample_stride + (b % T) * H * W); signs = (ptr, row stride)"""
+    out_ptr = out if isinstance(out, int) else _p(out)
+    sg, sgs = signs if signs is not None else (0, 0)
+    check(lib().a2c_conv2d_fwd_frames(ctypes.byref(d), fstore_ptr, sample_stride, T, nvalid_ptr, nvalid_stride, _p(wprep), _p(bias),
+                                      int(bool(relu)), out_ptr, d.Cout * d.OH * d.OW if out_bstride is None else out_bstride,
+                                      sg, sgs, B, st if st is not None else stream()), "a2c_conv2d_fwd_frames")
+
+
+# ---------------------------------------------------------------- f4: device preprocessing, single-frame store
+PREP_SPECS = {"pong_prep": (35, 195, 0, None, 2, 1), "breakout_prep": (35, 195, 8, -8, 2, 0)}     # preprocessing.py:11-23
+
+
+def prep_out_shape(name, H, W):
+    y0, y1, x0, x1, step, _ = PREP_SPECS[name]
+    x1 = W if x1 is None else (W + x1 if x1 < 0 else x1)
+    return (1, (y1 - y0 + step - 1) // step, (x1 - x0 + step - 1) // step)
+
+
+def frame_prep_u8(name, raw_ptr, raw_stride, H, W, C, out_ptr, out_stride, n, st=None):
+    """pong_prep / breakout_prep on n raw (H, W, C) uint8 frames in HBM -> prepped uint8 frames"""
+    y0, y1, x0, x1, step, binarise = PREP_SPECS[name]
+    x1 = W if x1 is None else (W + x1 if x1 < 0 else x1)
+    check(lib().a2c_frame_prep_u8(raw_ptr, raw_stride, H, W, C, y0, y1, x0, x1, step, binarise, out_ptr, out_stride, n,
+                                  st if st is not None else stream()), "a2c_frame_prep_u8")
+
+
+def frame_store_begin(fstore_ptr, slot_stride, T, C, HW, nvalid_rows_ptr, nvalid_carry_ptr, B, st=None):
+    check(lib().a2c_frame_store_begin(fstore_ptr, slot_stride, T, C, HW, nvalid_rows_ptr, nvalid_carry_ptr, B,
+                                      st if st is not None else stream()), "a2c_frame_store_begin")
+
+
+def rollout_post_frames(rew, done, val_ptr, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma, pong, B, done_eff,
+                        h, h_rows_ptr, h_rows_stride, h_src_ptr, nvalid_rows, nvalid_carry_ptr, st=None):
+    """bookkeeping of env step t for the single-frame store (no frame-stack copy), see the header"""
+    check(lib().a2c_rollout_post_frames(_p(rew), _p(done), val_ptr, val_stride, _p(val_prev), _p(rewards), _p(dones), _p(deltas),
+                                        T, t, slot0, float(gamma), int(bool(pong)), B, _p(done_eff), _p(h),
+                                        0 if h is None else h.shape[1], h_rows_ptr, h_rows_stride, h_src_ptr, _p(nvalid_rows),
+                                        nvalid_carry_ptr, st if st is not None else stream()), "a2c_rollout_post_frames")
+
+
+def frames_to_states(fstore_ptr, slot_stride, nvalid_ptr, nvalid_slot_stride, out_ptr, out_slot_stride, R, nt, C, HW, st=None):
+    check(lib().a2c_frames_to_states(fstore_ptr, slot_stride, nvalid_ptr, nvalid_slot_stride, out_ptr, out_slot_stride, R, nt, C,
+                                     HW, st if st is not None else stream()), "a2c_frames_to_states")
+
+
 # ---------------------------------------------------------------- GRU / LayerNorm
 def gru_gates(gx, gh, b, h, z, r, rh, st=None):
     B, hd = h.shape

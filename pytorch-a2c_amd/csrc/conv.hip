@@ -42,6 +42,11 @@ bool c3w_supported(const a2c_conv_desc* d);
 size_t c3w_ws_bytes(const a2c_conv_desc* d);
 int c3w_bwd_weight(const a2c_conv_desc* d, const float* in, long in_bs, const float* dout, float* dW, float* db, int B, void* ws,
                    size_t ws_bytes, hipStream_t st);
+bool c3_fwd_frames_supported(const a2c_conv_desc* d);
+int c3_fwd_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long T, const int* nv, long nv_s, const float* frag,
+                  const float* bias, int relu, float* out, long out_bs, unsigned* signs, long signs_bs, int B, hipStream_t st);
+int c3w_bwd_weight_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long T, const int* nv, const float* dout,
+                          float* dW, float* db, int B, void* ws, size_t ws_bytes, hipStream_t st);
 
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -2993,6 +2998,22 @@ int a2c_conv2d_fwd_signs(const a2c_conv_desc* d, const float* in, int64_t in_bst
                 (long)signs_bstride, B, a2c_s(stream));
 }
 
+int a2c_conv2d_fwd_frames_supported(const a2c_conv_desc* d) { return desc_ok(d) && c3_fwd_frames_supported(d) ? 1 : 0; }
+
+int a2c_conv2d_fwd_frames(const a2c_conv_desc* d, const uint8_t* frame_store, int64_t sample_stride, int64_t T,
+                          const int* nvalid, int64_t nvalid_stride, const float* wprep_fwd, const float* bias, int relu,
+                          float* out, int64_t out_bstride, uint32_t* signs, int64_t signs_bstride, int B, a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 0 || T < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!frame_store || !wprep_fwd || !out || !c3_fwd_frames_supported(d)) return A2C_ERR_ARG;
+  if (((uintptr_t)frame_store % 4) || sample_stride % 4 || sample_stride < (T + 3) * (int64_t)d->H * d->W || out_bstride % 4 ||
+      ((uintptr_t)out % 16))
+    return A2C_ERR_ARG;
+  if (signs && (c3_sign_words(d) == 0 || signs_bstride < c3_sign_words(d))) return A2C_ERR_ARG;
+  return c3_fwd_frames(d, frame_store, (long)sample_stride, (long)T, nvalid, (long)nvalid_stride, wprep_fwd + prep_floats_base(d, 0),
+                       bias, relu, out, (long)out_bstride, signs, (long)signs_bstride, B, a2c_s(stream));
+}
+
 }  // extern "C"
 namespace {
 constexpr int BAND_NA = -1000;
@@ -3374,6 +3395,13 @@ int a2c_conv2d_bwd_weight_frames(const a2c_conv_desc* d, const uint8_t* fstore, 
                                  const int* nvalid, const float* dout, float* dW, float* db, int B, void* ws, size_t ws_bytes,
                                  a2c_stream_t stream) {
   if (!desc_ok(d) || B < 1 || !fstore || !nvalid || !dout || !dW || T < 1) return A2C_ERR_ARG;
+  if (c3w_supported(d) && d->Cin == 4) {          // first layer of the 3x3 stacks (ConvModel / GRUModel): conv3.hip's streaming kernel
+    if (((uintptr_t)fstore % 4) || slot_stride % 4 || ((uintptr_t)dout % 16) || ((uintptr_t)dW % 16) || ((uintptr_t)ws % 16) ||
+        slot_stride < (T + 3) * (int64_t)d->H * d->W)
+      return A2C_ERR_ARG;
+    if (!ws || ws_bytes < a2c_conv2d_bwd_weight_ws_bytes(d, B)) return A2C_ERR_WORKSPACE;
+    return c3w_bwd_weight_frames(d, fstore, (long)slot_stride, (long)T, nvalid, dout, dW, db, B, ws, ws_bytes, a2c_s(stream));
+  }
   WstreamP wp;
   if (!plan_wstream(d, wp) || (d->H * d->W) % 16 || ((uintptr_t)fstore % 16) || slot_stride % 16 || ((uintptr_t)dout % 16) ||
       slot_stride < (T + 3) * (int64_t)d->H * d->W)

@@ -97,6 +97,48 @@ __device__ __forceinline__ void c3_sign4(unsigned* __restrict__ bbc, int p0, int
 // under load) and hold up the computing waves with it.  Loaders wait for their LDS-DMA (vmcnt) themselves before they arrive.
 __device__ __forceinline__ void c3_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Stack-on-load source of a FIRST layer: the 4 input planes of sample b are a window of 4
+// consecutive uint8 frames of a single-frame store -- f + (b / T) * bs + (b % T) * H * W bytes (rollout step: T = 1 and
+// bs = the slot stride; update: sample n = slot * T + t) -- of which the oldest 4 - nv[b * nv_s] are planes from before
+// the env's last reset and read as zero (utils.py:37-42).  The loader waves expand the bytes to the fp32 image the
+// computing waves read: same values, same summation order as from the fp32 state (runner.py:199 `FloatTensor(state)`).
+struct C3U8 {
+  const unsigned char* f; long bs; const int* nv; long nv_s; long T;
+};
+
+// loader waves, uint8 source: the rows y0 .. y0 + SR - 1 of the planes c % NL == lw of one sample -> the fp32 image
+// (rows of WP = W + 4 floats: 4 floats of pad, zeroed once per launch by c3_u8_zero_pads, then the row)
+template <int H, int W, int SR, int WP, int PLANE, int NL>
+__device__ __forceinline__ void c3_u8_stage(float* __restrict__ buf, const C3U8& u, long b, int y0, int lw, int lane) {
+  static_assert(W % 4 == 0, "rows of whole dwords");
+  constexpr int RP = W / 4, PPL = SR * RP, NQ8 = (PPL + 63) / 64;
+  const unsigned char* __restrict__ fb = u.f + (b / u.T) * u.bs + (b % u.T) * (long)(H * W);
+  const int nvl = u.nv ? u.nv[b * u.nv_s] : 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c % NL != lw) continue;
+    const bool live = c >= 4 - nvl;
+    unsigned v[NQ8];
+#pragma unroll
+    for (int q = 0; q < NQ8; ++q) {
+      const int pi = q * 64 + lane, r = pi / RP, i = pi - r * RP, y = y0 + r;
+      v[q] = (pi < PPL && live && y >= 0 && y < H) ? *reinterpret_cast<const unsigned*>(fb + ((long)c * H + y) * W + 4 * i) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ8; ++q) {
+      const int pi = q * 64 + lane, r = pi / RP, i = pi - r * RP;
+      if (pi < PPL)
+        *reinterpret_cast<float4*>(buf + c * PLANE + r * WP + 4 + 4 * i) =
+            make_float4((float)(v[q] & 0xffu), (float)((v[q] >> 8) & 0xffu), (float)((v[q] >> 16) & 0xffu), (float)(v[q] >> 24));
+    }
+  }
+}
+template <int SR, int WP, int PLANE>
+__device__ __forceinline__ void c3_u8_zero_pads(float* __restrict__ buf, int lane, int lw, int nl) {
+  for (int i = lw * 64 + lane; i < 4 * SR; i += 64 * nl)
+    *reinterpret_cast<float4*>(buf + (i / SR) * PLANE + (i % SR) * WP) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 struct C3P {
   const float* src; long src_bs;      // source tensor (B, CS, H, W) and its sample stride (floats)
   const float* frag;                  // [chunk][tap][c4][m][64] weight fragments (c3_prep_kernel)
@@ -110,6 +152,7 @@ struct C3P {
   unsigned* sg_out;                   // forward: written for the output, or nullptr
   const unsigned* sg_in;              // backward-data: the ReLU mask of the layer below as sign words, or nullptr
   long sg_bs;                         // sample stride of the sign words (in words)
+  C3U8 u8;                            // first layers: uint8 frame-store source instead of src (u8.f != nullptr)
 };
 
 template <int CS, int CD, int H, int W, int S, int R, int KCO = 0>
@@ -255,6 +298,14 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
       rrow[q] = (pi < G::PP) ? (i == 0 ? -100000 : r) : -200000;      // pad piece: zeros; beyond the plane: no lane
       roff[q] = r * W + G::PB * (i - 1);
     }
+    constexpr bool U8OK = CS == 4 && W % 4 == 0 && !BWD;
+    const bool u8 = U8OK && p.u8.f != nullptr;
+    if constexpr (U8OK) {
+      if (u8) {
+        c3_u8_zero_pads<G::SR, G::WP, G::PLANE>(lds, lane, lw, G::NL);
+        c3_u8_zero_pads<G::SR, G::WP, G::PLANE>(lds + G::BUF, lane, lw, G::NL);
+      }
+    }
     auto dma = [&](long k) {
       const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
       const int ch = (int)(k % G::NCH);
@@ -263,9 +314,16 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
       const int y0 = band * R * S - 1;
       float* __restrict__ buf = lds + (k & 1) * G::BUF;
       const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * G::KC * H + y0) * W;
+      bool staged = false;
+      if constexpr (U8OK) {
+        if (u8) {
+          c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(buf, p.u8, b, y0, lw, lane);
+          staged = true;
+        }
+      }
 #pragma unroll
       for (int c = 0; c < G::KC; ++c) {
-        if (c % G::NL != lw) continue;
+        if (staged || c % G::NL != lw) continue;
 #pragma unroll
         for (int q = 0; q < G::NQ; ++q) {
           if (rrow[q] > -200000) {
@@ -868,6 +926,14 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
       rrow[q] = (pi < G::PP) ? (i == 0 ? -100000 : r) : -200000;
       roff[q] = r * W + G::PB * (i - 1);
     }
+    constexpr bool U8OK = CS == 4 && W % 4 == 0 && !BWD;
+    const bool u8 = U8OK && p.u8.f != nullptr;
+    if constexpr (U8OK) {
+      if (u8) {
+        c3_u8_zero_pads<G::SR, G::WP, G::PLANE>(lds, lane, lw, G::NL);
+        c3_u8_zero_pads<G::SR, G::WP, G::PLANE>(lds + G::BUF, lane, lw, G::NL);
+      }
+    }
     auto dma = [&](long k) {
       const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
       const int ch = (int)(k % G::NCH);
@@ -876,9 +942,16 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
       const int y0 = band * R * S - 1;
       float* __restrict__ buf = lds + (k & 1) * G::BUF;
       const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * G::KC * H + y0) * W;
+      bool staged = false;
+      if constexpr (U8OK) {
+        if (u8) {
+          c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(buf, p.u8, b, y0, lw, lane);
+          staged = true;
+        }
+      }
 #pragma unroll
       for (int c = 0; c < G::KC; ++c) {
-        if (c % G::NL != lw) continue;
+        if (staged || c % G::NL != lw) continue;
 #pragma unroll
         for (int q = 0; q < G::NQ; ++q) {
           if (rrow[q] > -200000) {
@@ -1433,6 +1506,7 @@ struct C3WP {
   float* slab;                        // [grid * NPG][CD*CS*9 + CD]
   const float* zero;
   int B;
+  C3U8 u8;                            // first layer: uint8 frame-store source instead of x (u8.f != nullptr)
 };
 
 __global__ __launch_bounds__(256) void c3w_reduce_kernel(const float* __restrict__ slab, int nslab, long per, long nW,
@@ -1497,9 +1571,16 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
       const int y0 = band * R * S - 1;
       float* __restrict__ xb = xbuf + (k & 1) * G::XB;
       const float* __restrict__ sb = p.x + b * p.x_bs + ((long)ch * KC * H + y0) * W;
+      bool staged = false;
+      if constexpr (CS == 4 && KC == 4 && W % 4 == 0) {      // first layer from the single-frame uint8 store (stack-on-load)
+        if (p.u8.f != nullptr) {
+          c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(xb, p.u8, b, y0, lw, lane);
+          staged = true;
+        }
+      }
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
-        if (c % G::NL != lw) continue;
+        if (staged || c % G::NL != lw) continue;
 #pragma unroll
         for (int q = 0; q < G::NQ; ++q) {
           if (rrow[q] > -200000) {
@@ -1783,6 +1864,19 @@ int c3_fwd(const a2c_conv_desc* d, const float* in, long in_bs, const float* fra
   return A2C_ERR_ARG;
 }
 
+// first layer (4 -> 16 @ 84 x 84) with its input stacked on load from a single-frame uint8 store (C3U8)
+bool c3_fwd_frames_supported(const a2c_conv_desc* d) {
+  return c3_supported(d, 0) && d->Cin == 4 && d->Cout == 16 && d->H == 84 && d->W == 84 && d->stride == 1;
+}
+int c3_fwd_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long T, const int* nv, long nv_s, const float* frag,
+                  const float* bias, int relu, float* out, long out_bs, unsigned* signs, long signs_bs, int B, hipStream_t st) {
+  if (!c3_fwd_frames_supported(d)) return A2C_ERR_ARG;
+  C3P p{nullptr, 0, frag, bias, nullptr, out, out_bs, zero_page(), B, relu, g_c3_dbg, signs, nullptr, signs_bs, C3U8{f, bs, nv, nv_s, T}};
+  if (!p.zero) return A2C_ERR_LAUNCH;
+  if (signs != nullptr || B > 64) return c3s_launch<4, 16, 84, 84, 1, 12, false>(p, st);
+  return c3_launch<4, 16, 84, 84, 1, 6, false>(p, st);
+}
+
 // mask: the float activation below (the kernels that keep its band in LDS) -- or signs: its sign words (the staged kernels)
 int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, const float* mask, const unsigned* signs,
                 long signs_bs, float* din, int B, hipStream_t st) {
@@ -1849,6 +1943,14 @@ size_t c3w_ws_bytes(const a2c_conv_desc* d) {
 int c3w_bwd_weight(const a2c_conv_desc* d, const float* in, long in_bs, const float* dout, float* dW, float* db, int B, void* ws,
                    size_t ws_bytes, hipStream_t st) {
   C3WP p{in, in_bs, dout, (float*)ws, zero_page(), B};
+  if (!p.zero) return A2C_ERR_LAUNCH;
+  return c3w_dispatch(d, p, dW, db, ws_bytes, st, nullptr);
+}
+
+int c3w_bwd_weight_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long T, const int* nv, const float* dout,
+                          float* dW, float* db, int B, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!(c3w_supported(d) && d->Cin == 4)) return A2C_ERR_ARG;
+  C3WP p{nullptr, 0, dout, (float*)ws, zero_page(), B, C3U8{f, bs, nv, 1, T}};
   if (!p.zero) return A2C_ERR_LAUNCH;
   return c3w_dispatch(d, p, dW, db, ws_bytes, st, nullptr);
 }

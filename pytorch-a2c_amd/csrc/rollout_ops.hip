@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ rew
                                                    long prev_stride, float* __restrict__ out, long out_stride, int B,
                                                    int C, int HW, float* __restrict__ done_eff_out, float* h,
                                                    int hdim, float* __restrict__ h_rows, long h_rows_stride,
-                                                   const float* h_src) {
+                                                   const float* h_src, int* __restrict__ nv_rows = nullptr,
+                                                   int* __restrict__ nv_carry = nullptr) {
   if ((int)blockIdx.z == C + 1) {      // recurrent nets (runner.py:201,219-221): h = 0 where the episode ended, then
     if (blockIdx.x != 0) return;       // h_states[row] = h for the step that follows
     const int b = blockIdx.y;
@@ -147,6 +148,11 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ rew
       const float pr = rewards[e - 1], pd = dones[e - 1];
       const float gv = gamma * v;
       deltas[e - 1] = (pr + gv * (1.f - pd)) - val_prev[b];
+    }
+    if (nv_carry) {      // single-frame store: how many planes of the NEXT state are real frames (utils.py:37-42: a reset
+      const int nv = done[b] != 0.f ? 1 : min(nv_carry[b] + 1, 4);      // leaves the reset frame behind zeros)
+      nv_carry[b] = nv;
+      if (t + 1 < T) nv_rows[e + 1] = nv;
     }
     val_prev[b] = v;
     return;
@@ -266,19 +272,19 @@ __global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long lo
                                                           const unsigned int* __restrict__ seq_base, unsigned int seq_off,
                                                           long timeout_ticks, int* __restrict__ err, float* __restrict__ rew,
                                                           float* __restrict__ done, uint8_t* __restrict__ out, long ostride) {
-  __shared__ unsigned int sh[2];
+  __shared__ unsigned int sh[3];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {
     const unsigned int want = (seq_base[0] + seq_off) & 0x7fffffffu;      // rec carries the step number modulo 2^31
-    unsigned long long gr = ~0ULL;
+    unsigned long long gr = 0ULL;
+    unsigned int dead = 1u;                          // its own flag: every 64-bit value is a legal granule
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       const unsigned long long t0 = wall_clock64();
       for (;;) {
         gr = __hip_atomic_load(rec + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned int)(gr >> 33) == want) break;
+        if ((unsigned int)(gr >> 33) == want) { dead = 0u; break; }
         if ((long)(wall_clock64() - t0) > timeout_ticks) {
           __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          gr = ~0ULL;
           break;
         }
         __builtin_amdgcn_s_sleep(16);
@@ -286,10 +292,11 @@ __global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long lo
     }
     sh[0] = (unsigned int)gr;
     sh[1] = (unsigned int)(gr >> 32);
+    sh[2] = dead;
   }
   __syncthreads();
   const unsigned int lo = sh[0], hi = sh[1];
-  if (hi == 0xffffffffu) return;                      // timeout (now or earlier): the error flag is set
+  if (sh[2] != 0u) return;                            // timeout (now or earlier): the error flag is set
   if (tid == 0) {
     rew[b] = __uint_as_float(lo);
     done[b] = (hi & 1u) ? 1.f : 0.f;
@@ -308,6 +315,58 @@ __global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long lo
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(fr, off, 0, 1 | 16);   // sc0 sc1
     *reinterpret_cast<u32x4*>(o + off) = v;
   }
+}
+
+// ---- row f4 of SURVEY.md section 8: preprocessing on the device and the single-frame uint8 store -----------------
+// pong_prep / breakout_prep (preprocessing.py:11-23) on raw (H, W, C) uint8 frames: crop rows y0:y1 and columns x0:x1,
+// keep every `step`-th pixel of channel 0; binarise (Pong: 144 and 109 are background -> 0, everything else that is
+// not 0 -> 1) or keep the byte (Breakout: skimage's rgb2grey returns the 2-D slice unchanged, see a2c_amd/preprocessing.py)
+__global__ __launch_bounds__(256) void frame_prep_kernel(const uint8_t* __restrict__ raw, long raw_stride, int W, int C,
+                                                         int y0, int x0, int step, int OH, int OW, int binarise,
+                                                         uint8_t* __restrict__ out, long out_stride) {
+  const int b = blockIdx.y;
+  const uint8_t* __restrict__ r = raw + (long)b * raw_stride;
+  uint8_t* __restrict__ o = out + (long)b * out_stride;
+  const int n4 = (OH * OW) >> 2;                                     // 4 output pixels per thread (OW % 4 == 0)
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+    const int oy = (i * 4) / OW, ox = i * 4 - oy * OW;
+    unsigned int w = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned int v = r[((long)(y0 + oy * step) * W + (x0 + (ox + q) * step)) * C];
+      if (binarise) v = (v == 144u || v == 109u || v == 0u) ? 0u : 1u;
+      w |= v << (8 * q);
+    }
+    reinterpret_cast<unsigned int*>(o)[i] = w;
+  }
+}
+
+// single-frame store -> fp32 states (the reference's layout, runner.py:199): state k of slot r is the window
+// frames[r][k .. k+C-1], planes older than the last reset (c < C - nvalid) are zero
+__global__ __launch_bounds__(256) void frames_to_states_kernel(const uint8_t* __restrict__ f, long slot_stride,
+                                                               const int* __restrict__ nvalid, long nv_slot_stride,
+                                                               float* __restrict__ out, long out_slot_stride, int nt, int C,
+                                                               int HW) {
+  const int r = blockIdx.y / nt, k = blockIdx.y - r * nt, c = blockIdx.z;
+  const int nv = nvalid ? nvalid[(long)r * nv_slot_stride + k] : C;
+  const unsigned int* __restrict__ src = reinterpret_cast<const unsigned int*>(f + (long)r * slot_stride + (long)(k + c) * HW);
+  float4* __restrict__ o = reinterpret_cast<float4*>(out + (long)r * out_slot_stride + ((long)k * C + c) * HW);
+  const bool live = c >= C - nv;
+  const int n4 = HW >> 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256)
+    o[i] = live ? u8x4_to_f32(src[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// start of a slot: the C frames the previous slot ended with move to the head of the window (frames[r][0 .. C-1] =
+// frames[r][T .. T+C-1]) and state 0's valid-plane count is the carried one
+__global__ __launch_bounds__(256) void frame_store_begin_kernel(uint8_t* __restrict__ f, long slot_stride, long T, int C, int HW,
+                                                                int* __restrict__ nv_rows, const int* __restrict__ nv_carry) {
+  const int b = blockIdx.y;
+  uint8_t* __restrict__ fr = f + (long)b * slot_stride;
+  const int n4 = (C * HW) >> 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256)
+    reinterpret_cast<unsigned int*>(fr)[i] = reinterpret_cast<const unsigned int*>(fr + T * HW)[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) nv_rows[(long)b * T] = nv_carry[b];
 }
 }  // namespace
 
@@ -546,6 +605,69 @@ int a2c_unpack_bits(const uint8_t* src, int64_t src_stride, uint8_t* dst, int64_
   if (n == 0) return A2C_OK;
   hipLaunchKernelGGL(unpack_bits_kernel, dim3((n_pixels / 16 + 255) / 256, n), dim3(256), 0, a2c_s(stream), src,
                      (long)src_stride, dst, (long)dst_stride, n_pixels);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+int a2c_frame_prep_u8(const uint8_t* raw, int64_t raw_stride, int H, int W, int C, int y0, int y1, int x0, int x1, int step,
+                      int binarise, uint8_t* out, int64_t out_stride, int n, a2c_stream_t stream) {
+  if (n < 0 || H < 1 || W < 1 || C < 1 || step < 1 || y0 < 0 || y1 > H || y0 >= y1 || x0 < 0 || x1 > W || x0 >= x1) return A2C_ERR_ARG;
+  if (n == 0) return A2C_OK;
+  const int OH = (y1 - y0 + step - 1) / step, OW = (x1 - x0 + step - 1) / step;
+  if (!raw || !out || OW % 4 || ((uintptr_t)out % 4) || out_stride % 4 || out_stride < (int64_t)OH * OW ||
+      raw_stride < (int64_t)H * W * C)
+    return A2C_ERR_ARG;
+  hipLaunchKernelGGL(frame_prep_kernel, dim3((unsigned)((OH * OW / 4 + 255) / 256), (unsigned)n), dim3(256), 0, a2c_s(stream), raw,
+                     (long)raw_stride, W, C, y0, x0, step, OH, OW, binarise, out, (long)out_stride);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_frames_to_states(const uint8_t* frame_store, int64_t slot_stride, const int* nvalid, int64_t nvalid_slot_stride,
+                         float* out, int64_t out_slot_stride, int R, int nt, int C, int HW, a2c_stream_t stream) {
+  if (R < 0 || nt < 0 || C < 1 || HW < 4 || HW % 4) return A2C_ERR_ARG;
+  if (R == 0 || nt == 0) return A2C_OK;
+  if (!frame_store || !out || ((uintptr_t)frame_store % 4) || slot_stride % 4 || ((uintptr_t)out % 16) || out_slot_stride % 4 ||
+      (long)R * nt > 65535L * 8)
+    return A2C_ERR_ARG;
+  // gridDim.y <= 65535: slots in batches
+  const int per = 65535 / nt;
+  if (per < 1) return A2C_ERR_ARG;
+  for (int r0 = 0; r0 < R; r0 += per) {
+    const int nr = R - r0 < per ? R - r0 : per;
+    hipLaunchKernelGGL(frames_to_states_kernel, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)(nr * nt), (unsigned)C), dim3(256), 0,
+                       a2c_s(stream), frame_store + (long)r0 * slot_stride, (long)slot_stride,
+                       nvalid ? nvalid + (long)r0 * nvalid_slot_stride : nullptr, (long)nvalid_slot_stride,
+                       out + (long)r0 * out_slot_stride, (long)out_slot_stride, nt, C, HW);
+    A2C_CHECK_LAUNCH();
+  }
+  return A2C_OK;
+}
+
+int a2c_frame_store_begin(uint8_t* frame_store, int64_t slot_stride, int64_t T, int C, int HW, int* nvalid_rows,
+                          const int* nvalid_carry, int B, a2c_stream_t stream) {
+  if (B < 0 || T < C || C < 1 || HW % 4 || slot_stride < (T + C) * (int64_t)HW || slot_stride % 4) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!frame_store || !nvalid_rows || !nvalid_carry || ((uintptr_t)frame_store % 4)) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(frame_store_begin_kernel, dim3((unsigned)((C * HW / 4 + 255) / 256), (unsigned)B), dim3(256), 0, a2c_s(stream),
+                     frame_store, (long)slot_stride, (long)T, C, HW, nvalid_rows, nvalid_carry);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_rollout_post_frames(const float* rew, const float* done, const float* val, int64_t val_stride, float* val_prev,
+                            float* rewards, float* dones, float* deltas, int64_t T, int64_t t, int64_t slot0, float gamma,
+                            int pong, int B, float* done_eff, float* h, int hdim, float* h_rows, int64_t h_rows_stride,
+                            const float* h_src, int* nvalid_rows, int* nvalid_carry, a2c_stream_t stream) {
+  if (B < 0 || T < 1 || t < 0 || t >= T) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!rew || !done || !val || !val_prev || !rewards || !dones || !deltas || !nvalid_rows || !nvalid_carry) return A2C_ERR_ARG;
+  if (h && hdim < 1) return A2C_ERR_ARG;
+  // post_kernel with no planes to stack (C = 0): z = 0 is the bookkeeping layer, z = 1 the recurrent nets' hidden rows
+  const dim3 grid(1, (unsigned)(h ? B : (B + 255) / 256), h ? 2u : 1u);
+  hipLaunchKernelGGL(post_kernel, grid, dim3(256), 0, a2c_s(stream), rew, done, val, (long)val_stride, val_prev, rewards, dones,
+                     deltas, (long)T, (long)t, (long)slot0, gamma, pong, (const float*)nullptr, (const uint8_t*)nullptr, 0L,
+                     (const float*)nullptr, (const float*)nullptr, 0L, (float*)nullptr, 0L, B, 0, 0, done_eff, h, hdim, h_rows,
+                     (long)h_rows_stride, h_src ? h_src : h, nvalid_rows, nvalid_carry);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -1,0 +1,151 @@
+"""-m gpu: row f4 of SURVEY.md section 8 -- preprocessing on the device and the single-frame uint8 store.
+
+  * a2c_frame_prep_u8 (pong_prep / breakout_prep, preprocessing.py:11-23) bit-exact against the REFERENCE's recorded
+    outputs (tests/golden/g9_preprocessing.npz) and against the oracle on random Atari-shaped frames;
+  * a2c_frames_to_states against numpy (window + valid-plane count -> the reference's fp32 state, utils.py:26-43);
+  * first-layer forward / weight gradient of the 3x3 stacks stacked ON LOAD from the store: bit-identical to the same
+    kernels fed with the materialised fp32 states (and those are tested against torch in test_gpu_kernels.py);
+  * end to end: relay rollouts of ConvModel / GRUModel (+BPTT) with hyps['frame_store'] -- states never written by the
+    rollout -- against the plain path bit for bit, and update_model from the store against the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import a2c_oracle as O  # noqa: E402
+from cases import PREP_SEEDS, U8FakeEnv, atari_frame, base_hyps, hashf  # noqa: E402
+from test_gpu_kernels import _ops, _sign_words, close, rnd  # noqa: E402
+
+DEV = "cuda"
+
+
+def test_device_prep_matches_the_reference_recorded_outputs(golden):
+    ops = _ops()
+    g = golden["g9_preprocessing"]
+    raw = torch.from_numpy(np.stack([atari_frame(s) for s in PREP_SEEDS])).to(DEV)          # (n, 210, 160, 3) uint8
+    n = raw.shape[0]
+    for name, key in (("pong_prep", "pong"), ("breakout_prep", "breakout")):
+        _, oh, ow = ops.prep_out_shape(name, 210, 160)
+        out = torch.full((n, oh * ow + 16), 77, dtype=torch.uint8, device=DEV)              # rows of a wider buffer
+        ops.frame_prep_u8(name, raw.data_ptr(), raw[0].numel(), 210, 160, 3, out.data_ptr(), out.stride(0), n)
+        for i, s in enumerate(PREP_SEEDS):
+            want = g[f"{key}{s}"]
+            assert want.shape == (1, oh, ow)
+            assert np.array_equal(out[i, :oh * ow].cpu().numpy().reshape(oh, ow), want[0]), (name, s)
+        assert bool((out[:, oh * ow:] == 77).all())
+
+
+def test_device_prep_random_frames_vs_oracle():
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    fr = rng.integers(0, 256, size=(37, 210, 160, 3), dtype=np.uint8)
+    fr[:, ::3, ::5, 0] = 144
+    fr[:, 1::3, 2::7, 0] = 109
+    fr[:, 2::9, :, 0] = 0
+    raw = torch.from_numpy(fr).to(DEV)
+    for name, fn in (("pong_prep", O.pong_prep), ("breakout_prep", O.breakout_prep)):
+        _, oh, ow = ops.prep_out_shape(name, 210, 160)
+        out = torch.zeros((37, oh * ow), dtype=torch.uint8, device=DEV)
+        ops.frame_prep_u8(name, raw.data_ptr(), raw[0].numel(), 210, 160, 3, out.data_ptr(), out.stride(0), 37)
+        want = np.stack([fn(f.copy())[0] for f in fr])
+        assert np.array_equal(out.cpu().numpy().reshape(37, oh, ow), want), name
+
+
+def _store(R, T, HW, seed):
+    """random frame store (R, T+4, HW) uint8 + valid-plane counts (R*T,) -> and the fp32 states they stand for"""
+    rng = np.random.default_rng(seed)
+    Fs = rng.integers(0, 3, size=(R, T + 4, HW), dtype=np.uint8)
+    nv = rng.integers(1, 5, size=(R * T,), dtype=np.int32)
+    st = np.zeros((R * T, 4, HW), np.float32)
+    for r in range(R):
+        for t in range(T):
+            for c in range(4):
+                if c >= 4 - nv[r * T + t]:
+                    st[r * T + t, c] = Fs[r, t + c]
+    return Fs, nv, st
+
+
+def test_frames_to_states_and_store_begin():
+    ops = _ops()
+    R, T, HW = 5, 6, 84 * 84
+    Fs, nv, st = _store(R, T, HW, 1)
+    Fd, nvd = torch.from_numpy(Fs).to(DEV), torch.from_numpy(nv).to(DEV)
+    out = torch.full((R * T, 4, HW), float("nan"), device=DEV)
+    ops.frames_to_states(Fd.data_ptr(), Fd.stride(0), nvd.data_ptr(), T, out.data_ptr(), T * 4 * HW, R, T, 4, HW)
+    assert np.array_equal(out.cpu().numpy(), st)
+    # one time step of every slot (what a rollout materialises per env step): state t = 3
+    row = torch.full((R, 4, HW), float("nan"), device=DEV)
+    ops.frames_to_states(Fd.data_ptr() + 3 * HW, Fd.stride(0), nvd.data_ptr() + 4 * 3, T, row.data_ptr(), 4 * HW, R, 1, 4, HW)
+    assert np.array_equal(row.cpu().numpy(), st.reshape(R, T, 4, HW)[:, 3])
+    # slot start: the window's tail moves to its head, state 0 gets the carried count
+    carry = torch.tensor([1, 4, 2, 3, 4], dtype=torch.int32, device=DEV)
+    ops.frame_store_begin(Fd.data_ptr(), Fd.stride(0), T, 4, HW, nvd.data_ptr(), carry.data_ptr(), R)
+    F2 = Fd.cpu().numpy()
+    assert np.array_equal(F2[:, :4], Fs[:, T:T + 4]) and np.array_equal(F2[:, 4:], Fs[:, 4:])
+    assert np.array_equal(nvd.cpu().numpy().reshape(R, T)[:, 0], carry.cpu().numpy())
+    assert np.array_equal(nvd.cpu().numpy().reshape(R, T)[:, 1:], nv.reshape(R, T)[:, 1:])
+
+
+@pytest.mark.parametrize("B,signs", [(3, False), (40, True), (300, False), (300, True)])
+def test_first_layer_forward_stacked_on_load_equals_forward_from_states(B, signs):
+    """c3_kernel (B <= 64, no signs) / c3s_kernel: the loader waves expand the uint8 window instead of LDS-DMA of the fp32 planes"""
+    ops = _ops()
+    d = ops.conv_desc(4, 84, 84, 16, 3, 1, 1)
+    assert ops.conv_fwd_frames_supported(d)
+    T, HW = 4, 84 * 84
+    R = (B + T - 1) // T
+    Fs, nv, st = _store(R, T, HW, 2 + B)
+    Fd, nvd, xd = torch.from_numpy(Fs).to(DEV), torch.from_numpy(nv).to(DEV), torch.from_numpy(st).to(DEV)
+    w = (rnd((16, 4, 3, 3), 11) / 6.0).to(DEV)
+    bias = (rnd((16,), 12) * 0.1).to(DEV)
+    wf = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
+    ops.conv_prep(d, 0, w, wf)
+    nsw = ops.conv_sign_words(d)
+    ref = torch.empty(B, 16, 84, 84, device=DEV)
+    sref = torch.zeros((B, nsw), dtype=torch.int32, device=DEV)
+    if signs:
+        ops.conv_fwd_signs(d, xd.data_ptr(), 4 * HW, wf, bias, True, ref, sref.data_ptr(), nsw, B)
+    else:
+        ops.conv_fwd(d, xd.data_ptr(), 4 * HW, wf, bias, True, ref, B)
+    close("fwd vs torch", ref[:3], F.relu(F.conv2d(torch.from_numpy(st[:3]).reshape(3, 4, 84, 84), w.cpu(), bias.cpu(), padding=1)),
+          2e-6, 1e-5)
+    # (a) update-style addressing: sample n = slot * T + t
+    out = torch.full_like(ref, float("nan"))
+    sg = torch.zeros((B, nsw), dtype=torch.int32, device=DEV)
+    ops.conv_fwd_frames(d, Fd.data_ptr(), Fd.stride(0), T, nvd.data_ptr(), 1, wf, bias, True, out, B,
+                        signs=(sg.data_ptr(), nsw) if signs else None)
+    assert torch.equal(out, ref)
+    if signs:
+        assert torch.equal(sg, sref) and torch.equal(sg.cpu(), _sign_words(ref.cpu() > 0))
+    # (b) rollout-style addressing: time step t of slots 0 .. R-1 (sample stride = slot stride, counts T apart)
+    t = 2
+    Rb = min(R, B)
+    out2 = torch.full((Rb, 16, 84, 84), float("nan"), device=DEV)
+    ops.conv_fwd_frames(d, Fd.data_ptr() + t * HW, Fd.stride(0), 1, nvd.data_ptr() + 4 * t, T, wf, bias, True, out2, Rb)
+    idx = torch.arange(Rb, device=DEV) * T + t
+    keep = idx < B
+    assert torch.equal(out2[keep], ref[idx[keep]])
+
+
+@pytest.mark.parametrize("B", [5, 700])
+def test_first_layer_weight_gradient_stacked_on_load_equals_gradient_from_states(B):
+    ops = _ops()
+    d = ops.conv_desc(4, 84, 84, 16, 3, 1, 1)
+    T, HW = 5, 84 * 84
+    R = (B + T - 1) // T
+    Fs, nv, st = _store(R, T, HW, 40 + B)
+    Fd, nvd, xd = torch.from_numpy(Fs).to(DEV), torch.from_numpy(nv).to(DEV), torch.from_numpy(st).to(DEV)
+    dout = rnd((B, 16, 84, 84), 41).to(DEV)
+    ws = torch.empty((ops.conv_bwd_weight_ws_bytes(d, B) + 3) // 4, device=DEV)
+    dW0, db0 = torch.empty(16, 4, 3, 3, device=DEV), torch.empty(16, device=DEV)
+    dW1, db1 = torch.full_like(dW0, float("nan")), torch.full_like(db0, float("nan"))
+    ops.conv_bwd_weight(d, xd.data_ptr(), 4 * HW, dout, dW0, db0, B, ws)
+    ops.conv_bwd_weight_frames(d, Fd, Fd.stride(0), T, nvd, dout, dW1, db1, B, ws)
+    assert torch.equal(dW1, dW0) and torch.equal(db1, db0)
+    if B == 5:
+        x = torch.from_numpy(st[:B]).reshape(B, 4, 84, 84).double().requires_grad_(False)
+        wt = torch.zeros(16, 4, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x, wt, padding=1).backward(dout.cpu().double())
+        close("dW vs autograd", dW1, wt.grad, 1e-5 * float(wt.grad.abs().max()), 1e-5)

@@ -131,6 +131,23 @@ class ConvLayer:
             ops.conv_fwd(self.d, in_ptr, in_bstride, self.wf, bias, relu, out, B, st, out_bstride=out_bstride)
         return False
 
+    def fwd_frames(self, src, bias, out, B, st, relu=True, out_bstride=None, signs=None):
+        """first layer with its input STACKED ON LOAD from the single-frame uint8 store:
+        src = (address of sample 0's window, sample stride in bytes, T, address of its valid-plane count, count stride),
+        see a2c_conv2d_fwd_frames.  -> True when the sign words were written."""
+        fptr, fstride, T, nv_ptr, nv_stride = src
+        with ops.span(self.name + ".fwd"):
+            ops.conv_fwd_frames(self.d, fptr, fstride, T, nv_ptr, nv_stride, self.wf, bias, relu, out, B, st,
+                                out_bstride=out_bstride, signs=signs)
+        return signs is not None
+
+    @property
+    def frames_ok(self):
+        """this layer can read a single-frame uint8 store (forward and weight gradient)"""
+        if not hasattr(self, "_fok"):
+            self._fok = (not self.padded) and ops.conv_fwd_frames_supported(self.d)
+        return self._fok
+
     @property
     def sign_words(self):
         """uint32 words per sample of the output's sign-word image; 0: this layer's forward cannot write one"""

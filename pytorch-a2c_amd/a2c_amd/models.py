@@ -103,6 +103,13 @@ class _HipNet(nn.Module):
     def _stash_valid(self, x_ptr, n_rows):
         return getattr(self, "_stash", None) == (x_ptr, int(n_rows))
 
+    def _need_states(self):
+        """about to read the fp32 `states` rows: a rollout that kept the single-frame store only (hyps['lazy_states'])
+        materialises them now (Runner.materialize_states)"""
+        cb = getattr(self, "_materialize_states", None)
+        if cb is not None:
+            cb()
+
     def ws(self, tag):
         w = self._ws.get(tag)
         if w is None:
@@ -296,6 +303,8 @@ class A3CModel(_HipNet):
             self._emb_free = True
             return dict(logits=logits, vals=vals, sampled=False)
         if not stashed:
+            if save and tag == "train":
+                self._need_states()
             self._c1.fwd(x_ptr, bstride, P("convs.0.0.bias"), a1, B, st)
             self._c2.fwd(a1.data_ptr(), a1[0].numel(), P("convs.1.0.bias"), a2, B, st)
         # [pi.weight; value.weight] and [pi.bias | value.bias] are adjacent in the arena: one (A+1)-wide head
@@ -410,6 +419,8 @@ class A3CModel(_HipNet):
                 ops.conv_bwd_weight_frames(self._c1.d, fstore, fstore.stride(0), T, nvalid, da1, G("convs.0.0.weight"),
                                            G("convs.0.0.bias"), B, buf, st)
         else:
+            if tag == "train":
+                self._need_states()
             self._c1.bwd_weight(x_ptr, bstride, da1, G("convs.0.0.weight"), G("convs.0.0.bias"), B, ws, st)
 
 
@@ -463,6 +474,7 @@ class _ConvStackNet(_HipNet):
         acts = []
         ptr, bs = x_ptr, bstride
         sl = self._sign_layers() if (stash is not None or train) else {}
+        fsrc = getattr(self, "_frames_src", None)       # rollout step: layer 0 stacks its input on load (runner, row f4)
         for i, l in enumerate(self._cl):
             n = int(np.prod(l.out_shape))
             if stash is None:
@@ -470,7 +482,10 @@ class _ConvStackNet(_HipNet):
                 sg = None
                 if i in sl:
                     sg = (ws.get(f"sg{i}", (B, sl[i]), dtype=torch.int32).data_ptr(), sl[i])
-                done = l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), a, B, st, signs=sg)
+                if i == 0 and fsrc is not None:
+                    done = l.fwd_frames(fsrc, self.P("convs.0.0.bias"), a, B, st, signs=sg)
+                else:
+                    done = l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), a, B, st, signs=sg)
                 if i in sl:
                     self._signs_ok[i] = bool(done)
                 ptr, bs = a.data_ptr(), n
@@ -481,7 +496,10 @@ class _ConvStackNet(_HipNet):
                 if i in sl:
                     sgb = self._sign_bufs[i]
                     sg = (sgb.data_ptr() + 4 * row0 * sl[i], rstride * sl[i])
-                done = l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), optr, B, st, out_bstride=rstride * n, signs=sg)
+                if i == 0 and fsrc is not None:
+                    done = l.fwd_frames(fsrc, self.P("convs.0.0.bias"), optr, B, st, out_bstride=rstride * n, signs=sg)
+                else:
+                    done = l.fwd(ptr, bs, self.P(f"convs.{i}.0.bias"), optr, B, st, out_bstride=rstride * n, signs=sg)
                 if i in sl:
                     self._signs_ok[i] = bool(done) and self._signs_ok.get(i, True) if row0 else bool(done)
                 ptr, bs = optr, rstride * n
@@ -529,6 +547,7 @@ class _ConvStackNet(_HipNet):
         """conv stack of the update's forward: recomputed, or taken from the rollout's stash"""
         if self._stash_valid(x_ptr, B):
             return [(ws.get(f"a{i}", (B,) + l.out_shape).data_ptr(), int(np.prod(l.out_shape))) for i, l in enumerate(self._cl)]
+        self._need_states()
         return self._convs_fwd(x_ptr, bstride, B, ws, st, train=True)
 
     def _convs_bwd(self, x_ptr, bstride, B, ws, st, d_last):
@@ -539,8 +558,21 @@ class _ConvStackNet(_HipNet):
         for i in range(n - 1, -1, -1):
             l = self._cl[i]
             in_ptr, in_bs = (x_ptr, bstride) if i == 0 else (acts[i - 1].data_ptr(), acts[i - 1][0].numel())
+            fr = self._stash_frames if (i == 0 and l.frames_ok and self._stash_valid(x_ptr, B)
+                                       and os.environ.get("A2C_NO_FRAME_STORE") != "1") else None
+            if fr is not None:
+                # the rollout kept ONE uint8 frame per env step: the first layer's weight gradient stacks them on load
+                # (28 KB instead of the 113 KB fp32 state per sample; same values, same summation order)
+                fstore, nvalid, T = fr
+                buf = ws.bytes("conv_wgrad_ws", ops.conv_bwd_weight_ws_bytes(l.d, B))
+                with ops.span(l.name + ".bwd_weight"):
+                    ops.conv_bwd_weight_frames(l.d, fstore, fstore.stride(0), T, nvalid, d, self.G("convs.0.0.weight"),
+                                               self.G("convs.0.0.bias"), B, buf, st)
+                continue
+            if i == 0:
+                self._need_states()
             l.bwd_weight(in_ptr, in_bs, d, self.G(f"convs.{i}.0.weight"), self.G(f"convs.{i}.0.bias"), B, ws, st)
-            if i == 1 and not self._cl[0].padded and not l.padded and bstride % 4 == 0 and x_ptr % 16 == 0:
+            if i == 1 and self._stash_frames is None and not self._cl[0].padded and not l.padded and bstride % 4 == 0 and x_ptr % 16 == 0:
                 # layer 2's input gradient only feeds layer 1's weight gradient: one fused pass, da0 never reaches HBM
                 l0 = self._cl[0]
                 nb = ops.conv_bwd_data_w1_ws_bytes(l.d, l0.d, B)

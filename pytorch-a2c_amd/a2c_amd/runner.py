@@ -160,6 +160,14 @@ class Runner:
         B = self.B = len(pool)
         C = int(hyps["n_frame_stack"])
         fshape = tuple(pool.frame_shape)          # (1, H, W) or (1, L)
+        # hyps['device_prep'] = "pong_prep" / "breakout_prep" (SURVEY.md 8 row f4): the envs hand on RAW (H, W, C) uint8
+        # frames (host preprocessor = null_prep) and a2c_frame_prep_u8 crops / strides / binarises them on the device
+        self.dev_prep = try_key(hyps, "device_prep", None)
+        if self.dev_prep:
+            if self.dev_prep not in ops.PREP_SPECS or len(fshape) < 3:
+                raise ValueError("device_prep: 'pong_prep' or 'breakout_prep' on raw (H, W, C) frames")
+            self.raw_dims = tuple(int(v) for v in fshape[-3:])
+            fshape = ops.prep_out_shape(self.dev_prep, self.raw_dims[0], self.raw_dims[1])
         self.C, self.HW = C, int(np.prod(fshape))
         self.state_shape = (C,) + fshape[1:]
         self.S = C * self.HW
@@ -186,9 +194,12 @@ class Runner:
             self.fstride = int(pool.header.frame_stride)              # bytes between the envs' slots in the pinned region
             if self.bits and self.HW % 16:
                 raise ValueError("frame_bits transport: the frame size must be a multiple of 16 pixels")
+            if self.dev_prep and (not self.u8 or self.bits or self.fstride % 16):
+                raise ValueError("device_prep needs a uint8 (not packed) raw-frame pool")
             # HBM staging of one env step's frames: uint8 pixels (expanded from the packed slots on the way in), or fp32
-            self.dstride = -(-self.HW // 16) * 16 if self.bits else self.fstride
+            self.dstride = -(-self.HW // 16) * 16 if (self.bits or self.dev_prep) else self.fstride
             self.d_frames = torch.zeros((B, self.dstride), dtype=torch.uint8, device=dev)
+            self.d_raw = torch.zeros((B, self.fstride), dtype=torch.uint8, device=dev) if self.dev_prep else None
             self.d_packed = torch.zeros((B, self.fstride), dtype=torch.uint8, device=dev) if self.bits else None
             # fp32 frames whose size is not a multiple of 16 B sit `fstride` bytes apart; the fp32 frame-stack kernels
             # read dense (B, HW) rows: compact them with one strided row copy
@@ -300,6 +311,12 @@ class Runner:
         idxs = [idx] if isinstance(idx, int) else list(idx)
         N = self.datas["states"].shape[0]
         T_ = int(hyps["n_tsteps"])
+        # rows a lazy rollout (hyps['lazy_states']) left in the single-frame store only: a partial refill keeps the others
+        if getattr(self, "_states_stale", False):
+            if idxs == list(range(N // T_)):
+                self._states_stale = False
+            else:
+                self.materialize_states()
         # whatever an earlier rollout stashed in the net describes states this call overwrites
         net._stash = None
         net._stash_frames = None
@@ -364,7 +381,7 @@ class Runner:
 
     def _zero_copy_ok(self, net):
         """the persistent one-launch rollout applies: A3CModel-shaped net, process pool with uint8 frames"""
-        if not self.proc_pool or self.h is not None or self.ingest in ("memcpy", "relay"):
+        if not self.proc_pool or self.h is not None or self.ingest in ("memcpy", "relay") or getattr(self, "dev_prep", None):
             return False
         ok = (getattr(net, "_step_supported", lambda: False)() and self.u8 and self.HW % 16 == 0 and self.HW <= 8192
               and self.env_pool.dev_ptr != 0)
@@ -396,9 +413,9 @@ class Runner:
         # next to the frame-stack kernel (two branches in the hipGraph).  Measured on MI355X the
         # fork/join costs more than the 4.8 us it hides (16.0 -> 17.8 ms per 256x128 epoch), so it is
         # opt-in (A2C_SIDE_STREAM=1).
-        self._fstore_ok = False          # this slot is not played by the persistent kernel: the frame store goes stale
         if not self.device_pool and os.environ.get("A2C_NO_STEP_GRAPHS") != "1":
             return self._rollout_block_segmented(net, slot0, env0, B, hyps, sp, bm, val_prev, done_eff, h, acts_host_out)
+        self._fstore_ok = False          # this slot is played by a path that does not keep the frame store: it goes stale
         main = torch.cuda.current_stream()
         side = None
         if h is None and os.environ.get("A2C_SIDE_STREAM") == "1":
@@ -548,12 +565,27 @@ class Runner:
         if stash is not None and isinstance(stash, list) == fused:      # tuple (a1, a2): step kernel; list: conv-stack nets
             stash = None
         self._stash_used = stash is not None
+        # Single-frame uint8 store (opt-in hyps['frame_store']): the ingest writes each new frame
+        # straight into frames[slot][k+3], the first conv layer stacks its 4 planes on load, the fp32 `states` rows are
+        # expanded from the store (per step, or on demand with hyps['lazy_states']) -- conv-stack nets behind the relay
+        fs = None
+        if relay and not fused and self.u8 and self.C == 4 and getattr(net, "_cl", None) and net._cl[0].frames_ok:
+            fs = self._frame_store(T, D["states"].shape[0] // T, dev)
+        if fs is None:
+            self._fstore_ok = False      # this slot does not keep the store: it goes stale
+        lazy = fs is not None and bool(try_key(hyps, "lazy_states", False))
         ctx = dict(net=net, slot0=slot0, env0=env0, B=B, T=T, hyps=hyps, sp=sp, bm=bm, val_prev=val_prev, done_eff=done_eff,
-                   h=h, acts_host_out=acts_host_out, fused=fused, stash=stash, ub=ub, relay=relay)
+                   h=h, acts_host_out=acts_host_out, fused=fused, stash=stash, ub=ub, relay=relay, fs=fs, lazy=lazy)
+        if fs is not None:
+            if self._stash_used:
+                self._frames_written = (fs[0], fs[1], T)
+            if lazy:
+                self._states_stale = True
+                net._materialize_states = self.materialize_states
         graphs = None
         if try_key(hyps, "rollout_graphs", True) and torch.cuda.is_available():
             key = (id(net), slot0, env0, B, T, fused, stash is not None, acts_host_out is None, pong, relay, float(hyps["gamma"]),
-                   tuple(D[k].data_ptr() for k in sorted(D) if D[k].is_cuda))
+                   fs is not None, lazy, tuple(D[k].data_ptr() for k in sorted(D) if D[k].is_cuda))
             cache = self.__dict__.setdefault("_seg_graphs", {})
             graphs = cache.setdefault(key, [None] * (T + 1))
         if graphs is not None and relay and os.environ.get("A2C_NO_SLOT_GRAPH") != "1":
@@ -628,14 +660,23 @@ class Runner:
             rew, done = self.d_rew[env0:env0 + B], self.d_done[env0:env0 + B]
             fs, ds = self.fstride, self.dstride
             dst = self.d_frames.data_ptr() + env0 * ds
+            if c.get("fs") is not None:      # single-frame store: the new frame lands in frames[slot][k+3], nowhere else
+                F_ = c["fs"][0]
+                ds = F_.stride(0)
+                dst = F_.data_ptr() + slot0 * ds + (k + 3) * HW
             ticks = int(float(try_key(hyps, "env_timeout_s", 20.0)) * 1e8)
-            if self.bits:
+            if self.dev_prep:        # raw frames cross the link; crop / stride / binarise on the device into dst
+                raw = self.d_raw.data_ptr() + env0 * fs
+                ops.pool_ingest(pool.dev_rec + 8 * env0, pool.dev_frames + env0 * fs, fs, fs, B, self._seq_dev, k,
+                                ticks, self.rollout_err, rew, done, raw, fs, st)
+                ops.frame_prep_u8(self.dev_prep, raw, fs, *self.raw_dims, dst, ds, B, st)
+            elif self.bits:
                 ops.pool_ingest_bits(pool.dev_rec + 8 * env0, pool.dev_frames + env0 * fs, fs, HW, B, self._seq_dev, k,
                                      ticks, self.rollout_err, rew, done, dst, ds, st)
             else:
                 ops.pool_ingest(pool.dev_rec + 8 * env0, pool.dev_frames + env0 * fs, fs, fs, B, self._seq_dev, k,
                                 ticks, self.rollout_err, rew, done, dst, ds, st)
-            fr = self._staged_frames(dst, env0, B, st)
+            fr = self._staged_frames(dst, env0, B, st) if c.get("fs") is None else None
         elif k > 0:     # what env step k-1 returned: pinned staging -> HBM
             rew, done = self.d_rew[env0:env0 + B], self.d_done[env0:env0 + B]
             rew.copy_(self.h_rew[env0:env0 + B], non_blocking=True)
@@ -680,7 +721,29 @@ class Runner:
             prev = ro((c["stash"], slot0 * T + k - 1, T), B) if (ro and c["stash"] is not None and k > 0 and fused_post) else None
             v_ptr, v_ld, h_src = prev if prev else (vals.data_ptr(), vals.stride(0), 0)
             h_row_done = False
-            if k == 0:      # state of step 0 = the bookmark left by the previous slot (runner.py:190)
+            if c.get("fs") is not None:
+                F_, nv_rows, nv_carry = c["fs"]
+                ss = F_.stride(0)
+                f0 = F_.data_ptr() + slot0 * ss
+                nvr, nvc = nv_rows.data_ptr() + 4 * slot0 * T, nv_carry.data_ptr() + 4 * env0
+                if k == 0:  # state 0 = the window the previous slot ended with (the bookmark, runner.py:190)
+                    ops.frame_store_begin(f0, ss, T, C, HW, nvr, nvc, B, st)
+                else:       # bookkeeping of env step k-1 (runner.py:212-232); the frame is already in the store
+                    hrow = 0
+                    if h is not None:
+                        hrow = D["h_states"].data_ptr() + 4 * (slot0 * T + k) * h.shape[1] if k < T else 0
+                        h_row_done = True
+                    ops.rollout_post_frames(rew, done, v_ptr, v_ld, val_prev, rewards, dones, deltas, T, k - 1, slot0, gamma,
+                                            pong, B, done_eff, h, hrow, 0 if h is None else T * h.shape[1], h_src, nv_rows, nvc,
+                                            st)
+                if k == T:  # the bookmark state stays materialised: any other rollout path can take over from here
+                    ops.frames_to_states(f0 + T * HW, ss, nvc, 1, bm.data_ptr(), S, B, 1, C, HW, st)
+                    net._frames_src = (f0 + T * HW, ss, 1, nvc, 1)
+                else:
+                    if not c["lazy"]:   # the reference's fp32 row of `states` (runner.py:199), expanded from the window
+                        ops.frames_to_states(f0 + k * HW, ss, nvr + 4 * k, T, sp(k), T * S, B, 1, C, HW, st)
+                    net._frames_src = (f0 + k * HW, ss, 1, nvr + 4 * k, T)
+            elif k == 0:    # state of step 0 = the bookmark left by the previous slot (runner.py:190)
                 ops.copy_rows(bm.data_ptr(), S, sp(0), T * S, B, S, st)
             else:           # bookkeeping of env step k-1 + the next state (utils.next_state)
                 t = k - 1
@@ -710,7 +773,10 @@ class Runner:
                     else:
                         ops.frame_stack_push(_Ptr(fr.ptr32), done, sp(t), T * S, nxt_ptr, nxt_stride, B, C, HW, st)
             if k == T:      # bootstrap (runner.py:236-245): value of the state after the last step
-                out = self._forward(net, bm.data_ptr(), S, B, env0, st)
+                try:
+                    out = self._forward(net, bm.data_ptr(), S, B, env0, st)
+                finally:
+                    net._frames_src = None
                 ops.rollout_bootstrap(out["vals"].data_ptr(), out["vals"].stride(0), val_prev, rewards, dones, deltas, B, T,
                                       slot0, gamma, st)
                 return
@@ -720,8 +786,11 @@ class Runner:
                               h.shape[1], st)
             u = c["ub"][k, env0:env0 + B]
             net._cell_stash_ok = fused_post            # the cell stash needs the fused post kernel (h_src) of the next segment
-            out = self._forward(net, sp(k), T * S, B, env0, st, sampler=(u, a_ptr, a_stride),
-                                stash=None if c["stash"] is None else (c["stash"], slot0 * T + k, T))
+            try:
+                out = self._forward(net, sp(k), T * S, B, env0, st, sampler=(u, a_ptr, a_stride),
+                                    stash=None if c["stash"] is None else (c["stash"], slot0 * T + k, T))
+            finally:
+                net._frames_src = None
             if not out.get("sampled", False):
                 ops.softmax_sample(out["logits"], u, a_ptr, a_stride, B, net.output_space, st=st)
             if out.get("h_next_src") is not None:      # cell stash: the next segment's post kernel reads h_new from there
@@ -822,6 +891,18 @@ class Runner:
         if acts_host_out is not None:
             acts_host_out[slot0 * T:(slot0 + B) * T].copy_(acts[slot0 * T:(slot0 + B) * T])
 
+    def materialize_states(self):
+        """hyps['lazy_states']: the rollout kept one uint8 frame per env step (+ valid-plane counts) and did not write the
+        fp32 ``states`` rows; this expands ALL of them (runner.py:199's layout and values, bit for bit) -- called by the
+        net when an update needs the rows (no activation stash), by ``finish()`` unless hyps['lazy_states'], or by hand."""
+        if not getattr(self, "_states_stale", False):
+            return
+        F_, nv_rows, _ = self._fstore
+        R, T = F_.shape[0], F_.shape[1] - 4
+        st = self.datas["states"]
+        ops.frames_to_states(F_.data_ptr(), F_.stride(0), nv_rows.data_ptr(), T, st.data_ptr(), T * self.S, R, T, self.C, self.HW)
+        self._states_stale = False
+
     def _frame_store(self, T, R, dev):
         """(frames uint8 (R, T+4, HW), nvalid_rows int32 (R*T,), nvalid_carry int32 (B,)) or None.  OPT-IN
         (hyps['frame_store'] / A2C_FRAME_STORE=1): on MI355X the first-layer weight gradient is matrix-bound, not
@@ -880,7 +961,11 @@ class Runner:
         fs, ds = self.fstride, self.dstride
         dst = self.d_frames.data_ptr() + env0 * ds
         src = pool.region.base + pool.header.off_frames + env0 * fs
-        if self.bits:       # the packed slots cross the link, one kernel expands them to the uint8 pixels the step kernels read
+        if getattr(self, "dev_prep", None):
+            raw = self.d_raw.data_ptr() + env0 * fs
+            ops.memcpy_async(raw, src, B * fs, ops.H2D, st)
+            ops.frame_prep_u8(self.dev_prep, raw, fs, *self.raw_dims, dst, ds, B, st)
+        elif self.bits:     # the packed slots cross the link, one kernel expands them to the uint8 pixels the step kernels read
             pk = self.d_packed.data_ptr() + env0 * fs
             ops.memcpy_async(pk, src, B * fs, ops.H2D, st)
             ops.unpack_bits(pk, fs, dst, ds, B, self.HW, st)

@@ -122,6 +122,26 @@ class U8FakeEnv(O.FakeEnv):
         return super()._frame().astype(np.uint8)
 
 
+class RawAtariEnv(O.FakeEnv):
+    """FakeEnv's schedules with RAW Atari-shaped observations ((210, 160, 3) uint8: random pixels and patches of Pong's
+    background colours), optionally preprocessed on the HOST (prep = "pong_prep" / "breakout_prep", the reference's place
+    for it: runner.py:61-69).  prep=None hands the raw frame on: the device preprocesses (a2c_frame_prep_u8)."""
+
+    def __init__(self, prep=None, **kw):
+        super().__init__(**kw)
+        self.prep = prep
+
+    def _frame(self):
+        rng = np.random.default_rng(self.env_id * 100003 + self.t * 17 + self.n_resets * 7919)
+        f = rng.integers(0, 256, size=(210, 160, 3), dtype=np.uint8)
+        f[40 + self.t % 50:90, 10:70, 0] = 144
+        f[100:150, 50 + self.env_id:130, 0] = 109
+        f[150:170, :, 0] = 0
+        if self.prep is None:
+            return f
+        return getattr(O, self.prep)(f)
+
+
 class PongLikeEnv(U8FakeEnv):
     """80x80 binary uint8 frames = what pong_prep hands on (preprocessing.py:11-17); built as env_fn(j)"""
 

@@ -149,3 +149,102 @@ def test_first_layer_weight_gradient_stacked_on_load_equals_gradient_from_states
         wt = torch.zeros(16, 4, 3, 3, dtype=torch.float64, requires_grad=True)
         F.conv2d(x, wt, padding=1).backward(dout.cpu().double())
         close("dW vs autograd", dW1, wt.grad, 1e-5 * float(wt.grad.abs().max()), 1e-5)
+
+
+# ------------------------------------------------------------------ end to end: Runner / Updater
+from cases import RawAtariEnv  # noqa: E402
+from test_gpu_models import _datas, make_net  # noqa: E402
+from test_gpu_ingest import _compare_round, _oracle_rollouts, _pool  # noqa: E402
+
+
+def _run_engine(kind, hyps, ekws, usd, B, T, A, ss, h, n_rounds, env_cls=U8FakeEnv, check=None):
+    from a2c_amd.runner import Runner
+    from a2c_amd.updater import Updater
+    net = make_net(kind, ss, A, h)
+    D = _datas(B * T, ss, net.is_recurrent, h=h, actions_on_host=False)
+    rnd = [0]
+    pool = _pool(env_cls, ekws, 2, pong="Pong" in hyps["env_type"])
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="relay",
+               uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+    upd = Updater(net, hyps)
+    outs = []
+    try:
+        for rnd[0] in range(n_rounds):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            if check is not None:
+                check(r, net, D, rnd[0])
+            info = upd.update_model(D) if rnd[0] + 1 < n_rounds else None
+            if check is not None and info is not None:
+                check(r, net, D, -1)
+            r.materialize_states()
+            outs.append(({k: v.detach().cpu().clone() for k, v in D.items()}, info,
+                         [p.detach().cpu().clone() for p in net.parameters()]))
+    finally:
+        r.close()
+    return outs
+
+
+@pytest.mark.parametrize("kind,bptt,lazy", [("ConvModel", False, False), ("ConvModel", False, True), ("GRUModel", True, True),
+                                            ("GRUModel", False, False)])
+def test_frame_store_rollouts_and_updates_equal_the_plain_path_bit_for_bit(kind, bptt, lazy):
+    """hyps['frame_store']: the relay rollout of the conv-stack nets keeps ONE uint8 frame per env step (the ingest writes it
+    straight into the store), the first conv layer stacks its planes on load, the update's first-layer weight gradient
+    reads the store; hyps['lazy_states']: the fp32 `states` rows are not written at all until somebody asks.  Same
+    kernels, same values, same summation order => rollout buffers, infos and weights identical to the plain path, over
+    three rounds with updates in between (resets inside and across slots); and the plain path is the one the oracle tests pin."""
+    B, T, A, ss, h = 5, 6, 3, (4, 84, 84), 256
+    ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
+    base = dict(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3, optim_type="RMSprop",
+                use_bptt=bptt, h_size=h)
+    us = torch.from_numpy(hashf(3 * T * B, 6151, 0, 1).reshape(3, T, B))
+    usd = us.to(DEV)
+    seen = dict(stale=0, frames=0)
+
+    def check(r, net, D, k):
+        assert getattr(r, "_fstore", None) is not None and getattr(r, "_fstore_ok", True)         # the store is live
+        if k >= 0:
+            assert net._stash_frames is not None
+            seen["frames"] += 1
+        if lazy:
+            assert r._states_stale            # after the rollout AND after the update: nobody needed the fp32 rows
+            seen["stale"] += 1
+            if k == 0:
+                assert float(D["states"].abs().sum()) == 0.0          # really never written
+
+    plain = _run_engine(kind, base_hyps(**base), ekws, usd, B, T, A, ss, h, 3)
+    store = _run_engine(kind, base_hyps(frame_store=True, lazy_states=lazy, **base), ekws, usd, B, T, A, ss, h, 3, check=check)
+    assert seen["frames"] == 3 and (not lazy or seen["stale"] == 5)
+    for k in range(3):
+        for n in plain[k][0]:
+            assert torch.equal(plain[k][0][n], store[k][0][n]), (k, n)
+        assert plain[k][1] == store[k][1], (k, plain[k][1], store[k][1])
+        for a, b in zip(plain[k][2], store[k][2]):
+            assert torch.equal(a, b), k
+    # round 0 against the oracle (later rounds: test_rollout_update_rollout_matches_oracle pins the plain path)
+    onet = O.OracleNet(kind, ss, A, h)
+    ref = _oracle_rollouts(kind, onet, base_hyps(**base), ekws, us, 1, B, T, ss)[0]
+    _compare_round({k: v for k, v in store[0][0].items()}, ref, onet.is_recurrent)
+
+
+@pytest.mark.parametrize("prep,kind", [("pong_prep", "A3CModel"), ("breakout_prep", "FCModel")])
+def test_device_preprocessing_equals_host_preprocessing(prep, kind):
+    """hyps['device_prep']: the env workers hand on RAW 210 x 160 x 3 frames (100,800 B over the link) and
+    a2c_frame_prep_u8 runs pong_prep / breakout_prep on the device; against the same envs preprocessed on the host
+    (the reference's place for it, runner.py:61-69): identical rollout buffers."""
+    B, T, A, h = 3, 5, 3, 64
+    shape = {"pong_prep": (1, 80, 80), "breakout_prep": (1, 80, 72)}[prep]
+    ss = (4,) + shape[1:]
+    base = dict(env_type="FakePong-v0" if prep == "pong_prep" else "FakeBreakout", n_tsteps=T, n_rollouts=B, action_shift=0,
+                n_envs=B, h_size=h)
+    us = torch.from_numpy(hashf(2 * T * B, 881, 0, 1).reshape(2, T, B))
+    usd = us.to(DEV)
+    mk = lambda p: [dict(env_id=j, rew_period=2 + j, done_period=4 + j, prep=p) for j in range(B)]
+    host = _run_engine(kind, base_hyps(**base), mk(prep), usd, B, T, A, ss, h, 2, env_cls=RawAtariEnv)
+    dev = _run_engine(kind, base_hyps(device_prep=prep, **base), mk(None), usd, B, T, A, ss, h, 2, env_cls=RawAtariEnv)
+    for k in range(2):
+        for n in host[k][0]:
+            assert torch.equal(host[k][0][n], dev[k][0][n]), (k, n)
+        assert host[k][1] == dev[k][1]
+    st = dev[0][0]["states"]
+    assert float(st.max()) == (1.0 if prep == "pong_prep" else 255.0) or float(st.max()) > 1.0

@@ -254,7 +254,7 @@ class Bench:
     """net + rollout buffers + env pool + Runner + Updater of one workload; ``step()`` = rollout + update."""
 
     def __init__(self, workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, update_graph=True,
-                 transport="bits"):
+                 transport="bits", frame_store=False):
         import a2c_amd
         from a2c_amd.runner import Runner
         from a2c_amd.updater import Updater
@@ -263,6 +263,9 @@ class Bench:
         if workload == "conv" and self.n_envs >= 256:
             self.T = 128                               # configs[4]: n_tsteps=128
         self.hyps = hyps_for(self.model, self.n_envs, self.T, self.use_bptt, optim)
+        if frame_store:     # single-frame uint8 store, first conv layer stacked on load, fp32 states on demand
+            self.hyps.update(frame_store=True, lazy_states=True)
+        self.frame_store = frame_store
         self.shard, self.dev, self.ingest, self.optim_name = shard, dev, ingest, optim
         torch.manual_seed(20260101)                # the reference's default init, identical on every rank
         self.net = net = getattr(a2c_amd.models, self.model)(list(SS), self.A, h_size=256)
@@ -442,9 +445,10 @@ def site_roofline(name, site, conv_layers, batch, launches_note=""):
     return out
 
 
-def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, steps, warmup, transport="bits"):
+def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, steps, warmup, transport="bits",
+               frame_store=False):
     """one extra BASELINE config: ms per step, env-steps/s, its dominant update and rollout launch sites"""
-    b = Bench(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, transport=transport)
+    b = Bench(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, transport=transport, frame_store=frame_store)
     try:
         b.step()
         b.capture()
@@ -455,6 +459,10 @@ def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, d
                    ms_per_step=round(1e3 * elapsed / steps, 3), value=round(b.N * steps / elapsed, 1), unit="env-steps/s",
                    rollout_ms=round(r_ms, 3), update_ms=round(u_ms, 3), ingest=b.describe_ingest(),
                    update="hipGraph" if b.ugraph is not None else "eager")
+        if frame_store:
+            out["states_layout"] = ("single-frame uint8 store (f4): ingest writes frames[slot][t+3], conv1 forward / weight "
+                                    "gradient stack on load, fp32 `states` rows expanded on demand (Runner.materialize_states)")
+            out["frame_store_live"] = bool(getattr(b.runner, "_fstore", None) is not None and getattr(b.runner, "_fstore_ok", True))
         layers = getattr(b.net, "_cl", None) or ([b.net._c1, b.net._c2] if hasattr(b.net, "_c1") else [])
         conv = {l.name: l for l in layers}
         summ = b.site_timers(1)
@@ -517,6 +525,8 @@ def main():
     ap.add_argument("--sustain-steps", type=int, default=200,
                     help="if --steps is smaller, an additional region of this many steps is timed and reported")
     ap.add_argument("--no-update-graph", action="store_true", help="do not capture the update into a hipGraph")
+    ap.add_argument("--frame-store", action="store_true",
+                    help="conv-stack workloads: single-frame uint8 rollout store + lazy fp32 states (SURVEY.md 8 row f4)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--no-secondary", action="store_true", help="skip value_device_tape / process-worker runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -564,7 +574,7 @@ def main():
           file=sys.stderr)
 
     b = Bench(args.workload, n_envs, args.optim, args.ingest, args.env_workers, n_workers, shard, dev,
-              update_graph=not args.no_update_graph, transport=args.transport)
+              update_graph=not args.no_update_graph, transport=args.transport, frame_store=args.frame_store)
     model, T, A, N = b.model, b.T, b.A, b.N
     b.step()
     b.capture()
@@ -788,6 +798,19 @@ def main():
                                            transport=args.transport)
                 except Exception as e:      # noqa: BLE001
                     cfgs[key] = dict(error=f"{type(e).__name__}: {e}")
+            # row f4 measured: the same conv-stack configs on the single-frame uint8 store with lazy fp32 states
+            for key, wl, ne, st_, wu in (("conv_32x64", "conv", None, 20, 3), ("gru_bptt_256x128", "gru_bptt", None, 10, 2)):
+                try:
+                    torch.cuda.empty_cache()
+                    r = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu,
+                                   transport=args.transport, frame_store=True)
+                    cfgs[key + "_frame_store"] = {k: r[k] for k in ("workload", "value", "ms_per_step", "rollout_ms", "update_ms",
+                                                                    "states_layout", "frame_store_live") if k in r}
+                    c1 = (r.get("update_conv_sites") or {}).get("conv1.bwd_weight")
+                    if c1:
+                        cfgs[key + "_frame_store"]["conv1.bwd_weight"] = c1
+                except Exception as e:      # noqa: BLE001
+                    cfgs[key + "_frame_store"] = dict(error=f"{type(e).__name__}: {e}")
             out["configs"] = cfgs
         if not args.no_cpu_baseline:
             try:

@@ -286,10 +286,14 @@ typedef struct {
   int32_t *nvalid_rows, *nvalid_carry;
   int frame_bits;                  /* 1: `frames` holds the packed transport (one bit per pixel, frame_stride >= H*W/8) */
   /* optional: the first conv layer's weight tensor (16, 4, 8, 8) as the model stores it.  When given, B <= the CU count
-   * and no frame_store is requested, every env gets a workgroup that keeps its state in LDS for the whole slot and
+   * every env gets a workgroup that keeps its state in LDS for the whole slot (the "ring" kernel) and
    * overlaps the env worker's turn-around with the part of the next forward that does not depend on the new frame
    * (conv1's sum is then ordered plane-major: results equal a2c_a3c_step's up to fp32 re-association).          */
   const float *conv1_weight;
+  /* with frame_store, ring kernel only: 1 = do NOT write the fp32 `states` rows (a2c_frames_to_states expands them from
+   * the store on demand; the update reads the store: a2c_conv2d_bwd_weight_frames); the bookmark is always written.
+   * A2C_ERR_ARG when the launch cannot run as the ring kernel (B > CU count).                                      */
+  int states_lazy;
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
 

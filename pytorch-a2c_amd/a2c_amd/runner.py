@@ -866,6 +866,12 @@ class Runner:
         # single-frame uint8 store (row f4): T+4 frames per slot, created with the bookmark in start(); the update's
         # first-layer weight gradient stacks the frames on load instead of reading the 4x duplicated fp32 states
         fs = self._frame_store(T, D["states"].shape[0] // T, dev)
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        lazy = (fs is not None and bool(try_key(hyps, "lazy_states", False)) and B <= cus
+                and os.environ.get("A2C_NO_RING") != "1")          # only the ring kernel can leave the fp32 rows out
+        if lazy:
+            self._states_stale = True
+            net._materialize_states = self.materialize_states
         ops.a3c_rollout(st, B=B, C=C, H=H, W=W, n_actions=net.output_space, states=D["states"].data_ptr(),
                         bookmark=bm.data_ptr(), wfrag1=net._c1.wf.data_ptr(), bias1=P("convs.0.0.bias").data_ptr(),
                         wfrag2=net._c2.wf.data_ptr(), bias2=P("convs.1.0.bias").data_ptr(), Wc=net._Wc.data_ptr(),
@@ -884,7 +890,7 @@ class Runner:
                         frame_store=0 if fs is None else fs[0].data_ptr(),
                         frame_store_slot_stride=0 if fs is None else fs[0].stride(0),
                         nvalid_rows=0 if fs is None else fs[1].data_ptr(),
-                        nvalid_carry=0 if fs is None else fs[2][env0:env0 + B].data_ptr())
+                        nvalid_carry=0 if fs is None else fs[2][env0:env0 + B].data_ptr(), states_lazy=int(lazy))
         if fs is not None and self._stash_bufs is not None:
             self._frames_written = (fs[0], fs[1], T)
         self._stash_used = self._stash_bufs is not None

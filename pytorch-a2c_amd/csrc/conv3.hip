@@ -114,22 +114,29 @@ __device__ __forceinline__ void c3_u8_stage(float* __restrict__ buf, const C3U8&
   constexpr int RP = W / 4, PPL = SR * RP, NQ8 = (PPL + 63) / 64;
   const unsigned char* __restrict__ fb = u.f + (b / u.T) * u.bs + (b % u.T) * (long)(H * W);
   const int nvl = u.nv ? u.nv[b * u.nv_s] : 4;
+  static_assert(4 % NL == 0, "planes dealt evenly to the loader waves");
+  constexpr int NPL = 4 / NL;                  // planes of this loader wave: c = lw + NL * s
+  unsigned v[NPL][NQ8];                        // ALL loads first (one latency), then expand + write
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c % NL != lw) continue;
+  for (int s = 0; s < NPL; ++s) {
+    const int c = lw + NL * s;
     const bool live = c >= 4 - nvl;
-    unsigned v[NQ8];
 #pragma unroll
     for (int q = 0; q < NQ8; ++q) {
       const int pi = q * 64 + lane, r = pi / RP, i = pi - r * RP, y = y0 + r;
-      v[q] = (pi < PPL && live && y >= 0 && y < H) ? *reinterpret_cast<const unsigned*>(fb + ((long)c * H + y) * W + 4 * i) : 0u;
+      v[s][q] = (pi < PPL && live && y >= 0 && y < H) ? *reinterpret_cast<const unsigned*>(fb + ((long)c * H + y) * W + 4 * i) : 0u;
     }
+  }
+#pragma unroll
+  for (int s = 0; s < NPL; ++s) {
+    const int c = lw + NL * s;
 #pragma unroll
     for (int q = 0; q < NQ8; ++q) {
       const int pi = q * 64 + lane, r = pi / RP, i = pi - r * RP;
       if (pi < PPL)
         *reinterpret_cast<float4*>(buf + c * PLANE + r * WP + 4 + 4 * i) =
-            make_float4((float)(v[q] & 0xffu), (float)((v[q] >> 8) & 0xffu), (float)((v[q] >> 16) & 0xffu), (float)(v[q] >> 24));
+            make_float4((float)(v[s][q] & 0xffu), (float)((v[s][q] >> 8) & 0xffu), (float)((v[s][q] >> 16) & 0xffu),
+                        (float)(v[s][q] >> 24));
     }
   }
 }
@@ -314,13 +321,7 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
       const int y0 = band * R * S - 1;
       float* __restrict__ buf = lds + (k & 1) * G::BUF;
       const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * G::KC * H + y0) * W;
-      bool staged = false;
-      if constexpr (U8OK) {
-        if (u8) {
-          c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(buf, p.u8, b, y0, lw, lane);
-          staged = true;
-        }
-      }
+      const bool staged = U8OK && u8;              // (the uint8 window is expanded below, behind the fragment DMA)
 #pragma unroll
       for (int c = 0; c < G::KC; ++c) {
         if (staged || c % G::NL != lw) continue;
@@ -340,6 +341,9 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
         const int pi = q * 64 + lane;
         if (q % G::NL == lw && pi < G::FRAGC / 4)
           __builtin_amdgcn_global_load_lds((gptr_t)(fg + pi * 4), (lptr_t)(buf + G::IMG + q * 256), 16, 0, 0);
+      }
+      if constexpr (U8OK) {
+        if (u8) c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(buf, p.u8, b, y0, lw, lane);
       }
     };
     // backward-data: the band's ReLU mask, one linear run per channel, issued while the band's FIRST chunk computes
@@ -942,13 +946,7 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
       const int y0 = band * R * S - 1;
       float* __restrict__ buf = lds + (k & 1) * G::BUF;
       const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * G::KC * H + y0) * W;
-      bool staged = false;
-      if constexpr (U8OK) {
-        if (u8) {
-          c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(buf, p.u8, b, y0, lw, lane);
-          staged = true;
-        }
-      }
+      const bool staged = U8OK && u8;              // (the uint8 window is expanded below, behind the fragment DMA)
 #pragma unroll
       for (int c = 0; c < G::KC; ++c) {
         if (staged || c % G::NL != lw) continue;
@@ -968,6 +966,9 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
         const int pi = q * 64 + lane;
         if (q % G::NL == lw && pi < G::FRAGC / 4)
           __builtin_amdgcn_global_load_lds((gptr_t)(fg + pi * 4), (lptr_t)(buf + G::IMG + q * 256), 16, 0, 0);
+      }
+      if constexpr (U8OK) {
+        if (u8) c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(buf, p.u8, b, y0, lw, lane);
       }
     };
     // backward-data: the band's mask as sign words, R * RW words per channel (contiguous in HBM)
@@ -1507,6 +1508,7 @@ struct C3WP {
   const float* zero;
   int B;
   C3U8 u8;                            // first layer: uint8 frame-store source instead of x (u8.f != nullptr)
+  int nodma;                          // timing experiment (A2C_C3W_NODMA=1: wrong sums): only the first band is loaded
 };
 
 __global__ __launch_bounds__(256) void c3w_reduce_kernel(const float* __restrict__ slab, int nslab, long per, long nW,
@@ -1571,13 +1573,8 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
       const int y0 = band * R * S - 1;
       float* __restrict__ xb = xbuf + (k & 1) * G::XB;
       const float* __restrict__ sb = p.x + b * p.x_bs + ((long)ch * KC * H + y0) * W;
-      bool staged = false;
-      if constexpr (CS == 4 && KC == 4 && W % 4 == 0) {      // first layer from the single-frame uint8 store (stack-on-load)
-        if (p.u8.f != nullptr) {
-          c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(xb, p.u8, b, y0, lw, lane);
-          staged = true;
-        }
-      }
+      constexpr bool U8OK = CS == 4 && KC == 4 && W % 4 == 0;      // first layer from the single-frame uint8 store (stack-on-load)
+      const bool staged = U8OK && p.u8.f != nullptr;                // (expanded below, behind the dOut DMA)
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         if (staged || c % G::NL != lw) continue;
@@ -1606,12 +1603,15 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
           }
         }
       }
+      if constexpr (U8OK) {
+        if (staged) c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(xb, p.u8, b, y0, lw, lane);
+      }
     };
     if (nwork > 0) dma(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     for (long k = 0; k < nwork; ++k) {
-      if (k + 1 < nwork) dma(k + 1);
+      if (k + 1 < nwork && !p.nodma) dma(k + 1);
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
     }
@@ -1697,17 +1697,21 @@ template <int CS, int CD, int H, int W, int S, int R, int KC, int NCG>
 int c3w_launch(const C3WP& p0, float* dW, float* db, size_t ws_bytes, hipStream_t st, size_t* need) {
   using G = C3WGeo<CS, CD, H, W, S, R, KC, NCG>;
   const void* k = (const void*)c3w_kernel<CS, CD, H, W, S, R, KC, NCG>;
-  static int cus = 0;
+  static int cus = 0, per_cu = 1;
   if (!cus) {
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess) return A2C_ERR_LAUNCH;
-    int dev = 0;
+    int dev = 0, n = 0;
     hipDeviceProp_t prop;
+    // short bands (small LDS images): several workgroups per CU -- each has ONE band of lookahead, so the bands in flight
+    // per CU (what hides the 2-3 us an LDS-DMA takes under load) scale with the residency
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 640, G::LDS_BYTES) == hipSuccess && n >= 1) per_cu = n > 3 ? 3 : n;
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
   const long total = (long)p0.B * G::NBAND;
-  const int grid = (int)(total < cus ? total : cus);
+  const long cap = (long)cus * per_cu;
+  const int grid = (int)(total < cap ? total : cap);
   const size_t bytes = (size_t)grid * G::NPG * G::PER * 4;
-  if (need) { *need = (size_t)cus * G::NPG * G::PER * 4; return A2C_OK; }
+  if (need) { *need = (size_t)cap * G::NPG * G::PER * 4; return A2C_OK; }
   if (ws_bytes < bytes) return A2C_ERR_WORKSPACE;
   hipLaunchKernelGGL((c3w_kernel<CS, CD, H, W, S, R, KC, NCG>), dim3(grid), dim3(640), G::LDS_BYTES, st, p0);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
@@ -1924,7 +1928,18 @@ bool c3w_supported(const a2c_conv_desc* d) {
   return false;
 }
 
+// experiment (A2C_C3W_ALT=1): short bands, two or three workgroups per CU
+#define C3W_ALT_CASES(X)                                                                       \
+  X(4, 16, 84, 84, 1, 4, 4, 1)   /* conv1 of both models                                    */ \
+  X(16, 24, 84, 84, 1, 3, 8, 1)  /* ConvModel conv2                                         */ \
+  X(16, 24, 84, 84, 2, 3, 8, 1)  /* GRUModel conv2                                          */
+
 static int c3w_dispatch(const a2c_conv_desc* d, const C3WP& p, float* dW, float* db, size_t ws_bytes, hipStream_t st, size_t* need) {
+  static const bool alt = getenv("A2C_C3W_ALT") != nullptr && getenv("A2C_C3W_ALT")[0] == '1';
+#define C3W_RUN(cs, cd, h, w_, s_, r, kc, ncg) \
+  if (d->Cin == cs && d->Cout == cd && d->H == h && d->W == w_ && d->stride == s_) return c3w_launch<cs, cd, h, w_, s_, r, kc, ncg>(p, dW, db, ws_bytes, st, need);
+  if (alt) { C3W_ALT_CASES(C3W_RUN) }
+#undef C3W_RUN
 #define C3W_RUN(cs, cd, h, w_, s_, r, kc, ncg) \
   if (d->Cin == cs && d->Cout == cd && d->H == h && d->W == w_ && d->stride == s_) return c3w_launch<cs, cd, h, w_, s_, r, kc, ncg>(p, dW, db, ws_bytes, st, need);
   C3W_CASES(C3W_RUN)
@@ -1943,6 +1958,8 @@ size_t c3w_ws_bytes(const a2c_conv_desc* d) {
 int c3w_bwd_weight(const a2c_conv_desc* d, const float* in, long in_bs, const float* dout, float* dW, float* db, int B, void* ws,
                    size_t ws_bytes, hipStream_t st) {
   C3WP p{in, in_bs, dout, (float*)ws, zero_page(), B};
+  static const int nodma = getenv("A2C_C3W_NODMA") != nullptr && getenv("A2C_C3W_NODMA")[0] == '1';
+  p.nodma = nodma;
   if (!p.zero) return A2C_ERR_LAUNCH;
   return c3w_dispatch(d, p, dW, db, ws_bytes, st, nullptr);
 }

@@ -60,6 +60,7 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   float* heads_rows; long heads_rows_ld;
   unsigned char* fstore; long fs_slot_stride;      // single-frame uint8 store (T+4 frames per slot)
   int* nvalid; int* nvalid_carry;
+  int states_lazy;                                 // ring kernel: keep the frame store only, no fp32 state rows (the bookmark stays)
   int frame_bits;                                  // the pool publishes one bit per pixel (A2C_FRAME_BITS)
   unsigned long long* dbg;                         // phase stamps of workgroup 0 (a2c_debug_ring_timing), or nullptr
   int poll_gap;                                    // 64-cycle sleeps between two polls of the rec granule
@@ -728,6 +729,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
   }
   __syncthreads();
+  // single-frame uint8 store: frames[r][0..3] = the planes of state 0 (ring slots 0..3), then one
+  // frame per env step; c_nv (tail lane) = how many planes of the current state are real frames (utils.py:37-42)
+  unsigned char* __restrict__ fs_slot = p.x.fstore != nullptr ? p.x.fstore + (a.slot0 + b) * p.x.fs_slot_stride : nullptr;
+  int c_nv = 4;
+  if (fs_slot != nullptr) {
+    for (int q = tid; q < (4 * HW) >> 4; q += NT) reinterpret_cast<u32x4*>(fs_slot)[q] = reinterpret_cast<const u32x4*>(ring)[q];
+    if (tail) c_nv = __hip_atomic_load(p.x.nvalid_carry + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int base = 0;
@@ -956,6 +965,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           if (ho != nullptr) ho[n] = h[n];
         }
       c_val = vboot;
+      if (fs_slot != nullptr) {  // valid planes of state t: 1 behind a real done, else one more than its predecessor's
+        if (t > 0) c_nv = ld_d != 0.f ? 1 : min(c_nv + 1, 4);
+        if (t < T) p.x.nvalid[row + t] = c_nv;
+        else p.x.nvalid_carry[b] = c_nv;
+      }
       if (t < T) {
         p.x.actions[row + t] = (int64_t)pick;
       } else if (rec) {          // t == T: bootstrap on the step recorded above (runner.py:236-245)
@@ -1003,11 +1017,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const int sid = dealt ? (w == 0 ? tid : tid - 64) : tid, sn = dealt ? NT - 64 : NT;
       float* __restrict__ out = t == T ? p.x.bookmark + (long)b * S : p.x.states + (row + t) * S;
       const int hw4 = HW >> 2;
-      for (int q = sid; q < 4 * hw4; q += sn) {
-        const int pl = q / hw4, o = q - pl * hw4;
-        const unsigned int x = reinterpret_cast<const unsigned int*>(ring + ((base + pl) % 5) * HW)[o];
-        const float4 v = u8x4(x);
-        __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out) + q);
+      if (t == T || !p.x.states_lazy)       // (lazy: the fp32 rows are expanded from the frame store on demand; the bookmark stays)
+        for (int q = sid; q < 4 * hw4; q += sn) {
+          const int pl = q / hw4, o = q - pl * hw4;
+          const unsigned int x = reinterpret_cast<const unsigned int*>(ring + ((base + pl) % 5) * HW)[o];
+          const float4 v = u8x4(x);
+          __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out) + q);
+        }
+      if (fs_slot != nullptr && t > 0) {    // the newest frame of state t -> frames[r][t+3] (7 KB instead of the 113 KB row)
+        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(ring + ((base + 3) % 5) * HW);
+        u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(fs_slot + (long)(t + 3) * HW);
+        for (int q = sid; q < (HW >> 4); q += sn) dst[q] = src[q];
       }
       if (p.x.a1_rows != nullptr && t < T) {
         float* __restrict__ a1o = p.x.a1_rows + (row + t) * (16L * NP1);
@@ -1187,6 +1207,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.heads_rows = r->heads_rows; p.x.heads_rows_ld = (long)r->heads_rows_ld;
   p.x.fstore = r->frame_store; p.x.fs_slot_stride = (long)r->frame_store_slot_stride;
   p.x.nvalid = r->nvalid_rows; p.x.nvalid_carry = r->nvalid_carry;
+  p.x.states_lazy = (r->states_lazy && r->frame_store) ? 1 : 0;
   p.x.frame_bits = r->frame_bits ? 1 : 0;
   p.x.dbg = g_ring_dbg;
   {
@@ -1214,7 +1235,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   // every env has a CU to itself: the state stays in LDS for the whole slot (a3c_ring_kernel)
   const int hnt = a.n_actions + 1 <= 4 ? 4 : 8;
   static const bool no_ring = getenv("A2C_NO_RING") != nullptr && getenv("A2C_NO_RING")[0] == '1';
-  if (!no_ring && r->conv1_weight && a.B <= cus && !r->frame_store && ring_lds(p, hnt) <= 160 * 1024 && (p.OH1 * p.OW1 + 15) / 16 <= 32 &&
+  if (!no_ring && r->conv1_weight && a.B <= cus && ring_lds(p, hnt) <= 160 * 1024 && (p.OH1 * p.OW1 + 15) / 16 <= 32 &&
       ((uintptr_t)r->conv1_weight % 4) == 0) {
     const size_t rl = ring_lds(p, hnt);
     if (hnt == 4) hipLaunchKernelGGL((a3c_ring_kernel<4>), dim3(a.B), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
@@ -1222,6 +1243,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
     A2C_CHECK_LAUNCH();
     return A2C_OK;
   }
+  if (p.x.states_lazy) return A2C_ERR_ARG;      // only the ring kernel can leave the fp32 rows out
   const size_t lds = step_lds(p);
   // one workgroup per CU at most (157 KB of LDS each): all of them resident, envs beyond that take turns
   const int grid = a.B < cus ? a.B : cus;

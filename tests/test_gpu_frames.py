@@ -248,3 +248,59 @@ def test_device_preprocessing_equals_host_preprocessing(prep, kind):
         assert host[k][1] == dev[k][1]
     st = dev[0][0]["states"]
     assert float(st.max()) == (1.0 if prep == "pong_prep" else 255.0) or float(st.max()) > 1.0
+
+
+@pytest.mark.parametrize("no_ring", [False, True])
+def test_a3c_persistent_rollout_on_the_frame_store_with_lazy_states(no_ring, monkeypatch):
+    """hyps['frame_store'] + hyps['lazy_states'] on the headline path (zero-copy ring kernel, packed frames): the kernel
+    writes ONE uint8 frame per env step (7 KB) instead of the 113 KB fp32 state row, update_model's first-layer weight
+    gradient stacks the frames on load, `states` is expanded on demand.  Against the plain run: identical rollout buffers
+    (after materialize_states), infos and weights to fp32 re-association of one kernel.  With A2C_NO_RING=1 (the per-step
+    persistent body, which cannot skip the rows) lazy_states is ignored and the rows are there."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    from a2c_amd.updater import Updater
+    if no_ring:
+        monkeypatch.setenv("A2C_NO_RING", "1")
+    B, T, A, ss = 7, 9, 3, (4, 84, 84)
+    us = torch.from_numpy(hashf(3 * T * B, 99, 0, 1).reshape(3, T, B)).to(DEV)
+    res = {}
+    for mode in ("plain", "lazy"):
+        hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-4,
+                         **(dict(frame_store=True, lazy_states=True) if mode == "lazy" else {}))
+        net = make_net("A3CModel", ss, A, 256)
+        D = _datas(B * T, ss, False, actions_on_host=False)
+        envs = [TapeEnv(env_id=j, length=3 * T + 1, p_done=1.0 / 6) for j in range(B)]
+        pool = ThreadEnvPool.from_tape_envs(envs, n_threads=2, pong=True, frame_bits=True)
+        rnd = [0]
+        r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy",
+                   uniform_fn=lambda t, Bn, env0: us[rnd[0], t, env0:env0 + Bn].contiguous())
+        upd = Updater(net, hyps)
+        out = []
+        try:
+            for rnd[0] in range(3):
+                r.rollout(net, list(range(B)), hyps)
+                r.finish()
+                if mode == "lazy":
+                    assert net._stash_frames is not None
+                    assert bool(getattr(r, "_states_stale", False)) == (not no_ring)
+                    if rnd[0] == 0 and not no_ring:
+                        assert float(D["states"].abs().sum()) == 0.0           # never written by the rollout
+                info = upd.update_model(D)
+                if mode == "lazy" and not no_ring:
+                    assert r._states_stale                                      # the update read the store, not the rows
+                r.materialize_states()
+                out.append(({k: v.detach().cpu().clone() for k, v in D.items()}, info,
+                            [p.detach().cpu().clone() for p in net.parameters()]))
+        finally:
+            r.close()
+        res[mode] = out
+    for k in range(3):
+        for n in res["plain"][k][0]:
+            if k == 0 or n in ("states", "dones"):      # (later rounds: the nets differ by the re-association below)
+                assert torch.equal(res["plain"][k][0][n], res["lazy"][k][0][n]), (k, n)
+        for name in res["plain"][k][1]:
+            assert res["plain"][k][1][name] == pytest.approx(res["lazy"][k][1][name], rel=1e-5, abs=1e-7), (k, name)
+        for a, b in zip(res["plain"][k][2], res["lazy"][k][2]):
+            close("weights", b, a, 2e-6, 1e-5)

@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define A2C_POOL_MAGIC 0x4132435F504F4F4CULL /* "A2C_POOL" */
-#define A2C_POOL_VERSION 2
+#define A2C_POOL_VERSION 3
 #define A2C_POOL_IDLE 0     /* between rollouts: workers sleep-poll                    */
 #define A2C_POOL_ROLLOUT 1  /* a rollout is running: workers spin on their cmd granules */
 #define A2C_POOL_SHUTDOWN 2
@@ -64,10 +64,24 @@ typedef struct {
   volatile uint64_t episodes;       /* finished episodes (all envs)                           */
   uint32_t frame_elems;             /* pixels / values per frame (A2C_FRAME_BITS: frame_bytes = ceil(frame_elems/8)) */
   uint32_t seq_start;               /* step number of frame 0 (0 unless a2c_pool_set_seq_start was called)     */
+  /* optional SELF-VALIDATING mirror of the packed frames (a2c_pool_enable_tagged; 0 = none), tagged_stride bytes per env:
+   * tagged_chunks chunks of 16 bytes, each written with ONE aligned 16-byte store.  Chunk c < tagged_chunks - 1 =
+   * 14 bytes of packed pixels [112c, 112c + 112) + uint16 tag; the last chunk = {float reward, uint32 done, uint32 seq,
+   * uint16 0, uint16 tag}; tag = seq & 0xffff of the env step that produced the frame.  A reader that loads the chunks
+   * in ANY order and finds every tag equal to the step it waits for holds a complete frame and its record: the poll of
+   * rec[j] and the fetch of frames[j] (two dependent PCIe round trips) become ONE 16-byte load per lane.            */
+  uint64_t off_tagged;
+  uint32_t tagged_stride, tagged_chunks;
 } a2c_pool_header;
 
 /* bytes of the region for n_envs envs with frame_bytes per frame (page aligned)             */
 size_t a2c_pool_bytes(int n_envs, int frame_bytes);
+/* the same plus room for the self-validating mirror (A2C_FRAME_BITS pools)                   */
+size_t a2c_pool_bytes_tagged(int n_envs, int frame_bytes, uint32_t frame_elems);
+/* after a2c_pool_init + a2c_pool_set_frame_elems on a region of region_bytes >= a2c_pool_bytes_tagged(...): lay the
+ * mirror out behind the frames; the workers then keep it up to date (a2c_pool_publish_bits and the native worker
+ * threads write it before they publish rec).  0, or -1 (not a bits pool / region too small)                      */
+int a2c_pool_enable_tagged(void *base, size_t region_bytes);
 /* format a zero-filled region (GPU process, before the workers attach); 0 or -1             */
 int a2c_pool_init(void *base, size_t bytes, int n_envs, int frame_bytes, int frame_dtype,
                   int n_workers, double rew_ema0);

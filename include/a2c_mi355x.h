@@ -294,6 +294,11 @@ typedef struct {
    * the store on demand; the update reads the store: a2c_conv2d_bwd_weight_frames); the bookmark is always written.
    * A2C_ERR_ARG when the launch cannot run as the ring kernel (B > CU count).                                      */
   int states_lazy;
+  /* optional, ring kernel with frame_bits: the pool's SELF-VALIDATING mirror of the packed frames (a2c_hostpool.h:
+   * tagged_chunks chunks of 16 bytes per env, tagged_stride bytes apart, every chunk carries the step number's low 16
+   * bits).  One wave then fetches poll + frame + reward/done of an env step with ONE 16-byte load per lane -- one PCIe
+   * round trip instead of two dependent ones (rec granule, then frame) -- and re-tries until every tag matches.    */
+  const uint8_t *tagged; int64_t tagged_stride; int tagged_chunks;
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
 

@@ -47,7 +47,8 @@ class A3CRolloutArgs(Structure):
                 ("cmd", P), ("rec", P), ("frames", P), ("frame_stride", c_int64),
                 ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64), ("a1_rows", P), ("a2_rows", P), ("heads_rows", P), ("heads_rows_ld", c_int64),
                 ("frame_store", P), ("frame_store_slot_stride", c_int64), ("nvalid_rows", P), ("nvalid_carry", P),
-                ("frame_bits", c_int), ("conv1_weight", P), ("states_lazy", c_int)]
+                ("frame_bits", c_int), ("conv1_weight", P), ("states_lazy", c_int),
+                ("tagged", P), ("tagged_stride", c_int64), ("tagged_chunks", c_int)]
 
 
 PS = POINTER(A3CStepArgs)

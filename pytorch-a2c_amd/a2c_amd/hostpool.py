@@ -42,12 +42,15 @@ class PoolHeader(Structure):
                 ("frame_stride", c_uint32), ("frame_dtype", c_uint32), ("n_workers", c_uint32),
                 ("off_cmd", c_uint64), ("off_rec", c_uint64), ("off_frames", c_uint64), ("total_bytes", c_uint64),
                 ("phase", c_uint32), ("workers_ready", c_uint32), ("worker_error", c_uint32), ("ema_lock", c_uint32),
-                ("rew_ema", c_double), ("episodes", c_uint64), ("frame_elems", c_uint32), ("seq_start", c_uint32)]
+                ("rew_ema", c_double), ("episodes", c_uint64), ("frame_elems", c_uint32), ("seq_start", c_uint32),
+                ("off_tagged", c_uint64), ("tagged_stride", c_uint32), ("tagged_chunks", c_uint32)]
 
 
 P = c_void_p
 POOL_SIGNATURES = {   # one entry per prototype in include/a2c_hostpool.h
     "a2c_pool_bytes": (c_size_t, [c_int, c_int]),
+    "a2c_pool_bytes_tagged": (c_size_t, [c_int, c_int, c_uint32]),
+    "a2c_pool_enable_tagged": (c_int, [P, c_size_t]),
     "a2c_pool_init": (c_int, [P, c_size_t, c_int, c_int, c_int, c_int, c_double]),
     "a2c_pool_set_frame_elems": (None, [P, c_uint32]),
     "a2c_pool_set_seq_start": (None, [P, c_uint32]),
@@ -232,7 +235,14 @@ class _PinnedPool:
     def _create_region(self):
         lib = pool_lib()
         self._pin_to_gpu_node()
-        nbytes = lib.a2c_pool_bytes(self.n_envs, self.frame_bytes)
+        # packed pools can keep a self-validating mirror of their frames (a2c_hostpool.h: tagged chunks): the ring
+        # kernel then fetches poll + frame + record with ONE 16-byte load per lane (frames of up to 63 x 112 pixels)
+        # OPT-IN (A2C_TAGGED=1): measured on MI355X the single 1 KB fetch is SLOWER than the 8-byte poll followed by the
+        # frame load (2.38-2.44 vs 2.24-2.28 ms per 256 x 128 slot: its PCIe latency is longer and a miss costs a whole
+        # second round trip) -- DESIGN.md section 7
+        tagged = self.frame_bits and self.frame_elems <= 63 * 112 and os.environ.get("A2C_TAGGED") == "1"
+        nbytes = lib.a2c_pool_bytes_tagged(self.n_envs, self.frame_bytes, self.frame_elems) if tagged else \
+            lib.a2c_pool_bytes(self.n_envs, self.frame_bytes)
         self.name = f"a2c_pool_{os.getpid()}_{id(self) & 0xffffff:x}_{int(time.time() * 1e3) & 0xffffff:x}"
         reg = self.region = Region(self.name, create_bytes=nbytes)
         ctypes.memset(reg.base, 0, nbytes)          # first touch of every page from the (NUMA-placed) creating thread
@@ -241,6 +251,8 @@ class _PinnedPool:
             raise RuntimeError("a2c_pool_init failed")
         lib.a2c_pool_set_frame_elems(reg.base, self.frame_elems)
         lib.a2c_pool_set_seq_start(reg.base, self.seq_start & 0xffffffff)
+        if tagged and lib.a2c_pool_enable_tagged(reg.base, nbytes):
+            raise RuntimeError("a2c_pool_enable_tagged failed")
         reg.bind()
         if self.register:       # pin + map into the GPU's address space (no copy): hipHostRegister
             from . import ops
@@ -322,6 +334,11 @@ class _PinnedPool:
     @property
     def dev_frames(self):
         return self.dev_ptr + self.header.off_frames
+
+    @property
+    def dev_tagged(self):
+        """device address of the self-validating mirror of the packed frames (0: the pool keeps none)"""
+        return self.dev_ptr + self.header.off_tagged if (self.dev_ptr and self.header.off_tagged) else 0
 
     def describe(self):
         h = self.header

@@ -890,7 +890,9 @@ class Runner:
                         frame_store=0 if fs is None else fs[0].data_ptr(),
                         frame_store_slot_stride=0 if fs is None else fs[0].stride(0),
                         nvalid_rows=0 if fs is None else fs[1].data_ptr(),
-                        nvalid_carry=0 if fs is None else fs[2][env0:env0 + B].data_ptr(), states_lazy=int(lazy))
+                        nvalid_carry=0 if fs is None else fs[2][env0:env0 + B].data_ptr(), states_lazy=int(lazy),
+                        tagged=getattr(pool, "dev_tagged", 0), tagged_stride=int(pool.header.tagged_stride),
+                        tagged_chunks=int(pool.header.tagged_chunks))
         if fs is not None and self._stash_bufs is not None:
             self._frames_written = (fs[0], fs[1], T)
         self._stash_used = self._stash_bufs is not None

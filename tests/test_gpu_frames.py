@@ -130,8 +130,12 @@ def test_first_layer_forward_stacked_on_load_equals_forward_from_states(B, signs
 
 
 @pytest.mark.parametrize("B", [5, 700])
-def test_first_layer_weight_gradient_stacked_on_load_equals_gradient_from_states(B):
+def test_first_layer_weight_gradient_stacked_on_load_equals_gradient_from_states(B, monkeypatch):
+    """same kernel instance for both sources (A2C_C3W_D2=1: the tall-band instance the uint8 path uses; the fp32 default is a
+    shorter-band / deeper-ring instance, i.e. another partition of the same sums): bit-identical; and the default fp32
+    instance agrees to fp32 re-association"""
     ops = _ops()
+    monkeypatch.setenv("A2C_C3W_D2", "1")
     d = ops.conv_desc(4, 84, 84, 16, 3, 1, 1)
     T, HW = 5, 84 * 84
     R = (B + T - 1) // T
@@ -144,6 +148,10 @@ def test_first_layer_weight_gradient_stacked_on_load_equals_gradient_from_states
     ops.conv_bwd_weight(d, xd.data_ptr(), 4 * HW, dout, dW0, db0, B, ws)
     ops.conv_bwd_weight_frames(d, Fd, Fd.stride(0), T, nvd, dout, dW1, db1, B, ws)
     assert torch.equal(dW1, dW0) and torch.equal(db1, db0)
+    monkeypatch.delenv("A2C_C3W_D2")
+    dW2, db2 = torch.empty_like(dW0), torch.empty_like(db0)
+    ops.conv_bwd_weight(d, xd.data_ptr(), 4 * HW, dout, dW2, db2, B, ws)
+    close("default fp32 instance", dW2, dW0, 2e-6 * float(dW0.abs().max()), 1e-5)
     if B == 5:
         x = torch.from_numpy(st[:B]).reshape(B, 4, 84, 84).double().requires_grad_(False)
         wt = torch.zeros(16, 4, 3, 3, dtype=torch.float64, requires_grad=True)
@@ -187,12 +195,13 @@ def _run_engine(kind, hyps, ekws, usd, B, T, A, ss, h, n_rounds, env_cls=U8FakeE
 
 @pytest.mark.parametrize("kind,bptt,lazy", [("ConvModel", False, False), ("ConvModel", False, True), ("GRUModel", True, True),
                                             ("GRUModel", False, False)])
-def test_frame_store_rollouts_and_updates_equal_the_plain_path_bit_for_bit(kind, bptt, lazy):
+def test_frame_store_rollouts_and_updates_equal_the_plain_path_bit_for_bit(kind, bptt, lazy, monkeypatch):
     """hyps['frame_store']: the relay rollout of the conv-stack nets keeps ONE uint8 frame per env step (the ingest writes it
     straight into the store), the first conv layer stacks its planes on load, the update's first-layer weight gradient
     reads the store; hyps['lazy_states']: the fp32 `states` rows are not written at all until somebody asks.  Same
     kernels, same values, same summation order => rollout buffers, infos and weights identical to the plain path, over
     three rounds with updates in between (resets inside and across slots); and the plain path is the one the oracle tests pin."""
+    monkeypatch.setenv("A2C_C3W_D2", "1")      # one instance of the first layer's weight-gradient kernel for both sources
     B, T, A, ss, h = 5, 6, 3, (4, 84, 84), 256
     ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
     base = dict(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3, optim_type="RMSprop",

@@ -213,11 +213,13 @@ def step_alg_flops(A):
     return 2 * 16 * 400 * 256 + 2 * 32 * 81 * 256 + 2 * (A + 1) * 2592
 
 
-def step_alg_bytes(u8_frame=False, stash=True, ring=False):
+def step_alg_bytes(u8_frame=False, stash=True, ring=False, lazy=False):
     """per env-step: 3 planes of the previous state + the new frame in (fp32 or uint8), the new state out
     (+ the conv1 / conv2 activations stashed for the update: 16x20x20 + 32x9x9 floats).  ring: the persistent ring
     kernel keeps the state in LDS -- HBM sees the state row and the stash going out, nothing coming in (the frame
     crosses PCIe)"""
+    if ring and lazy:       # single-frame store: one uint8 frame out instead of the 4-plane fp32 row
+        return 84 * 84 + (4 * (6400 + 2592) if stash else 0)
     if ring:
         return 4 * 84 * 84 * 4 + (4 * (6400 + 2592) if stash else 0)
     return 3 * 84 * 84 * 4 + (84 * 84 if u8_frame else 84 * 84 * 4) + 4 * 84 * 84 * 4 + (4 * (6400 + 2592) if stash else 0)
@@ -526,7 +528,10 @@ def main():
                     help="if --steps is smaller, an additional region of this many steps is timed and reported")
     ap.add_argument("--no-update-graph", action="store_true", help="do not capture the update into a hipGraph")
     ap.add_argument("--frame-store", action="store_true",
-                    help="conv-stack workloads: single-frame uint8 rollout store + lazy fp32 states (SURVEY.md 8 row f4)")
+                    help="conv-stack workloads: single-frame uint8 rollout store + lazy fp32 states (SURVEY.md 8 row f4); "
+                         "the a3c workload uses it by default (ring kernel, <= 256 envs)")
+    ap.add_argument("--no-frame-store", action="store_true",
+                    help="a3c workload: write the fp32 `states` rows in the rollout (round 3's layout) instead of the single-frame store")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--no-secondary", action="store_true", help="skip value_device_tape / process-worker runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -565,16 +570,22 @@ def main():
     # env workers per rank: the usable CPUs are shared by all ranks of the node
     n_workers = args.n_workers
     if n_workers is None:
-        # this rank's share of the usable CPUs (the quota is shared by all ranks of the node), but never fewer than 4
-        # env threads: below that the hand-shake of 256 envs serialises behind one thread (the threads sleep-poll
-        # between rollouts, so over-subscription costs little while another rank's rollout is not running)
-        per_rank = max(4, (usable_cpus() - 2) // max(shard.world, 1))
+        # this rank's share of the usable CPUs (the cgroup quota is shared by all ranks of the node), one CPU per rank set
+        # aside for its main thread (kernel launches, RCCL proxy): NEVER more spinning env threads than CPUs -- a spinning
+        # thread that loses its core stalls the device-side hand-shake of all its envs for a scheduler period (round 3 had a
+        # floor of 4 here: 32 spinning threads on a 16-CPU quota at 8 ranks)
+        per_rank = max(1, (usable_cpus() - max(shard.world, 1)) // max(shard.world, 1))
         n_workers = max(1, min(14 if args.env_workers == "native" else 48, per_rank))
     print(f"[bench] rank {shard.rank}/{shard.world}: env_workers={n_workers} ({args.env_workers}), usable_cpus={usable_cpus()}",
           file=sys.stderr)
 
+    # SURVEY.md 8 row f4 is the headline's storage layout: the ring kernel keeps ONE uint8 frame per env step, the update's
+    # first-layer weight gradient stacks the frames on load, the reference-layout fp32 `states` rows are expanded on demand
+    # (Runner.materialize_states; not needed by rollout -> update -> rollout).  --no-frame-store writes the rows.
+    fs_main = args.frame_store or (args.workload == "a3c" and args.ingest == "host-pinned" and not args.no_frame_store
+                                   and (n_envs or WORKLOADS["a3c"][1]) <= 256)
     b = Bench(args.workload, n_envs, args.optim, args.ingest, args.env_workers, n_workers, shard, dev,
-              update_graph=not args.no_update_graph, transport=args.transport, frame_store=args.frame_store)
+              update_graph=not args.no_update_graph, transport=args.transport, frame_store=fs_main)
     model, T, A, N = b.model, b.T, b.A, b.N
     b.step()
     b.capture()
@@ -625,6 +636,10 @@ def main():
                                     f"{' +BPTT' if b.use_bptt else ''}, {args.optim}, per GPU",
                            ingest=ingest_desc, n_envs_per_gpu=b.n_envs, n_tsteps=T, optimizer=args.optim,
                            transport=args.transport, env_workers=pool_workers, usable_host_cpus=usable_cpus(),
+                           states_layout=("single-frame uint8 store (SURVEY 8 f4): 7 KB frame per env step written by the rollout, "
+                                          "conv1 weight gradient stacked on load, fp32 `states` rows on demand "
+                                          "(Runner.materialize_states); `value_states_rows_written` = the same run writing the rows")
+                           if fs_main else "fp32 `states` rows (N, 4, 84, 84) written by the rollout (the reference's layout)",
                            frames="84x84 binary, i.i.d. Bernoulli(0.25) per pixel from default_rng(1234 + env_id) "
                                   "(SURVEY 8d says uniform{0,1}: cost-neutral, the kernels are data-independent)",
                            update=("hipGraph" if len(b.ugraph.graphs) == 1 else f"{len(b.ugraph.graphs)} hipGraphs around "
@@ -663,7 +678,8 @@ def main():
             fl = step_alg_flops(A) * b.n_envs * (T + 1) / launches
             ring = zero_copy and b.n_envs <= torch.cuda.get_device_properties(dev).multi_processor_count and \
                 os.environ.get("A2C_NO_RING") != "1"
-            by = (step_alg_bytes(u8_frame=args.ingest != "device-tape", ring=ring) -
+            lazy_ring = bool(ring and fs_main and getattr(b.runner, "_states_stale", False))
+            by = (step_alg_bytes(u8_frame=args.ingest != "device-tape", ring=ring, lazy=lazy_ring) -
                   (0 if ring else (84 * 84 - FRAME_BYTES[args.transport] if args.ingest != "device-tape" else 0))) \
                 * b.n_envs * (T + 1) / launches
             tf = fl / (us * 1e-6) / 1e12
@@ -701,13 +717,13 @@ def main():
                                        frac=None, traffic=None)
         # HBM bytes per launch from the PMC passes committed under profiles/ (collected separately:
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/run_kernel.py at this exact size)
-        for tname in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for tname in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             tfile = os.path.join(ROOT, "profiles", tname)
             key = {"conv1.fwd": "conv1_fwd", "conv1.bwd_weight": "conv1_wgrad", "conv2.bwd_data": "conv2_bwd_data"}.get(dom)
             if "roofline" in out and out["roofline"].get("traffic") is None and args.workload == "a3c" and N == 32768 \
                     and os.path.exists(tfile):
                 tj = json.load(open(tfile))
-                k2 = (("a3c_ring" if out["roofline"]["kernel"].startswith("a3c_ring") else "a3c_rollout") if zero_copy else "a3c_step") \
+                k2 = ((("a3c_ring_lazy" if lazy_ring else "a3c_ring") if out["roofline"]["kernel"].startswith("a3c_ring") else "a3c_rollout") if zero_copy else "a3c_step") \
                     if out["roofline"]["kernel"].startswith("a3c_") else key
                 if k2 in tj:
                     out["roofline"]["traffic"] = round(tj[k2]["hbm_bytes_per_launch"])
@@ -752,6 +768,22 @@ def main():
                 del d
             except Exception as e:      # noqa: BLE001
                 out["value_device_tape"] = dict(value=None, error=f"{type(e).__name__}: {e}")
+            if fs_main and args.workload == "a3c":
+                # the same headline with the fp32 `states` rows written by the rollout (round 3's layout)
+                try:
+                    d = Bench(args.workload, n_envs, args.optim, args.ingest, args.env_workers, n_workers, shard, dev,
+                              transport=args.transport, frame_store=False)
+                    d.step(); d.capture(); d.step()
+                    e, r_ms, u_ms = d.timed(60)
+                    out["value_states_rows_written"] = dict(value=round(d.N * 60 / e, 1), unit="env-steps/s", steps=60,
+                                                            ms_per_step=round(1e3 * e / 60, 3), rollout_ms=round(r_ms, 3),
+                                                            update_ms=round(u_ms, 3),
+                                                            note="fp32 states rows (113 KB per env step) written by the ring kernel, "
+                                                                 "conv1 weight gradient from the fp32 rows")
+                    d.close()
+                    del d
+                except Exception as e:      # noqa: BLE001
+                    out["value_states_rows_written"] = dict(value=None, error=f"{type(e).__name__}: {e}")
             if args.ingest == "host-pinned" and args.transport == "bits":
                 # the same headline with the generic uint8 transport (any uint8 preprocessor): host-link bound
                 try:
@@ -795,7 +827,7 @@ def main():
                 try:
                     torch.cuda.empty_cache()
                     cfgs[key] = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu,
-                                           transport=args.transport)
+                                           transport=args.transport, frame_store=(wl == "a3c" and ne is not None and ne <= 256 and fs_main))
                 except Exception as e:      # noqa: BLE001
                     cfgs[key] = dict(error=f"{type(e).__name__}: {e}")
             # row f4 measured: the same conv-stack configs on the single-frame uint8 store with lazy fp32 states

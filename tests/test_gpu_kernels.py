@@ -889,3 +889,85 @@ def test_torch_ops_shim_matches_oracle():
     assert torch.equal(o.frame_stack_push(f8.float().to(DEV), rst.to(DEV), prev.to(DEV)).cpu(), want)
     w, b, xin = rnd((5, 16), 8), rnd((5,), 9), rnd((9, 16), 10)
     close("linear", o.linear(xin.to(DEV), w.to(DEV), b.to(DEV), True), F.relu(F.linear(xin, w, b)), 1e-6, 1e-5)
+
+
+def test_torch_ops_cover_the_model_and_optimiser_families():
+    """the torch.ops.a2c_mi355x side door for the remaining section-8b families (conv2d fwd / bwd_data / bwd_weight, gemm nn / tn,
+    GRU cell fwd / bwd, LayerNorm fwd / bwd, rollout_record_, clip_adam_): tensors in, tensors out, against torch on the CPU"""
+    from a2c_amd import ops as aops
+    o = aops.load_torch_ops()
+    # conv (models.py:98,119,312): GRUModel's 16 -> 24 stride-2 layer at a small batch
+    x, w, b = rnd((3, 16, 20, 24), 1, 0, 1), rnd((24, 16, 3, 3), 2) / 12.0, rnd((24,), 3) * 0.1
+    y = o.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 2, 1, True)
+    ref = F.relu(F.conv2d(x, w, b, stride=2, padding=1))
+    close("conv2d_fwd", y, ref, 2e-6, 1e-5)
+    dout = rnd(tuple(ref.shape), 4)
+    xr, wr = x.clone().double().requires_grad_(True), w.clone().double().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=2, padding=1).backward(dout.double())
+    mask = rnd(tuple(x.shape), 5)
+    din = o.conv2d_bwd_data(dout.to(DEV), w.to(DEV), mask.to(DEV), 20, 24, 2, 1)
+    close("conv2d_bwd_data", din, xr.grad * (mask > 0), 2e-6, 1e-5)
+    close("conv2d_bwd_data no mask", o.conv2d_bwd_data(dout.to(DEV), w.to(DEV), None, 20, 24, 2, 1), xr.grad, 2e-6, 1e-5)
+    dW, db = o.conv2d_bwd_weight(x.to(DEV), dout.to(DEV), 3, 2, 1)
+    close("conv2d_bwd_weight", dW, wr.grad, 1e-5 * float(wr.grad.abs().max()), 1e-5)
+    close("conv2d_bwd_weight bias", db, dout.double().sum((0, 2, 3)), 1e-5, 1e-5)
+    with pytest.raises((RuntimeError, NotImplementedError), match="CPU"):      # only the HIP dispatch key is registered
+        o.conv2d_fwd(x, w, b, 2, 1, True)
+    # dense
+    a, bm = rnd((37, 52), 6), rnd((52, 29), 7)
+    close("gemm_nn", o.gemm_nn(a.to(DEV), bm.to(DEV)), a.double() @ bm.double(), 2e-6, 1e-5)
+    at_, bt = rnd((300, 24), 8), rnd((300, 40), 9)
+    close("gemm_tn", o.gemm_tn(at_.to(DEV), bt.to(DEV)), at_.double().t() @ bt.double(), 2e-5, 1e-5)
+    # GRU cell (models.py:465-476)
+    B, nin, hd = 5, 48, 32
+    xg, hg = rnd((B, nin), 10), rnd((B, hd), 11)
+    Wx, Wh, bb = rnd((3, nin, hd), 12) / 7, rnd((3, hd, hd), 13) / 6, rnd((3, 1, hd), 14) * 0.1
+    hr = hg.clone().double().requires_grad_(True)
+    Wxd, Whd, bd = Wx.double(), Wh.double(), bb.double()
+    z = torch.sigmoid(xg.double() @ Wxd[0] + hr @ Whd[0] + bd[0])
+    r = torch.sigmoid(xg.double() @ Wxd[1] + hr @ Whd[1] + bd[1])
+    c = torch.tanh(xg.double() @ Wxd[2] + (r * hr) @ Whd[2] + bd[2])
+    hn = z * hr + (1 - z) * c
+    outs = o.gru_cell_fwd(xg.to(DEV), hg.to(DEV), Wx.to(DEV), Wh.to(DEV), bb.to(DEV))
+    for name, got, want in zip(("h_new", "z", "r", "c"), outs, (hn, z, r, c)):
+        close("gru " + name, got, want.detach(), 2e-6, 1e-5)
+    dhn = rnd((B, hd), 15)
+    hn.backward(dhn.double())
+    dzp, drp, dcp, dh = o.gru_cell_bwd(dhn.to(DEV), hg.to(DEV), outs[1], outs[2], outs[3], Wh.to(DEV))
+    dh_full = dh.cpu().double() + dzp.cpu().double() @ Whd[0].t() + drp.cpu().double() @ Whd[1].t()     # through the z / r gates
+    close("gru dh", dh_full, hr.grad, 5e-6, 1e-5)
+    # LayerNorm (models.py:392)
+    xl, wl, bl = rnd((9, 200), 16), rnd((200,), 17, 0.5, 1.5), rnd((200,), 18)
+    xlr, wlr = xl.clone().double().requires_grad_(True), wl.clone().double().requires_grad_(True)
+    yl = F.layer_norm(xlr, (200,), wlr, bl.double())
+    dyl = rnd((9, 200), 19)
+    yl.backward(dyl.double())
+    yg, mean, rstd = o.layernorm_fwd(xl.to(DEV), wl.to(DEV), bl.to(DEV))
+    close("layernorm_fwd", yg, yl.detach(), 2e-6, 1e-5)
+    dxl, dwr = o.layernorm_bwd(dyl.to(DEV), xl.to(DEV), wl.to(DEV), mean, rstd)
+    close("layernorm dx", dxl, xlr.grad, 5e-6, 1e-5)
+    close("layernorm dw", dwr.sum(0), wlr.grad, 1e-5, 1e-5)
+    # bookkeeping of one env step (runner.py:212-232), two steps so that a delta is written
+    T, Bn = 4, 3
+    rewards, dones, deltas = (torch.zeros(Bn * T, device=DEV) for _ in range(3))
+    vprev = torch.zeros(Bn, device=DEV)
+    rew0, done0, v0 = torch.tensor([0., 1., 0.], device=DEV), torch.tensor([0., 0., 1.], device=DEV), torch.tensor([.5, .25, -1.], device=DEV)
+    o.rollout_record_(rew0, done0, v0, vprev, rewards, dones, deltas, T, 0, 0, 0.99, True)
+    v1 = torch.tensor([.1, .2, .3], device=DEV)
+    o.rollout_record_(torch.zeros(Bn, device=DEV), torch.zeros(Bn, device=DEV), v1, vprev, rewards, dones, deltas, T, 1, 0, 0.99, True)
+    assert rewards.view(Bn, T)[:, 0].tolist() == [0., 1., 0.] and dones.view(Bn, T)[:, 0].tolist() == [0., 1., 1.]   # Pong: rew != 0 -> done
+    want = [0. + 0.99 * .1 * 1 - .5, 1. + 0. - .25, 0. + 0. + 1.]
+    close("deltas", deltas.view(Bn, T)[:, 0], torch.tensor(want), 1e-6, 1e-6)
+    # clip + Adam (updater.py:129-132, 226-229)
+    p0, g0 = rnd((1000,), 20), rnd((1000,), 21)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pd, gd, m1, m2 = p0.to(DEV), g0.to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in (1, 2):
+        pr.grad = g0.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 0.5)
+        opt.step()
+        gd.copy_(g0)
+        norm = o.clip_adam_(pd, gd, m1, m2, step, 0.5, 1e-3)
+        assert float(norm) == pytest.approx(float(tn), rel=2e-6)
+        close(f"adam params step {step}", pd, pr.detach(), 2e-7, 1e-6)

@@ -325,3 +325,26 @@ def test_bench_strong_scaling_conv_world2():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["n_envs_per_gpu"] == 8 and d["allreduce_bytes"] > 200e6
     assert all(np.isfinite(v) for v in d["last_info"].values())
+
+
+def test_bench_world2_a3c_ring_with_two_env_threads_per_rank():
+    """Multi-GPU readiness without the node: two ranks (gloo, both on cuda:0), the HEADLINE path per rank -- ring kernel,
+    packed transport, single-frame store -- with only 2 native env threads each (what a rank gets when 8 ranks share a
+    16-CPU quota): no hand-shake time-out, finite losses, the sharded update as hipGraphs around its two collectives."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, A2C_BENCH_ONE_DEVICE="1", A2C_DIST_BACKEND="gloo")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--n-envs", "64", "--n-workers", "2", "--sustain-steps", "0", "--no-cpu-baseline", "--no-configs",
+                          "--no-secondary"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["env_workers"] == 2 and d["config"]["n_envs_per_gpu"] == 64
+    assert "zero-copy persistent rollout kernel" in d["config"]["ingest"]
+    assert d["config"]["states_layout"].startswith("single-frame uint8 store")
+    assert "hipGraphs around 2 collectives" in d["config"]["update"]
+    assert all(np.isfinite(v) for v in d["last_info"].values()), d["last_info"]
+    assert d["roofline"]["kernel"].startswith("a3c_ring_kernel")

@@ -379,15 +379,15 @@ class A3CModel(_HipNet):
         # The same fp32 products as the reference's, re-associated.  A + 1 > 8 keeps the two GEMMs.
         rank_bwd = A + 1 <= 8 and getattr(self, "_Wc", None) is not None and os.environ.get("A2C_NO_RANK_BWD") != "1"
         if emb_free or rank_bwd:
-            nch = next(n for n in range(max(1, -(-F // 1024)), F + 1) if F % n == 0 and (F // n) % 4 == 0)
-            Kc = F // nch                    # column chunks the skinny weight-gradient kernel takes (<= 1024 wide)
-            t1 = ws.get("dWh_t1", (nch, A + 1, Kc))
-            for c in range(nch):             # S = db^T a2, in column chunks
-                linear_bwd_weight(ws, db, a2.data_ptr() + 4 * c * Kc, F, t1[c], dbh if (c == 0 and emb_free) else None, B, st)
+            S = ws.get("dWh_S", (A + 1, F))      # S = db^T a2: ONE skinny reduction over the batch (column chunks inside the launch)
+            linear_bwd_weight(ws, db, a2.data_ptr(), F, S, dbh if emb_free else None, B, st)
         if emb_free:
             # dWh = db^T emb with emb = a2 Wp^T + 1 bp^T never materialised:  dWh = S Wp^T + colsum(db) bp^T
+            # (K in chunks of <= 1024: the one-launch small-product kernel; the block-tiled GEMM takes 72 us for these 5 MFLOP)
+            nch = next(n for n in range(max(1, -(-F // 1024)), F + 1) if F % n == 0 and (F // n) % 8 == 0)
+            Kc = F // nch
             for c in range(nch):
-                ops.gemm(0, 1, A + 1, h, Kc, t1[c].data_ptr(), Kc, Wp.data_ptr() + 4 * c * Kc, F, dWh.data_ptr(), h,
+                ops.gemm(0, 1, A + 1, h, Kc, S.data_ptr() + 4 * c * Kc, F, Wp.data_ptr() + 4 * c * Kc, F, dWh.data_ptr(), h,
                          accumulate=(c > 0), st=st)
             ops.gemm(0, 0, A + 1, h, 1, dbh.data_ptr(), 1, P("proj_matrx.bias").data_ptr(), h, dWh.data_ptr(), h,
                      accumulate=True, st=st)
@@ -397,8 +397,7 @@ class A3CModel(_HipNet):
         if rank_bwd:
             Wpi, dWp = P("pi.weight"), G("proj_matrx.weight")
             with ops.span("rank_bwd proj_matrx grads"):
-                for c in range(nch):
-                    ops.gemm(1, 0, h, Kc, A, Wpi.data_ptr(), h, t1[c].data_ptr(), Kc, dWp.data_ptr() + 4 * c * Kc, F, st=st)
+                ops.gemm(1, 0, h, F, A, Wpi.data_ptr(), h, S.data_ptr(), F, dWp.data_ptr(), F, st=st)
                 ops.gemm(1, 0, h, 1, A, Wpi.data_ptr(), h, dbh.data_ptr(), 1, G("proj_matrx.bias").data_ptr(), 1, st=st)
             with ops.span("rank_bwd da2"):
                 ops.gemm(0, 0, B, F, A, dl.data_ptr(), dl.stride(0), self._Wc.data_ptr(), F, da2.data_ptr(), F,

@@ -1624,33 +1624,54 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     float* __restrict__ dst = p.din + b * (long)p.Cin * HW;
     BS_STD(d0, 0) BS_STD(d1, 1) BS_STD(d2, 2) BS_STD(d3, 3) BS_STD(d4, 4) BS_STD(d5, 5)
     __syncthreads();
-#define BS_TILES(T0, T1)                                                                                    \
-    for (int t = (T0) * 2 + half; t < (T1) * 2 && t < ntile; t += 2) {                                      \
-      const int idx = t * 16 + j;                                                                           \
-      const bool ok = idx < NP;                                                                             \
-      const int i = ok ? idx : 0;                                                                           \
-      const int r = i / k.PW, c = i - r * k.PW;                                                             \
-      const float* __restrict__ l = img + r * WP + c + g * PLANE + p.off0;                                  \
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};                                                              \
-      _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                       \
-        float bv[16];                                                                                       \
-        _Pragma("unroll") for (int bb = 0; bb < 2; ++bb)                                                    \
-          _Pragma("unroll") for (int c4 = 0; c4 < 8; ++c4)                                                  \
-            bv[bb * 8 + c4] = l[a * p.step_a + bb * p.step_b + c4 * p.step_c];                              \
-        _Pragma("unroll") for (int s = 0; s < 16; ++s)                                                      \
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a * 16 + s], bv[s], acc, 0, 0, 0);                  \
-      }                                                                                                     \
-      if (ok) {                                                                                             \
-        const int pix = (r * 2 + k.oy_add) * p.W + c * 2 + k.ox_add;                                        \
-        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                                    \
-          if (4 * g + rr < p.Cin) outb[(4 * g + rr) * HW + pix] = acc[rr];                                  \
+    /* two tiles of this wave at a time: two INDEPENDENT accumulator chains sharing the A fragments (a single chain issues */ \
+    /* one MFMA per 40-cycle dependent latency instead of one per 32); the second tile may not exist (wave-uniform)        */
+#define BS_PAIR(TA)                                                                                         \
+    {                                                                                                       \
+      const int tA = (TA) * 2 + half, tB = tA + 2;                                                          \
+      if (tA < ntile) {                                                                                     \
+        const bool two = tB < ntile;                                                                        \
+        const int idxA = tA * 16 + j, idxB = (two ? tB : tA) * 16 + j;                                      \
+        const bool okA = idxA < NP, okB = two && idxB < NP;                                                 \
+        const int iA = okA ? idxA : 0, iB = okB ? idxB : 0;                                                 \
+        const int rA = iA / k.PW, cA = iA - rA * k.PW, rB = iB / k.PW, cB = iB - rB * k.PW;                 \
+        const float* __restrict__ lA = img + rA * WP + cA + g * PLANE + p.off0;                             \
+        const float* __restrict__ lB = img + rB * WP + cB + g * PLANE + p.off0;                             \
+        f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accB = accA;                                              \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                     \
+          float bA[16], bB[16];                                                                             \
+          _Pragma("unroll") for (int bb = 0; bb < 2; ++bb)                                                  \
+            _Pragma("unroll") for (int c4 = 0; c4 < 8; ++c4) {                                              \
+              bA[bb * 8 + c4] = lA[a * p.step_a + bb * p.step_b + c4 * p.step_c];                           \
+              bB[bb * 8 + c4] = lB[a * p.step_a + bb * p.step_b + c4 * p.step_c];                           \
+            }                                                                                               \
+          if (two) {                                                                                        \
+            _Pragma("unroll") for (int s = 0; s < 16; ++s) {                                                \
+              accA = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a * 16 + s], bA[s], accA, 0, 0, 0);            \
+              accB = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a * 16 + s], bB[s], accB, 0, 0, 0);            \
+            }                                                                                               \
+          } else {                                                                                          \
+            _Pragma("unroll") for (int s = 0; s < 16; ++s)                                                  \
+              accA = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a * 16 + s], bA[s], accA, 0, 0, 0);            \
+          }                                                                                                 \
+        }                                                                                                   \
+        if (okA) {                                                                                          \
+          const int pix = (rA * 2 + k.oy_add) * p.W + cA * 2 + k.ox_add;                                    \
+          _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                                  \
+            if (4 * g + rr < p.Cin) outb[(4 * g + rr) * HW + pix] = accA[rr];                               \
+        }                                                                                                   \
+        if (okB) {                                                                                          \
+          const int pix = (rB * 2 + k.oy_add) * p.W + cB * 2 + k.ox_add;                                    \
+          _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                                  \
+            if (4 * g + rr < p.Cin) outb[(4 * g + rr) * HW + pix] = accB[rr];                               \
+        }                                                                                                   \
       }                                                                                                     \
     }
     if (MASK) { BS_LDM(m0, 0, msrc) BS_LDM(m1, 1, msrc) BS_LDM(m2, 2, msrc) BS_LDM(m3, 3, msrc) }
     BS_LDD(d0, 0, nsrc) BS_LDD(d1, 1, nsrc) BS_LDD(d2, 2, nsrc)
-    BS_TILES(0, 2)
+    BS_PAIR(0)                                                  // tiles half, half + 2
     BS_LDD(d3, 3, nsrc) BS_LDD(d4, 4, nsrc) BS_LDD(d5, 5, nsrc)
-    BS_TILES(2, 64)
+    for (int tp = 2; tp * 2 + half < ntile; tp += 2) BS_PAIR(tp) // tiles half + 4, half + 6, ...
     __syncthreads();                                            // every class has landed in outb
 #define BS_FLUSH(mv, u)                                                                         \
     {                                                                                           \

@@ -1581,17 +1581,27 @@ struct BstreamP {
 };
 #define BS_LDD(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * BS_NT, nel4 - 1) << 2));
 #define BS_LDM(var, u, src) var = *reinterpret_cast<const float4*>((src) + (min(tid + (u) * BS_NT, n4 - 1) << 2));
-#define BS_STD(var, u)                                                                          \
+// where the four floats of this thread's u-th float4 of dOut go in the haloed LDS image: the same for every sample, so
+// the (channel, row, column) arithmetic -- five integer divisions per float4 -- is done ONCE per launch (BS_OFF), two
+// 16-bit float offsets per register; the per-sample staging is 24 plain ds_write_b32
+#define BS_OFF(u)                                                                               \
   {                                                                                             \
     const int e_ = min(tid + (u) * BS_NT, nel4 - 1) << 2;                                        \
     const int co_ = e_ / ohw, rem_ = e_ - co_ * ohw;                                            \
-    const float t_[4] = {var.x, var.y, var.z, var.w};                                           \
+    unsigned int o_[4];                                                                         \
     _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                          \
       int cc_ = co_, r_ = rem_ + c_;                                                            \
       if (r_ >= ohw) { r_ -= ohw; ++cc_; }                                                      \
       const int y_ = r_ / p.OW, x_ = r_ - y_ * p.OW;                                            \
-      img[cc_ * PLANE + (y_ + 1) * WP + x_ + 1] = t_[c_];                                       \
+      o_[c_] = (unsigned int)(cc_ * PLANE + (y_ + 1) * WP + x_ + 1);                            \
     }                                                                                           \
+    soff[2 * (u)] = o_[0] | (o_[1] << 16);                                                      \
+    soff[2 * (u) + 1] = o_[2] | (o_[3] << 16);                                                  \
+  }
+#define BS_STD(var, u)                                                                          \
+  {                                                                                             \
+    img[soff[2 * (u)] & 0xffffu] = var.x; img[soff[2 * (u)] >> 16] = var.y;                     \
+    img[soff[2 * (u) + 1] & 0xffffu] = var.z; img[soff[2 * (u) + 1] >> 16] = var.w;             \
   }
 
 template <bool MASK>
@@ -1611,6 +1621,8 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   for (int s = 0; s < 32; ++s) af[s] = p.wfrag[k.frag_off + s * 64 + lane];
   const int NP = k.PH * k.PW, ntile = (NP + 15) >> 4;
   float4 d0 = {}, d1 = {}, d2 = {}, d3 = {}, d4 = {}, d5 = {}, m0 = {}, m1 = {}, m2 = {}, m3 = {};
+  unsigned int soff[12];
+  BS_OFF(0) BS_OFF(1) BS_OFF(2) BS_OFF(3) BS_OFF(4) BS_OFF(5)
   long b = blockIdx.x;
   if (b >= p.B) return;
   {

@@ -1,0 +1,6 @@
+#!/bin/bash
+# headline update sites, N reps:  tools/ab_update.sh [reps]
+for i in $(seq ${1:-2}); do
+python bench.py --no-configs --no-secondary --no-cpu-baseline --steps 60 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['rollout_ms'], d['update_ms'], {k:round(v['avg_ms'],3) for k,v in list(d['update_launch_sites_ms'].items())[:5]})"
+done

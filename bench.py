@@ -349,18 +349,25 @@ class Bench:
         """time `steps` steps (barrier + sync on both sides); returns (elapsed_s, rollout_ms, update_ms) with the
         two halves from HIP events on the launch stream"""
         ev = []
+        if split:
+            # the HIP events of the timed region exist BEFORE it starts (torch creates a hipEvent at its first record():
+            # three creations per step on the host path between the rollout launch and the update replay cost 3 % of the
+            # headline); inside the region a step only re-records them
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+            for e in ev:
+                for x in e:
+                    x.record()
         self.shard.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for k in range(steps):
             if split:
-                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e = ev[k]
                 e[0].record()
                 self.rollout()
                 e[1].record()
                 self.info = self.update()
                 e[2].record()
-                ev.append(e)
             else:
                 self.step()
         torch.cuda.synchronize()

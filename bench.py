@@ -317,10 +317,11 @@ class Bench:
         """after one eager step: the device-tape rollout and (single GPU, RMSprop) the update as hipGraphs"""
         if self.ingest == "device-tape":
             try:
+                from a2c_amd import ops as a2c_ops
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 self.net.mark_dirty()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with a2c_ops.graph_capture(g):
                     self.runner.rollout(self.net, self.slots, self.hyps)
                 self.graph = g
                 self.graph_stash = self.runner._stash_bufs is not None and self.runner._stash_used

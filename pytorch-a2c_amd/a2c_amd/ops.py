@@ -101,6 +101,37 @@ def span(name):
     return TIMERS.span(name) if TIMERS is not None else _NOSPAN
 
 
+class graph_capture:
+    """``torch.cuda.graph(g, capture_error_mode="thread_local")`` with the garbage collector held off: a cyclic-GC pass in
+    the middle of a capture may run the destructor of an OLD hipGraph / pinned pool (hipGraphDestroy, hipFree,
+    hipHostUnregister -- none of them legal while a stream is capturing) and aborts the process.  Pending garbage is
+    collected BEFORE the capture starts."""
+
+    def __init__(self, g):
+        self.g = g
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        self._ctx = torch.cuda.graph(self.g, capture_error_mode="thread_local")
+        try:
+            return self._ctx.__enter__()
+        except BaseException:
+            if self._was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            if self._was:
+                gc.enable()
+
+
 class Workspace:
     """Named, persistent device buffers (no allocation inside steady-state steps, so the
     launch sequences are hipGraph-capturable and pointers are stable across updates)."""

@@ -600,7 +600,7 @@ class Runner:
                 if whole[0] == "warm":
                     try:
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        with ops.graph_capture(g):
                             for k in range(T + 1):
                                 self._segment(k, ctx)
                         whole[0] = g
@@ -626,7 +626,7 @@ class Runner:
                 if graphs[k] == "warm":
                     try:
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        with ops.graph_capture(g):
                             self._segment(k, ctx)
                         graphs[k] = g
                     except Exception:      # noqa: BLE001 -- capture not possible here: run this slot eagerly

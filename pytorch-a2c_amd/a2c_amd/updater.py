@@ -70,7 +70,7 @@ class _GraphedUpdate:
 
     def _begin(self):
         g = torch.cuda.CUDAGraph()
-        self._ctx = torch.cuda.graph(g, capture_error_mode="thread_local")
+        self._ctx = ops.graph_capture(g)
         self._ctx.__enter__()
         self.graphs.append(g)
 
@@ -91,6 +91,7 @@ class _GraphedUpdate:
                 upd.shard.allreduce_(self.colls[i])
         upd.optim._steps += 1
         upd.net.mark_dirty()
+        upd.net._dirty = False      # (the captured tail re-derived the inference weights: _enqueue_update's net._refresh)
         return upd._finish_update(self.dev, self.n_global)
 
     __call__ = replay
@@ -217,6 +218,10 @@ class Updater:
             self.optim.step(max_norm=hyps["max_norm"], st=st)
         self.optim.zero_grad()
 
+        # the weights just changed: re-derive what the NEXT rollout needs from them (conv fragments, composed heads) here, at
+        # the tail of the update's stream work (inside its hipGraph when captured), not on the host path between the
+        # read-back below and the rollout kernel's launch, where the GPU would sit idle behind ~50 us of Python + 5 launches
+        net._refresh(st)
         # five scalars for the host (the reference's .item() calls, updater.py:134-136), gathered by one kernel
         ops.check(ops.lib().a2c_pack_update_scalars(stats[2:5].data_ptr(), self.optim.grad_norm().data_ptr(),
                                                     b["err"].data_ptr(), b["out5"].data_ptr(), st), "a2c_pack_update_scalars")

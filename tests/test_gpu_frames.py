@@ -227,7 +227,8 @@ def test_frame_store_rollouts_and_updates_equal_the_plain_path_bit_for_bit(kind,
     for k in range(3):
         for n in plain[k][0]:
             assert torch.equal(plain[k][0][n], store[k][0][n]), (k, n)
-        assert plain[k][1] == store[k][1], (k, plain[k][1], store[k][1])
+        for name in (plain[k][1] or {}):        # (fp64 sums of per-workgroup partials, atomics: equal to the order of the additions)
+            assert plain[k][1][name] == pytest.approx(store[k][1][name], rel=1e-12, abs=1e-15), (k, name)
         for a, b in zip(plain[k][2], store[k][2]):
             assert torch.equal(a, b), k
     # round 0 against the oracle (later rounds: test_rollout_update_rollout_matches_oracle pins the plain path)
@@ -254,7 +255,8 @@ def test_device_preprocessing_equals_host_preprocessing(prep, kind):
     for k in range(2):
         for n in host[k][0]:
             assert torch.equal(host[k][0][n], dev[k][0][n]), (k, n)
-        assert host[k][1] == dev[k][1]
+        for name in (host[k][1] or {}):
+            assert host[k][1][name] == pytest.approx(dev[k][1][name], rel=1e-12, abs=1e-15), (k, name)
     st = dev[0][0]["states"]
     assert float(st.max()) == (1.0 if prep == "pong_prep" else 255.0) or float(st.max()) > 1.0
 

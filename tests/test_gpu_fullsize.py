@@ -183,4 +183,8 @@ def test_update_with_sign_word_masks_equals_float_masks_bit_for_bit(kind, bptt, 
         res[signs] = ({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, infos)
     for k in res[True][0]:
         assert torch.equal(res[True][0][k], res[False][0][k]), k
-    assert res[True][1] == res[False][1]
+    # the reported scalars are fp64 sums of per-workgroup partials added with atomics (loss.hip): equal up to the ORDER of
+    # those additions, i.e. to ~1e-16 relative -- the weights above are the bit-for-bit statement
+    for a, b in zip(res[True][1], res[False][1]):
+        for k in a:
+            assert a[k] == pytest.approx(b[k], rel=1e-12, abs=1e-15), k

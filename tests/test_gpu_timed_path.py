@@ -91,7 +91,8 @@ def test_graphed_update_replays_equal_eager_updates_and_the_oracle(kind, ingest,
                     assert eg.upd.optim._steps == steps0                   # the capture executed nothing
                 gi = eg.g.replay()
             ei = ee.upd.update_model(ee.D)
-            assert gi == ei, (k, gi, ei)
+            for name in ei:                 # (fp64 sums of per-workgroup partials added with atomics: order-dependent at 1e-16)
+                assert gi[name] == pytest.approx(ei[name], rel=1e-12, abs=1e-15), (k, name, gi, ei)
             assert eg.upd.optim._steps == ee.upd.optim._steps == k + 1
             for (n, p), (_, q) in zip(eg.net.named_parameters(), ee.net.named_parameters()):
                 assert torch.equal(p, q), (k, n)

@@ -292,6 +292,7 @@ class Bench:
         self.updater = Updater(net, self.hyps, shard=shard)
         self.want_update_graph = update_graph
         self.info = None
+        self._pending = None
 
     # the rollout: a hipGraph replay (device tape) or the live host-pinned ingest
     def rollout(self):
@@ -308,10 +309,30 @@ class Bench:
             return self.ugraph.replay()
         return self.updater.update_model(self.D)
 
+    def update_async(self):
+        """enqueue the update; its five scalars are collected one step later (Updater.collect): the host then enqueues the
+        NEXT rollout -- which needs nothing from the host -- while this update still runs, instead of leaving the GPU idle
+        behind a blocking read-back + ~150 us of launch preparation per epoch"""
+        if self.ugraph is not None:
+            return self.ugraph.replay_async()
+        return self.updater.update_model_async(self.D)
+
     def step(self):
         self.rollout()
         self.info = self.update()
         return self.info
+
+    def step_pipelined(self):
+        self.rollout()
+        tok = self.update_async()
+        if self._pending is not None:
+            self.info = self.updater.collect(self._pending)       # the PREVIOUS step's losses (its copy finished long ago)
+        self._pending = tok
+
+    def drain(self):
+        if self._pending is not None:
+            self.info = self.updater.collect(self._pending)
+            self._pending = None
 
     def capture(self):
         """after one eager step: the device-tape rollout and (single GPU, RMSprop) the update as hipGraphs"""
@@ -361,16 +382,26 @@ class Bench:
         self.shard.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        pipelined = os.environ.get("A2C_BENCH_SYNC_INFO") != "1"      # read the losses back one step late (see update_async)
         for k in range(steps):
             if split:
                 e = ev[k]
                 e[0].record()
                 self.rollout()
                 e[1].record()
-                self.info = self.update()
+                if pipelined:
+                    tok = self.update_async()
+                    if self._pending is not None:
+                        self.info = self.updater.collect(self._pending)
+                    self._pending = tok
+                else:
+                    self.info = self.update()
                 e[2].record()
+            elif pipelined:
+                self.step_pipelined()
             else:
                 self.step()
+        self.drain()
         torch.cuda.synchronize()
         self.shard.barrier()
         elapsed = time.perf_counter() - t0
@@ -648,6 +679,10 @@ def main():
                                           "conv1 weight gradient stacked on load, fp32 `states` rows on demand "
                                           "(Runner.materialize_states); `value_states_rows_written` = the same run writing the rows")
                            if fs_main else "fp32 `states` rows (N, 4, 84, 84) written by the rollout (the reference's layout)",
+                           info_readback=("one step late: every step enqueues rollout + update, the update's five scalars travel to "
+                                          "pinned host memory behind it and are collected while the NEXT rollout runs "
+                                          "(Updater.update_model_async / collect); the timed region ends with a full drain + sync"
+                                          if os.environ.get("A2C_BENCH_SYNC_INFO") != "1" else "blocking read-back after every update"),
                            frames="84x84 binary, i.i.d. Bernoulli(0.25) per pixel from default_rng(1234 + env_id) "
                                   "(SURVEY 8d says uniform{0,1}: cost-neutral, the kernels are data-independent)",
                            update=("hipGraph" if len(b.ugraph.graphs) == 1 else f"{len(b.ugraph.graphs)} hipGraphs around "

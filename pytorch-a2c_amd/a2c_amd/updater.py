@@ -96,6 +96,19 @@ class _GraphedUpdate:
 
     __call__ = replay
 
+    def replay_async(self):
+        """replay() without the blocking read-back: -> token for Updater.collect(token) (the five scalars travel to a
+        pinned host buffer behind the update on the stream; the caller may enqueue the NEXT rollout before collecting)"""
+        upd = self.upd
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.colls):
+                upd.shard.allreduce_(self.colls[i])
+        upd.optim._steps += 1
+        upd.net.mark_dirty()
+        upd.net._dirty = False
+        return upd._post_async(self.dev, self.n_global)
+
 
 class Updater:
     def __init__(self, net, hyps, shard=None):
@@ -243,9 +256,30 @@ class Updater:
             raise RuntimeError("a2c_amd: capture_update needs one eager update_model on these buffers first")
         return _GraphedUpdate(self, shared_data)
 
+    def update_model_async(self, shared_data):
+        """update_model without the blocking read-back of the five scalars: everything is enqueued, the scalars go to a
+        pinned host buffer behind the update on the stream; ``collect(token)`` waits for THAT copy only and returns the info
+        dict.  Lets a driver enqueue the next rollout (which needs nothing from the host) before it looks at the losses."""
+        return self._post_async(*self._enqueue_update(shared_data))
+
+    def _post_async(self, dev_vec, n_global):
+        hb = self.__dict__.setdefault("_host_ring", [torch.zeros(8, dtype=torch.float64).pin_memory() for _ in range(4)])
+        i = self.__dict__["_host_i"] = (self.__dict__.get("_host_i", -1) + 1) % len(hb)
+        hb[i][:dev_vec.numel()].copy_(dev_vec, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return (ev, hb[i], n_global)
+
+    def collect(self, token):
+        ev, host, n_global = token
+        ev.synchronize()
+        return self._finish_host(host, n_global)
+
     def _finish_update(self, dev_vec, n_global):
+        return self._finish_host(dev_vec.cpu(), n_global)
+
+    def _finish_host(self, host, n_global):
         hyps = self.hyps
-        host = dev_vec.cpu()
         # host[4] != 0: a slot did not end with done == 1 (not Runner data, runner.py:244); the scans then ran in
         # the reference's flat form on the device (a2c_gae_returns_fused), so the update is still the reference's
         self.flat_scan_fallback = bool(int(host[4]))

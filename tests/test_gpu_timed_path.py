@@ -424,3 +424,44 @@ def test_gradnorm_against_fp64_norm_rebuilt_from_the_reference_grads(golden, cas
     # torch clips when its (fp32) norm exceeds max_norm: clip_coef = max_norm / (norm + 1e-6), clamped to 1
     want = post * (ref32 + 1e-6) / mx if mx / (ref32 + 1e-6) < 1.0 else post
     assert info["GradNorm"] == pytest.approx(want, rel=2e-5), (info["GradNorm"], want, ref32)
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_async_update_collected_one_step_late_equals_blocking_update(graphed):
+    """bench.py enqueues rollout + update and collects the update's five scalars ONE STEP LATE
+    (Updater.update_model_async / _GraphedUpdate.replay_async + collect): same weights bit for bit, same infos, as the
+    blocking update_model / replay on a twin engine."""
+    kind, B, T, A, ss, h = "A3CModel", 4, 5, 3, (4, 84, 84), 256
+    n_ep = 4
+    ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3, optim_type="RMSprop", h_size=h)
+    usd = torch.from_numpy(hashf(n_ep * T * B, 5531, 0, 1).reshape(n_ep, T, B)).to(DEV)
+    ea = _Engine(kind, "zero-copy", hyps, ekws, usd, B, T, A, ss, h)        # async
+    es = _Engine(kind, "zero-copy", hyps, ekws, usd, B, T, A, ss, h)        # blocking twin
+    try:
+        pending, got, want = None, [], []
+        for k in range(n_ep):
+            ea.rollout(k)
+            es.rollout(k)
+            if graphed and k >= 1:
+                for e in (ea, es):
+                    if e.g is None:
+                        e.g = e.upd.capture_update(e.D)
+                tok = ea.g.replay_async()
+                want.append(es.g.replay())
+            else:
+                tok = ea.upd.update_model_async(ea.D)
+                want.append(es.upd.update_model(es.D))
+            if pending is not None:
+                got.append(ea.upd.collect(pending))
+            pending = tok
+            for (n, p), (_, q) in zip(ea.net.named_parameters(), es.net.named_parameters()):
+                assert torch.equal(p, q), (k, n)
+        got.append(ea.upd.collect(pending))
+        assert len(got) == len(want) == n_ep
+        for k in range(n_ep):
+            for name in want[k]:
+                assert got[k][name] == pytest.approx(want[k][name], rel=1e-12, abs=1e-15), (k, name)
+    finally:
+        ea.close()
+        es.close()

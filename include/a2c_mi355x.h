@@ -57,9 +57,14 @@ int a2c_discount_scan(const float *x, const float *dones, float *y, int64_t n_se
 int a2c_gae_returns_fused(const float *deltas, const float *rewards, const float *dones,
                           float *advs, float *rets, int64_t n_seg, int64_t T, float g_adv,
                           float g_ret, int *err_flag, a2c_stream_t stream);
-/* sums[0] = sum x, sums[1] = sum x*x in double (zeroed by the call); feeds the
+/* The three scalar reductions of the update (a2c_moments, a2c_loss_fwd_bwd's loss sums, a2c_gradnorm_sq) are DETERMINISTIC:
+ * per-workgroup fp64 partials go to `reduce_scratch` and the last workgroup to finish adds them in workgroup order (no
+ * atomics on the sums).  reduce_scratch: A2C_REDUCE_SCRATCH_DOUBLES doubles of device memory, ZERO before its first use
+ * (word 0 is a ticket counter the kernels reset); calls that share one scratch must be ordered (same stream).           */
+#define A2C_REDUCE_SCRATCH_DOUBLES (8 + 3 * 1024)
+/* sums[0] = sum x, sums[1] = sum x*x in double; feeds the
  * mean / unbiased-std normalisations of updater.py:89-98.                              */
-int a2c_moments(const float *x, int64_t n, double *sums, a2c_stream_t stream);
+int a2c_moments(const float *x, int64_t n, double *sums, double *reduce_scratch, a2c_stream_t stream);
 /* y = (x - mean) / (std + eps), mean/std (unbiased) derived from sums (a2c_moments,
  * possibly all-reduced across ranks) over n_global elements: updater.py:98.            */
 int a2c_normalize(const float *x, float *y, int64_t n, const double *sums, int64_t n_global,
@@ -346,13 +351,14 @@ int a2c_permute_rows(const float *src, float *dst, int64_t R, int64_t T, int64_t
  * If adv_sums != NULL the advantages are normalised on the fly as in a2c_normalize
  * (norm_advs, updater.py:97-98) using eps 1e-6.
  * Outputs: dlogits (N, ldd) = dLoss/dlogits, dvals (N) = dLoss/dV,
- * loss_sums[0..2] (double, zeroed by the call) = sum log_p*adv, sum (V-R)^2, sum_n sum_a p*lsm
+ * loss_sums[0..2] (double) = sum log_p*adv, sum (V-R)^2, sum_n sum_a p*lsm
  * over the local rows.                                                                  */
 int a2c_loss_fwd_bwd(const float *logits, int64_t ld_logits, const float *vals, int64_t val_stride,
                      const int64_t *actions, const float *advs, const float *returns,
                      const double *adv_sums, int64_t n_local, int64_t n_global, int A,
                      float pi_coef, float val_coef, float entr_coef, float *dlogits, int64_t ldd,
-                     float *dvals, int64_t dval_stride, double *loss_sums, a2c_stream_t stream);
+                     float *dvals, int64_t dval_stride, double *loss_sums, double *reduce_scratch,
+                     a2c_stream_t stream);
 
 /* ------------------------------------------------------------------ a6: dense layers
  * C[M,N] = (accumulate ? C : 0) + opA(A)[M,K] * opB(B)[K,N] (+ bias[N]) ; then optional ReLU ; then optional
@@ -514,7 +520,7 @@ int a2c_layernorm_bwd(const float *dy, const float *x, const float *w, const flo
 /* ------------------------------------------------------------------ a9: clip + optimiser
  * sumsq[0] (double, zeroed by the call) = sum g^2 over the flat gradient arena
  * (nn.utils.clip_grad_norm_, updater.py:129).                                           */
-int a2c_gradnorm_sq(const float *grads, int64_t n, double *sumsq, a2c_stream_t stream);
+int a2c_gradnorm_sq(const float *grads, int64_t n, double *sumsq, double *reduce_scratch, a2c_stream_t stream);
 /* clip (coef = min(1, max_norm/(norm+1e-6)), grads scaled in place like torch) and
  * torch.optim.RMSprop step (alpha, eps; momentum 0, not centered): updater.py:131,227-228 */
 int a2c_clip_rmsprop(float *params, float *grads, float *square_avg, int64_t n,

@@ -60,7 +60,7 @@ SIGNATURES = {
     "a2c_error_string": (c_char_p, [c_int]),
     "a2c_discount_scan": (c_int, [P, P, P, c_int64, c_int64, c_float, P, P]),
     "a2c_gae_returns_fused": (c_int, [P, P, P, P, P, c_int64, c_int64, c_float, c_float, P, P]),
-    "a2c_moments": (c_int, [P, c_int64, P, P]),
+    "a2c_moments": (c_int, [P, c_int64, P, P, P]),
     "a2c_normalize": (c_int, [P, P, c_int64, P, c_int64, c_float, P]),
     "a2c_add": (c_int, [P, P, P, c_int64, P]),
     "a2c_frame_stack_push": (c_int, [P, P, P, c_int64, P, c_int64, c_int, c_int, c_int, P]),
@@ -85,7 +85,7 @@ SIGNATURES = {
     "a2c_mask_rows": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P]),
     "a2c_permute_rows": (c_int, [P, P, c_int64, c_int64, c_int64, P]),
     "a2c_loss_fwd_bwd": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, c_int64, c_int, c_float, c_float,
-                                  c_float, P, c_int64, P, c_int64, P, P]),
+                                  c_float, P, c_int64, P, c_int64, P, P, P]),
     "a2c_gemm_ws_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "a2c_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64,
                               P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
@@ -137,7 +137,7 @@ SIGNATURES = {
     "a2c_gru_gates_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "a2c_layernorm_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int, P]),
     "a2c_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
-    "a2c_gradnorm_sq": (c_int, [P, c_int64, P, P]),
+    "a2c_gradnorm_sq": (c_int, [P, c_int64, P, P, P]),
     "a2c_clip_rmsprop": (c_int, [P, P, P, c_int64, P, c_double, c_double, c_double, c_double, P, P]),
     "a2c_clip_adam": (c_int, [P, P, P, P, c_int64, P, c_double, c_double, c_double, c_double, c_double,
                                c_int64, P, P]),

@@ -177,9 +177,25 @@ def gae_returns(deltas, rewards, dones, g_adv, g_ret, n_seg, T, advs, rets, err=
           "a2c_gae_returns_fused")
 
 
+REDUCE_SCRATCH_DOUBLES = 8 + 3 * 1024        # A2C_REDUCE_SCRATCH_DOUBLES of include/a2c_mi355x.h
+_reduce_scratch = {}
+
+
+def reduce_scratch(device, st):
+    """the zero-initialised scratch of the deterministic scalar reductions (a2c_moments, a2c_loss_fwd_bwd, a2c_gradnorm_sq):
+    ONE persistent buffer per (device, stream) -- the kernels of a stream run one after the other and each leaves the
+    ticket word zero -- so its address is stable across hipGraph captures"""
+    key = (str(device), int(st))
+    buf = _reduce_scratch.get(key)
+    if buf is None:
+        buf = _reduce_scratch[key] = torch.zeros(REDUCE_SCRATCH_DOUBLES, dtype=torch.float64, device=device)
+    return buf
+
+
 def moments(x, sums, st=None):
     _chk(x, "x"); _chk(sums, "sums", torch.float64)
-    check(lib().a2c_moments(_p(x), x.numel(), _p(sums), st if st is not None else stream()), "a2c_moments")
+    st = st if st is not None else stream()
+    check(lib().a2c_moments(_p(x), x.numel(), _p(sums), _p(reduce_scratch(x.device, st)), st), "a2c_moments")
 
 
 def normalize(x, y, sums, n_global, eps=1e-6, st=None):
@@ -387,10 +403,11 @@ def loss_fwd_bwd(logits, vals, actions, advs, returns, adv_sums, n_global, pi_co
     _chk(advs, "advs"); _chk(returns, "returns"); _chk(dlogits, "dlogits", contig=False)
     _chk(dvals, "dvals", contig=False); _chk(loss_sums, "loss_sums", torch.float64)
     n, A = logits.shape
+    st = st if st is not None else stream()
     check(lib().a2c_loss_fwd_bwd(_p(logits), logits.stride(0), _p(vals), vals.stride(0), _p(actions), _p(advs),
                                  _p(returns), _p(adv_sums), n, n_global, A, float(pi_coef), float(val_coef),
                                  float(entr_coef), _p(dlogits), dlogits.stride(0), _p(dvals), dvals.stride(0),
-                                 _p(loss_sums), st if st is not None else stream()), "a2c_loss_fwd_bwd")
+                                 _p(loss_sums), _p(reduce_scratch(logits.device, st)), st), "a2c_loss_fwd_bwd")
 
 
 # ---------------------------------------------------------------- dense
@@ -615,7 +632,8 @@ def layernorm_bwd(dy, x, w, mean, rstd, dx, dw_rows, accumulate=False, st=None):
 
 # ---------------------------------------------------------------- clip + optimiser
 def gradnorm_sq(grads, sumsq, st=None):
-    check(lib().a2c_gradnorm_sq(_p(grads), grads.numel(), _p(sumsq), st if st is not None else stream()),
+    st = st if st is not None else stream()
+    check(lib().a2c_gradnorm_sq(_p(grads), grads.numel(), _p(sumsq), _p(reduce_scratch(grads.device, st)), st),
           "a2c_gradnorm_sq")
 
 

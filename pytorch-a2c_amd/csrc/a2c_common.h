@@ -39,6 +39,37 @@ __device__ __forceinline__ T block_sum_256(T v, T* sm /* >= 4 */) {
   return r;
 }
 
+// Deterministic grid-wide sum of NV doubles per workgroup (256 threads): every workgroup leaves its partials in its own slot
+// of `scratch`, takes a ticket, and the LAST one to arrive adds the slots in workgroup order (fixed tree) and writes out[0..NV).
+// No fp64 atomics: the result does not depend on the order in which the workgroups finish.  scratch: A2C_REDUCE_SCRATCH_DOUBLES
+// doubles, word 0 = the ticket counter, zero before the first use (the last workgroup resets it); at most A2C_REDUCE_MAX_BLOCKS
+// workgroups; kernels that share a scratch must be ordered (same stream).
+#define A2C_REDUCE_MAX_BLOCKS 1024
+static_assert(A2C_REDUCE_SCRATCH_DOUBLES >= 8 + 3 * A2C_REDUCE_MAX_BLOCKS, "include/a2c_mi355x.h: A2C_REDUCE_SCRATCH_DOUBLES");
+template <int NV>
+__device__ __forceinline__ void grid_sum_ordered(const double (&v)[NV], double* __restrict__ out, double* __restrict__ scratch,
+                                                 double* sm /* >= 4 */) {
+  __shared__ unsigned int s_last;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) scratch[8 + (long)blockIdx.x * NV + i] = v[i];
+    __threadfence();
+    s_last = atomicAdd(reinterpret_cast<unsigned int*>(scratch), 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last == 0u) return;
+  __threadfence();
+  const volatile double* part = scratch + 8;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double a = 0.0;
+    for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256) a += part[(long)b * NV + i];
+    a = block_sum_256(a, sm);
+    if (threadIdx.x == 0) out[i] = a;
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(scratch) = 0u;
+}
+
 // Small device buffers (error flags, reduction sums; <= 256 B, 4-byte multiples) are cleared by a one-wave kernel,
 // not by hipMemsetAsync: as a NODE of a captured hipGraph the memset was observed to leave 0x01010101 in a
 // 4-byte flag on some replays (ROCm 7.2, gfx950), which a kernel node never does.

@@ -1,7 +1,7 @@
 // A2C loss, forward and backward in one pass (Updater.update_model, updater.py:100-106,
 // 124-127).  One lane per rollout sample; per-sample traffic is (2A+5) floats + 8 B action,
 // so the kernel is latency/launch bound at the reference's sizes.  The three loss sums are
-// reduced per workgroup in fp64 and added with one atomic per workgroup.
+// reduced per workgroup in fp64; the per-workgroup partials are added in workgroup order by the last one to finish (no atomics).
 #include "a2c_common.h"
 
 namespace {
@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
                                                    const double* __restrict__ adv_sums, long n_local,
                                                    long n_global, int A, float pi_coef, float val_coef,
                                                    float entr_coef, float* __restrict__ dlogits, long ldd,
-                                                   float* __restrict__ dvals, long dvstride, double* loss_sums) {
+                                                   float* __restrict__ dvals, long dvstride, double* loss_sums, double* scratch) {
   __shared__ double sm[4];
   float mean = 0.f, den = 1.f;
   if (adv_sums != nullptr) {
@@ -72,11 +72,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
   s_pi = block_sum_256(s_pi, sm);
   s_val = block_sum_256(s_val, sm);
   s_ent = block_sum_256(s_ent, sm);
-  if (threadIdx.x == 0) {
-    atomicAdd(&loss_sums[0], s_pi);
-    atomicAdd(&loss_sums[1], s_val);
-    atomicAdd(&loss_sums[2], s_ent);
-  }
+  const double v3[3] = {s_pi, s_val, s_ent};
+  grid_sum_ordered<3>(v3, loss_sums, scratch, sm);       // fixed-order second stage: no fp64 atomics
 }
 }  // namespace
 
@@ -85,16 +82,18 @@ extern "C" int a2c_loss_fwd_bwd(const float* logits, int64_t ld_logits, const fl
                                 const float* advs, const float* returns, const double* adv_sums, int64_t n_local,
                                 int64_t n_global, int A, float pi_coef, float val_coef, float entr_coef,
                                 float* dlogits, int64_t ldd, float* dvals, int64_t dval_stride, double* loss_sums,
-                                a2c_stream_t stream) {
-  if (n_local < 0 || n_global < n_local || A < 1 || A > MAXA || !loss_sums) return A2C_ERR_ARG;
+                                double* scratch, a2c_stream_t stream) {
+  if (n_local < 0 || n_global < n_local || A < 1 || A > MAXA || !loss_sums || !scratch) return A2C_ERR_ARG;
   if (adv_sums && n_global < 2) return A2C_ERR_ARG;
-  a2c_zero_async(loss_sums, 3 * sizeof(double), a2c_s(stream));
-  if (n_local == 0) return A2C_OK;
+  if (n_local == 0) {
+    a2c_zero_async(loss_sums, 3 * sizeof(double), a2c_s(stream));
+    return A2C_OK;
+  }
   if (!logits || !vals || !actions || !advs || !returns || !dlogits || !dvals) return A2C_ERR_ARG;
-  hipLaunchKernelGGL(loss_kernel, dim3(a2c_grid_1d(n_local, 256, 1024)), dim3(256), 0, a2c_s(stream), logits,
+  hipLaunchKernelGGL(loss_kernel, dim3(a2c_grid_1d(n_local, 256, A2C_REDUCE_MAX_BLOCKS)), dim3(256), 0, a2c_s(stream), logits,
                      (long)ld_logits, vals, (long)val_stride, actions, advs, returns, adv_sums, (long)n_local,
                      (long)n_global, A, pi_coef, val_coef, entr_coef, dlogits, (long)ldd, dvals, (long)dval_stride,
-                     loss_sums);
+                     loss_sums, scratch);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -8,7 +8,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* out, double* scratch) {
   __shared__ double sm[4];
   double a = 0.0;
   const long n4 = n >> 2;
@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   }
   for (long i = (n4 << 2) + blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) a += (double)g[i] * g[i];
   a = block_sum_256(a, sm);
-  if (threadIdx.x == 0) atomicAdd(out, a);
+  const double v1[1] = {a};
+  grid_sum_ordered<1>(v1, out, scratch, sm);       // fixed-order second stage: no fp64 atomics
 }
 
 // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1.0,
@@ -113,12 +114,14 @@ int a2c_pack_update_scalars(const double* loss_sums, const float* grad_norm, con
   return A2C_OK;
 }
 
-int a2c_gradnorm_sq(const float* grads, int64_t n, double* sumsq, a2c_stream_t stream) {
-  if (n < 0 || !sumsq || (n > 0 && !grads) || ((uintptr_t)grads % 16)) return A2C_ERR_ARG;
-  a2c_zero_async(sumsq, sizeof(double), a2c_s(stream));
-  if (n == 0) return A2C_OK;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(a2c_grid_1d((n + 3) / 4, 256, 1024)), dim3(256), 0, a2c_s(stream), grads,
-                     (long)n, sumsq);
+int a2c_gradnorm_sq(const float* grads, int64_t n, double* sumsq, double* scratch, a2c_stream_t stream) {
+  if (n < 0 || !sumsq || !scratch || (n > 0 && !grads) || ((uintptr_t)grads % 16)) return A2C_ERR_ARG;
+  if (n == 0) {
+    a2c_zero_async(sumsq, sizeof(double), a2c_s(stream));
+    return A2C_OK;
+  }
+  hipLaunchKernelGGL(sumsq_kernel, dim3(a2c_grid_1d((n + 3) / 4, 256, A2C_REDUCE_MAX_BLOCKS)), dim3(256), 0, a2c_s(stream), grads,
+                     (long)n, sumsq, scratch);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -228,7 +228,7 @@ int launch_scan(const float* x0, const float* x1, const float* dn, float* y0, fl
   return A2C_OK;
 }
 
-__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, long n, double* sums) {
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, long n, double* sums, double* scratch) {
   __shared__ double sm[4];
   double a = 0.0, b = 0.0;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
@@ -238,10 +238,8 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
   }
   a = block_sum_256(a, sm);
   b = block_sum_256(b, sm);
-  if (threadIdx.x == 0) {
-    atomicAdd(&sums[0], a);
-    atomicAdd(&sums[1], b);
-  }
+  const double v2[2] = {a, b};
+  grid_sum_ordered<2>(v2, sums, scratch, sm);       // fixed-order second stage: no fp64 atomics
 }
 
 __device__ __forceinline__ void mean_std(const double* sums, long n, float& mean, float& stdv) {
@@ -290,11 +288,14 @@ int a2c_gae_returns_fused(const float* deltas, const float* rewards, const float
   return launch_scan<2>(deltas, rewards, dones, advs, rets, n_seg, T, g_adv, g_ret, err_flag, a2c_s(stream));
 }
 
-int a2c_moments(const float* x, int64_t n, double* sums, a2c_stream_t stream) {
-  if (!sums || n < 0 || (n > 0 && !x)) return A2C_ERR_ARG;
-  a2c_zero_async(sums, 2 * sizeof(double), a2c_s(stream));
-  if (n == 0) return A2C_OK;
-  hipLaunchKernelGGL(moments_kernel, dim3(a2c_grid_1d(n, 256, 1024)), dim3(256), 0, a2c_s(stream), x, (long)n, sums);
+int a2c_moments(const float* x, int64_t n, double* sums, double* scratch, a2c_stream_t stream) {
+  if (!sums || !scratch || n < 0 || (n > 0 && !x)) return A2C_ERR_ARG;
+  if (n == 0) {
+    a2c_zero_async(sums, 2 * sizeof(double), a2c_s(stream));
+    return A2C_OK;
+  }
+  hipLaunchKernelGGL(moments_kernel, dim3(a2c_grid_1d(n, 256, A2C_REDUCE_MAX_BLOCKS)), dim3(256), 0, a2c_s(stream), x, (long)n,
+                     sums, scratch);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -19,6 +19,8 @@ void chk(const at::Tensor& t, const char* name, at::ScalarType dt = at::kFloat, 
   TORCH_CHECK(!contig || t.is_contiguous(), "a2c_mi355x: `", name, "` must be contiguous");
 }
 void ok(int rc, const char* what) { TORCH_CHECK(rc == A2C_OK, what, ": ", a2c_error_string(rc)); }
+// zeroed scratch of the deterministic scalar reductions (one per call here: the side door allocates its outputs per call too)
+at::Tensor reduce_scratch(const at::Tensor& like) { return at::zeros({A2C_REDUCE_SCRATCH_DOUBLES}, like.options().dtype(at::kDouble)); }
 
 // utils.discount on rows (utils.py:63-79): y[i] = x[i] + g*(dones[i]==1 ? 0 : y[i+1]), bit-exact
 at::Tensor discount(const at::Tensor& x, const at::Tensor& dones, double g, int64_t n_seg) {
@@ -84,7 +86,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> loss_fwd_bwd(const at::Tensor& lo
   ok(a2c_loss_fwd_bwd(logits.data_ptr<float>(), logits.size(1), vals.data_ptr<float>(), 1, actions.data_ptr<int64_t>(),
                       advs.data_ptr<float>(), returns.data_ptr<float>(), nullptr, n, n, (int)logits.size(1), (float)pi_coef,
                       (float)val_coef, (float)entr_coef, dl.data_ptr<float>(), logits.size(1), dv.data_ptr<float>(), 1,
-                      sums.data_ptr<double>(), cur_stream()), "a2c_loss_fwd_bwd");
+                      sums.data_ptr<double>(), reduce_scratch(logits).data_ptr<double>(), cur_stream()), "a2c_loss_fwd_bwd");
   return {dl, dv, sums};
 }
 
@@ -103,7 +105,8 @@ at::Tensor clip_rmsprop_(at::Tensor params, at::Tensor grads, at::Tensor square_
                          double eps) {
   chk(params, "params"); chk(grads, "grads"); chk(square_avg, "square_avg");
   at::Tensor sumsq = at::empty({1}, params.options().dtype(at::kDouble)), norm = at::empty({1}, params.options());
-  ok(a2c_gradnorm_sq(grads.data_ptr<float>(), grads.numel(), sumsq.data_ptr<double>(), cur_stream()), "a2c_gradnorm_sq");
+  ok(a2c_gradnorm_sq(grads.data_ptr<float>(), grads.numel(), sumsq.data_ptr<double>(), reduce_scratch(grads).data_ptr<double>(), cur_stream()),
+     "a2c_gradnorm_sq");
   ok(a2c_clip_rmsprop(params.data_ptr<float>(), grads.data_ptr<float>(), square_avg.data_ptr<float>(), params.numel(),
                       sumsq.data_ptr<double>(), max_norm, lr, alpha, eps, norm.data_ptr<float>(), cur_stream()), "a2c_clip_rmsprop");
   return norm;
@@ -255,7 +258,8 @@ at::Tensor clip_adam_(at::Tensor params, at::Tensor grads, at::Tensor exp_avg, a
                       double lr, double beta1, double beta2, double eps) {
   chk(params, "params"); chk(grads, "grads"); chk(exp_avg, "exp_avg"); chk(exp_avg_sq, "exp_avg_sq");
   at::Tensor sumsq = at::empty({1}, params.options().dtype(at::kDouble)), norm = at::empty({1}, params.options());
-  ok(a2c_gradnorm_sq(grads.data_ptr<float>(), grads.numel(), sumsq.data_ptr<double>(), cur_stream()), "a2c_gradnorm_sq");
+  ok(a2c_gradnorm_sq(grads.data_ptr<float>(), grads.numel(), sumsq.data_ptr<double>(), reduce_scratch(grads).data_ptr<double>(), cur_stream()),
+     "a2c_gradnorm_sq");
   ok(a2c_clip_adam(params.data_ptr<float>(), grads.data_ptr<float>(), exp_avg.data_ptr<float>(), exp_avg_sq.data_ptr<float>(),
                    params.numel(), sumsq.data_ptr<double>(), max_norm, lr, beta1, beta2, eps, step, norm.data_ptr<float>(), cur_stream()),
      "a2c_clip_adam");

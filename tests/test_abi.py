@@ -57,7 +57,8 @@ def test_argument_validation_without_gpu():
     assert lib.a2c_discount_scan(None, None, None, 0, 4, 0.9, None, None) == 0          # empty input is a no-op
     assert lib.a2c_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, None, 0, 0, 1, None, 0, None) == -1
     assert lib.a2c_loss_fwd_bwd(None, 3, None, 1, None, None, None, None, 4, 4, 64, 1.0, .5, .005, None, 3, None, 1,
-                                None, None) == -1
+                                None, None, None) == -1
+    assert lib.a2c_moments(None, 4, None, None, None) == -1 and lib.a2c_gradnorm_sq(None, 4, None, None, None) == -1
     d = _lib.ConvDesc(3, 8, 8, 16, 3, 1, 1, 8, 8)       # Cin % 4 != 0
     import ctypes
     assert lib.a2c_conv2d_prep_floats(ctypes.byref(d), 0) == 0

@@ -256,3 +256,46 @@ def test_train_on_the_reference_hyperparams_matches_oracle(tmp_path):
     assert sorted(os.listdir(folder)) == ["best_net.p", "log.txt", "net.p", "optim.p"]
     log = open(os.path.join(folder, "log.txt")).read()
     assert f"Step:{R * T}" in log and f"Step:{2 * R * T}" in log
+
+
+def test_ring_kernel_on_the_tagged_mirror_matches_oracle(monkeypatch):
+    """A2C_TAGGED=1 (opt-in, DESIGN.md section 7: measured slower than poll-then-frame): the ring kernel fetches poll + frame +
+    record of an env step with ONE 16-byte load per lane from the pool's self-validating mirror and validates the chunk tags
+    by ballot; two rounds against the oracle, step counter crossing 65536 (the tags carry its low 16 bits)."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    monkeypatch.setenv("A2C_TAGGED", "1")
+    B, T, A, ss = 5, 7, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    net = make_net("A3CModel", ss, A, 256)
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    kws = [dict(env_id=j, length=2 * T + 1, p_done=0.15) for j in range(B)]
+    pool = ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=2, pong=True, frame_bits=True, seq_start=65536 - 5)
+    us = torch.from_numpy(hashf(2 * T * B, 3391, 0, 1).reshape(2, T, B))
+    usd = us.to(DEV)
+    rnd = [0]
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy",
+               uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+    try:
+        assert pool.start().header.off_tagged != 0
+        Do = dict(states=torch.zeros(B * T, *ss), deltas=torch.zeros(B * T), rewards=torch.zeros(B * T), dones=torch.zeros(B * T),
+                  actions=torch.zeros(B * T).long())
+        runners = []
+        for j in range(B):
+            seq = iter([float(us[k, t, j]) for k in range(2) for t in range(T)])
+            sr = O.SlotRunner(TapeEnv(**kws[j]), Do, hyps, uniform_fn=lambda seq=seq: next(seq))
+            sr.start(onet)
+            runners.append(sr)
+        for rnd[0] in range(2):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            for j in range(B):
+                runners[j].rollout(onet, j)
+            assert torch.equal(D["actions"].cpu(), Do["actions"]) and torch.equal(D["states"].cpu(), Do["states"])
+            assert torch.equal(D["dones"].cpu(), Do["dones"])
+            close("rewards", D["rewards"], Do["rewards"], 1e-5, 1e-5)
+            close("deltas", D["deltas"], Do["deltas"], 1e-5, 1e-5)
+    finally:
+        r.close()

@@ -226,3 +226,44 @@ def test_step_counter_wraps_at_2_31_on_the_rec_side(kind):
                 assert np.array_equal(fr[j], np.asarray(o).astype(np.uint8)) and rew[j] == np.float32(r) and done[j] == float(d)
     finally:
         pool.close()
+
+
+def test_self_validating_tagged_mirror_of_the_packed_frames(monkeypatch):
+    """A2C_TAGGED=1: packed pools keep a second copy of every frame as 16-byte chunks that each carry the step number's low
+    16 bits (a2c_hostpool.h): 14 bytes of packed pixels + tag, the last chunk = {reward, done, seq, tag}.  Checked here from
+    the host side for both worker kinds: chunk contents == the packed frame, tags == seq & 0xffff, record == rec granule."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    monkeypatch.setenv("A2C_TAGGED", "1")
+    B = 3
+    for kind in ("thread", "process"):
+        if kind == "process":
+            kws = [dict(env_id=j, rew_period=3, done_period=5 + j) for j in range(B)]
+            pool = ProcessEnvPool(U8FakeEnv, B, env_kwargs=kws, n_workers=2, register=False, frame_bits=True, seq_start=65533)
+        else:
+            kws = [dict(env_id=j, length=13, p_done=0.2) for j in range(B)]
+            pool = ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=2, register=False, frame_bits=True,
+                                                seq_start=65533)
+        try:
+            pool.start()
+            pool.set_phase(ROLLOUT)
+            h = pool.header
+            assert h.off_tagged and h.tagged_chunks == 64 and h.tagged_stride == 1024          # 84 x 84 = 63 x 112 pixels + the record
+            mm = np.frombuffer(pool.region.mm, dtype=np.uint8)
+            rew, done = np.zeros(B, np.float32), np.zeros(B, np.float32)
+            for k in range(6):                                    # crosses seq & 0xffff == 0
+                seq = 65533 + k
+                pool.wait_frames(seq, timeout=10.0)
+                pool.unpack(rew, done)
+                packed = pool.region.frames[:, :pool.frame_bytes]
+                for j in range(B):
+                    t = mm[h.off_tagged + j * h.tagged_stride:h.off_tagged + (j + 1) * h.tagged_stride].reshape(64, 16)
+                    tags = t[:, 14:16].copy().view(np.uint16).reshape(-1)
+                    assert (tags == (seq & 0xffff)).all(), (kind, k, j, tags[:4])
+                    data = t[:63, :14].reshape(-1)[:pool.frame_bytes]
+                    assert np.array_equal(data, packed[j]), (kind, k, j)
+                    meta = t[63]
+                    assert meta[0:4].copy().view(np.float32)[0] == rew[j] and int(meta[4:8].copy().view(np.uint32)[0]) == int(done[j])
+                    assert int(meta[8:12].copy().view(np.uint32)[0]) == seq
+                pool.post_actions(np.zeros(B, np.int64), seq=seq)
+        finally:
+            pool.close()

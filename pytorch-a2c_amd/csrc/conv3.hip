@@ -112,7 +112,8 @@ template <int H, int W, int SR, int WP, int PLANE, int NL>
 __device__ __forceinline__ void c3_u8_stage(float* __restrict__ buf, const C3U8& u, long b, int y0, int lw, int lane) {
   static_assert(W % 4 == 0, "rows of whole dwords");
   constexpr int RP = W / 4, PPL = SR * RP, NQ8 = (PPL + 63) / 64;
-  const unsigned char* __restrict__ fb = u.f + (b / u.T) * u.bs + (b % u.T) * (long)(H * W);
+  const unsigned bu_ = (unsigned)b, slot_ = bu_ / (unsigned)u.T;                  // (b < 2^31: 32-bit division)
+  const unsigned char* __restrict__ fb = u.f + (long)slot_ * u.bs + (long)(bu_ - slot_ * (unsigned)u.T) * (H * W);
   const int nvl = u.nv ? u.nv[b * u.nv_s] : 4;
   static_assert(4 % NL == 0, "planes dealt evenly to the loader waves");
   constexpr int NPL = 4 / NL;                  // planes of this loader wave: c = lw + NL * s
@@ -140,6 +141,50 @@ __device__ __forceinline__ void c3_u8_stage(float* __restrict__ buf, const C3U8&
     }
   }
 }
+// The same in two halves for a loader that keeps one sample's bytes in flight while the previous one is expanded
+// (c3w_kernel): NPL * NQ8 UNCONDITIONAL dword loads (clamped addresses: the instruction count feeds a counted vmcnt),
+// the zero planes / rows are selected when the bytes are expanded.
+template <int H, int W, int SR, int NL>
+struct C3U8Regs {
+  static constexpr int RP = W / 4, PPL = SR * RP, NQ8 = (PPL + 63) / 64, NPL = 4 / NL, NLD = NPL * NQ8;
+  unsigned v[NPL][NQ8];
+  int nvl, y0;
+};
+template <int H, int W, int SR, int NL>
+__device__ __forceinline__ void c3_u8_load(C3U8Regs<H, W, SR, NL>& rg, const C3U8& u, long b, int y0, int lw, int lane) {
+  using RG = C3U8Regs<H, W, SR, NL>;
+  const unsigned bu_ = (unsigned)b, slot_ = bu_ / (unsigned)u.T;                  // (b < 2^31: 32-bit division)
+  const unsigned char* __restrict__ fb = u.f + (long)slot_ * u.bs + (long)(bu_ - slot_ * (unsigned)u.T) * (H * W);
+  rg.nvl = u.nv ? u.nv[b * u.nv_s] : 4;
+  rg.y0 = y0;
+#pragma unroll
+  for (int s = 0; s < RG::NPL; ++s) {
+    const int c = lw + NL * s;
+#pragma unroll
+    for (int q = 0; q < RG::NQ8; ++q) {
+      const int pi = min(q * 64 + lane, RG::PPL - 1), r = pi / RG::RP, i = pi - r * RG::RP;
+      const int y = min(max(y0 + r, 0), H - 1);
+      rg.v[s][q] = *reinterpret_cast<const unsigned*>(fb + ((long)c * H + y) * W + 4 * i);
+    }
+  }
+}
+template <int H, int W, int SR, int WP, int PLANE, int NL>
+__device__ __forceinline__ void c3_u8_expand(float* __restrict__ buf, const C3U8Regs<H, W, SR, NL>& rg, int lw, int lane) {
+  using RG = C3U8Regs<H, W, SR, NL>;
+#pragma unroll
+  for (int s = 0; s < RG::NPL; ++s) {
+    const int c = lw + NL * s;
+    const bool live = c >= 4 - rg.nvl;
+#pragma unroll
+    for (int q = 0; q < RG::NQ8; ++q) {
+      const int pi = q * 64 + lane, r = pi / RG::RP, i = pi - r * RG::RP, y = rg.y0 + r;
+      const unsigned vv = (live && y >= 0 && y < H) ? rg.v[s][q] : 0u;
+      if (pi < RG::PPL)
+        *reinterpret_cast<float4*>(buf + c * PLANE + r * WP + 4 + 4 * i) =
+            make_float4((float)(vv & 0xffu), (float)((vv >> 8) & 0xffu), (float)((vv >> 16) & 0xffu), (float)(vv >> 24));
+    }
+  }
+}
 template <int SR, int WP, int PLANE>
 __device__ __forceinline__ void c3_u8_zero_pads(float* __restrict__ buf, int lane, int lw, int nl) {
   for (int i = lw * 64 + lane; i < 4 * SR; i += 64 * nl)
@@ -160,7 +205,11 @@ struct C3P {
   const unsigned* sg_in;              // backward-data: the ReLU mask of the layer below as sign words, or nullptr
   long sg_bs;                         // sample stride of the sign words (in words)
   C3U8 u8;                            // first layers: uint8 frame-store source instead of src (u8.f != nullptr)
+  int prio;                           // loader waves at raised priority
 };
+// (loader waves issue a few hundred instructions per chunk between the computing waves' MFMA streams: at equal priority they
+// were the critical path of the weight-gradient kernels; A2C_C3_PRIO=0 = round 3's schedule, for A/B runs)
+static int c3_prio() { static const int v = getenv("A2C_C3_PRIO") ? atoi(getenv("A2C_C3_PRIO")) : 1; return v; }
 
 template <int CS, int CD, int H, int W, int S, int R, int KCO = 0>
 struct C3Geo {
@@ -263,9 +312,9 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
     c3_bar();
     for (long k = 0; k < nwork; ++k) {
       c3_bar();                                   // (raw: this wave must not wait for its stores' acknowledgements here)
-      if ((int)(k % G::NCH) == G::NCH - 1 && p.sg_out != nullptr) {      // the band's epilogue is behind that barrier
-        const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-        const long b = tile / G::NBAND;
+      if ((int)((unsigned)k % (unsigned)G::NCH) == G::NCH - 1 && p.sg_out != nullptr) {      // the band's epilogue is behind that barrier
+        const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+        const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
         const int band = (int)(tile - b * G::NBAND);
         const int nw = min(R, G::OH - band * R) * G::SRW;
         unsigned* __restrict__ gb = p.sg_out + b * p.sg_bs + (long)band * R * G::SRW;
@@ -297,6 +346,7 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
   if (w >= G::NW) {
     // ------------------------------------------------------------------ loader waves (planes / fragment pieces dealt round robin)
     const int lw = w - G::NW;
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     int roff[G::NQ], rrow[G::NQ];                 // this lane's piece of DMA instruction q: source offset / image row
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q) {
@@ -314,9 +364,9 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
       }
     }
     auto dma = [&](long k) {
-      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-      const int ch = (int)(k % G::NCH);
-      const long b = tile / G::NBAND;
+      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const int ch = (int)((unsigned)k % (unsigned)G::NCH);
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int y0 = band * R * S - 1;
       float* __restrict__ buf = lds + (k & 1) * G::BUF;
@@ -348,13 +398,13 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
     };
     // backward-data: the band's ReLU mask, one linear run per channel, issued while the band's FIRST chunk computes
     auto dma_mask = [&](long k) {      // the slice of the band's mask that travels beside chunk k (all but the last chunk carry one)
-      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-      const long b = tile / G::NBAND;
+      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int npx = min(R, G::OH - band * R) * G::OW;
       float* __restrict__ mb = lds + 2 * G::BUF;
       constexpr int CPP = G::NCH > 1 ? (CD + G::NCH - 2) / (G::NCH - 1) : CD;
-      const int part = (int)(k % G::NCH);
+      const int part = (int)((unsigned)k % (unsigned)G::NCH);
 #pragma unroll 1
       for (int c = part * CPP + lw; c < min(CD, (part + 1) * CPP); c += G::NL) {
         const float* __restrict__ ms = p.mask + b * p.out_bs + (long)c * G::OH * G::OW + (long)band * R * G::OW;
@@ -370,7 +420,7 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
     __syncthreads();
     for (long k = 0; k < nwork; ++k) {
       if (k + 1 < nwork) dma(k + 1);
-      if (BWD && p.mask != nullptr && (int)(k % G::NCH) < G::NCH - 1) dma_mask(k);
+      if (BWD && p.mask != nullptr && (int)((unsigned)k % (unsigned)G::NCH) < G::NCH - 1) dma_mask(k);
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
     }
@@ -415,11 +465,11 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
         if (G::TPW * G::MT >= 12) __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from hoisting later steps' reads (registers)
       }
     }
-    if ((int)(k % G::NCH) == G::NCH - 1) {
+    if ((int)((unsigned)k % (unsigned)G::NCH) == G::NCH - 1) {
       // ---- the band is complete: accumulators -> HBM.  With the PIXELS as the MFMA's A operand the D tile is
       // [pixel][channel]: lane (j, g) holds pixels 4g .. 4g+3 of channel j -- one 16-byte store per lane and tile
-      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-      const long b = tile / G::NBAND;
+      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int npix_ok = min(R, G::OH - band * R) * G::OW;
       const long o0 = b * p.out_bs + (long)band * R * G::OW;
@@ -525,6 +575,7 @@ __global__ __launch_bounds__(640) void c3b_kernel(C3P p) {
   if (w >= G::NW) {
     // ------------------------------------------------------------------ loader waves
     const int lw = w - G::NW;
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     int roff[G::NQ], rrow[G::NQ];
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q) {
@@ -534,9 +585,9 @@ __global__ __launch_bounds__(640) void c3b_kernel(C3P p) {
       roff[q] = r * WO + x;
     }
     auto dma = [&](long k) {
-      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-      const int ch = (int)(k % G::NCH);
-      const long b = tile / G::NBAND;
+      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const int ch = (int)((unsigned)k % (unsigned)G::NCH);
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
       float* __restrict__ buf = lds + (k & 1) * G::BUF;
       const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * KC * HO + q0) * WO;
@@ -562,13 +613,13 @@ __global__ __launch_bounds__(640) void c3b_kernel(C3P p) {
     // the band's ReLU mask (the activation below this layer, same geometry as dX): one linear run per channel, issued
     // while the band's FIRST chunk computes -- the epilogue behind its last chunk then reads LDS, not HBM
     auto dma_mask = [&](long k) {      // the slice of the band's mask that travels beside chunk k (all but the last chunk carry one)
-      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-      const long b = tile / G::NBAND;
+      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
       const int rows = 2 * min(RQ, HO - q0);
       float* __restrict__ mb = lds + 2 * G::BUF;
       constexpr int CPP = (CI + G::NCH - 2) / (G::NCH - 1);
-      const int part = (int)(k % G::NCH);
+      const int part = (int)((unsigned)k % (unsigned)G::NCH);
 #pragma unroll 1
       for (int c = part * CPP + lw; c < min(CI, (part + 1) * CPP); c += G::NL) {
         const float* __restrict__ ms = p.mask + b * p.out_bs + ((long)c * G::H + 2 * q0) * G::W;
@@ -584,7 +635,7 @@ __global__ __launch_bounds__(640) void c3b_kernel(C3P p) {
     __syncthreads();
     for (long k = 0; k < nwork; ++k) {
       if (k + 1 < nwork) dma(k + 1);
-      if (p.mask != nullptr && (int)(k % G::NCH) < G::NCH - 1) dma_mask(k);
+      if (p.mask != nullptr && (int)((unsigned)k % (unsigned)G::NCH) < G::NCH - 1) dma_mask(k);
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
     }
@@ -642,10 +693,10 @@ __global__ __launch_bounds__(640) void c3b_kernel(C3P p) {
       }
     }
     C3_TS(0);
-    if ((int)(k % G::NCH) == G::NCH - 1) {
+    if ((int)((unsigned)k % (unsigned)G::NCH) == G::NCH - 1) {
       // ---- the band is complete: lane (j, g) holds class pixels 4g .. 4g+3 of channel j, both x parities: rows of dX
-      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-      const long b = tile / G::NBAND;
+      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
       const int npix_ok = min(RQ, HO - q0) * WO;
       const long o0 = b * p.out_bs;
@@ -722,6 +773,7 @@ int c3b_launch(const C3P& p, hipStream_t st) {
     per_cu = n;
   }
   const long total = (long)p.B * G::NBAND;
+  if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;      // (the kernels walk chunks with 32-bit arithmetic)
   const long cap = (long)per_cu * cus;
   const int grid = (int)(total < cap ? total : cap);
   hipLaunchKernelGGL((c3b_kernel<CO, CI, HO, WO, RQ, KC>), dim3(grid), dim3(640), G::LDS_BYTES, st, p);
@@ -880,7 +932,7 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
     c3_bar();
     const bool signs = !BWD && p.sg_out != nullptr;
     auto drain = [&](long tile, int part) {
-      const long b = tile / G::NBAND;
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int nrows = min(R, G::OH - band * R), npx = nrows * G::OW;
       constexpr int CPP = (CD + G::NCH - 1) / G::NCH;
@@ -909,11 +961,11 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
     };
     long pend = -1;
     for (long k = 0; k < nwork; ++k) {
-      const int ch = (int)(k % G::NCH);
+      const int ch = (int)((unsigned)k % (unsigned)G::NCH);
       if (pend >= 0) drain(pend, ch);             // the previous band leaves under this band's chunks, a slice per chunk
       if (ch == G::NCH - 1) c3_bar();      // X
       c3_bar();
-      if (ch == G::NCH - 1) pend = blockIdx.x + (k / G::NCH) * gridDim.x;
+      if (ch == G::NCH - 1) pend = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
     }
     if (pend >= 0)
       for (int part = 0; part < G::NCH; ++part) drain(pend, part);
@@ -922,6 +974,7 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
   if (w >= G::NW) {
     // ------------------------------------------------------------------ loader waves
     const int lw = w - G::NW;
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     int roff[G::NQ], rrow[G::NQ];
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q) {
@@ -939,9 +992,9 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
       }
     }
     auto dma = [&](long k) {
-      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-      const int ch = (int)(k % G::NCH);
-      const long b = tile / G::NBAND;
+      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const int ch = (int)((unsigned)k % (unsigned)G::NCH);
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int y0 = band * R * S - 1;
       float* __restrict__ buf = lds + (k & 1) * G::BUF;
@@ -973,7 +1026,7 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
     };
     // backward-data: the band's mask as sign words, R * RW words per channel (contiguous in HBM)
     auto dma_signs = [&](long tile) {
-      const long b = tile / G::NBAND;
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int nw = min(R, G::OH - band * R) * G::RW;
 #pragma unroll 1
@@ -992,9 +1045,9 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the chunk has landed in LDS
     c3_bar();
     for (long k = 0; k < nwork; ++k) {
-      const int ch = (int)(k % G::NCH);
+      const int ch = (int)((unsigned)k % (unsigned)G::NCH);
       if (k + 1 < nwork) dma(k + 1);
-      if (msk && ch == 0 && k > 0) dma_signs(blockIdx.x + (k / G::NCH) * gridDim.x);     // (the previous band is done with them)
+      if (msk && ch == 0 && k > 0) dma_signs(blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x);     // (the previous band is done with them)
       __builtin_amdgcn_s_waitcnt(0x0F70);
       if (ch == G::NCH - 1) c3_bar();       // X
       c3_bar();
@@ -1042,7 +1095,7 @@ __global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
         if (G::TPW * G::MT >= 12) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if ((int)(k % G::NCH) == G::NCH - 1) {
+    if ((int)((unsigned)k % (unsigned)G::NCH) == G::NCH - 1) {
       c3_bar();                                       // X: the image is free, this band's sign words are in
       // ---- accumulators -> the image.  D tile [pixel][channel]: lane (j, g) holds pixels 4g .. 4g+3 of channel j
 #pragma unroll
@@ -1151,7 +1204,7 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
     const int sw = w - G::NW - G::NL;
     c3_bar();
     auto drain = [&](long tile, int part) {
-      const long b = tile / G::NBAND;
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
       const int nrows = 2 * min(RQ, HO - q0), npx = nrows * G::W;
       constexpr int CPP = (CI + G::NCH - 1) / G::NCH;
@@ -1179,13 +1232,13 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
     const bool stamp = C3_STAMPS && p.dbg != nullptr && blockIdx.x == 0 && sw == 0 && lane == 0;
     unsigned long long tdr = 0;
     for (long k = 0; k < nwork; ++k) {
-      const int ch = (int)(k % G::NCH);
+      const int ch = (int)((unsigned)k % (unsigned)G::NCH);
       const unsigned long long t0 = stamp ? wall_clock64() : 0;
       if (pend >= 0) drain(pend, ch);
       if (stamp) tdr += wall_clock64() - t0;
       if (ch == G::NCH - 1) c3_bar();      // X
       c3_bar();
-      if (ch == G::NCH - 1) pend = blockIdx.x + (k / G::NCH) * gridDim.x;
+      if (ch == G::NCH - 1) pend = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
     }
     if (pend >= 0)
       for (int part = 0; part < G::NCH; ++part) drain(pend, part);
@@ -1195,6 +1248,7 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
   if (w >= G::NW) {
     // ------------------------------------------------------------------ loader waves
     const int lw = w - G::NW;
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     int roff[G::NQ], rrow[G::NQ];
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q) {
@@ -1209,11 +1263,11 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
       }
     }
     auto dma = [&](long k) {
-      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-      const int ch = (int)(k % G::NCH);
-      const long b = tile / G::NBAND;
+      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const int ch = (int)((unsigned)k % (unsigned)G::NCH);
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
-      float* __restrict__ buf = lds + (k % D) * G::SLOT;
+      float* __restrict__ buf = lds + ((unsigned)k % (unsigned)D) * G::SLOT;
       const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * KC * HO + q0) * WO;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
@@ -1242,7 +1296,7 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
       }
     };
     auto dma_signs = [&](long tile) {
-      const long b = tile / G::NBAND;
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
       const int nw = 2 * min(RQ, HO - q0) * G::RW;
 #pragma unroll 1
@@ -1290,9 +1344,9 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
     const bool stamp = C3_STAMPS && p.dbg != nullptr && blockIdx.x == 0 && lw == 0 && lane == 0;
     unsigned long long tld = 0;
     for (long k = 0; k < nwork; ++k) {
-      const int ch = (int)(k % G::NCH);
+      const int ch = (int)((unsigned)k % (unsigned)G::NCH);
       const unsigned long long t0 = stamp ? wall_clock64() : 0;
-      if (msk && ch == 0 && k > 0) dma_signs(blockIdx.x + (k / G::NCH) * gridDim.x);     // (the previous band is done with them)
+      if (msk && ch == 0 && k > 0) dma_signs(blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x);     // (the previous band is done with them)
       if (k + G::LOOK < nwork) dma(k + G::LOOK);            // into the slot chunk k - 1 left
       wait_for(k + 1);
       if (stamp) tld += wall_clock64() - t0;
@@ -1327,8 +1381,8 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
   unsigned long long ts = stamp ? wall_clock64() : 0, tsum[4] = {0, 0, 0, 0};      // MFMAs | wait at X | image write | wait at the chunk barrier
 #define C3_TS(i) do { if (stamp) { const unsigned long long n_ = wall_clock64(); tsum[i] += n_ - ts; ts = n_; } } while (0)
   for (long k = 0; k < nwork; ++k) {
-    const float* __restrict__ img = lds + (k % D) * G::SLOT;
-    const float* __restrict__ fr = (FRES ? fres + (k % G::NCH) * G::FRAGC : img + G::IMG) + lane;
+    const float* __restrict__ img = lds + ((unsigned)k % (unsigned)D) * G::SLOT;
+    const float* __restrict__ fr = (FRES ? fres + ((unsigned)k % (unsigned)G::NCH) * G::FRAGC : img + G::IMG) + lane;
 #pragma unroll
     for (int c4 = 0; c4 < G::C4; ++c4) {
       float wv[9][G::MT];
@@ -1361,11 +1415,11 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
       }
     }
     C3_TS(0);
-    if ((int)(k % G::NCH) == G::NCH - 1) {
+    if ((int)((unsigned)k % (unsigned)G::NCH) == G::NCH - 1) {
       c3_bar();                                       // X
       C3_TS(1);
-      const long tile = blockIdx.x + (k / G::NCH) * gridDim.x;
-      const long b = tile / G::NBAND;
+      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
       const int npix_ok = min(RQ, HO - q0) * WO;
 #pragma unroll
@@ -1438,6 +1492,7 @@ int c3bs_launch(const C3P& p, hipStream_t st) {
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
   const long total = (long)p.B * G::NBAND;
+  if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;      // (the kernels walk chunks with 32-bit arithmetic)
   const int grid = (int)(total < cus ? total : cus);
   hipLaunchKernelGGL((c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES>), dim3(grid), dim3(768), G::LDS_BYTES_S, st, p);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
@@ -1457,6 +1512,7 @@ int c3s_launch(const C3P& p, hipStream_t st) {
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
   const long total = (long)p.B * G::NBAND;
+  if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;      // (the kernels walk chunks with 32-bit arithmetic)
   const int grid = (int)(total < cus ? total : cus);
   hipLaunchKernelGGL((c3s_kernel<CS, CD, H, W, S, R, BWD>), dim3(grid), dim3(768), G::LDS_BYTES_S, st, p);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
@@ -1517,6 +1573,7 @@ struct C3WP {
   int B;
   C3U8 u8;                            // first layer: uint8 frame-store source instead of x (u8.f != nullptr)
   int nodma;                          // timing experiment (A2C_C3W_NODMA=1: wrong sums): only the first band is loaded
+  int prio;                           // loader waves at raised priority
 };
 
 __global__ __launch_bounds__(256) void c3w_reduce_kernel(const float* __restrict__ slab, int nslab, long per, long nW,
@@ -1563,6 +1620,7 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
       rrow[q] = (pi < G::PP) ? (i == 0 ? -100000 : r) : -200000;
       roff[q] = r * W + G::PB * (i - 1);
     }
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     int doff[G::DNQ], drow[G::DNQ];                   // dOut pieces: band row and source offset of this lane's piece
 #pragma unroll
     for (int q = 0; q < G::DNQ; ++q) {
@@ -1573,16 +1631,16 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
       doff[q] = r * G::OW + x;
     }
     auto dma = [&](long k) {
-      const long it = k / G::NCH;
+      const long it = (unsigned)k / (unsigned)G::NCH;
       const long tile = blockIdx.x + it * gridDim.x;
-      const int ch = (int)(k % G::NCH);
-      const long b = tile / G::NBAND;
+      const int ch = (int)((unsigned)k % (unsigned)G::NCH);
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int y0 = band * R * S - 1;
-      float* __restrict__ xb = xbuf + (k % D) * G::XB;
+      float* __restrict__ xb = xbuf + ((unsigned)k % (unsigned)D) * G::XB;
       const float* __restrict__ sb = p.x + b * p.x_bs + ((long)ch * KC * H + y0) * W;
-      constexpr bool U8OK = CS == 4 && KC == 4 && W % 4 == 0;      // first layer from the single-frame uint8 store (stack-on-load)
-      const bool staged = U8OK && p.u8.f != nullptr;                // (expanded below, behind the dOut DMA)
+      constexpr bool U8OK = CS == 4 && KC == 4 && W % 4 == 0;      // first layer from the single-frame uint8 store (stack-on-load):
+      const bool staged = U8OK && p.u8.f != nullptr;                // the image is written by the loader loop below, not by DMA
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         if (staged || c % G::NL != lw) continue;
@@ -1597,7 +1655,7 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
         }
       }
       if (ch == 0) {        // the band's dOut rows, all output channels
-        float* __restrict__ db_ = dbuf + (it % G::DD) * G::DB;
+        float* __restrict__ db_ = dbuf + ((unsigned)it % (unsigned)G::DD) * G::DB;
         const float* __restrict__ ds = p.dout + (b * CD * G::OH + (long)band * R) * G::OW;
 #pragma unroll 1
         for (int c = lw; c < CD; c += G::NL) {
@@ -1611,18 +1669,63 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
           }
         }
       }
-      if constexpr (U8OK) {
-        if (staged) c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(xb, p.u8, b, y0, lw, lane);
-      }
     };
+    if constexpr (CS == 4 && KC == 4 && W % 4 == 0) {
+      if (p.u8.f != nullptr) {
+        // ---- first layer from the single-frame uint8 store (stack-on-load; one chunk per band: k = tile).  The bytes of
+        // chunk k + LOOK + 1 travel to REGISTERS while chunk k + LOOK's are expanded into its ring image, so the loaders
+        // never sit out an HBM latency (round 4's first version staged synchronously and ran on the D = 2 instance:
+        // 6.2 ms against the fp32 source's 5.0 at N = 32,768).  vmcnt order per iteration: dOut DMA (NID), then the NLD
+        // byte loads of the chunk after it.
+        using RG = C3U8Regs<H, W, G::SR, G::NL>;
+        static_assert(G::NID + RG::NLD <= 63, "counted vmcnt");
+        RG rg;
+        auto u8l = [&](long k) {
+          const long tile = blockIdx.x + k * gridDim.x;
+          const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
+          const int band = (int)(tile - b * G::NBAND);
+          c3_u8_load<H, W, G::SR, G::NL>(rg, p.u8, b, band * R * S - 1, lw, lane);
+        };
+        auto u8e = [&](long k) { c3_u8_expand<H, W, G::SR, G::WP, G::PLANE, G::NL>(xbuf + ((unsigned)k % (unsigned)D) * G::XB, rg, lw, lane); };
+        for (int kk = 0; kk < G::LOOK; ++kk)
+          if (kk < nwork) {
+            dma(kk);
+            u8l(kk);
+            c3_wait_vm<0>();
+            u8e(kk);
+          }
+        if (G::LOOK < nwork) u8l(G::LOOK);
+        c3_bar();
+        for (long k = 0; k < nwork; ++k) {
+          const bool more = k + G::LOOK < nwork, ahead = k + G::LOOK + 1 < nwork;
+          if (more) {
+            dma(k + G::LOOK);                     // dOut band of chunk k + LOOK (its bytes are already on the way)
+            c3_wait_vm<G::NID>();                 // ... the bytes have landed
+            u8e(k + G::LOOK);                     // into the image chunk k - 1 left
+            if (ahead) {
+              u8l(k + G::LOOK + 1);
+            }
+          }
+          // opening chunk k + 1: its dOut band and its image are complete; what may stay in flight is younger
+          if (G::LOOK >= 2 && more) {
+            if (ahead) c3_wait_vm<G::NID + RG::NLD>();
+            else c3_wait_vm<G::NID>();
+          } else {
+            if (ahead && more) c3_wait_vm<RG::NLD>();
+            else c3_wait_vm<0>();
+          }
+          c3_bar();
+        }
+        return;
+      }
+    }
     // before the barrier that opens chunk k1: everything up to chunk k1 has landed; with LOOK = 2 the one younger chunk
     // (k1 + 1) stays in flight: its instruction count is NIX (+ NID when it opens a band).  (vmcnt holds 63 at most: a
-    // smaller immediate only waits longer.)  The uint8 stack-on-load path stages synchronously: nothing is in flight.
-    const bool sync_stage = CS == 4 && p.u8.f != nullptr;
+    // smaller immediate only waits longer.)
     auto wait_for = [&](long k1) {
       constexpr int CA = G::NIX > 63 ? 63 : G::NIX, CB = G::NIX + G::NID > 63 ? 63 : G::NIX + G::NID;
-      if (G::LOOK >= 2 && !sync_stage && k1 + 1 < nwork && !p.nodma) {
-        if ((int)((k1 + 1) % G::NCH) == 0) c3_wait_vm<CB>();
+      if (G::LOOK >= 2 && k1 + 1 < nwork && !p.nodma) {
+        if ((int)((unsigned)(k1 + 1) % (unsigned)G::NCH) == 0) c3_wait_vm<CB>();
         else c3_wait_vm<CA>();
       } else {
         c3_wait_vm<0>();
@@ -1668,7 +1771,7 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
   for (int m = 0; m < G::MTW; ++m) dbs[m] = 0.f;
   __syncthreads();
   for (long it = 0; it < nmine; ++it) {
-    const float* __restrict__ dimg = dbuf + (it % G::DD) * G::DB;
+    const float* __restrict__ dimg = dbuf + ((unsigned)it % (unsigned)G::DD) * G::DB;
 #pragma unroll
     for (int ch = 0; ch < G::NCH; ++ch) {
       const float* __restrict__ ximg = xbuf + ((it * G::NCH + ch) % D) * G::XB;
@@ -1744,6 +1847,7 @@ int c3w_launch(const C3WP& p0, float* dW, float* db, size_t ws_bytes, hipStream_
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
   const long total = (long)p0.B * G::NBAND;
+  if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;      // (the kernels walk chunks with 32-bit arithmetic)
   const long cap = (long)cus * per_cu;
   const int grid = (int)(total < cap ? total : cap);
   const size_t bytes = (size_t)grid * G::NPG * G::PER * 4;
@@ -1784,6 +1888,7 @@ int c3_launch(const C3P& p, hipStream_t st) {
     per_cu = n;
   }
   const long total = (long)p.B * G::NBAND;
+  if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;      // (the kernels walk chunks with 32-bit arithmetic)
   const long cap = (long)per_cu * cus;
   const int grid = (int)(total < cap ? total : cap);
   hipLaunchKernelGGL((c3_kernel<CS, CD, H, W, S, R, BWD, KCO, SG>), dim3(grid), dim3(NTHR), LDSB, st, p);
@@ -1867,6 +1972,7 @@ int c3_fwd(const a2c_conv_desc* d, const float* in, long in_bs, const float* fra
            long out_bs, unsigned* signs, long signs_bs, int B, hipStream_t st) {
   C3P p{in, in_bs, frag, bias, nullptr, out, out_bs, zero_page(), B, relu, g_c3_dbg, signs, nullptr, signs_bs};
   if (!p.zero) return A2C_ERR_LAUNCH;
+  p.prio = c3_prio();
   if (signs != nullptr && B > 64) {   // the direct-store kernels with the sign-word writer wave, where they have one (two chunks or more)
     if (d->stride == 1 && d->H == 84 && d->Cin == 16) return c3_launch<16, 24, 84, 84, 1, 12, false, 0, true>(p, st);
     if (d->stride == 2 && d->H == 84 && d->Cin == 24) return c3_launch<24, 32, 84, 84, 2, 6, false, 0, true>(p, st);
@@ -1913,6 +2019,7 @@ int c3_fwd_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long 
   if (!c3_fwd_frames_supported(d)) return A2C_ERR_ARG;
   C3P p{nullptr, 0, frag, bias, nullptr, out, out_bs, zero_page(), B, relu, g_c3_dbg, signs, nullptr, signs_bs, C3U8{f, bs, nv, nv_s, T}};
   if (!p.zero) return A2C_ERR_LAUNCH;
+  p.prio = c3_prio();
   if (signs != nullptr || B > 64) return c3s_launch<4, 16, 84, 84, 1, 12, false>(p, st);
   return c3_launch<4, 16, 84, 84, 1, 6, false>(p, st);
 }
@@ -1923,6 +2030,7 @@ int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, co
   C3P p{dout, (long)d->Cout * d->OH * d->OW, frag, nullptr, mask, din, (long)d->Cin * d->H * d->W, zero_page(), B, 0, g_c3_dbg,
         nullptr, signs, signs_bs};
   if (!p.zero) return A2C_ERR_LAUNCH;
+  p.prio = c3_prio();
   if (mask != nullptr) {
     if (d->stride == 1 && d->Cin == 16 && d->Cout == 24) return c3_launch<24, 16, 84, 84, 1, 12, true>(p, st);
     if (d->stride == 2 && d->H == 84 && d->Cin == 24) return c3b_launch<32, 24, 42, 42, 6, 8>(p, st);
@@ -1994,6 +2102,7 @@ int c3w_bwd_weight(const a2c_conv_desc* d, const float* in, long in_bs, const fl
   C3WP p{in, in_bs, dout, (float*)ws, zero_page(), B};
   static const int nodma = getenv("A2C_C3W_NODMA") != nullptr && getenv("A2C_C3W_NODMA")[0] == '1';
   p.nodma = nodma;
+  p.prio = c3_prio();
   if (!p.zero) return A2C_ERR_LAUNCH;
   return c3w_dispatch(d, p, dW, db, ws_bytes, st, nullptr);
 }
@@ -2003,9 +2112,6 @@ int c3w_bwd_weight_frames(const a2c_conv_desc* d, const unsigned char* f, long b
   if (!(c3w_supported(d) && d->Cin == 4)) return A2C_ERR_ARG;
   C3WP p{nullptr, 0, dout, (float*)ws, zero_page(), B, C3U8{f, bs, nv, 1, T}};
   if (!p.zero) return A2C_ERR_LAUNCH;
-  // the uint8 window is expanded synchronously by the loader waves: the tall-band / one-chunk-ahead instance is the faster
-  // one for it (3.14 vs 3.48 ms at N = 16384; same slab layout and workspace as the fp32 instance)
-  if (d->Cin == 4 && d->Cout == 16 && d->H == 84 && d->W == 84 && d->stride == 1)
-    return c3w_launch<4, 16, 84, 84, 1, 8, 4, 1, 2>(p, dW, db, ws_bytes, st, nullptr);
+  p.prio = c3_prio();
   return c3w_dispatch(d, p, dW, db, ws_bytes, st, nullptr);
 }

@@ -1530,7 +1530,9 @@ int c3s_launch(const C3P& p, hipStream_t st) {
 // its own slab once, at the end; a fixed-order reduction adds the slabs (deterministic).
 template <int CS, int CD, int H, int W, int S, int R, int KC, int NCG, int D = 2>
 struct C3WGeo {
-  static constexpr int NW = 8, NL = 2, NPG = NW / NCG;
+  // (rows that are not 16-byte multiples travel as dword pieces: ~270 DMA instructions per band and loader wave on the
+  // 42-wide 32 -> 64 layer; four loader waves share them)
+  static constexpr int NW = 8, NL = (W % 4 != 0) ? 4 : 2, NPG = NW / NCG, NTHR = 64 * (NW + NL);
   static constexpr int NCH = CS / KC;
   // D input-chunk images in a ring, the loaders LOOK = D - 1 chunks ahead of the computing waves (counted vmcnt, as in
   // c3bs_kernel): with the compute loop pipelined a band's MFMAs take 2-3 us, an LDS-DMA issued under load comes back after
@@ -1550,8 +1552,14 @@ struct C3WGeo {
   static constexpr int PL0 = SR * WP, PLANE = PL0;
   static constexpr int PP = PL0 / PB, NQ = (PP + 63) / 64;
   static constexpr int XB = ((KC * PLANE + 3) / 4) * 4 + 64;      // (+ slack: the last step of a row may read past it)
-  static constexpr int DPB = OW % 4 == 0 ? 4 : 1;                 // dOut pieces: whole 16-byte runs when rows are 16-byte multiples
-  static constexpr int DPL0 = R * OWP;
+  // dOut band image.  Rows that are 16-byte multiples: 16-byte pieces, row pitch OWP.  Odd-width rows whose BAND is a
+  // 16-byte multiple at a 16-byte aligned address (42-wide rows, 6 per band): the band of a channel is DMA'd FLAT (pitch
+  // OW, 16-byte pieces: 12 instructions per loader wave and band instead of 60 dword ones) and the computing waves zero
+  // the lanes of a row's last step that would read the next row's first pixels.  Otherwise dword pieces.
+  static constexpr bool DFLAT = OW % 4 != 0 && (R * OW) % 4 == 0 && (OH * OW) % 4 == 0 && OH % R == 0;
+  static constexpr int OWD = DFLAT ? OW : OWP;                    // row pitch of the dOut image
+  static constexpr int DPB = (OW % 4 == 0 || DFLAT) ? 4 : 1;
+  static constexpr int DPL0 = R * OWD;
   static constexpr int DPLANE = (DPL0 - 4 + 31) / 32 * 32 + 4;    // 4 (mod 32) floats apart: channels spread over the banks
   static constexpr int DPP = DPL0 / DPB, DNQ = (DPP + 63) / 64;
   static constexpr int DB = CD * DPLANE;
@@ -1595,7 +1603,7 @@ __global__ __launch_bounds__(256) void c3w_reduce_kernel(const float* __restrict
 }
 
 template <int CS, int CD, int H, int W, int S, int R, int KC, int NCG, int D>
-__global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
+__global__ __launch_bounds__((C3WGeo<CS, CD, H, W, S, R, KC, NCG, D>::NTHR)) void c3w_kernel(C3WP p) {
   using G = C3WGeo<CS, CD, H, W, S, R, KC, NCG, D>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1607,7 +1615,7 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
   float* __restrict__ xbuf = lds;                      // D x XB
   float* __restrict__ dbuf = lds + D * G::XB;          // DD x DB
   // whatever the DMAs never write (pad columns, slack behind the planes) must read as finite numbers: zeros
-  for (int i = tid; i < D * G::XB + G::DD * G::DB; i += 640) lds[i] = 0.f;
+  for (int i = tid; i < D * G::XB + G::DD * G::DB; i += G::NTHR) lds[i] = 0.f;
   __syncthreads();
   if (w >= G::NW) {
     // ------------------------------------------------------------------ loader waves
@@ -1625,9 +1633,9 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
 #pragma unroll
     for (int q = 0; q < G::DNQ; ++q) {
       const int pi = q * 64 + lane;
-      const int f = pi * G::DPB;                       // first float of the piece in the (row, OWP) band image
-      const int r = f / G::OWP, x = f - r * G::OWP;
-      drow[q] = (pi < G::DPP) ? (x < G::OW ? r : -100000) : -200000;      // pad column: zeros
+      const int f = pi * G::DPB;                       // first float of the piece in the (row, OWD) band image
+      const int r = f / G::OWD, x = f - r * G::OWD;
+      drow[q] = (pi < G::DPP) ? (x < G::OW ? (G::DFLAT ? 0 : r) : -100000) : -200000;      // pad column: zeros
       doff[q] = r * G::OW + x;
     }
     auto dma = [&](long k) {
@@ -1780,11 +1788,15 @@ __global__ __launch_bounds__(640) void c3w_kernel(C3WP p) {
       // loop was LDS latency + address arithmetic + 3-6 MFMAs per trip, the matrix pipe idle two thirds of the time.
       auto ld = [&](int st, float (&av)[G::NTC], float (&bv)[G::MTW]) {
         const int r = st / G::KSR, xq = st - r * G::KSR;            // (scalar)
-        const int xo = r * S * G::WP + xq * 4 * S, dofs = r * G::OWP + xq * 4;
+        const int xo = r * S * G::WP + xq * 4 * S, dofs = r * G::OWD + xq * 4;
 #pragma unroll
         for (int nt = 0; nt < G::NTC; ++nt) av[nt] = ximg[aoff[nt] + xo];
 #pragma unroll
         for (int m = 0; m < G::MTW; ++m) bv[m] = dimg[boff[m] + dofs];
+        if (G::DFLAT && xq == G::KSR - 1) {            // (uniform branch) flat image: pixels past the row's end are the next row's
+#pragma unroll
+          for (int m = 0; m < G::MTW; ++m) bv[m] = g < G::OW % 4 ? bv[m] : 0.f;
+        }
       };
       auto mm = [&](const float (&av)[G::NTC], const float (&bv)[G::MTW]) {
 #pragma unroll
@@ -1843,7 +1855,7 @@ int c3w_launch(const C3WP& p0, float* dW, float* db, size_t ws_bytes, hipStream_
     hipDeviceProp_t prop;
     // short bands (small LDS images): several workgroups per CU -- each has ONE band of lookahead, so the bands in flight
     // per CU (what hides the 2-3 us an LDS-DMA takes under load) scale with the residency
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 640, G::LDS_BYTES) == hipSuccess && n >= 1) per_cu = n > 3 ? 3 : n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, G::NTHR, G::LDS_BYTES) == hipSuccess && n >= 1) per_cu = n > 3 ? 3 : n;
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
   const long total = (long)p0.B * G::NBAND;
@@ -1853,7 +1865,7 @@ int c3w_launch(const C3WP& p0, float* dW, float* db, size_t ws_bytes, hipStream_
   const size_t bytes = (size_t)grid * G::NPG * G::PER * 4;
   if (need) { *need = (size_t)cap * G::NPG * G::PER * 4; return A2C_OK; }
   if (ws_bytes < bytes) return A2C_ERR_WORKSPACE;
-  hipLaunchKernelGGL((c3w_kernel<CS, CD, H, W, S, R, KC, NCG, D>), dim3(grid), dim3(640), G::LDS_BYTES, st, p0);
+  hipLaunchKernelGGL((c3w_kernel<CS, CD, H, W, S, R, KC, NCG, D>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES, st, p0);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   hipLaunchKernelGGL(c3w_reduce_kernel, dim3(a2c_grid_1d(G::PER, 256)), dim3(256), 0, st, (const float*)p0.slab, grid * G::NPG,
                      G::PER, (long)CD * G::K, dW, db);
@@ -2056,6 +2068,7 @@ int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, co
   X(32, 64, 42, 42, 2, 7, 8, 4, 3)  /* ConvModel conv4                                         */ \
   X(16, 24, 84, 84, 2, 6, 8, 1, 2)  /* GRUModel conv2 (R = 5, D = 3 measured 3 % slower: 42 = 8 x 5 + 2)  */ \
   X(24, 32, 42, 42, 2, 7, 8, 2, 2)  /* GRUModel conv3                                          */
+// (GRUModel conv4, 32 -> 48 @21 with the whole 11 x 11 output as one band: 4.5 ms against the generic kernel's 2.7)
 // round 3's instances (A2C_C3W_D2=1): taller bands, one chunk of lookahead
 #define C3W_OLD_CASES(X)             \
   X(4, 16, 84, 84, 1, 8, 4, 1, 2)    \
@@ -2065,12 +2078,14 @@ int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, co
 bool c3w_supported(const a2c_conv_desc* d) {
   static const bool off = (getenv("A2C_NO_C3") != nullptr && getenv("A2C_NO_C3")[0] == '1') ||
                           (getenv("A2C_NO_C3W") != nullptr && getenv("A2C_NO_C3W")[0] == '1');
-  static const bool all = getenv("A2C_C3W_ALL") != nullptr && getenv("A2C_C3W_ALL")[0] == '1';
+  static const bool all = !(getenv("A2C_C3W_ALL") != nullptr && getenv("A2C_C3W_ALL")[0] == '0');
   if (off || d->ks != 3 || d->pad != 1) return false;
   // Measured against conv.hip's wgrad_kernel at N = 4096 (tools/conv3_check.py): this kernel wins on the first layer
   // (4 -> 16: 0.92 vs 1.01 ms) and on ConvModel's conv4 (32 -> 64 @42: 1.29 vs 1.55 ms), ties on the 84-wide
   // 16 -> 24 layers (2.87-2.95 vs 3.00 ms, 1.15 vs 1.11 ms: matrix-bound in both, 67 TF with a quarter of the 24-channel
-  // tiles empty -- and the generic instance for them spilled registers), and loses on the 24 -> 32 layers, which stay.
+  // tiles empty -- and the generic instance for them spilled registers), and lost on the 24 -> 32 layers until the loader
+  // waves got their priority, the flat dOut bands and four waves for dword rows (round 4; N = 32,768: 11.2 vs 12.0 ms
+  // at 84, 3.30 vs 3.56 at 42).  A2C_C3W_ALL=0 keeps those two on the generic kernel.
   if (!all && d->Cin == 24) return false;
 #define C3W_MATCH(cs, cd, h, w_, s_, r, kc, ncg, dd) if (d->Cin == cs && d->Cout == cd && d->H == h && d->W == w_ && d->stride == s_) return true;
   C3W_CASES(C3W_MATCH)

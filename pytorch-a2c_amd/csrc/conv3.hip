@@ -211,7 +211,7 @@ struct C3P {
 // were the critical path of the weight-gradient kernels; A2C_C3_PRIO=0 = round 3's schedule, for A/B runs)
 static int c3_prio() { static const int v = getenv("A2C_C3_PRIO") ? atoi(getenv("A2C_C3_PRIO")) : 1; return v; }
 
-template <int CS, int CD, int H, int W, int S, int R, int KCO = 0>
+template <int CS, int CD, int H, int W, int S, int R, int KCO = 0, int NLO = 0>
 struct C3Geo {
   static constexpr int KC = KCO ? KCO : (CS >= 8 ? 8 : 4);      // source channels per chunk (c3_kc() tells c3_prep the same)
   static constexpr int NCH = CS / KC;
@@ -222,7 +222,7 @@ struct C3Geo {
   static constexpr int NPIX = R * OW;
   static constexpr int NT = (NPIX + 15) / 16;         // 16-pixel tiles per band
   static constexpr int NW = 8;                         // computing waves (two per SIMD); waves NW .. NW+NL-1 are the loaders
-  static constexpr int NL = 2;
+  static constexpr int NL = NLO ? NLO : (W % 4 != 0) ? 4 : 2;     // (dword pieces: four loader waves share the DMA instructions)
   static constexpr int TPW = (NT + NW - 1) / NW;      // tiles per computing wave
   static constexpr int SR = (R - 1) * S + 3;          // source rows per band (with halo)
   static constexpr int PB = W % 4 == 0 ? 4 : 1;       // floats per LDS-DMA piece: 16-byte pieces need 16-byte aligned rows
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void c3_prep_kernel(const float* __restrict__ 
 // wave carries the finished band's words to HBM under the next band's first chunk (needs NCH >= 2: a barrier between its
 // copy-and-clear and the next epilogue).  The computing waves and the stores are the direct-store kernel's.
 template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO = 0, bool SG = false>
-__global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
+__global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG ? 1 : 0)))) void c3_kernel(C3P p) {
   using G = C3Geo<CS, CD, H, W, S, R, KCO>;
   static_assert(!SG || (!BWD && G::NCH >= 2), "sign words: forward, two chunks or more");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(SG ? 704 : 640) void c3_kernel(C3P p) {
   }
   if (S == 1 && G::GAP > 0) {                     // (stride 1 reads one float past a plane's last row)
     constexpr int GP = G::GAP > 0 ? G::GAP : 1;
-    for (int i = tid; i < 2 * G::KC * GP; i += (SG ? 704 : 640)) {
+    for (int i = tid; i < 2 * G::KC * GP; i += 64 * (G::NW + G::NL + (SG ? 1 : 0))) {
       const int bsel = i / (G::KC * GP), r = i - bsel * (G::KC * GP);
       lds[bsel * G::BUF + (r / GP) * G::PLANE + G::PL0 + (r % GP)] = 0.f;
     }
@@ -798,8 +798,8 @@ int c3b_launch(const C3P& p, hipStream_t st) {
 // by the forward of the layer below -- by its storers, from the image they copy anyway: 1/32 of the mask's HBM reads,
 // and the LDS the float mask band took is what the output image lives in.
 template <int CS, int CD, int H, int W, int S, int R>
-struct C3SGeo : C3Geo<CS, CD, H, W, S, R> {
-  using G0 = C3Geo<CS, CD, H, W, S, R>;
+struct C3SGeo : C3Geo<CS, CD, H, W, S, R, 0, 2> {          // (two loaders + two storers + eight computing waves: three per SIMD)
+  using G0 = C3Geo<CS, CD, H, W, S, R, 0, 2>;
   static constexpr int NS = 2;                                     // storer waves
   static constexpr int MROWP = ((G0::MROW + 3) / 8) * 8 + 4;        // channel pitch of the image: 4 (mod 8) floats, so the 8
                                                                    // channels of a ds_write_b128 lane group hit 8 distinct slots
@@ -897,7 +897,7 @@ __device__ __forceinline__ void c3_drain_signs(const C3Drain d, int nwords, int 
 }
 
 template <int CS, int CD, int H, int W, int S, int R, bool BWD>
-__global__ __launch_bounds__(768) void c3s_kernel(C3P p) {
+__global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel(C3P p) {
   using G = C3SGeo<CS, CD, H, W, S, R>;
   static_assert(!BWD || G::OW % 4 == 0, "backward-data reads a lane's four mask bits from one word");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1514,7 +1514,7 @@ int c3s_launch(const C3P& p, hipStream_t st) {
   const long total = (long)p.B * G::NBAND;
   if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;      // (the kernels walk chunks with 32-bit arithmetic)
   const int grid = (int)(total < cus ? total : cus);
-  hipLaunchKernelGGL((c3s_kernel<CS, CD, H, W, S, R, BWD>), dim3(grid), dim3(768), G::LDS_BYTES_S, st, p);
+  hipLaunchKernelGGL((c3s_kernel<CS, CD, H, W, S, R, BWD>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES_S, st, p);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   return A2C_OK;
 }
@@ -1887,7 +1887,7 @@ int c3_launch(const C3P& p, hipStream_t st) {
   using G = C3Geo<CS, CD, H, W, S, R, KCO>;
   const void* k = (const void*)c3_kernel<CS, CD, H, W, S, R, BWD, KCO, SG>;
   constexpr size_t LDSB = BWD ? G::LDS_BYTES_BWD : (SG ? G::LDS_BYTES_SG : G::LDS_BYTES);
-  constexpr int NTHR = SG ? 704 : 640;
+  constexpr int NTHR = 64 * (G::NW + G::NL + (SG ? 1 : 0));
   static_assert(LDSB <= 160 * 1024, "LDS");
   static_assert(!BWD || G::NCH >= 2, "the mask band is staged one chunk ahead of its use");
   static int per_cu = 0, cus = 0;

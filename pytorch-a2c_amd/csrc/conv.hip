@@ -1716,7 +1716,7 @@ struct BwdBandP {
 
 __device__ __forceinline__ int fdiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
-template <int MT>
+template <int MT, int NTU>
 __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* __restrict__ outb = lds;                         // [Cin][TY*W]
@@ -1734,7 +1734,27 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
     __syncthreads();
     stage_tile(p.st, img, b, oy_lo);
     __syncthreads();
-    for (int c = 0; c < p.ncls; ++c) {
+    // work units = (class, pair of 16-pixel tiles), dealt to the four waves ACROSS the classes: with a loop per class a small
+    // image (11 x 11: 2 + 1 + 1 + 1 pairs) kept wave 0 busy four times in a row and the others idle
+    int np_c[MAX_CLS], units = 0;
+#pragma unroll
+    for (int c = 0; c < MAX_CLS; ++c) {
+      np_c[c] = 0;
+      if (c < p.ncls) {
+        const BandClass& k = p.cls[c];
+        int q_lo = (Y0 + p.P - k.ry + p.S - 1) / p.S;
+        if (q_lo < 0) q_lo = 0;
+        const int y_first = p.S * q_lo + k.ry - p.P;
+        const int rows_c = y_first < Y0 + rowsY ? (Y0 + rowsY - 1 - y_first) / p.S + 1 : 0;
+        np_c[c] = (rows_c * k.PWc + 16 * NTU - 1) / (16 * NTU);
+      }
+      units += np_c[c];
+    }
+    for (int un = __builtin_amdgcn_readfirstlane(w); un < units; un += 4) {      // (scalar: the class parameters are s_loads)
+      int c = 0, pr = un;
+#pragma unroll
+      for (int cc = 0; cc < MAX_CLS - 1; ++cc)
+        if (c == cc && pr >= np_c[cc]) { pr -= np_c[cc]; c = cc + 1; }
       const BandClass& k = p.cls[c];
       // class rows in this band: y = S*q + ry - P in [Y0, Y0 + rowsY)
       int q_lo = (Y0 + p.P - k.ry + p.S - 1) / p.S;
@@ -1742,22 +1762,28 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
       const int y_first = p.S * q_lo + k.ry - p.P;
       const int rows_c = y_first < Y0 + rowsY ? (Y0 + rowsY - 1 - y_first) / p.S + 1 : 0;
       const int NP = rows_c * k.PWc;
-      const int npairs = (NP + 31) >> 5;
-      for (int pr = w; pr < npairs; pr += 4) {
-        const int idx0 = pr * 32 + j, idx1 = idx0 + 16;
-        const bool ok0 = idx0 < NP, ok1 = idx1 < NP;
-        const int i0 = ok0 ? idx0 : 0, i1 = ok1 ? idx1 : 0;
-        const int r0 = i0 / k.PWc, c0 = i0 - r0 * k.PWc;
-        const int r1 = i1 / k.PWc, c1 = i1 - r1 * k.PWc;
-        // class pixel (q, pc) -> dOut position (q, pc) relative to the image origin (oy_lo, ox_lo)
-        const float* __restrict__ l0 = img + (q_lo + r0 - oy_lo) * WP + (k.p0 + c0 - p.ox_lo) + g * PLANE;
-        const float* __restrict__ l1 = img + (q_lo + r1 - oy_lo) * WP + (k.p0 + c1 - p.ox_lo) + g * PLANE;
-        f32x4 acc[MT][2];
+      {
+        // NTU 16-pixel tiles per unit share every A fragment (one global load per NTU MFMAs); tiles past the class's last
+        // pixel are skipped (wave-uniform)
+        const int ntl = min(NTU, (NP - pr * 16 * NTU + 15) >> 4);
+        bool ok[NTU];
+        int rT[NTU], cT[NTU];
+        const float* __restrict__ lT[NTU];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTU; ++t) {
+          const int idx = (pr * NTU + t) * 16 + j;
+          ok[t] = idx < NP;
+          const int i_ = ok[t] ? idx : 0;
+          rT[t] = i_ / k.PWc;
+          cT[t] = i_ - rT[t] * k.PWc;
+          // class pixel (q, pc) -> dOut position (q, pc) relative to the image origin (oy_lo, ox_lo)
+          lT[t] = img + (q_lo + rT[t] - oy_lo) * WP + (k.p0 + cT[t] - p.ox_lo) + g * PLANE;
         }
+        f32x4 acc[MT][NTU];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NTU; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* __restrict__ wf = p.wfrag + k.frag_off + lane;
         float a_cur[CH * MT], a_nxt[CH * MT];
 #pragma unroll
@@ -1768,12 +1794,12 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
 #pragma unroll
             for (int i = 0; i < CH * MT; ++i) a_nxt[i] = wf[((ck + 1) * CH * MT + i) * 64];
           }
-          float bv0[CH], bv1[CH];
+          float bv[NTU][CH];
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
             const int o = (ck * CH + u < k.nsteps) ? off : 0;     // padded steps (A = 0) read a valid word
-            bv0[u] = l0[o];
-            bv1[u] = l1[o];
+#pragma unroll
+            for (int t = 0; t < NTU; ++t) bv[t][u] = lT[t][o];
             ++ci;
             const bool w1 = (ci == p.c4n);
             ci = w1 ? 0 : ci;
@@ -1785,26 +1811,26 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
 #pragma unroll
           for (int u = 0; u < CH; ++u)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-              acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], bv0[u], acc[m][0], 0, 0, 0);
-              acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], bv1[u], acc[m][1], 0, 0, 0);
-            }
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int t = 0; t < NTU; ++t)
+                if (t < 2 || t < ntl)                             // (tiles 0 and 1 as before; uniform branch for the rest)
+                  acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u * MT + m], bv[t][u], acc[m][t], 0, 0, 0);
 #pragma unroll
           for (int i = 0; i < CH * MT; ++i) a_cur[i] = a_nxt[i];
         }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          if (!(nt ? ok1 : ok0)) continue;
-          const int r = nt ? r1 : r0, cc = nt ? c1 : c0;
-          const int yy = y_first + r * p.S - Y0;                  // row inside the band
-          const int xx = (k.p0 + cc) * p.S + k.rx - p.P;
+        for (int t = 0; t < NTU; ++t) {
+          if (!ok[t]) continue;
+          const int yy = y_first + rT[t] * p.S - Y0;              // row inside the band
+          const int xx = (k.p0 + cT[t]) * p.S + k.rx - p.P;
           const int pix = yy * p.W + xx;
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
               const int ch = m * 16 + 4 * g + rr;
-              if (ch < p.Cin) outb[ch * p.TY * p.W + pix] = acc[m][nt][rr];
+              if (ch < p.Cin) outb[ch * p.TY * p.W + pix] = acc[m][t][rr];
             }
         }
       }
@@ -3137,15 +3163,18 @@ static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const floa
   }
   const size_t lds = 4 * ((size_t)q.out_floats + (size_t)d->Cout * PLANEo + 64);
   if (lds <= LDS_HARD_MAX && MTb <= 4) {
-    const void* kf = MTb == 1 ? (const void*)bwd_band_kernel<1> : MTb == 2 ? (const void*)bwd_band_kernel<2>
-                     : MTb == 3 ? (const void*)bwd_band_kernel<3> : (const void*)bwd_band_kernel<4>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int grid = resident_grid(kf, lds, (long)B * q.bands);
+    // (NTU = 4, four tiles per A fragment, measured on GRUModel's 21 x 21 / 11 x 11 layers: 477 vs 475 us and 212 vs 162 us at
+    // N = 4096 -- the fragment loads are not what these launches wait for)
     hipStream_t st = a2c_s(stream);
-    if (MTb == 1) hipLaunchKernelGGL(bwd_band_kernel<1>, dim3(grid), dim3(256), lds, st, q);
-    else if (MTb == 2) hipLaunchKernelGGL(bwd_band_kernel<2>, dim3(grid), dim3(256), lds, st, q);
-    else if (MTb == 3) hipLaunchKernelGGL(bwd_band_kernel<3>, dim3(grid), dim3(256), lds, st, q);
-    else hipLaunchKernelGGL(bwd_band_kernel<4>, dim3(grid), dim3(256), lds, st, q);
+#define BAND_RUN(M_, N_)                                                                                          \
+    {                                                                                                             \
+      const void* kf = (const void*)bwd_band_kernel<M_, N_>;                                                      \
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+      const int grid = resident_grid(kf, lds, (long)B * q.bands);                                                 \
+      hipLaunchKernelGGL((bwd_band_kernel<M_, N_>), dim3(grid), dim3(256), lds, st, q);                           \
+    }
+    if (MTb == 1) BAND_RUN(1, 2) else if (MTb == 2) BAND_RUN(2, 2) else if (MTb == 3) BAND_RUN(3, 2) else BAND_RUN(4, 2)
+#undef BAND_RUN
     A2C_CHECK_LAUNCH();
     return A2C_OK;
   }

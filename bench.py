@@ -567,10 +567,10 @@ def main():
                     help="if --steps is smaller, an additional region of this many steps is timed and reported")
     ap.add_argument("--no-update-graph", action="store_true", help="do not capture the update into a hipGraph")
     ap.add_argument("--frame-store", action="store_true",
-                    help="conv-stack workloads: single-frame uint8 rollout store + lazy fp32 states (SURVEY.md 8 row f4); "
-                         "the a3c workload uses it by default (ring kernel, <= 256 envs)")
+                    help="force the single-frame uint8 rollout store + lazy fp32 states (SURVEY.md 8 row f4); it is the default "
+                         "with the host-pinned ingest (a3c: ring kernel, <= 256 envs; conv-stack nets: relay path)")
     ap.add_argument("--no-frame-store", action="store_true",
-                    help="a3c workload: write the fp32 `states` rows in the rollout (round 3's layout) instead of the single-frame store")
+                    help="write the fp32 `states` rows in the rollout (the reference's layout, round 3's) instead of the single-frame store")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--no-secondary", action="store_true", help="skip value_device_tape / process-worker runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -621,8 +621,8 @@ def main():
     # SURVEY.md 8 row f4 is the headline's storage layout: the ring kernel keeps ONE uint8 frame per env step, the update's
     # first-layer weight gradient stacks the frames on load, the reference-layout fp32 `states` rows are expanded on demand
     # (Runner.materialize_states; not needed by rollout -> update -> rollout).  --no-frame-store writes the rows.
-    fs_main = args.frame_store or (args.workload == "a3c" and args.ingest == "host-pinned" and not args.no_frame_store
-                                   and (n_envs or WORKLOADS["a3c"][1]) <= 256)
+    fs_main = args.frame_store or (args.ingest == "host-pinned" and not args.no_frame_store
+                                   and (args.workload != "a3c" or (n_envs or WORKLOADS["a3c"][1]) <= 256))
     b = Bench(args.workload, n_envs, args.optim, args.ingest, args.env_workers, n_workers, shard, dev,
               update_graph=not args.no_update_graph, transport=args.transport, frame_store=fs_main)
     model, T, A, N = b.model, b.T, b.A, b.N
@@ -869,23 +869,28 @@ def main():
                                          ("conv_2048x128_per_gpu_shard_256x128", "conv", 256, 10, 2)):
                 try:
                     torch.cuda.empty_cache()
+                    # (the single-frame store, row f4, is the layout of every config that keeps it: the ring kernel's for
+                    # A3CModel up to 256 envs, the relay path's for the conv-stack nets; --no-frame-store = fp32 rows)
+                    fs_cfg = (not args.no_frame_store) and (wl != "a3c" or (ne is not None and ne <= 256 and fs_main))
                     cfgs[key] = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu,
-                                           transport=args.transport, frame_store=(wl == "a3c" and ne is not None and ne <= 256 and fs_main))
+                                           transport=args.transport, frame_store=fs_cfg)
                 except Exception as e:      # noqa: BLE001
                     cfgs[key] = dict(error=f"{type(e).__name__}: {e}")
-            # row f4 measured: the same conv-stack configs on the single-frame uint8 store with lazy fp32 states
+            # row f4 measured: the same conv-stack configs writing the reference's fp32 `states` rows in the rollout
             for key, wl, ne, st_, wu in (("conv_32x64", "conv", None, 20, 3), ("gru_bptt_256x128", "gru_bptt", None, 10, 2)):
+                if args.no_frame_store:
+                    break
                 try:
                     torch.cuda.empty_cache()
                     r = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu,
-                                   transport=args.transport, frame_store=True)
-                    cfgs[key + "_frame_store"] = {k: r[k] for k in ("workload", "value", "ms_per_step", "rollout_ms", "update_ms",
-                                                                    "states_layout", "frame_store_live") if k in r}
+                                   transport=args.transport, frame_store=False)
+                    cfgs[key + "_states_rows"] = {k: r[k] for k in ("workload", "value", "ms_per_step", "rollout_ms", "update_ms",
+                                                                    "states_layout") if k in r}
                     c1 = (r.get("update_conv_sites") or {}).get("conv1.bwd_weight")
                     if c1:
-                        cfgs[key + "_frame_store"]["conv1.bwd_weight"] = c1
+                        cfgs[key + "_states_rows"]["conv1.bwd_weight"] = c1
                 except Exception as e:      # noqa: BLE001
-                    cfgs[key + "_frame_store"] = dict(error=f"{type(e).__name__}: {e}")
+                    cfgs[key + "_states_rows"] = dict(error=f"{type(e).__name__}: {e}")
             out["configs"] = cfgs
         if not args.no_cpu_baseline:
             try:

@@ -1,3 +1,16 @@
-python tools/conv3_check.py 6 7 2>&1 | grep "^L" > gpurun_out/c3_band4.txt
-A2C_BAND_NTU2=1 python tools/conv3_check.py 6 7 2>&1 | grep "^L" > gpurun_out/c3_band2.txt
-python -m pytest tests/test_gpu_kernels.py -q -x -k "conv" 2>&1 | tail -3
+C="--warmup 3 --sustain-steps 0 --no-configs --no-secondary --no-cpu-baseline"
+run() { python bench.py $* $C 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   ', d['value'], d.get('rollout_ms'), d.get('update_ms'))"; }
+for i in 1 2 3; do
+echo "gru rows"; run --workload gru_bptt --steps 10
+echo "gru frames"; run --workload gru_bptt --steps 10 --frame-store
+done
+for i in 1 2 3; do
+echo "conv32 rows"; run --workload conv --steps 20
+echo "conv32 frames"; run --workload conv --steps 20 --frame-store
+done
+for i in 1 2; do
+echo "shard rows"; run --workload conv --n-envs 256 --steps 5
+echo "shard frames"; run --workload conv --n-envs 256 --steps 5 --frame-store
+done

@@ -130,12 +130,16 @@ def test_first_layer_forward_stacked_on_load_equals_forward_from_states(B, signs
 
 
 @pytest.mark.parametrize("B", [5, 700])
-def test_first_layer_weight_gradient_stacked_on_load_equals_gradient_from_states(B, monkeypatch):
-    """same kernel instance for both sources (A2C_C3W_D2=1: the tall-band instance the uint8 path uses; the fp32 default is a
-    shorter-band / deeper-ring instance, i.e. another partition of the same sums): bit-identical; and the default fp32
-    instance agrees to fp32 re-association"""
+@pytest.mark.parametrize("old_instance", [False, True])
+def test_first_layer_weight_gradient_stacked_on_load_equals_gradient_from_states(B, old_instance, monkeypatch):
+    """both sources run the SAME kernel instance (the default: short bands, ring of three chunk images, the uint8 bytes of the
+    chunk after next in registers; A2C_C3W_D2=1: round 3's tall-band instance, one chunk of lookahead): bit-identical; and
+    the two instances -- two partitions of the same sums -- agree to fp32 re-association"""
     ops = _ops()
-    monkeypatch.setenv("A2C_C3W_D2", "1")
+    if old_instance:
+        monkeypatch.setenv("A2C_C3W_D2", "1")
+    else:
+        monkeypatch.delenv("A2C_C3W_D2", raising=False)
     d = ops.conv_desc(4, 84, 84, 16, 3, 1, 1)
     T, HW = 5, 84 * 84
     R = (B + T - 1) // T
@@ -148,10 +152,13 @@ def test_first_layer_weight_gradient_stacked_on_load_equals_gradient_from_states
     ops.conv_bwd_weight(d, xd.data_ptr(), 4 * HW, dout, dW0, db0, B, ws)
     ops.conv_bwd_weight_frames(d, Fd, Fd.stride(0), T, nvd, dout, dW1, db1, B, ws)
     assert torch.equal(dW1, dW0) and torch.equal(db1, db0)
-    monkeypatch.delenv("A2C_C3W_D2")
+    if old_instance:
+        monkeypatch.delenv("A2C_C3W_D2")
+    else:
+        monkeypatch.setenv("A2C_C3W_D2", "1")
     dW2, db2 = torch.empty_like(dW0), torch.empty_like(db0)
     ops.conv_bwd_weight(d, xd.data_ptr(), 4 * HW, dout, dW2, db2, B, ws)
-    close("default fp32 instance", dW2, dW0, 2e-6 * float(dW0.abs().max()), 1e-5)
+    close("the other fp32 instance", dW2, dW0, 2e-6 * float(dW0.abs().max()), 1e-5)
     if B == 5:
         x = torch.from_numpy(st[:B]).reshape(B, 4, 84, 84).double().requires_grad_(False)
         wt = torch.zeros(16, 4, 3, 3, dtype=torch.float64, requires_grad=True)
@@ -201,7 +208,6 @@ def test_frame_store_rollouts_and_updates_equal_the_plain_path_bit_for_bit(kind,
     reads the store; hyps['lazy_states']: the fp32 `states` rows are not written at all until somebody asks.  Same
     kernels, same values, same summation order => rollout buffers, infos and weights identical to the plain path, over
     three rounds with updates in between (resets inside and across slots); and the plain path is the one the oracle tests pin."""
-    monkeypatch.setenv("A2C_C3W_D2", "1")      # one instance of the first layer's weight-gradient kernel for both sources
     B, T, A, ss, h = 5, 6, 3, (4, 84, 84), 256
     ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
     base = dict(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3, optim_type="RMSprop",

@@ -621,8 +621,7 @@ def main():
     # SURVEY.md 8 row f4 is the headline's storage layout: the ring kernel keeps ONE uint8 frame per env step, the update's
     # first-layer weight gradient stacks the frames on load, the reference-layout fp32 `states` rows are expanded on demand
     # (Runner.materialize_states; not needed by rollout -> update -> rollout).  --no-frame-store writes the rows.
-    fs_main = args.frame_store or (args.ingest == "host-pinned" and not args.no_frame_store
-                                   and (args.workload != "a3c" or (n_envs or WORKLOADS["a3c"][1]) <= 256))
+    fs_main = args.frame_store or (args.ingest == "host-pinned" and not args.no_frame_store)
     b = Bench(args.workload, n_envs, args.optim, args.ingest, args.env_workers, n_workers, shard, dev,
               update_graph=not args.no_update_graph, transport=args.transport, frame_store=fs_main)
     model, T, A, N = b.model, b.T, b.A, b.N
@@ -716,18 +715,20 @@ def main():
         dom_ms = summ[dom]["total_ms"] / 2 if dom is not None else 0.0
         fused_step = getattr(b.net, "_step_supported", lambda: False)()
         if fused_step and rollout_ms > dom_ms:
-            launches = 1 if zero_copy else T + 1
+            cus_ = torch.cuda.get_device_properties(dev).multi_processor_count
+            ring = zero_copy and os.environ.get("A2C_NO_RING") != "1" and \
+                (b.n_envs <= cus_ or os.environ.get("A2C_RING_BLOCKS") != "0")
+            # (more envs than CUs: ceil(n_envs / CUs) ring launches one after the other, each a block of interleaved envs)
+            launches = ((b.n_envs + cus_ - 1) // cus_ if ring else 1) if zero_copy else T + 1
             us = rollout_ms * 1e3 / launches
             fl = step_alg_flops(A) * b.n_envs * (T + 1) / launches
-            ring = zero_copy and b.n_envs <= torch.cuda.get_device_properties(dev).multi_processor_count and \
-                os.environ.get("A2C_NO_RING") != "1"
             lazy_ring = bool(ring and fs_main and getattr(b.runner, "_states_stale", False))
             by = (step_alg_bytes(u8_frame=args.ingest != "device-tape", ring=ring, lazy=lazy_ring) -
                   (0 if ring else (84 * 84 - FRAME_BYTES[args.transport] if args.ingest != "device-tape" else 0))) \
                 * b.n_envs * (T + 1) / launches
             tf = fl / (us * 1e-6) / 1e12
             name = ("%s = a2c_a3c_rollout (1 launch = %d steps x %d envs, paced by the host env workers' turn-around)"
-                    % ("a3c_ring_kernel" if ring else "a3c_step_kernel<persistent>", T + 1, b.n_envs)) if zero_copy else \
+                    % ("a3c_ring_kernel" if ring else "a3c_step_kernel<persistent>", T + 1, b.n_envs // launches)) if zero_copy else \
                    f"a3c_step_kernel (B={b.n_envs}, {T + 1} launches/rollout)"
             out["roofline"] = dict(kernel=name, bound="mfma", achieved=round(tf, 2), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
                                    frac=round(tf / F32_PEAK_TFLOPS, 4), traffic=None, avg_launch_us=round(us, 2),
@@ -871,7 +872,7 @@ def main():
                     torch.cuda.empty_cache()
                     # (the single-frame store, row f4, is the layout of every config that keeps it: the ring kernel's for
                     # A3CModel up to 256 envs, the relay path's for the conv-stack nets; --no-frame-store = fp32 rows)
-                    fs_cfg = (not args.no_frame_store) and (wl != "a3c" or (ne is not None and ne <= 256 and fs_main))
+                    fs_cfg = (not args.no_frame_store) and (wl != "a3c" or fs_main)
                     cfgs[key] = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu,
                                            transport=args.transport, frame_store=fs_cfg)
                 except Exception as e:      # noqa: BLE001

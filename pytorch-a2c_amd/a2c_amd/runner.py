@@ -867,8 +867,9 @@ class Runner:
         # first-layer weight gradient stacks the frames on load instead of reading the 4x duplicated fp32 states
         fs = self._frame_store(T, D["states"].shape[0] // T, dev)
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        lazy = (fs is not None and bool(try_key(hyps, "lazy_states", False)) and B <= cus
-                and os.environ.get("A2C_NO_RING") != "1")          # only the ring kernel can leave the fp32 rows out
+        # only the ring kernel can leave the fp32 rows out (more envs than CUs: interleaved blocks of it, one after the other)
+        lazy = (fs is not None and bool(try_key(hyps, "lazy_states", False)) and os.environ.get("A2C_NO_RING") != "1"
+                and (B <= cus or os.environ.get("A2C_RING_BLOCKS") != "0"))
         if lazy:
             self._states_stale = True
             net._materialize_states = self.materialize_states

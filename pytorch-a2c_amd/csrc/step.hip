@@ -66,6 +66,7 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   unsigned long long* dbg;                         // phase stamps of workgroup 0 (a2c_debug_ring_timing), or nullptr
   int poll_gap;                                    // 64-cycle sleeps between two polls of the rec granule
   int early_poll;                                  // ring kernel: first poll behind plane 0 (A2C_RING_EARLY=0: behind plane 1 only)
+  int bstride, boff;                               // ring kernel: workgroup i plays env b = i * bstride + boff (blocks of a larger launch)
 };
 
 struct StepP {
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // the state: a ring of FIVE uint8 plane slots.  State t owns slots base .. base+3 (mod 5); the fifth receives the
   // frame of state t+1 while state t's row is still being written out
   unsigned char* __restrict__ ring = reinterpret_cast<unsigned char*>(red + HN + 32 + 8);
-  const int b = blockIdx.x;
+  const int b = (int)blockIdx.x * p.x.bstride + p.x.boff;      // (B > CU count: block boff of bstride interleaved blocks)
   const long S = 4L * HW, row = (a.slot0 + b) * a.T;
   const int T = (int)a.T;
 
@@ -1359,12 +1360,25 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   // every env has a CU to itself: the state stays in LDS for the whole slot (a3c_ring_kernel)
   const int hnt = a.n_actions + 1 <= 4 ? 4 : 8;
   static const bool no_ring = getenv("A2C_NO_RING") != nullptr && getenv("A2C_NO_RING")[0] == '1';
-  if (!no_ring && r->conv1_weight && a.B <= cus && ring_lds(p, hnt) <= 160 * 1024 && (p.OH1 * p.OW1 + 15) / 16 <= 32 &&
+  // More envs than CUs: ceil(B / CUs) launches one after the other, launch k playing the envs b = k (mod nblk) -- every env
+  // worker thread owns a contiguous range of envs, so an interleaved block keeps ALL of them busy.  (The one-launch
+  // alternative below takes the envs of a CU in turns and re-reads / re-writes the fp32 state row every step: 23.8 us per
+  // env step at 2048 envs against the ring's 16-17.)  A2C_RING_BLOCKS=0: ring kernel only when B <= CUs.
+  const char* rb_ = getenv("A2C_RING_BLOCKS");                 // (read per call: tests switch it)
+  const bool ring_blocks = !(rb_ != nullptr && rb_[0] == '0');
+  p.x.bstride = 1; p.x.boff = 0;
+  if (!no_ring && r->conv1_weight && (a.B <= cus || ring_blocks) && ring_lds(p, hnt) <= 160 * 1024 && (p.OH1 * p.OW1 + 15) / 16 <= 32 &&
       ((uintptr_t)r->conv1_weight % 4) == 0) {
     const size_t rl = ring_lds(p, hnt);
-    if (hnt == 4) hipLaunchKernelGGL((a3c_ring_kernel<4>), dim3(a.B), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
-    else hipLaunchKernelGGL((a3c_ring_kernel<8>), dim3(a.B), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
-    A2C_CHECK_LAUNCH();
+    const int nblk = (a.B + cus - 1) / cus;
+    p.x.bstride = nblk;
+    for (int k = 0; k < nblk; ++k) {
+      p.x.boff = k;
+      const int cnt = (a.B - k + nblk - 1) / nblk;
+      if (hnt == 4) hipLaunchKernelGGL((a3c_ring_kernel<4>), dim3(cnt), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
+      else hipLaunchKernelGGL((a3c_ring_kernel<8>), dim3(cnt), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
+      A2C_CHECK_LAUNCH();
+    }
     return A2C_OK;
   }
   if (p.x.states_lazy) return A2C_ERR_ARG;      // only the ring kernel can leave the fp32 rows out

@@ -267,20 +267,21 @@ def test_device_preprocessing_equals_host_preprocessing(prep, kind):
     assert float(st.max()) == (1.0 if prep == "pong_prep" else 255.0) or float(st.max()) > 1.0
 
 
-@pytest.mark.parametrize("no_ring", [False, True])
-def test_a3c_persistent_rollout_on_the_frame_store_with_lazy_states(no_ring, monkeypatch):
+@pytest.mark.parametrize("no_ring,B,T", [(False, 7, 9), (True, 7, 9), (False, 300, 5)])
+def test_a3c_persistent_rollout_on_the_frame_store_with_lazy_states(no_ring, B, T, monkeypatch):
     """hyps['frame_store'] + hyps['lazy_states'] on the headline path (zero-copy ring kernel, packed frames): the kernel
     writes ONE uint8 frame per env step (7 KB) instead of the 113 KB fp32 state row, update_model's first-layer weight
     gradient stacks the frames on load, `states` is expanded on demand.  Against the plain run: identical rollout buffers
     (after materialize_states), infos and weights to fp32 re-association of one kernel.  With A2C_NO_RING=1 (the per-step
-    persistent body, which cannot skip the rows) lazy_states is ignored and the rows are there."""
+    persistent body, which cannot skip the rows) lazy_states is ignored and the rows are there.  300 envs: more envs than
+    CUs, two interleaved blocks of the ring kernel one after the other."""
     from a2c_amd.hostpool import ThreadEnvPool
     from a2c_amd.runner import Runner
     from a2c_amd.synthetic import TapeEnv
     from a2c_amd.updater import Updater
     if no_ring:
         monkeypatch.setenv("A2C_NO_RING", "1")
-    B, T, A, ss = 7, 9, 3, (4, 84, 84)
+    A, ss = 3, (4, 84, 84)
     us = torch.from_numpy(hashf(3 * T * B, 99, 0, 1).reshape(3, T, B)).to(DEV)
     res = {}
     for mode in ("plain", "lazy"):
@@ -289,7 +290,7 @@ def test_a3c_persistent_rollout_on_the_frame_store_with_lazy_states(no_ring, mon
         net = make_net("A3CModel", ss, A, 256)
         D = _datas(B * T, ss, False, actions_on_host=False)
         envs = [TapeEnv(env_id=j, length=3 * T + 1, p_done=1.0 / 6) for j in range(B)]
-        pool = ThreadEnvPool.from_tape_envs(envs, n_threads=2, pong=True, frame_bits=True)
+        pool = ThreadEnvPool.from_tape_envs(envs, n_threads=2 if B < 64 else 6, pong=True, frame_bits=True)
         rnd = [0]
         r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy",
                    uniform_fn=lambda t, Bn, env0: us[rnd[0], t, env0:env0 + Bn].contiguous())
@@ -319,5 +320,16 @@ def test_a3c_persistent_rollout_on_the_frame_store_with_lazy_states(no_ring, mon
                 assert torch.equal(res["plain"][k][0][n], res["lazy"][k][0][n]), (k, n)
         for name in res["plain"][k][1]:
             assert res["plain"][k][1][name] == pytest.approx(res["lazy"][k][1][name], rel=1e-5, abs=1e-7), (k, name)
-        for a, b in zip(res["plain"][k][2], res["lazy"][k][2]):
-            close("weights", b, a, 2e-6, 1e-5)
+        if B < 64:
+            for a, b in zip(res["plain"][k][2], res["lazy"][k][2]):
+                close("weights", b, a, 2e-6, 1e-5)
+        elif k == 0:
+            # N = 1500 samples: RMSprop divides by sqrt(mean-square), so where a gradient element is at rounding-noise level the
+            # step is up to lr / sqrt(1 - alpha) = 1e-3 whatever its size and the re-association of the first layer's weight
+            # gradient decides it -- the first update must differ in that layer ONLY; later rounds start from nets that differ
+            # there and are compared through their infos above
+            for i, (a, b) in enumerate(zip(res["plain"][k][2], res["lazy"][k][2])):
+                if i < 2:
+                    close("conv1 weights", b, a, 1e-4, 1e-5)
+                else:
+                    assert torch.equal(a, b), i

@@ -157,10 +157,14 @@ def test_rollout_update_rollout_matches_oracle(kind, ingest, bptt):
         r.close()
 
 
-def test_zero_copy_more_envs_than_cus_and_sampled_oracle():
-    """300 envs on 256 CUs: workgroups play several envs in turn (a2c_a3c_rollout); every env's data against
-    the layered per-step path, sampled envs against the oracle"""
+@pytest.mark.parametrize("ring_blocks", [True, False])
+def test_zero_copy_more_envs_than_cus_and_sampled_oracle(ring_blocks, monkeypatch):
+    """300 envs on 256 CUs (a2c_a3c_rollout): two interleaved blocks of the ring kernel one after the other (default), or
+    -- A2C_RING_BLOCKS=0 -- ONE launch of the per-step body whose workgroups play several envs in turn; every env's data
+    against the layered per-step path (the ring kernel sums conv1 plane-major: its values, hence its deltas, agree to fp32
+    re-association, everything else bit for bit), sampled envs against the oracle"""
     from a2c_amd.runner import Runner
+    monkeypatch.setenv("A2C_RING_BLOCKS", "1" if ring_blocks else "0")
     B, T, A, ss = 300, 4, 3, (4, 84, 84)
     ekws = [dict(env_id=j, rew_period=2 + j % 3, done_period=3 + j % 7) for j in range(B)]
     hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
@@ -180,7 +184,10 @@ def test_zero_copy_more_envs_than_cus_and_sampled_oracle():
             r.close()
         out[ingest] = {k: v.cpu() for k, v in D.items()}
     for k in ("states", "actions", "dones", "rewards", "deltas"):
-        assert torch.equal(out["zero-copy"][k], out["memcpy"][k]), k
+        if k in ("deltas", "rewards") and ring_blocks:      # (rewards: the bootstrap adds gamma * V to a slot's last one)
+            close(k + " (ring)", out["zero-copy"][k], out["memcpy"][k], 2e-6, 1e-5)
+        else:
+            assert torch.equal(out["zero-copy"][k], out["memcpy"][k]), k
         assert torch.equal(out["relay"][k], out["memcpy"][k]), k      # the device relay hands over the same bytes
     onet = O.OracleNet("A3CModel", ss, A, 256)
     for j in (0, 137, 255, 256, 299):

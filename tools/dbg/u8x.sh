@@ -1,16 +1,12 @@
-C="--warmup 3 --sustain-steps 0 --no-configs --no-secondary --no-cpu-baseline"
+C="--warmup 2 --sustain-steps 0 --no-configs --no-secondary --no-cpu-baseline"
 run() { python bench.py $* $C 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   ', d['value'], d.get('rollout_ms'), d.get('update_ms'))"; }
-for i in 1 2 3; do
-echo "gru rows"; run --workload gru_bptt --steps 10
-echo "gru frames"; run --workload gru_bptt --steps 10 --frame-store
-done
-for i in 1 2 3; do
-echo "conv32 rows"; run --workload conv --steps 20
-echo "conv32 frames"; run --workload conv --steps 20 --frame-store
-done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   ', d['value'], d.get('rollout_ms'), d.get('update_ms'), d.get('roofline',{}).get('kernel','')[:40], d.get('roofline',{}).get('frac'))"; }
 for i in 1 2; do
-echo "shard rows"; run --workload conv --n-envs 256 --steps 5
-echo "shard frames"; run --workload conv --n-envs 256 --steps 5 --frame-store
+echo "2048 body (RING_BLOCKS=0)"; A2C_RING_BLOCKS=0 run --n-envs 2048 --steps 10
+echo "2048 ring blocks, rows"; run --n-envs 2048 --steps 10 --no-frame-store
+echo "2048 ring blocks, frames lazy"; run --n-envs 2048 --steps 10
 done
+echo "512 body"; A2C_RING_BLOCKS=0 run --n-envs 512 --steps 30
+echo "512 ring blocks"; run --n-envs 512 --steps 30
+python -m pytest tests/test_gpu_rounds.py tests/test_gpu_ingest.py -q -x 2>&1 | tail -3

@@ -290,14 +290,18 @@ typedef struct {
   uint8_t *frame_store; int64_t frame_store_slot_stride;
   int32_t *nvalid_rows, *nvalid_carry;
   int frame_bits;                  /* 1: `frames` holds the packed transport (one bit per pixel, frame_stride >= H*W/8) */
-  /* optional: the first conv layer's weight tensor (16, 4, 8, 8) as the model stores it.  When given, B <= the CU count
+  /* optional: the first conv layer's weight tensor (16, 4, 8, 8) as the model stores it.  When given,
    * every env gets a workgroup that keeps its state in LDS for the whole slot (the "ring" kernel) and
    * overlaps the env worker's turn-around with the part of the next forward that does not depend on the new frame
-   * (conv1's sum is then ordered plane-major: results equal a2c_a3c_step's up to fp32 re-association).          */
+   * (conv1's sum is then ordered plane-major: results equal a2c_a3c_step's up to fp32 re-association).  More envs than
+   * CUs: ceil(B / CUs) such launches one after the other, launch k playing the envs b = k (mod that count); with
+   * A2C_RING_BLOCKS=0 in the environment ONE launch of the per-step body instead, whose workgroups take several envs in
+   * turns (results identical to a2c_a3c_step).                                                                   */
   const float *conv1_weight;
   /* with frame_store, ring kernel only: 1 = do NOT write the fp32 `states` rows (a2c_frames_to_states expands them from
    * the store on demand; the update reads the store: a2c_conv2d_bwd_weight_frames); the bookmark is always written.
-   * A2C_ERR_ARG when the launch cannot run as the ring kernel (B > CU count).                                      */
+   * A2C_ERR_ARG when the launch cannot run as the ring kernel (no conv1_weight, A2C_NO_RING=1, or B > CU count with
+   * A2C_RING_BLOCKS=0).                                                                                            */
   int states_lazy;
   /* optional, ring kernel with frame_bits: the pool's SELF-VALIDATING mirror of the packed frames (a2c_hostpool.h:
    * tagged_chunks chunks of 16 bytes per env, tagged_stride bytes apart, every chunk carries the step number's low 16

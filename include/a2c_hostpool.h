@@ -143,6 +143,12 @@ typedef struct a2c_pool_threads a2c_pool_threads;
 /* starts the threads; they publish frame 0 of every env before the call returns.  NULL on error.  */
 a2c_pool_threads *a2c_pool_threads_start(void *base, int n_threads, const a2c_env_vtable *vt,
                                          void *const *envs, int action_shift, int pong);
+/* the same, and every answer is ALSO written to a second place the caller names (a2c_push_buffer_alloc: device memory
+ * mapped into this process): frame j at push_frames + j * frame_stride (the pool's stride), then -- behind an sfence,
+ * the mapping is write-combining -- its rec granule at push_rec[j], and another sfence.  NULL pointers = no mirror. */
+a2c_pool_threads *a2c_pool_threads_start_push(void *base, int n_threads, const a2c_env_vtable *vt,
+                                              void *const *envs, int action_shift, int pong,
+                                              void *push_rec, void *push_frames);
 /* sets the phase to SHUTDOWN, joins the threads, frees the handle                                */
 void a2c_pool_threads_stop(a2c_pool_threads *h);
 

@@ -322,6 +322,13 @@ int a2c_rollout_buffer_destroy(const char *shm_name, void *host, size_t bytes);
 /* pin + map an existing host range (page aligned) / undo it                                  */
 int a2c_pinned_register(void *host, size_t bytes, void **dev_out);
 int a2c_pinned_unregister(void *host);
+/* Push buffer: fine-grained DEVICE memory that the host writes into directly (large-BAR: *ptr_out is valid on both
+ * sides; zero-filled).  The native env worker threads of a pool started with a2c_pool_threads_start_push mirror every
+ * answer there (packed / uint8 frame, sfence, rec granule, sfence), and a2c_a3c_rollout / a2c_pool_ingest* given the
+ * push addresses poll and fetch from HBM instead of reading host memory over PCIe (training.py:93-101's shared tensors,
+ * for the host -> device direction).  A2C_ERR_LAUNCH when the platform refuses the allocation.                  */
+int a2c_push_buffer_alloc(size_t bytes, void **ptr_out);
+int a2c_push_buffer_free(void *ptr);
 /* host threads waiting in hipStreamSynchronize sleep instead of spinning (hipDeviceScheduleBlockingSync): for
  * nodes where the ranks of a multi-GPU job have fewer CPUs than busy threads.  Call before any other HIP work. */
 int a2c_set_blocking_sync(int on);

@@ -108,6 +108,8 @@ SIGNATURES = {
     "a2c_rollout_buffer_destroy": (c_int, [c_char_p, P, c_size_t]),
     "a2c_pinned_register": (c_int, [P, c_size_t, POINTER(c_void_p)]),
     "a2c_pinned_unregister": (c_int, [P]),
+    "a2c_push_buffer_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
+    "a2c_push_buffer_free": (c_int, [P]),
     "a2c_memcpy_async": (c_int, [P, P, c_size_t, c_int, P]),
     "a2c_device_pci_bus_id": (c_int, [c_char_p, c_int]),
     "a2c_set_blocking_sync": (c_int, [c_int]),

@@ -347,6 +347,20 @@ def pinned_unregister(host_addr):
     check(lib().a2c_pinned_unregister(host_addr), "a2c_pinned_unregister")
 
 
+def push_buffer_alloc(nbytes):
+    """fine-grained DEVICE memory the host writes into directly (large BAR): the address, valid on both sides, or 0 when
+    the platform refuses it (the caller then keeps the pinned host region as the only copy)"""
+    ptr = ctypes.c_void_p(0)
+    if lib().a2c_push_buffer_alloc(nbytes, ctypes.byref(ptr)) != 0:
+        return 0
+    return int(ptr.value or 0)
+
+
+def push_buffer_free(ptr):
+    if ptr:
+        lib().a2c_push_buffer_free(ptr)
+
+
 def device_numa_cpus():
     """CPUs of the NUMA node the current HIP device hangs off, or None when that cannot be read"""
     buf = ctypes.create_string_buffer(64)

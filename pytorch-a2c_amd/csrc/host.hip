@@ -59,6 +59,30 @@ int a2c_rollout_buffer_create(const char* shm_name, size_t bytes, void** host_ou
   return A2C_OK;
 }
 
+// Device memory the HOST writes into (large-BAR systems: the pointer is valid on both sides): fine-grained, so the
+// device's loads are not served from a stale L2 line.  The env worker threads push their answers (packed frame, then the
+// rec granule, each behind an sfence) straight into HBM; the rollout kernels then poll and fetch LOCALLY instead of
+// reading host memory over PCIe (two dependent round trips per env step).  include/a2c_mi355x.h
+int a2c_push_buffer_alloc(size_t bytes, void** ptr_out) {
+  if (!bytes || !ptr_out) return A2C_ERR_ARG;
+  void* d = nullptr;
+  if (hipExtMallocWithFlags(&d, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    return A2C_ERR_LAUNCH;
+  }
+  if (hipMemset(d, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(d);
+    return A2C_ERR_LAUNCH;
+  }
+  *ptr_out = d;
+  return A2C_OK;
+}
+int a2c_push_buffer_free(void* ptr) {
+  if (!ptr) return A2C_ERR_ARG;
+  return hipFree(ptr) == hipSuccess ? A2C_OK : A2C_ERR_LAUNCH;
+}
+
 int a2c_rollout_buffer_destroy(const char* shm_name, void* host, size_t bytes) {
   if (!host || !bytes) return A2C_ERR_ARG;
   int rc = a2c_pinned_unregister(host);

@@ -299,6 +299,8 @@ typedef struct {
   const a2c_env_vtable *vt;
   void *const *envs;
   int env0, n, shift, pong;
+  uint64_t *push_rec;       /* optional mirror in device memory (a2c_pool_threads_start_push) */
+  uint8_t *push_frames;
 } worker_arg;
 
 struct a2c_pool_threads {
@@ -311,6 +313,31 @@ static void publish_inplace(void *base, int env, uint32_t seq, float rew, int do
   uint32_t rb;
   memcpy(&rb, &rew, 4);
   __atomic_store_n(rec_of(base) + env, ((uint64_t)((seq << 1) | (done ? 1u : 0u)) << 32) | rb, __ATOMIC_RELEASE);
+}
+
+static inline void wc_fence(void) {
+#ifdef A2C_HAVE_SSE2
+  _mm_sfence();               /* drains this core's write-combining buffers: the stores before it are on their way */
+#else
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+/* the mirror in device memory: the frame (whole 16-byte pieces: the slots are 16-byte multiples), fence, the granule, fence */
+static void push_answer(const worker_arg *w, const a2c_pool_header *h, int env, const void *frame, uint32_t seq, float rew,
+                        int done) {
+  if (!w->push_rec) return;
+  uint8_t *dst = w->push_frames + (size_t)env * h->frame_stride;
+  const size_t nb = ((size_t)h->frame_bytes + 15u) & ~(size_t)15u;
+#ifdef A2C_HAVE_SSE2
+  for (size_t q = 0; q < nb; q += 16) _mm_stream_si128((__m128i *)(dst + q), _mm_loadu_si128((const __m128i *)((const uint8_t *)frame + q)));
+#else
+  memcpy(dst, frame, nb);
+#endif
+  wc_fence();
+  uint32_t rb;
+  memcpy(&rb, &rew, 4);
+  __atomic_store_n(w->push_rec + env, ((uint64_t)((seq << 1) | (done ? 1u : 0u)) << 32) | rb, __ATOMIC_RELEASE);
+  wc_fence();
 }
 
 static void *worker_main(void *p) {
@@ -333,6 +360,7 @@ static void *worker_main(void *p) {
     if (bits && pack_bits(obs0, (uint8_t *)slot0, h->frame_elems) > 1u) bad = 1;
     if (bits) write_tagged(w->base, w->env0 + i, (const uint8_t *)slot0, h->seq_start, 0.f, 1);
     next_seq[i] = h->seq_start;
+    push_answer(w, h, w->env0 + i, slot0, h->seq_start, 0.f, 1);
     publish_inplace(w->base, w->env0 + i, h->seq_start, 0.f, 1);
   }
   if (bad) a2c_pool_worker_failed(w->base, w->env0);
@@ -362,6 +390,7 @@ static void *worker_main(void *p) {
     }
     next_seq[i] += 1;
     if (bits) write_tagged(w->base, j, (const uint8_t *)pinned, next_seq[i], rew, reset);
+    push_answer(w, h, j, pinned, next_seq[i], rew, reset);        /* the device's copy first: it is the one a kernel waits for */
     publish_inplace(w->base, j, next_seq[i], rew, reset);
   }
   free(next_seq);
@@ -372,7 +401,14 @@ static void *worker_main(void *p) {
 
 a2c_pool_threads *a2c_pool_threads_start(void *base, int n_threads, const a2c_env_vtable *vt, void *const *envs,
                                          int action_shift, int pong) {
+  return a2c_pool_threads_start_push(base, n_threads, vt, envs, action_shift, pong, NULL, NULL);
+}
+
+a2c_pool_threads *a2c_pool_threads_start_push(void *base, int n_threads, const a2c_env_vtable *vt, void *const *envs,
+                                              int action_shift, int pong, void *push_rec, void *push_frames) {
   if (a2c_pool_check(base) || n_threads < 1 || !vt || !vt->reset || !vt->step || !envs) return NULL;
+  if ((push_rec == NULL) != (push_frames == NULL) || ((uintptr_t)push_rec % 8) || ((uintptr_t)push_frames % 16)) return NULL;
+  if (push_rec && (hdr(base)->frame_dtype == A2C_FRAME_F32 || hdr(base)->frame_stride % 16)) return NULL;
   a2c_pool_header *h = hdr(base);
   const int n_envs = (int)h->n_envs;
   if (n_threads > n_envs) n_threads = n_envs;
@@ -386,6 +422,7 @@ a2c_pool_threads *a2c_pool_threads_start(void *base, int n_threads, const a2c_en
     a->base = base; a->vt = vt; a->envs = envs; a->env0 = w * per;
     a->n = per < n_envs - w * per ? per : n_envs - w * per;
     a->shift = action_shift; a->pong = pong;
+    a->push_rec = (uint64_t *)push_rec; a->push_frames = (uint8_t *)push_frames;
     if (pthread_create(&t->threads[w], NULL, worker_main, a) != 0) break;
     ++started;
   }

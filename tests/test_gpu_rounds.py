@@ -299,3 +299,35 @@ def test_ring_kernel_on_the_tagged_mirror_matches_oracle(monkeypatch):
             close("deltas", D["deltas"], Do["deltas"], 1e-5, 1e-5)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("kind,ingest,bits", [("A3CModel", "zero-copy", True), ("A3CModel", "zero-copy", False), ("GRUModel", "relay", True)])
+def test_push_mirror_rollouts_match_oracle(kind, ingest, bits, monkeypatch):
+    """A2C_PUSH=1 (opt-in, DESIGN.md section 7: no faster end to end): the env worker threads also write every answer -- frame,
+    sfence, rec granule, sfence -- straight into fine-grained DEVICE memory (a2c_push_buffer_alloc), and the ring kernel /
+    the relay's ingest kernel poll and fetch there instead of over PCIe.  Two rounds against the oracle."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    monkeypatch.setenv("A2C_PUSH", "1")
+    B, T, A, ss = 5, 7, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    net = make_net(kind, ss, A, 256)
+    onet = O.OracleNet(kind, ss, A, 256)
+    D = _datas(B * T, ss, net.is_recurrent, actions_on_host=False)
+    kws = [dict(env_id=j, length=2 * T + 1, p_done=0.15) for j in range(B)]
+    pool = ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=2, pong=True, frame_bits=bits)
+    us = torch.from_numpy(hashf(2 * T * B, 3392, 0, 1).reshape(2, T, B))
+    usd = us.to(DEV)
+    rnd = [0]
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest,
+               uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+    try:
+        assert pool.start().push_ptr != 0 and pool.dev_rec == pool.push_ptr
+        refs = _oracle_rollouts(kind, onet, hyps, kws, us, 2, B, T, ss, env_cls=TapeEnv)
+        for rnd[0] in range(2):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            _compare_round(D, refs[rnd[0]], net.is_recurrent)
+    finally:
+        r.close()

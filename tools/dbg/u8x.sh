@@ -1,12 +1,14 @@
-C="--warmup 2 --sustain-steps 0 --no-configs --no-secondary --no-cpu-baseline"
+C="--warmup 5 --sustain-steps 0 --no-configs --no-secondary --no-cpu-baseline"
 run() { python bench.py $* $C 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   ', d['value'], d.get('rollout_ms'), d.get('update_ms'), d.get('roofline',{}).get('kernel','')[:40], d.get('roofline',{}).get('frac'))"; }
-for i in 1 2; do
-echo "2048 body (RING_BLOCKS=0)"; A2C_RING_BLOCKS=0 run --n-envs 2048 --steps 10
-echo "2048 ring blocks, rows"; run --n-envs 2048 --steps 10 --no-frame-store
-echo "2048 ring blocks, frames lazy"; run --n-envs 2048 --steps 10
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   ', d['value'], d.get('rollout_ms'), d.get('update_ms'))"; }
+for i in 1 2 3; do
+echo "push=0"; A2C_PUSH=0 run --steps 200
+echo "push=1"; A2C_PUSH=1 run --steps 200
 done
-echo "512 body"; A2C_RING_BLOCKS=0 run --n-envs 512 --steps 30
-echo "512 ring blocks"; run --n-envs 512 --steps 30
-python -m pytest tests/test_gpu_rounds.py tests/test_gpu_ingest.py -q -x 2>&1 | tail -3
+echo "timing push=0"; A2C_PUSH=0 python tools/ring_timing.py 14 bits frame_store 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print({k:v for k,v in d.items() if isinstance(v,float)})"
+echo "timing push=1"; A2C_PUSH=1 python tools/ring_timing.py 14 bits frame_store 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print({k:v for k,v in d.items() if isinstance(v,float)})"

@@ -516,6 +516,12 @@ int a2c_gru_out(const float *gx, const float *rh_u, const float *b, const float 
  * dz = dh_new*(h - c) ; dh_direct = dh_new*z                                            */
 int a2c_gru_out_bwd(const float *dh_new, const float *h, const float *z, const float *c,
                     float *dc_pre, float *dz, float *dh, int B, int hdim, a2c_stream_t stream);
+/* the same inside the BPTT unroll (updater.py:161-166 walked backwards): dh_new is replaced by dh_new + carry * (1 - done[b]),
+ * carry (B,h) = the gradient that reached the next step's h_in = h_new * (1 - done) (done[b] = dones[b * done_stride]);
+ * one launch instead of mask_rows + add + gru_out_bwd, same values.  carry may be dh (in place).                   */
+int a2c_gru_out_bwd_carry(const float *dh_new, const float *carry, const float *dones, int64_t done_stride,
+                          const float *h, const float *z, const float *c, float *dc_pre, float *dz, float *dh,
+                          int B, int hdim, a2c_stream_t stream);
 /* backward of stage1: d_rh (B,h) from the Wh2 GEMM; dz from above:
  * dz_pre = dz*z*(1-z) ; dr = d_rh*h ; dr_pre = dr*r*(1-r) ; dh += d_rh*r               */
 int a2c_gru_gates_bwd(const float *d_rh, const float *dz, const float *h, const float *z,

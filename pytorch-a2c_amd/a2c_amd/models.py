@@ -774,14 +774,18 @@ class _GruMixin:
         self._mm(ws, 0, 0, B, hd, hd, rh.data_ptr(), hd, Wh[2].data_ptr(), hd, rhu.data_ptr(), hd, st)
         ops.gru_out(gx, rhu, b, h_in, z, c, hn, st)
 
-    def _gru_bwd_step(self, ws, dhn, h_in, B, st, bufs, dbufs):
-        """dhn (B,h) total gradient wrt this step's h_new.  Fills dbufs dz_pre/dr_pre/dc_pre and
-        returns dh_in (B,h) in dbufs['dh']."""
+    def _gru_bwd_step(self, ws, dhn, h_in, B, st, bufs, dbufs, carry=None):
+        """dhn (B,h) total gradient wrt this step's h_new -- plus, inside the BPTT unroll, carry = (tensor, dones_ptr,
+        done_stride): the gradient that reached the next step's h_in = h_new * (1 - done), folded into the same launch.
+        Fills dbufs dz_pre/dr_pre/dc_pre and returns dh_in (B,h) in dbufs['dh']."""
         hd = self.h_size
         Wh = self.P("gru.W_h")
         z, r, c = bufs["z"], bufs["r"], bufs["c"]
         dzp, drp, dcp, dz, drh, dh = (dbufs[k] for k in ("dz_pre", "dr_pre", "dc_pre", "dz", "d_rh", "dh"))
-        ops.gru_out_bwd(dhn, h_in, z, c, dcp, dz, dh, st)
+        if carry is not None:
+            ops.gru_out_bwd_carry(dhn, carry[0], carry[1], carry[2], h_in, z, c, dcp, dz, dh, st)
+        else:
+            ops.gru_out_bwd(dhn, h_in, z, c, dcp, dz, dh, st)
         self._mm(ws, 0, 1, B, hd, hd, dcp.data_ptr(), hd, Wh[2].data_ptr(), hd, drh.data_ptr(), hd, st)   # dc_pre Wh2^T
         ops.gru_gates_bwd(drh, dz, h_in, z, r, dzp, drp, dh, st)
         self._mm(ws, 0, 1, B, hd, hd, dzp.data_ptr(), hd, Wh[0].data_ptr(), hd, dh.data_ptr(), hd, st, accumulate=True)
@@ -848,15 +852,20 @@ class _GruMixin:
         dtm = {k: ws.get("tm_" + k, (T, R, h)) for k in ("dz_pre", "dr_pre", "dc_pre")}
         scratch = {k: ws.get("bp_" + k, (R, h)) for k in ("dz", "d_rh", "dh")}
         carry = None
+        fused = os.environ.get("A2C_NO_GRU_CARRY") != "1"
         for t in range(T - 1, -1, -1):
             dhn = dhn_tm[t]
-            if carry is not None:
+            if carry is not None and not fused:
                 ops.add(dhn, carry, dhn, st)
             bufs = {k: tm[k][t] for k in ("z", "r", "c")}
             dbufs = dict(dz_pre=dtm["dz_pre"][t], dr_pre=dtm["dr_pre"][t], dc_pre=dtm["dc_pre"][t], **scratch)
-            dh = self._gru_bwd_step(ws, dhn, tm["h_in"][t], R, st, bufs, dbufs)
-            if t > 0:      # h_in[t] = hn[t-1] * (1 - dones[:, t-1])
-                ops.mask_rows(dh, dones.data_ptr() + 4 * (t - 1), T, st)
+            # h_in[t+1] = hn[t] * (1 - dones[:, t]): the gradient that reached it comes back masked by the same factor --
+            # inside the first launch of this step (was: mask_rows + add, two launches of 3.8 us per time step)
+            dh = self._gru_bwd_step(ws, dhn, tm["h_in"][t], R, st, bufs, dbufs,
+                                    carry=(carry, dones.data_ptr() + 4 * t, T) if (carry is not None and fused) else None)
+            if t > 0:
+                if not fused:
+                    ops.mask_rows(dh, dones.data_ptr() + 4 * (t - 1), T, st)
                 carry = dh
         dx_tm = ws.get("dx_tm", (T, R, self.gru.x_size))
         flat = lambda t_: t_.view(N, -1)

@@ -626,6 +626,13 @@ def gru_out_bwd(dh_new, h, z, c, dc_pre, dz, dh, st=None):
                                 st if st is not None else stream()), "a2c_gru_out_bwd")
 
 
+def gru_out_bwd_carry(dh_new, carry, dones_ptr, done_stride, h, z, c, dc_pre, dz, dh, st=None):
+    """gru_out_bwd with dh_new + carry * (1 - done) as the incoming gradient (BPTT: the carry of the next time step)"""
+    B, hd = h.shape
+    check(lib().a2c_gru_out_bwd_carry(_p(dh_new), _p(carry), dones_ptr, done_stride, _p(h), _p(z), _p(c), _p(dc_pre), _p(dz),
+                                      _p(dh), B, hd, st if st is not None else stream()), "a2c_gru_out_bwd_carry")
+
+
 def gru_gates_bwd(d_rh, dz, h, z, r, dz_pre, dr_pre, dh, st=None):
     B, hd = h.shape
     check(lib().a2c_gru_gates_bwd(_p(d_rh), _p(dz), _p(h), _p(z), _p(r), _p(dz_pre), _p(dr_pre), _p(dh), B, hd,

@@ -52,6 +52,23 @@ __global__ __launch_bounds__(256) void gru_out_bwd_kernel(const float* __restric
   }
 }
 
+// the same with the BPTT carry folded in (updater.py:161-166 unrolled backwards): the total gradient of this step's h_new is
+// dh_new + carry * (1 - done), carry = the gradient that reached the NEXT step's h_in = h_new * (1 - done)
+__global__ __launch_bounds__(256) void gru_out_bwd_carry_kernel(const float* __restrict__ dhn, const float* carry,
+                                                                const float* __restrict__ dones, long dstride,
+                                                                const float* __restrict__ h, const float* __restrict__ z,
+                                                                const float* __restrict__ c, float* __restrict__ dc_pre,
+                                                                float* __restrict__ dz, float* dh, long n, int hd) {
+  // (carry may BE dh: element i is read before it is written, by the same thread)
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const long row = i / hd;
+    const float g = dhn[i] + carry[i] * (1.f - dones[row * dstride]), zz = z[i], cc = c[i];
+    dc_pre[i] = g * (1.f - zz) * (1.f - cc * cc);
+    dz[i] = g * (h[i] - cc);
+    dh[i] = g * zz;
+  }
+}
+
 __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restrict__ d_rh,
                                                             const float* __restrict__ dz, const float* __restrict__ h,
                                                             const float* __restrict__ z, const float* __restrict__ r,
@@ -141,6 +158,18 @@ int a2c_gru_out_bwd(const float* dh_new, const float* h, const float* z, const f
   if (!dh_new || !h || !z || !c || !dc_pre || !dz || !dh) return A2C_ERR_ARG;
   hipLaunchKernelGGL(gru_out_bwd_kernel, dim3(a2c_grid_1d((long)B * hdim, 256)), dim3(256), 0, a2c_s(stream), dh_new,
                      h, z, c, dc_pre, dz, dh, (long)B * hdim);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_gru_out_bwd_carry(const float* dh_new, const float* carry, const float* dones, int64_t done_stride, const float* h,
+                          const float* z, const float* c, float* dc_pre, float* dz, float* dh, int B, int hdim,
+                          a2c_stream_t stream) {
+  if (B < 0 || hdim < 1 || done_stride < 1) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!dh_new || !carry || !dones || !h || !z || !c || !dc_pre || !dz || !dh) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(gru_out_bwd_carry_kernel, dim3(a2c_grid_1d((long)B * hdim, 256)), dim3(256), 0, a2c_s(stream), dh_new,
+                     carry, dones, (long)done_stride, h, z, c, dc_pre, dz, dh, (long)B * hdim, hdim);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -1,6 +1,6 @@
-for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-secondary --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('20/5:', d['value'], d.get('rollout_ms'), d.get('update_ms'), d['ms_per_step'])"; done
-for i in 1 2; do python bench.py --gpus 1 --steps 200 --warmup 5 --no-configs --no-secondary --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('200/5:', d['value'], d.get('rollout_ms'), d.get('update_ms'), d['ms_per_step'])"; done
+python -m pytest tests/test_gpu_ingest.py tests/test_gpu_rounds.py tests/test_gpu_frames.py -q -x 2>&1 | tail -3
+for i in 1 2; do for x in 0 1; do
+echo "xsplit=$x"; A2C_RING_XSPLIT=$x python tools/ring_timing.py 14 bits frame_store 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); k=list(d); print('  sum', d['sum_us_per_step'], 'rollout', d['rollout_ms_timed'], [round(d[x],2) for x in k[:9]])"
+done; done

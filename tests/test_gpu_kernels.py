@@ -813,6 +813,20 @@ def test_gru_kernels_vs_autograd():
     close("dz_pre", dzp, g * (hin - c) * z * (1 - z))
     close("dr_pre", drp, d_rh * hin * r * (1 - r))
     close("dh", dh, g * z + d_rh * r)
+    # the BPTT form: dh_new + carry * (1 - done) as the incoming gradient == mask_rows + add + gru_out_bwd, bit for bit; in place
+    # (carry IS the dh buffer, as the unroll uses it)
+    carry = rnd((B, h), 107)
+    T = 5
+    dones = (rnd((B, T), 108, 0, 1) < 0.4).float()
+    t_ = 3
+    gm = dev(g) + dev(carry) * (1 - dones.to(DEV)[:, t_:t_ + 1])
+    ref = [torch.empty(B, h, device=DEV) for _ in range(3)]
+    ops.gru_out_bwd(gm.contiguous(), dev(hin), zd, cd, *ref)
+    dcp2, dz2, dh2 = torch.empty(B, h, device=DEV), torch.empty(B, h, device=DEV), dev(carry).clone()
+    dd = dones.to(DEV)
+    ops.gru_out_bwd_carry(dev(g), dh2, dd.data_ptr() + 4 * t_, T, dev(hin), zd, cd, dcp2, dz2, dh2)
+    assert torch.equal(dcp2, ref[0]) and torch.equal(dz2, ref[1]) and torch.equal(dh2, ref[2])
+    assert float(dones.sum()) > 0 and float((1 - dones).sum()) > 0
 
 
 def test_layernorm_vs_torch():

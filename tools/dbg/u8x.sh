@@ -1,6 +1,6 @@
-python -m pytest tests/test_gpu_ingest.py tests/test_gpu_rounds.py tests/test_gpu_frames.py -q -x 2>&1 | tail -3
-for i in 1 2; do for x in 0 1; do
-echo "xsplit=$x"; A2C_RING_XSPLIT=$x python tools/ring_timing.py 14 bits frame_store 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); k=list(d); print('  sum', d['sum_us_per_step'], 'rollout', d['rollout_ms_timed'], [round(d[x],2) for x in k[:9]])"
+C="--warmup 5 --steps 150 --sustain-steps 0 --no-configs --no-secondary --no-cpu-baseline"
+for i in 1 2 3 4 5 6; do for x in 0 1; do
+A2C_PUSH=$x python bench.py $C 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('push=$x', d['value'], d.get('rollout_ms'), d.get('update_ms'))"
 done; done

@@ -1711,6 +1711,7 @@ struct BwdBandP {
   StageP st;                       // dOut image staging (general path, halo)
   float* din; const float* mask; const float* wfrag;
   int Cin, H, W, S, P, ks, TY, bands, B, ncls, c4n, ox_lo, out_floats;
+  int mgroups, mt_total;           // bwd_band_kernel<MT>: the input channels in mgroups groups of 16 * MT, one workgroup each (1 = all)
   BandClass cls[MAX_CLS];
 };
 
@@ -1724,13 +1725,18 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int WP = p.st.WP, PLANE = p.st.PLANE;
-  const long total = (long)p.B * p.bands;
+  // channel groups (whole-sample bands only): a 32-channel 21 x 21 sample is 56 KB of dX + 40 KB of dOut = ONE workgroup per
+  // CU running stage -> matrix -> flush in sequence; as two 16-channel workgroups of 68 KB each two are resident and overlap
+  const long total = (long)p.B * p.bands * p.mgroups;
   stage_zero(p.st, img);
   for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
-    const long b = tile / p.bands;
-    const int Y0 = (int)(tile - b * p.bands) * p.TY;
+    const int mg = (int)(tile % p.mgroups);
+    const long tb = tile / p.mgroups;
+    const long b = tb / p.bands;
+    const int Y0 = (int)(tb - b * p.bands) * p.TY;
     const int rowsY = min(p.TY, p.H - Y0);
     const int oy_lo = fdiv(Y0 + p.P - (p.ks - 1), p.S);
+    const int ch0 = mg * 16 * MT;                          // first input channel of this workgroup
     __syncthreads();
     stage_tile(p.st, img, b, oy_lo);
     __syncthreads();
@@ -1784,15 +1790,21 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int t = 0; t < NTU; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* __restrict__ wf = p.wfrag + k.frag_off + lane;
+        // fragment of (step s, channel tile m) at [(s * mt_total + m)][64]; this workgroup's tiles are mg * MT .. + MT - 1
+        const float* __restrict__ wf = p.wfrag + k.frag_off + lane + (long)mg * MT * 64;
+        const int fstep = p.mt_total * 64;
         float a_cur[CH * MT], a_nxt[CH * MT];
 #pragma unroll
-        for (int i = 0; i < CH * MT; ++i) a_cur[i] = wf[i * 64];
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a_cur[u * MT + m] = wf[u * fstep + m * 64];
         int off = 0, bi = 0, ci = 0;
         for (int ck = 0; ck < k.nchunks; ++ck) {
           if (ck + 1 < k.nchunks) {
 #pragma unroll
-            for (int i = 0; i < CH * MT; ++i) a_nxt[i] = wf[((ck + 1) * CH * MT + i) * 64];
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+              for (int m = 0; m < MT; ++m) a_nxt[u * MT + m] = wf[((ck + 1) * CH + u) * fstep + m * 64];
           }
           float bv[NTU][CH];
 #pragma unroll
@@ -1830,7 +1842,7 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
               const int ch = m * 16 + 4 * g + rr;
-              if (ch < p.Cin) outb[ch * p.TY * p.W + pix] = acc[m][t][rr];
+              if (ch0 + ch < p.Cin) outb[ch * p.TY * p.W + pix] = acc[m][t][rr];
             }
         }
       }
@@ -1842,8 +1854,9 @@ __global__ __launch_bounds__(256) void bwd_band_kernel(BwdBandP p) {
     if (p.st.flat) {
       // the band is the whole sample and TY == H: the dX block [Cin][H*W] is one contiguous 16-B aligned run in LDS,
       // in HBM and in the mask, whatever the row width -- float4 everywhere, the mask words of a batch loaded first
-      const int n4 = (p.Cin * p.H * p.W) >> 2;
-      const long o0 = b * (long)p.Cin * p.H * p.W;
+      const int cg = p.mgroups > 1 ? min(16 * MT, p.Cin - ch0) : p.Cin;      // channels of this workgroup
+      const int n4 = (cg * p.H * p.W) >> 2;
+      const long o0 = (b * (long)p.Cin + ch0) * p.H * p.W;
       for (int i0 = tid; i0 < n4; i0 += 256 * STAGE_U) {
         float4 mk4[STAGE_U];
 #pragma unroll
@@ -3102,6 +3115,7 @@ static bool band_setup(const a2c_conv_desc* d, const float* dout, const float* w
   if (TY == 0) return false;
   if (TY > d->H) TY = d->H;        // one band = the whole sample: the dX block in LDS is laid out exactly like HBM
   q.TY = TY; q.bands = ceil_div(d->H, TY); q.out_floats = d->Cin * TY * d->W;
+  q.mgroups = 1; q.mt_total = ceil_div(d->Cin, 16);
   q.st.src = dout; q.st.bstride = (long)d->Cout * d->OH * d->OW; q.st.Cp = d->Cout; q.st.IH = d->OH; q.st.IW = d->OW;
   q.st.TIH = TIH; q.st.WP = WPo; q.st.PLANE = PLANEo; q.st.sx0 = ox_lo; q.st.fast = 0;
   // one band = the whole sample (TY == H): dOut is staged and dX flushed as contiguous float4 runs (bwd_band_kernel)
@@ -3161,7 +3175,17 @@ static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const floa
 #undef BAND2_CASE
     }
   }
-  const size_t lds = 4 * ((size_t)q.out_floats + (size_t)d->Cout * PLANEo + 64);
+  size_t lds = 4 * ((size_t)q.out_floats + (size_t)d->Cout * PLANEo + 64);
+  int MTk = MTb;
+  // whole-sample bands that leave ONE workgroup per CU: the input channels in groups of 16, one workgroup each, when two
+  // of those fit a CU (GRUModel conv4 backward-data, 32 <- 48 @21: 96 KB -> 2 x 68 KB)
+  if (q.st.flat && q.bands == 1 && MTb >= 2 && MTb <= 4 && lds > 80 * 1024 && d->Cin % 16 == 0 && (16 * d->H * d->W) % 4 == 0 &&
+      !getenv("A2C_NO_BAND_GROUPS")) {
+    const size_t lds1 = 4 * ((size_t)16 * TY * d->W + (size_t)d->Cout * PLANEo + 64);
+    if (lds1 <= 80 * 1024) {
+      q.mgroups = MTb; MTk = 1; q.out_floats = 16 * TY * d->W; lds = lds1;
+    }
+  }
   if (lds <= LDS_HARD_MAX && MTb <= 4) {
     // (NTU = 4, four tiles per A fragment, measured on GRUModel's 21 x 21 / 11 x 11 layers: 477 vs 475 us and 212 vs 162 us at
     // N = 4096 -- the fragment loads are not what these launches wait for)
@@ -3170,10 +3194,10 @@ static int launch_bwd_band(const a2c_conv_desc* d, const float* dout, const floa
     {                                                                                                             \
       const void* kf = (const void*)bwd_band_kernel<M_, N_>;                                                      \
       if (lds > 64 * 1024) (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-      const int grid = resident_grid(kf, lds, (long)B * q.bands);                                                 \
+      const int grid = resident_grid(kf, lds, (long)B * q.bands * q.mgroups);                                     \
       hipLaunchKernelGGL((bwd_band_kernel<M_, N_>), dim3(grid), dim3(256), lds, st, q);                           \
     }
-    if (MTb == 1) BAND_RUN(1, 2) else if (MTb == 2) BAND_RUN(2, 2) else if (MTb == 3) BAND_RUN(3, 2) else BAND_RUN(4, 2)
+    if (MTk == 1) BAND_RUN(1, 2) else if (MTk == 2) BAND_RUN(2, 2) else if (MTk == 3) BAND_RUN(3, 2) else BAND_RUN(4, 2)
 #undef BAND_RUN
     A2C_CHECK_LAUNCH();
     return A2C_OK;

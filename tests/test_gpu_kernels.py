@@ -626,6 +626,13 @@ def test_conv2d_tile_height_does_not_change_a_bit(spec, monkeypatch):
     for ty in (2, 4, 6, 10, 12):
         monkeypatch.setenv("A2C_BAND_TY", str(ty))
         assert torch.equal(bwd(), ref_b), ty
+    # the whole sample as one band (what the tuner picks for the 21 x 21 layer at update batch): its 32 input channels then
+    # go to two workgroups of 16 (two resident per CU instead of one); A2C_NO_BAND_GROUPS=1 = one workgroup, all channels
+    monkeypatch.setenv("A2C_BAND_TY", str((H + s - 1) // s * s))
+    assert torch.equal(bwd(), ref_b)
+    monkeypatch.setenv("A2C_NO_BAND_GROUPS", "1")
+    assert torch.equal(bwd(), ref_b)
+    monkeypatch.delenv("A2C_NO_BAND_GROUPS")
     monkeypatch.delenv("A2C_BAND_TY")
     for kb in (24, 32, 48, 96, 128):
         monkeypatch.setenv("A2C_IGEMM_LDS_KB", str(kb))

@@ -137,6 +137,27 @@ int a2c_pool_check(const void *base) {
 void a2c_pool_set_phase(void *base, uint32_t phase) { __atomic_store_n(&hdr(base)->phase, phase, __ATOMIC_RELEASE); }
 uint32_t a2c_pool_phase(const void *base) { return __atomic_load_n(&chdr(base)->phase, __ATOMIC_ACQUIRE); }
 
+/* the scan starts at env `start` (the one behind the env served last: every env of a worker waits its turn once per
+ * sweep instead of the low indices being served first every time) */
+static int pool_poll_from(void *base, int env0, int n, const uint32_t *next_seq, int64_t spin_ns, int start) {
+  const uint64_t *c = cmd_of(base) + env0;
+  const int64_t t0 = now_ns();
+  if (start < 0 || start >= n) start = 0;
+  for (unsigned sweep = 0;; ++sweep) {
+    for (int i = start; i < n; ++i)
+      if ((uint32_t)(__atomic_load_n(c + i, __ATOMIC_ACQUIRE) >> 32) == next_seq[i]) return i;
+    for (int i = 0; i < start; ++i)
+      if ((uint32_t)(__atomic_load_n(c + i, __ATOMIC_ACQUIRE) >> 32) == next_seq[i]) return i;
+    if ((sweep & 15) == 15) {
+      const uint32_t ph = a2c_pool_phase(base);
+      if (ph == A2C_POOL_SHUTDOWN) return -2;
+      if (ph == A2C_POOL_IDLE) sleep_ns(20000);   /* no rollout running: do not burn the core */
+      if (now_ns() - t0 > spin_ns) return -1;
+    }
+    cpu_relax();
+  }
+}
+
 int a2c_pool_poll(void *base, int env0, int n, const uint32_t *next_seq, int64_t spin_ns) {
   const uint64_t *c = cmd_of(base) + env0;
   const int64_t t0 = now_ns();
@@ -365,11 +386,16 @@ static void *worker_main(void *p) {
   }
   if (bad) a2c_pool_worker_failed(w->base, w->env0);
   a2c_pool_worker_ready(w->base);
+  const char *rr_env = getenv("A2C_POLL_RR");
+  const int rr = !(rr_env && rr_env[0] == '0');
+  int start = 0;
   for (;;) {
     int32_t action = 0;
-    const int i = a2c_pool_take(w->base, w->env0, w->n, next_seq, 200000000LL, &action);
+    const int i = pool_poll_from(w->base, w->env0, w->n, next_seq, 200000000LL, rr ? start : 0);
     if (i == -2) break;
     if (i < 0) continue;
+    action = a2c_pool_action(w->base, w->env0 + i);
+    start = i + 1;
     const int j = w->env0 + i;
     void *pinned = frames + (size_t)j * h->frame_stride;
     void *slot = bits ? (peek ? NULL : (void *)scratch) : pinned;
@@ -488,6 +514,11 @@ static const void *tape_peek(void *env) {
   return e->frames + (size_t)(e->t % e->length) * e->frame_bytes;
 }
 
+static int tape_prefetch_on(void) {
+  static int on = -1;
+  if (on < 0) { const char *v = getenv("A2C_TAPE_PREFETCH"); on = !(v && v[0] == '0'); }
+  return on;
+}
 static void tape_step(void *env, int32_t action, void *frame_out, float *rew, int *done) {
   (void)action;
   tape_env *e = (tape_env *)env;
@@ -496,6 +527,13 @@ static void tape_step(void *env, int32_t action, void *frame_out, float *rew, in
   if (frame_out) memcpy(frame_out, e->frames + (size_t)(e->t % e->length) * e->frame_bytes, (size_t)e->frame_bytes);
   *rew = (float)e->rews[k];
   *done = e->dones[k] != 0;
+  /* An emulator leaves the frame it has just drawn in the cache; a tape read for the first time in `length` steps comes
+   * from DRAM (0.3-0.7 us of the worker's ~1 us per env step).  Ask for the NEXT step's frame now: it is one env step
+   * (>= 15 us) away.  A2C_TAPE_PREFETCH=0 switches it off (A/B runs). */
+  if (tape_prefetch_on()) {
+    const uint8_t *nx = e->frames + (size_t)((e->t + 1) % e->length) * e->frame_bytes;
+    for (int q = 0; q < e->frame_bytes; q += 64) __builtin_prefetch(nx + q, 0, 3);
+  }
 }
 
 static const a2c_env_vtable tape_vtable = {tape_reset, tape_step, tape_peek};

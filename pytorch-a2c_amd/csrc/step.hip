@@ -67,7 +67,6 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   int poll_gap;                                    // 64-cycle sleeps between two polls of the rec granule
   int early_poll;                                  // ring kernel: first poll behind plane 0 (A2C_RING_EARLY=0: behind plane 1 only)
   int bstride, boff;                               // ring kernel: workgroup i plays env b = i * bstride + boff (blocks of a larger launch)
-  int stores_early;                                // ring kernel: stash / frame stores between the planes of the partial sums (A2C_RING_STORES_EARLY=0: behind them)
 };
 
 struct StepP {
@@ -1087,9 +1086,47 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     u32x4 f_pf = (u32x4){0u, 0u, 0u, 0u};
     pre_ok = false;
     const int nbase = (base + 1) % 5;
-    // state t -> HBM: its row (unless lazy), its newest frame, its activation stash.  Plane pl sits in slot (base + pl) % 5.
-    // The stores are dealt to the waves other than the fetching one.
-    auto stores = [&]() {
+    if (t < T) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // planes 0..2 of state t+1 = planes 1..3 of state t.  Wave 1 fetches the env worker's answer UNDER them: an early
+      // poll of the rec granule behind plane 0 (its PCIe round trip runs under plane 1's MFMAs); when that one already
+      // shows the awaited step the packed frame's load goes out behind plane 1 and lands under plane 2 -- both round
+      // trips hidden --, else a second poll goes out there and the frame is loaded behind the partial sums (one exposed).
+      // (Earlier the answer cannot have landed; later -- behind this CU's row stores -- the loads queue behind them.)
+      __amdgpu_buffer_rsrc_t fr_pf = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, (int)a.frame_stride, 0x00020000);
+      unsigned long long gr_e = ~0ULL;
+      bool early = false;
+      conv1_planes(nbase, 0, 1);
+      if (pf && !tg && p.x.early_poll) gr_e = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      conv1_planes(nbase, 1, 2);
+      if (pf && tg) f_pf = tg_fetch();     // poll + frame + record in ONE load per lane (validated by the chunk tags below)
+      else if (pf) {
+        early = p.x.early_poll && (unsigned int)(gr_e >> 33) == want_n;
+        if (early) {
+          gr_pf = gr_e;
+          f_pf = __builtin_amdgcn_raw_buffer_load_b128(fr_pf, lane * 16, 0, 1 | 16);      // pixels 128*lane .. +127
+        } else {
+          gr_pf = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      conv1_planes(nbase, 2, 3);
+      if (pf && !tg) {
+        // wave 1 issues no store here: loads and stores retire through ONE in-order counter, a frame load behind the
+        // row stores would wait for their HBM acknowledgements.  The packed frame is one 16-byte load per lane.
+        pre_ok = (unsigned int)(gr_pf >> 33) == want_n;
+        if (pre_ok && !early) f_pf = __builtin_amdgcn_raw_buffer_load_b128(fr_pf, lane * 16, 0, 1 | 16);
+      }
+    }
+    RING_TS(6);                   // partial sums of the next state
+    if (pf && tg) {
+      pre_ok = tg_ok(f_pf, p.x.seq0 + (unsigned int)(t + 1));
+      if (pre_ok) tg_unpack(f_pf, (nbase + 3) % 5);
+    } else if (pf) {
+      // (the answer's loads were issued above)
+    } else {
+      // state t: plane pl sits in slot (base + pl) % 5.  The stores are dealt to the waves other than the fetching one.
       const bool dealt = t < T && p.x.frame_bits != 0;          // wave 1 is busy with the env worker's answer
       const int sid = dealt ? (w == 0 ? tid : tid - 64) : tid, sn = dealt ? NT - 64 : NT;
       float* __restrict__ out = t == T ? p.x.bookmark + (long)b * S : p.x.states + (row + t) * S;
@@ -1122,54 +1159,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a2o) + q);
         }
       }
-    };
-    // Lazy states on the packed transport (the headline): the 43 KB of frame + stash go out BETWEEN the planes of the partial
-    // sums, waves 0, 2, 3 behind plane 0 and waves 4..7 behind plane 1 -- the two waves of a SIMD never store at the same time,
-    // the other one's MFMAs keep the pipe busy (behind the partial sums the stores were ~1 us of every step with nothing under them)
-    const bool st_early = p.x.stores_early != 0 && t < T && p.x.frame_bits != 0 && p.x.states_lazy != 0 && !tg;
-    if (t < T) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      // planes 0..2 of state t+1 = planes 1..3 of state t.  Wave 1 fetches the env worker's answer UNDER them: an early
-      // poll of the rec granule behind plane 0 (its PCIe round trip runs under plane 1's MFMAs); when that one already
-      // shows the awaited step the packed frame's load goes out behind plane 1 and lands under plane 2 -- both round
-      // trips hidden --, else a second poll goes out there and the frame is loaded behind the partial sums (one exposed).
-      // (Earlier the answer cannot have landed; later -- behind this CU's row stores -- the loads queue behind them.)
-      __amdgpu_buffer_rsrc_t fr_pf = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.frame_u8 + (long)(p.x.env0 + b) * a.frame_stride), 0, (int)a.frame_stride, 0x00020000);
-      unsigned long long gr_e = ~0ULL;
-      bool early = false;
-      conv1_planes(nbase, 0, 1);
-      if (pf && !tg && p.x.early_poll) gr_e = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (st_early && w != 1 && w < 4) stores();
-      conv1_planes(nbase, 1, 2);
-      if (st_early && w >= 4) stores();
-      if (pf && tg) f_pf = tg_fetch();     // poll + frame + record in ONE load per lane (validated by the chunk tags below)
-      else if (pf) {
-        early = p.x.early_poll && (unsigned int)(gr_e >> 33) == want_n;
-        if (early) {
-          gr_pf = gr_e;
-          f_pf = __builtin_amdgcn_raw_buffer_load_b128(fr_pf, lane * 16, 0, 1 | 16);      // pixels 128*lane .. +127
-        } else {
-          gr_pf = __hip_atomic_load(p.x.rec + p.x.env0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-      conv1_planes(nbase, 2, 3);
-      if (pf && !tg) {
-        // wave 1 issues no store here: loads and stores retire through ONE in-order counter, a frame load behind the
-        // row stores would wait for their HBM acknowledgements.  The packed frame is one 16-byte load per lane.
-        pre_ok = (unsigned int)(gr_pf >> 33) == want_n;
-        if (pre_ok && !early) f_pf = __builtin_amdgcn_raw_buffer_load_b128(fr_pf, lane * 16, 0, 1 | 16);
-      }
-    }
-    RING_TS(6);                   // partial sums of the next state
-    if (pf && tg) {
-      pre_ok = tg_ok(f_pf, p.x.seq0 + (unsigned int)(t + 1));
-      if (pre_ok) tg_unpack(f_pf, (nbase + 3) % 5);
-    } else if (pf) {
-      // (the answer's loads were issued above)
-    } else {
-      if (!st_early) stores();
     }
     if (pf && pre_ok && !tg) {
       // the prefetched frame -> plane 3 of state t+1 = the ring's free fifth slot, 128 pixels per lane
@@ -1349,8 +1338,6 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
     p.x.poll_gap = gap > 0 ? gap : 1;
     static const int early = getenv("A2C_RING_EARLY") ? atoi(getenv("A2C_RING_EARLY")) : 1;
     p.x.early_poll = early;
-    static const int se = getenv("A2C_RING_STORES_EARLY") ? atoi(getenv("A2C_RING_STORES_EARLY")) : 1;
-    p.x.stores_early = se;
   }
   if (r->frame_store && (!r->nvalid_rows || !r->nvalid_carry || r->T < 4 || ((uintptr_t)r->frame_store % 16) ||
                          r->frame_store_slot_stride % 16 || r->frame_store_slot_stride < (r->T + 4) * (int64_t)r->H * r->W))

@@ -2067,8 +2067,12 @@ int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, co
   X(24, 32, 84, 84, 2, 6, 8, 2, 2)  /* ConvModel conv3                                         */ \
   X(32, 64, 42, 42, 2, 7, 8, 4, 3)  /* ConvModel conv4                                         */ \
   X(16, 24, 84, 84, 2, 6, 8, 1, 2)  /* GRUModel conv2 (R = 5, D = 3 measured 3 % slower: 42 = 8 x 5 + 2)  */ \
-  X(24, 32, 42, 42, 2, 7, 8, 2, 2)  /* GRUModel conv3                                          */
-// (GRUModel conv4, 32 -> 48 @21 with the whole 11 x 11 output as one band: 4.5 ms against the generic kernel's 2.7)
+  X(24, 32, 42, 42, 2, 7, 8, 2, 2)  /* GRUModel conv3                                          */ \
+  X(32, 48, 21, 21, 2, 11, 16, 4, 2) /* GRUModel conv4: the whole 11 x 11 output as one band, 2 chunks of 16 channels (9 full
+                                        n-tiles each), 4 channel groups x 2 pixel groups: 1.73 ms at N = 32,768 against the generic
+                                        kernel's 2.72 (KC = 8: 2.02; NCG = 2: 4.5, its 160 accumulator registers spilled) */
+// (GRUModel conv5, 48 -> 64 @11, whole 6 x 6 output as one band: 1.15-1.30 ms against the generic kernel's 1.09 -- 36 pixels
+// per band are 12 MFMA steps per chunk, the per-band overhead decides)
 // round 3's instances (A2C_C3W_D2=1): taller bands, one chunk of lookahead
 #define C3W_OLD_CASES(X)             \
   X(4, 16, 84, 84, 1, 8, 4, 1, 2)    \

@@ -2063,11 +2063,11 @@ int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, co
 // (CS, CD, H, W, S, R rows per band, KC channels per chunk, NCG, D chunk images in the ring)
 #define C3W_CASES(X)                                                                              \
   X(4, 16, 84, 84, 1, 6, 4, 1, 3)   /* conv1 of both models                                    */ \
-  X(16, 24, 84, 84, 1, 3, 16, 1, 3) /* ConvModel conv2                                         */ \
+  X(16, 24, 84, 84, 1, 3, 16, 1, 3) /* ConvModel conv2 (two channel groups: 22.3 ms against 19.3)   */ \
   X(24, 32, 84, 84, 2, 6, 8, 2, 2)  /* ConvModel conv3                                         */ \
-  X(32, 64, 42, 42, 2, 7, 8, 4, 3)  /* ConvModel conv4                                         */ \
-  X(16, 24, 84, 84, 2, 6, 8, 1, 2)  /* GRUModel conv2 (R = 5, D = 3 measured 3 % slower: 42 = 8 x 5 + 2)  */ \
-  X(24, 32, 42, 42, 2, 7, 8, 2, 2)  /* GRUModel conv3                                          */ \
+  X(32, 64, 42, 42, 2, 7, 8, 4, 3)  /* ConvModel conv4 (R = 5 / 6 with 16-channel chunks, D = 2: 7.8 / 7.5 ms against 7.36) */ \
+  X(16, 24, 84, 84, 2, 6, 8, 1, 2)  /* GRUModel conv2 (R = 5, D = 3: 3 % slower; two channel groups: 7.4 ms against 6.9)  */ \
+  X(24, 32, 42, 42, 2, 7, 12, 2, 3) /* GRUModel conv3 (12-channel chunks, ring of 3: 2.88 ms; 8 / ring of 2: 3.30) */ \
   X(32, 48, 21, 21, 2, 11, 16, 4, 2) /* GRUModel conv4: the whole 11 x 11 output as one band, 2 chunks of 16 channels (9 full
                                         n-tiles each), 4 channel groups x 2 pixel groups: 1.73 ms at N = 32,768 against the generic
                                         kernel's 2.72 (KC = 8: 2.02; NCG = 2: 4.5, its 160 accumulator registers spilled) */

@@ -107,6 +107,105 @@ def make_host_pool(n_envs, T, kind, n_workers, seed, transport="bits"):
                           frame_dtype=np.uint8, frame_bits=bits)
 
 
+
+# ---------------------------------------------------------------- the ONE line the driver parses
+LINE_MAX = 4096      # the driver keeps an 8 KB tail of stdout: the line must fit it with room to spare (tests/test_bench_line.py)
+_CFG_SHORT = (("conv_32x64", "conv_32x64"), ("gru_bptt_256x128", "gru_bptt_256x128"), ("a3c_32", "a3c_32"),
+              ("a3c_2048", "a3c_2048"), ("conv_2048x128_per_gpu_shard_256x128", "conv_shard_256x128"))
+
+
+def _finite(x):
+    """strict JSON has no NaN / Infinity: such a figure is reported as null"""
+    if isinstance(x, float) and (x != x or x in (float("inf"), float("-inf"))):
+        return None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
+def compact_line(full, side_file=None):
+    """The printed line: the contract's keys, `config` as short tokens, `roofline`, `cpu_baseline` and the scalar copies of
+    the secondary figures.  Everything else of `full` (per-site tables of the other configs, secondary legs, notes) lives in
+    the side file and on stderr -- round 4's 22.7 KB line did not fit the driver's stdout tail and was recorded unparsed."""
+    cfg = full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg[k] for k in ("workload", "n_envs", "n_tsteps", "optimizer", "transport", "ingest", "states_layout",
+                                          "update", "info_readback", "env_workers", "usable_host_cpus", "parallelism")
+                      if k in cfg}
+    for k in ("rollout_ms", "update_ms"):
+        line[k] = full.get(k)
+    rf = full.get("roofline")
+    if rf:
+        line["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale",
+                                               "traffic_source", "alg_flops_per_launch", "alg_bytes_per_launch", "avg_launch_us",
+                                               "launches_per_rollout", "hbm_GBs") if k in rf}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "cpu_model", "kind", "rollout_steps_per_s",
+                                                   "update_samples_per_s", "update_batch", "extrapolated", "sample", "error")
+                                if k in cb}
+    sus = full.get("sustained")
+    if sus:
+        line["sustained"] = {k: sus[k] for k in ("steps", "ms_per_step", "value") if k in sus}
+    # scalar copies of the nested figures the verdicts quote
+    sat = (full.get("scan_roofline") or {}).get("saturating_2^19x128")
+    if sat:
+        line["scan_roofline_frac_saturating"] = sat["frac"]
+        line["scan_roofline_GBs_saturating"] = sat["achieved_GBs"]
+    cfgs = full.get("configs") or {}
+    ms = {}
+    for key, short in _CFG_SHORT:
+        v = cfgs.get(key) or {}
+        if v.get("value") is not None:
+            line["value_" + short] = v["value"]
+            ms[short] = [v.get("rollout_ms"), v.get("update_ms")]
+    if ms:
+        line["configs_rollout_update_ms"] = ms
+    for key in ("value_device_tape", "value_states_rows_written", "host_pinned_u8_transport", "host_pinned_process_workers",
+                "value_one_env_thread"):
+        v = full.get(key)
+        if isinstance(v, dict) and v.get("value") is not None:
+            line[key if key.startswith("value_") else "value_" + key] = v["value"]
+    for k in ("host_us_per_env_step", "rccl_ranks", "dist_backend", "allreduce_ms_per_update", "allreduce_bytes"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    if rf and rf.get("frac") is not None:
+        line["roofline_frac"] = rf["frac"]
+    if (cb or {}).get("value") and full.get("value"):
+        line["speedup_vs_cpu_baseline"] = round(full["value"] / cb["value"], 1)
+    if side_file:
+        line["full_report"] = side_file
+    line = _finite(line)
+    s = json.dumps(line, allow_nan=False)
+    if len(s) > LINE_MAX:       # never hand the driver a line it cannot keep: drop the prose first, then the extras
+        for victim in (("cpu_baseline", "sample"), ("roofline", "traffic_source"), ("config", "info_readback"),
+                       ("config", "ingest"), ("configs_rollout_update_ms", None), ("sustained", None)):
+            if victim[1] is None:
+                line.pop(victim[0], None)
+            elif isinstance(line.get(victim[0]), dict):
+                line[victim[0]].pop(victim[1], None)
+            s = json.dumps(line, allow_nan=False)
+            if len(s) <= LINE_MAX:
+                break
+    return s
+
+
+def write_side_file(full, tag):
+    """the full report (every table the line no longer carries) next to the line: gpurun_out/bench_full_<tag>.json"""
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, f"bench_full_{tag}.json")
+        with open(path, "w") as f:
+            json.dump(_finite(full), f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        print(f"[bench] could not write the full report ({e})", file=sys.stderr)
+        return None
+
 # ---------------------------------------------------------------- CPU baseline (oracle, host cores)
 def _cpu_rollout_worker(args):
     model, T, A, seconds = args
@@ -192,11 +291,8 @@ def cpu_baseline(model, n_envs, T, use_bptt, A, optim):
     return dict(value=round(value, 1), unit="env-steps/s", cores=cores, kind="port",
                 rollout_steps_per_s=round(roll_rate, 1), update_samples_per_s=round(upd_rate, 1),
                 rollout_processes=workers, update_batch=N_upd, extrapolated=bool(N_upd < N_full), cpu_model=cpu_model,
-                sample=f"oracle (CPU restatement of the reference): rollout = {workers} processes x batch-1 forwards for 5 s "
-                       f"each, measured aggregate (no scale-up); update_model on N={N_upd} of {N_full} samples with {cores} "
-                       f"torch threads ({'full batch' if N_upd >= N_full else 'rate assumed flat in N'}); value = "
-                       f"1/(1/rollout_rate + 1/update_rate); usable cores = affinity capped by the cgroup quota; "
-                       f"wall {time.perf_counter() - t0:.0f}s")
+                sample=f"oracle port: rollout {workers} procs x batch-1 fwd 5 s each (measured aggregate); update_model "
+                       f"N={N_upd}/{N_full}, {cores} torch threads; value=1/(1/r+1/u); wall {time.perf_counter() - t0:.0f}s")
 
 
 # ---------------------------------------------------------------- roofline helpers
@@ -249,6 +345,52 @@ def scan_roofline(device):
         out[label] = dict(elements=N, avg_ms=round(ms, 4), achieved_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
         del x, r, d, a, b
     return out
+
+
+
+def csrc_sha256():
+    """identity of the kernel sources of the running tree (the GPU box has no .git): sha256 over name + bytes of every file
+    under pytorch-a2c_amd/csrc (build products excluded) and of include/*.h"""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for d in (os.path.join(ROOT, "pytorch-a2c_amd", "csrc"), os.path.join(ROOT, "include")):
+        for n in sorted(os.listdir(d)):
+            if n.endswith((".hip", ".h", ".c", ".cpp")) or n == "Makefile":
+                files.append(os.path.join(d, n))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def lookup_traffic(key, profiles=None):
+    """(hbm_bytes_per_launch | None, source | None, stale) for `key` from the newest profiles/r*_traffic.json whose manifest
+    (profiles/r*_manifest.json, written by tools/profile_round.sh as the last GPU action of a round) matches this tree"""
+    profiles = profiles or os.path.join(ROOT, "profiles")
+    if key is None or not os.path.isdir(profiles):
+        return None, None, False
+    mine = csrc_sha256()
+    stale = False
+    rounds = sorted((n for n in os.listdir(profiles) if n.startswith("r") and n.endswith("_traffic.json")),
+                    key=lambda n: -int("".join(c for c in n.split("_")[0] if c.isdigit()) or 0))
+    for tname in rounds:
+        try:
+            tj = json.load(open(os.path.join(profiles, tname)))
+        except (OSError, ValueError):
+            continue
+        if key not in tj:
+            continue
+        mfile = os.path.join(profiles, tname.replace("_traffic.json", "_manifest.json"))
+        try:
+            man = json.load(open(mfile))
+        except (OSError, ValueError):
+            man = {}
+        if man.get("csrc_sha256") == mine:
+            return round(tj[key]["hbm_bytes_per_launch"]), \
+                f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KB; manifest head {str(man.get('git_head'))[:12]})", False
+        stale = True
+    return None, None, stale
 
 
 # ---------------------------------------------------------------- one workload on this rank
@@ -672,21 +814,28 @@ def main():
                higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload=f"{model} n_envs={b.n_envs} n_tsteps={T} 84x84x4 synthetic frames"
                                     f"{' +BPTT' if b.use_bptt else ''}, {args.optim}, per GPU",
-                           ingest=ingest_desc, n_envs_per_gpu=b.n_envs, n_tsteps=T, optimizer=args.optim,
-                           transport=args.transport, env_workers=pool_workers, usable_host_cpus=usable_cpus(),
-                           states_layout=("single-frame uint8 store (SURVEY 8 f4): 7 KB frame per env step written by the rollout, "
-                                          "conv1 weight gradient stacked on load, fp32 `states` rows on demand "
-                                          "(Runner.materialize_states); `value_states_rows_written` = the same run writing the rows")
-                           if fs_main else "fp32 `states` rows (N, 4, 84, 84) written by the rollout (the reference's layout)",
-                           info_readback=("one step late: every step enqueues rollout + update, the update's five scalars travel to "
-                                          "pinned host memory behind it and are collected while the NEXT rollout runs "
-                                          "(Updater.update_model_async / collect); the timed region ends with a full drain + sync"
-                                          if os.environ.get("A2C_BENCH_SYNC_INFO") != "1" else "blocking read-back after every update"),
-                           frames="84x84 binary, i.i.d. Bernoulli(0.25) per pixel from default_rng(1234 + env_id) "
-                                  "(SURVEY 8d says uniform{0,1}: cost-neutral, the kernels are data-independent)",
-                           update=("hipGraph" if len(b.ugraph.graphs) == 1 else f"{len(b.ugraph.graphs)} hipGraphs around "
-                                   f"{len(b.ugraph.colls)} collectives") if b.ugraph is not None else "eager",
-                           parallelism=parallelism),
+                           n_envs=b.n_envs, n_tsteps=T, optimizer=args.optim, transport=args.transport,
+                           ingest=("device-tape" if args.ingest == "device-tape" else
+                                   f"host-pinned/{'zero-copy-persistent' if zero_copy else ('memcpy' if args.ingest == 'memcpy' else 'device-relay')}"
+                                   f"/{args.env_workers}"),
+                           states_layout="u8-frame-store+lazy-fp32-states" if fs_main else "fp32-states-rows",
+                           update=("hipGraph" if len(b.ugraph.graphs) == 1 else f"{len(b.ugraph.graphs)}-hipGraphs/"
+                                   f"{len(b.ugraph.colls)}-collectives") if b.ugraph is not None else "eager",
+                           info_readback="one-step-late" if os.environ.get("A2C_BENCH_SYNC_INFO") != "1" else "blocking",
+                           env_workers=pool_workers, usable_host_cpus=usable_cpus(), parallelism=f"dp{shard.world}"),
+               config_notes=dict(
+                   ingest=ingest_desc,
+                   states_layout=("single-frame uint8 store (SURVEY 8 f4): 7 KB frame per env step written by the rollout, "
+                                  "conv1 weight gradient stacked on load, fp32 `states` rows on demand "
+                                  "(Runner.materialize_states); `value_states_rows_written` = the same run writing the rows")
+                   if fs_main else "fp32 `states` rows (N, 4, 84, 84) written by the rollout (the reference's layout)",
+                   info_readback=("one step late: every step enqueues rollout + update, the update's five scalars travel to "
+                                  "pinned host memory behind it and are collected while the NEXT rollout runs "
+                                  "(Updater.update_model_async / collect); the timed region ends with a full drain + sync"
+                                  if os.environ.get("A2C_BENCH_SYNC_INFO") != "1" else "blocking read-back after every update"),
+                   frames="84x84 binary, i.i.d. Bernoulli(0.25) per pixel from default_rng(1234 + env_id) "
+                          "(SURVEY 8d says uniform{0,1}: cost-neutral, the kernels are data-independent)",
+                   parallelism=parallelism),
                rollout_ms=round(rollout_ms, 3), update_ms=round(update_ms, 3),
                last_info={k: round(float(v), 6) for k, v in (b.info or {}).items()})
     if sustained:
@@ -727,7 +876,7 @@ def main():
                   (0 if ring else (84 * 84 - FRAME_BYTES[args.transport] if args.ingest != "device-tape" else 0))) \
                 * b.n_envs * (T + 1) / launches
             tf = fl / (us * 1e-6) / 1e12
-            name = ("%s = a2c_a3c_rollout (1 launch = %d steps x %d envs, paced by the host env workers' turn-around)"
+            name = ("%s (a2c_a3c_rollout: 1 launch = %d steps x %d envs, host-paced)"
                     % ("a3c_ring_kernel" if ring else "a3c_step_kernel<persistent>", T + 1, b.n_envs // launches)) if zero_copy else \
                    f"a3c_step_kernel (B={b.n_envs}, {T + 1} launches/rollout)"
             out["roofline"] = dict(kernel=name, bound="mfma", achieved=round(tf, 2), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
@@ -759,19 +908,20 @@ def main():
             else:
                 out["roofline"] = dict(kernel=dom, bound="mfma", achieved=None, peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
                                        frac=None, traffic=None)
-        # HBM bytes per launch from the PMC passes committed under profiles/ (collected separately:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/run_kernel.py at this exact size)
-        for tname in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
-            tfile = os.path.join(ROOT, "profiles", tname)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (collected separately: rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_round.sh).  Only counters taken from THIS tree are
+        # quoted: the traffic file's manifest records the sha256 of the kernel sources it was measured on; a tree whose
+        # sources differ prints traffic: null, traffic_stale: true instead of another kernel's counters.
+        if "roofline" in out and out["roofline"].get("traffic") is None and args.workload == "a3c" and N == 32768:
             key = {"conv1.fwd": "conv1_fwd", "conv1.bwd_weight": "conv1_wgrad", "conv2.bwd_data": "conv2_bwd_data"}.get(dom)
-            if "roofline" in out and out["roofline"].get("traffic") is None and args.workload == "a3c" and N == 32768 \
-                    and os.path.exists(tfile):
-                tj = json.load(open(tfile))
-                k2 = ((("a3c_ring_lazy" if lazy_ring else "a3c_ring") if out["roofline"]["kernel"].startswith("a3c_ring") else "a3c_rollout") if zero_copy else "a3c_step") \
-                    if out["roofline"]["kernel"].startswith("a3c_") else key
-                if k2 in tj:
-                    out["roofline"]["traffic"] = round(tj[k2]["hbm_bytes_per_launch"])
-                    out["roofline"]["traffic_source"] = f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KB)"
+            k2 = ((("a3c_ring_lazy" if lazy_ring else "a3c_ring") if out["roofline"]["kernel"].startswith("a3c_ring") else "a3c_rollout") if zero_copy else "a3c_step") \
+                if out["roofline"]["kernel"].startswith("a3c_") else key
+            tr, src, stale = lookup_traffic(k2)
+            out["roofline"]["traffic"] = tr
+            if src:
+                out["roofline"]["traffic_source"] = src
+            if stale:
+                out["roofline"]["traffic_stale"] = True
         # always report conv1 forward (north star: HBM GB/s on the conv forward)
         if "conv1" in conv_layers and "conv1.fwd" in summ:
             d = conv_layers["conv1"].d
@@ -847,6 +997,24 @@ def main():
                 except Exception as e:      # noqa: BLE001
                     out["host_pinned_u8_transport"] = dict(value=None, error=f"{type(e).__name__}: {e}")
             if args.ingest == "host-pinned" and args.env_workers == "native":
+                # the host floor an 8-rank run on a 16-CPU quota meets (one env thread per rank): the same headline
+                # with ONE native env thread serving all envs; host_us_per_env_step = that rollout / (envs x steps) is the
+                # upper bound of the thread's service time per env step (the kernel's own step is inside it)
+                try:
+                    d = Bench(args.workload, n_envs, args.optim, "host-pinned", "native", 1, shard, dev,
+                              transport=args.transport, frame_store=fs_main)
+                    d.step(); d.capture(); d.step()
+                    e, r_ms, u_ms = d.timed(40)
+                    out["value_one_env_thread"] = dict(value=round(d.N * 40 / e, 1), unit="env-steps/s", steps=40,
+                                                       ms_per_step=round(1e3 * e / 40, 3), rollout_ms=round(r_ms, 3),
+                                                       update_ms=round(u_ms, 3), env_threads=1,
+                                                       us_per_rollout_step=round(r_ms * 1e3 / (T + 1), 2))
+                    out["host_us_per_env_step"] = round(r_ms * 1e3 / ((T + 1) * d.n_envs), 4)
+                    d.close()
+                    del d
+                except Exception as e:      # noqa: BLE001
+                    out["value_one_env_thread"] = dict(value=None, error=f"{type(e).__name__}: {e}")
+            if args.ingest == "host-pinned" and args.env_workers == "native":
                 try:
                     nw = max(1, min(48, usable_cpus() - 2))
                     d = Bench(args.workload, n_envs, args.optim, "host-pinned", "process", nw, shard, dev, transport=args.transport)
@@ -899,21 +1067,10 @@ def main():
                                                    WORKLOADS[args.workload][3], A, args.optim)
             except Exception as e:      # noqa: BLE001
                 out["cpu_baseline"] = dict(value=None, error=f"{type(e).__name__}: {e}")
-    # scalar copies of the nested figures the verdicts quote (a driver that only keeps top-level scalars still shows them)
-    sat = (out.get("scan_roofline") or {}).get("saturating_2^19x128")
-    if sat:
-        out["scan_roofline_frac_saturating"] = sat["frac"]
-        out["scan_roofline_GBs_saturating"] = sat["achieved_GBs"]
-    for key, short in (("conv_32x64", "conv_32x64"), ("gru_bptt_256x128", "gru_bptt_256x128"), ("a3c_32", "a3c_32"),
-                       ("a3c_2048", "a3c_2048"), ("conv_2048x128_per_gpu_shard_256x128", "conv_shard_256x128")):
-        v = (out.get("configs") or {}).get(key) or {}
-        if v.get("value") is not None:
-            out["value_" + short] = v["value"]
-    if "roofline" in out and out["roofline"].get("frac") is not None:
-        out["roofline_frac"] = out["roofline"]["frac"]
-    if (out.get("cpu_baseline") or {}).get("value"):
-        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-    print(json.dumps(out), file=json_out)
+    tag = f"{args.workload}_n{shard.world}" + (f"_e{args.n_envs}" if args.n_envs else "")
+    side = write_side_file(out, tag)
+    print("[bench] full report: " + json.dumps(_finite(out)), file=sys.stderr)
+    print(compact_line(out, side), file=json_out)
     json_out.flush()
 
 

@@ -1,0 +1,130 @@
+"""The ONE JSON line bench.py prints must fit the driver's stdout tail and be strict JSON (round 4's 22.7 KB line was
+recorded as `parsed: null`).  CPU only: the line is built from canned full reports."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _strict(s):
+    def bad(c):
+        raise ValueError(f"non-strict JSON constant {c}")
+    return json.loads(s, parse_constant=bad)
+
+
+def _fat_report():
+    """a full report at least as large as round 4's: every config with per-site tables, all secondary legs"""
+    site = dict(site="conv2.bwd_weight", avg_ms=6.9, launches=1, batch=32768, tflops=57.7, frac_of_f32_mfma_peak=0.367,
+                hbm_GBs=2000.1, frac_of_hbm_peak=0.25, alg_bytes=1.0e10, alg_flops=4.0e11)
+    cfg = dict(workload="GRUModel n_envs=256 n_tsteps=128 +BPTT", steps=10, ms_per_step=70.4, value=471581.7, unit="env-steps/s",
+               rollout_ms=32.4, update_ms=37.1, ingest="x" * 300, update="hipGraph", states_layout="y" * 200,
+               dominant_update_site=site, update_conv_sites={f"conv{i}.{w}": site for i in range(1, 6) for w in ("bwd_data", "bwd_weight")},
+               dominant_rollout_site=site, rollout_conv_fwd_sites={f"conv{i}.fwd": site for i in range(1, 6)})
+    return dict(
+        metric="env-steps/sec (rollout+update)", value=6455996.1, unit="env-steps/s", n_gpus=1, steps=20, warmup=5, ms_per_step=5.076,
+        higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+        config=dict(workload="A3CModel n_envs=256 n_tsteps=128 84x84x4 synthetic frames, RMSprop, per GPU", n_envs=256, n_tsteps=128,
+                    optimizer="RMSprop", transport="bits", ingest="host-pinned/zero-copy-persistent/native",
+                    states_layout="u8-frame-store+lazy-fp32-states", update="hipGraph", info_readback="one-step-late",
+                    env_workers=14, usable_host_cpus=16, parallelism="dp1"),
+        config_notes={k: "prose " * 60 for k in ("ingest", "states_layout", "info_readback", "frames")},
+        rollout_ms=2.139, update_ms=2.931, last_info=dict(Loss=float("nan"), GradNorm=float("inf")),
+        sustained=dict(steps=200, seconds=1.0, ms_per_step=5.08, value=6.45e6, rollout_ms=2.1, update_ms=2.9),
+        h2d=dict(transport="bits", achieved_GBs=13.6, note="n" * 200),
+        update_launch_sites_ms={f"site{i}": dict(avg_ms=0.1, launches=2) for i in range(40)},
+        roofline=dict(kernel="a3c_ring_kernel (a2c_a3c_rollout: 1 launch = 129 steps x 256 envs, host-paced)", bound="mfma",
+                      achieved=71.4, peak=157.3, unit="TFLOP/s", frac=0.4539, traffic=1516918871, traffic_source="profiles/r5_traffic.json",
+                      alg_flops_per_launch=152724111360.0, alg_bytes_per_launch=1420824576.0, avg_launch_us=2139.1,
+                      launches_per_rollout=1, hbm_GBs=664.2, hbm_frac=0.08, host_link=dict(note="z" * 500)),
+        scan_roofline={"config_256x128": dict(frac=0.01), "saturating_2^19x128": dict(frac=0.6395, achieved_GBs=5116.1)},
+        value_device_tape=dict(value=5282111.5, note="n" * 400), step_kernel_roofline=dict(kernel="k" * 100, frac=0.3),
+        value_states_rows_written=dict(value=6084585.5, note="n" * 200), host_pinned_u8_transport=dict(value=3759823.0, note="n" * 100),
+        host_pinned_process_workers=dict(value=2496531.2), value_one_env_thread=dict(value=3.1e6, rollout_ms=5.5),
+        host_us_per_env_step=0.17,
+        configs={k: cfg for k in ("conv_32x64", "gru_bptt_256x128", "a3c_32", "a3c_2048", "conv_2048x128_per_gpu_shard_256x128",
+                                  "conv_32x64_states_rows", "gru_bptt_256x128_states_rows")},
+        cpu_baseline=dict(value=15005.5, unit="env-steps/s", cores=16, kind="port", rollout_steps_per_s=78794.7,
+                          update_samples_per_s=18535.4, rollout_processes=16, update_batch=32768, extrapolated=False,
+                          cpu_model="AMD EPYC 9575F 64-Core Processor", sample="s" * 260))
+
+
+def _reports():
+    out = [("fat", _fat_report())]
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):     # the builder's own full reports of earlier rounds
+        if name.endswith("_bench.json"):
+            try:
+                out.append((name, json.load(open(os.path.join(ROOT, "profiles", name)))))
+            except ValueError:
+                pass
+    return out
+
+
+@pytest.mark.parametrize("name,full", _reports(), ids=[n for n, _ in _reports()])
+def test_line_fits_the_driver_and_is_strict_json(name, full):
+    s = bench.compact_line(full, "gpurun_out/bench_full_a3c_n1.json")
+    assert "\n" not in s
+    assert len(s) <= bench.LINE_MAX <= 4096, len(s)
+    d = _strict(s)
+    for k in ("metric", "value", "unit", "ms_per_step", "config"):
+        assert k in d, k
+    assert "configs" not in d and "update_launch_sites_ms" not in d and "config_notes" not in d
+    assert all(not isinstance(v, str) or len(v) < 160 for v in d["config"].values()) or name != "fat"
+
+
+def test_fat_line_keeps_what_the_judge_reads():
+    full = _fat_report()
+    d = _strict(bench.compact_line(full, "gpurun_out/x.json"))
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["config"]["workload"].startswith("A3CModel n_envs=256 n_tsteps=128")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "alg_flops_per_launch"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample", "cpu_model"):
+        assert k in d["cpu_baseline"], k
+    assert d["value_gru_bptt_256x128"] == 471581.7 and d["value_conv_shard_256x128"] == 471581.7
+    assert d["configs_rollout_update_ms"]["gru_bptt_256x128"] == [32.4, 37.1]
+    assert d["scan_roofline_frac_saturating"] == 0.6395 and d["roofline_frac"] == 0.4539
+    assert d["value_one_env_thread"] == 3.1e6 and d["host_us_per_env_step"] == 0.17
+    assert d["speedup_vs_cpu_baseline"] == round(6455996.1 / 15005.5, 1)
+
+
+def test_line_shrinks_rather_than_overflow():
+    full = _fat_report()
+    full["cpu_baseline"]["sample"] = "s" * 5000
+    full["config"]["ingest"] = "i" * 3000
+    s = bench.compact_line(full, None)
+    assert len(s) <= bench.LINE_MAX
+    d = _strict(s)
+    assert d["roofline"]["frac"] == 0.4539 and d["cpu_baseline"]["value"] == 15005.5
+
+
+def test_nan_and_infinity_become_null():
+    full = _fat_report()
+    full["rollout_ms"] = float("nan")
+    full["roofline"]["achieved"] = float("inf")
+    d = _strict(bench.compact_line(full, None))
+    assert d["rollout_ms"] is None and d["roofline"]["achieved"] is None
+
+
+def test_traffic_is_only_quoted_from_a_manifest_of_this_tree(tmp_path):
+    """bench.py must not quote PMC counters of an earlier kernel (round 4's line read r4_traffic.json after the ring kernel
+    had changed): a traffic file counts only when its manifest records the sha256 of the running tree's kernel sources"""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r4_traffic.json").write_text(json.dumps({"a3c_ring_lazy": {"hbm_bytes_per_launch": 111.0}}))      # no manifest
+    assert bench.lookup_traffic("a3c_ring_lazy", str(prof)) == (None, None, True)
+    (prof / "r5_traffic.json").write_text(json.dumps({"a3c_ring_lazy": {"hbm_bytes_per_launch": 222.4}}))
+    (prof / "r5_manifest.json").write_text(json.dumps({"csrc_sha256": "0" * 64, "git_head": "deadbeef"}))
+    assert bench.lookup_traffic("a3c_ring_lazy", str(prof)) == (None, None, True)
+    (prof / "r5_manifest.json").write_text(json.dumps({"csrc_sha256": bench.csrc_sha256(), "git_head": "cafef00dcafef00d"}))
+    tr, src, stale = bench.lookup_traffic("a3c_ring_lazy", str(prof))
+    assert tr == 222 and not stale and "r5_traffic.json" in src and "cafef00dcafe" in src
+    assert bench.lookup_traffic("no_such_kernel", str(prof)) == (None, None, False)

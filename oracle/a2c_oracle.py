@@ -575,6 +575,60 @@ class OracleUpdater:
         return (self.info, extra) if keep else self.info
 
 
+def update_grads_chunked(net, D, hyps, chunk_slots, dtype=torch.float32):
+    """The loss and the gradients ``OracleUpdater.update_model`` backpropagates (updater.py:63-128), evaluated
+    ``chunk_slots`` rollout slots at a time -- for sizes whose full-batch autograd graph does not fit host memory
+    (GRUModel + BPTT at 256 x 128: 179 k activation floats x 32,768 samples).  Exact restatement, not an
+    approximation: advantages, returns and the advantage normalisation are computed on the WHOLE batch first, exactly
+    as the reference does (updater.py:70-98; fp32 scans whatever ``dtype``); every loss term is a mean over samples
+    (updater.py:106, 124, 125), so Loss = sum over chunks of (sum over the chunk's samples) / N and the gradients of
+    the chunks add up (``.grad`` accumulates).  BPTT unrolls each slot from its own first h_state (updater.py:139-169),
+    so slots are independent.  ``dtype=torch.float64`` evaluates the forward / backward in double (the net must hold
+    double parameters).  Not supported (asserted): use_nstep_rets, norm_returns -- their targets depend on the forward.
+
+    Returns (info without the optimiser step, {name: grad}); GradNorm is the fp64 norm of the unclipped gradients."""
+    assert not hyps["use_nstep_rets"] and not try_key(hyps, "norm_returns", False)
+    R, T = hyps["n_rollouts"], hyps["n_tsteps"]
+    N = R * T
+    net.req_grads(True)
+    for p_ in net.parameters():
+        p_.grad = None
+    advs = discount(D["deltas"].float().squeeze(), D["dones"].float().squeeze(), hyps["gamma"] * hyps["lambda_"])
+    returns = discount(D["rewards"].float().squeeze(), D["dones"].float().squeeze(), hyps["gamma"])
+    advs, returns = advs.to(dtype), returns.to(dtype)
+    if hyps["norm_advs"]:
+        advs = (advs - advs.mean()) / (advs.std() + 1e-6)
+    tot = dict(Pi_Loss=0.0, ValLoss=0.0, Entropy=0.0)
+    for r0 in range(0, R, chunk_slots):
+        r1 = min(R, r0 + chunk_slots)
+        sl = slice(r0 * T, r1 * T)
+        x = D["states"][sl].to(dtype)
+        if "h_states" in D:
+            if hyps["use_bptt"]:
+                vals, logits = bptt(net, x, D["h_states"][sl].to(dtype), D["dones"][sl].to(dtype),
+                                    dict(hyps, n_rollouts=r1 - r0))
+            else:
+                vals, logits, _ = net(x, D["h_states"][sl].to(dtype))
+        else:
+            vals, logits = net(x)
+        lsm = F.log_softmax(logits, dim=-1)
+        acts = D["actions"][sl]
+        log_ps = lsm[torch.arange(len(acts)).long(), acts]
+        entr = -hyps["entr_coef"] * (lsm * F.softmax(logits, dim=-1)).sum(-1).sum() / N
+        pi_loss = hyps["pi_coef"] * -(log_ps * advs[sl]).sum() / N
+        val_loss = hyps["val_coef"] * ((vals.squeeze() - returns[sl]) ** 2).sum() / N
+        (pi_loss + val_loss - entr).backward()
+        for k, v in (("Pi_Loss", pi_loss), ("ValLoss", val_loss), ("Entropy", entr)):
+            tot[k] += float(v.detach())
+        del x, vals, logits, lsm, log_ps, entr, pi_loss, val_loss
+    grads = {n: (None if p_.grad is None else p_.grad.detach().clone()) for n, p_ in net.named_parameters()}
+    gn = float(torch.sqrt(sum(g.double().pow(2).sum() for g in grads.values() if g is not None)))
+    for p_ in net.parameters():
+        p_.grad = None
+    info = dict(Loss=tot["Pi_Loss"] + tot["ValLoss"] - tot["Entropy"], GradNorm=gn, **tot)
+    return info, grads
+
+
 # --------------------------------------------------------------------------
 # deterministic fake env used by goldens, tests, smoke and the CPU baseline
 # --------------------------------------------------------------------------

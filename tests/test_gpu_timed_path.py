@@ -91,14 +91,17 @@ def test_graphed_update_replays_equal_eager_updates_and_the_oracle(kind, ingest,
                     assert eg.upd.optim._steps == steps0                   # the capture executed nothing
                 gi = eg.g.replay()
             ei = ee.upd.update_model(ee.D)
-            for name in ei:                 # (fp64 sums of per-workgroup partials added with atomics: order-dependent at 1e-16)
-                assert gi[name] == pytest.approx(ei[name], rel=1e-12, abs=1e-15), (k, name, gi, ei)
+            for name in ei:                 # (fixed-order fp64 reductions, loss.hip grid_sum_ordered: bit for bit)
+                assert gi[name] == ei[name], (k, name, gi, ei)
             assert eg.upd.optim._steps == ee.upd.optim._steps == k + 1
             for (n, p), (_, q) in zip(eg.net.named_parameters(), ee.net.named_parameters()):
                 assert torch.equal(p, q), (k, n)
             oi = refs[k]["info"]
             for name in oi:
-                assert abs(gi[name] - oi[name]) <= 2e-5 + 5e-4 * abs(oi[name]), (k, name, gi[name], oi[name])
+                # epoch 0: identical weights on both sides -> the fp32 bar; later epochs carry RMSprop's amplification of
+                # the first step's gradient noise (see below)
+                tol_i = 2e-6 + 3e-5 * abs(oi[name]) if k == 0 else 2e-5 + 5e-4 * abs(oi[name])
+                assert abs(gi[name] - oi[name]) <= tol_i, (k, name, gi[name], oi[name])
         # lr = 1e-3: RMSprop's first steps move every weight by ~1e-2 .. 1e-3 whatever |g| (1/sqrt(v) normalises), so the
         # direction of noise-level gradients is not pinned by fp32; 4 updates -> 4 steps of lr * 10 at most per weight
         for (n, p), (n2, q) in zip(eg.net.named_parameters(), onet.named_parameters()):
@@ -240,11 +243,25 @@ def _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, max_norm):
         close(f"param samples {n}", p.detach().reshape(-1)[idx.to(DEV)], q.detach().reshape(-1)[idx], 3e-5, 1e-5)
 
 
-def test_full_size_headline_update_matches_the_oracle_updater(monkeypatch):
+def _assert_states_are_the_tapes(D, envs, B, T, rows=(0, 1)):
+    """the newest plane of state (j, t) is the frame env step t-1 of env j returned (runner.py:199, utils.py:26-43)"""
+    for j in rows:
+        st = D["states"][j * T:(j + 1) * T].cpu().reshape(T, 4, -1)
+        L = len(envs[j].frames)
+        for t in (1, 2, T // 2, T - 1):
+            assert np.array_equal(st[t, 3].numpy(), envs[j].frames[t % L].reshape(-1).astype(np.float32)), (j, t)
+
+
+@pytest.mark.parametrize("layout", ["store", "rows"])
+def test_full_size_headline_update_matches_the_oracle_updater(layout, monkeypatch):
     """A3CModel, 256 envs x 128 steps (N = 32,768: the stash-only forward, wgrad_stream / bwd_stream / wgrad_run kernels,
     the rank-A backward and the skinny reductions at their full row counts), rollout through the headline path
     (zero-copy ring kernel, packed frames), then update_model from the stash vs OracleUpdater on the SAME recorded
-    buffers (updater.py:63-137).  Then a second epoch as a hipGraph replay, against the oracle's second update."""
+    buffers (updater.py:63-137).  Then a second epoch the way bench.py times it: capture_update + replay_async / collect.
+
+    layout "store" = what bench.py runs (hyps frame_store + lazy_states): the ring kernel keeps ONE uint8 frame per env step,
+    `wgrad_stream_kernel<U8>` stacks the frames on load at N = 32,768, and the fp32 `states` rows do not exist until
+    Runner.materialize_states() -- called here only AFTER the update, for the oracle; "rows" = the reference's layout."""
     from a2c_amd.hostpool import ThreadEnvPool
     from a2c_amd.runner import Runner
     from a2c_amd.synthetic import TapeEnv
@@ -252,7 +269,10 @@ def test_full_size_headline_update_matches_the_oracle_updater(monkeypatch):
     torch.set_num_threads(max(4, min(16, len(os.sched_getaffinity(0)))))
     torch.manual_seed(20260104)          # the runner's sampling uniforms (torch.rand on the device)
     B, T, A, ss = 256, 128, 3, (4, 84, 84)
+    store = layout == "store"
     hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    if store:
+        hyps.update(frame_store=True, lazy_states=True)
     net = make_net("A3CModel", ss, A, 256)
     onet = O.OracleNet("A3CModel", ss, A, 256)
     D = _datas(B * T, ss, False, actions_on_host=False)
@@ -266,13 +286,24 @@ def test_full_size_headline_update_matches_the_oracle_updater(monkeypatch):
             r.rollout(net, list(range(B)), hyps)
             r.finish()
             assert net._stash_valid(D["states"].data_ptr(), B * T)          # the update below starts behind the convs
-            Do = {k: v.cpu().clone() for k, v in D.items()}
+            if store:
+                assert r._states_stale and r._fstore is not None           # no fp32 row was written by this rollout
+                if ep == 0:
+                    assert float(D["states"].abs().max()) == 0.0
             if ep == 0:
                 info = upd.update_model(D)
             else:
                 g = upd.capture_update(D)
-                info = g.replay()
+                info = upd.collect(g.replay_async())                        # bench.py's timed step
             assert not upd.flat_scan_fallback
+            if store:
+                assert r._states_stale                                      # ... and the update never asked for one
+                r.materialize_states()
+                assert not r._states_stale
+            torch.cuda.synchronize()
+            if ep == 0:
+                _assert_states_are_the_tapes(D, envs, B, T, rows=(0, 101, 255))
+            Do = {k: v.cpu().clone() for k, v in D.items()}
             if ep == 0:
                 oinfo, g32, oinfo64, g64 = _oracle_updates_fp32_and_fp64("A3CModel", ss, A, 256, oupd, Do, hyps, monkeypatch)
                 _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, hyps["max_norm"])
@@ -288,9 +319,12 @@ def test_full_size_headline_update_matches_the_oracle_updater(monkeypatch):
     torch.set_num_threads(4)
 
 
-def test_full_size_conv_32x64_update_matches_the_oracle_updater(monkeypatch):
+@pytest.mark.parametrize("layout", ["store", "rows"])
+def test_full_size_conv_32x64_update_matches_the_oracle_updater(layout, monkeypatch):
     """ConvModel 32 x 64 (BASELINE configs[1]; N = 2,048): relay rollout with every layer + embedding stashed, update vs
-    OracleUpdater on the recorded buffers."""
+    OracleUpdater on the recorded buffers.  layout "store" = bench.py's (single-frame uint8 store written by the relay
+    ingest, conv1 forward / weight gradient stacked on load, fp32 rows only on demand); the timed form of the update
+    (capture_update + replay_async / collect) on the second epoch."""
     from a2c_amd.hostpool import ThreadEnvPool
     from a2c_amd.runner import Runner
     from a2c_amd.synthetic import TapeEnv
@@ -298,22 +332,42 @@ def test_full_size_conv_32x64_update_matches_the_oracle_updater(monkeypatch):
     torch.set_num_threads(max(4, min(16, len(os.sched_getaffinity(0)))))
     torch.manual_seed(20260105)
     B, T, A, ss = 32, 64, 3, (4, 84, 84)
+    store = layout == "store"
     hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B)
+    if store:
+        hyps.update(frame_store=True, lazy_states=True)
     net = make_net("ConvModel", ss, A, 256)
     onet = O.OracleNet("ConvModel", ss, A, 256)
     D = _datas(B * T, ss, False, actions_on_host=False)
-    envs = [TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 100) for j in range(B)]
+    envs = [TapeEnv(env_id=j, length=2 * T + 1, p_done=1.0 / 100) for j in range(B)]
     pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=True, frame_bits=True)
     r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="relay")
+    upd, oupd = Updater(net, hyps), O.OracleUpdater(onet, hyps)
     try:
-        r.rollout(net, list(range(B)), hyps)
-        r.finish()
-        Do = {k: v.cpu().clone() for k, v in D.items()}
-        upd = Updater(net, hyps)
-        info = upd.update_model(D)
-        oinfo, g32, oinfo64, g64 = _oracle_updates_fp32_and_fp64("ConvModel", ss, A, 256, O.OracleUpdater(onet, hyps), Do, hyps,
-                                                                 monkeypatch)
-        _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, hyps["max_norm"])
+        for ep in range(2):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            if store:
+                assert r._states_stale and r._fstore is not None and getattr(r, "_fstore_ok", True)
+            if ep == 0:
+                info = upd.update_model(D)
+            else:
+                info = upd.collect(upd.capture_update(D).replay_async())
+            if store:
+                assert r._states_stale
+                r.materialize_states()
+            torch.cuda.synchronize()
+            if ep == 0:
+                _assert_states_are_the_tapes(D, envs, B, T, rows=(0, 17, 31))
+            Do = {k: v.cpu().clone() for k, v in D.items()}
+            if ep == 0:
+                oinfo, g32, oinfo64, g64 = _oracle_updates_fp32_and_fp64("ConvModel", ss, A, 256, oupd, Do, hyps, monkeypatch)
+                _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, hyps["max_norm"])
+            else:
+                oinfo = oupd.update_model(Do)
+                for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy", "GradNorm"):
+                    assert info[k] == pytest.approx(oinfo[k], rel=5e-3, abs=2e-5), (ep, k, info[k], oinfo[k])
+            del Do
     finally:
         r.close()
     torch.set_num_threads(4)
@@ -461,7 +515,7 @@ def test_async_update_collected_one_step_late_equals_blocking_update(graphed):
         assert len(got) == len(want) == n_ep
         for k in range(n_ep):
             for name in want[k]:
-                assert got[k][name] == pytest.approx(want[k][name], rel=1e-12, abs=1e-15), (k, name)
+                assert got[k][name] == want[k][name], (k, name)
     finally:
         ea.close()
         es.close()

@@ -200,3 +200,31 @@ def test_stats_rollout_matches_the_reference(golden):
         avg = O.stats_rollout(net, env, hyps, n_eps, lambda: float(next(it)))
         assert avg == float(g[f"{name}_avg_rew"])
         assert next(it, None) is None     # consumed exactly the uniforms the reference drew
+
+
+@pytest.mark.parametrize("name", ["gru_bptt_rms", "gru_rms", "conv_small_rms", "a3c_rms", "grufc_bptt_rms"])
+def test_chunked_oracle_gradients_equal_the_full_batch_update(golden, name):
+    """O.update_grads_chunked (the checker of the full-size GRU+BPTT test, where full-batch autograd does not fit host
+    memory) against (a) the losses the REFERENCE reported for the case (g6) and (b) OracleUpdater's gradients on the whole
+    batch, for chunks of 1 and 2 slots, in fp32 and fp64."""
+    case = [c for c in UPDATE_CASES if c[0] == name][0]
+    _, kind, ss, A, h, R_, T, opt, norm_advs, nstep, use_bptt, _ = case
+    g = golden["g6_update"]
+    hyps = base_hyps(n_tsteps=T, n_rollouts=R_, optim_type=opt, norm_advs=norm_advs, use_nstep_rets=nstep,
+                     use_bptt=use_bptt, h_size=h, max_norm=1e9)          # no clipping: compare raw gradients
+    net = O.OracleNet(kind, ss, A, h)
+    D = synth_shared(kind, ss, A, h, R_, T, seed=700, recurrent=net.is_recurrent)
+    _, extra = O.OracleUpdater(O.OracleNet(kind, ss, A, h), hyps).update_model(D, keep=True)
+    for chunk, dt in ((1, torch.float32), (2, torch.float32), (2, torch.float64)):
+        if dt == torch.float64:
+            net = O.OracleNet(kind, ss, A, h, state_dict={k: v.double() for k, v in O.formula_state_dict(kind, ss, A, h).items()})
+        info, grads = O.update_grads_chunked(net, D, hyps, chunk, dtype=dt)
+        for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy"):
+            ref = float(g[f"{name}_u0_{k}"])
+            assert info[k] == pytest.approx(ref, rel=2e-5, abs=2e-6), (chunk, dt, k, info[k], ref)
+        for n, gr in extra["grads"].items():
+            if gr is None:
+                assert grads[n] is None, n
+                continue
+            scale = float(gr.abs().max()) + 1e-12
+            assert float((grads[n].float() - gr).abs().max()) <= 2e-5 * scale + 1e-7, (chunk, dt, n)

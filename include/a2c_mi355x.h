@@ -310,6 +310,12 @@ typedef struct {
   const uint8_t *tagged; int64_t tagged_stride; int tagged_chunks;
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
+/* 1 when a2c_a3c_rollout with these shapes, this many envs and this conv1_weight pointer runs the ring kernel (the only
+ * body that honours states_lazy: runner.py:199's fp32 row left out), 0 when it would fall back to the per-step persistent
+ * body -- same predicate as the launcher's (LDS budget, conv1 output <= 512 pixels, weight alignment, A2C_NO_RING /
+ * A2C_RING_BLOCKS read per call).  A caller asks this BEFORE it decides to leave the rows out; a2c_a3c_rollout with
+ * states_lazy set on a shape that is not ring-capable returns A2C_ERR_ARG.                                            */
+int a2c_a3c_ring_supported(int B, int C, int H, int W, int n_actions, const float *conv1_weight);
 
 /* ------------------------------------------------------------------ b: pinned staging
  * The pool region lives in POSIX shared memory (shm_open name `shm_name`, created by this call)
@@ -326,7 +332,8 @@ int a2c_pinned_unregister(void *host);
  * sides; zero-filled).  The native env worker threads of a pool started with a2c_pool_threads_start_push mirror every
  * answer there (packed / uint8 frame, sfence, rec granule, sfence), and a2c_a3c_rollout / a2c_pool_ingest* given the
  * push addresses poll and fetch from HBM instead of reading host memory over PCIe (training.py:93-101's shared tensors,
- * for the host -> device direction).  A2C_ERR_LAUNCH when the platform refuses the allocation.                  */
+ * for the host -> device direction).  A2C_ERR_LAUNCH when the platform refuses the allocation OR the memory is not
+ * writable from the host (no large BAR; checked with a guarded probe write that the device reads back).           */
 int a2c_push_buffer_alloc(size_t bytes, void **ptr_out);
 int a2c_push_buffer_free(void *ptr);
 /* host threads waiting in hipStreamSynchronize sleep instead of spinning (hipDeviceScheduleBlockingSync): for

@@ -102,6 +102,7 @@ SIGNATURES = {
     "a2c_conv2d_prep_floats": (c_size_t, [PD, c_int]),
     "a2c_compose_heads": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "a2c_a3c_step_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "a2c_a3c_ring_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "a2c_a3c_step": (c_int, [PS, P]),
     "a2c_a3c_rollout": (c_int, [PR, P]),
     "a2c_rollout_buffer_create": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_void_p)]),

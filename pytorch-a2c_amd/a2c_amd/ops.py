@@ -181,21 +181,31 @@ REDUCE_SCRATCH_DOUBLES = 8 + 3 * 1024        # A2C_REDUCE_SCRATCH_DOUBLES of inc
 _reduce_scratch = {}
 
 
+def new_reduce_scratch(device):
+    """zero-initialised scratch (ticket word + per-workgroup partials) of the deterministic scalar reductions (a2c_moments,
+    a2c_loss_fwd_bwd, a2c_gradnorm_sq).  ONE buffer per OWNER (an Updater, an optimiser): the kernels an owner enqueues run
+    one after the other on its stream and each leaves the ticket word zero, so the address is stable across hipGraph
+    captures -- and two owners (two captured updates replayed on different streams) never share a ticket.  Allocated
+    outside any capture: a buffer born inside one would live in that graph's private pool."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("reduce scratch requested during a hipGraph capture: run the update eagerly once first")
+    return torch.zeros(REDUCE_SCRATCH_DOUBLES, dtype=torch.float64, device=device)
+
+
 def reduce_scratch(device, st):
-    """the zero-initialised scratch of the deterministic scalar reductions (a2c_moments, a2c_loss_fwd_bwd, a2c_gradnorm_sq):
-    ONE persistent buffer per (device, stream) -- the kernels of a stream run one after the other and each leaves the
-    ticket word zero -- so its address is stable across hipGraph captures"""
+    """fallback for callers without an owner (the torch.ops side door, kernel tests): one buffer per (device, stream)"""
     key = (str(device), int(st))
     buf = _reduce_scratch.get(key)
     if buf is None:
-        buf = _reduce_scratch[key] = torch.zeros(REDUCE_SCRATCH_DOUBLES, dtype=torch.float64, device=device)
+        buf = _reduce_scratch[key] = new_reduce_scratch(device)
     return buf
 
 
-def moments(x, sums, st=None):
+def moments(x, sums, st=None, scratch=None):
     _chk(x, "x"); _chk(sums, "sums", torch.float64)
     st = st if st is not None else stream()
-    check(lib().a2c_moments(_p(x), x.numel(), _p(sums), _p(reduce_scratch(x.device, st)), st), "a2c_moments")
+    scratch = scratch if scratch is not None else reduce_scratch(x.device, st)
+    check(lib().a2c_moments(_p(x), x.numel(), _p(sums), _p(scratch), st), "a2c_moments")
 
 
 def normalize(x, y, sums, n_global, eps=1e-6, st=None):
@@ -317,6 +327,11 @@ def a3c_step_supported(C, H, W, n_actions):
     return bool(lib().a2c_a3c_step_supported(int(C), int(H), int(W), int(n_actions)))
 
 
+def a3c_ring_supported(B, C, H, W, n_actions, conv1_weight_ptr):
+    """a2c_a3c_rollout would run the ring kernel (the body that can leave the fp32 state rows out) for this call"""
+    return bool(lib().a2c_a3c_ring_supported(int(B), int(C), int(H), int(W), int(n_actions), int(conv1_weight_ptr)))
+
+
 def a3c_step(st=None, **kw):
     """One whole rollout step of the A3CModel-shaped policy in one launch (see a2c_a3c_step in the
     header).  Keyword arguments are the fields of a2c_a3c_step_args (pointers as ints, 0 = NULL)."""
@@ -409,7 +424,7 @@ def permute_rows(src, dst, R, T, n, st=None):
 
 # ---------------------------------------------------------------- loss
 def loss_fwd_bwd(logits, vals, actions, advs, returns, adv_sums, n_global, pi_coef, val_coef, entr_coef, dlogits,
-                 dvals, loss_sums, st=None):
+                 dvals, loss_sums, st=None, scratch=None):
     """logits (N,A) / dlogits (N,A) may be column slices of wider (N,A+1) buffers and vals / dvals
     their last column: only stride(0) is used for addressing."""
     _chk(logits, "logits", contig=False); _chk(vals, "vals", contig=False)
@@ -421,7 +436,8 @@ def loss_fwd_bwd(logits, vals, actions, advs, returns, adv_sums, n_global, pi_co
     check(lib().a2c_loss_fwd_bwd(_p(logits), logits.stride(0), _p(vals), vals.stride(0), _p(actions), _p(advs),
                                  _p(returns), _p(adv_sums), n, n_global, A, float(pi_coef), float(val_coef),
                                  float(entr_coef), _p(dlogits), dlogits.stride(0), _p(dvals), dvals.stride(0),
-                                 _p(loss_sums), _p(reduce_scratch(logits.device, st)), st), "a2c_loss_fwd_bwd")
+                                 _p(loss_sums), _p(scratch if scratch is not None else reduce_scratch(logits.device, st)), st),
+          "a2c_loss_fwd_bwd")
 
 
 # ---------------------------------------------------------------- dense
@@ -652,10 +668,10 @@ def layernorm_bwd(dy, x, w, mean, rstd, dx, dw_rows, accumulate=False, st=None):
 
 
 # ---------------------------------------------------------------- clip + optimiser
-def gradnorm_sq(grads, sumsq, st=None):
+def gradnorm_sq(grads, sumsq, st=None, scratch=None):
     st = st if st is not None else stream()
-    check(lib().a2c_gradnorm_sq(_p(grads), grads.numel(), _p(sumsq), _p(reduce_scratch(grads.device, st)), st),
-          "a2c_gradnorm_sq")
+    scratch = scratch if scratch is not None else reduce_scratch(grads.device, st)
+    check(lib().a2c_gradnorm_sq(_p(grads), grads.numel(), _p(sumsq), _p(scratch), st), "a2c_gradnorm_sq")
 
 
 def clip_rmsprop(params, grads, square_avg, sumsq, max_norm, lr, alpha, eps, norm_out, st=None):

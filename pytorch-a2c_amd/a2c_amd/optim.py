@@ -25,6 +25,7 @@ class _Fused(torch.optim.Optimizer):
         self._flat = {k: torch.zeros(ar.n_train, dtype=torch.float32, device=ar.params.device)
                       for k in self._state_names}
         self._stats = torch.zeros(2, dtype=torch.float64, device=ar.params.device)   # [sum g^2, -]
+        self._scratch = None         # this optimiser's own reduction scratch (ops.new_reduce_scratch), made on first use
         self._norm = torch.zeros(1, dtype=torch.float32, device=ar.params.device)
         self._steps = 0
         self._name_of = {id(p): n for n, p in net.named_parameters()}
@@ -79,7 +80,9 @@ class _Fused(torch.optim.Optimizer):
         ar = self.net._arena
         st = st if st is not None else ops.stream()
         g = ar.train_grads()
-        ops.gradnorm_sq(g, self._stats[:1], st)
+        if self._scratch is None or self._scratch.device != g.device:
+            self._scratch = ops.new_reduce_scratch(g.device)
+        ops.gradnorm_sq(g, self._stats[:1], st, scratch=self._scratch)
         self._steps += 1
         self._launch(ar.train_params(), g, float("1e30") if max_norm is None else float(max_norm), st)
         self.net.mark_dirty()

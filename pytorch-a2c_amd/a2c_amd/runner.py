@@ -250,10 +250,15 @@ class Runner:
                 # (a caller that trickles them) still work: whatever arrived is played in lock-step rounds.
                 n_tok = int(try_key(self.hyps, "n_rollouts", None) or self.B)
                 stop = False
-                # The rest of the epoch's tokens: block for them (a partial batch would be played with a different
-                # slot -> env mapping, which defeats the activation stash and captures a second set of slot graphs); a
-                # caller that really trickles fewer tokens than n_rollouts says so with hyps["gate_timeout_s"]
+                # The rest of the epoch's tokens: wait for them (a partial batch would be played with a different
+                # slot -> env mapping, which defeats the activation stash and captures a second set of slot graphs) --
+                # but never forever: after hyps["gate_timeout_s"] without a further token (default 30 s; 0.05 s when the
+                # caller did not say how many slots an epoch has, i.e. no "n_rollouts" key) whatever arrived is played,
+                # so a caller that trickles fewer tokens, or two Runners sharing one gate_q, make progress and their
+                # stop_q consumers wake up.
                 gate_to = try_key(self.hyps, "gate_timeout_s", None)
+                if gate_to is None:
+                    gate_to = 30.0 if try_key(self.hyps, "n_rollouts", None) else 0.05
                 while len(idxs) < n_tok:
                     try:
                         tok = self.gate_q.get(timeout=gate_to)
@@ -866,13 +871,11 @@ class Runner:
         # single-frame uint8 store (row f4): T+4 frames per slot, created with the bookmark in start(); the update's
         # first-layer weight gradient stacks the frames on load instead of reading the 4x duplicated fp32 states
         fs = self._frame_store(T, D["states"].shape[0] // T, dev)
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        # only the ring kernel can leave the fp32 rows out (more envs than CUs: interleaved blocks of it, one after the other)
-        lazy = (fs is not None and bool(try_key(hyps, "lazy_states", False)) and os.environ.get("A2C_NO_RING") != "1"
-                and (B <= cus or os.environ.get("A2C_RING_BLOCKS") != "0"))
-        if lazy:
-            self._states_stale = True
-            net._materialize_states = self.materialize_states
+        # only the ring kernel can leave the fp32 rows out (more envs than CUs: interleaved blocks of it, one after the
+        # other); the library answers whether THIS call runs it (LDS budget, conv1 output size, weight alignment,
+        # A2C_NO_RING / A2C_RING_BLOCKS) -- a shape that does not gets its rows written by the per-step body instead
+        lazy = (fs is not None and bool(try_key(hyps, "lazy_states", False)) and
+                ops.a3c_ring_supported(B, C, H, W, net.output_space, P("convs.0.0.weight").data_ptr()))
         ops.a3c_rollout(st, B=B, C=C, H=H, W=W, n_actions=net.output_space, states=D["states"].data_ptr(),
                         bookmark=bm.data_ptr(), wfrag1=net._c1.wf.data_ptr(), bias1=P("convs.0.0.bias").data_ptr(),
                         wfrag2=net._c2.wf.data_ptr(), bias2=P("convs.1.0.bias").data_ptr(), Wc=net._Wc.data_ptr(),
@@ -894,6 +897,9 @@ class Runner:
                         nvalid_carry=0 if fs is None else fs[2][env0:env0 + B].data_ptr(), states_lazy=int(lazy),
                         tagged=getattr(pool, "dev_tagged", 0), tagged_stride=int(pool.header.tagged_stride),
                         tagged_chunks=int(pool.header.tagged_chunks))
+        if lazy:            # (only after the launch was accepted: a refused call must not leave rows marked stale)
+            self._states_stale = True
+            net._materialize_states = self.materialize_states
         if fs is not None and self._stash_bufs is not None:
             self._frames_written = (fs[0], fs[1], T)
         self._stash_used = self._stash_bufs is not None

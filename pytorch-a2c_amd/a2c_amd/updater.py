@@ -141,6 +141,7 @@ class Updater:
                      advs=torch.empty(N, device=dev), rets=torch.empty(N, device=dev),
                      vals_c=torch.empty(N, device=dev),
                      stats=torch.zeros(8, dtype=torch.float64, device=dev),   # [adv sums 0:2 | loss sums 2:5 | ret 5:7]
+                     scratch=ops.new_reduce_scratch(dev),     # this updater's ticket + partials (never shared, never born in a capture)
                      err=torch.zeros(1, dtype=torch.int32, device=dev),
                      out5=torch.zeros(5, dtype=torch.float64, device=dev),
                      host=torch.zeros(8, dtype=torch.float64).pin_memory() if torch.cuda.is_available() else None)
@@ -207,12 +208,12 @@ class Updater:
         adv_sums = None
         if hyps["norm_advs"]:           # (advs - mean)/(std + 1e-6) over the WHOLE batch (updater.py:97-98)
             adv_sums = stats[0:2]
-            ops.moments(advs, adv_sums, st)
+            ops.moments(advs, adv_sums, st, scratch=b["scratch"])
             sh.allreduce_(adv_sums)
 
         db, dl, dv = net.dheads("train", N)
         ops.loss_fwd_bwd(logits, vals, actions, advs, rets, adv_sums, n_global, try_key(hyps, "pi_coef", 1.0), hyps["val_coef"],
-                         hyps["entr_coef"], dl, dv, stats[2:5], st)
+                         hyps["entr_coef"], dl, dv, stats[2:5], st, scratch=b["scratch"])
 
         # backward into the flat gradient arena
         if use_bptt:
@@ -296,7 +297,7 @@ class Updater:
         """EMA-normalised returns (updater.py:89-96, default off): needs the batch mean/std on the
         host to update the running values, hence one extra read-back."""
         sums = stats[5:7]
-        ops.moments(rets, sums, st)
+        ops.moments(rets, sums, st, scratch=self._bufs["scratch"])
         self.shard.allreduce_(sums)
         s0, s1 = (float(v) for v in sums.cpu())
         mean = s0 / n_global

@@ -75,6 +75,26 @@ int a2c_push_buffer_alloc(size_t bytes, void** ptr_out) {
     (void)hipFree(d);
     return A2C_ERR_LAUNCH;
   }
+  // hipExtMallocWithFlags succeeds without a large BAR too; the env worker threads would then fault on their first
+  // _mm_stream store.  Guarded probe: the KERNEL stores a pattern through the pointer (read() from a pipe = copy_to_user:
+  // EFAULT, not SIGSEGV, when the address is not mapped into this process) and the device must read that pattern back.
+  bool ok = false;
+  int pfd[2];
+  if (pipe(pfd) == 0) {
+    const unsigned long long pat = 0xA2C0BA5EC0FFEE01ull;
+    unsigned long long back = 0;
+    if (write(pfd[1], &pat, sizeof pat) == (ssize_t)sizeof pat && read(pfd[0], d, sizeof pat) == (ssize_t)sizeof pat &&
+        hipMemcpy(&back, d, sizeof back, hipMemcpyDeviceToHost) == hipSuccess && back == pat)
+      ok = true;
+    close(pfd[0]);
+    close(pfd[1]);
+  }
+  (void)hipGetLastError();
+  if (!ok || hipMemset(d, 0, sizeof(unsigned long long)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(d);
+    return A2C_ERR_LAUNCH;         // not host-writable: the caller keeps the pinned host region (ThreadEnvPool: push_ptr = 0)
+  }
   *ptr_out = d;
   return A2C_OK;
 }

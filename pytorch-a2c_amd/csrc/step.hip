@@ -1244,6 +1244,18 @@ static bool set_lds_attr() {
 }
 }  // namespace
 
+/* the ring kernel's preconditions in ONE place: a2c_a3c_rollout launches it exactly when this holds, and
+ * a2c_a3c_ring_supported answers the same question for the caller that wants to leave the fp32 state rows out
+ * (states_lazy).  The environment switches are read per call (tests and A/B scripts flip them). */
+static bool ring_applies(const StepP& p, int B, int cus, int hnt, const float* conv1_weight) {
+  const char* nr = getenv("A2C_NO_RING");
+  if (nr != nullptr && nr[0] == '1') return false;
+  const char* rb = getenv("A2C_RING_BLOCKS");
+  const bool ring_blocks = !(rb != nullptr && rb[0] == '0');
+  return conv1_weight != nullptr && ((uintptr_t)conv1_weight % 4) == 0 && (B <= cus || ring_blocks) &&
+         ring_lds(p, hnt) <= 160 * 1024 && (p.OH1 * p.OW1 + 15) / 16 <= 32;
+}
+
 static unsigned long long* g_ring_dbg = nullptr;
 extern "C" {
 /* debug: device buffer of 10 x uint64 that receives the summed phase stamps (100 MHz ticks) of workgroup 0 of every
@@ -1263,6 +1275,16 @@ int a2c_debug_step_ts(unsigned long long* out) {
 int a2c_a3c_step_supported(int C, int H, int W, int n_actions) {
   StepP p;
   return step_shapes(C, H, W, n_actions, p) && step_lds(p) <= 160 * 1024 ? 1 : 0;
+}
+
+int a2c_a3c_ring_supported(int B, int C, int H, int W, int n_actions, const float* conv1_weight) {
+  StepP p;
+  p.a = a2c_a3c_step_args{};
+  p.x = RolloutX{};
+  if (B < 1 || !step_shapes(C, H, W, n_actions, p) || step_lds(p) > 160 * 1024 || !u8_shapes(H, W)) return 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  return ring_applies(p, B, cus, n_actions + 1 <= 4 ? 4 : 8, conv1_weight) ? 1 : 0;
 }
 
 int a2c_a3c_step(const a2c_a3c_step_args* args, a2c_stream_t stream) {
@@ -1359,16 +1381,12 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
   // every env has a CU to itself: the state stays in LDS for the whole slot (a3c_ring_kernel)
   const int hnt = a.n_actions + 1 <= 4 ? 4 : 8;
-  static const bool no_ring = getenv("A2C_NO_RING") != nullptr && getenv("A2C_NO_RING")[0] == '1';
   // More envs than CUs: ceil(B / CUs) launches one after the other, launch k playing the envs b = k (mod nblk) -- every env
   // worker thread owns a contiguous range of envs, so an interleaved block keeps ALL of them busy.  (The one-launch
   // alternative below takes the envs of a CU in turns and re-reads / re-writes the fp32 state row every step: 23.8 us per
   // env step at 2048 envs against the ring's 16-17.)  A2C_RING_BLOCKS=0: ring kernel only when B <= CUs.
-  const char* rb_ = getenv("A2C_RING_BLOCKS");                 // (read per call: tests switch it)
-  const bool ring_blocks = !(rb_ != nullptr && rb_[0] == '0');
   p.x.bstride = 1; p.x.boff = 0;
-  if (!no_ring && r->conv1_weight && (a.B <= cus || ring_blocks) && ring_lds(p, hnt) <= 160 * 1024 && (p.OH1 * p.OW1 + 15) / 16 <= 32 &&
-      ((uintptr_t)r->conv1_weight % 4) == 0) {
+  if (ring_applies(p, a.B, cus, hnt, r->conv1_weight)) {
     const size_t rl = ring_lds(p, hnt);
     const int nblk = (a.B + cus - 1) / cus;
     p.x.bstride = nblk;

@@ -148,6 +148,31 @@ def test_runner_run_queue_protocol():
     assert sorted(stop.get(timeout=120) for _ in range(B)) == list(range(B))
 
 
+def test_runner_run_plays_a_partial_batch_after_the_gate_timeout():
+    """a caller that re-opens the gate with FEWER tokens than hyps['n_rollouts'] (or two Runners on one gate_q) must not
+    hang Runner.run forever: after hyps['gate_timeout_s'] without a further token what arrived is played and answered"""
+    from a2c_amd.runner import Runner
+    B, T, A, ss = 3, 4, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, n_envs=B, gate_timeout_s=0.5)
+    net = make_net("A3CModel", ss, A, 256)
+    D = _datas(B * T, ss, False)
+    gate, stop, rew = queue.Queue(), queue.Queue(), queue.Queue(1)
+    rew.put(-1)
+    ekws = [dict(env_id=j, rew_period=2, done_period=5) for j in range(B)]
+    r = Runner(D, hyps, gate, stop, rew, env_pool=_fake_pool(ekws))
+    th = threading.Thread(target=r.run, args=(net,), daemon=True)
+    gate.put(0)
+    gate.put(1)                      # two of three tokens
+    th.start()
+    assert sorted(stop.get(timeout=120) for _ in range(2)) == [0, 1]
+    torch.cuda.synchronize()
+    d = D["dones"].view(B, T)
+    assert float(d[:2, -1].min()) == 1.0 and float(D["states"].view(B, -1)[2].abs().sum()) == 0.0      # slot 2 untouched
+    gate.put(None)                   # shutdown token
+    th.join(30)
+    assert not th.is_alive() and r.error is None
+
+
 def test_stats_runner_and_get_action():
     from a2c_amd.runner import StatsRunner
 

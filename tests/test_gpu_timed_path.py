@@ -225,7 +225,10 @@ def _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, max_norm):
     tensor's rms from fp64 (tools/dbg/fullsize_grad_stats.py), so an element-wise 1e-5 comparison with them would test noise."""
     for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy"):
         assert info[k] == pytest.approx(oinfo[k], rel=3e-5, abs=2e-6), (k, info[k], oinfo[k])
-        assert abs(info[k] - oinfo64[k]) <= 2 * abs(oinfo[k] - oinfo64[k]) + 1e-6 * abs(oinfo64[k]) + 1e-9, k
+        # ... and no further from the fp64 evaluation than torch's fp32 path is, up to the noise floor of a mean of N terms
+        # of size O(1) each carrying ~1e-7 of fp32 rounding (Pi_Loss = mean(log_p * adv) cancels to ~1e-3 with normalised
+        # advantages: the floor is absolute, 1e-7 / sqrt(N) x a few -- 3e-8 at N = 2,048)
+        assert abs(info[k] - oinfo64[k]) <= 2 * abs(oinfo[k] - oinfo64[k]) + 1e-6 * abs(oinfo64[k]) + 3e-8, k
     assert oinfo64["GradNorm"] <= max_norm          # (no clipping at these sizes: the recorded grads are the raw ones)
     assert info["GradNorm"] == pytest.approx(oinfo64["GradNorm"], rel=5e-6), (info["GradNorm"], oinfo64["GradNorm"])
     for (n, p), (n2, q) in zip(net.named_parameters(), onet.named_parameters()):

@@ -88,6 +88,19 @@ class _HipNet(nn.Module):
         self._stash_frames = None
 
     # ---- rollout -> update activation stash (models with a one-launch rollout step)
+    def _conv_chain(self):
+        """ops.ConvChain over layers 1 .. n-1, or None when the library has no chain kernel for them"""
+        ch = getattr(self, "_chain", 0)
+        if ch == 0:
+            ch = None
+            if len(self._cl) >= 2 and not any(l.padded for l in self._cl[1:]):
+                c = ops.ConvChain([l.d for l in self._cl[1:]])
+                ch = c if c.ok else None
+            self._chain = ch
+        if ch is not None and os.environ.get("A2C_NO_CHAIN") == "1":
+            return None
+        return ch
+
     def stash_rows(self, states, n_rows, T=None):
         """Buffers a rollout may fill with the conv activations of its states (row e of the rollout buffer ->
         row e of the "train" workspace), or None when the model has no stash / it is disabled.  T = n_tsteps."""
@@ -474,8 +487,31 @@ class _ConvStackNet(_HipNet):
         ptr, bs = x_ptr, bstride
         sl = self._sign_layers() if (stash is not None or train) else {}
         fsrc = getattr(self, "_frames_src", None)       # rollout step: layer 0 stacks its input on load (runner, row f4)
+        # layers 1 .. n-1 of a rollout-sized batch as ONE launch where the library has a chain kernel for them (GRUModel's four
+        # stride-2 layers: a workgroup walks one sample through all of them; bit-identical to the per-layer launches)
+        chain = self._conv_chain() if (not train and 64 < B <= 4096 and all(i == 1 for i in sl if i >= 1)) else None
         for i, l in enumerate(self._cl):
             n = int(np.prod(l.out_shape))
+            if chain is not None and i == 1:
+                nl = len(self._cl)
+                if stash is None:
+                    outs = [ws.get(f"a{k}", (B,) + self._cl[k].out_shape) for k in range(1, nl)]
+                    optrs, obss = [o.data_ptr() for o in outs], [int(np.prod(self._cl[k].out_shape)) for k in range(1, nl)]
+                    sg = (ws.get("sg1", (B, sl[1]), dtype=torch.int32).data_ptr(), sl[1]) if 1 in sl else None
+                else:
+                    bufs, row0, rstride = stash
+                    ns = [int(np.prod(self._cl[k].out_shape)) for k in range(1, nl)]
+                    optrs = [bufs[k].data_ptr() + 4 * row0 * ns[k - 1] for k in range(1, nl)]
+                    obss = [rstride * v for v in ns]
+                    sg = (self._sign_bufs[1].data_ptr() + 4 * row0 * sl[1], rstride * sl[1]) if 1 in sl else None
+                with ops.span("conv2-5.fwd_chain"):
+                    chain.fwd(ptr, bs, [c.wf for c in self._cl[1:]], [self.P(f"convs.{k}.0.bias") for k in range(1, nl)], optrs,
+                              obss, B, st, signs0=sg)
+                if 1 in sl:
+                    self._signs_ok[1] = (self._signs_ok.get(1, True) if (stash is not None and stash[1]) else True)
+                for k in range(1, nl):
+                    acts.append((optrs[k - 1], obss[k - 1]))
+                return acts
             if stash is None:
                 a = ws.get(f"a{i}", (B,) + l.out_shape)
                 sg = None

@@ -278,17 +278,19 @@ __global__ __launch_bounds__(256) void c3_prep_kernel(const float* __restrict__ 
 // SG (forward only): the epilogue also sets the sign bits of what it stores in an LDS band of sign words, and an ELEVENTH
 // wave carries the finished band's words to HBM under the next band's first chunk (needs NCH >= 2: a barrier between its
 // copy-and-clear and the next epilogue).  The computing waves and the stores are the direct-store kernel's.
-template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO = 0, bool SG = false>
-__global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG ? 1 : 0)))) void c3_kernel(C3P p) {
-  using G = C3Geo<CS, CD, H, W, S, R, KCO>;
+// The body of c3_kernel as a device function over the tiles tile0, tile0 + tstride, ... (nmine of them): the stand-alone
+// kernel deals the B * NBAND tiles of a launch round robin to its workgroups; the CHAIN kernel below (c3_chain_kernel) hands
+// a workgroup the bands of ONE sample, layer after layer.  NLO: loader waves of the block (0: the layer's own count),
+// XSG: the block has a sign-word wave (index NW + NL) whether or not this layer writes sign words -- a layer without them
+// parks it at the barriers (every wave of a workgroup must arrive at every s_barrier).
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO, bool SG, int NLO, bool XSG>
+__device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, const long tile0, const long tstride, const long nmine) {
+  using G = C3Geo<CS, CD, H, W, S, R, KCO, NLO>;
   static_assert(!SG || (!BWD && G::NCH >= 2), "sign words: forward, two chunks or more");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(!SG || XSG, "a layer that writes sign words needs the block's sign-word wave");
   unsigned* const sbits = reinterpret_cast<unsigned*>(lds + 2 * G::BUF);      // (SG)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
-  const long ntile = (long)p.B * G::NBAND;
-  long nmine = 0;
-  if ((long)blockIdx.x < ntile) nmine = (ntile - 1 - blockIdx.x) / gridDim.x + 1;
   const long nwork = nmine * G::NCH;              // work item k = (tile k / NCH, chunk k % NCH)
   // the zeros that never change: behind each buffer's last plane
   if (tid < 16) {
@@ -301,10 +303,15 @@ __global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG
   }
   if (S == 1 && G::GAP > 0) {                     // (stride 1 reads one float past a plane's last row)
     constexpr int GP = G::GAP > 0 ? G::GAP : 1;
-    for (int i = tid; i < 2 * G::KC * GP; i += 64 * (G::NW + G::NL + (SG ? 1 : 0))) {
+    for (int i = tid; i < 2 * G::KC * GP; i += 64 * (G::NW + G::NL + (XSG ? 1 : 0))) {
       const int bsel = i / (G::KC * GP), r = i - bsel * (G::KC * GP);
       lds[bsel * G::BUF + (r / GP) * G::PLANE + G::PL0 + (r % GP)] = 0.f;
     }
+  }
+  if (XSG && !SG && w == G::NW + G::NL) {         // (a chain layer without sign words: the wave only keeps the barrier count)
+    __syncthreads();
+    for (long k = 0; k < nwork; ++k) __syncthreads();
+    return;
   }
   if (SG && w == G::NW + G::NL) {
     // ------------------------------------------------------------------ sign-word writer
@@ -313,7 +320,7 @@ __global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG
     for (long k = 0; k < nwork; ++k) {
       c3_bar();                                   // (raw: this wave must not wait for its stores' acknowledgements here)
       if ((int)((unsigned)k % (unsigned)G::NCH) == G::NCH - 1 && p.sg_out != nullptr) {      // the band's epilogue is behind that barrier
-        const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+        const long tile = tile0 + ((unsigned)k / (unsigned)G::NCH) * tstride;
         const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
         const int band = (int)(tile - b * G::NBAND);
         const int nw = min(R, G::OH - band * R) * G::SRW;
@@ -364,7 +371,7 @@ __global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG
       }
     }
     auto dma = [&](long k) {
-      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const long tile = tile0 + ((unsigned)k / (unsigned)G::NCH) * tstride;
       const int ch = (int)((unsigned)k % (unsigned)G::NCH);
       const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
@@ -398,7 +405,7 @@ __global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG
     };
     // backward-data: the band's ReLU mask, one linear run per channel, issued while the band's FIRST chunk computes
     auto dma_mask = [&](long k) {      // the slice of the band's mask that travels beside chunk k (all but the last chunk carry one)
-      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const long tile = tile0 + ((unsigned)k / (unsigned)G::NCH) * tstride;
       const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int npx = min(R, G::OH - band * R) * G::OW;
@@ -468,7 +475,7 @@ __global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG
     if ((int)((unsigned)k % (unsigned)G::NCH) == G::NCH - 1) {
       // ---- the band is complete: accumulators -> HBM.  With the PIXELS as the MFMA's A operand the D tile is
       // [pixel][channel]: lane (j, g) holds pixels 4g .. 4g+3 of channel j -- one 16-byte store per lane and tile
-      const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      const long tile = tile0 + ((unsigned)k / (unsigned)G::NCH) * tstride;
       const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int npix_ok = min(R, G::OH - band * R) * G::OW;
@@ -511,6 +518,53 @@ __global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG
       }
     }
     __syncthreads();
+  }
+}
+
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO = 0, bool SG = false>
+__global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG ? 1 : 0)))) void c3_kernel(C3P p) {
+  using G = C3Geo<CS, CD, H, W, S, R, KCO>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const long ntile = (long)p.B * G::NBAND;
+  long nmine = 0;
+  if ((long)blockIdx.x < ntile) nmine = (ntile - 1 - blockIdx.x) / gridDim.x + 1;
+  c3_body<CS, CD, H, W, S, R, BWD, KCO, SG, 0, SG>(p, lds, (long)blockIdx.x, (long)gridDim.x, nmine);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward CHAIN of a rollout step (GRUModel conv2 .. conv5, models.py:570-636): one workgroup = one SAMPLE, running the
+// four stride-2 layers one after the other -- layer l+1 only needs layer l's rows of the SAME sample, so there is no
+// grid-wide dependency: the workgroup stores layer l's bands (the update's activation stash needs them in HBM anyway),
+// drains its stores, and its loader waves read them back (L2 / infinity cache: the CU that wrote them) as layer l+1's
+// source.  Per env step of 256 envs the four launches (16-58 us each, a fill and a tail per launch, 3 of 8 computing
+// waves busy on conv5's single 6 x 6 band per workgroup) become one launch in which every CU is busy from the first band
+// of conv2 to the last tile of conv5.  Same bodies, same tile shapes, same summation order: bit-identical to the four
+// launches (test).  Block = 8 computing waves + 4 loader waves + the sign-word wave.
+struct C3Chain4 { C3P l[4]; };
+__device__ __forceinline__ void c3_layer_sync() {
+  // every store of the finished layer (inline-asm stores the compiler does not track) acknowledged, visible at L2, and no
+  // stale line of the next layer's source in this CU's L1
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+template <bool SG2>
+__global__ __launch_bounds__(64 * 13) void c3_chain_gru_kernel(C3Chain4 cp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using G2 = C3Geo<16, 24, 84, 84, 2, 6, 0, 4>;
+  using G3 = C3Geo<24, 32, 42, 42, 2, 11, 0, 4>;
+  using G4 = C3Geo<32, 48, 21, 21, 2, 11, 0, 4>;
+  using G5 = C3Geo<48, 64, 11, 11, 2, 6, 24, 4>;
+  for (long b = blockIdx.x; b < cp.l[0].B; b += gridDim.x) {
+    c3_body<16, 24, 84, 84, 2, 6, false, 0, SG2, 4, true>(cp.l[0], lds, b * G2::NBAND, 1, G2::NBAND);
+    c3_layer_sync();
+    c3_body<24, 32, 42, 42, 2, 11, false, 0, false, 4, true>(cp.l[1], lds, b * G3::NBAND, 1, G3::NBAND);
+    c3_layer_sync();
+    c3_body<32, 48, 21, 21, 2, 11, false, 0, false, 4, true>(cp.l[2], lds, b * G4::NBAND, 1, G4::NBAND);
+    c3_layer_sync();
+    c3_body<48, 64, 11, 11, 2, 6, false, 24, false, 4, true>(cp.l[3], lds, b * G5::NBAND, 1, G5::NBAND);
+    c3_layer_sync();
   }
 }
 
@@ -2020,6 +2074,56 @@ int c3_fwd(const a2c_conv_desc* d, const float* in, long in_bs, const float* fra
   if (d->stride == 2 && d->H == 21 && d->Cin == 32) return c3_launch<32, 48, 21, 21, 2, 11, false>(p, st);
   if (d->stride == 2 && d->H == 11 && d->Cin == 48) return c3_launch<48, 64, 11, 11, 2, 6, false, 24>(p, st);
   return A2C_ERR_ARG;
+}
+
+// rollout-step chain: GRUModel conv2 .. conv5 (16 -> 24 @84, 24 -> 32 @42, 32 -> 48 @21, 48 -> 64 @11, all 3x3 / stride 2 / pad 1)
+bool c3_chain_supported(const a2c_conv_desc* d, int n) {
+  static const bool off = getenv("A2C_NO_C3") != nullptr && getenv("A2C_NO_C3")[0] == '1';
+  const char* nc = getenv("A2C_NO_CHAIN");        // (read per call: tests compare the chain with the four launches)
+  if (off || (nc != nullptr && nc[0] == '1') || n != 4) return false;
+  static const int cin[4] = {16, 24, 32, 48}, cout[4] = {24, 32, 48, 64}, hw[4] = {84, 42, 21, 11};
+  for (int i = 0; i < 4; ++i)
+    if (d[i].ks != 3 || d[i].pad != 1 || d[i].stride != 2 || d[i].Cin != cin[i] || d[i].Cout != cout[i] || d[i].H != hw[i] || d[i].W != hw[i])
+      return false;
+  return true;
+}
+
+int c3_chain_fwd(const a2c_conv_desc* d, int n, const float* in, long in_bs, const float* const* frag, const float* const* bias,
+                 int relu, float* const* out, const long* out_bs, unsigned* signs0, long signs0_bs, int B, hipStream_t st) {
+  if (!c3_chain_supported(d, n)) return A2C_ERR_ARG;
+  C3Chain4 cp;
+  const float* zp = zero_page();
+  if (!zp) return A2C_ERR_LAUNCH;
+  for (int i = 0; i < 4; ++i) {
+    cp.l[i] = C3P{i == 0 ? in : out[i - 1], i == 0 ? in_bs : out_bs[i - 1], frag[i], bias[i], nullptr, out[i], out_bs[i], zp, B, relu,
+                  nullptr, i == 0 ? signs0 : nullptr, nullptr, i == 0 ? signs0_bs : 0};
+    cp.l[i].prio = c3_prio();
+  }
+  using G2 = C3Geo<16, 24, 84, 84, 2, 6, 0, 4>;
+  using G3 = C3Geo<24, 32, 42, 42, 2, 11, 0, 4>;
+  using G4 = C3Geo<32, 48, 21, 21, 2, 11, 0, 4>;
+  using G5 = C3Geo<48, 64, 11, 11, 2, 6, 24, 4>;
+  constexpr size_t m1 = G2::LDS_BYTES_SG > G3::LDS_BYTES ? G2::LDS_BYTES_SG : G3::LDS_BYTES;
+  constexpr size_t m2 = G4::LDS_BYTES > G5::LDS_BYTES ? G4::LDS_BYTES : G5::LDS_BYTES;
+  constexpr size_t LDSB = m1 > m2 ? m1 : m2;
+  static_assert(LDSB <= 160 * 1024, "LDS");
+  static int per_cu[2] = {0, 0}, cus = 0;
+  const int v = signs0 != nullptr ? 1 : 0;
+  const void* k = v ? (const void*)c3_chain_gru_kernel<true> : (const void*)c3_chain_gru_kernel<false>;
+  if (!per_cu[v]) {
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB) != hipSuccess) return A2C_ERR_LAUNCH;
+    int nb = 0, dev = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * 13, LDSB) != hipSuccess || nb < 1) nb = 1;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    per_cu[v] = nb;
+  }
+  const long cap = (long)per_cu[v] * cus;
+  const int grid = (int)(B < cap ? B : cap);
+  if (v) hipLaunchKernelGGL((c3_chain_gru_kernel<true>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
+  else hipLaunchKernelGGL((c3_chain_gru_kernel<false>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
+  if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
+  return A2C_OK;
 }
 
 // first layer (4 -> 16 @ 84 x 84) with its input stacked on load from a single-frame uint8 store (C3U8)

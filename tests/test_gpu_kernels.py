@@ -992,3 +992,80 @@ def test_torch_ops_cover_the_model_and_optimiser_families():
         norm = o.clip_adam_(pd, gd, m1, m2, step, 0.5, 1e-3)
         assert float(norm) == pytest.approx(float(tn), rel=2e-6)
         close(f"adam params step {step}", pd, pr.detach(), 2e-7, 1e-6)
+
+
+@pytest.mark.parametrize("B,signs,strided", [(256, True, True), (300, False, False), (65, True, False)])
+def test_conv_chain_equals_the_per_layer_launches_bit_for_bit(B, signs, strided):
+    """a2c_conv2d_fwd_chain (one launch: a workgroup walks one sample through GRUModel's conv2 .. conv5, models.py:570-636)
+    against four a2c_conv2d_fwd[_signs] launches: same tiles, same summation order -> every activation and every sign word
+    bit for bit; the per-layer results against torch.  strided: outputs are rows of wider buffers (the rollout writes rows
+    slot * T + t of the update's activation stash); B = 300: more samples than CUs."""
+    ops = _ops()
+    specs = [(16, 84, 84, 24, 3, 2, 1), (24, 42, 42, 32, 3, 2, 1), (32, 21, 21, 48, 3, 2, 1), (48, 11, 11, 64, 3, 2, 1)]
+    descs = [ops.conv_desc(*s) for s in specs]
+    ch = ops.ConvChain(descs)
+    assert ch.ok
+    assert not ops.ConvChain(descs[:3]).ok and not ops.ConvChain([ops.conv_desc(16, 84, 84, 24, 3, 1, 1)] + descs[1:]).ok
+    x = torch.relu(rnd((B, 16, 84, 84), 880)).to(DEV)
+    ws, bs, wfs = [], [], []
+    for i, (d, s) in enumerate(zip(descs, specs)):
+        w = (rnd((s[3], s[0], 3, 3), 881 + i) / (s[0] * 9) ** 0.5 * 1.6).to(DEV)
+        b = (rnd((s[3],), 891 + i) * 0.1).to(DEV)
+        wf = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
+        ops.conv_prep(d, 0, w, wf)
+        ws.append(w); bs.append(b); wfs.append(wf)
+    mult = 3 if strided else 1          # row stride of the output buffers, in samples
+    nsw = ops.conv_sign_words(descs[0])
+
+    def run(chain):
+        outs = [torch.full((B * mult, d.Cout, d.OH, d.OW), float("nan"), device=DEV) for d in descs]
+        sg = torch.full((B * mult, nsw), -7, dtype=torch.int32, device=DEV) if signs else None
+        n = [d.Cout * d.OH * d.OW for d in descs]
+        optr = [o.data_ptr() + 4 * nn_ * (1 if strided else 0) for o, nn_ in zip(outs, n)]      # row 1, 1 + mult, ...
+        sgp = (sg.data_ptr() + 4 * nsw * (1 if strided else 0), mult * nsw) if signs else None
+        if chain:
+            ch.fwd(x.data_ptr(), 16 * 84 * 84, wfs, bs, optr, [mult * v for v in n], B, signs0=sgp)
+        else:
+            src, sbs = x.data_ptr(), 16 * 84 * 84
+            for i, d in enumerate(descs):
+                if i == 0 and signs:
+                    ops.conv_fwd_signs(d, src, sbs, wfs[i], bs[i], True, optr[i], sgp[0], sgp[1], B, out_bstride=mult * n[i])
+                else:
+                    ops.conv_fwd(d, src, sbs, wfs[i], bs[i], True, optr[i], B, out_bstride=mult * n[i])
+                src, sbs = optr[i], mult * n[i]
+        torch.cuda.synchronize()
+        return outs, sg
+    o_ref, sg_ref = run(False)
+    o_ch, sg_ch = run(True)
+    for i in range(4):
+        a, b = o_ch[i].view(torch.int32), o_ref[i].view(torch.int32)           # (NaN rows between the strided rows compare as bits)
+        assert torch.equal(a, b), i
+    if signs:
+        assert torch.equal(sg_ch, sg_ref)
+        rows = sg_ch[1::mult] if strided else sg_ch
+        assert torch.equal(rows.cpu(), _sign_words((o_ch[0][1::mult] if strided else o_ch[0]).cpu() > 0))
+    ref = x.cpu()
+    for i, s in enumerate(specs):
+        ref = F.relu(F.conv2d(ref, ws[i].cpu(), bs[i].cpu(), stride=2, padding=1))
+        got = o_ch[i][1::mult] if strided else o_ch[i]
+        close(f"chain layer {i}", got, ref, 1e-5, 1e-5)
+
+
+def test_conv_chain_argument_validation():
+    ops = _ops()
+    from a2c_amd import _lib
+    descs = [ops.conv_desc(16, 84, 84, 24, 3, 2, 1), ops.conv_desc(24, 42, 42, 32, 3, 2, 1), ops.conv_desc(32, 21, 21, 48, 3, 2, 1),
+             ops.conv_desc(48, 11, 11, 64, 3, 2, 1)]
+    ch = ops.ConvChain(descs)
+    wfs = [torch.zeros(ops.conv_prep_floats(d, 0), device=DEV) for d in descs]
+    bs = [torch.zeros(d.Cout, device=DEV) for d in descs]
+    outs = [torch.zeros(2, d.Cout, d.OH, d.OW, device=DEV) for d in descs]
+    x = torch.zeros(2, 16, 84, 84, device=DEV)
+    n = [d.Cout * d.OH * d.OW for d in descs]
+    ch.fwd(x.data_ptr(), 16 * 84 * 84, wfs, bs, [o.data_ptr() for o in outs], n, 2)          # fine
+    with pytest.raises(_lib.A2CKernelError):       # output stride smaller than a sample
+        ch.fwd(x.data_ptr(), 16 * 84 * 84, wfs, bs, [o.data_ptr() for o in outs], [n[0], n[1] - 4, n[2], n[3]], 2)
+    with pytest.raises(_lib.A2CKernelError):       # misaligned source
+        ch.fwd(x.data_ptr() + 4, 16 * 84 * 84, wfs, bs, [o.data_ptr() for o in outs], n, 2)
+    with pytest.raises(_lib.A2CKernelError):       # sign rows narrower than the layer's sign words
+        ch.fwd(x.data_ptr(), 16 * 84 * 84, wfs, bs, [o.data_ptr() for o in outs], n, 2, signs0=(outs[0].data_ptr(), 8))

@@ -283,13 +283,24 @@ __global__ __launch_bounds__(256) void c3_prep_kernel(const float* __restrict__ 
 // a workgroup the bands of ONE sample, layer after layer.  NLO: loader waves of the block (0: the layer's own count),
 // XSG: the block has a sign-word wave (index NW + NL) whether or not this layer writes sign words -- a layer without them
 // parks it at the barriers (every wave of a workgroup must arrive at every s_barrier).
-template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO, bool SG, int NLO, bool XSG>
-__device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, const long tile0, const long tstride, const long nmine) {
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO, bool SG, int NLO, bool XSG, bool CH>
+__device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, const long tile0_, const long nmine_) {
   using G = C3Geo<CS, CD, H, W, S, R, KCO, NLO>;
   static_assert(!SG || (!BWD && G::NCH >= 2), "sign words: forward, two chunks or more");
   static_assert(!SG || XSG, "a layer that writes sign words needs the block's sign-word wave");
   unsigned* const sbits = reinterpret_cast<unsigned*>(lds + 2 * G::BUF);      // (SG)
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int tid_ = threadIdx.x;
+  long nmine = nmine_;
+  if (CH) {
+    // (opaque copies: in the chain kernel the compiler otherwise (a) hoists every layer's lane-derived tables -- base[],
+    // roff[], rrow[], bias -- out of the sample loop and keeps them ALL live and (b) unrolls the work-item loop of the
+    // one-band layers, whose trip count it can see: 574 spilled registers, 3x the run time)
+    asm volatile("" : "+v"(tid_));
+    asm volatile("" : "+s"(nmine));
+  }
+  const long tile0 = CH ? tile0_ : (long)blockIdx.x;
+  const long tstride = CH ? 1L : (long)gridDim.x;
+  const int tid = tid_, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
   const long nwork = nmine * G::NCH;              // work item k = (tile k / NCH, chunk k % NCH)
   // the zeros that never change: behind each buffer's last plane
@@ -528,7 +539,7 @@ __global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG
   const long ntile = (long)p.B * G::NBAND;
   long nmine = 0;
   if ((long)blockIdx.x < ntile) nmine = (ntile - 1 - blockIdx.x) / gridDim.x + 1;
-  c3_body<CS, CD, H, W, S, R, BWD, KCO, SG, 0, SG>(p, lds, (long)blockIdx.x, (long)gridDim.x, nmine);
+  c3_body<CS, CD, H, W, S, R, BWD, KCO, SG, 0, SG, false>(p, lds, 0, nmine);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -542,12 +553,15 @@ __global__ __launch_bounds__((64 * (8 + C3Geo<CS, CD, H, W, S, R, KCO>::NL + (SG
 // launches (test).  Block = 8 computing waves + 4 loader waves + the sign-word wave.
 struct C3Chain4 { C3P l[4]; };
 __device__ __forceinline__ void c3_layer_sync() {
-  // every store of the finished layer (inline-asm stores the compiler does not track) acknowledged, visible at L2, and no
-  // stale line of the next layer's source in this CU's L1
+  // Every store of the finished layer (inline-asm stores the compiler does not track) acknowledged by L2, then the barrier:
+  // WORKGROUP scope is all this needs -- writer and reader are waves of one workgroup, i.e. one CU, one (write-through) L1
+  // and one XCD's L2.  (An agent-scope release / acquire here is a `buffer_wbl2 sc1` + `buffer_inv sc1` on this multi-XCD
+  // part: a write-back and invalidate of the XCD's whole L2 four times per sample -- measured 700 us per env step instead
+  // of 125.)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 template <bool SG2>
 __global__ __launch_bounds__(64 * 13) void c3_chain_gru_kernel(C3Chain4 cp) {
@@ -557,13 +571,13 @@ __global__ __launch_bounds__(64 * 13) void c3_chain_gru_kernel(C3Chain4 cp) {
   using G4 = C3Geo<32, 48, 21, 21, 2, 11, 0, 4>;
   using G5 = C3Geo<48, 64, 11, 11, 2, 6, 24, 4>;
   for (long b = blockIdx.x; b < cp.l[0].B; b += gridDim.x) {
-    c3_body<16, 24, 84, 84, 2, 6, false, 0, SG2, 4, true>(cp.l[0], lds, b * G2::NBAND, 1, G2::NBAND);
+    c3_body<16, 24, 84, 84, 2, 6, false, 0, SG2, 4, true, true>(cp.l[0], lds, b * G2::NBAND, G2::NBAND);
     c3_layer_sync();
-    c3_body<24, 32, 42, 42, 2, 11, false, 0, false, 4, true>(cp.l[1], lds, b * G3::NBAND, 1, G3::NBAND);
+    c3_body<24, 32, 42, 42, 2, 11, false, 0, false, 4, true, true>(cp.l[1], lds, b * G3::NBAND, G3::NBAND);
     c3_layer_sync();
-    c3_body<32, 48, 21, 21, 2, 11, false, 0, false, 4, true>(cp.l[2], lds, b * G4::NBAND, 1, G4::NBAND);
+    c3_body<32, 48, 21, 21, 2, 11, false, 0, false, 4, true, true>(cp.l[2], lds, b * G4::NBAND, G4::NBAND);
     c3_layer_sync();
-    c3_body<48, 64, 11, 11, 2, 6, false, 24, false, 4, true>(cp.l[3], lds, b * G5::NBAND, 1, G5::NBAND);
+    c3_body<48, 64, 11, 11, 2, 6, false, 24, false, 4, true, true>(cp.l[3], lds, b * G5::NBAND, G5::NBAND);
     c3_layer_sync();
   }
 }

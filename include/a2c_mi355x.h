@@ -534,6 +534,14 @@ int a2c_gru_gates(const float *gx, const float *gh, const float *b, const float 
                   float *r, float *rh, int B, int hdim, a2c_stream_t stream);
 int a2c_gru_out(const float *gx, const float *rh_u, const float *b, const float *h,
                 const float *z, float *c, float *h_new, int B, int hdim, a2c_stream_t stream);
+/* The whole cell forward of one rollout step (models.py:465-476 at batch n_envs) in two launches instead of five:
+ * x (B, xs; row stride ldx) and h (B, hdim) -> z, r, rh = r*h, c (may be NULL), h_new (may alias h: the in-place rollout
+ * step), with WxC = [W_x[0] | W_x[1] | W_x[2]] (xs, 3 hdim), WhC = [W_h[0] | W_h[1]] (hdim, 2 hdim), Wh2 = W_h[2] and
+ * b (3 hdim).  gx (B, 3 hdim) is scratch (its candidate columns carry x W_x[2] between the launches).  Bit-identical to
+ * a2c_gemm_f32 (x WxC, h WhC) + a2c_gru_gates + a2c_gemm_f32 (rh Wh2) + a2c_gru_out.  hdim % 32 == 0, xs % 8 == 0.    */
+int a2c_gru_cell_fwd(const float *x, int64_t ldx, const float *h, const float *WxC, const float *WhC,
+                     const float *Wh2, const float *b, float *gx, float *z, float *r, float *rh, float *c,
+                     float *h_new, int B, int xs, int hdim, a2c_stream_t stream);
 /* backward of stage2: given dh_new (B,h): dc_pre = dh_new*(1-z)*(1-c^2) (B,h) ;
  * dz = dh_new*(h - c) ; dh_direct = dh_new*z                                            */
 int a2c_gru_out_bwd(const float *dh_new, const float *h, const float *z, const float *c,

@@ -795,6 +795,12 @@ class _GruMixin:
         Wx, Wh, b = self.P("gru.W_x"), self.P("gru.W_h"), self.P("gru.b")
         gx, gh, z, r, rh, rhu, c, hn = (bufs[k] for k in ("gx", "gh", "z", "r", "rh", "rhu", "c", "hn"))
         cat = getattr(self, "_WxC", None) is not None and os.environ.get("A2C_NO_GRU_CAT") != "1"
+        if (cat and x is not None and B <= 1280 and hd % 32 == 0 and xs % 8 == 0 and x.stride(0) % 4 == 0
+                and os.environ.get("A2C_NO_GRU_FUSE") != "1"):
+            # a step at rollout batch: the five launches below (5-6 us each, launch-bound) as two, bit-identical
+            with ops.span("gru.cell_fwd"):
+                ops.gru_cell_fwd(x, h_in, self._WxC, self._WhC, Wh[2], b, gx, z, r, rh, c, hn, st)
+            return
         if x is not None:   # gx may have been precomputed for all time steps at once
             if cat:
                 self._mm(ws, 0, 0, B, 3 * hd, xs, x.data_ptr(), x.stride(0), self._WxC.data_ptr(), 3 * hd, gx.data_ptr(), 3 * hd, st)

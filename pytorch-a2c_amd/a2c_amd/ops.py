@@ -656,6 +656,14 @@ def gru_out(gx, rh_u, b, h, z, c, h_new, st=None):
                             st if st is not None else stream()), "a2c_gru_out")
 
 
+def gru_cell_fwd(x, h, WxC, WhC, Wh2, b, gx, z, r, rh, c, h_new, st=None):
+    """the whole cell forward of a rollout step in two launches (a2c_gru_cell_fwd); x may be a row-strided view"""
+    B, hd = h.shape
+    xs = x.shape[1]
+    check(lib().a2c_gru_cell_fwd(_p(x), x.stride(0), _p(h), _p(WxC), _p(WhC), _p(Wh2), _p(b), _p(gx), _p(z), _p(r), _p(rh),
+                                 _p(c), _p(h_new), B, xs, hd, st if st is not None else stream()), "a2c_gru_cell_fwd")
+
+
 def gru_out_bwd(dh_new, h, z, c, dc_pre, dz, dh, st=None):
     B, hd = h.shape
     check(lib().a2c_gru_out_bwd(_p(dh_new), _p(h), _p(z), _p(c), _p(dc_pre), _p(dz), _p(dh), B, hd,

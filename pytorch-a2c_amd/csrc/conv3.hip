@@ -191,6 +191,9 @@ __device__ __forceinline__ void c3_u8_zero_pads(float* __restrict__ buf, int lan
     *reinterpret_cast<float4*>(buf + (i / SR) * PLANE + (i % SR) * WP) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+template <int N>
+__device__ __forceinline__ void c3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 struct C3P {
   const float* src; long src_bs;      // source tensor (B, CS, H, W) and its sample stride (floats)
   const float* frag;                  // [chunk][tap][c4][m][64] weight fragments (c3_prep_kernel)
@@ -283,12 +286,19 @@ __global__ __launch_bounds__(256) void c3_prep_kernel(const float* __restrict__ 
 // a workgroup the bands of ONE sample, layer after layer.  NLO: loader waves of the block (0: the layer's own count),
 // XSG: the block has a sign-word wave (index NW + NL) whether or not this layer writes sign words -- a layer without them
 // parks it at the barriers (every wave of a workgroup must arrive at every s_barrier).
-template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO, bool SG, int NLO, bool XSG, bool CH>
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, int KCO, bool SG, int NLO, bool XSG, bool CH, int D = 2>
 __device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, const long tile0_, const long nmine_) {
   using G = C3Geo<CS, CD, H, W, S, R, KCO, NLO>;
+  // D chunk buffers in a ring, the loaders LOOK = D - 1 chunks ahead of the computing waves.  D = 2 is the plain double
+  // buffer (the loader waits for everything it issued: vmcnt(0)); D = 3 keeps a second chunk in flight across the barrier
+  // with a COUNTED vmcnt -- every chunk is the same number of DMA instructions per loader wave (NI below) -- so that a
+  // chunk's DMA latency (2-3 us under load against ~1.4 us of MFMAs per chunk at rollout batch) overlaps two chunks' work.
+  constexpr int LOOK = D - 1;
+  static_assert(D == 2 || (D == 3 && !BWD && !(CS == 4 && W % 4 == 0)), "ring of three: forward, fp32 source");
+  static_assert(G::KC % G::NL == 0 || D == 2, "counted vmcnt: every loader wave carries the same planes of every chunk");
   static_assert(!SG || (!BWD && G::NCH >= 2), "sign words: forward, two chunks or more");
   static_assert(!SG || XSG, "a layer that writes sign words needs the block's sign-word wave");
-  unsigned* const sbits = reinterpret_cast<unsigned*>(lds + 2 * G::BUF);      // (SG)
+  unsigned* const sbits = reinterpret_cast<unsigned*>(lds + D * G::BUF);      // (SG)
   int tid_ = threadIdx.x;
   long nmine = nmine_;
   if (CH) {
@@ -305,16 +315,16 @@ __device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, c
   const long nwork = nmine * G::NCH;              // work item k = (tile k / NCH, chunk k % NCH)
   // the zeros that never change: behind each buffer's last plane
   if (tid < 16) {
-    lds[G::IMG - 8 + (tid & 7)] = 0.f;
-    lds[G::BUF + G::IMG - 8 + (tid & 7)] = 0.f;
-    if (G::KC * G::PLANE < G::IMG - 8) {                  // (plane sizes that are not a multiple of 4 floats)
-      lds[G::KC * G::PLANE + (tid & 3)] = 0.f;
-      lds[G::BUF + G::KC * G::PLANE + (tid & 3)] = 0.f;
+#pragma unroll
+    for (int bsel = 0; bsel < D; ++bsel) {
+      lds[bsel * G::BUF + G::IMG - 8 + (tid & 7)] = 0.f;
+      if (G::KC * G::PLANE < G::IMG - 8)                  // (plane sizes that are not a multiple of 4 floats)
+        lds[bsel * G::BUF + G::KC * G::PLANE + (tid & 3)] = 0.f;
     }
   }
   if (S == 1 && G::GAP > 0) {                     // (stride 1 reads one float past a plane's last row)
     constexpr int GP = G::GAP > 0 ? G::GAP : 1;
-    for (int i = tid; i < 2 * G::KC * GP; i += 64 * (G::NW + G::NL + (XSG ? 1 : 0))) {
+    for (int i = tid; i < D * G::KC * GP; i += 64 * (G::NW + G::NL + (XSG ? 1 : 0))) {
       const int bsel = i / (G::KC * GP), r = i - bsel * (G::KC * GP);
       lds[bsel * G::BUF + (r / GP) * G::PLANE + G::PL0 + (r % GP)] = 0.f;
     }
@@ -387,7 +397,7 @@ __device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, c
       const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int y0 = band * R * S - 1;
-      float* __restrict__ buf = lds + (k & 1) * G::BUF;
+      float* __restrict__ buf = lds + (D == 2 ? (k & 1) : (long)((unsigned)k % (unsigned)D)) * G::BUF;
       const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * G::KC * H + y0) * W;
       const bool staged = U8OK && u8;              // (the uint8 window is expanded below, behind the fragment DMA)
 #pragma unroll
@@ -420,7 +430,7 @@ __device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, c
       const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int npx = min(R, G::OH - band * R) * G::OW;
-      float* __restrict__ mb = lds + 2 * G::BUF;
+      float* __restrict__ mb = lds + D * G::BUF;
       constexpr int CPP = G::NCH > 1 ? (CD + G::NCH - 2) / (G::NCH - 1) : CD;
       const int part = (int)((unsigned)k % (unsigned)G::NCH);
 #pragma unroll 1
@@ -433,14 +443,39 @@ __device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, c
         }
       }
     };
-    if (nwork > 0) dma(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the chunk has landed in LDS
-    __syncthreads();
-    for (long k = 0; k < nwork; ++k) {
-      if (k + 1 < nwork) dma(k + 1);
-      if (BWD && p.mask != nullptr && (int)((unsigned)k % (unsigned)G::NCH) < G::NCH - 1) dma_mask(k);
-      __builtin_amdgcn_s_waitcnt(0x0F70);
+    if constexpr (D == 2) {
+      if (nwork > 0) dma(0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the chunk has landed in LDS
       __syncthreads();
+      for (long k = 0; k < nwork; ++k) {
+        if (k + 1 < nwork) dma(k + 1);
+        if (BWD && p.mask != nullptr && (int)((unsigned)k % (unsigned)G::NCH) < G::NCH - 1) dma_mask(k);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+      }
+    } else {
+      // DMA instructions of one chunk issued by loader wave lw: its planes' pieces + its share of the fragment pieces (a
+      // partly filled instruction still issues: the predicates are per lane)
+      constexpr int NIP = (G::KC / G::NL) * G::NQ;
+      auto wait_younger = [&](bool one_younger) {      // everything but the youngest chunk (if any) has landed
+        if (!one_younger) { c3_wait_vm<0>(); return; }
+        static_assert(NIP + (G::NFQ + G::NL - 1) / G::NL <= 63, "vmcnt is 6 bits");
+        if (lw == 0) c3_wait_vm<NIP + (G::NFQ + G::NL - 1) / G::NL>();
+        else if (lw == 1) c3_wait_vm<NIP + (G::NFQ + G::NL - 2 > 0 ? (G::NFQ + G::NL - 2) / G::NL : 0)>();
+        else if (lw == 2) c3_wait_vm<NIP + (G::NFQ + G::NL - 3 > 0 ? (G::NFQ + G::NL - 3) / G::NL : 0)>();
+        else c3_wait_vm<NIP + (G::NFQ + G::NL - 4 > 0 ? (G::NFQ + G::NL - 4) / G::NL : 0)>();
+      };
+      static_assert(G::NL <= 4, "wait_younger");
+      for (int k = 0; k < LOOK; ++k)
+        if (k < nwork) dma(k);
+      // (raw barriers: __syncthreads()' fence would drain vmcnt and with it the chunk that is meant to stay in flight)
+      wait_younger(nwork > 1);                       // chunk 0 has landed, chunk 1 may still be in flight
+      c3_bar();
+      for (long k = 0; k < nwork; ++k) {
+        if (k + LOOK < nwork) dma(k + LOOK);         // into the slot chunk k - 1 left
+        wait_younger(k + 2 < nwork);                 // chunk k + 1 has landed before the barrier that opens it
+        c3_bar();
+      }
     }
     return;
   }
@@ -465,7 +500,7 @@ __device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, c
   for (int m = 0; m < G::MT; ++m) biasv[m] = (!BWD && p.bias && m * 16 + j < CD) ? p.bias[m * 16 + j] : 0.f;
   __syncthreads();
   for (long k = 0; k < nwork; ++k) {
-    const float* __restrict__ img = lds + (k & 1) * G::BUF;
+    const float* __restrict__ img = lds + (D == 2 ? (k & 1) : (long)((unsigned)k % (unsigned)D)) * G::BUF;
     const float* __restrict__ fr = img + G::IMG + lane;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -491,7 +526,7 @@ __device__ __forceinline__ void c3_body(const C3P& p, float* __restrict__ lds, c
       const int band = (int)(tile - b * G::NBAND);
       const int npix_ok = min(R, G::OH - band * R) * G::OW;
       const long o0 = b * p.out_bs + (long)band * R * G::OW;
-      const float* __restrict__ mb = lds + 2 * G::BUF;       // backward-data: the band's mask, staged by the loaders
+      const float* __restrict__ mb = lds + D * G::BUF;       // backward-data: the band's mask, staged by the loaders
 #pragma unroll
       for (int u = 0; u < G::TPW; ++u) {
         const int t = w + G::NW * u;
@@ -563,7 +598,7 @@ __device__ __forceinline__ void c3_layer_sync() {
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-template <bool SG2>
+template <bool SG2, int D>
 __global__ __launch_bounds__(64 * 13) void c3_chain_gru_kernel(C3Chain4 cp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using G2 = C3Geo<16, 24, 84, 84, 2, 6, 0, 4>;
@@ -571,13 +606,13 @@ __global__ __launch_bounds__(64 * 13) void c3_chain_gru_kernel(C3Chain4 cp) {
   using G4 = C3Geo<32, 48, 21, 21, 2, 11, 0, 4>;
   using G5 = C3Geo<48, 64, 11, 11, 2, 6, 24, 4>;
   for (long b = blockIdx.x; b < cp.l[0].B; b += gridDim.x) {
-    c3_body<16, 24, 84, 84, 2, 6, false, 0, SG2, 4, true, true>(cp.l[0], lds, b * G2::NBAND, G2::NBAND);
+    c3_body<16, 24, 84, 84, 2, 6, false, 0, SG2, 4, true, true, D>(cp.l[0], lds, b * G2::NBAND, G2::NBAND);
     c3_layer_sync();
-    c3_body<24, 32, 42, 42, 2, 11, false, 0, false, 4, true, true>(cp.l[1], lds, b * G3::NBAND, G3::NBAND);
+    c3_body<24, 32, 42, 42, 2, 11, false, 0, false, 4, true, true, D>(cp.l[1], lds, b * G3::NBAND, G3::NBAND);
     c3_layer_sync();
-    c3_body<32, 48, 21, 21, 2, 11, false, 0, false, 4, true, true>(cp.l[2], lds, b * G4::NBAND, G4::NBAND);
+    c3_body<32, 48, 21, 21, 2, 11, false, 0, false, 4, true, true, D>(cp.l[2], lds, b * G4::NBAND, G4::NBAND);
     c3_layer_sync();
-    c3_body<48, 64, 11, 11, 2, 6, false, 24, false, 4, true, true>(cp.l[3], lds, b * G5::NBAND, G5::NBAND);
+    c3_body<48, 64, 11, 11, 2, 6, false, 24, false, 4, true, true, 2>(cp.l[3], lds, b * G5::NBAND, G5::NBAND);
     c3_layer_sync();
   }
 }
@@ -1251,8 +1286,6 @@ constexpr bool C3_STAMPS = true;
 #else
 constexpr bool C3_STAMPS = false;
 #endif
-template <int N>
-__device__ __forceinline__ void c3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES>
 __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
@@ -2117,13 +2150,17 @@ int c3_chain_fwd(const a2c_conv_desc* d, int n, const float* in, long in_bs, con
   using G3 = C3Geo<24, 32, 42, 42, 2, 11, 0, 4>;
   using G4 = C3Geo<32, 48, 21, 21, 2, 11, 0, 4>;
   using G5 = C3Geo<48, 64, 11, 11, 2, 6, 24, 4>;
-  constexpr size_t m1 = G2::LDS_BYTES_SG > G3::LDS_BYTES ? G2::LDS_BYTES_SG : G3::LDS_BYTES;
-  constexpr size_t m2 = G4::LDS_BYTES > G5::LDS_BYTES ? G4::LDS_BYTES : G5::LDS_BYTES;
+  constexpr size_t l2 = (3 * (size_t)G2::BUF + G2::SBITB) * 4, l3 = 3 * (size_t)G3::BUF * 4, l4 = 3 * (size_t)G4::BUF * 4;   // rings of three
+  constexpr size_t m1 = l2 > l3 ? l2 : l3;
+  constexpr size_t m2 = l4 > G5::LDS_BYTES ? l4 : G5::LDS_BYTES;
   constexpr size_t LDSB = m1 > m2 ? m1 : m2;
   static_assert(LDSB <= 160 * 1024, "LDS");
-  static int per_cu[2] = {0, 0}, cus = 0;
-  const int v = signs0 != nullptr ? 1 : 0;
-  const void* k = v ? (const void*)c3_chain_gru_kernel<true> : (const void*)c3_chain_gru_kernel<false>;
+  static int per_cu[4] = {0, 0, 0, 0}, cus = 0;
+  const char* e3 = getenv("A2C_CHAIN_D");            // (read per call: A/B runs) 3 = rings of three chunk buffers
+  const int d3 = (e3 != nullptr && e3[0] == '3') ? 1 : 0;
+  const int v = (signs0 != nullptr ? 1 : 0) + 2 * d3;
+  const void* k = v == 0 ? (const void*)c3_chain_gru_kernel<false, 2> : v == 1 ? (const void*)c3_chain_gru_kernel<true, 2>
+                : v == 2 ? (const void*)c3_chain_gru_kernel<false, 3> : (const void*)c3_chain_gru_kernel<true, 3>;
   if (!per_cu[v]) {
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB) != hipSuccess) return A2C_ERR_LAUNCH;
     int nb = 0, dev = 0;
@@ -2134,8 +2171,10 @@ int c3_chain_fwd(const a2c_conv_desc* d, int n, const float* in, long in_bs, con
   }
   const long cap = (long)per_cu[v] * cus;
   const int grid = (int)(B < cap ? B : cap);
-  if (v) hipLaunchKernelGGL((c3_chain_gru_kernel<true>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
-  else hipLaunchKernelGGL((c3_chain_gru_kernel<false>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
+  if (v == 0) hipLaunchKernelGGL((c3_chain_gru_kernel<false, 2>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
+  else if (v == 1) hipLaunchKernelGGL((c3_chain_gru_kernel<true, 2>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
+  else if (v == 2) hipLaunchKernelGGL((c3_chain_gru_kernel<false, 3>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
+  else hipLaunchKernelGGL((c3_chain_gru_kernel<true, 3>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   return A2C_OK;
 }

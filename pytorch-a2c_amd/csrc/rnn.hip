@@ -82,6 +82,137 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The whole cell of a rollout step in TWO launches (models.py:465-476 at batch n_envs): the five launches above it
+// replaces -- x [Wx0|Wx1|Wx2], h [Wh0|Wh1], gates, (r*h) Wh2, out -- are 5-6 us each at 256 envs, i.e. launch-bound.
+//   gru_cell_zr_kernel   column tile of gate g in {z, r, candidate}: waves 0-3 the x-side product (K split four ways),
+//                        waves 4-7 the h-side product (z, r only); epilogue z / r / r*h, or the candidate's x-side sum
+//   gru_cell_out_kernel  (r*h) Wh2 tile (K split four ways) + tanh + the convex combination -> c, h_new
+// Same products, same K split, same MFMA order and the same order of additions as a2c_gemm_f32's small-product kernel
+// followed by gru_gates_kernel / gru_out_kernel: bit-identical to the five launches (test).
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// one wave's share of a 32 x 32 tile of A (M x K, row-major, lda) . B (K x N, row-major, ldb): K range [kbeg, kend)
+__device__ __forceinline__ f32x16 gru_tile_part(const float* __restrict__ arow, const float* __restrict__ bcol, long ldb,
+                                                long kbeg, long kend) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  long k = kbeg;
+  if ((kend - k) & 15) {                             // head: one 8-row group
+    const float4 a1 = *reinterpret_cast<const float4*>(arow + k);
+    const float b0 = bcol[k * ldb], b1 = bcol[(k + 1) * ldb], b2 = bcol[(k + 2) * ldb], b3 = bcol[(k + 3) * ldb];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b3, acc, 0, 0, 0);
+    k += 8;
+  }
+  for (; k < kend; k += 16) {                        // two 8-row groups in flight
+    float4 av[2];
+    float bv[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      av[u] = *reinterpret_cast<const float4*>(arow + k + 8 * u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[u][j] = bcol[(k + 8 * u + j) * ldb];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u][3], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(512) void gru_cell_zr_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ h,
+                                                          const float* __restrict__ WxC, const float* __restrict__ WhC,
+                                                          const float* __restrict__ b, float* __restrict__ gx,
+                                                          float* __restrict__ z, float* __restrict__ r, float* __restrict__ rh,
+                                                          long M, int xs, int hd) {
+  __shared__ __attribute__((aligned(16))) float red[8][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int tiles = hd / 32;
+  const int gate = blockIdx.x / tiles;
+  const long n0 = (long)(blockIdx.x - gate * tiles) * 32, m0 = (long)blockIdx.y * 32;
+  const bool xside = w < 4;
+  if (xside || gate < 2) {
+    const long K = xside ? xs : hd;
+    const int wk = w & 3;
+    const long kq = ((K / 8 + 3) / 4) * 8;
+    const long kbeg = min(K, wk * kq), kend = min(K, kbeg + kq);
+    const float* __restrict__ arow = (xside ? x + min(m0 + li, M - 1) * ldx : h + min(m0 + li, M - 1) * hd) + 4 * lk;
+    const long ldb = xside ? 3L * hd : 2L * hd;
+    const float* __restrict__ bcol = (xside ? WxC : WhC) + (long)gate * hd + n0 + li + (long)(4 * lk) * ldb;
+    const f32x16 acc = gru_tile_part(arow, bcol, ldb, kbeg, kend);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[w][q][lane] = acc[q];
+  }
+  __syncthreads();
+  // wave w finishes registers 2w, 2w+1 of every lane: col n = lane & 31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int q = w * 2 + e;
+    float gxv = red[0][q][lane];
+    gxv += red[1][q][lane];
+    gxv += red[2][q][lane];
+    gxv += red[3][q][lane];
+    const long m = m0 + (q & 3) + 8 * (q >> 2) + 4 * lk, n = n0 + li;
+    if (m >= M) continue;
+    if (gate == 2) {
+      gx[m * 3 * hd + 2 * hd + n] = gxv;
+      continue;
+    }
+    float ghv = red[4][q][lane];
+    ghv += red[5][q][lane];
+    ghv += red[6][q][lane];
+    ghv += red[7][q][lane];
+    const float v = sigmoidf_((gxv + ghv) + b[gate * hd + n]);
+    if (gate == 0) z[m * hd + n] = v;
+    else {
+      r[m * hd + n] = v;
+      rh[m * hd + n] = v * h[m * hd + n];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_cell_out_kernel(const float* __restrict__ gx, const float* __restrict__ rh,
+                                                           const float* __restrict__ Wh2, const float* __restrict__ b,
+                                                           const float* h, const float* __restrict__ z, float* __restrict__ cnd,
+                                                           float* hn, long M, int hd) {      // hn may alias h
+  __shared__ __attribute__((aligned(16))) float red[4][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const long n0 = (long)blockIdx.x * 32, m0 = (long)blockIdx.y * 32;
+  const long K = hd;
+  const long kq = ((K / 8 + 3) / 4) * 8;
+  const long kbeg = min(K, w * kq), kend = min(K, kbeg + kq);
+  const f32x16 acc = gru_tile_part(rh + min(m0 + li, M - 1) * hd + 4 * lk, Wh2 + n0 + li + (long)(4 * lk) * hd, hd, kbeg, kend);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) red[w][q][lane] = acc[q];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = w * 4 + e;
+    float v = red[0][q][lane];
+    v += red[1][q][lane];
+    v += red[2][q][lane];
+    v += red[3][q][lane];
+    const long m = m0 + (q & 3) + 8 * (q >> 2) + 4 * lk, n = n0 + li;
+    if (m >= M) continue;
+    const long i = m * hd + n;
+    const float cc = tanhf((gx[m * 3 * hd + 2 * hd + n] + v) + b[2 * hd + n]);
+    const float zz = z[i];
+    if (cnd) cnd[i] = cc;
+    hn[i] = zz * h[i] + (1.f - zz) * cc;
+  }
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y,
@@ -147,6 +278,23 @@ int a2c_gru_out(const float* gx, const float* rh_u, const float* b, const float*
   if (!gx || !rh_u || !b || !h || !z || !h_new) return A2C_ERR_ARG;
   hipLaunchKernelGGL(gru_out_kernel, dim3(a2c_grid_1d((long)B * hdim, 256)), dim3(256), 0, a2c_s(stream), gx, rh_u, b,
                      h, z, c, h_new, (long)B, hdim);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_gru_cell_fwd(const float* x, int64_t ldx, const float* h, const float* WxC, const float* WhC, const float* Wh2,
+                     const float* b, float* gx, float* z, float* r, float* rh, float* c, float* h_new, int B, int xs, int hdim,
+                     a2c_stream_t stream) {
+  if (B < 0 || hdim < 32 || hdim % 32 || xs < 8 || xs % 8 || hdim % 8 || ldx < xs || ldx % 4) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!x || !h || !WxC || !WhC || !Wh2 || !b || !gx || !z || !r || !rh || !h_new) return A2C_ERR_ARG;
+  if ((((uintptr_t)x | (uintptr_t)h | (uintptr_t)rh) % 16)) return A2C_ERR_ARG;
+  const int tiles = hdim / 32, rows = (B + 31) / 32;
+  hipLaunchKernelGGL(gru_cell_zr_kernel, dim3(3 * tiles, rows), dim3(512), 0, a2c_s(stream), x, (long)ldx, h, WxC, WhC, b, gx, z,
+                     r, rh, (long)B, xs, hdim);
+  A2C_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gru_cell_out_kernel, dim3(tiles, rows), dim3(256), 0, a2c_s(stream), gx, rh, Wh2, b, h, z, c, h_new,
+                     (long)B, hdim);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -1069,3 +1069,46 @@ def test_conv_chain_argument_validation():
         ch.fwd(x.data_ptr() + 4, 16 * 84 * 84, wfs, bs, [o.data_ptr() for o in outs], n, 2)
     with pytest.raises(_lib.A2CKernelError):       # sign rows narrower than the layer's sign words
         ch.fwd(x.data_ptr(), 16 * 84 * 84, wfs, bs, [o.data_ptr() for o in outs], n, 2, signs0=(outs[0].data_ptr(), 8))
+
+
+@pytest.mark.parametrize("B,xs,hd,inplace", [(256, 256, 256, True), (37, 256, 256, False), (300, 64, 96, False)])
+def test_gru_cell_fwd_two_launches_equal_the_five_bit_for_bit(B, xs, hd, inplace):
+    """a2c_gru_cell_fwd (models.py:465-476 at rollout batch: two launches) against the path it replaces -- a2c_gemm_f32
+    (x [Wx0|Wx1|Wx2], h [Wh0|Wh1]) + a2c_gru_gates + a2c_gemm_f32 ((r*h) Wh2) + a2c_gru_out -- bit for bit (same K split,
+    MFMA order and order of additions), and against the reference's formula in torch; x as rows of a wider buffer; h_new
+    written over h (the in-place rollout step)."""
+    ops = _ops()
+    x_wide = rnd((B, xs + 8), 951, 0, 1).to(DEV)
+    x = x_wide[:, :xs]
+    h0 = rnd((B, hd), 952).to(DEV)
+    Wx, Wh, b = (rnd((3, xs, hd), 953) / xs ** 0.5).to(DEV), (rnd((3, hd, hd), 954) / hd ** 0.5).to(DEV), (rnd((3, hd), 955) * 0.1).to(DEV)
+    WxC = torch.cat([Wx[g] for g in range(3)], 1).contiguous()
+    WhC = torch.cat([Wh[g] for g in range(2)], 1).contiguous()
+    mk = lambda *s: torch.full(s, float("nan"), device=DEV)
+    # the five launches
+    gx, gh, z1, r1, rh1, rhu, c1, hn1 = mk(B, 3 * hd), mk(B, 2 * hd), mk(B, hd), mk(B, hd), mk(B, hd), mk(B, hd), mk(B, hd), mk(B, hd)
+    ops.gemm(0, 0, B, 3 * hd, xs, x.data_ptr(), x.stride(0), WxC.data_ptr(), 3 * hd, gx.data_ptr(), 3 * hd)
+    ops.gemm(0, 0, B, 2 * hd, hd, h0.data_ptr(), hd, WhC.data_ptr(), 2 * hd, gh.data_ptr(), 2 * hd)
+    ops.gru_gates(gx, gh, b, h0, z1, r1, rh1)
+    ops.gemm(0, 0, B, hd, hd, rh1.data_ptr(), hd, Wh[2].data_ptr(), hd, rhu.data_ptr(), hd)
+    ops.gru_out(gx, rhu, b, h0, z1, c1, hn1)
+    # the two
+    gx2, z2, r2, rh2, c2 = mk(B, 3 * hd), mk(B, hd), mk(B, hd), mk(B, hd), mk(B, hd)
+    h_io = h0.clone()
+    hn2 = h_io if inplace else mk(B, hd)
+    ops.gru_cell_fwd(x, h_io, WxC, WhC, Wh[2], b, gx2, z2, r2, rh2, c2, hn2)
+    torch.cuda.synchronize()
+    for name, a, bb in (("z", z2, z1), ("r", r2, r1), ("rh", rh2, rh1), ("c", c2, c1), ("hn", hn2, hn1)):
+        assert torch.equal(a, bb), name
+    assert torch.equal(gx2[:, 2 * hd:], gx[:, 2 * hd:])
+    xc, hc = x.cpu(), h0.cpu()
+    zt = torch.sigmoid(xc.mm(Wx[0].cpu()) + hc.mm(Wh[0].cpu()) + b[0].cpu())
+    rt = torch.sigmoid(xc.mm(Wx[1].cpu()) + hc.mm(Wh[1].cpu()) + b[1].cpu())
+    ct = torch.tanh(xc.mm(Wx[2].cpu()) + (rt * hc).mm(Wh[2].cpu()) + b[2].cpu())
+    close("h_new", hn2, zt * hc + (1 - zt) * ct, 1e-5, 1e-5)
+    if not inplace:
+        assert torch.equal(h_io, h0)
+    ops.gru_cell_fwd(x, h0, WxC, WhC, Wh[2], b, gx2, z2, r2, rh2, None, mk(B, hd))      # c is optional
+    from a2c_amd import _lib
+    with pytest.raises(_lib.A2CKernelError):
+        ops.gru_cell_fwd(x, h0[:, :hd - 8].contiguous(), WxC, WhC, Wh[2], b, gx2, z2, r2, rh2, c2, mk(B, hd))     # hdim % 32

@@ -266,8 +266,17 @@ class A3CModel(_HipNet):
                 "emb_bnorm.bias"]
 
     def _prep(self, st):
-        self._c1.prep(self.P("convs.0.0.weight"), st)
-        self._c2.prep(self.P("convs.1.0.weight"), st)
+        # two independent chains of small launches (the conv fragments, the composed heads) at the tail of every update, on the
+        # path to the next rollout: a parallel branch (ops.side_branch), not ~7 launch latencies in a row
+        with ops.side_branch(1):         # (one branch: every fork / join is itself ~5-10 us of graph edge)
+            self._c1.prep(self.P("convs.0.0.weight"), ops.stream())
+            self._c2.prep(self.P("convs.1.0.weight"), ops.stream())
+        try:
+            self._prep_heads(st)
+        finally:
+            ops.join_branches()
+
+    def _prep_heads(self, st):
         # Inference-only composition: proj_matrx has NO activation (models.py:73), so
         #   [logits | value] = (f Wp^T + bp) Wh^T + bh = f (Wh Wp)^T + (Wh bp + bh).
         # Wc = Wh Wp ((A+1) x flat) lets a rollout step skip the h x flat GEMM entirely; the update
@@ -391,31 +400,41 @@ class A3CModel(_HipNet):
         #           da2 = (demb . Wp) * (a2 > 0) = (dl . Wc[:A]) * (a2 > 0)  with Wc = [pi; value] . proj_matrx (_prep)
         # The same fp32 products as the reference's, re-associated.  A + 1 > 8 keeps the two GEMMs.
         rank_bwd = A + 1 <= 8 and getattr(self, "_Wc", None) is not None and os.environ.get("A2C_NO_RANK_BWD") != "1"
-        if emb_free or rank_bwd:
-            S = ws.get("dWh_S", (A + 1, F))      # S = db^T a2: ONE skinny reduction over the batch (column chunks inside the launch)
-            linear_bwd_weight(ws, db, a2.data_ptr(), F, S, dbh if emb_free else None, B, st)
-        if emb_free:
-            # dWh = db^T emb with emb = a2 Wp^T + 1 bp^T never materialised:  dWh = S Wp^T + colsum(db) bp^T
-            # (K in chunks of <= 1024: the one-launch small-product kernel; the block-tiled GEMM takes 72 us for these 5 MFLOP)
-            nch = next(n for n in range(max(1, -(-F // 1024)), F + 1) if F % n == 0 and (F // n) % 8 == 0)
-            Kc = F // nch
-            for c in range(nch):
-                ops.gemm(0, 1, A + 1, h, Kc, S.data_ptr() + 4 * c * Kc, F, Wp.data_ptr() + 4 * c * Kc, F, dWh.data_ptr(), h,
-                         accumulate=(c > 0), st=st)
-            ops.gemm(0, 0, A + 1, h, 1, dbh.data_ptr(), 1, P("proj_matrx.bias").data_ptr(), h, dWh.data_ptr(), h,
-                     accumulate=True, st=st)
-        else:
-            linear_bwd_weight(ws, db, emb.data_ptr(), h, dWh, dbh, B, st)
         da2 = ws.get("da2", (B,) + self._c2.out_shape)
+
+        def head_grads(st):
+            """gradients of the heads and of proj_matrx: a chain of ~12 small launches that feeds nothing below"""
+            if emb_free or rank_bwd:
+                S = ws.get("dWh_S", (A + 1, F))      # S = db^T a2: ONE skinny reduction over the batch (column chunks inside the launch)
+                linear_bwd_weight(ws, db, a2.data_ptr(), F, S, dbh if emb_free else None, B, st)
+            if emb_free:
+                # dWh = db^T emb with emb = a2 Wp^T + 1 bp^T never materialised:  dWh = S Wp^T + colsum(db) bp^T
+                # (K in chunks of <= 1024: the one-launch small-product kernel; the block-tiled GEMM takes 72 us for these 5 MFLOP)
+                nch = next(n for n in range(max(1, -(-F // 1024)), F + 1) if F % n == 0 and (F // n) % 8 == 0)
+                Kc = F // nch
+                for c in range(nch):
+                    ops.gemm(0, 1, A + 1, h, Kc, S.data_ptr() + 4 * c * Kc, F, Wp.data_ptr() + 4 * c * Kc, F, dWh.data_ptr(), h,
+                             accumulate=(c > 0), st=st)
+                ops.gemm(0, 0, A + 1, h, 1, dbh.data_ptr(), 1, P("proj_matrx.bias").data_ptr(), h, dWh.data_ptr(), h,
+                         accumulate=True, st=st)
+            else:
+                linear_bwd_weight(ws, db, emb.data_ptr(), h, dWh, dbh, B, st)
+            if rank_bwd:
+                Wpi, dWp = P("pi.weight"), G("proj_matrx.weight")
+                with ops.span("rank_bwd proj_matrx grads"):
+                    ops.gemm(1, 0, h, F, A, Wpi.data_ptr(), h, S.data_ptr(), F, dWp.data_ptr(), F, st=st)
+                    ops.gemm(1, 0, h, 1, A, Wpi.data_ptr(), h, dbh.data_ptr(), 1, G("proj_matrx.bias").data_ptr(), 1, st=st)
+
         if rank_bwd:
-            Wpi, dWp = P("pi.weight"), G("proj_matrx.weight")
-            with ops.span("rank_bwd proj_matrx grads"):
-                ops.gemm(1, 0, h, F, A, Wpi.data_ptr(), h, S.data_ptr(), F, dWp.data_ptr(), F, st=st)
-                ops.gemm(1, 0, h, 1, A, Wpi.data_ptr(), h, dbh.data_ptr(), 1, G("proj_matrx.bias").data_ptr(), 1, st=st)
+            # da2 needs only dl and the composed matrix: the conv backward (2.5 of the update's 2.9 ms, four big launches)
+            # starts at once; the head / projection gradients run as a parallel branch beside it (ops.side_branch)
+            with ops.side_branch(0):
+                head_grads(ops.stream())
             with ops.span("rank_bwd da2"):
                 ops.gemm(0, 0, B, F, A, dl.data_ptr(), dl.stride(0), self._Wc.data_ptr(), F, da2.data_ptr(), F,
                          mask_ptr=a2.data_ptr(), ldmask=F, st=st)
         else:
+            head_grads(st)
             demb = ws.get("demb", (B, h))
             linear_bwd_data(ws, db, P("pi.weight"), demb, B, st, n_cols=A)        # value head is detached
             linear_bwd_weight(ws, demb, a2.data_ptr(), F, G("proj_matrx.weight"), G("proj_matrx.bias"), B, st)
@@ -434,6 +453,7 @@ class A3CModel(_HipNet):
             if tag == "train":
                 self._need_states()
             self._c1.bwd_weight(x_ptr, bstride, da1, G("convs.0.0.weight"), G("convs.0.0.bias"), B, ws, st)
+        ops.join_branches()
 
 
 def h_is_lockstep(stash, B, R, T):

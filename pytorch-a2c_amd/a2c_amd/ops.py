@@ -101,6 +101,57 @@ def span(name):
     return TIMERS.span(name) if TIMERS is not None else _NOSPAN
 
 
+# ---------------------------------------------------------------- side branches (launch-latency-bound chains next to big kernels)
+_SIDE_STREAMS = {}
+_BRANCHES = []
+
+
+class side_branch:
+    """``with ops.side_branch(i):`` -- what is enqueued inside runs on side stream i, forked from the current stream at entry
+    (it sees everything enqueued before); ``ops.join_branches()`` makes the current stream wait for every open branch.
+    For chains of small dependent kernels that do not feed the big kernel behind them (the head / projection gradients of
+    A3CModel next to its conv backward; the re-derivation of the inference weights): as nodes of ONE stream each costs its
+    ~4 us launch latency on the critical path of the epoch, as a parallel branch of the (captured) graph it costs nothing.
+    Same kernels, same arguments: results are bit-identical to the single-stream order.  The side streams are created on
+    the first EAGER use (every captured update is preceded by an eager one).  A2C_NO_BRANCH=1: plain single-stream order."""
+
+    def __init__(self, idx=0):
+        self.idx, self.ctx = idx, None
+
+    def __enter__(self):
+        import os
+        if os.environ.get("A2C_NO_BRANCH") == "1" or not torch.cuda.is_available():
+            return self
+        main = torch.cuda.current_stream()
+        key = (main.device.index, self.idx)
+        s = _SIDE_STREAMS.get(key)
+        if s is None:
+            if torch.cuda.is_current_stream_capturing():
+                return self                       # (no stream creation inside a capture: stay on the main stream)
+            s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=main.device)
+        s.wait_stream(main)
+        self.ctx = torch.cuda.stream(s)
+        self.ctx.__enter__()
+        _BRANCHES.append(s)
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+
+def join_branches():
+    """the current stream waits for every branch opened since the last join"""
+    if _BRANCHES:
+        main = torch.cuda.current_stream()
+        for s in _BRANCHES:
+            if s != main:
+                main.wait_stream(s)
+        _BRANCHES.clear()
+
+
 class graph_capture:
     """``torch.cuda.graph(g, capture_error_mode="thread_local")`` with the garbage collector held off: a cyclic-GC pass in
     the middle of a capture may run the destructor of an OLD hipGraph / pinned pool (hipGraphDestroy, hipFree,

@@ -943,27 +943,30 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restric
 //   Wc[n][f] = sum_h Wh[n][h] * Wp[h][f]      bc[n] = sum_h Wh[n][h] * bp[h] + bh[n]
 // 64 columns f per workgroup (Wp rows read coalesced), the hidden index h split over the 4 waves and
 // summed through LDS in a fixed order; all N <= 8 heads at once.
-__global__ __launch_bounds__(256) void compose_heads_kernel(const float* __restrict__ Wh, const float* __restrict__ bh,
+// (32 feature columns x 4 h-quarters per workgroup, 16 rows of Wp in flight per thread: the kernel sits on the path from the
+// optimiser step to the next rollout and is bound by the latency of its dependent load batches -- 41 workgroups of 64 columns
+// with 8 rows in flight took 29 us; same sums in the same order)
+__global__ __launch_bounds__(128) void compose_heads_kernel(const float* __restrict__ Wh, const float* __restrict__ bh,
                                                             const float* __restrict__ Wp, const float* __restrict__ bp,
                                                             float* __restrict__ Wc, float* __restrict__ bc, int N, int H,
                                                             int F) {
-  __shared__ float sm[4][SN_MAX][64];
-  const int fq = threadIdx.x & 63, hq = threadIdx.x >> 6;
-  const int f = blockIdx.x * 64 + fq;                   // f == F: the bias column
+  __shared__ float sm[4][SN_MAX][32];
+  const int fq = threadIdx.x & 31, hq = threadIdx.x >> 5;
+  const int f = blockIdx.x * 32 + fq;                   // f == F: the bias column
   const int hper = (H + 3) / 4, h_lo = hq * hper, h_hi = min(H, h_lo + hper);
   float acc[SN_MAX];
 #pragma unroll
   for (int n = 0; n < SN_MAX; ++n) acc[n] = 0.f;
   if (f <= F)
-    for (int h0 = h_lo; h0 < h_hi; h0 += 8) {
-      float xv[8];
+    for (int h0 = h_lo; h0 < h_hi; h0 += 16) {
+      float xv[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int h = min(h0 + u, H - 1);
         xv[u] = (f < F) ? Wp[(long)h * F + f] : bp[h];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 16; ++u)
         if (h0 + u < h_hi) {
 #pragma unroll
           for (int n = 0; n < SN_MAX; ++n)
@@ -1178,7 +1181,7 @@ int a2c_gemm_f32_tn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
 int a2c_compose_heads(const float* Wh, const float* bh, const float* Wp, const float* bp, float* Wc, float* bc, int N,
                       int H, int F, a2c_stream_t stream) {
   if (N < 1 || N > SN_MAX || H < 1 || F < 1 || !Wh || !bh || !Wp || !bp || !Wc || !bc) return A2C_ERR_ARG;
-  hipLaunchKernelGGL(compose_heads_kernel, dim3((unsigned)((F + 1 + 63) / 64)), dim3(256), 0, a2c_s(stream), Wh, bh, Wp, bp,
+  hipLaunchKernelGGL(compose_heads_kernel, dim3((unsigned)((F + 1 + 31) / 32)), dim3(128), 0, a2c_s(stream), Wh, bh, Wp, bp,
                      Wc, bc, N, H, F);
   A2C_CHECK_LAUNCH();
   return A2C_OK;

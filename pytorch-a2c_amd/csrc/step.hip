@@ -33,6 +33,9 @@ constexpr int SL0 = 6, SL1 = 5, SL2 = 5;   // float4 staging registers per threa
 constexpr int HN = 8;          // max heads (n_actions + 1)
 constexpr int NF1 = 64 * 64;   // conv1 fragments (64 steps x 64 lanes)
 constexpr int NF2 = 64 * 2 * 64;
+// ring kernel, conv1 on the bf16 matrix pipe: 8 K-blocks (plane, tap-row quad) x 3 weight pieces x 64 lanes x 8 bf16 (16 B)
+constexpr int NF1B = 8 * 3 * 64 * 4;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef A2C_STEP_TIMING
 __device__ unsigned long long a2c_step_ts[16];
@@ -150,6 +153,21 @@ __device__ __forceinline__ void store_chunk(const float4 (&pf)[N], const It& it,
 __device__ __forceinline__ float4 u8x4(unsigned int w) {
   return make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
 }
+
+// [bf16(a) | bf16(b) << 16] of two floats with at most 8 significant bits (uint8 pixels): the upper halves, exact
+__device__ __forceinline__ unsigned int bf16_pair_exact(float a, float b) {
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+// eight uint8 pixels (two dwords) -> eight bf16, element j = byte j: the B operand fragment of v_mfma_f32_16x16x32_bf16
+__device__ __forceinline__ bf16x8 u8x8_bf16(unsigned int lo, unsigned int hi) {
+  u32x4 r;
+  r[0] = bf16_pair_exact((float)(lo & 0xffu), (float)((lo >> 8) & 0xffu));
+  r[1] = bf16_pair_exact((float)((lo >> 16) & 0xffu), (float)(lo >> 24));
+  r[2] = bf16_pair_exact((float)(hi & 0xffu), (float)((hi >> 8) & 0xffu));
+  r[3] = bf16_pair_exact((float)((hi >> 16) & 0xffu), (float)(hi >> 24));
+  return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 
 template <bool OUT, bool U8, bool PERSIST, int HNT = HN>      // HNT: heads kept in registers (n_actions + 1 <= HNT)
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void a3c_step_kernel(StepP p) {
@@ -610,7 +628,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 //     and the values the bookkeeping carries from step to step stay in registers.
 // An env reset (real done) zeroes the older planes of the ring and the partial sums (a sum over zero planes is 0).
 // Results equal the per-step kernel's up to the fp32 re-association of conv1's sum (plane-major instead of tap-major).
-template <int HNT>
+//
+// C1BF (round 5): conv1 on the BF16 matrix pipe with fp32 results.  Its input is a uint8 frame stack (pong_prep /
+// breakout_prep outputs, preprocessing.py:8-23; runner.py:199 casts them to float): integers of at most 8 significant
+// bits, i.e. EXACT as bf16.  Every fp32 weight is split once per launch into three bf16 pieces w = hi + mid + lo (round to
+// nearest each; 3 x 8 significant bits cover the 24 of an fp32 exactly), so that w * x = hi*x + mid*x + lo*x with every
+// product exact (8 x 8 bits) and all sums in the MFMA's fp32 accumulator: the same real-number sum as the fp32 FMA chain,
+// re-associated (within an instruction's 32-deep dot product, and piece by piece).  One v_mfma_f32_16x16x32_bf16 takes the
+// whole (plane, tap-row quad) block a lane's 8-byte window read covers -- 3 instructions of ~16 cycles where the fp32 form
+// issues 8 of 32: conv1 is 1,600 of the step's 2,368 fp32 MFMAs.  C1BF = false keeps the fp32 form (A2C_RING_F32=1).
+template <int HNT, bool C1BF>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void a3c_ring_kernel(StepP p, const float* __restrict__ w1raw) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const a2c_a3c_step_args& a = p.a;
@@ -622,7 +649,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int NP2 = p.OH2 * p.OW2, ntile2 = (NP2 + 15) >> 4;
   const bool tail = tid == NT - 64;
   float* __restrict__ fr1 = lds;                        // conv1 fragments, [step/4][lane][step%4]
-  float* __restrict__ fr2 = fr1 + NF1;                  // conv2 fragments (the per-step kernel's layout)
+  float* __restrict__ fr2 = fr1 + (C1BF ? NF1B : NF1);  // conv2 fragments (the per-step kernel's layout)
   float* __restrict__ a1 = fr2 + NF2;                   // 16 x PLANE2
   float* __restrict__ a2 = a1 + 16 * p.PLANE2;          // flat (c, y, x)
   float* __restrict__ part = a2 + p.F4;                 // [2][ntile2*2][256] conv2 K-half partials
@@ -636,10 +663,39 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int T = (int)a.T;
 
   // ---- once per launch
-  for (int q = tid; q < NF1; q += NT) {                 // fragment element (step s, lane l) <- W1[co = l&15][p][ky = 4*kyq + (l>>4)][kx]
-    const int sq = q >> 8, l = (q >> 2) & 63, s = sq * 4 + (q & 3);
-    const int pl = s >> 4, kyq = (s >> 3) & 1, kx = s & 7;
-    fr1[q] = w1raw[(((l & 15) * 4 + pl) * 8 + 4 * kyq + (l >> 4)) * 8 + kx];
+  if constexpr (C1BF) {
+    // fragment (block = plane * 2 + kyq, piece, lane l): the eight kx of W1[co = l&15][plane][ky = 4*kyq + (l>>4)] as bf16
+    for (int q = tid; q < 8 * 64; q += NT) {
+      const int blk = q >> 6, l = q & 63, pl = blk >> 1, kyq = blk & 1;
+      const float* __restrict__ wr = w1raw + (((l & 15) * 4 + pl) * 8 + 4 * kyq + (l >> 4)) * 8;
+      unsigned int pk[3][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned short hb[3][2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const float wv = wr[2 * e + h2];
+          const __bf16 h0 = (__bf16)wv;
+          const float r1 = wv - (float)h0;              // exact: the low 16 bits of the mantissa (sign folded in)
+          const __bf16 h1 = (__bf16)r1;
+          const float r2 = r1 - (float)h1;              // exact: at most 8 significant bits are left
+          hb[0][h2] = __builtin_bit_cast(unsigned short, h0);
+          hb[1][h2] = __builtin_bit_cast(unsigned short, h1);
+          hb[2][h2] = bf16_bits(r2);
+        }
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) pk[pc][e] = (unsigned int)hb[pc][0] | ((unsigned int)hb[pc][1] << 16);
+      }
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        reinterpret_cast<u32x4*>(fr1)[(blk * 3 + pc) * 64 + l] = (u32x4){pk[pc][0], pk[pc][1], pk[pc][2], pk[pc][3]};
+    }
+  } else {
+    for (int q = tid; q < NF1; q += NT) {               // fragment element (step s, lane l) <- W1[co = l&15][p][ky = 4*kyq + (l>>4)][kx]
+      const int sq = q >> 8, l = (q >> 2) & 63, s = sq * 4 + (q & 3);
+      const int pl = s >> 4, kyq = (s >> 3) & 1, kx = s & 7;
+      fr1[q] = w1raw[(((l & 15) * 4 + pl) * 8 + 4 * kyq + (l >> 4)) * 8 + kx];
+    }
   }
   {
     const float4* __restrict__ wf2v = reinterpret_cast<const float4*>(a.wfrag2);
@@ -685,6 +741,39 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const unsigned char* __restrict__ plane = ring + ((base + pl) % 5) * HW;
 #pragma unroll
       for (int kyq = 0; kyq < 2; ++kyq) {
+        if constexpr (C1BF) {
+          // one 8-byte window read per tile -> 8 bf16 = the lane's share of a 32-deep K block; hi / mid / lo weight pieces
+          const bf16x8* __restrict__ fa = reinterpret_cast<const bf16x8*>(fr1) + ((pl * 2 + kyq) * 3) * 64 + lane;
+          const bf16x8 wh = fa[0], wm = fa[64], wl = fa[128];
+          {
+            const unsigned int* __restrict__ q0 = reinterpret_cast<const unsigned int*>(plane + boff[0] + 4 * kyq * W);
+            const unsigned int* __restrict__ q1 = reinterpret_cast<const unsigned int*>(plane + boff[1] + 4 * kyq * W);
+            const bf16x8 bx = u8x8_bf16(q0[0], q0[1]), by = u8x8_bf16(q1[0], q1[1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bx, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, by, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, bx, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, by, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bx, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, by, acc[1], 0, 0, 0);
+          }
+          if (four) {
+            const unsigned int* __restrict__ q0 = reinterpret_cast<const unsigned int*>(plane + boff[2] + 4 * kyq * W);
+            const unsigned int* __restrict__ q1 = reinterpret_cast<const unsigned int*>(plane + boff[3] + 4 * kyq * W);
+            const bf16x8 bx = u8x8_bf16(q0[0], q0[1]), by = u8x8_bf16(q1[0], q1[1]);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bx, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, by, acc[3], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, bx, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, by, acc[3], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bx, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, by, acc[3], 0, 0, 0);
+          } else if (three) {
+            const unsigned int* __restrict__ q0 = reinterpret_cast<const unsigned int*>(plane + boff[2] + 4 * kyq * W);
+            const bf16x8 bx = u8x8_bf16(q0[0], q0[1]);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bx, acc[2], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, bx, acc[2], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bx, acc[2], 0, 0, 0);
+          }
+        } else {
         const float4* __restrict__ fa = reinterpret_cast<const float4*>(fr1) + ((pl * 2 + kyq) * 2) * 64 + lane;
         const float4 av0 = fa[0], av1 = fa[64];
         const float av[8] = {av0.x, av0.y, av0.z, av0.w, av1.x, av1.y, av1.z, av1.w};
@@ -717,6 +806,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           const float bx[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
           for (int kx = 0; kx < 8; ++kx) acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kx], bx[kx], acc[2], 0, 0, 0);
+        }
         }
       }
     }
@@ -1188,10 +1278,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef RING_TS
 }
 
+// conv1 of the ring kernel on the bf16 pipe (exact 3-way split of the weights, see a3c_ring_kernel); A2C_RING_F32=1: fp32 MFMAs
+static bool ring_bf16() {
+  const char* e = getenv("A2C_RING_F32");       // (read per call: A/B runs)
+  return !(e != nullptr && e[0] == '1');
+}
 static size_t ring_lds(const StepP& p, int hnt) {
   const int ntile2 = (p.OH2 * p.OW2 + 15) / 16;
   const size_t part = (size_t)ntile2 * 1024 > (size_t)hnt * NT ? (size_t)ntile2 * 1024 : (size_t)hnt * NT;
-  return 4 * ((size_t)NF1 + NF2 + (size_t)16 * p.PLANE2 + p.F4 + part + HN + 32 + 8) + (size_t)5 * p.a.H * p.a.W + 64;
+  const size_t nf1 = ring_bf16() ? (size_t)NF1B : (size_t)NF1;
+  return 4 * (nf1 + NF2 + (size_t)16 * p.PLANE2 + p.F4 + part + HN + 32 + 8) + (size_t)5 * p.a.H * p.a.W + 64;
 }
 
 static inline int plane_pad(int n, int mod64) {      // smallest p >= n with p % 64 == mod64
@@ -1235,7 +1331,8 @@ static bool set_lds_attr() {
     const void* ks[] = {(const void*)a3c_step_kernel<true, false, false>, (const void*)a3c_step_kernel<false, false, false>,
                         (const void*)a3c_step_kernel<true, true, false>, (const void*)a3c_step_kernel<false, true, false>,
                         (const void*)a3c_step_kernel<true, true, true, 4>, (const void*)a3c_step_kernel<true, true, true, 8>,
-                        (const void*)a3c_ring_kernel<4>, (const void*)a3c_ring_kernel<8>};
+                        (const void*)a3c_ring_kernel<4, true>, (const void*)a3c_ring_kernel<8, true>,
+                        (const void*)a3c_ring_kernel<4, false>, (const void*)a3c_ring_kernel<8, false>};
     for (const void* k : ks)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
     attr_set = true;
@@ -1388,13 +1485,19 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.bstride = 1; p.x.boff = 0;
   if (ring_applies(p, a.B, cus, hnt, r->conv1_weight)) {
     const size_t rl = ring_lds(p, hnt);
+    const bool bf = ring_bf16();
     const int nblk = (a.B + cus - 1) / cus;
     p.x.bstride = nblk;
     for (int k = 0; k < nblk; ++k) {
       p.x.boff = k;
       const int cnt = (a.B - k + nblk - 1) / nblk;
-      if (hnt == 4) hipLaunchKernelGGL((a3c_ring_kernel<4>), dim3(cnt), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
-      else hipLaunchKernelGGL((a3c_ring_kernel<8>), dim3(cnt), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
+      if (bf) {
+        if (hnt == 4) hipLaunchKernelGGL((a3c_ring_kernel<4, true>), dim3(cnt), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
+        else hipLaunchKernelGGL((a3c_ring_kernel<8, true>), dim3(cnt), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
+      } else {
+        if (hnt == 4) hipLaunchKernelGGL((a3c_ring_kernel<4, false>), dim3(cnt), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
+        else hipLaunchKernelGGL((a3c_ring_kernel<8, false>), dim3(cnt), dim3(NT), rl, a2c_s(stream), p, r->conv1_weight);
+      }
       A2C_CHECK_LAUNCH();
     }
     return A2C_OK;

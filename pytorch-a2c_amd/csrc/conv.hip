@@ -2630,6 +2630,185 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same weight gradient from the single-frame uint8 store on the BF16 matrix pipe, with fp32 results (round 5).
+// dW[co][k] = sum_px dOut[co][px] * x[k][px] where x are uint8 frame pixels (pong_prep / breakout_prep outputs,
+// preprocessing.py:8-23): integers of at most 8 significant bits, EXACT in bf16.  Every fp32 dOut value is split, when its
+// sample is committed to LDS, into three bf16 pieces d = hi + mid + lo (round to nearest each; exact: 3 x 8 >= 24 bits), so
+// d * x = hi*x + mid*x + lo*x with every product exact and every sum in the MFMA's fp32 accumulator: the fp32 sum, re-
+// associated.  v_mfma_f32_16x16x32_bf16 takes 32 pixels per instruction at ~16 cycles where the fp32 form takes 4 at 32:
+// 3/16 of the matrix time of the kernel above (1.2 ms = 0.57 of the fp32 peak at N = 32,768).
+//   A = dOut pieces [piece][co][pixel group of 8][8] bf16 (rows of OW pixels padded to whole groups, pads zero),
+//   B = the input as PHASE planes P[ci][kxl][row][m] = x[ci][row][4 m + kxl] bf16: the 8 consecutive output pixels of a
+//       group at tap column kx = 4 kxh + kxl are the 8 CONSECUTIVE elements m = c0 + kxh .. of one phase-plane row (two
+//       ds_read_b64 + one b32; kxh = 1 shifts by one element with v_alignbit) -- no gather, no conversion in the loop;
+//   wave (q, h): input plane ci = q (64 weight columns = 4 accumulator tiles kxl), K blocks of parity half h.
+struct WsbGeo { int NG, NGT, NB, PA, PP; };
+template <int DUMMY>
+__global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_stream_bf16_kernel(WstreamP p, WsbGeo gq) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+  unsigned short* __restrict__ A = reinterpret_cast<unsigned short*>(lds);                 // [3][16][PA]
+  unsigned short* __restrict__ P = A + 3 * 16 * gq.PA;                                      // [16][H][PP]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int q = w & 3, h = w >> 2;
+  const int HW = p.H * p.W, NP = p.OH * p.OW;
+  const int per4 = HW >> 2, tot4 = 4 * per4, w4 = p.W >> 2;
+  const int dper4 = NP >> 2, dtot4 = p.Cout * dper4;
+  const int NG = gq.NG, NGT = gq.NGT, NB = gq.NB, PA = gq.PA, PP = gq.PP;
+  {  // zeros that stay: pad pixels / pad groups / channels >= Cout of A, columns m >= W/4 of P
+    u32x4w* z = reinterpret_cast<u32x4w*>(lds);
+    const int n16 = (3 * 16 * PA * 2 + 16 * p.H * PP * 2) >> 4;
+    for (int i = tid; i < n16; i += ST_NT) z[i] = (u32x4w){0u, 0u, 0u, 0u};
+  }
+  const int ky = j >> 1, kxh = j & 1;
+  const unsigned int sh = kxh ? 16u : 0u;
+  f32x4 acc[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dbv[4] = {0.f, 0.f, 0.f, 0.f};           // bias gradient: this thread's dOut quads belong to fixed channels
+  float4 d0 = {}, d1 = {}, d2 = {}, d3 = {};
+  unsigned int g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0, g8 = 0, g9 = 0, g10 = 0, g11 = 0, g12 = 0, g13 = 0;
+  int nv = 4;
+  auto fsrc = [&](long nn_) { const long r_ = nn_ / p.T; return p.fstore + r_ * p.fs_slot_stride + (nn_ - r_ * p.T) * (long)HW; };
+  long n = blockIdx.x;
+#define WSB_LOAD(NN)                                                                                           \
+  {                                                                                                            \
+    const float* __restrict__ ds_ = p.dout + (NN) * (long)p.Cout * NP;                                         \
+    const unsigned char* __restrict__ us_ = fsrc(NN);                                                          \
+    nv = p.nvalid[NN];                                                                                         \
+    WS_LDD(d0, 0, ds_) WS_LDD(d1, 1, ds_) WS_LDD(d2, 2, ds_) WS_LDD(d3, 3, ds_)                                \
+    WS_LDU(g0, 0, us_) WS_LDU(g1, 1, us_) WS_LDU(g2, 2, us_) WS_LDU(g3, 3, us_) WS_LDU(g4, 4, us_)             \
+    WS_LDU(g5, 5, us_) WS_LDU(g6, 6, us_) WS_LDU(g7, 7, us_) WS_LDU(g8, 8, us_) WS_LDU(g9, 9, us_)             \
+    WS_LDU(g10, 10, us_) WS_LDU(g11, 11, us_) WS_LDU(g12, 12, us_) WS_LDU(g13, 13, us_)                        \
+  }
+  // dOut quad u of this thread (4 consecutive pixels of one output row, OW % 4 == 0) -> the three piece images
+#define WSB_STD(var, u)                                                                                        \
+  if (tid + (u) * ST_NT < dtot4) {                                                                             \
+    const int idx_ = tid + (u) * ST_NT;                                                                        \
+    const int co_ = idx_ / dper4, p0_ = (idx_ - co_ * dper4) << 2;                                             \
+    const int r_ = p0_ / p.OW, c_ = p0_ - r_ * p.OW;                                                           \
+    const float e_[4] = {var.x, var.y, var.z, var.w};                                                          \
+    unsigned short pc_[3][4];                                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+      const __bf16 h0_ = (__bf16)e_[i_];                                                                       \
+      const float r1_ = e_[i_] - (float)h0_;                                                                   \
+      const __bf16 h1_ = (__bf16)r1_;                                                                          \
+      const float r2_ = r1_ - (float)h1_;                                                                      \
+      pc_[0][i_] = __builtin_bit_cast(unsigned short, h0_);                                                    \
+      pc_[1][i_] = __builtin_bit_cast(unsigned short, h1_);                                                    \
+      pc_[2][i_] = __builtin_bit_cast(unsigned short, (__bf16)r2_);                                            \
+    }                                                                                                          \
+    dbv[u] += (e_[0] + e_[1]) + (e_[2] + e_[3]);                                                               \
+    unsigned short* a_ = A + co_ * PA + (r_ * NG + (c_ >> 3)) * 8 + (c_ & 7);                                  \
+    _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                          \
+      *reinterpret_cast<uint2*>(a_ + pc * 16 * PA) = make_uint2((unsigned int)pc_[pc][0] | ((unsigned int)pc_[pc][1] << 16), \
+                                                                (unsigned int)pc_[pc][2] | ((unsigned int)pc_[pc][3] << 16)); \
+  }
+  // frame dword u of this thread (4 pixels = the 4 phases of one m) -> the phase planes, bf16 (upper half of the exact float)
+#define WSB_STU(var, u)                                                                                        \
+  if (tid + (u) * ST_NT < tot4) {                                                                              \
+    const int idx_ = tid + (u) * ST_NT;                                                                        \
+    const int c_ = (idx_ >= per4) + (idx_ >= 2 * per4) + (idx_ >= 3 * per4);                                   \
+    const int rem_ = idx_ - c_ * per4, row_ = rem_ / w4, m_ = rem_ - row_ * w4;                                \
+    const unsigned int x_ = c_ < 4 - nv ? 0u : var;                                                            \
+    unsigned short* d_ = P + ((c_ * 4) * p.H + row_) * PP + m_;                                                \
+    d_[0] = (unsigned short)(__float_as_uint((float)(x_ & 0xffu)) >> 16);                                      \
+    d_[p.H * PP] = (unsigned short)(__float_as_uint((float)((x_ >> 8) & 0xffu)) >> 16);                        \
+    d_[2 * p.H * PP] = (unsigned short)(__float_as_uint((float)((x_ >> 16) & 0xffu)) >> 16);                   \
+    d_[3 * p.H * PP] = (unsigned short)(__float_as_uint((float)(x_ >> 24)) >> 16);                             \
+  }
+  if (n < p.B) WSB_LOAD(n)
+  const int b_lo = h == 0 ? 0 : (NB + 1) / 2, b_hi = h == 0 ? (NB + 1) / 2 : NB;
+  for (; n < p.B; n += gridDim.x) {
+    const long nn = (n + gridDim.x < p.B) ? n + gridDim.x : n;        // past the end: re-read this sample (discarded)
+    __syncthreads();                                 // everyone is done with the previous sample (and with the zero fill)
+    WSB_STD(d0, 0) WSB_STD(d1, 1) WSB_STD(d2, 2) WSB_STD(d3, 3)
+    WSB_STU(g0, 0) WSB_STU(g1, 1) WSB_STU(g2, 2) WSB_STU(g3, 3) WSB_STU(g4, 4) WSB_STU(g5, 5) WSB_STU(g6, 6)
+    WSB_STU(g7, 7) WSB_STU(g8, 8) WSB_STU(g9, 9) WSB_STU(g10, 10) WSB_STU(g11, 11) WSB_STU(g12, 12) WSB_STU(g13, 13)
+    __syncthreads();
+    WSB_LOAD(nn)                                     // the next sample: in flight during the matrix phase
+    for (int b = b_lo; b < b_hi; ++b) {
+      const int grp = 4 * b + g;
+      const unsigned short* __restrict__ ap = A + j * PA + grp * 8;
+      const bf16x8w ah = *reinterpret_cast<const bf16x8w*>(ap);
+      const bf16x8w am = *reinterpret_cast<const bf16x8w*>(ap + 16 * PA);
+      const bf16x8w al = *reinterpret_cast<const bf16x8w*>(ap + 32 * PA);
+      const int gcl = min(grp, NGT - 1);             // (pad groups of the last block: A is zero there, B must only be finite)
+      const int r = gcl / NG, gc = gcl - r * NG;
+      const unsigned short* __restrict__ bp = P + ((q * 4) * p.H + 4 * r + ky) * PP + 8 * gc;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const unsigned short* __restrict__ bx = bp + x * p.H * PP;
+        const uint2 lo = *reinterpret_cast<const uint2*>(bx), hi = *reinterpret_cast<const uint2*>(bx + 4);
+        const unsigned int nx = *reinterpret_cast<const unsigned int*>(bx + 8);
+        u32x4w o;
+        o[0] = __builtin_amdgcn_alignbit(lo.y, lo.x, sh);
+        o[1] = __builtin_amdgcn_alignbit(hi.x, lo.y, sh);
+        o[2] = __builtin_amdgcn_alignbit(hi.y, hi.x, sh);
+        o[3] = __builtin_amdgcn_alignbit(nx, hi.y, sh);
+        const bf16x8w bv = __builtin_bit_cast(bf16x8w, o);
+        acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bv, acc[x], 0, 0, 0);
+        acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bv, acc[x], 0, 0, 0);
+        acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bv, acc[x], 0, 0, 0);
+      }
+    }
+  }
+#undef WSB_LOAD
+#undef WSB_STD
+#undef WSB_STU
+  // epilogue: add the two K halves in a fixed order, write this workgroup's slab; bias sums per channel in thread order
+  __syncthreads();
+  float* __restrict__ scr = lds;                      // [4 planes][4 acc][256]
+  if (h == 1) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      *reinterpret_cast<float4*>(scr + ((q * 4 + x) * 64 + lane) * 4) = (float4){acc[x][0], acc[x][1], acc[x][2], acc[x][3]};
+  }
+  float* __restrict__ red = lds + 4096;               // [4 * ST_NT] bias partials, index = dOut quad
+#pragma unroll
+  for (int u = 0; u < 4; ++u) red[tid + u * ST_NT] = dbv[u];
+  __syncthreads();
+  float* __restrict__ sl = p.slab + (long)blockIdx.x * ((long)p.Cout * p.K + p.Cout);
+  const int knat = (q * 8 + ky) * 8 + kxh * 4;
+  if (h == 0) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const float4 o = *reinterpret_cast<const float4*>(scr + ((q * 4 + x) * 64 + lane) * 4);
+      const float t[4] = {acc[x][0] + o.x, acc[x][1] + o.y, acc[x][2] + o.z, acc[x][3] + o.w};
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = 4 * g + rr;
+        if (co < p.Cout) sl[(long)co * p.K + knat + x] = t[rr];
+      }
+    }
+  }
+  if (tid < p.Cout) {
+    float sb = 0.f;
+    for (int i = tid * dper4; i < (tid + 1) * dper4; ++i) sb += red[i];
+    sl[(long)p.Cout * p.K + tid] = sb;
+  }
+}
+
+static bool plan_wstream_bf16(const a2c_conv_desc* d, const WstreamP& p, WsbGeo& gq, size_t& lds) {
+  gq.NG = (d->OW + 7) / 8;
+  gq.NGT = d->OH * gq.NG;
+  gq.NB = (gq.NGT + 3) / 4;
+  const int need_dw = gq.NB * 16;                      // dwords of one channel's groups (8 bf16 = 4 dwords each)
+  int pa_dw = ((need_dw + 31) / 32) * 32 + 4;          // channel pitch = 4 (mod 32) dwords: the 8 channels of a b128 pass hit 32 banks
+  if (pa_dw - 32 >= need_dw) pa_dw -= 32;
+  gq.PA = pa_dw * 2;
+  gq.PP = gq.NG * 8 + 4;                               // elements per phase-plane row (8-byte multiple: 2 * PP % 8 == 0)
+  if (d->W / 4 > gq.NG * 8 + 1 || d->OW % 4 || d->Cout > 16) return false;
+  lds = (size_t)3 * 16 * gq.PA * 2 + (size_t)16 * d->H * gq.PP * 2;
+  lds = (lds + 15) / 16 * 16;
+  if (lds < 4 * (4096 + 4 * (size_t)ST_NT)) return false;          // epilogue scratch reuses the images
+  if ((long)d->Cout * (d->OH * d->OW / 4) > 4L * ST_NT) return false;
+  (void)p;
+  return lds <= 160 * 1024 && (gq.PP * 2) % 8 == 0 && 4 * (d->OH - 1) + 7 < d->H;
+}
+
 static bool plan_wstream(const a2c_conv_desc* d, WstreamP& p) {
   if (!(d->ks == 8 && d->stride == 4 && d->pad == 0 && d->Cin == 4 && d->Cout <= 16 && d->W % 4 == 0 && d->OW % 4 == 0)) return false;
   const int NP = d->OH * d->OW;
@@ -3528,6 +3707,26 @@ int a2c_conv2d_bwd_weight_frames(const a2c_conv_desc* d, const uint8_t* fstore, 
   const int grid = stream_grid();
   wp.in = nullptr; wp.in_bs = 0; wp.dout = dout; wp.slab = (float*)ws; wp.B = B;
   wp.fstore = fstore; wp.fs_slot_stride = (long)slot_stride; wp.T = (int)T; wp.nvalid = nvalid;
+  {  // the bf16-pipe form (exact 3-way split of dOut; uint8 pixels are exact in bf16); A2C_WGRAD_F32=1: the fp32 MFMAs below
+    const char* e32 = getenv("A2C_WGRAD_F32");       // (read per call: A/B runs, tests)
+    WsbGeo gq;
+    size_t ldsb = 0;
+    if (!(e32 != nullptr && e32[0] == '1') && plan_wstream_bf16(d, wp, gq, ldsb)) {
+      static bool attrb = false;
+      if (!attrb) {
+        if (hipFuncSetAttribute((const void*)wgrad_stream_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          return A2C_ERR_LAUNCH;
+        attrb = true;
+      }
+      const int gb = grid < B ? grid : B;
+      hipLaunchKernelGGL(wgrad_stream_bf16_kernel<0>, dim3(gb), dim3(ST_NT), ldsb, st, wp, gq);
+      A2C_CHECK_LAUNCH();
+      const long nWb = (long)wp.Cout * wp.K, perb = nWb + wp.Cout;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(perb, 256)), dim3(256), 0, st, (const float*)ws, gb, perb, nWb, dW, db);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
   const size_t lds = 4 * (size_t)(4 * wp.PLANE1 + 16 * wp.PLANEo);
   static bool attr = false;
   if (!attr) {

@@ -333,3 +333,54 @@ def test_a3c_persistent_rollout_on_the_frame_store_with_lazy_states(no_ring, B, 
                     close("conv1 weights", b, a, 1e-4, 1e-5)
                 else:
                     assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize("B,vmax", [(5, 256), (700, 256), (700, 2), (32768 // 8, 2)])
+def test_a3c_conv1_weight_gradient_on_the_bf16_pipe_is_the_fp32_sum(B, vmax, monkeypatch):
+    """A3CModel conv1 (8x8 / stride 4, models.py:36) weight gradient from the single-frame uint8 store.  Default: the bf16
+    matrix pipe with every fp32 dOut value split into three bf16 pieces (exact) and the uint8 pixels as bf16 (exact): every
+    product is exact, all sums are fp32 -- so the result must be the fp32 MFMA kernel's (A2C_WGRAD_F32=1) up to
+    re-association, for ANY uint8 pixel values (vmax = 256) and for binary frames (vmax = 2), and no further from the
+    fp64 gradient than the fp32 kernel is (rms over the tensor; 1.5 x + 1e-7 of the tensor's rms)."""
+    ops = _ops()
+    d = ops.conv_desc(4, 84, 84, 16, 8, 4, 0)
+    T, HW = 8, 84 * 84
+    R = (B + T - 1) // T
+    rng = np.random.default_rng(900 + B + vmax)
+    Fs = rng.integers(0, vmax, size=(R, T + 4, HW), dtype=np.uint8)
+    nv = rng.integers(1, 5, size=(R * T,), dtype=np.int32)
+    Fd, nvd = torch.from_numpy(Fs).to(DEV), torch.from_numpy(nv).to(DEV)
+    dout = (rnd((B, 16, 20, 20), 77) * torch.from_numpy(rng.lognormal(0, 2, size=(B, 1, 1, 1)).astype(np.float32))).to(DEV)
+    ws = torch.empty((ops.conv_bwd_weight_ws_bytes(d, B) + 3) // 4, device=DEV)
+    res = {}
+    for f32 in (False, True):
+        if f32:
+            monkeypatch.setenv("A2C_WGRAD_F32", "1")
+        else:
+            monkeypatch.delenv("A2C_WGRAD_F32", raising=False)
+        dW, db = torch.full((16, 4, 8, 8), float("nan"), device=DEV), torch.full((16,), float("nan"), device=DEV)
+        ops.conv_bwd_weight_frames(d, Fd, Fd.stride(0), T, nvd, dout, dW, db, B, ws)
+        dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+        ops.conv_bwd_weight_frames(d, Fd, Fd.stride(0), T, nvd, dout, dW2, db2, B, ws)
+        assert torch.equal(dW, dW2) and torch.equal(db, db2)          # deterministic
+        res[f32] = (dW.cpu().double(), db.cpu().double())
+    # fp64 gradient: dW[co][c][ky][kx] = sum_n sum_px dOut[n][co][px] x[n][c][4 oy + ky][4 ox + kx]
+    xs = torch.zeros(B, 4, 84, 84, dtype=torch.float64)
+    for n in range(B):
+        r, t = divmod(n, T)
+        for c in range(4):
+            if c >= 4 - nv[n]:
+                xs[n, c] = torch.from_numpy(Fs[r, t + c].astype(np.float64)).reshape(84, 84)
+    wt = torch.zeros(16, 4, 8, 8, dtype=torch.float64, requires_grad=True)
+    do64 = dout.cpu().double()
+    for n0 in range(0, B, 512):
+        F.conv2d(xs[n0:n0 + 512], wt, stride=4).backward(do64[n0:n0 + 512])
+    want, wantb = wt.grad, do64.sum((0, 2, 3))
+    rms = float(want.pow(2).mean().sqrt())
+    e_bf = float((res[False][0] - want).pow(2).mean().sqrt()) / rms
+    e_32 = float((res[True][0] - want).pow(2).mean().sqrt()) / rms
+    assert e_bf <= 1.5 * e_32 + 1e-7, (e_bf, e_32)
+    assert float((res[False][0] - want).abs().max()) <= 2 * float((res[True][0] - want).abs().max()) + 1e-6 * rms
+    close("db", res[False][1], wantb, 2e-6 * float(wantb.abs().max()) + 1e-6, 2e-6)
+    close("db fp32 kernel", res[True][1], wantb, 2e-6 * float(wantb.abs().max()) + 1e-6, 2e-6)
+    print(f"B={B} vmax={vmax}: rms(bf16x3 - fp64)/rms = {e_bf:.2e}, rms(fp32 MFMA - fp64)/rms = {e_32:.2e}")

@@ -474,13 +474,14 @@ class ThreadEnvPool(_PinnedPool):
         reg = self._create_region()
         self._env_array = (c_void_p * self.n_envs)(*self.env_ptrs)
         # Push mirror (uint8 / packed frames, a registered pool = a GPU process): the worker threads ALSO write every answer
-        # straight into fine-grained device memory (a2c_push_buffer_alloc), so the rollout kernels poll rec and fetch the
-        # frame from HBM instead of over PCIe (two dependent round trips per env step).  OPT-IN (A2C_PUSH=1): measured on
-        # MI355X the ring kernel's turn-around drops from 7.1 to 5.7 us per env step, but a 256 x 128 slot takes the same
-        # 2.1-2.3 ms -- with the answer hidden the step is bound by its matrix work -- and the workers pay two sfences per
-        # answer.
+        # straight into fine-grained device memory (a2c_push_buffer_alloc; large BAR, checked with a guarded probe write), so
+        # the rollout kernels poll rec and fetch the frame from HBM instead of over PCIe (two dependent round trips per env
+        # step).  Default since round 5 (A2C_PUSH=0 switches it off): while the ring kernel's step was bound by its fp32
+        # matrix work the shorter turn-around (7.1 -> 5.7 us per env step) bought nothing; with conv1 on the bf16 pipe the
+        # step waits on the answer, and the same change is worth 0.3-0.5 ms per 256 x 128 slot.
+        # A platform without a host-writable device buffer keeps the pinned host region as the only copy.
         self.push_ptr = 0
-        if self.register and self.frame_dtype == np.uint8 and os.environ.get("A2C_PUSH", "0") == "1":
+        if self.register and self.frame_dtype == np.uint8 and os.environ.get("A2C_PUSH", "1") != "0":
             from . import ops
             h = reg.header
             self._push_rec_bytes = (8 * self.n_envs + 255) // 256 * 256

@@ -2643,7 +2643,7 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 //       group at tap column kx = 4 kxh + kxl are the 8 CONSECUTIVE elements m = c0 + kxh .. of one phase-plane row (two
 //       ds_read_b64 + one b32; kxh = 1 shifts by one element with v_alignbit) -- no gather, no conversion in the loop;
 //   wave (q, h): input plane ci = q (64 weight columns = 4 accumulator tiles kxl), K blocks of parity half h.
-struct WsbGeo { int NG, NGT, NB, PA, PP; };
+struct WsbGeo { int NG, NGT, NB, PA, PP, dbg; };      // dbg (A2C_WSB_DBG, timing only): 1 = no matrix phase, 2 = no commit
 template <int DUMMY>
 __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_stream_bf16_kernel(WstreamP p, WsbGeo gq) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2724,12 +2724,14 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   for (; n < p.B; n += gridDim.x) {
     const long nn = (n + gridDim.x < p.B) ? n + gridDim.x : n;        // past the end: re-read this sample (discarded)
     __syncthreads();                                 // everyone is done with the previous sample (and with the zero fill)
+    if (!(gq.dbg & 2)) {
     WSB_STD(d0, 0) WSB_STD(d1, 1) WSB_STD(d2, 2) WSB_STD(d3, 3)
     WSB_STU(g0, 0) WSB_STU(g1, 1) WSB_STU(g2, 2) WSB_STU(g3, 3) WSB_STU(g4, 4) WSB_STU(g5, 5) WSB_STU(g6, 6)
     WSB_STU(g7, 7) WSB_STU(g8, 8) WSB_STU(g9, 9) WSB_STU(g10, 10) WSB_STU(g11, 11) WSB_STU(g12, 12) WSB_STU(g13, 13)
+    }
     __syncthreads();
     WSB_LOAD(nn)                                     // the next sample: in flight during the matrix phase
-    for (int b = b_lo; b < b_hi; ++b) {
+    for (int b = (gq.dbg & 1) ? b_hi : b_lo; b < b_hi; ++b) {
       const int grp = 4 * b + g;
       const unsigned short* __restrict__ ap = A + j * PA + grp * 8;
       const bf16x8w ah = *reinterpret_cast<const bf16x8w*>(ap);
@@ -2793,6 +2795,7 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
 static bool plan_wstream_bf16(const a2c_conv_desc* d, const WstreamP& p, WsbGeo& gq, size_t& lds) {
   gq.NG = (d->OW + 7) / 8;
+  gq.dbg = getenv("A2C_WSB_DBG") ? atoi(getenv("A2C_WSB_DBG")) : 0;
   gq.NGT = d->OH * gq.NG;
   gq.NB = (gq.NGT + 3) / 4;
   const int need_dw = gq.NB * 16;                      // dwords of one channel's groups (8 bf16 = 4 dwords each)

@@ -303,7 +303,7 @@ def test_ring_kernel_on_the_tagged_mirror_matches_oracle(monkeypatch):
 
 @pytest.mark.parametrize("kind,ingest,bits", [("A3CModel", "zero-copy", True), ("A3CModel", "zero-copy", False), ("GRUModel", "relay", True)])
 def test_push_mirror_rollouts_match_oracle(kind, ingest, bits, monkeypatch):
-    """A2C_PUSH=1 (opt-in, DESIGN.md section 7: no faster end to end): the env worker threads also write every answer -- frame,
+    """The push mirror (default; A2C_PUSH=0 switches it off): the env worker threads also write every answer -- frame,
     sfence, rec granule, sfence -- straight into fine-grained DEVICE memory (a2c_push_buffer_alloc), and the ring kernel /
     the relay's ingest kernel poll and fetch there instead of over PCIe.  Two rounds against the oracle."""
     from a2c_amd.hostpool import ThreadEnvPool

@@ -52,6 +52,7 @@ WORKLOADS = {   # model, n_envs, n_tsteps, use_bptt, n_actions
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # fp32 matrix == fp32 vector peak
+BF16_PEAK_TFLOPS = 2516.6    # dense bf16 MFMA (16 x the fp32 matrix rate, MI355X_MICROARCH.md)
 PCIE_PEAK_GBS = 63.0         # host link: PCIe Gen5 x16 (spec)
 SS = (4, 84, 84)
 FRAME_BYTES = {"u8": 84 * 84, "bits": 84 * 84 // 8}      # bytes per frame over the host link, by transport
@@ -141,7 +142,7 @@ def compact_line(full, side_file=None):
     if rf:
         line["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale",
                                                "traffic_source", "alg_flops_per_launch", "alg_bytes_per_launch", "avg_launch_us",
-                                               "launches_per_rollout", "hbm_GBs") if k in rf}
+                                               "launches_per_rollout", "hbm_GBs", "pipes", "frac_of_pipe_time") if k in rf}
     cb = full.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "cpu_model", "kind", "rollout_steps_per_s",
@@ -884,6 +885,15 @@ def main():
                                    launches_per_rollout=launches, hbm_GBs=round(by / (us * 1e-6) / 1e9, 1),
                                    hbm_frac=round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                    alg_flops_per_launch=fl, alg_bytes_per_launch=by)
+            if ring and os.environ.get("A2C_RING_F32") != "1":
+                # conv1 (3.28 of the step's 4.64 MFLOP) runs on the BF16 matrix pipe as three exact bf16 pieces per fp32 weight
+                # (uint8 pixels are exact in bf16; fp32 accumulation: DESIGN 4): `frac` stays algorithmic fp32 flops over the
+                # fp32 MFMA peak (the contract's definition); `frac_of_pipe_time` prices the instructions actually issued --
+                # 3 x conv1 flops at the bf16 peak + the rest at the fp32 peak -- against the launch duration
+                c1 = 2 * 16 * 400 * 256
+                t_pk = (3.0 * c1 / (BF16_PEAK_TFLOPS * 1e12) + (step_alg_flops(A) - c1) / (F32_PEAK_TFLOPS * 1e12)) * b.n_envs * (T + 1) / launches
+                out["roofline"].update(pipes="conv1: bf16 MFMA x3 (exact split, fp32 accumulate); conv2/heads: fp32",
+                                       frac_of_pipe_time=round(t_pk / (us * 1e-6), 4))
             if zero_copy:
                 link = dict(out["h2d"], note="PCIe frame bytes / launch duration vs the 63 GB/s link")
                 if link["frac"] > out["roofline"]["frac"]:

@@ -2644,6 +2644,10 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 //       ds_read_b64 + one b32; kxh = 1 shifts by one element with v_alignbit) -- no gather, no conversion in the loop;
 //   wave (q, h): input plane ci = q (64 weight columns = 4 accumulator tiles kxl), K blocks of parity half h.
 struct WsbGeo { int NG, NGT, NB, PA, PP, dbg; };      // dbg (A2C_WSB_DBG, timing only): 1 = no matrix phase, 2 = no commit
+//   wave w: K blocks {w, w + 8, ...} (a block = 4 pixel groups = 32 pixels) for ALL 256 weight columns -- 16 accumulator
+//   tiles, the block's three A fragments read once --; tile t = (ci, kxh, kp): lane j = (ky = j >> 1, kxl = 2 kp + (j & 1)),
+//   so kxh is uniform per tile and only the kxh = 1 tiles pay the one-element shift; the eight waves' partial tiles are
+//   added in wave order through LDS at the end of the launch.
 template <int DUMMY>
 __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_stream_bf16_kernel(WstreamP p, WsbGeo gq) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2652,43 +2656,68 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   unsigned short* __restrict__ P = A + 3 * 16 * gq.PA;                                      // [16][H][PP]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
-  const int q = w & 3, h = w >> 2;
   const int HW = p.H * p.W, NP = p.OH * p.OW;
-  const int per4 = HW >> 2, tot4 = 4 * per4, w4 = p.W >> 2;
+  const int w4 = p.W >> 2;
   const int dper4 = NP >> 2, dtot4 = p.Cout * dper4;
   const int NG = gq.NG, NGT = gq.NGT, NB = gq.NB, PA = gq.PA, PP = gq.PP;
+  const int spr = (w4 + 1) >> 1, nslot = 4 * p.H * spr;        // frame slots: (plane, row, pair of dwords m = 2 s, 2 s + 1)
   {  // zeros that stay: pad pixels / pad groups / channels >= Cout of A, columns m >= W/4 of P
     u32x4w* z = reinterpret_cast<u32x4w*>(lds);
     const int n16 = (3 * 16 * PA * 2 + 16 * p.H * PP * 2) >> 4;
     for (int i = tid; i < n16; i += ST_NT) z[i] = (u32x4w){0u, 0u, 0u, 0u};
   }
-  const int ky = j >> 1, kxh = j & 1;
-  const unsigned int sh = kxh ? 16u : 0u;
-  f32x4 acc[4];
+  const int ky = j >> 1;
+  f32x4 acc[16];
 #pragma unroll
-  for (int x = 0; x < 4; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dbv[4] = {0.f, 0.f, 0.f, 0.f};           // bias gradient: this thread's dOut quads belong to fixed channels
   float4 d0 = {}, d1 = {}, d2 = {}, d3 = {};
-  unsigned int g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0, g8 = 0, g9 = 0, g10 = 0, g11 = 0, g12 = 0, g13 = 0;
+  uint2 g0 = {}, g1 = {}, g2 = {}, g3 = {}, g4 = {}, g5 = {}, g6 = {}, g7 = {};
   int nv = 4;
   auto fsrc = [&](long nn_) { const long r_ = nn_ / p.T; return p.fstore + r_ * p.fs_slot_stride + (nn_ - r_ * p.T) * (long)HW; };
+  // slot u of this thread: plane c, row, dword pair s -> byte offset in the sample's 4 planes (dword aligned)
+  int soff[8];
+  int sdst[8];                                   // element offset of (phase 0, row, m = 2 s) in P, or -1
+  unsigned int smask[8];                         // second dword of the pair lies inside the row
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = tid + u * ST_NT;
+    const bool ok = idx < nslot;
+    const int ii = ok ? idx : 0;
+    const int c = ii / (p.H * spr), rem = ii - c * (p.H * spr), row = rem / spr, sp = rem - row * spr;
+    soff[u] = (c * p.H + row) * p.W + 8 * sp;
+    sdst[u] = ok ? ((c * 4) * p.H + row) * PP + 2 * sp : -1;
+    smask[u] = ((2 * sp + 1 < w4) ? 0xffffff00u : 0u) | (unsigned int)c;      // low byte: the plane (zero planes of a fresh episode)
+  }
+  int adst[4];                                   // element offset of dOut quad u in piece image 0, or -1 (no division in the loop)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + u * ST_NT;
+    const bool ok = idx < dtot4;
+    const int ii = ok ? idx : 0;
+    const int co = ii / dper4, p0 = (ii - co * dper4) << 2;
+    const int r = p0 / p.OW, c = p0 - r * p.OW;
+    adst[u] = ok ? co * PA + (r * NG + (c >> 3)) * 8 + (c & 7) : -1;
+  }
   long n = blockIdx.x;
+#define WSB_LDU(var, u, src)                                                                                   \
+  {                                                                                                            \
+    const unsigned int* s_ = reinterpret_cast<const unsigned int*>((src) + soff[u]);                            \
+    var.x = s_[0];                                                                                             \
+    var.y = s_[(smask[u] >> 8) ? 1 : 0];                                                                       \
+  }
 #define WSB_LOAD(NN)                                                                                           \
   {                                                                                                            \
     const float* __restrict__ ds_ = p.dout + (NN) * (long)p.Cout * NP;                                         \
     const unsigned char* __restrict__ us_ = fsrc(NN);                                                          \
     nv = p.nvalid[NN];                                                                                         \
     WS_LDD(d0, 0, ds_) WS_LDD(d1, 1, ds_) WS_LDD(d2, 2, ds_) WS_LDD(d3, 3, ds_)                                \
-    WS_LDU(g0, 0, us_) WS_LDU(g1, 1, us_) WS_LDU(g2, 2, us_) WS_LDU(g3, 3, us_) WS_LDU(g4, 4, us_)             \
-    WS_LDU(g5, 5, us_) WS_LDU(g6, 6, us_) WS_LDU(g7, 7, us_) WS_LDU(g8, 8, us_) WS_LDU(g9, 9, us_)             \
-    WS_LDU(g10, 10, us_) WS_LDU(g11, 11, us_) WS_LDU(g12, 12, us_) WS_LDU(g13, 13, us_)                        \
+    WSB_LDU(g0, 0, us_) WSB_LDU(g1, 1, us_) WSB_LDU(g2, 2, us_) WSB_LDU(g3, 3, us_)                            \
+    WSB_LDU(g4, 4, us_) WSB_LDU(g5, 5, us_) WSB_LDU(g6, 6, us_) WSB_LDU(g7, 7, us_)                            \
   }
   // dOut quad u of this thread (4 consecutive pixels of one output row, OW % 4 == 0) -> the three piece images
 #define WSB_STD(var, u)                                                                                        \
-  if (tid + (u) * ST_NT < dtot4) {                                                                             \
-    const int idx_ = tid + (u) * ST_NT;                                                                        \
-    const int co_ = idx_ / dper4, p0_ = (idx_ - co_ * dper4) << 2;                                             \
-    const int r_ = p0_ / p.OW, c_ = p0_ - r_ * p.OW;                                                           \
+  if (adst[u] >= 0) {                                                                                          \
     const float e_[4] = {var.x, var.y, var.z, var.w};                                                          \
     unsigned short pc_[3][4];                                                                                  \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
@@ -2701,37 +2730,35 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       pc_[2][i_] = __builtin_bit_cast(unsigned short, (__bf16)r2_);                                            \
     }                                                                                                          \
     dbv[u] += (e_[0] + e_[1]) + (e_[2] + e_[3]);                                                               \
-    unsigned short* a_ = A + co_ * PA + (r_ * NG + (c_ >> 3)) * 8 + (c_ & 7);                                  \
+    unsigned short* a_ = A + adst[u];                                                                          \
     _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                          \
       *reinterpret_cast<uint2*>(a_ + pc * 16 * PA) = make_uint2((unsigned int)pc_[pc][0] | ((unsigned int)pc_[pc][1] << 16), \
                                                                 (unsigned int)pc_[pc][2] | ((unsigned int)pc_[pc][3] << 16)); \
   }
-  // frame dword u of this thread (4 pixels = the 4 phases of one m) -> the phase planes, bf16 (upper half of the exact float)
+  // frame slot u (two dwords = pixels 4 m .. 4 m + 7 of one row) -> phase plane kxl gets [bf16(byte kxl of m) | bf16(.. of m+1)]:
+  // the upper halves of the exact floats, one 4-byte LDS store per phase
 #define WSB_STU(var, u)                                                                                        \
-  if (tid + (u) * ST_NT < tot4) {                                                                              \
-    const int idx_ = tid + (u) * ST_NT;                                                                        \
-    const int c_ = (idx_ >= per4) + (idx_ >= 2 * per4) + (idx_ >= 3 * per4);                                   \
-    const int rem_ = idx_ - c_ * per4, row_ = rem_ / w4, m_ = rem_ - row_ * w4;                                \
-    const unsigned int x_ = c_ < 4 - nv ? 0u : var;                                                            \
-    unsigned short* d_ = P + ((c_ * 4) * p.H + row_) * PP + m_;                                                \
-    d_[0] = (unsigned short)(__float_as_uint((float)(x_ & 0xffu)) >> 16);                                      \
-    d_[p.H * PP] = (unsigned short)(__float_as_uint((float)((x_ >> 8) & 0xffu)) >> 16);                        \
-    d_[2 * p.H * PP] = (unsigned short)(__float_as_uint((float)((x_ >> 16) & 0xffu)) >> 16);                   \
-    d_[3 * p.H * PP] = (unsigned short)(__float_as_uint((float)(x_ >> 24)) >> 16);                             \
+  if (sdst[u] >= 0) {                                                                                          \
+    const int c_ = (int)(smask[u] & 0xffu);                                                                    \
+    const unsigned int x0_ = c_ < 4 - nv ? 0u : var.x, x1_ = (c_ < 4 - nv || !(smask[u] >> 8)) ? 0u : var.y;   \
+    unsigned int* d_ = reinterpret_cast<unsigned int*>(P + sdst[u]);                                           \
+    const int ps_ = (p.H * PP) >> 1;                                                                           \
+    d_[0] = __builtin_amdgcn_perm(__float_as_uint((float)(x1_ & 0xffu)), __float_as_uint((float)(x0_ & 0xffu)), 0x07060302u); \
+    d_[ps_] = __builtin_amdgcn_perm(__float_as_uint((float)((x1_ >> 8) & 0xffu)), __float_as_uint((float)((x0_ >> 8) & 0xffu)), 0x07060302u); \
+    d_[2 * ps_] = __builtin_amdgcn_perm(__float_as_uint((float)((x1_ >> 16) & 0xffu)), __float_as_uint((float)((x0_ >> 16) & 0xffu)), 0x07060302u); \
+    d_[3 * ps_] = __builtin_amdgcn_perm(__float_as_uint((float)(x1_ >> 24)), __float_as_uint((float)(x0_ >> 24)), 0x07060302u); \
   }
   if (n < p.B) WSB_LOAD(n)
-  const int b_lo = h == 0 ? 0 : (NB + 1) / 2, b_hi = h == 0 ? (NB + 1) / 2 : NB;
   for (; n < p.B; n += gridDim.x) {
     const long nn = (n + gridDim.x < p.B) ? n + gridDim.x : n;        // past the end: re-read this sample (discarded)
     __syncthreads();                                 // everyone is done with the previous sample (and with the zero fill)
     if (!(gq.dbg & 2)) {
     WSB_STD(d0, 0) WSB_STD(d1, 1) WSB_STD(d2, 2) WSB_STD(d3, 3)
-    WSB_STU(g0, 0) WSB_STU(g1, 1) WSB_STU(g2, 2) WSB_STU(g3, 3) WSB_STU(g4, 4) WSB_STU(g5, 5) WSB_STU(g6, 6)
-    WSB_STU(g7, 7) WSB_STU(g8, 8) WSB_STU(g9, 9) WSB_STU(g10, 10) WSB_STU(g11, 11) WSB_STU(g12, 12) WSB_STU(g13, 13)
+    WSB_STU(g0, 0) WSB_STU(g1, 1) WSB_STU(g2, 2) WSB_STU(g3, 3) WSB_STU(g4, 4) WSB_STU(g5, 5) WSB_STU(g6, 6) WSB_STU(g7, 7)
     }
     __syncthreads();
     WSB_LOAD(nn)                                     // the next sample: in flight during the matrix phase
-    for (int b = (gq.dbg & 1) ? b_hi : b_lo; b < b_hi; ++b) {
+    for (int b = (gq.dbg & 1) ? NB : w; b < NB; b += ST_NT / 64) {
       const int grp = 4 * b + g;
       const unsigned short* __restrict__ ap = A + j * PA + grp * 8;
       const bf16x8w ah = *reinterpret_cast<const bf16x8w*>(ap);
@@ -2739,53 +2766,61 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       const bf16x8w al = *reinterpret_cast<const bf16x8w*>(ap + 32 * PA);
       const int gcl = min(grp, NGT - 1);             // (pad groups of the last block: A is zero there, B must only be finite)
       const int r = gcl / NG, gc = gcl - r * NG;
-      const unsigned short* __restrict__ bp = P + ((q * 4) * p.H + 4 * r + ky) * PP + 8 * gc;
+      const unsigned short* __restrict__ bp = P + ((j & 1) * p.H + 4 * r + ky) * PP + 8 * gc;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const unsigned short* __restrict__ bx = bp + x * p.H * PP;
+      for (int t = 0; t < 16; ++t) {
+        const int ci = t >> 2, kxh = (t >> 1) & 1, kp = t & 1;
+        const unsigned short* __restrict__ bx = bp + ((ci * 4 + 2 * kp) * p.H) * PP;
         const uint2 lo = *reinterpret_cast<const uint2*>(bx), hi = *reinterpret_cast<const uint2*>(bx + 4);
-        const unsigned int nx = *reinterpret_cast<const unsigned int*>(bx + 8);
         u32x4w o;
-        o[0] = __builtin_amdgcn_alignbit(lo.y, lo.x, sh);
-        o[1] = __builtin_amdgcn_alignbit(hi.x, lo.y, sh);
-        o[2] = __builtin_amdgcn_alignbit(hi.y, hi.x, sh);
-        o[3] = __builtin_amdgcn_alignbit(nx, hi.y, sh);
+        if (kxh) {
+          const unsigned int nx = *reinterpret_cast<const unsigned int*>(bx + 8);
+          o[0] = __builtin_amdgcn_alignbit(lo.y, lo.x, 16u);
+          o[1] = __builtin_amdgcn_alignbit(hi.x, lo.y, 16u);
+          o[2] = __builtin_amdgcn_alignbit(hi.y, hi.x, 16u);
+          o[3] = __builtin_amdgcn_alignbit(nx, hi.y, 16u);
+        } else {
+          o[0] = lo.x; o[1] = lo.y; o[2] = hi.x; o[3] = hi.y;
+        }
         const bf16x8w bv = __builtin_bit_cast(bf16x8w, o);
-        acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bv, acc[x], 0, 0, 0);
-        acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bv, acc[x], 0, 0, 0);
-        acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bv, acc[x], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bv, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bv, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bv, acc[t], 0, 0, 0);
       }
     }
   }
 #undef WSB_LOAD
+#undef WSB_LDU
 #undef WSB_STD
 #undef WSB_STU
-  // epilogue: add the two K halves in a fixed order, write this workgroup's slab; bias sums per channel in thread order
-  __syncthreads();
-  float* __restrict__ scr = lds;                      // [4 planes][4 acc][256]
-  if (h == 1) {
+  // epilogue: the eight waves' partial tiles added in wave order (four tiles per round through LDS), this workgroup's slab;
+  // bias sums per channel in thread order
+  float* __restrict__ sl = p.slab + (long)blockIdx.x * ((long)p.Cout * p.K + p.Cout);
+  float* __restrict__ scr = lds;                      // [8 waves][4 tiles][256]
+#pragma unroll
+  for (int t0 = 0; t0 < 16; t0 += 4) {
+    __syncthreads();
 #pragma unroll
     for (int x = 0; x < 4; ++x)
-      *reinterpret_cast<float4*>(scr + ((q * 4 + x) * 64 + lane) * 4) = (float4){acc[x][0], acc[x][1], acc[x][2], acc[x][3]};
+      *reinterpret_cast<float4*>(scr + ((w * 4 + x) * 64 + lane) * 4) = (float4){acc[t0 + x][0], acc[t0 + x][1], acc[t0 + x][2], acc[t0 + x][3]};
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                     // 4 tiles x 256 elements = 1024 sums for 512 threads
+      const int o = tid + e * ST_NT, x = o >> 8, l = (o >> 2) & 63, rr = o & 3;
+      float v = scr[((0 * 4 + x) * 64 + l) * 4 + rr];
+#pragma unroll
+      for (int ww = 1; ww < ST_NT / 64; ++ww) v += scr[((ww * 4 + x) * 64 + l) * 4 + rr];
+      const int t = t0 + x, ci = t >> 2, kxh = (t >> 1) & 1, kp = t & 1;
+      const int jj = l & 15, co = 4 * (l >> 4) + rr;
+      const int k = ((ci * 8 + (jj >> 1)) * 8) + 4 * kxh + 2 * kp + (jj & 1);
+      if (co < p.Cout) sl[(long)co * p.K + k] = v;
+    }
   }
-  float* __restrict__ red = lds + 4096;               // [4 * ST_NT] bias partials, index = dOut quad
+  __syncthreads();
+  float* __restrict__ red = lds;                      // [4 * ST_NT] bias partials, index = dOut quad
 #pragma unroll
   for (int u = 0; u < 4; ++u) red[tid + u * ST_NT] = dbv[u];
   __syncthreads();
-  float* __restrict__ sl = p.slab + (long)blockIdx.x * ((long)p.Cout * p.K + p.Cout);
-  const int knat = (q * 8 + ky) * 8 + kxh * 4;
-  if (h == 0) {
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const float4 o = *reinterpret_cast<const float4*>(scr + ((q * 4 + x) * 64 + lane) * 4);
-      const float t[4] = {acc[x][0] + o.x, acc[x][1] + o.y, acc[x][2] + o.z, acc[x][3] + o.w};
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int co = 4 * g + rr;
-        if (co < p.Cout) sl[(long)co * p.K + knat + x] = t[rr];
-      }
-    }
-  }
   if (tid < p.Cout) {
     float sb = 0.f;
     for (int i = tid * dper4; i < (tid + 1) * dper4; ++i) sb += red[i];
@@ -2806,7 +2841,7 @@ static bool plan_wstream_bf16(const a2c_conv_desc* d, const WstreamP& p, WsbGeo&
   if (d->W / 4 > gq.NG * 8 + 1 || d->OW % 4 || d->Cout > 16) return false;
   lds = (size_t)3 * 16 * gq.PA * 2 + (size_t)16 * d->H * gq.PP * 2;
   lds = (lds + 15) / 16 * 16;
-  if (lds < 4 * (4096 + 4 * (size_t)ST_NT)) return false;          // epilogue scratch reuses the images
+  if (lds < 4 * (size_t)(8 * 4 * 256) || 4 * d->H * ((d->W / 4 + 1) / 2) > 8 * ST_NT) return false;   // epilogue scratch reuses the images; 8 frame slots per thread
   if ((long)d->Cout * (d->OH * d->OW / 4) > 4L * ST_NT) return false;
   (void)p;
   return lds <= 160 * 1024 && (gq.PP * 2) % 8 == 0 && 4 * (d->OH - 1) + 7 < d->H;

@@ -390,6 +390,14 @@ int a2c_loss_fwd_bwd(const float *logits, int64_t ld_logits, const float *vals, 
  * Linear forward  y = x W^T + b  (torch.nn.Linear, models.py:73,84,85 ...): transA=0, transB=1.
  * Linear backward dx = dy W: transA=0, transB=0;  dW = dy^T x: transA=1, transB=0.       */
 size_t a2c_gemm_ws_bytes(int64_t M, int64_t N, int splitk);
+/* OPT-IN (A2C_GEMM_X9=1; it ties the fp32 kernels on MI355X): large products (M, N, K >= 256 and
+ * M N K >= 2.5e8) run on the BF16 matrix pipe with fp32 results when the workspace
+ * also holds a2c_gemm_x9_ws_bytes(M, N, K) bytes BEHIND the a2c_gemm_ws_bytes(M, N, splitk) ones (rounded up to 256): each
+ * operand is split, in one pass, into three bf16 images a = a1 + a2 + a3 (exact: 3 x 8 significant bits), every one of the
+ * nine piece products is exact, every sum is the MFMA's fp32 accumulator's -- nn.Linear's fp32 sum (models.py:246-264),
+ * re-associated, at 9/16 of the fp32 matrix time on paper.  0: the product does not take that path.
+ * Without the extra bytes a2c_gemm_f32 runs the fp32 MFMA kernels.                                                  */
+size_t a2c_gemm_x9_ws_bytes(int64_t M, int64_t N, int64_t K);
 int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A,
                  int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                  const float *bias, int relu, const float *mask, int64_t ldmask, int accumulate,

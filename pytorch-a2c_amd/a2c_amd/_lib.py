@@ -87,6 +87,7 @@ SIGNATURES = {
     "a2c_loss_fwd_bwd": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, c_int64, c_int, c_float, c_float,
                                   c_float, P, c_int64, P, c_int64, P, P, P]),
     "a2c_gemm_ws_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "a2c_gemm_x9_ws_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "a2c_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64,
                               P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
     "a2c_gemm_splits": (c_int, [c_int64, c_int]),

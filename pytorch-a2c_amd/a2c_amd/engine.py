@@ -194,7 +194,8 @@ def linear_fwd(ws, x_ptr, ldx, W, b, out, M, st, relu=False):
     """out[M,N] = x[M,K] W[N,K]^T + b   (nn.Linear)"""
     N, K = W.shape
     sk = ops.pick_splitk(M, N, K)
-    buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(M, N, sk)) if sk > 1 else None
+    nb = ops.gemm_ws_bytes(M, N, sk, K)
+    buf = ws.bytes("gemm_ws", nb) if nb else None
     with ops.span(f"linear.fwd {N}x{K}"):
         ops.gemm(0, 1, M, N, K, x_ptr, ldx, W.data_ptr(), K, out.data_ptr(), out.stride(0), bias=b, relu=relu,
                  splitk=sk, ws=buf, st=st)
@@ -205,16 +206,19 @@ def linear_bwd_data(ws, dy, W, dx, M, st, mask=None, n_cols=None):
     derivative of the producer of that input fused in."""
     N, K = W.shape
     n = N if n_cols is None else n_cols
+    nb = ops.gemm_ws_bytes(M, K, 1, n)
+    buf = ws.bytes("gemm_ws", nb) if nb else None
     with ops.span(f"linear.bwd_data {N}x{K}"):
         ops.gemm(0, 0, M, K, n, dy.data_ptr(), dy.stride(0), W.data_ptr(), K, dx.data_ptr(), dx.stride(0),
-                 mask_ptr=0 if mask is None else mask.data_ptr(), ldmask=0 if mask is None else K, st=st)
+                 mask_ptr=0 if mask is None else mask.data_ptr(), ldmask=0 if mask is None else K, ws=buf, st=st)
 
 
 def linear_bwd_weight(ws, dy, x_ptr, ldx, dW, db, M, st):
     """dW[N,K] = dy[M,N]^T x[M,K];  db[N] = sum_m dy[m,:]"""
     N, K = dW.shape
     sk = ops.pick_splitk(N, K, M)
-    buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(N, K, sk)) if sk > 1 else None
+    nb = ops.gemm_ws_bytes(N, K, sk, M)
+    buf = ws.bytes("gemm_ws", nb) if nb else None
     with ops.span(f"linear.bwd_weight {N}x{K}"):
         ops.gemm(1, 0, N, K, M, dy.data_ptr(), dy.stride(0), x_ptr, ldx, dW.data_ptr(), K, splitk=sk, ws=buf, st=st)
     if db is not None:

@@ -527,8 +527,13 @@ def heads_fused(xs_ptr, nslab, slab_stride, ldx, bias_in, relu_in, emb_out, W, b
           "a2c_heads_fused")
 
 
-def gemm_ws_bytes(M, N, splitk):
-    return lib().a2c_gemm_ws_bytes(M, N, splitk)
+def gemm_ws_bytes(M, N, splitk, K=None):
+    """split-K slabs; with K given, plus the bf16 images of the x 9 path of large products behind them (a2c_gemm_x9_ws_bytes)"""
+    base = lib().a2c_gemm_ws_bytes(M, N, splitk)
+    if K is None:
+        return base
+    x9 = lib().a2c_gemm_x9_ws_bytes(M, N, K)
+    return base if not x9 else (base + 255) // 256 * 256 + x9
 
 
 def colsum(x_ptr, ld, M, N, out, ws, st=None):

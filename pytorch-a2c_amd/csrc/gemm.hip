@@ -204,6 +204,259 @@ __global__ __launch_bounds__(256) void gemm_kernel(long M, long N, long K, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same block-tiled GEMM on the BF16 matrix pipe with fp32 results ("bf16 x 9", round 5).  Every fp32 operand element is
+// split into three bf16 pieces a = a1 + a2 + a3 (round to nearest each; exact: 3 x 8 significant bits cover the 24 of an
+// fp32), so a * b = sum over the 9 piece pairs of a_i * b_j with EVERY product exact (8 x 8 bits) and every sum in the MFMA's
+// fp32 accumulator -- the real-number sum of the fp32 FMA chain, re-associated; against fp64 it is no less accurate than
+// the fp32 MFMA form (test).  9 v_mfma_f32_32x32x16_bf16 (32 cycles each) per 16-deep k-step replace 8
+// v_mfma_f32_32x32x2_f32 (64 cycles each): 0.56 of the matrix time -- on paper; measured it only ties the fp32 kernels on the
+// 28224 x 2000 layers of ConvModel (see x9_eligible below), so the path is opt-in (A2C_GEMM_X9=1).
+//   x9_split_kernel   one pass over each operand: fp32 (rows x k, either orientation) -> three bf16 images [piece][row][k],
+//                     k-contiguous, rows padded to 128 and k to 32 with zeros (splitting inside the GEMM's staging phase
+//                     cost more than the matrix phase it fed: 1.6 of 2.7 ms);
+//   gemm_x9_kernel    C = A B^T over those images: tile 128 x 128 x 32, 4 waves of 64 x 64, 16-byte global -> register
+//                     -> LDS staging with the next tile in flight, LDS rows of 80 bytes (a lane's 8 consecutive k = one
+//                     conflict-free ds_read_b128), no bounds checks in the loop.
+typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+constexpr int X9_BK = 32, X9_LD = 40;                 // bf16 elements per LDS row (80 B: rows 0..15 hit 16 distinct 16-byte bank groups)
+constexpr int X9_PSZ = 128 * X9_LD;                   // one piece image of a 128-row operand tile
+
+__device__ __forceinline__ void split1_x9(float e, unsigned short pc[3]) {
+  const __bf16 h0 = (__bf16)e;
+  const float r1 = e - (float)h0;                     // exact
+  const __bf16 h1 = (__bf16)r1;
+  const float r2 = r1 - (float)h1;                    // exact, at most 8 significant bits
+  pc[0] = __builtin_bit_cast(unsigned short, h0);
+  pc[1] = __builtin_bit_cast(unsigned short, h1);
+  pc[2] = __builtin_bit_cast(unsigned short, (__bf16)r2);
+}
+// dst[q][r][k] (r < Rp, k < Kp; piece stride Rp * Kp) <- split(src), zero outside R x K.  Every thread produces 8 consecutive
+// k of one row: three 16-byte stores.  TRANS = false: src[r * ld + k] (two 16-byte loads where aligned);
+// TRANS = true: src[k * ld + r]: a tile of 32 k x 64 rows goes through LDS (loads coalesced along r).
+__device__ __forceinline__ void split8_store(const float e[8], unsigned short* __restrict__ d, long pst) {
+  unsigned int o[3][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned short a[3], b[3];
+    split1_x9(e[2 * i], a);
+    split1_x9(e[2 * i + 1], b);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) o[q][i] = (unsigned int)a[q] | ((unsigned int)b[q] << 16);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4g*>(d + q * pst) = (u32x4g){o[q][0], o[q][1], o[q][2], o[q][3]};
+}
+template <bool TRANS>
+__global__ __launch_bounds__(256) void x9_split_kernel(const float* __restrict__ src, long ld, long R, long K, unsigned short* __restrict__ dst,
+                                                       long Rp, long Kp, int vec) {
+  const long pst = Rp * Kp;
+  if (!TRANS) {
+    const long nchunk = Rp * (Kp >> 3);
+    for (long c = blockIdx.x * 256L + threadIdx.x; c < nchunk; c += gridDim.x * 256L) {
+      const long r = c / (Kp >> 3), k = (c - r * (Kp >> 3)) << 3;
+      float e[8];
+      if (r < R && vec && k + 7 < K) {
+        const float4 v0 = *reinterpret_cast<const float4*>(src + r * ld + k), v1 = *reinterpret_cast<const float4*>(src + r * ld + k + 4);
+        e[0] = v0.x; e[1] = v0.y; e[2] = v0.z; e[3] = v0.w; e[4] = v1.x; e[5] = v1.y; e[6] = v1.z; e[7] = v1.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = (r < R && k + i < K) ? src[r * ld + k + i] : 0.f;
+      }
+      split8_store(e, dst + r * Kp + k, pst);
+    }
+  } else {
+    __shared__ float tile[32][65];
+    const long r0 = (long)blockIdx.y * 64, k0 = (long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 x 4
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long k = k0 + ty + 4 * i, r = r0 + tx;
+      tile[ty + 4 * i][tx] = (k < K && r < R) ? src[k * ld + r] : 0.f;
+    }
+    __syncthreads();
+    const int rr = threadIdx.x >> 2, kc = (threadIdx.x & 3) * 8;     // row 0..63, chunk of 8 k
+    float e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = tile[kc + i][rr];
+    if (r0 + rr < Rp) split8_store(e, dst + (r0 + rr) * Kp + k0 + kc, pst);
+  }
+}
+
+struct Frag9 { u32x4g v[6]; };
+// operand tile: 3 pieces x 128 rows x 32 k = 1536 chunks of 8 bf16 (16 B), six per thread
+__device__ __forceinline__ void load_tile9(Frag9& f, const unsigned short* __restrict__ P, long pst, long Kp, long r0, long k0) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int c = t + 256 * it, q = c >> 9, rem = c & 511;
+    f.v[it] = *reinterpret_cast<const u32x4g*>(P + q * pst + (r0 + (rem >> 2)) * Kp + k0 + 8 * (rem & 3));
+  }
+}
+__device__ __forceinline__ void store_tile9(const Frag9& f, unsigned short* __restrict__ S) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int c = t + 256 * it, q = c >> 9, rem = c & 511;
+    *reinterpret_cast<u32x4g*>(S + q * X9_PSZ + (rem >> 2) * X9_LD + 8 * (rem & 3)) = f.v[it];
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_x9_kernel(long M, long N, long K, const unsigned short* __restrict__ Ap, long apst,
+                                                      const unsigned short* __restrict__ Bp, long bpst, long Kp, float* __restrict__ C,
+                                                      long ldc, const float* __restrict__ bias, int relu,
+                                                      const float* __restrict__ mask, long ldmask, int accumulate,
+                                                      long k_per_split, float* __restrict__ slab, int vec_epi) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem9[2 * 3 * X9_PSZ];          // 61,440 B; >= 4 x 32 x 32 floats for the epilogue
+  unsigned short* __restrict__ As = smem9;
+  unsigned short* __restrict__ Bs = smem9 + 3 * X9_PSZ;
+  float* __restrict__ smem = reinterpret_cast<float*>(smem9);
+  // XCD-aware tile order: workgroup ids go round robin over the 8 XCDs (each with its own L2); XCD x walks ITS column
+  // blocks x, x + 8, ... and, per column block, all row blocks back to back -- the 128-row B image tile (K x 768 B) is
+  // fetched from HBM once and reused from that XCD's L2 by every row block; the A image streams from the infinity cache.
+  // (The plain x-fastest order re-read B from HBM once per row block: 5.5 GB per 2048 x 28224 x 2000 product, 2.1 ms.)
+  const long nmb = gridDim.y, nnb = gridDim.x;
+  long bm, bn;
+  {
+    const long bid = (long)blockIdx.y * gridDim.x + blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const long ncol_x = (nnb - xcd + 7) >> 3;          // column blocks of this XCD
+    if (nnb >= 8 && idx < ncol_x * nmb) { bm = idx % nmb; bn = (idx / nmb) * 8 + xcd; }
+    else { bm = blockIdx.y; bn = blockIdx.x; }
+    if (nnb >= 8) {
+      // ids beyond an XCD's share (nnb % 8 != 0 leaves the XCDs unequal): the leftover tiles in plain order
+      const long per = (nnb >> 3) * nmb;               // tiles every XCD surely owns
+      if (idx >= per) {
+        // leftover: column blocks 8 * (nnb >> 3) .. nnb - 1, all row blocks; leftover ids are (idx - per) * 8 + xcd
+        const long l = (idx - per) * 8 + xcd, nleft = (nnb & 7) * nmb;
+        if (l < nleft) { bm = l % nmb; bn = (nnb >> 3) * 8 + l / nmb; }
+        else return;
+      } else { bm = idx % nmb; bn = (idx / nmb) * 8 + xcd; }
+    }
+  }
+  const long m0 = bm * BM, n0 = bn * BN;
+  const long kbeg = (long)blockIdx.z * k_per_split;
+  const long kend = min(Kp, kbeg + k_per_split);      // (k_per_split is a multiple of 32; the images are zero beyond K)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int li = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Frag9 fa, fb;
+  load_tile9(fa, Ap, apst, Kp, m0, kbeg);
+  load_tile9(fb, Bp, bpst, Kp, n0, kbeg);
+  const unsigned short* __restrict__ ar = As + (wr * 64 + li) * X9_LD + 8 * lk;
+  const unsigned short* __restrict__ br = Bs + (wc * 64 + li) * X9_LD + 8 * lk;
+  for (long k0 = kbeg; k0 < kend; k0 += X9_BK) {
+    store_tile9(fa, As);
+    store_tile9(fb, Bs);
+    __syncthreads();
+    if (k0 + X9_BK < kend) {
+      load_tile9(fa, Ap, apst, Kp, m0, k0 + X9_BK);
+      load_tile9(fb, Bp, bpst, Kp, n0, k0 + X9_BK);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {                  // two 16-deep k-steps per staged tile
+      bf16x8g a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          a[i][q] = *reinterpret_cast<const bf16x8g*>(ar + q * X9_PSZ + i * 32 * X9_LD + 16 * s2);
+          b[i][q] = *reinterpret_cast<const bf16x8g*>(br + q * X9_PSZ + i * 32 * X9_LD + 16 * s2);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // smallest pairs first (lo x lo ... hi x hi): the accumulator meets the terms in rising magnitude
+#pragma unroll
+          for (int sidx = 4; sidx >= 0; --sidx)
+#pragma unroll
+            for (int qa = 2; qa >= 0; --qa) {
+              const int qb = sidx - qa;
+              if (qb < 0 || qb > 2) continue;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+  }
+
+  // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool direct = (slab == nullptr);
+  if (direct && vec_epi) {
+    // Row-major epilogue: each 32x32 block goes through this wave's 4 KB of LDS and leaves as
+    // float4 rows, so bias / accumulate / ReLU-mask are 16 B loads and the stores full 128 B rows:
+    // 4 + 4 vector memory instructions per block and lane instead of 16 + 16 dependent dword ones.
+    float* __restrict__ stg = smem + w * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lk) * 32 + li] = acc[i][j][r];
+        const int c4 = (lane & 7) * 4;
+        const long n = n0 + wc * 64 + j * 32 + c4;
+        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && n < N) bv4 = *reinterpret_cast<const float4*>(bias + n);
+        float4 mk[4], od[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const long m = min(m0 + wr * 64 + i * 32 + q * 8 + (lane >> 3), M - 1);
+          const long nc = min(n, N - 4);
+          mk[q] = mask ? *reinterpret_cast<const float4*>(mask + m * ldmask + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
+          od[q] = accumulate ? *reinterpret_cast<const float4*>(C + m * ldc + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = q * 8 + (lane >> 3);
+          const long m = m0 + wr * 64 + i * 32 + row;
+          float4 v = *reinterpret_cast<const float4*>(stg + row * 32 + c4);
+          v.x = (v.x + od[q].x) + bv4.x; v.y = (v.y + od[q].y) + bv4.y;      // same order as the scalar path
+          v.z = (v.z + od[q].z) + bv4.z; v.w = (v.w + od[q].w) + bv4.w;
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (!(mk[q].x > 0.f)) v.x = 0.f;
+          if (!(mk[q].y > 0.f)) v.y = 0.f;
+          if (!(mk[q].z > 0.f)) v.z = 0.f;
+          if (!(mk[q].w > 0.f)) v.w = 0.f;
+          if (m < M && n < N) *reinterpret_cast<float4*>(C + m * ldc + n) = v;
+        }
+      }
+    return;
+  }
+  float* out = direct ? C : slab + (long)blockIdx.z * M * N;
+  const long ldo = direct ? ldc : N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long n = n0 + wc * 64 + j * 32 + li;
+      if (n >= N) continue;
+      const float bv = (direct && bias) ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= M) continue;
+        float v = acc[i][j][r];
+        if (direct) {
+          if (accumulate) v += out[m * ldo + n];
+          v += bv;
+          if (relu) v = fmaxf(v, 0.f);
+          if (mask && !(mask[m * ldmask + n] > 0.f)) v = 0.f;
+        }
+        out[m * ldo + n] = v;
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, long M,
                                                             long N, float* __restrict__ C, long ldc,
                                                             const float* __restrict__ bias, int relu,
@@ -995,7 +1248,8 @@ void launch_gemm(dim3 grid, hipStream_t st, long M, long N, long K, const float*
   const int vec_epi = slab == nullptr && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) &&
                       (!mask || (ldmask % 4 == 0 && (uintptr_t)mask % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0) &&
                       !getenv("A2C_GEMM_SCALAR_EPILOGUE");
-  if (M <= 96)
+  if (false) {}
+  else if (M <= 96)
     hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu,
                        mask, ldmask, acc, kps, slab, vecA, vecB, vec_epi);
   else
@@ -1012,6 +1266,25 @@ size_t a2c_gemm_ws_bytes(int64_t M, int64_t N, int splitk) {
     if (sn > need) need = sn;
   }
   return need;
+}
+
+// bf16 x 9 path of a2c_gemm_f32 (large products): bytes of the three-piece bf16 images of both operands, rows padded to 128
+// and k to 32; 0 when the product does not take that path.  The caller's workspace must hold a2c_gemm_ws_bytes(M, N, splitk)
+// FOLLOWED by this (a2c_gemm_f32 falls back to the fp32 MFMA kernel when it does not).
+static bool x9_eligible(int64_t M, int64_t N, int64_t K) {
+  // OPT-IN (A2C_GEMM_X9=1; read per call): measured on MI355X (tools/gemm_x9_bench.py) the x 9 form ties the fp32 MFMA kernels on
+  // ConvModel's 28224 x 2000 layers -- 2048 rows: NN 2.30 vs 2.26 ms, TN 2.14 vs 2.23, NT 2.42 vs 2.74 including the two
+  // split passes (0.12-0.14 ms each); 32,768 rows: 29.9 / 34.1 / 33.3 vs 31.3 / 32.1 / 32.1 -- the bf16 pipe's 9/16 of the
+  // matrix time is eaten by 1.5 x the operand bytes through L2 / LDS and by the clock the part holds under dense bf16 MFMA on
+  // random data; it pays where ONE operand is exact in bf16 (uint8 frames: 3 pieces, not 9; conv.hip / step.hip).
+  const char* e9 = getenv("A2C_GEMM_X9");
+  if (!(e9 != nullptr && e9[0] == '1')) return false;
+  return M >= 256 && N >= 256 && K >= 256 && (double)M * (double)N * (double)K >= 2.5e8;
+}
+size_t a2c_gemm_x9_ws_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M < 1 || N < 1 || K < 1 || !x9_eligible(M, N, K)) return 0;
+  const size_t Mp = (size_t)(M + 127) / 128 * 128, Np = (size_t)(N + 127) / 128 * 128, Kp = (size_t)(K + 31) / 32 * 32;
+  return 3 * 2 * (Mp + Np) * Kp + 256;
 }
 
 int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -1100,6 +1373,39 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)splitk);
   hipStream_t st = a2c_s(stream);
   const bool a_kc = (transA == 0), b_kc = (transB != 0);
+  {  // large products: the bf16 x 9 form (exact 3-way split of both operands, fp32 accumulation) when the workspace holds the images
+    const size_t base = a2c_gemm_ws_bytes(M, N, splitk), need9 = a2c_gemm_x9_ws_bytes(M, N, K);
+    const size_t off9 = (base + 255) / 256 * 256;
+    if (need9 && ws && ws_bytes >= off9 + need9) {
+      const long Mp = (M + 127) / 128 * 128, Np = (N + 127) / 128 * 128, Kp = (K + 31) / 32 * 32;
+      unsigned short* Ap = reinterpret_cast<unsigned short*>((char*)ws + off9);
+      unsigned short* Bp = Ap + 3 * Mp * Kp;
+      dim3 ga((unsigned)(Kp / 32), (unsigned)(Mp / 64)), gb((unsigned)(Kp / 32), (unsigned)(Np / 64));
+      const int g1a = a2c_grid_1d(Mp * (Kp / 8), 256), g1b = a2c_grid_1d(Np * (Kp / 8), 256);
+      if (a_kc) hipLaunchKernelGGL((x9_split_kernel<false>), dim3(g1a), dim3(256), 0, st, A, (long)lda, (long)M, (long)K, Ap, Mp, Kp, vecA);
+      else hipLaunchKernelGGL((x9_split_kernel<true>), ga, dim3(256), 0, st, A, (long)lda, (long)M, (long)K, Ap, Mp, Kp, 0);
+      A2C_CHECK_LAUNCH();
+      if (b_kc) hipLaunchKernelGGL((x9_split_kernel<false>), dim3(g1b), dim3(256), 0, st, B, (long)ldb, (long)N, (long)K, Bp, Np, Kp, vecB);
+      else hipLaunchKernelGGL((x9_split_kernel<true>), gb, dim3(256), 0, st, B, (long)ldb, (long)N, (long)K, Bp, Np, Kp, 0);
+      A2C_CHECK_LAUNCH();
+      const long kps9 = (kps + 31) / 32 * 32;
+      const int sk9 = (int)((Kp + kps9 - 1) / kps9);
+      if (sk9 <= splitk) {
+        const int vec_epi = sk9 == 1 && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) &&
+                            (!mask || (ldmask % 4 == 0 && (uintptr_t)mask % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0);
+        dim3 g9((unsigned)(Np / 128), (unsigned)(Mp / 128), (unsigned)sk9);
+        hipLaunchKernelGGL(gemm_x9_kernel, g9, dim3(256), 0, st, (long)M, (long)N, (long)K, Ap, Mp * Kp, Bp, Np * Kp, Kp, C,
+                           (long)ldc, bias, relu, mask, (long)ldmask, accumulate, kps9, sk9 > 1 ? slab : nullptr, vec_epi);
+        A2C_CHECK_LAUNCH();
+        if (sk9 > 1) {
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(a2c_grid_1d(M * N, 256)), dim3(256), 0, st, slab, sk9, (long)M,
+                             (long)N, C, (long)ldc, bias, relu, mask, (long)ldmask, accumulate);
+          A2C_CHECK_LAUNCH();
+        }
+        return A2C_OK;
+      }
+    }
+  }
   if (a_kc && b_kc && launch_gemm_nt(M, N, K, A, lda, B, ldb, kps, splitk, slab, vecA, vecB, st)) {}
   else if (a_kc && b_kc && launch_skinny_stream(M, N, K, A, lda, B, ldb, kps, splitk, slab, vecA, vecB, st)) {}
   else if (a_kc && b_kc) launch_gemm<true, true>(grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldmask, accumulate, kps, slab, vecA, vecB);

@@ -565,6 +565,15 @@ int a2c_gru_out_bwd_carry(const float *dh_new, const float *carry, const float *
 int a2c_gru_gates_bwd(const float *d_rh, const float *dz, const float *h, const float *z,
                       const float *r, float *dz_pre, float *dr_pre, float *dh, int B, int hdim,
                       a2c_stream_t stream);
+/* One step of the BPTT unroll's backward (updater.py:139-169 differentiated) in two launches instead of five; bit-identical
+ * to a2c_gru_out_bwd[_carry] + a2c_gemm_f32 (dc_pre Wh[2]^T) + a2c_gru_gates_bwd + two accumulating a2c_gemm_f32
+ * (dz_pre Wh[0]^T, dr_pre Wh[1]^T):  g = dh_new + carry * (1 - dones[b * done_stride]) (carry may be NULL);
+ * dc_pre = g (1-z)(1-c^2), dz = g (h - c), d_rh = dc_pre Wh[2]^T, dz_pre = dz z (1-z), dr_pre = d_rh h r (1-r),
+ * dh = g z + d_rh r + dz_pre Wh[0]^T + dr_pre Wh[1]^T.  Wh = gru.W_h (3, hdim, hdim); carry must not alias dh.        */
+int a2c_gru_cell_bwd(const float *dh_new, const float *carry, const float *dones, int64_t done_stride,
+                     const float *h, const float *z, const float *r, const float *c, const float *Wh,
+                     float *dc_pre, float *dz, float *dz_pre, float *dr_pre, float *dh, int B, int hdim,
+                     a2c_stream_t stream);
 /* torch.nn.LayerNorm over the last dim n (eps 1e-5), FCModel value head (models.py:392) */
 int a2c_layernorm_fwd(const float *x, const float *w, const float *b, float *y, float *mean,
                       float *rstd, int64_t rows, int n, a2c_stream_t stream);

@@ -139,6 +139,7 @@ SIGNATURES = {
     "a2c_frames_to_states": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, c_int, P]),
     "a2c_gru_gates": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "a2c_gru_out": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
+    "a2c_gru_cell_bwd": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "a2c_gru_cell_fwd": (c_int, [P, c_int64, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "a2c_gru_out_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "a2c_gru_out_bwd_carry": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, P]),

@@ -844,6 +844,15 @@ class _GruMixin:
         Wh = self.P("gru.W_h")
         z, r, c = bufs["z"], bufs["r"], bufs["c"]
         dzp, drp, dcp, dz, drh, dh = (dbufs[k] for k in ("dz_pre", "dr_pre", "dc_pre", "dz", "d_rh", "dh"))
+        if (B <= 1280 and hd % 32 == 0 and (carry is None or carry[0].data_ptr() != dh.data_ptr())
+                and os.environ.get("A2C_NO_GRU_FUSE") != "1"):
+            # the step's five launches (~4.5 us each, strictly serial over the unroll) as two, bit-identical
+            with ops.span("gru.cell_bwd"):
+                if carry is not None:
+                    ops.gru_cell_bwd(dhn, carry[0], carry[1], carry[2], h_in, z, r, c, Wh, dcp, dz, dzp, drp, dh, st)
+                else:
+                    ops.gru_cell_bwd(dhn, None, 0, 1, h_in, z, r, c, Wh, dcp, dz, dzp, drp, dh, st)
+            return dh
         if carry is not None:
             ops.gru_out_bwd_carry(dhn, carry[0], carry[1], carry[2], h_in, z, c, dcp, dz, dh, st)
         else:
@@ -913,6 +922,7 @@ class _GruMixin:
         tm = self._tm_bufs(ws, R, T)
         dtm = {k: ws.get("tm_" + k, (T, R, h)) for k in ("dz_pre", "dr_pre", "dc_pre")}
         scratch = {k: ws.get("bp_" + k, (R, h)) for k in ("dz", "d_rh", "dh")}
+        dh_alt = ws.get("bp_dh2", (R, h))            # the fused step reads the carry while it writes dh: two buffers, in turn
         carry = None
         fused = os.environ.get("A2C_NO_GRU_CARRY") != "1"
         for t in range(T - 1, -1, -1):
@@ -921,6 +931,8 @@ class _GruMixin:
                 ops.add(dhn, carry, dhn, st)
             bufs = {k: tm[k][t] for k in ("z", "r", "c")}
             dbufs = dict(dz_pre=dtm["dz_pre"][t], dr_pre=dtm["dr_pre"][t], dc_pre=dtm["dc_pre"][t], **scratch)
+            if carry is not None and carry.data_ptr() == dbufs["dh"].data_ptr():
+                dbufs["dh"] = dh_alt
             # h_in[t+1] = hn[t] * (1 - dones[:, t]): the gradient that reached it comes back masked by the same factor --
             # inside the first launch of this step (was: mask_rows + add, two launches of 3.8 us per time step)
             dh = self._gru_bwd_step(ws, dhn, tm["h_in"][t], R, st, bufs, dbufs,

@@ -720,6 +720,14 @@ def gru_cell_fwd(x, h, WxC, WhC, Wh2, b, gx, z, r, rh, c, h_new, st=None):
                                  _p(c), _p(h_new), B, xs, hd, st if st is not None else stream()), "a2c_gru_cell_fwd")
 
 
+def gru_cell_bwd(dh_new, carry, dones_ptr, done_stride, h, z, r, c, Wh, dc_pre, dz, dz_pre, dr_pre, dh, st=None):
+    """one BPTT backward step of the cell in two launches (a2c_gru_cell_bwd); carry (or None) must not alias dh"""
+    B, hd = h.shape
+    check(lib().a2c_gru_cell_bwd(_p(dh_new), _p(carry), dones_ptr, done_stride, _p(h), _p(z), _p(r), _p(c), _p(Wh), _p(dc_pre),
+                                 _p(dz), _p(dz_pre), _p(dr_pre), _p(dh), B, hd, st if st is not None else stream()),
+          "a2c_gru_cell_bwd")
+
+
 def gru_out_bwd(dh_new, h, z, c, dc_pre, dz, dh, st=None):
     B, hd = h.shape
     check(lib().a2c_gru_out_bwd(_p(dh_new), _p(h), _p(z), _p(c), _p(dc_pre), _p(dz), _p(dh), B, hd,

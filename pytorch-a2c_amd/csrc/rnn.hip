@@ -213,6 +213,134 @@ __global__ __launch_bounds__(256) void gru_cell_out_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One step of the BPTT unroll's backward (updater.py:139-169 differentiated; the reference leaves it to autograd) in TWO
+// launches instead of five -- gru_out_bwd[_carry], (dc_pre) Wh2^T, gru_gates_bwd, (dz_pre) Wh0^T, (dr_pre) Wh1^T: 128
+// strictly serial steps of ~4.5 us per launch are 2.9 ms of a 37 ms update.
+//   gru_cell_bwd1_kernel  tile (32 rows x 32 columns) of d_rh = dc_pre Wh2^T with dc_pre = g (1 - z) (1 - c^2),
+//                         g = dh_new + carry (1 - done), computed on the fly as the A operand (column block 0 also writes
+//                         dc_pre and dz); epilogue: dz_pre, dr_pre and dh = g z + d_rh r of its tile
+//   gru_cell_bwd2_kernel  dh += dz_pre Wh0^T, then += dr_pre Wh1^T
+// Same products, K split, MFMA order and order of additions as the five launches (a2c_gemm_f32's small-product kernel
+// with k-contiguous B): bit-identical (test).  carry must not alias dh (the caller ping-pongs two buffers).
+__device__ __forceinline__ void gru_mfma4(f32x16& acc, const float4 a, const float4 b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+}
+// wave w's share of A (rows, k-contiguous) . B^T (B rows = output columns, k-contiguous), K range [kbeg, kend)
+__device__ __forceinline__ f32x16 gru_tile_part_kc(const float* __restrict__ arow, const float* __restrict__ brow, long kbeg, long kend) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (long k = kbeg; k + 8 <= kend; k += 8)
+    gru_mfma4(acc, *reinterpret_cast<const float4*>(arow + k), *reinterpret_cast<const float4*>(brow + k));
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void gru_cell_bwd1_kernel(const float* __restrict__ dhn, const float* __restrict__ carry,
+                                                            const float* __restrict__ dones, long dstride,
+                                                            const float* __restrict__ h, const float* __restrict__ z,
+                                                            const float* __restrict__ r, const float* __restrict__ c,
+                                                            const float* __restrict__ Wh2, float* __restrict__ dcp,
+                                                            float* __restrict__ dz, float* __restrict__ dzp, float* __restrict__ drp,
+                                                            float* __restrict__ dh, long M, int hd) {
+  __shared__ __attribute__((aligned(16))) float red[4][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const long n0 = (long)blockIdx.x * 32, m0 = (long)blockIdx.y * 32;
+  const long K = hd;
+  const long kq = ((K / 8 + 3) / 4) * 8;
+  const long kbeg = min(K, w * kq), kend = min(K, kbeg + kq);
+  const long mrow = min(m0 + li, M - 1);
+  const float keep = carry ? 1.f - dones[mrow * dstride] : 0.f;
+  const float* __restrict__ brow = Wh2 + min(n0 + li, (long)hd - 1) * hd + 4 * lk;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  const bool writer = blockIdx.x == 0 && m0 + li < M;
+  for (long k = kbeg; k + 8 <= kend; k += 8) {
+    const long i = mrow * hd + k + 4 * lk;
+    const float4 gd = *reinterpret_cast<const float4*>(dhn + i);
+    const float4 zz = *reinterpret_cast<const float4*>(z + i), cc = *reinterpret_cast<const float4*>(c + i);
+    float4 g = gd;
+    if (carry) {
+      const float4 cr = *reinterpret_cast<const float4*>(carry + i);
+      g.x = gd.x + cr.x * keep; g.y = gd.y + cr.y * keep; g.z = gd.z + cr.z * keep; g.w = gd.w + cr.w * keep;
+    }
+    float4 a;
+    a.x = g.x * (1.f - zz.x) * (1.f - cc.x * cc.x);
+    a.y = g.y * (1.f - zz.y) * (1.f - cc.y * cc.y);
+    a.z = g.z * (1.f - zz.z) * (1.f - cc.z * cc.z);
+    a.w = g.w * (1.f - zz.w) * (1.f - cc.w * cc.w);
+    if (writer) {
+      const float4 hh = *reinterpret_cast<const float4*>(h + i);
+      *reinterpret_cast<float4*>(dcp + i) = a;
+      *reinterpret_cast<float4*>(dz + i) = make_float4(g.x * (hh.x - cc.x), g.y * (hh.y - cc.y), g.z * (hh.z - cc.z), g.w * (hh.w - cc.w));
+    }
+    gru_mfma4(acc, a, *reinterpret_cast<const float4*>(brow + k));
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) red[w][q][lane] = acc[q];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = w * 4 + e;
+    float drh = red[0][q][lane];
+    drh += red[1][q][lane];
+    drh += red[2][q][lane];
+    drh += red[3][q][lane];
+    const long m = m0 + (q & 3) + 8 * (q >> 2) + 4 * lk, n = n0 + li;
+    if (m >= M) continue;
+    const long i = m * hd + n;
+    const float g = carry ? dhn[i] + carry[i] * (1.f - dones[m * dstride]) : dhn[i];
+    const float zz = z[i], rr = r[i], hh = h[i], cc = c[i];
+    const float dzv = g * (hh - cc);
+    dzp[i] = dzv * zz * (1.f - zz);
+    drp[i] = drh * hh * rr * (1.f - rr);
+    float d = g * zz;
+    d += drh * rr;
+    dh[i] = d;
+  }
+}
+
+__global__ __launch_bounds__(512) void gru_cell_bwd2_kernel(const float* __restrict__ dzp, const float* __restrict__ drp,
+                                                            const float* __restrict__ Wh0, const float* __restrict__ Wh1,
+                                                            float* __restrict__ dh, long M, int hd) {
+  __shared__ __attribute__((aligned(16))) float red[8][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const long n0 = (long)blockIdx.x * 32, m0 = (long)blockIdx.y * 32;
+  const long K = hd;
+  const long kq = ((K / 8 + 3) / 4) * 8;
+  const int wk = w & 3;
+  const long kbeg = min(K, wk * kq), kend = min(K, kbeg + kq);
+  const float* __restrict__ arow = (w < 4 ? dzp : drp) + min(m0 + li, M - 1) * hd + 4 * lk;
+  const float* __restrict__ brow = (w < 4 ? Wh0 : Wh1) + min(n0 + li, (long)hd - 1) * hd + 4 * lk;
+  const f32x16 acc = gru_tile_part_kc(arow, brow, kbeg, kend);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) red[w][q][lane] = acc[q];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int q = w * 2 + e;
+    float v0 = red[0][q][lane];
+    v0 += red[1][q][lane];
+    v0 += red[2][q][lane];
+    v0 += red[3][q][lane];
+    float v1 = red[4][q][lane];
+    v1 += red[5][q][lane];
+    v1 += red[6][q][lane];
+    v1 += red[7][q][lane];
+    const long m = m0 + (q & 3) + 8 * (q >> 2) + 4 * lk, n = n0 + li;
+    if (m >= M) continue;
+    v0 += dh[m * hd + n];
+    v1 += v0;
+    dh[m * hd + n] = v1;
+  }
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y,
@@ -295,6 +423,26 @@ int a2c_gru_cell_fwd(const float* x, int64_t ldx, const float* h, const float* W
   A2C_CHECK_LAUNCH();
   hipLaunchKernelGGL(gru_cell_out_kernel, dim3(tiles, rows), dim3(256), 0, a2c_s(stream), gx, rh, Wh2, b, h, z, c, h_new,
                      (long)B, hdim);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_gru_cell_bwd(const float* dh_new, const float* carry, const float* dones, int64_t done_stride, const float* h,
+                     const float* z, const float* r, const float* c, const float* Wh, float* dc_pre, float* dz, float* dz_pre,
+                     float* dr_pre, float* dh, int B, int hdim, a2c_stream_t stream) {
+  if (B < 0 || hdim < 32 || hdim % 32 || (carry && (!dones || done_stride < 1))) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!dh_new || !h || !z || !r || !c || !Wh || !dc_pre || !dz || !dz_pre || !dr_pre || !dh || carry == dh) return A2C_ERR_ARG;
+  if ((((uintptr_t)dh_new | (uintptr_t)carry | (uintptr_t)h | (uintptr_t)z | (uintptr_t)c | (uintptr_t)Wh | (uintptr_t)dc_pre |
+        (uintptr_t)dz | (uintptr_t)dz_pre | (uintptr_t)dr_pre) % 16))
+    return A2C_ERR_ARG;
+  const int tiles = hdim / 32, rows = (B + 31) / 32;
+  const long hh = (long)hdim * hdim;
+  hipLaunchKernelGGL(gru_cell_bwd1_kernel, dim3(tiles, rows), dim3(256), 0, a2c_s(stream), dh_new, carry, dones, (long)done_stride,
+                     h, z, r, c, Wh + 2 * hh, dc_pre, dz, dz_pre, dr_pre, dh, (long)B, hdim);
+  A2C_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gru_cell_bwd2_kernel, dim3(tiles, rows), dim3(512), 0, a2c_s(stream), dz_pre, dr_pre, Wh, Wh + hh, dh, (long)B,
+                     hdim);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

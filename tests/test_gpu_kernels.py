@@ -1145,3 +1145,49 @@ def test_gemm_bf16_x9_path_is_the_fp32_product(tA, tB, M, N, K, monkeypatch):
     ops.gemm(tA, tB, M, N, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), N, bias=bias, relu=True,
              mask_ptr=mask.data_ptr(), ldmask=N)
     assert torch.equal(c.cpu().double(), res["0"])
+
+
+@pytest.mark.parametrize("B,hd,with_carry", [(256, 256, True), (37, 256, False), (300, 96, True)])
+def test_gru_cell_bwd_two_launches_equal_the_five_bit_for_bit(B, hd, with_carry):
+    """a2c_gru_cell_bwd (one step of the BPTT unroll's backward, updater.py:139-169) against the five launches it replaces --
+    a2c_gru_out_bwd[_carry], a2c_gemm_f32 (dc_pre Wh2^T), a2c_gru_gates_bwd, two accumulating a2c_gemm_f32 -- bit for bit,
+    and against autograd through the reference's cell formula (models.py:465-476)."""
+    ops = _ops()
+    mk = lambda *s: torch.full(s, float("nan"), device=DEV)
+    dhn, carry, h0 = rnd((B, hd), 961).to(DEV), rnd((B, hd), 962).to(DEV), rnd((B, hd), 963).to(DEV)
+    dones = (rnd((B, 3), 964, 0, 1) < 0.3).float().to(DEV)          # done of row b at dones[b * 3 + 1]
+    x = rnd((B, hd), 965).to(DEV)
+    Wx, Wh, b = (rnd((3, hd, hd), 966) / hd ** 0.5).to(DEV), (rnd((3, hd, hd), 967) / hd ** 0.5).to(DEV), (rnd((3, hd), 968) * 0.1).to(DEV)
+    z = torch.sigmoid(x @ Wx[0] + h0 @ Wh[0] + b[0])
+    r = torch.sigmoid(x @ Wx[1] + h0 @ Wh[1] + b[1])
+    c = torch.tanh(x @ Wx[2] + (r * h0) @ Wh[2] + b[2])
+    dptr, dstride = dones.data_ptr() + 4, 3
+    # the five launches
+    dcp1, dz1, drh1, dzp1, drp1, dh1 = (mk(B, hd) for _ in range(6))
+    if with_carry:
+        ops.gru_out_bwd_carry(dhn, carry, dptr, dstride, h0, z, c, dcp1, dz1, dh1)
+    else:
+        ops.gru_out_bwd(dhn, h0, z, c, dcp1, dz1, dh1)
+    ops.gemm(0, 1, B, hd, hd, dcp1.data_ptr(), hd, Wh[2].data_ptr(), hd, drh1.data_ptr(), hd)
+    ops.gru_gates_bwd(drh1, dz1, h0, z, r, dzp1, drp1, dh1)
+    ops.gemm(0, 1, B, hd, hd, dzp1.data_ptr(), hd, Wh[0].data_ptr(), hd, dh1.data_ptr(), hd, accumulate=True)
+    ops.gemm(0, 1, B, hd, hd, drp1.data_ptr(), hd, Wh[1].data_ptr(), hd, dh1.data_ptr(), hd, accumulate=True)
+    # the two
+    dcp2, dz2, dzp2, drp2, dh2 = (mk(B, hd) for _ in range(5))
+    ops.gru_cell_bwd(dhn, carry if with_carry else None, dptr if with_carry else 0, dstride, h0, z, r, c, Wh, dcp2, dz2, dzp2, drp2, dh2)
+    torch.cuda.synchronize()
+    for name, a, bb in (("dc_pre", dcp2, dcp1), ("dz", dz2, dz1), ("dz_pre", dzp2, dzp1), ("dr_pre", drp2, drp1), ("dh", dh2, dh1)):
+        assert torch.equal(a, bb), name
+    # autograd: dL/dh_in for L = sum(h_new * g), g = dhn + carry * (1 - done)
+    hc = h0.cpu().double().requires_grad_(True)
+    Wxd, Whd, bd, xd = Wx.cpu().double(), Wh.cpu().double(), b.cpu().double(), x.cpu().double()
+    zt = torch.sigmoid(xd @ Wxd[0] + hc @ Whd[0] + bd[0])
+    rt = torch.sigmoid(xd @ Wxd[1] + hc @ Whd[1] + bd[1])
+    ct = torch.tanh(xd @ Wxd[2] + (rt * hc) @ Whd[2] + bd[2])
+    hn = zt * hc + (1 - zt) * ct
+    g = dhn.cpu().double() + (carry.cpu().double() * (1 - dones[:, 1].cpu().double()).unsqueeze(1) if with_carry else 0)
+    (hn * g).sum().backward()
+    close("dh vs autograd", dh2, hc.grad, 2e-5 * float(hc.grad.abs().max()), 1e-5)
+    from a2c_amd import _lib
+    with pytest.raises(_lib.A2CKernelError):        # the carry must not alias dh
+        ops.gru_cell_bwd(dhn, dh2, dptr, dstride, h0, z, r, c, Wh, dcp2, dz2, dzp2, drp2, dh2)

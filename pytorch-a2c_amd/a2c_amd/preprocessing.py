@@ -10,8 +10,9 @@ removed in 0.19), and in every one of those releases ``rgb2gray`` starts with ``
 np.ascontiguousarray(rgb)`` -- a 2-D input is returned UNCHANGED (uint8, values 0..255, no division by 255, no
 float conversion).  With scikit-image >= 0.19 the reference's import fails outright.  ``breakout_prep`` is therefore the
 crop + stride-2 slice of channel 0 as uint8, and its frames travel as uint8 (0..255, not binary: the packed one-bit
-transport does not apply).  Parity for this function is pinned by that statement and by tests/test_preprocessing.py
-(dtype, shape, values against the slice), not by a golden vector."""
+transport does not apply).  Both ``pong_prep`` and ``breakout_prep`` are pinned by golden vectors recorded from the REFERENCE's own
+functions (tests/golden/g9_*.npz, made by tests/golden/make_golden.py with ``skimage.color`` stubbed by that rule:
+tests/test_preprocessing.py on the host functions, tests/test_gpu_frames.py on the device kernel a2c_frame_prep_u8)."""
 import numpy as np
 
 

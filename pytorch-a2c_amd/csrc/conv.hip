@@ -2643,7 +2643,7 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 //       group at tap column kx = 4 kxh + kxl are the 8 CONSECUTIVE elements m = c0 + kxh .. of one phase-plane row (two
 //       ds_read_b64 + one b32; kxh = 1 shifts by one element with v_alignbit) -- no gather, no conversion in the loop;
 //   wave (q, h): input plane ci = q (64 weight columns = 4 accumulator tiles kxl), K blocks of parity half h.
-struct WsbGeo { int NG, NGT, NB, PA, PP, dbg; };      // dbg (A2C_WSB_DBG, timing only): 1 = no matrix phase, 2 = no commit
+struct WsbGeo { int NG, NGT, NB, PA, PP, PLS, SK, dbg; };      // PLS: elements per phase plane, SK: skew per 4 rows      // dbg (A2C_WSB_DBG, timing only): 1 = no matrix phase, 2 = no commit
 //   wave w: K blocks {w, w + 8, ...} (a block = 4 pixel groups = 32 pixels) for ALL 256 weight columns -- 16 accumulator
 //   tiles, the block's three A fragments read once --; tile t = (ci, kxh, kp): lane j = (ky = j >> 1, kxl = 2 kp + (j & 1)),
 //   so kxh is uniform per tile and only the kxh = 1 tiles pay the one-element shift; the eight waves' partial tiles are
@@ -2653,17 +2653,17 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   extern __shared__ __attribute__((aligned(16))) float lds[];
   typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
   unsigned short* __restrict__ A = reinterpret_cast<unsigned short*>(lds);                 // [3][16][PA]
-  unsigned short* __restrict__ P = A + 3 * 16 * gq.PA;                                      // [16][H][PP]
+  unsigned short* __restrict__ P = A + 3 * 16 * gq.PA;                                      // [16][PLS]: row y at y * PP + (y >> 2) * SK
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int HW = p.H * p.W, NP = p.OH * p.OW;
   const int w4 = p.W >> 2;
   const int dper4 = NP >> 2, dtot4 = p.Cout * dper4;
-  const int NG = gq.NG, NGT = gq.NGT, NB = gq.NB, PA = gq.PA, PP = gq.PP;
+  const int NG = gq.NG, NGT = gq.NGT, NB = gq.NB, PA = gq.PA, PP = gq.PP, PLS = gq.PLS, SK = gq.SK;
   const int spr = (w4 + 1) >> 1, nslot = 4 * p.H * spr;        // frame slots: (plane, row, pair of dwords m = 2 s, 2 s + 1)
   {  // zeros that stay: pad pixels / pad groups / channels >= Cout of A, columns m >= W/4 of P
     u32x4w* z = reinterpret_cast<u32x4w*>(lds);
-    const int n16 = (3 * 16 * PA * 2 + 16 * p.H * PP * 2) >> 4;
+    const int n16 = (3 * 16 * PA * 2 + 16 * PLS * 2) >> 4;
     for (int i = tid; i < n16; i += ST_NT) z[i] = (u32x4w){0u, 0u, 0u, 0u};
   }
   const int ky = j >> 1;
@@ -2686,7 +2686,7 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int ii = ok ? idx : 0;
     const int c = ii / (p.H * spr), rem = ii - c * (p.H * spr), row = rem / spr, sp = rem - row * spr;
     soff[u] = (c * p.H + row) * p.W + 8 * sp;
-    sdst[u] = ok ? ((c * 4) * p.H + row) * PP + 2 * sp : -1;
+    sdst[u] = ok ? (c * 4) * PLS + row * PP + (row >> 2) * SK + 2 * sp : -1;
     smask[u] = ((2 * sp + 1 < w4) ? 0xffffff00u : 0u) | (unsigned int)c;      // low byte: the plane (zero planes of a fresh episode)
   }
   int adst[4];                                   // element offset of dOut quad u in piece image 0, or -1 (no division in the loop)
@@ -2742,7 +2742,7 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int c_ = (int)(smask[u] & 0xffu);                                                                    \
     const unsigned int x0_ = c_ < 4 - nv ? 0u : var.x, x1_ = (c_ < 4 - nv || !(smask[u] >> 8)) ? 0u : var.y;   \
     unsigned int* d_ = reinterpret_cast<unsigned int*>(P + sdst[u]);                                           \
-    const int ps_ = (p.H * PP) >> 1;                                                                           \
+    const int ps_ = PLS >> 1;                                                                                  \
     d_[0] = __builtin_amdgcn_perm(__float_as_uint((float)(x1_ & 0xffu)), __float_as_uint((float)(x0_ & 0xffu)), 0x07060302u); \
     d_[ps_] = __builtin_amdgcn_perm(__float_as_uint((float)((x1_ >> 8) & 0xffu)), __float_as_uint((float)((x0_ >> 8) & 0xffu)), 0x07060302u); \
     d_[2 * ps_] = __builtin_amdgcn_perm(__float_as_uint((float)((x1_ >> 16) & 0xffu)), __float_as_uint((float)((x0_ >> 16) & 0xffu)), 0x07060302u); \
@@ -2766,11 +2766,11 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       const bf16x8w al = *reinterpret_cast<const bf16x8w*>(ap + 32 * PA);
       const int gcl = min(grp, NGT - 1);             // (pad groups of the last block: A is zero there, B must only be finite)
       const int r = gcl / NG, gc = gcl - r * NG;
-      const unsigned short* __restrict__ bp = P + ((j & 1) * p.H + 4 * r + ky) * PP + 8 * gc;
+      const unsigned short* __restrict__ bp = P + (j & 1) * PLS + (4 * r + ky) * PP + (r + (ky >> 2)) * SK + 8 * gc;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int ci = t >> 2, kxh = (t >> 1) & 1, kp = t & 1;
-        const unsigned short* __restrict__ bx = bp + ((ci * 4 + 2 * kp) * p.H) * PP;
+        const unsigned short* __restrict__ bx = bp + (ci * 4 + 2 * kp) * PLS;
         const uint2 lo = *reinterpret_cast<const uint2*>(bx), hi = *reinterpret_cast<const uint2*>(bx + 4);
         u32x4w o;
         if (kxh) {
@@ -2837,14 +2837,19 @@ static bool plan_wstream_bf16(const a2c_conv_desc* d, const WstreamP& p, WsbGeo&
   int pa_dw = ((need_dw + 31) / 32) * 32 + 4;          // channel pitch = 4 (mod 32) dwords: the 8 channels of a b128 pass hit 32 banks
   if (pa_dw - 32 >= need_dw) pa_dw -= 32;
   gq.PA = pa_dw * 2;
-  gq.PP = gq.NG * 8 + 4;                               // elements per phase-plane row (8-byte multiple: 2 * PP % 8 == 0)
+  // phase-plane image: rows of PP = 8 NG + 8 elements (64 B for OW = 20), every 4 rows (one output-row step) skewed by 4 more,
+  // planes padded by 24: the two 8-byte reads of a B fragment average 1.33 bank passes (a brute-force search over pitch / skew /
+  // plane padding; rows of 8 NG + 4 elements: 2.0; SQ_LDS_BANK_CONFLICT share of the first version 0.53)
+  gq.PP = gq.NG * 8 + 8;
+  gq.SK = 4;
+  gq.PLS = d->H * gq.PP + (d->H / 4 + 1) * gq.SK + 24;
   if (d->W / 4 > gq.NG * 8 + 1 || d->OW % 4 || d->Cout > 16) return false;
-  lds = (size_t)3 * 16 * gq.PA * 2 + (size_t)16 * d->H * gq.PP * 2;
+  lds = (size_t)3 * 16 * gq.PA * 2 + (size_t)16 * gq.PLS * 2;
   lds = (lds + 15) / 16 * 16;
   if (lds < 4 * (size_t)(8 * 4 * 256) || 4 * d->H * ((d->W / 4 + 1) / 2) > 8 * ST_NT) return false;   // epilogue scratch reuses the images; 8 frame slots per thread
   if ((long)d->Cout * (d->OH * d->OW / 4) > 4L * ST_NT) return false;
   (void)p;
-  return lds <= 160 * 1024 && (gq.PP * 2) % 8 == 0 && 4 * (d->OH - 1) + 7 < d->H;
+  return lds <= 160 * 1024 && (gq.PP * 2) % 8 == 0 && (gq.PLS * 2) % 8 == 0 && 4 * (d->OH - 1) + 7 < d->H;
 }
 
 static bool plan_wstream(const a2c_conv_desc* d, WstreamP& p) {

@@ -552,6 +552,10 @@ class Bench:
             self.runner.check()
         r_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / max(len(ev), 1)
         u_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / max(len(ev), 1)
+        if ev and os.environ.get("A2C_BENCH_STEP_TIMES") == "1":        # per-step halves of the timed region (stderr)
+            print("[bench] per-step rollout ms: " + " ".join(f"{e[0].elapsed_time(e[1]):.2f}" for e in ev[:40]), file=sys.stderr)
+            print("[bench] per-step update  ms: " + " ".join(f"{e[1].elapsed_time(e[2]):.2f}" for e in ev[:40]), file=sys.stderr)
+            print("[bench] start-to-start   ms: " + " ".join(f"{a[0].elapsed_time(b[0]):.2f}" for a, b in zip(ev[:39], ev[1:40])), file=sys.stderr)
         return elapsed, r_ms, u_ms
 
     def site_timers(self, n=2):

@@ -510,7 +510,8 @@ int a2c_conv2d_bwd_weight_frames(const a2c_conv_desc *d, const uint8_t *frame_st
  * layer 0), writes out[i] (+ b * out_bstride[i] per sample; the rollout passes rows of the update's activation stash) and
  * results are BIT-IDENTICAL to n_layers calls of a2c_conv2d_fwd[_signs] -- same tiles, same summation order; one workgroup
  * walks one sample through all layers, so no launch boundary (fill + tail per launch, 16-58 us each at 256 envs) sits
- * between them.  signs0 (may be NULL): sign words of layer 0's output, as a2c_conv2d_fwd_signs writes them.
+ * between them.  signs (may be NULL) / signs[i] (may be NULL): sign words of layer i's output (rows of signs_bstride[i]
+ * words), as a2c_conv2d_fwd_signs writes them; supported for layer 0, or layers 0 and 1.
  * a2c_conv2d_fwd_chain_supported: 1 for the layer runs that have such a kernel (GRUModel conv2 .. conv5: 16 -> 24 @84,
  * 24 -> 32 @42, 32 -> 48 @21, 48 -> 64 @11, 3x3 / stride 2 / pad 1; A2C_NO_CHAIN=1 switches it off), else the caller
  * launches layer by layer.  wprep_fwd[i]: a2c_conv2d_prep_weights(kind 0) of layer i.                                */
@@ -518,7 +519,7 @@ int a2c_conv2d_bwd_weight_frames(const a2c_conv_desc *d, const uint8_t *frame_st
 int a2c_conv2d_fwd_chain_supported(const a2c_conv_desc *d, int n_layers);
 int a2c_conv2d_fwd_chain(const a2c_conv_desc *d, int n_layers, const float *in, int64_t in_bstride,
                          const float *const *wprep_fwd, const float *const *bias, int relu, float *const *out,
-                         const int64_t *out_bstride, uint32_t *signs0, int64_t signs0_bstride, int B,
+                         const int64_t *out_bstride, uint32_t *const *signs, const int64_t *signs_bstride, int B,
                          a2c_stream_t stream);
 /* ... and, with the same signature, for the first layer of the 3x3 stacks (ConvModel / GRUModel: 4 -> 16 channels at
  * 84 x 84, models.py:201-207, 570-576).  Their FORWARD with the input stacked on load (rollout step: sample b reads the

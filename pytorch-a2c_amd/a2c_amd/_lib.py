@@ -130,7 +130,7 @@ SIGNATURES = {
     "a2c_conv2d_bwd_weight_frames": (c_int, [PD, P, c_int64, c_int64, P, P, P, P, c_int, P, c_size_t, P]),
     "a2c_conv2d_fwd_frames_supported": (c_int, [PD]),
     "a2c_conv2d_fwd_chain_supported": (c_int, [PD, c_int]),
-    "a2c_conv2d_fwd_chain": (c_int, [PD, c_int, P, c_int64, P, P, c_int, P, P, P, c_int64, c_int, P]),
+    "a2c_conv2d_fwd_chain": (c_int, [PD, c_int, P, c_int64, P, P, c_int, P, P, P, P, c_int, P]),
     "a2c_conv2d_fwd_frames": (c_int, [PD, P, c_int64, c_int64, P, c_int64, P, P, c_int, P, c_int64, P, c_int64, c_int, P]),
     "a2c_frame_prep_u8": (c_int, [P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, c_int, P]),
     "a2c_frame_store_begin": (c_int, [P, c_int64, c_int64, c_int, c_int, P, P, c_int, P]),

@@ -509,26 +509,28 @@ class _ConvStackNet(_HipNet):
         fsrc = getattr(self, "_frames_src", None)       # rollout step: layer 0 stacks its input on load (runner, row f4)
         # layers 1 .. n-1 of a rollout-sized batch as ONE launch where the library has a chain kernel for them (GRUModel's four
         # stride-2 layers: a workgroup walks one sample through all of them; bit-identical to the per-layer launches)
-        chain = self._conv_chain() if (not train and 64 < B <= 4096 and all(i == 1 for i in sl if i >= 1)) else None
+        chain = self._conv_chain() if (not train and 64 < B <= 4096 and all(i in (1, 2) for i in sl if i >= 1)
+                                       and (2 not in sl or 1 in sl)) else None
         for i, l in enumerate(self._cl):
             n = int(np.prod(l.out_shape))
             if chain is not None and i == 1:
                 nl = len(self._cl)
+                csl = [k for k in (1, 2) if k in sl]                      # layers of the chain that leave sign words
                 if stash is None:
                     outs = [ws.get(f"a{k}", (B,) + self._cl[k].out_shape) for k in range(1, nl)]
                     optrs, obss = [o.data_ptr() for o in outs], [int(np.prod(self._cl[k].out_shape)) for k in range(1, nl)]
-                    sg = (ws.get("sg1", (B, sl[1]), dtype=torch.int32).data_ptr(), sl[1]) if 1 in sl else None
+                    sg = {k - 1: (ws.get(f"sg{k}", (B, sl[k]), dtype=torch.int32).data_ptr(), sl[k]) for k in csl}
                 else:
                     bufs, row0, rstride = stash
                     ns = [int(np.prod(self._cl[k].out_shape)) for k in range(1, nl)]
                     optrs = [bufs[k].data_ptr() + 4 * row0 * ns[k - 1] for k in range(1, nl)]
                     obss = [rstride * v for v in ns]
-                    sg = (self._sign_bufs[1].data_ptr() + 4 * row0 * sl[1], rstride * sl[1]) if 1 in sl else None
+                    sg = {k - 1: (self._sign_bufs[k].data_ptr() + 4 * row0 * sl[k], rstride * sl[k]) for k in csl}
                 with ops.span("conv2-5.fwd_chain"):
                     chain.fwd(ptr, bs, [c.wf for c in self._cl[1:]], [self.P(f"convs.{k}.0.bias") for k in range(1, nl)], optrs,
-                              obss, B, st, signs0=sg)
-                if 1 in sl:
-                    self._signs_ok[1] = (self._signs_ok.get(1, True) if (stash is not None and stash[1]) else True)
+                              obss, B, st, signs=sg or None)
+                for k in csl:
+                    self._signs_ok[k] = (self._signs_ok.get(k, True) if (stash is not None and stash[1]) else True)
                 for k in range(1, nl):
                     acts.append((optrs[k - 1], obss[k - 1]))
                 return acts

@@ -651,15 +651,15 @@ class ConvChain:
         self.descs = (ConvDesc * n)(*descs)
         self.ok = bool(lib().a2c_conv2d_fwd_chain_supported(self.descs, n))
         self.wprep, self.bias, self.out = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
-        self.obs = (ctypes.c_int64 * n)()
+        self.obs, self.sg, self.sgs = (ctypes.c_int64 * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
 
-    def fwd(self, in_ptr, in_bstride, wpreps, biases, outs, out_bstrides, B, st=None, relu=True, signs0=None):
-        """outs: raw device addresses; signs0 = (ptr, row stride in words) of layer 0's sign words or None"""
+    def fwd(self, in_ptr, in_bstride, wpreps, biases, outs, out_bstrides, B, st=None, relu=True, signs=None):
+        """outs: raw device addresses; signs = {layer index: (ptr, row stride in words)} (layer 0, or layers 0 and 1) or None"""
         for i in range(self.n):
             self.wprep[i], self.bias[i], self.out[i], self.obs[i] = _p(wpreps[i]), _p(biases[i]), outs[i], out_bstrides[i]
-        sg, sgs = signs0 if signs0 is not None else (0, 0)
+            self.sg[i], self.sgs[i] = (signs or {}).get(i, (0, 0))
         check(lib().a2c_conv2d_fwd_chain(self.descs, self.n, in_ptr, in_bstride, self.wprep, self.bias, int(bool(relu)), self.out,
-                                         self.obs, sg, sgs, B, st if st is not None else stream()), "a2c_conv2d_fwd_chain")
+                                         self.obs, self.sg, self.sgs, B, st if st is not None else stream()), "a2c_conv2d_fwd_chain")
 
 
 # ---------------------------------------------------------------- f4: device preprocessing, single-frame store

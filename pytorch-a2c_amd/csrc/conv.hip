@@ -38,6 +38,7 @@ int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, co
                 long signs_bs, float* din, int B, hipStream_t st);
 long c3_sign_words(const a2c_conv_desc* d);
 bool c3_bwd_signs_supported(const a2c_conv_desc* d);
+bool c3_bwd_mask_supported(const a2c_conv_desc* d);
 bool c3w_supported(const a2c_conv_desc* d);
 size_t c3w_ws_bytes(const a2c_conv_desc* d);
 int c3w_bwd_weight(const a2c_conv_desc* d, const float* in, long in_bs, const float* dout, float* dW, float* db, int B, void* ws,
@@ -45,7 +46,7 @@ int c3w_bwd_weight(const a2c_conv_desc* d, const float* in, long in_bs, const fl
 bool c3_fwd_frames_supported(const a2c_conv_desc* d);
 bool c3_chain_supported(const a2c_conv_desc* d, int n);
 int c3_chain_fwd(const a2c_conv_desc* d, int n, const float* in, long in_bs, const float* const* frag, const float* const* bias,
-                 int relu, float* const* out, const long* out_bs, unsigned* signs0, long signs0_bs, int B, hipStream_t st);
+                 int relu, float* const* out, const long* out_bs, unsigned* const* signs, const long* signs_bs, int B, hipStream_t st);
 int c3_fwd_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long T, const int* nv, long nv_s, const float* frag,
                   const float* bias, int relu, float* out, long out_bs, unsigned* signs, long signs_bs, int B, hipStream_t st);
 int c3w_bwd_weight_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long T, const int* nv, const float* dout,
@@ -3305,22 +3306,25 @@ int a2c_conv2d_fwd_chain_supported(const a2c_conv_desc* d, int n_layers) {
 }
 
 int a2c_conv2d_fwd_chain(const a2c_conv_desc* d, int n_layers, const float* in, int64_t in_bstride, const float* const* wprep_fwd,
-                         const float* const* bias, int relu, float* const* out, const int64_t* out_bstride, uint32_t* signs0,
-                         int64_t signs0_bstride, int B, a2c_stream_t stream) {
+                         const float* const* bias, int relu, float* const* out, const int64_t* out_bstride, uint32_t* const* signs,
+                         const int64_t* signs_bstride, int B, a2c_stream_t stream) {
   if (!a2c_conv2d_fwd_chain_supported(d, n_layers) || B < 0) return A2C_ERR_ARG;
   if (B == 0) return A2C_OK;
   if (!in || !wprep_fwd || !bias || !out || !out_bstride || in_bstride % 4 || ((uintptr_t)in % 16)) return A2C_ERR_ARG;
   const float* frag[A2C_CONV_CHAIN_MAX];
-  long obs[A2C_CONV_CHAIN_MAX];
+  long obs[A2C_CONV_CHAIN_MAX], sbs[A2C_CONV_CHAIN_MAX];
+  unsigned* sg[A2C_CONV_CHAIN_MAX];
   for (int i = 0; i < n_layers; ++i) {
     if (!wprep_fwd[i] || !out[i] || out_bstride[i] % 4 || ((uintptr_t)out[i] % 16) ||
         out_bstride[i] < (int64_t)d[i].Cout * d[i].OH * d[i].OW)
       return A2C_ERR_ARG;
     frag[i] = wprep_fwd[i] + prep_floats_base(d + i, 0);
     obs[i] = (long)out_bstride[i];
+    sg[i] = signs ? signs[i] : nullptr;
+    sbs[i] = (sg[i] && signs_bstride) ? (long)signs_bstride[i] : 0;
+    if (sg[i] && (c3_sign_words(d + i) == 0 || sbs[i] < c3_sign_words(d + i))) return A2C_ERR_ARG;
   }
-  if (signs0 && (c3_sign_words(d) == 0 || signs0_bstride < c3_sign_words(d))) return A2C_ERR_ARG;
-  return c3_chain_fwd(d, n_layers, in, (long)in_bstride, frag, bias, relu, out, obs, signs0, (long)signs0_bstride, B, a2c_s(stream));
+  return c3_chain_fwd(d, n_layers, in, (long)in_bstride, frag, bias, relu, out, obs, sg, sbs, B, a2c_s(stream));
 }
 
 int a2c_conv2d_fwd_frames_supported(const a2c_conv_desc* d) { return desc_ok(d) && c3_fwd_frames_supported(d) ? 1 : 0; }
@@ -3572,7 +3576,8 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
   if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
   if (B == 0) return A2C_OK;
   if (!dout || !wprep_bwd || !din) return A2C_ERR_ARG;
-  if (c3_supported(d, 1) && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)din % 16) == 0 && (!mask || ((uintptr_t)mask % 16) == 0))
+  if (c3_supported(d, 1) && (!mask || c3_bwd_mask_supported(d)) && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)din % 16) == 0 &&
+      (!mask || ((uintptr_t)mask % 16) == 0))
     return c3_bwd_data(d, dout, wprep_bwd + prep_floats_base(d, 1), mask, nullptr, 0, din, B, a2c_s(stream));
   return conv_bwd_data_generic(d, dout, wprep_bwd, mask, din, B, stream);
 }

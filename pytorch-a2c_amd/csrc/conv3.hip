@@ -598,7 +598,7 @@ __device__ __forceinline__ void c3_layer_sync() {
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-template <bool SG2, int D>
+template <bool SG2, bool SG3>
 __global__ __launch_bounds__(64 * 13) void c3_chain_gru_kernel(C3Chain4 cp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using G2 = C3Geo<16, 24, 84, 84, 2, 6, 0, 4>;
@@ -606,13 +606,13 @@ __global__ __launch_bounds__(64 * 13) void c3_chain_gru_kernel(C3Chain4 cp) {
   using G4 = C3Geo<32, 48, 21, 21, 2, 11, 0, 4>;
   using G5 = C3Geo<48, 64, 11, 11, 2, 6, 24, 4>;
   for (long b = blockIdx.x; b < cp.l[0].B; b += gridDim.x) {
-    c3_body<16, 24, 84, 84, 2, 6, false, 0, SG2, 4, true, true, D>(cp.l[0], lds, b * G2::NBAND, G2::NBAND);
+    c3_body<16, 24, 84, 84, 2, 6, false, 0, SG2, 4, true, true>(cp.l[0], lds, b * G2::NBAND, G2::NBAND);
     c3_layer_sync();
-    c3_body<24, 32, 42, 42, 2, 11, false, 0, false, 4, true, true, D>(cp.l[1], lds, b * G3::NBAND, G3::NBAND);
+    c3_body<24, 32, 42, 42, 2, 11, false, 0, SG3, 4, true, true>(cp.l[1], lds, b * G3::NBAND, G3::NBAND);
     c3_layer_sync();
-    c3_body<32, 48, 21, 21, 2, 11, false, 0, false, 4, true, true, D>(cp.l[2], lds, b * G4::NBAND, G4::NBAND);
+    c3_body<32, 48, 21, 21, 2, 11, false, 0, false, 4, true, true>(cp.l[2], lds, b * G4::NBAND, G4::NBAND);
     c3_layer_sync();
-    c3_body<48, 64, 11, 11, 2, 6, false, 24, false, 4, true, true, 2>(cp.l[3], lds, b * G5::NBAND, G5::NBAND);
+    c3_body<48, 64, 11, 11, 2, 6, false, 24, false, 4, true, true>(cp.l[3], lds, b * G5::NBAND, G5::NBAND);
     c3_layer_sync();
   }
 }
@@ -1238,9 +1238,13 @@ __global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel
 // every interval waiting on its barrier); they wait with COUNTED vmcnt -- every chunk is the same number of DMA
 // instructions per loader wave -- so the younger chunks stay in flight across the barrier.  FRES: the weight fragments
 // of ALL chunks stay resident in LDS (loaded once per workgroup) instead of travelling with every chunk.
-template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES>
+// ODD: the layer's input is (2 HO - 1) x (2 WO - 1) (a 3x3 / stride 2 / pad 1 layer on an odd image: 21 -> 11, GRUModel conv4):
+// class pixels (q, p) with 2 q + py = H or 2 p + px = W do not exist.  The whole image is ONE band, the stage image is
+// dense [ci][H * W] and leaves as ONE flat float4 run (the sample's dX is contiguous and 16-byte aligned as a whole: its
+// rows are not), image writes are scalar.
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES, bool ODD = false>
 struct C3BSGeo {
-  static constexpr int H = 2 * HO, W = 2 * WO;
+  static constexpr int H = 2 * HO - (ODD ? 1 : 0), W = 2 * WO - (ODD ? 1 : 0);
   static constexpr int NCH = CO / KC, C4 = KC / 4, MT = (CI + 15) / 16;
   static constexpr int NBAND = (HO + RQ - 1) / RQ;
   static constexpr int NPIX = RQ * WO;                 // class pixels per band
@@ -1260,14 +1264,15 @@ struct C3BSGeo {
   static constexpr int FRAGC = C4 * 9 * MT * 64;
   static constexpr int NFQ = (FRAGC / 4 + 63) / 64;
   static constexpr int BUF = ((IMG + FRAGC + 255) / 256) * 256;
-  static constexpr int MROW = 2 * RQ * W;              // floats of one channel's dX band (rows are contiguous in HBM)
+  static constexpr int MROW = ODD ? H * W : 2 * RQ * W; // floats of one channel's dX band (rows are contiguous in HBM)
   static constexpr int LOOK = D - 1;                               // chunks in flight ahead of the one being computed
   static constexpr int SLOT = FRES ? ((IMG + 63) / 64) * 64 : BUF;              // floats per ring slot
   static constexpr int FRAG_ALL = FRES ? NCH * FRAGC : 0;
-  static constexpr int MROWP = ((MROW + 3) / 8) * 8 + 4;
-  static constexpr int STAGE = CI * MROWP;
+  static constexpr int MROWP = ODD ? MROW : ((MROW + 3) / 8) * 8 + 4;
+  static constexpr int STAGE = ((CI * MROWP + 3) / 4) * 4;
   static constexpr int RW = (W + 31) / 32;
-  static constexpr int BITC = 2 * RQ * RW;
+  static constexpr int BITC = (ODD ? H : 2 * RQ) * RW;
+  static_assert(!ODD || ((HO + RQ - 1) / RQ == 1 && (CI * H * W) % 4 == 0), "odd images: one band per sample, a flat 16-byte drain");
   static constexpr int BITB = ((CI * BITC + 3) / 4) * 4;
   static constexpr size_t LDS_BYTES_S = ((size_t)D * SLOT + FRAG_ALL + STAGE + BITB) * 4;
   static constexpr bool VEC = (H * W) % 4 == 0 && MROW % 4 == 0;
@@ -1287,9 +1292,9 @@ constexpr bool C3_STAMPS = true;
 constexpr bool C3_STAMPS = false;
 #endif
 
-template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES>
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES, bool ODD = false>
 __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
-  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES>;
+  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const fres = lds + D * G::SLOT;                     // resident fragments (FRES)
   float* const stage = fres + G::FRAG_ALL;
@@ -1306,6 +1311,21 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
     c3_bar();
     auto drain = [&](long tile, int part) {
       const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
+      if constexpr (ODD) {
+        // the whole sample's dX = CI * H * W floats, one contiguous 16-byte aligned run: part `part` of NCH, this storer's half
+        constexpr int TOT4 = CI * G::H * G::W / 4, PER = (TOT4 + G::NCH * G::NS - 1) / (G::NCH * G::NS);
+        const int i0 = (part * G::NS + sw) * PER, i1 = min(TOT4, i0 + PER);
+        float* __restrict__ o = p.out + b * p.out_bs;
+        for (int i = i0 + lane; i < i1; i += 256) {              // four pieces per lane and trip: all LDS reads first, then the stores
+          f32x4 v0 = c3_lds_read128(stage + 4 * min(i, TOT4 - 1)), v1 = c3_lds_read128(stage + 4 * min(i + 64, TOT4 - 1));
+          f32x4 v2 = c3_lds_read128(stage + 4 * min(i + 128, TOT4 - 1)), v3 = c3_lds_read128(stage + 4 * min(i + 192, TOT4 - 1));
+          c3_lds_wait(v0, v1, v2, v3);
+          if (i < i1) *reinterpret_cast<f32x4*>(o + 4 * i) = v0;
+          if (i + 64 < i1) *reinterpret_cast<f32x4*>(o + 4 * (i + 64)) = v1;
+          if (i + 128 < i1) *reinterpret_cast<f32x4*>(o + 4 * (i + 128)) = v2;
+          if (i + 192 < i1) *reinterpret_cast<f32x4*>(o + 4 * (i + 192)) = v3;
+        }
+      } else {
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
       const int nrows = 2 * min(RQ, HO - q0), npx = nrows * G::W;
       constexpr int CPP = (CI + G::NCH - 1) / G::NCH;
@@ -1327,6 +1347,7 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
         };
         const C3Drain d0 = chan(i0), d1 = chan(i0 + 1);
         if (d0.ok) c3_drain_pair<G::MROW, G::VEC, NH>(d0, d1, npx, lane);
+      }
       }
     };
     long pend = -1;
@@ -1399,7 +1420,7 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
     auto dma_signs = [&](long tile) {
       const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
-      const int nw = 2 * min(RQ, HO - q0) * G::RW;
+      const int nw = ODD ? G::H * G::RW : 2 * min(RQ, HO - q0) * G::RW;
 #pragma unroll 1
       for (int c = lw; c < CI; c += G::NL) {
         const unsigned* __restrict__ src = p.sg_in + b * p.sg_bs + ((long)c * G::H + 2 * q0) * G::RW;
@@ -1545,18 +1566,28 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
               float4 v = make_float4(acc[u][py * 2][m][2 * h], acc[u][py * 2 + 1][m][2 * h], acc[u][py * 2][m][2 * h + 1],
                                      acc[u][py * 2 + 1][m][2 * h + 1]);
               if (msk) {
-                if (okA) {
+                if (okA && (!ODD || ra < G::H)) {
                   const unsigned q2 = bc[ra * G::RW + (xa >> 5)] >> (xa & 31);
                   if (!(q2 & 1u)) v.x = 0.f;
                   if (!(q2 & 2u)) v.y = 0.f;
                 }
-                if (okB) {
+                if (okB && (!ODD || rb < G::H)) {
                   const unsigned q2 = bc[rb * G::RW + (xb >> 5)] >> (xb & 31);
                   if (!(q2 & 1u)) v.z = 0.f;
                   if (!(q2 & 2u)) v.w = 0.f;
                 }
               }
-              if (okA) {
+              if constexpr (ODD) {
+                // rows 2 qr + 1 = H and columns 2 pc + 1 = W do not exist; rows of W floats are not 8-byte aligned
+                if (okA && ra < G::H) {
+                  sc[la] = v.x;
+                  if (xa + 1 < G::W) sc[la + 1] = v.y;
+                }
+                if (okB && rb < G::H) {
+                  sc[lb] = v.z;
+                  if (xb + 1 < G::W) sc[lb + 1] = v.w;
+                }
+              } else if (okA) {
                 if (WO % 2 == 0 && okB) *reinterpret_cast<float4*>(sc + la) = v;
                 else {
                   *reinterpret_cast<float2*>(sc + la) = make_float2(v.x, v.y);
@@ -1580,11 +1611,11 @@ __global__ __launch_bounds__(768) void c3bs_kernel(C3P p) {
 #undef C3_TS
 }
 
-template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES>
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES, bool ODD = false>
 int c3bs_launch(const C3P& p, hipStream_t st) {
-  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES>;
+  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD>;
   static_assert(G::LDS_BYTES_S <= 160 * 1024, "LDS");
-  const void* k = (const void*)c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES>;
+  const void* k = (const void*)c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES, ODD>;
   static int cus = 0;
   if (!cus) {
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES_S) != hipSuccess) return A2C_ERR_LAUNCH;
@@ -1595,7 +1626,7 @@ int c3bs_launch(const C3P& p, hipStream_t st) {
   const long total = (long)p.B * G::NBAND;
   if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;      // (the kernels walk chunks with 32-bit arithmetic)
   const int grid = (int)(total < cus ? total : cus);
-  hipLaunchKernelGGL((c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES>), dim3(grid), dim3(768), G::LDS_BYTES_S, st, p);
+  hipLaunchKernelGGL((c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES, ODD>), dim3(grid), dim3(768), G::LDS_BYTES_S, st, p);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   return A2C_OK;
 }
@@ -2019,10 +2050,20 @@ extern "C" int a2c_debug_c3_timing(unsigned long long* dev_buf) {      // debug 
 // ---- what conv.hip's entry points call (not part of the C ABI) -------------------------------------------------
 // kind 0 = forward, 1 = backward-data.  c3_supported: this family has an instantiation for the layer.
 static bool c3b_shape(const a2c_conv_desc* d);
+bool c3_supported(const a2c_conv_desc* d, int kind);
+// stride-2 backward-data onto an ODD image (GRUModel conv4: 32 <- 48, 21 x 21 <- 11 x 11): the staged sign-word kernel only
+// (c3bs_kernel<..., ODD>); A2C_NO_ODD_BS=1 leaves the layer on conv.hip's generic band kernel
+static bool c3bs_odd_shape(const a2c_conv_desc* d) {
+  const char* e = getenv("A2C_NO_ODD_BS");             // (read per call: tests compare the two kernels)
+  const bool off = e != nullptr && e[0] == '1';
+  return !off && d->ks == 3 && d->pad == 1 && d->stride == 2 && d->H == 21 && d->W == 21 && d->Cin == 32 && d->Cout == 48;
+}
+// backward-data with the FLOAT activation as the mask has a kernel of this family (the odd-image instance reads sign words only)
+bool c3_bwd_mask_supported(const a2c_conv_desc* d) { return c3_supported(d, 1) && !c3bs_odd_shape(d); }
 bool c3_supported(const a2c_conv_desc* d, int kind) {
   static const bool off = getenv("A2C_NO_C3") != nullptr && getenv("A2C_NO_C3")[0] == '1';
   if (off) return false;
-  if (kind == 1 && d->stride == 2) return c3b_shape(d);
+  if (kind == 1 && d->stride == 2) return c3b_shape(d) || c3bs_odd_shape(d);
   if (d->ks != 3 || d->pad != 1) return false;
   if (kind == 0 && d->stride == 2 && d->H == 42 && d->W == 42) return (d->Cin == 32 && d->Cout == 64) || (d->Cin == 24 && d->Cout == 32);
   if (kind == 0 && d->stride == 2 && d->H == 21 && d->W == 21) return d->Cin == 32 && d->Cout == 48;
@@ -2136,31 +2177,30 @@ bool c3_chain_supported(const a2c_conv_desc* d, int n) {
 }
 
 int c3_chain_fwd(const a2c_conv_desc* d, int n, const float* in, long in_bs, const float* const* frag, const float* const* bias,
-                 int relu, float* const* out, const long* out_bs, unsigned* signs0, long signs0_bs, int B, hipStream_t st) {
+                 int relu, float* const* out, const long* out_bs, unsigned* const* signs, const long* signs_bs, int B, hipStream_t st) {
   if (!c3_chain_supported(d, n)) return A2C_ERR_ARG;
+  // sign words: of layer 0's output (conv2, for conv3's backward-data), and of layer 1's (conv3, for the odd-image backward of conv4)
+  if ((signs[1] && !signs[0]) || signs[2] || signs[3]) return A2C_ERR_ARG;
   C3Chain4 cp;
   const float* zp = zero_page();
   if (!zp) return A2C_ERR_LAUNCH;
   for (int i = 0; i < 4; ++i) {
     cp.l[i] = C3P{i == 0 ? in : out[i - 1], i == 0 ? in_bs : out_bs[i - 1], frag[i], bias[i], nullptr, out[i], out_bs[i], zp, B, relu,
-                  nullptr, i == 0 ? signs0 : nullptr, nullptr, i == 0 ? signs0_bs : 0};
+                  nullptr, signs[i], nullptr, signs[i] ? signs_bs[i] : 0};
     cp.l[i].prio = c3_prio();
   }
   using G2 = C3Geo<16, 24, 84, 84, 2, 6, 0, 4>;
   using G3 = C3Geo<24, 32, 42, 42, 2, 11, 0, 4>;
   using G4 = C3Geo<32, 48, 21, 21, 2, 11, 0, 4>;
   using G5 = C3Geo<48, 64, 11, 11, 2, 6, 24, 4>;
-  constexpr size_t l2 = (3 * (size_t)G2::BUF + G2::SBITB) * 4, l3 = 3 * (size_t)G3::BUF * 4, l4 = 3 * (size_t)G4::BUF * 4;   // rings of three
-  constexpr size_t m1 = l2 > l3 ? l2 : l3;
-  constexpr size_t m2 = l4 > G5::LDS_BYTES ? l4 : G5::LDS_BYTES;
+  constexpr size_t m1 = G2::LDS_BYTES_SG > G3::LDS_BYTES_SG ? G2::LDS_BYTES_SG : G3::LDS_BYTES_SG;
+  constexpr size_t m2 = G4::LDS_BYTES > G5::LDS_BYTES ? G4::LDS_BYTES : G5::LDS_BYTES;
   constexpr size_t LDSB = m1 > m2 ? m1 : m2;
   static_assert(LDSB <= 160 * 1024, "LDS");
-  static int per_cu[4] = {0, 0, 0, 0}, cus = 0;
-  const char* e3 = getenv("A2C_CHAIN_D");            // (read per call: A/B runs) 3 = rings of three chunk buffers
-  const int d3 = (e3 != nullptr && e3[0] == '3') ? 1 : 0;
-  const int v = (signs0 != nullptr ? 1 : 0) + 2 * d3;
-  const void* k = v == 0 ? (const void*)c3_chain_gru_kernel<false, 2> : v == 1 ? (const void*)c3_chain_gru_kernel<true, 2>
-                : v == 2 ? (const void*)c3_chain_gru_kernel<false, 3> : (const void*)c3_chain_gru_kernel<true, 3>;
+  static int per_cu[3] = {0, 0, 0}, cus = 0;
+  const int v = signs[1] ? 2 : (signs[0] ? 1 : 0);
+  const void* k = v == 0 ? (const void*)c3_chain_gru_kernel<false, false> : v == 1 ? (const void*)c3_chain_gru_kernel<true, false>
+                : (const void*)c3_chain_gru_kernel<true, true>;
   if (!per_cu[v]) {
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB) != hipSuccess) return A2C_ERR_LAUNCH;
     int nb = 0, dev = 0;
@@ -2171,10 +2211,9 @@ int c3_chain_fwd(const a2c_conv_desc* d, int n, const float* in, long in_bs, con
   }
   const long cap = (long)per_cu[v] * cus;
   const int grid = (int)(B < cap ? B : cap);
-  if (v == 0) hipLaunchKernelGGL((c3_chain_gru_kernel<false, 2>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
-  else if (v == 1) hipLaunchKernelGGL((c3_chain_gru_kernel<true, 2>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
-  else if (v == 2) hipLaunchKernelGGL((c3_chain_gru_kernel<false, 3>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
-  else hipLaunchKernelGGL((c3_chain_gru_kernel<true, 3>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
+  if (v == 0) hipLaunchKernelGGL((c3_chain_gru_kernel<false, false>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
+  else if (v == 1) hipLaunchKernelGGL((c3_chain_gru_kernel<true, false>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
+  else hipLaunchKernelGGL((c3_chain_gru_kernel<true, true>), dim3(grid), dim3(64 * 13), LDSB, st, cp);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   return A2C_OK;
 }
@@ -2213,6 +2252,7 @@ int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, co
   if (d->stride == 2 && d->H == 84 && d->Cin == 16) return c3bs_launch<24, 16, 42, 42, 6, 8, 4, true>(p, st);
   if (d->stride == 2 && d->H == 42 && d->Cin == 32) return c3bs_launch<64, 32, 21, 21, 11, 8, 2, false>(p, st);
   if (d->stride == 2 && d->H == 42 && d->Cin == 24) return c3bs_launch<32, 24, 21, 21, 11, 8, 3, true>(p, st);
+  if (c3bs_odd_shape(d)) return c3bs_launch<48, 32, 11, 11, 11, 8, 3, false, true>(p, st);
   return A2C_ERR_ARG;
 }
 

@@ -536,13 +536,24 @@ def test_conv2d_sign_words(spec, B):
     din_s = torch.full((B, Cin, H, W), float("nan"), device=DEV)
     ops.conv_bwd_data(d, dout, wb, mask.to(DEV), din_f, B)
     ops.conv_bwd_data_signs(d, dout, wb, words, din_s, B)
-    assert torch.equal(din_s, din_f)
+    # even images: the float-mask and the sign-word kernels are the same streaming family (same summation order): bit for bit.
+    # The odd image (21 <- 11, GRUModel conv4) has a sign-word kernel only; its float-mask twin is conv.hip's generic band
+    # kernel, another order of the same sums.
+    odd = H % 2 == 1
+    if odd:
+        close("bwd_data signs vs float mask (generic kernel)", din_s, din_f, 2e-6 * float(din_f.abs().max()), 1e-5)
+        assert bool(((din_s != 0) == (din_f != 0)).all()) or float((din_s - din_f).abs().max()) < 1e-6
+    else:
+        assert torch.equal(din_s, din_f)
+    want = F.conv_transpose2d(dout[:3].cpu(), w, stride=s, padding=p, output_padding=(H + 2 * p - ks) % s)
+    close("bwd_data", din_s[:3], want * (mask[:3] > 0), 2e-6, 1e-5)
     if B == 3:
-        want = F.conv_transpose2d(dout.cpu(), w, stride=s, padding=p, output_padding=(H + 2 * p - ks) % s)
-        close("bwd_data", din_s, want * (mask > 0), 2e-6, 1e-5)
         ops.conv_bwd_data(d, dout, wb, None, din_f, B)
         ops.conv_bwd_data_signs(d, dout, wb, None, din_s, B)
-        assert torch.equal(din_s, din_f)
+        if odd:
+            close("bwd_data no mask, both kernels", din_s, din_f, 2e-6 * float(din_f.abs().max()), 1e-5)
+        else:
+            assert torch.equal(din_s, din_f)
         close("bwd_data no mask", din_s, want, 2e-6, 1e-5)
 
 
@@ -994,7 +1005,7 @@ def test_torch_ops_cover_the_model_and_optimiser_families():
         close(f"adam params step {step}", pd, pr.detach(), 2e-7, 1e-6)
 
 
-@pytest.mark.parametrize("B,signs,strided", [(256, True, True), (300, False, False), (65, True, False)])
+@pytest.mark.parametrize("B,signs,strided", [(256, 2, True), (300, 0, False), (65, 1, False)])
 def test_conv_chain_equals_the_per_layer_launches_bit_for_bit(B, signs, strided):
     """a2c_conv2d_fwd_chain (one launch: a workgroup walks one sample through GRUModel's conv2 .. conv5, models.py:570-636)
     against four a2c_conv2d_fwd[_signs] launches: same tiles, same summation order -> every activation and every sign word
@@ -1015,21 +1026,21 @@ def test_conv_chain_equals_the_per_layer_launches_bit_for_bit(B, signs, strided)
         ops.conv_prep(d, 0, w, wf)
         ws.append(w); bs.append(b); wfs.append(wf)
     mult = 3 if strided else 1          # row stride of the output buffers, in samples
-    nsw = ops.conv_sign_words(descs[0])
+    nsw = [ops.conv_sign_words(d) for d in descs]        # signs = number of leading layers that leave sign words (0, 1 or 2)
 
     def run(chain):
         outs = [torch.full((B * mult, d.Cout, d.OH, d.OW), float("nan"), device=DEV) for d in descs]
-        sg = torch.full((B * mult, nsw), -7, dtype=torch.int32, device=DEV) if signs else None
+        sg = [torch.full((B * mult, nsw[i]), -7, dtype=torch.int32, device=DEV) for i in range(signs)]
         n = [d.Cout * d.OH * d.OW for d in descs]
         optr = [o.data_ptr() + 4 * nn_ * (1 if strided else 0) for o, nn_ in zip(outs, n)]      # row 1, 1 + mult, ...
-        sgp = (sg.data_ptr() + 4 * nsw * (1 if strided else 0), mult * nsw) if signs else None
+        sgp = {i: (sg[i].data_ptr() + 4 * nsw[i] * (1 if strided else 0), mult * nsw[i]) for i in range(signs)}
         if chain:
-            ch.fwd(x.data_ptr(), 16 * 84 * 84, wfs, bs, optr, [mult * v for v in n], B, signs0=sgp)
+            ch.fwd(x.data_ptr(), 16 * 84 * 84, wfs, bs, optr, [mult * v for v in n], B, signs=sgp or None)
         else:
             src, sbs = x.data_ptr(), 16 * 84 * 84
             for i, d in enumerate(descs):
-                if i == 0 and signs:
-                    ops.conv_fwd_signs(d, src, sbs, wfs[i], bs[i], True, optr[i], sgp[0], sgp[1], B, out_bstride=mult * n[i])
+                if i in sgp:
+                    ops.conv_fwd_signs(d, src, sbs, wfs[i], bs[i], True, optr[i], sgp[i][0], sgp[i][1], B, out_bstride=mult * n[i])
                 else:
                     ops.conv_fwd(d, src, sbs, wfs[i], bs[i], True, optr[i], B, out_bstride=mult * n[i])
                 src, sbs = optr[i], mult * n[i]
@@ -1040,10 +1051,10 @@ def test_conv_chain_equals_the_per_layer_launches_bit_for_bit(B, signs, strided)
     for i in range(4):
         a, b = o_ch[i].view(torch.int32), o_ref[i].view(torch.int32)           # (NaN rows between the strided rows compare as bits)
         assert torch.equal(a, b), i
-    if signs:
-        assert torch.equal(sg_ch, sg_ref)
-        rows = sg_ch[1::mult] if strided else sg_ch
-        assert torch.equal(rows.cpu(), _sign_words((o_ch[0][1::mult] if strided else o_ch[0]).cpu() > 0))
+    for i in range(signs):
+        assert torch.equal(sg_ch[i], sg_ref[i]), i
+        rows = sg_ch[i][1::mult] if strided else sg_ch[i]
+        assert torch.equal(rows.cpu(), _sign_words((o_ch[i][1::mult] if strided else o_ch[i]).cpu() > 0)), i
     ref = x.cpu()
     for i, s in enumerate(specs):
         ref = F.relu(F.conv2d(ref, ws[i].cpu(), bs[i].cpu(), stride=2, padding=1))
@@ -1068,7 +1079,7 @@ def test_conv_chain_argument_validation():
     with pytest.raises(_lib.A2CKernelError):       # misaligned source
         ch.fwd(x.data_ptr() + 4, 16 * 84 * 84, wfs, bs, [o.data_ptr() for o in outs], n, 2)
     with pytest.raises(_lib.A2CKernelError):       # sign rows narrower than the layer's sign words
-        ch.fwd(x.data_ptr(), 16 * 84 * 84, wfs, bs, [o.data_ptr() for o in outs], n, 2, signs0=(outs[0].data_ptr(), 8))
+        ch.fwd(x.data_ptr(), 16 * 84 * 84, wfs, bs, [o.data_ptr() for o in outs], n, 2, signs={0: (outs[0].data_ptr(), 8)})
 
 
 @pytest.mark.parametrize("B,xs,hd,inplace", [(256, 256, 256, True), (37, 256, 256, False), (300, 64, 96, False)])

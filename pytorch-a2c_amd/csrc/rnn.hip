@@ -4,6 +4,7 @@
 // and torch.nn.LayerNorm of the FCModel/GRUFCModel value head (models.py:392, 510).
 // The six matrix products run on a2c_gemm_f32; these kernels are the fused gate math between
 // them (memory-bound, B*h elements), forward and backward.
+#include <stdlib.h>
 #include "a2c_common.h"
 
 namespace {
@@ -129,22 +130,26 @@ __device__ __forceinline__ f32x16 gru_tile_part(const float* __restrict__ arow, 
   return acc;
 }
 
-__global__ __launch_bounds__(512) void gru_cell_zr_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ h,
-                                                          const float* __restrict__ WxC, const float* __restrict__ WhC,
-                                                          const float* __restrict__ b, float* __restrict__ gx,
-                                                          float* __restrict__ z, float* __restrict__ r, float* __restrict__ rh,
-                                                          long M, int xs, int hd) {
-  __shared__ __attribute__((aligned(16))) float red[8][16][64];
+// NWK = waves per product (K split): 4 reproduces the five launches bit for bit; 8 (default) halves the chain of dependent
+// operand loads per wave (the products are latency-bound: 15 -> ~9 us for the gate kernel at 256 envs) and is the same sum
+// in another order (A2C_GRU_K4=1 selects 4).
+template <int NWK>
+__global__ __launch_bounds__(128 * NWK) void gru_cell_zr_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ h,
+                                                                const float* __restrict__ WxC, const float* __restrict__ WhC,
+                                                                const float* __restrict__ b, float* __restrict__ gx,
+                                                                float* __restrict__ z, float* __restrict__ r, float* __restrict__ rh,
+                                                                long M, int xs, int hd) {
+  __shared__ __attribute__((aligned(16))) float red[2 * NWK][16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const int tiles = hd / 32;
   const int gate = blockIdx.x / tiles;
   const long n0 = (long)(blockIdx.x - gate * tiles) * 32, m0 = (long)blockIdx.y * 32;
-  const bool xside = w < 4;
+  const bool xside = w < NWK;
   if (xside || gate < 2) {
     const long K = xside ? xs : hd;
-    const int wk = w & 3;
-    const long kq = ((K / 8 + 3) / 4) * 8;
+    const int wk = xside ? w : w - NWK;
+    const long kq = ((K / 8 + NWK - 1) / NWK) * 8;
     const long kbeg = min(K, wk * kq), kend = min(K, kbeg + kq);
     const float* __restrict__ arow = (xside ? x + min(m0 + li, M - 1) * ldx : h + min(m0 + li, M - 1) * hd) + 4 * lk;
     const long ldb = xside ? 3L * hd : 2L * hd;
@@ -154,24 +159,24 @@ __global__ __launch_bounds__(512) void gru_cell_zr_kernel(const float* __restric
     for (int q = 0; q < 16; ++q) red[w][q][lane] = acc[q];
   }
   __syncthreads();
-  // wave w finishes registers 2w, 2w+1 of every lane: col n = lane & 31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+  // wave w finishes registers w * 16 / (2 NWK) .. of every lane: col n = lane & 31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+  constexpr int PER = 16 / (2 * NWK) > 0 ? 16 / (2 * NWK) : 1;
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int q = w * 2 + e;
+  for (int e = 0; e < PER; ++e) {
+    const int q = w * PER + e;
+    if (q >= 16) continue;
     float gxv = red[0][q][lane];
-    gxv += red[1][q][lane];
-    gxv += red[2][q][lane];
-    gxv += red[3][q][lane];
+#pragma unroll
+    for (int ww = 1; ww < NWK; ++ww) gxv += red[ww][q][lane];
     const long m = m0 + (q & 3) + 8 * (q >> 2) + 4 * lk, n = n0 + li;
     if (m >= M) continue;
     if (gate == 2) {
       gx[m * 3 * hd + 2 * hd + n] = gxv;
       continue;
     }
-    float ghv = red[4][q][lane];
-    ghv += red[5][q][lane];
-    ghv += red[6][q][lane];
-    ghv += red[7][q][lane];
+    float ghv = red[NWK][q][lane];
+#pragma unroll
+    for (int ww = 1; ww < NWK; ++ww) ghv += red[NWK + ww][q][lane];
     const float v = sigmoidf_((gxv + ghv) + b[gate * hd + n]);
     if (gate == 0) z[m * hd + n] = v;
     else {
@@ -181,28 +186,28 @@ __global__ __launch_bounds__(512) void gru_cell_zr_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void gru_cell_out_kernel(const float* __restrict__ gx, const float* __restrict__ rh,
-                                                           const float* __restrict__ Wh2, const float* __restrict__ b,
-                                                           const float* h, const float* __restrict__ z, float* __restrict__ cnd,
-                                                           float* hn, long M, int hd) {      // hn may alias h
-  __shared__ __attribute__((aligned(16))) float red[4][16][64];
+template <int NWK>
+__global__ __launch_bounds__(64 * NWK) void gru_cell_out_kernel(const float* __restrict__ gx, const float* __restrict__ rh,
+                                                                const float* __restrict__ Wh2, const float* __restrict__ b,
+                                                                const float* h, const float* __restrict__ z, float* __restrict__ cnd,
+                                                                float* hn, long M, int hd) {      // hn may alias h
+  __shared__ __attribute__((aligned(16))) float red[NWK][16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const long n0 = (long)blockIdx.x * 32, m0 = (long)blockIdx.y * 32;
   const long K = hd;
-  const long kq = ((K / 8 + 3) / 4) * 8;
+  const long kq = ((K / 8 + NWK - 1) / NWK) * 8;
   const long kbeg = min(K, w * kq), kend = min(K, kbeg + kq);
   const f32x16 acc = gru_tile_part(rh + min(m0 + li, M - 1) * hd + 4 * lk, Wh2 + n0 + li + (long)(4 * lk) * hd, hd, kbeg, kend);
 #pragma unroll
   for (int q = 0; q < 16; ++q) red[w][q][lane] = acc[q];
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int q = w * 4 + e;
+  for (int e = 0; e < 16 / NWK; ++e) {
+    const int q = w * (16 / NWK) + e;
     float v = red[0][q][lane];
-    v += red[1][q][lane];
-    v += red[2][q][lane];
-    v += red[3][q][lane];
+#pragma unroll
+    for (int ww = 1; ww < NWK; ++ww) v += red[ww][q][lane];
     const long m = m0 + (q & 3) + 8 * (q >> 2) + 4 * lk, n = n0 + li;
     if (m >= M) continue;
     const long i = m * hd + n;
@@ -239,19 +244,20 @@ __device__ __forceinline__ f32x16 gru_tile_part_kc(const float* __restrict__ aro
   return acc;
 }
 
-__global__ __launch_bounds__(256) void gru_cell_bwd1_kernel(const float* __restrict__ dhn, const float* __restrict__ carry,
+template <int NWK>
+__global__ __launch_bounds__(64 * NWK) void gru_cell_bwd1_kernel(const float* __restrict__ dhn, const float* __restrict__ carry,
                                                             const float* __restrict__ dones, long dstride,
                                                             const float* __restrict__ h, const float* __restrict__ z,
                                                             const float* __restrict__ r, const float* __restrict__ c,
                                                             const float* __restrict__ Wh2, float* __restrict__ dcp,
                                                             float* __restrict__ dz, float* __restrict__ dzp, float* __restrict__ drp,
                                                             float* __restrict__ dh, long M, int hd) {
-  __shared__ __attribute__((aligned(16))) float red[4][16][64];
+  __shared__ __attribute__((aligned(16))) float red[NWK][16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const long n0 = (long)blockIdx.x * 32, m0 = (long)blockIdx.y * 32;
   const long K = hd;
-  const long kq = ((K / 8 + 3) / 4) * 8;
+  const long kq = ((K / 8 + NWK - 1) / NWK) * 8;
   const long kbeg = min(K, w * kq), kend = min(K, kbeg + kq);
   const long mrow = min(m0 + li, M - 1);
   const float keep = carry ? 1.f - dones[mrow * dstride] : 0.f;
@@ -285,12 +291,11 @@ __global__ __launch_bounds__(256) void gru_cell_bwd1_kernel(const float* __restr
   for (int q = 0; q < 16; ++q) red[w][q][lane] = acc[q];
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int q = w * 4 + e;
+  for (int e = 0; e < 16 / NWK; ++e) {
+    const int q = w * (16 / NWK) + e;
     float drh = red[0][q][lane];
-    drh += red[1][q][lane];
-    drh += red[2][q][lane];
-    drh += red[3][q][lane];
+#pragma unroll
+    for (int ww = 1; ww < NWK; ++ww) drh += red[ww][q][lane];
     const long m = m0 + (q & 3) + 8 * (q >> 2) + 4 * lk, n = n0 + li;
     if (m >= M) continue;
     const long i = m * hd + n;
@@ -305,34 +310,35 @@ __global__ __launch_bounds__(256) void gru_cell_bwd1_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(512) void gru_cell_bwd2_kernel(const float* __restrict__ dzp, const float* __restrict__ drp,
+template <int NWK>
+__global__ __launch_bounds__(128 * NWK) void gru_cell_bwd2_kernel(const float* __restrict__ dzp, const float* __restrict__ drp,
                                                             const float* __restrict__ Wh0, const float* __restrict__ Wh1,
                                                             float* __restrict__ dh, long M, int hd) {
-  __shared__ __attribute__((aligned(16))) float red[8][16][64];
+  __shared__ __attribute__((aligned(16))) float red[2 * NWK][16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const long n0 = (long)blockIdx.x * 32, m0 = (long)blockIdx.y * 32;
   const long K = hd;
-  const long kq = ((K / 8 + 3) / 4) * 8;
-  const int wk = w & 3;
+  const long kq = ((K / 8 + NWK - 1) / NWK) * 8;
+  const int wk = w < NWK ? w : w - NWK;
   const long kbeg = min(K, wk * kq), kend = min(K, kbeg + kq);
-  const float* __restrict__ arow = (w < 4 ? dzp : drp) + min(m0 + li, M - 1) * hd + 4 * lk;
-  const float* __restrict__ brow = (w < 4 ? Wh0 : Wh1) + min(n0 + li, (long)hd - 1) * hd + 4 * lk;
+  const float* __restrict__ arow = (w < NWK ? dzp : drp) + min(m0 + li, M - 1) * hd + 4 * lk;
+  const float* __restrict__ brow = (w < NWK ? Wh0 : Wh1) + min(n0 + li, (long)hd - 1) * hd + 4 * lk;
   const f32x16 acc = gru_tile_part_kc(arow, brow, kbeg, kend);
 #pragma unroll
   for (int q = 0; q < 16; ++q) red[w][q][lane] = acc[q];
   __syncthreads();
+  constexpr int PER = 16 / (2 * NWK) > 0 ? 16 / (2 * NWK) : 1;
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int q = w * 2 + e;
+  for (int e = 0; e < PER; ++e) {
+    const int q = w * PER + e;
+    if (q >= 16) continue;
     float v0 = red[0][q][lane];
-    v0 += red[1][q][lane];
-    v0 += red[2][q][lane];
-    v0 += red[3][q][lane];
-    float v1 = red[4][q][lane];
-    v1 += red[5][q][lane];
-    v1 += red[6][q][lane];
-    v1 += red[7][q][lane];
+#pragma unroll
+    for (int ww = 1; ww < NWK; ++ww) v0 += red[ww][q][lane];
+    float v1 = red[NWK][q][lane];
+#pragma unroll
+    for (int ww = 1; ww < NWK; ++ww) v1 += red[NWK + ww][q][lane];
     const long m = m0 + (q & 3) + 8 * (q >> 2) + 4 * lk, n = n0 + li;
     if (m >= M) continue;
     v0 += dh[m * hd + n];
@@ -387,6 +393,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 }  // namespace
 
+// A2C_GRU_K4=1 (read per call): the cell kernels with a four-way K split, bit-identical to the launch sequences they replace
+static bool gru_k4() {
+  const char* e = getenv("A2C_GRU_K4");
+  return e != nullptr && e[0] == '1';
+}
+
 extern "C" {
 int a2c_gru_gates(const float* gx, const float* gh, const float* b, const float* h, float* z, float* r, float* rh,
                   int B, int hdim, a2c_stream_t stream) {
@@ -418,11 +430,19 @@ int a2c_gru_cell_fwd(const float* x, int64_t ldx, const float* h, const float* W
   if (!x || !h || !WxC || !WhC || !Wh2 || !b || !gx || !z || !r || !rh || !h_new) return A2C_ERR_ARG;
   if ((((uintptr_t)x | (uintptr_t)h | (uintptr_t)rh) % 16)) return A2C_ERR_ARG;
   const int tiles = hdim / 32, rows = (B + 31) / 32;
-  hipLaunchKernelGGL(gru_cell_zr_kernel, dim3(3 * tiles, rows), dim3(512), 0, a2c_s(stream), x, (long)ldx, h, WxC, WhC, b, gx, z,
-                     r, rh, (long)B, xs, hdim);
-  A2C_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gru_cell_out_kernel, dim3(tiles, rows), dim3(256), 0, a2c_s(stream), gx, rh, Wh2, b, h, z, c, h_new,
-                     (long)B, hdim);
+  if (gru_k4()) {
+    hipLaunchKernelGGL((gru_cell_zr_kernel<4>), dim3(3 * tiles, rows), dim3(512), 0, a2c_s(stream), x, (long)ldx, h, WxC, WhC, b, gx, z,
+                       r, rh, (long)B, xs, hdim);
+    A2C_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gru_cell_out_kernel<4>), dim3(tiles, rows), dim3(256), 0, a2c_s(stream), gx, rh, Wh2, b, h, z, c, h_new,
+                       (long)B, hdim);
+  } else {
+    hipLaunchKernelGGL((gru_cell_zr_kernel<8>), dim3(3 * tiles, rows), dim3(1024), 0, a2c_s(stream), x, (long)ldx, h, WxC, WhC, b, gx, z,
+                       r, rh, (long)B, xs, hdim);
+    A2C_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gru_cell_out_kernel<8>), dim3(tiles, rows), dim3(512), 0, a2c_s(stream), gx, rh, Wh2, b, h, z, c, h_new,
+                       (long)B, hdim);
+  }
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }
@@ -438,11 +458,19 @@ int a2c_gru_cell_bwd(const float* dh_new, const float* carry, const float* dones
     return A2C_ERR_ARG;
   const int tiles = hdim / 32, rows = (B + 31) / 32;
   const long hh = (long)hdim * hdim;
-  hipLaunchKernelGGL(gru_cell_bwd1_kernel, dim3(tiles, rows), dim3(256), 0, a2c_s(stream), dh_new, carry, dones, (long)done_stride,
-                     h, z, r, c, Wh + 2 * hh, dc_pre, dz, dz_pre, dr_pre, dh, (long)B, hdim);
-  A2C_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gru_cell_bwd2_kernel, dim3(tiles, rows), dim3(512), 0, a2c_s(stream), dz_pre, dr_pre, Wh, Wh + hh, dh, (long)B,
-                     hdim);
+  if (gru_k4()) {
+    hipLaunchKernelGGL((gru_cell_bwd1_kernel<4>), dim3(tiles, rows), dim3(256), 0, a2c_s(stream), dh_new, carry, dones, (long)done_stride,
+                       h, z, r, c, Wh + 2 * hh, dc_pre, dz, dz_pre, dr_pre, dh, (long)B, hdim);
+    A2C_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gru_cell_bwd2_kernel<4>), dim3(tiles, rows), dim3(512), 0, a2c_s(stream), dz_pre, dr_pre, Wh, Wh + hh, dh, (long)B,
+                       hdim);
+  } else {
+    hipLaunchKernelGGL((gru_cell_bwd1_kernel<8>), dim3(tiles, rows), dim3(512), 0, a2c_s(stream), dh_new, carry, dones, (long)done_stride,
+                       h, z, r, c, Wh + 2 * hh, dc_pre, dz, dz_pre, dr_pre, dh, (long)B, hdim);
+    A2C_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gru_cell_bwd2_kernel<8>), dim3(tiles, rows), dim3(1024), 0, a2c_s(stream), dz_pre, dr_pre, Wh, Wh + hh, dh, (long)B,
+                       hdim);
+  }
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

@@ -1083,12 +1083,15 @@ def test_conv_chain_argument_validation():
 
 
 @pytest.mark.parametrize("B,xs,hd,inplace", [(256, 256, 256, True), (37, 256, 256, False), (300, 64, 96, False)])
-def test_gru_cell_fwd_two_launches_equal_the_five_bit_for_bit(B, xs, hd, inplace):
+@pytest.mark.parametrize("k4", [True, False])
+def test_gru_cell_fwd_two_launches_equal_the_five_bit_for_bit(B, xs, hd, inplace, k4, monkeypatch):
     """a2c_gru_cell_fwd (models.py:465-476 at rollout batch: two launches) against the path it replaces -- a2c_gemm_f32
-    (x [Wx0|Wx1|Wx2], h [Wh0|Wh1]) + a2c_gru_gates + a2c_gemm_f32 ((r*h) Wh2) + a2c_gru_out -- bit for bit (same K split,
-    MFMA order and order of additions), and against the reference's formula in torch; x as rows of a wider buffer; h_new
-    written over h (the in-place rollout step)."""
+    (x [Wx0|Wx1|Wx2], h [Wh0|Wh1]) + a2c_gru_gates + a2c_gemm_f32 ((r*h) Wh2) + a2c_gru_out -- bit for bit with the
+    four-way K split (A2C_GRU_K4=1: same K split, MFMA order and order of additions), within fp32 rounding of it with the
+    default eight-way split (the same sums in another order), and against the reference's formula in torch; x as rows of a
+    wider buffer; h_new written over h (the in-place rollout step)."""
     ops = _ops()
+    monkeypatch.setenv("A2C_GRU_K4", "1" if k4 else "0")
     x_wide = rnd((B, xs + 8), 951, 0, 1).to(DEV)
     x = x_wide[:, :xs]
     h0 = rnd((B, hd), 952).to(DEV)
@@ -1110,8 +1113,14 @@ def test_gru_cell_fwd_two_launches_equal_the_five_bit_for_bit(B, xs, hd, inplace
     ops.gru_cell_fwd(x, h_io, WxC, WhC, Wh[2], b, gx2, z2, r2, rh2, c2, hn2)
     torch.cuda.synchronize()
     for name, a, bb in (("z", z2, z1), ("r", r2, r1), ("rh", rh2, rh1), ("c", c2, c1), ("hn", hn2, hn1)):
-        assert torch.equal(a, bb), name
-    assert torch.equal(gx2[:, 2 * hd:], gx[:, 2 * hd:])
+        if k4:
+            assert torch.equal(a, bb), name
+        else:
+            close(name, a, bb, 4e-6, 0)
+    if k4:
+        assert torch.equal(gx2[:, 2 * hd:], gx[:, 2 * hd:])
+    else:
+        close("gx", gx2[:, 2 * hd:], gx[:, 2 * hd:], 4e-6, 0)
     xc, hc = x.cpu(), h0.cpu()
     zt = torch.sigmoid(xc.mm(Wx[0].cpu()) + hc.mm(Wh[0].cpu()) + b[0].cpu())
     rt = torch.sigmoid(xc.mm(Wx[1].cpu()) + hc.mm(Wh[1].cpu()) + b[1].cpu())
@@ -1159,11 +1168,14 @@ def test_gemm_bf16_x9_path_is_the_fp32_product(tA, tB, M, N, K, monkeypatch):
 
 
 @pytest.mark.parametrize("B,hd,with_carry", [(256, 256, True), (37, 256, False), (300, 96, True)])
-def test_gru_cell_bwd_two_launches_equal_the_five_bit_for_bit(B, hd, with_carry):
+@pytest.mark.parametrize("k4", [True, False])
+def test_gru_cell_bwd_two_launches_equal_the_five_bit_for_bit(B, hd, with_carry, k4, monkeypatch):
     """a2c_gru_cell_bwd (one step of the BPTT unroll's backward, updater.py:139-169) against the five launches it replaces --
-    a2c_gru_out_bwd[_carry], a2c_gemm_f32 (dc_pre Wh2^T), a2c_gru_gates_bwd, two accumulating a2c_gemm_f32 -- bit for bit,
-    and against autograd through the reference's cell formula (models.py:465-476)."""
+    a2c_gru_out_bwd[_carry], a2c_gemm_f32 (dc_pre Wh2^T), a2c_gru_gates_bwd, two accumulating a2c_gemm_f32 -- bit for bit
+    with the four-way K split (A2C_GRU_K4=1), within fp32 rounding with the default eight-way split, and against autograd
+    through the reference's cell formula (models.py:465-476)."""
     ops = _ops()
+    monkeypatch.setenv("A2C_GRU_K4", "1" if k4 else "0")
     mk = lambda *s: torch.full(s, float("nan"), device=DEV)
     dhn, carry, h0 = rnd((B, hd), 961).to(DEV), rnd((B, hd), 962).to(DEV), rnd((B, hd), 963).to(DEV)
     dones = (rnd((B, 3), 964, 0, 1) < 0.3).float().to(DEV)          # done of row b at dones[b * 3 + 1]
@@ -1188,7 +1200,10 @@ def test_gru_cell_bwd_two_launches_equal_the_five_bit_for_bit(B, hd, with_carry)
     ops.gru_cell_bwd(dhn, carry if with_carry else None, dptr if with_carry else 0, dstride, h0, z, r, c, Wh, dcp2, dz2, dzp2, drp2, dh2)
     torch.cuda.synchronize()
     for name, a, bb in (("dc_pre", dcp2, dcp1), ("dz", dz2, dz1), ("dz_pre", dzp2, dzp1), ("dr_pre", drp2, drp1), ("dh", dh2, dh1)):
-        assert torch.equal(a, bb), name
+        if k4:
+            assert torch.equal(a, bb), name
+        else:
+            close(name, a, bb, 4e-6 * float(bb.abs().max()), 0)
     # autograd: dL/dh_in for L = sum(h_new * g), g = dhn + carry * (1 - done)
     hc = h0.cpu().double().requires_grad_(True)
     Wxd, Whd, bd, xd = Wx.cpu().double(), Wh.cpu().double(), b.cpu().double(), x.cpu().double()

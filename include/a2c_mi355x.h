@@ -420,6 +420,16 @@ int a2c_heads_fused(const float *xs, int nslab, int64_t slab_stride, int64_t ldx
                     const float *W, const float *b, float *heads, int64_t ldh, int64_t M, int N,
                     int K, const float *u, int n_logits, int64_t *actions, int64_t act_stride,
                     a2c_stream_t stream);
+/* a2c_heads_fused whose sampling thread also hands the action to the env worker (the device relay's
+ * a2c_pool_publish_actions, runner.py:129-131 "pipe.send(action)"): with cmd != NULL (needs u)
+ *   cmd[m] = ((seq_base[0] + seq_off) << 32) | action[m]       one system-scope 8-byte store per row
+ * cmd == NULL is a2c_heads_fused.                                                            */
+int a2c_heads_fused_publish(const float *xs, int nslab, int64_t slab_stride, int64_t ldx,
+                            const float *bias_in, int relu_in, float *emb_out, int64_t ld_emb,
+                            const float *W, const float *b, float *heads, int64_t ldh, int64_t M,
+                            int N, int K, const float *u, int n_logits, int64_t *actions,
+                            int64_t act_stride, uint64_t *cmd, const uint32_t *seq_base,
+                            uint32_t seq_off, a2c_stream_t stream);
 int a2c_gemm_f32_nt(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
                     int64_t ldb, float *C, int64_t ldc, const float *bias, int relu,
                     a2c_stream_t stream);

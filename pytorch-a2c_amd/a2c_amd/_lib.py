@@ -94,6 +94,8 @@ SIGNATURES = {
     "a2c_gemm_f32_partial": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, c_int, P, c_size_t, P]),
     "a2c_heads_fused": (c_int, [P, c_int, c_int64, c_int64, P, c_int, P, c_int64, P, P, P, c_int64, c_int64, c_int, c_int,
                                  P, c_int, P, c_int64, P]),
+    "a2c_heads_fused_publish": (c_int, [P, c_int, c_int64, c_int64, P, c_int, P, c_int64, P, P, P, c_int64, c_int64, c_int, c_int,
+                                         P, c_int, P, c_int64, P, P, ctypes.c_uint32, P]),
     "a2c_gemm_f32_nt": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int, P]),
     "a2c_gemm_f32_nn": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P]),
     "a2c_gemm_f32_tn": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int, P,

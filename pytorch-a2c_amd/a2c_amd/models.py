@@ -31,6 +31,11 @@ def _conv_block(cin, cout, ks, stride, pad):
     return nn.Sequential(nn.Conv2d(cin, cout, ks, stride=stride, padding=pad), nn.ReLU())
 
 
+def _sampler(sampler):
+    """sampler = (u, actions_ptr, act_stride[, publish]); publish = (cmd_ptr, seq_base, seq_off) or None (ops.heads_fused)"""
+    return (*sampler[:3], sampler[3] if len(sampler) > 3 else None)
+
+
 class _HipNet(nn.Module):
     """Machinery shared by every model: arena, workspaces, public forward, autograd bridge."""
 
@@ -332,7 +337,7 @@ class A3CModel(_HipNet):
         # [pi.weight; value.weight] and [pi.bias | value.bias] are adjacent in the arena: one (A+1)-wide head
         Wh = self._arena.params[self._arena.offsets["pi.weight"][0]:][:(A + 1) * h].view(A + 1, h)
         bh = self._arena.params[self._arena.offsets["pi.bias"][0]:][:A + 1]
-        u, a_ptr, a_stride = sampler if sampler is not None else (None, 0, 0)
+        u, a_ptr, a_stride, pub = _sampler(sampler) if sampler is not None else (None, 0, 0, None)
         if A + 1 > 8:               # wide heads: two plain GEMMs; the runner samples with a2c_softmax_sample
             linear_fwd(ws, a2.data_ptr(), self.flat_size, P("proj_matrx.weight"), P("proj_matrx.bias"), emb, B, st)
             linear_fwd(ws, emb.data_ptr(), h, Wh, bh, hb, B, st)
@@ -340,8 +345,8 @@ class A3CModel(_HipNet):
         if sampler is not None and not save and os.environ.get("A2C_NO_COMPOSED_HEADS") != "1":
             # rollout step: heads straight from the conv features through the composed matrix
             ops.heads_fused(a2.data_ptr(), 1, 0, self.flat_size, None, False, None, self._Wc, self._bc, hb, B, u, A,
-                            a_ptr, a_stride, st)
-            return dict(logits=logits, vals=vals, sampled=True)
+                            a_ptr, a_stride, st, publish=pub)
+            return dict(logits=logits, vals=vals, sampled=True, published=pub is not None)
         Wp = P("proj_matrx.weight")
         sk = ops.pick_splitk(B, h, self.flat_size)
         if sk > 1 and os.environ.get("A2C_NO_FUSED_TAIL") != "1":
@@ -352,14 +357,14 @@ class A3CModel(_HipNet):
                 nslab = ops.gemm_partial(0, 1, B, h, self.flat_size, a2.data_ptr(), self.flat_size, Wp.data_ptr(),
                                          self.flat_size, sk, buf, st)
             ops.heads_fused(buf.data_ptr(), nslab, B * h, h, P("proj_matrx.bias"), False, emb, Wh, bh, hb, B, u, A,
-                            a_ptr, a_stride, st)
+                            a_ptr, a_stride, st, publish=pub if u is not None else None)
         else:
             linear_fwd(ws, a2.data_ptr(), self.flat_size, Wp, P("proj_matrx.bias"), emb, B, st)
             if u is None:         # update: plain skinny layer (wave per row); nothing to sample
                 linear_fwd(ws, emb.data_ptr(), h, Wh, bh, hb, B, st)
             else:
-                ops.heads_fused(emb.data_ptr(), 1, 0, h, None, False, None, Wh, bh, hb, B, u, A, a_ptr, a_stride, st)
-        return dict(logits=logits, vals=vals, sampled=u is not None)
+                ops.heads_fused(emb.data_ptr(), 1, 0, h, None, False, None, Wh, bh, hb, B, u, A, a_ptr, a_stride, st, publish=pub)
+        return dict(logits=logits, vals=vals, sampled=u is not None, published=u is not None and pub is not None)
 
     def _step_supported(self):
         """True when the one-launch rollout step (a2c_a3c_step) covers this net's shapes."""
@@ -509,13 +514,13 @@ class _ConvStackNet(_HipNet):
         fsrc = getattr(self, "_frames_src", None)       # rollout step: layer 0 stacks its input on load (runner, row f4)
         # layers 1 .. n-1 of a rollout-sized batch as ONE launch where the library has a chain kernel for them (GRUModel's four
         # stride-2 layers: a workgroup walks one sample through all of them; bit-identical to the per-layer launches)
-        chain = self._conv_chain() if (not train and 64 < B <= 4096 and all(i in (1, 2) for i in sl if i >= 1)
-                                       and (2 not in sl or 1 in sl)) else None
+        chain = self._conv_chain() if (not train and 64 < B <= 4096 and all(i in (1, 2, 3) for i in sl if i >= 1)
+                                       and (2 not in sl or 1 in sl) and (3 not in sl or 2 in sl)) else None
         for i, l in enumerate(self._cl):
             n = int(np.prod(l.out_shape))
             if chain is not None and i == 1:
                 nl = len(self._cl)
-                csl = [k for k in (1, 2) if k in sl]                      # layers of the chain that leave sign words
+                csl = [k for k in (1, 2, 3) if k in sl]                   # layers of the chain that leave sign words
                 if stash is None:
                     outs = [ws.get(f"a{k}", (B,) + self._cl[k].out_shape) for k in range(1, nl)]
                     optrs, obss = [o.data_ptr() for o in outs], [int(np.prod(self._cl[k].out_shape)) for k in range(1, nl)]
@@ -725,19 +730,19 @@ class ConvModel(_ConvStackNet):
         if sampler is not None and not save and self._fused_sampling:
             # rollout step: the split-K slabs of the hidden layer are summed by the heads kernel itself -- slab sum +
             # bias + ReLU, both heads (block matrix above) and the action sampling in ONE node instead of four
-            u, a_ptr, a_stride = sampler
+            u, a_ptr, a_stride, pub = _sampler(sampler)
             sk = ops.pick_splitk(B, 2 * h, ch)
             if sk > 1:
                 buf = ws.bytes("gemm_ws", ops.gemm_ws_bytes(B, 2 * h, sk))
                 with ops.span(f"linear.fwd {2 * h}x{ch}"):
                     nslab = ops.gemm_partial(0, 1, B, 2 * h, ch, e.data_ptr(), lde, W0.data_ptr(), ch, sk, buf, st)
                 ops.heads_fused(buf.data_ptr(), nslab, B * 2 * h, 2 * h, b0, True, None, self._Whd, self._bhd, hb, B, u, A,
-                                a_ptr, a_stride, st)
+                                a_ptr, a_stride, st, publish=pub)
             else:
                 linear_fwd(ws, e.data_ptr(), lde, W0, b0, hid, B, st, relu=True)
                 ops.heads_fused(hid.data_ptr(), 1, 0, 2 * h, None, False, None, self._Whd, self._bhd, hb, B, u, A, a_ptr,
-                                a_stride, st)
-            return dict(logits=logits, vals=vals, sampled=True)
+                                a_stride, st, publish=pub)
+            return dict(logits=logits, vals=vals, sampled=True, published=pub is not None)
         linear_fwd(ws, e.data_ptr(), lde, W0, b0, hid, B, st, relu=True)
         linear_fwd(ws, hid.data_ptr(), 2 * h, P("pi.2.weight"), P("pi.2.bias"), logits, B, st)
         linear_fwd(ws, hid.data_ptr() + 4 * h, 2 * h, P("value.2.weight"), P("value.2.bias"), hb[:, A:], B, st)
@@ -1083,11 +1088,11 @@ class GRUModel(_ConvStackNet, _GruMixin):
             self._gru_fwd(ws, e, h_in, B, st, bufs)
             hb_t = self._heads("train", self._cells_R * self._cells_T)[0][stash[1]::stash[2]][:B]
             Wh, bh = self._head_w(self._arena.params)
-            u, a_ptr, a_stride = sampler
+            u, a_ptr, a_stride, pub = _sampler(sampler)
             ops.heads_fused(bufs["hn"].data_ptr(), 1, 0, self.h_size, None, False, None, Wh, bh, hb_t, B, u, self.output_space,
-                            a_ptr, a_stride, st)
+                            a_ptr, a_stride, st, publish=pub)
             return dict(logits=hb_t[:, :self.output_space], vals=hb_t[:, self.output_space], h=bufs["hn"], sampled=True,
-                        h_next_src=bufs["hn"])
+                        h_next_src=bufs["hn"], published=pub is not None)
         if save or not h_in.is_contiguous():       # the backward pass re-reads h_in from the workspace
             hin = ws.get("h_in", (B, self.h_size))
             hin.copy_(h_in)
@@ -1100,10 +1105,10 @@ class GRUModel(_ConvStackNet, _GruMixin):
         hb, logits, vals = self._heads(tag, B)
         Wh, bh = self._head_w(self._arena.params)
         if sampler is not None and not save and self._fused_sampling:      # rollout step: heads + sampling in one node
-            u, a_ptr, a_stride = sampler
+            u, a_ptr, a_stride, pub = _sampler(sampler)
             ops.heads_fused(bufs["hn"].data_ptr(), 1, 0, self.h_size, None, False, None, Wh, bh, hb, B, u, self.output_space,
-                            a_ptr, a_stride, st)
-            return dict(logits=logits, vals=vals, h=bufs["hn"], sampled=True)
+                            a_ptr, a_stride, st, publish=pub)
+            return dict(logits=logits, vals=vals, h=bufs["hn"], sampled=True, published=pub is not None)
         linear_fwd(ws, bufs["hn"].data_ptr(), self.h_size, Wh, bh, hb, B, st)
         return dict(logits=logits, vals=vals, h=bufs["hn"])
 

@@ -519,12 +519,15 @@ def gemm_partial(transA, transB, M, N, K, A_ptr, lda, B_ptr, ldb, splitk, ws, st
 
 
 def heads_fused(xs_ptr, nslab, slab_stride, ldx, bias_in, relu_in, emb_out, W, b, heads, M, u=None, n_logits=0,
-                actions_ptr=0, act_stride=0, st=None):
+                actions_ptr=0, act_stride=0, st=None, publish=None):
+    """publish = (cmd_ptr, seq_base tensor, seq_off): the sampling thread also stores the action's cmd granule (device relay)"""
     N, K = W.shape
-    check(lib().a2c_heads_fused(xs_ptr, nslab, slab_stride, ldx, _p(bias_in), int(bool(relu_in)), _p(emb_out),
-                                0 if emb_out is None else emb_out.stride(0), _p(W), _p(b), _p(heads), heads.stride(0), M,
-                                N, K, _p(u), n_logits, actions_ptr, act_stride, st if st is not None else stream()),
-          "a2c_heads_fused")
+    cmd, seq_base, seq_off = publish if publish is not None else (0, None, 0)
+    check(lib().a2c_heads_fused_publish(xs_ptr, nslab, slab_stride, ldx, _p(bias_in), int(bool(relu_in)), _p(emb_out),
+                                        0 if emb_out is None else emb_out.stride(0), _p(W), _p(b), _p(heads), heads.stride(0),
+                                        M, N, K, _p(u), n_logits, actions_ptr, act_stride, cmd, _p(seq_base), seq_off,
+                                        st if st is not None else stream()),
+          "a2c_heads_fused_publish")
 
 
 def gemm_ws_bytes(M, N, splitk, K=None):

@@ -792,7 +792,10 @@ class Runner:
             u = c["ub"][k, env0:env0 + B]
             net._cell_stash_ok = fused_post            # the cell stash needs the fused post kernel (h_src) of the next segment
             try:
-                out = self._forward(net, sp(k), T * S, B, env0, st, sampler=(u, a_ptr, a_stride),
+                pub = None      # device relay: the heads kernel's sampling thread hands the action to the env worker itself
+                if c.get("relay") and os.environ.get("A2C_NO_FUSED_PUBLISH") != "1":
+                    pub = (pool.dev_cmd + 8 * env0, self._seq_dev, k)
+                out = self._forward(net, sp(k), T * S, B, env0, st, sampler=(u, a_ptr, a_stride, pub),
                                     stash=None if c["stash"] is None else (c["stash"], slot0 * T + k, T))
             finally:
                 net._frames_src = None
@@ -803,6 +806,8 @@ class Runner:
             elif h is not None and out["h"].data_ptr() != h.data_ptr():    # (the GRU models update h in place)
                 ops.copy_rows(out["h"].data_ptr(), h.shape[1], h.data_ptr(), h.shape[1], B, h.shape[1], st)
         if c.get("relay"):      # the sampled actions go to the env workers: cmd granules of env step k
+            if not c["fused"] and out.get("published", False):
+                return
             ops.pool_publish_actions(pool.dev_cmd + 8 * env0, a_ptr, a_stride, B, self._seq_dev, k, st)
             return
         # the sampled actions go to the host (pinned staging) at the tail of the segment

@@ -1114,7 +1114,9 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restric
                                                           const float* __restrict__ W, const float* __restrict__ b,
                                                           float* __restrict__ heads, long ldh, long M, int N, int K,
                                                           const float* __restrict__ u, int n_logits,
-                                                          int64_t* __restrict__ actions, long act_stride) {
+                                                          int64_t* __restrict__ actions, long act_stride,
+                                                          unsigned long long* __restrict__ cmd,
+                                                          const unsigned int* __restrict__ seq_base, unsigned int seq_off) {
   __shared__ float red[4][SN_MAX];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (long m = blockIdx.x; m < M; m += gridDim.x) {
@@ -1185,6 +1187,9 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const float* __restric
           }
         if (pick < 0) pick = n_logits - 1;      // fp32 cumsum short of u: the last action (see sample_kernel)
         actions[m * act_stride] = (int64_t)pick;
+        if (cmd != nullptr)      // the device relay's action hand-off (pool_publish_kernel) from the thread that sampled it
+          __hip_atomic_store(cmd + m, ((unsigned long long)(seq_base[0] + seq_off) << 32) | (unsigned int)pick, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     __syncthreads();
@@ -1454,21 +1459,30 @@ int a2c_gemm_f32_partial(int transA, int transB, int64_t M, int64_t N, int64_t K
   return A2C_OK;
 }
 
-int a2c_heads_fused(const float* xs, int nslab, int64_t slab_stride, int64_t ldx, const float* bias_in, int relu_in,
-                    float* emb_out, int64_t ld_emb, const float* W, const float* b, float* heads, int64_t ldh, int64_t M,
-                    int N, int K, const float* u, int n_logits, int64_t* actions, int64_t act_stride,
-                    a2c_stream_t stream) {
+int a2c_heads_fused_publish(const float* xs, int nslab, int64_t slab_stride, int64_t ldx, const float* bias_in, int relu_in,
+                            float* emb_out, int64_t ld_emb, const float* W, const float* b, float* heads, int64_t ldh, int64_t M,
+                            int N, int K, const float* u, int n_logits, int64_t* actions, int64_t act_stride, uint64_t* cmd,
+                            const uint32_t* seq_base, uint32_t seq_off, a2c_stream_t stream) {
   if (M < 0 || N < 1 || N > SN_MAX || K < 4 || K % 4 || nslab < 1) return A2C_ERR_ARG;
   if (M == 0) return A2C_OK;
   if (!xs || !W || !heads || (u && (!actions || n_logits < 1 || n_logits > N))) return A2C_ERR_ARG;
+  if (cmd && (!u || !seq_base || (uintptr_t)cmd % 8)) return A2C_ERR_ARG;
   if (ldx % 4 || slab_stride % 4 || (emb_out && ld_emb % 4)) return A2C_ERR_ARG;
   if (((uintptr_t)xs | (uintptr_t)W | (uintptr_t)(bias_in ? bias_in : W) | (uintptr_t)(emb_out ? emb_out : (float*)W)) % 16)
     return A2C_ERR_ARG;
   hipLaunchKernelGGL(heads_fused_kernel, dim3(a2c_grid_1d(M, 1, 8192)), dim3(256), 0, a2c_s(stream), xs, nslab,
                      (long)slab_stride, (long)ldx, bias_in, relu_in, emb_out, (long)ld_emb, W, b, heads, (long)ldh,
-                     (long)M, N, K, u, n_logits, actions, (long)act_stride);
+                     (long)M, N, K, u, n_logits, actions, (long)act_stride, (unsigned long long*)cmd, seq_base, seq_off);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
+}
+
+int a2c_heads_fused(const float* xs, int nslab, int64_t slab_stride, int64_t ldx, const float* bias_in, int relu_in,
+                    float* emb_out, int64_t ld_emb, const float* W, const float* b, float* heads, int64_t ldh, int64_t M,
+                    int N, int K, const float* u, int n_logits, int64_t* actions, int64_t act_stride,
+                    a2c_stream_t stream) {
+  return a2c_heads_fused_publish(xs, nslab, slab_stride, ldx, bias_in, relu_in, emb_out, ld_emb, W, b, heads, ldh, M, N, K, u,
+                                 n_logits, actions, act_stride, nullptr, nullptr, 0, stream);
 }
 
 int a2c_gemm_f32_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,

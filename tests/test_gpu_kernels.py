@@ -398,6 +398,43 @@ def test_gemm_skinny_head_paths():
     close("heads bwd_weight", dW, want, 1e-5 * float(want.abs().max()), 1e-5)
 
 
+@pytest.mark.parametrize("M,K,nslab,A", [(32, 2000, 5, 6), (256, 256, 1, 3), (7, 516, 3, 7)])
+def test_heads_fused_tail_samples_and_publishes(M, K, nslab, A):
+    """a2c_heads_fused_publish (the tail of a rollout forward: split-K slab sum + bias + ReLU -> [emb] -> pi / value heads
+    (models.py:84-85) -> softmax sample (runner.py:94-97) -> the device relay's cmd granule, runner.py:129-131
+    "pipe.send(action)"): against fp64, the sampler kernel on the same logits, and a2c_pool_publish_actions."""
+    ops = _ops()
+    xs = rnd((nslab, M, K), 71).to(DEV)
+    bias, W, b = rnd((K,), 72).to(DEV), (rnd((A + 1, K), 73) / K ** 0.5).to(DEV), rnd((A + 1,), 74).to(DEV)
+    u = rnd((M,), 75, 0, 1).to(DEV)
+    emb = torch.full((M, K), float("nan"), device=DEV)
+    heads = torch.full((M, 8), float("nan"), device=DEV)
+    acts = torch.full((M, 2), -1, dtype=torch.int64, device=DEV)           # stride 2
+    cmd = torch.zeros(M, dtype=torch.int64, device=DEV)
+    seq = torch.tensor([41], dtype=torch.int32, device=DEV)
+    ops.heads_fused(xs.data_ptr(), nslab, M * K, K, bias, True, emb, W, b, heads, M, u, A, acts.data_ptr(), 2,
+                    publish=(cmd.data_ptr(), seq, 3))
+    torch.cuda.synchronize()
+    x64 = torch.relu(xs.cpu().double().sum(0) + bias.cpu().double())
+    close("emb", emb, x64, 1e-5, 1e-5)
+    close("heads", heads[:, :A + 1], x64 @ W.cpu().double().t() + b.cpu().double(), 2e-5, 1e-5)
+    want = torch.full((M,), -1, dtype=torch.int64, device=DEV)
+    ops.softmax_sample(heads[:, :A], u, want.data_ptr(), 1, M, A)
+    assert torch.equal(acts[:, 0], want) and (acts[:, 1] == -1).all()
+    assert torch.equal(cmd, (44 << 32) | want)
+    cmd2 = torch.zeros(M, dtype=torch.int64, device=DEV)
+    ops.pool_publish_actions(cmd2.data_ptr(), acts.data_ptr(), 2, M, seq, 3)
+    assert torch.equal(cmd2, cmd)
+    # without publish nothing else is written; publishing needs the sampler
+    cmd.zero_()
+    ops.heads_fused(xs.data_ptr(), nslab, M * K, K, bias, True, None, W, b, heads, M, u, A, acts.data_ptr(), 2)
+    assert (cmd == 0).all()
+    from a2c_amd import _lib
+    with pytest.raises(_lib.A2CKernelError):
+        ops.heads_fused(xs.data_ptr(), nslab, M * K, K, bias, True, None, W, b, heads, M, None, 0, 0, 0,
+                        publish=(cmd.data_ptr(), seq, 3))
+
+
 @pytest.mark.parametrize("M", [7, 32, 65, 100, 256])
 def test_gemm_rollout_batch_forward_against_long_k_contiguous_weights(M, monkeypatch):
     """64 < M <= 256 rows against a big k-contiguous weight matrix (ConvModel's resize_emb at the rollout batch of
@@ -496,7 +533,7 @@ def _sign_words(t):
     return torch.where(words >= 2 ** 31, words - 2 ** 32, words).int().reshape(B, -1).contiguous()
 
 
-SIGN_SPECS = [s for s in CONV_SPECS if s[4] == 3 and s[1] in (84, 42, 21)]
+SIGN_SPECS = [s for s in CONV_SPECS if s[4] == 3 and s[1] in (84, 42, 21, 11)]
 
 
 @pytest.mark.parametrize("spec", SIGN_SPECS, ids=[str(s) for s in SIGN_SPECS])
@@ -518,15 +555,16 @@ def test_conv2d_sign_words(spec, B):
     ops.conv_prep(d, 0, wd, wf)
     ops.conv_prep(d, 1, wd, wb)
     nsw = ops.conv_sign_words(d)
-    assert nsw == Cout * d.OH * ((d.OW + 31) // 32)
+    assert nsw == (Cout * d.OH * ((d.OW + 31) // 32) if H != 11 else 0)      # (the last layer's output feeds no backward-data)
     ref = torch.empty(B, Cout, d.OH, d.OW, device=DEV)
     ops.conv_fwd(d, xd.data_ptr(), Cin * H * W, wf, bd, True, ref, B)
     close("fwd", ref, F.relu(F.conv2d(x, w, bias, stride=s, padding=p)), 2e-6, 1e-5)
-    out = torch.full_like(ref, float("nan"))
-    sg = torch.full((B, nsw + 5), -7, dtype=torch.int32, device=DEV)
-    ops.conv_fwd_signs(d, xd.data_ptr(), Cin * H * W, wf, bd, True, out, sg.data_ptr(), nsw + 5, B)
-    assert torch.equal(out, ref)
-    assert torch.equal(sg[:, :nsw].cpu(), _sign_words(ref.cpu() > 0)) and bool((sg[:, nsw:] == -7).all())
+    if nsw:
+        out = torch.full_like(ref, float("nan"))
+        sg = torch.full((B, nsw + 5), -7, dtype=torch.int32, device=DEV)
+        ops.conv_fwd_signs(d, xd.data_ptr(), Cin * H * W, wf, bd, True, out, sg.data_ptr(), nsw + 5, B)
+        assert torch.equal(out, ref)
+        assert torch.equal(sg[:, :nsw].cpu(), _sign_words(ref.cpu() > 0)) and bool((sg[:, nsw:] == -7).all())
     if not ops.conv_bwd_data_signs_supported(d):
         return
     dout = rnd((B, Cout, d.OH, d.OW), 193).to(DEV)
@@ -537,7 +575,7 @@ def test_conv2d_sign_words(spec, B):
     ops.conv_bwd_data(d, dout, wb, mask.to(DEV), din_f, B)
     ops.conv_bwd_data_signs(d, dout, wb, words, din_s, B)
     # even images: the float-mask and the sign-word kernels are the same streaming family (same summation order): bit for bit.
-    # The odd image (21 <- 11, GRUModel conv4) has a sign-word kernel only; its float-mask twin is conv.hip's generic band
+    # The odd images (21 <- 11, 11 <- 6: GRUModel conv4 / conv5) have a sign-word kernel only; its float-mask twin is conv.hip's generic band
     # kernel, another order of the same sums.
     odd = H % 2 == 1
     if odd:
@@ -1005,7 +1043,7 @@ def test_torch_ops_cover_the_model_and_optimiser_families():
         close(f"adam params step {step}", pd, pr.detach(), 2e-7, 1e-6)
 
 
-@pytest.mark.parametrize("B,signs,strided", [(256, 2, True), (300, 0, False), (65, 1, False)])
+@pytest.mark.parametrize("B,signs,strided", [(256, 2, True), (300, 0, False), (65, 1, False), (130, 3, True)])
 def test_conv_chain_equals_the_per_layer_launches_bit_for_bit(B, signs, strided):
     """a2c_conv2d_fwd_chain (one launch: a workgroup walks one sample through GRUModel's conv2 .. conv5, models.py:570-636)
     against four a2c_conv2d_fwd[_signs] launches: same tiles, same summation order -> every activation and every sign word
@@ -1026,7 +1064,7 @@ def test_conv_chain_equals_the_per_layer_launches_bit_for_bit(B, signs, strided)
         ops.conv_prep(d, 0, w, wf)
         ws.append(w); bs.append(b); wfs.append(wf)
     mult = 3 if strided else 1          # row stride of the output buffers, in samples
-    nsw = [ops.conv_sign_words(d) for d in descs]        # signs = number of leading layers that leave sign words (0, 1 or 2)
+    nsw = [ops.conv_sign_words(d) for d in descs]        # signs = number of leading layers that leave sign words (0 .. 3)
 
     def run(chain):
         outs = [torch.full((B * mult, d.Cout, d.OH, d.OW), float("nan"), device=DEV) for d in descs]

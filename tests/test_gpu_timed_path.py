@@ -192,13 +192,24 @@ def test_sharded_graphed_update_equals_single_process_eager(kind):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    # The two runs differ by the order of the gradient sums only (~1e-8 relative after update 0).  Later updates amplify that:
+    # a pre-activation within fp32 noise of zero flips its ReLU decision in one run and not in the other, the small gradient
+    # elements it feeds change by O(1) of themselves, and RMSprop turns those into parameter steps of a few lr (measured with
+    # tools/dbg/shard_noise.py: GradNorm 1e-5 .. 1e-4 apart at the fourth update for three of four kernel selections, 6e-7 for
+    # the fourth; everything <= 1e-6 before; 1,603 of 1,037,692 parameters further than 4e-6 in the worst of them).  So:
+    # updates 0 and 1 tight, 2 and 3 at 5e-4; parameters within 10 lr, all but half a percent of them within 4e-6.  A stale
+    # buffer or a missed replay input is O(1) in every info.
     for rank, infos, params, n_graphs, n_colls in res:
         assert (n_graphs, n_colls) == (3, 2)
         for u in range(4):
             for k in ref_infos[u]:
-                assert infos[u][k] == pytest.approx(ref_infos[u][k], rel=2e-5, abs=1e-7), (rank, u, k)
+                assert infos[u][k] == pytest.approx(ref_infos[u][k], rel=2e-5 if u < 2 else 5e-4, abs=1e-7), (rank, u, k)
+        n_off = n_all = 0
         for a, b in zip(params, ref_params):
-            np.testing.assert_allclose(a, b, rtol=0, atol=4e-6)
+            np.testing.assert_allclose(a, b, rtol=0, atol=10 * 1e-4)
+            n_off += int((np.abs(a - b) > 4e-6).sum())
+            n_all += a.size
+        assert n_off <= 5e-3 * n_all, (n_off, n_all)
     for a, b in zip(res[0][2], res[1][2]):
         assert np.array_equal(a, b)
 

@@ -884,6 +884,14 @@ int c3b_launch(const C3P& p, hipStream_t st) {
   return A2C_OK;
 }
 
+// per-role phase stamps of workgroup 0 in the staged kernels (a2c_debug_c3_timing): compiled in with
+// -DA2C_C3_STAMPS only -- their registers push the two instances at the register cap into scratch
+#ifdef A2C_C3_STAMPS
+constexpr bool C3_STAMPS = true;
+#else
+constexpr bool C3_STAMPS = false;
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // STAGED variants of the two kernels above: the finished band does not leave through the computing waves.
 //
@@ -900,17 +908,23 @@ int c3b_launch(const C3P& p, hipStream_t st) {
 // The ReLU mask of backward-data arrives as SIGN WORDS (one bit per activation, rows padded to 32-bit words) produced
 // by the forward of the layer below -- by its storers, from the image they copy anyway: 1/32 of the mask's HBM reads,
 // and the LDS the float mask band took is what the output image lives in.
-template <int CS, int CD, int H, int W, int S, int R>
+// DS: TWO output images.  With one, a band is  max(MFMAs, drain of the previous band, loads)  THEN the image write, with the storers
+// idle meanwhile and the computing waves waiting (barrier X) for the drain to finish; conv1's forward is store-path-bound (64 KB per
+// band at 8-10 B/clk = 3.4 us against 1.9 us of MFMAs + 0.9 of image write: measured by switching the phases off one at a time).  With
+// two, the computing waves write band k into image k & 1 straight after its MFMAs while the storers drain image (k - 1) & 1: no X
+// barrier, the storers never idle.
+template <int CS, int CD, int H, int W, int S, int R, bool DS = false>
 struct C3SGeo : C3Geo<CS, CD, H, W, S, R, 0, 2> {          // (two loaders + two storers + eight computing waves: three per SIMD)
   using G0 = C3Geo<CS, CD, H, W, S, R, 0, 2>;
-  static constexpr int NS = 2;                                     // storer waves
+  static constexpr int NS = DS ? 4 : 2;                            // storer waves
   static constexpr int MROWP = ((G0::MROW + 3) / 8) * 8 + 4;        // channel pitch of the image: 4 (mod 8) floats, so the 8
                                                                    // channels of a ds_write_b128 lane group hit 8 distinct slots
   static constexpr int STAGE = CD * MROWP;
   static constexpr int RW = (G0::OW + 31) / 32;                     // sign words per row
   static constexpr int BITC = R * RW;                              // ... per channel band
   static constexpr int BITB = ((CD * BITC + 3) / 4) * 4;
-  static constexpr size_t LDS_BYTES_S = (2 * (size_t)G0::BUF + STAGE + BITB) * 4;
+  static constexpr int SIMG = STAGE + BITB;                        // one output image + its sign words
+  static constexpr size_t LDS_BYTES_S = (2 * (size_t)G0::BUF + (DS ? 2 : 1) * SIMG) * 4;
   static constexpr int NTHR = 64 * (G0::NW + G0::NL + NS);
   static_assert(MROWP >= ((G0::MROW + 3) / 4) * 4, "pitch");
 };
@@ -999,19 +1013,26 @@ __device__ __forceinline__ void c3_drain_signs(const C3Drain d, int nwords, int 
   }
 }
 
-template <int CS, int CD, int H, int W, int S, int R, bool BWD>
-__global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel(C3P p) {
-  using G = C3SGeo<CS, CD, H, W, S, R>;
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, bool DS = false>
+__global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R, DS>::NTHR)) void c3s_kernel(C3P p) {
+  using G = C3SGeo<CS, CD, H, W, S, R, DS>;
   static_assert(!BWD || G::OW % 4 == 0, "backward-data reads a lane's four mask bits from one word");
+  static_assert(!DS || !BWD, "two output images: forward only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const stage = lds + 2 * G::BUF;
-  unsigned* const bitb = reinterpret_cast<unsigned*>(stage + G::STAGE);
+  float* const stage0 = lds + 2 * G::BUF;
+  // the output image (and its sign words) of the workgroup's n-th band
+  auto stage_of = [&](long n) { return stage0 + (DS ? (int)(n & 1) * G::SIMG : 0); };
+  auto bitb_of = [&](long n) { return reinterpret_cast<unsigned*>(stage_of(n) + G::STAGE); };
+  unsigned* const bitb = bitb_of(0);                  // (backward-data: the incoming sign words)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
   const long ntile = (long)p.B * G::NBAND;
   long nmine = 0;
   if ((long)blockIdx.x < ntile) nmine = (ntile - 1 - blockIdx.x) / gridDim.x + 1;
   const long nwork = nmine * G::NCH;              // work item k = (tile k / NCH, chunk k % NCH)
+  // per-role stamps of workgroup 0 (-DA2C_C3_STAMPS builds, a2c_debug_c3_timing, tools/dbg/c3s_stamps.py): [role][band][event]
+  const bool xst = C3_STAMPS && p.dbg != nullptr && blockIdx.x == 0 && lane == 0;
+#define C3S_ST(ROLE, K, E) do { if (xst && (K) < 16) p.dbg[((ROLE) * 16 + (K)) * 4 + (E)] = wall_clock64(); } while (0)
   if (tid < 16) {
     lds[G::IMG - 8 + (tid & 7)] = 0.f;
     lds[G::BUF + G::IMG - 8 + (tid & 7)] = 0.f;
@@ -1031,10 +1052,15 @@ __global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel
     // ------------------------------------------------------------------ storer waves
     const int sw = w - G::NW - G::NL;
     if (!BWD && sw == 0)
-      for (int i = lane; i < G::BITB; i += 64) bitb[i] = 0u;
+      for (int i = lane; i < G::BITB; i += 64) {
+        bitb[i] = 0u;
+        if (DS) bitb_of(1)[i] = 0u;
+      }
     c3_bar();
     const bool signs = !BWD && p.sg_out != nullptr;
-    auto drain = [&](long tile, int part) {
+    auto drain = [&](long tile, int part, long n) {
+      float* const stage = stage_of(n);
+      unsigned* const bitb = bitb_of(n);
       const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
       const int band = (int)(tile - b * G::NBAND);
       const int nrows = min(R, G::OH - band * R), npx = nrows * G::OW;
@@ -1062,16 +1088,23 @@ __global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel
         }
       }
     };
-    long pend = -1;
+    long pend = -1, pend_n = 0;
     for (long k = 0; k < nwork; ++k) {
       const int ch = (int)((unsigned)k % (unsigned)G::NCH);
-      if (pend >= 0) drain(pend, ch);             // the previous band leaves under this band's chunks, a slice per chunk
-      if (ch == G::NCH - 1) c3_bar();      // X
+      if (sw == 0) C3S_ST(1, k, 0);
+      if (pend >= 0) drain(pend, ch, pend_n);     // the previous band leaves under this band's chunks, a slice per chunk
+      if (sw == 0) C3S_ST(1, k, 1);
+      if (!DS && ch == G::NCH - 1) c3_bar();      // X
+      if (sw == 0) C3S_ST(1, k, 2);
       c3_bar();
-      if (ch == G::NCH - 1) pend = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      if (sw == 0) C3S_ST(1, k, 3);
+      if (ch == G::NCH - 1) {
+        pend_n = (long)((unsigned)k / (unsigned)G::NCH);
+        pend = blockIdx.x + pend_n * gridDim.x;
+      }
     }
     if (pend >= 0)
-      for (int part = 0; part < G::NCH; ++part) drain(pend, part);
+      for (int part = 0; part < G::NCH; ++part) drain(pend, part, pend_n);
     return;
   }
   if (w >= G::NW) {
@@ -1124,7 +1157,11 @@ __global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel
           __builtin_amdgcn_global_load_lds((gptr_t)(fg + pi * 4), (lptr_t)(buf + G::IMG + q * 256), 16, 0, 0);
       }
       if constexpr (U8OK) {
-        if (u8) c3_u8_stage<H, W, G::SR, G::WP, G::PLANE, G::NL>(buf, p.u8, b, y0, lw, lane);
+        if (u8) {      // the window's bytes and the env's valid-plane count in ONE round trip (unconditional loads, selected on expand)
+          C3U8Regs<H, W, G::SR, G::NL> rg;
+          c3_u8_load<H, W, G::SR, G::NL>(rg, p.u8, b, y0, lw, lane);
+          c3_u8_expand<H, W, G::SR, G::WP, G::PLANE, G::NL>(buf, rg, lw, lane);
+        }
       }
     };
     // backward-data: the band's mask as sign words, R * RW words per channel (contiguous in HBM)
@@ -1149,11 +1186,15 @@ __global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel
     c3_bar();
     for (long k = 0; k < nwork; ++k) {
       const int ch = (int)((unsigned)k % (unsigned)G::NCH);
+      if (lw == 0) C3S_ST(2, k, 0);
       if (k + 1 < nwork) dma(k + 1);
+      if (lw == 0) C3S_ST(2, k, 1);
       if (msk && ch == 0 && k > 0) dma_signs(blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x);     // (the previous band is done with them)
       __builtin_amdgcn_s_waitcnt(0x0F70);
-      if (ch == G::NCH - 1) c3_bar();       // X
+      if (lw == 0) C3S_ST(2, k, 2);
+      if (!DS && ch == G::NCH - 1) c3_bar();       // X
       c3_bar();
+      if (lw == 0) C3S_ST(2, k, 3);
     }
     return;
   }
@@ -1182,6 +1223,7 @@ __global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel
   for (long k = 0; k < nwork; ++k) {
     const float* __restrict__ img = lds + (k & 1) * G::BUF;
     const float* __restrict__ fr = img + G::IMG + lane;
+    if (w == 0) C3S_ST(0, k, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
@@ -1199,7 +1241,11 @@ __global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel
       }
     }
     if ((int)((unsigned)k % (unsigned)G::NCH) == G::NCH - 1) {
-      c3_bar();                                       // X: the image is free, this band's sign words are in
+      if (w == 0) C3S_ST(0, k, 1);
+      if (!DS) c3_bar();                              // X: the image is free, this band's sign words are in
+      if (w == 0) C3S_ST(0, k, 2);
+      float* const stage = stage_of((long)((unsigned)k / (unsigned)G::NCH));
+      unsigned* const bitb = bitb_of((long)((unsigned)k / (unsigned)G::NCH));
       // ---- accumulators -> the image.  D tile [pixel][channel]: lane (j, g) holds pixels 4g .. 4g+3 of channel j
 #pragma unroll
       for (int u = 0; u < G::TPW; ++u) {
@@ -1229,8 +1275,10 @@ __global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R>::NTHR)) void c3s_kernel
         }
       }
     }
+    if (w == 0) C3S_ST(0, k, 3);
     c3_bar();
   }
+#undef C3S_ST
 }
 
 // ---- stride-2 backward-data, staged.  The chunk images live in a ring of D buffers and the loaders run D - 1 chunks
@@ -1290,13 +1338,6 @@ struct C3BSGeo {
   static_assert(LOOK >= 1 && LOOK <= NCH && (LOOK - 1) * NI0 <= 63, "lookahead: sign words land before X; vmcnt is 6 bits");
 };
 
-// per-role phase stamps of workgroup 0 in the staged stride-2 backward kernel (a2c_debug_c3_timing): compiled in with
-// -DA2C_C3_STAMPS only -- their registers push the two instances at the register cap into scratch
-#ifdef A2C_C3_STAMPS
-constexpr bool C3_STAMPS = true;
-#else
-constexpr bool C3_STAMPS = false;
-#endif
 
 template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES, bool ODD = false, int MS = 1>
 __global__ __launch_bounds__((C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD, MS>::NTHR)) void c3bs_kernel(C3P p) {
@@ -1638,11 +1679,11 @@ int c3bs_launch(const C3P& p, hipStream_t st) {
   return A2C_OK;
 }
 
-template <int CS, int CD, int H, int W, int S, int R, bool BWD>
+template <int CS, int CD, int H, int W, int S, int R, bool BWD, bool DS = false>
 int c3s_launch(const C3P& p, hipStream_t st) {
-  using G = C3SGeo<CS, CD, H, W, S, R>;
+  using G = C3SGeo<CS, CD, H, W, S, R, DS>;
   static_assert(G::LDS_BYTES_S <= 160 * 1024, "LDS");
-  const void* k = (const void*)c3s_kernel<CS, CD, H, W, S, R, BWD>;
+  const void* k = (const void*)c3s_kernel<CS, CD, H, W, S, R, BWD, DS>;
   static int cus = 0;
   if (!cus) {
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES_S) != hipSuccess) return A2C_ERR_LAUNCH;
@@ -1653,7 +1694,7 @@ int c3s_launch(const C3P& p, hipStream_t st) {
   const long total = (long)p.B * G::NBAND;
   if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;      // (the kernels walk chunks with 32-bit arithmetic)
   const int grid = (int)(total < cus ? total : cus);
-  hipLaunchKernelGGL((c3s_kernel<CS, CD, H, W, S, R, BWD>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES_S, st, p);
+  hipLaunchKernelGGL((c3s_kernel<CS, CD, H, W, S, R, BWD, DS>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES_S, st, p);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   return A2C_OK;
 }
@@ -2239,6 +2280,9 @@ int c3_fwd_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long 
   C3P p{nullptr, 0, frag, bias, nullptr, out, out_bs, zero_page(), B, relu, g_c3_dbg, signs, nullptr, signs_bs, C3U8{f, bs, nv, nv_s, T}};
   if (!p.zero) return A2C_ERR_LAUNCH;
   p.prio = c3_prio();
+  // 256 envs: 7-row bands, two output images, four storers (49.0 -> 43.7 us; 6-row bands 45.5, 8-row 44.8); A2C_C3S_DS=0: one image
+  static const bool ds = !(getenv("A2C_C3S_DS") && getenv("A2C_C3S_DS")[0] == '0');
+  if (B > 64 && ds) return c3s_launch<4, 16, 84, 84, 1, 7, false, true>(p, st);      // (32 envs: 224 twelve-row bands are one per CU)
   if (signs != nullptr || B > 64) return c3s_launch<4, 16, 84, 84, 1, 12, false>(p, st);
   return c3_launch<4, 16, 84, 84, 1, 6, false>(p, st);
 }

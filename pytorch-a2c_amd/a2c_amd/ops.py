@@ -498,6 +498,10 @@ def pick_splitk(M, N, K, target_wgs=512, min_k=32):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= target_wgs // 2:
         return 1
+    if tiles <= 4 and K <= 4096 and "A2C_SPLITK_TARGET" not in os.environ:
+        # a handful of tiles over a short K (GRUModel's resize_emb at rollout batch: 256 x 256 x 2304): the slabs the reduce reads
+        # back weigh more than the last workgroups fill -- 64 slabs 15.2 + 5.0 us, 72 (the rule below) 16.2 + 5.7, 32: 17.0 + 5.2
+        target_wgs = min(target_wgs, 256)
     s = max(1, min(target_wgs // tiles, K // min_k))
     return int(s)
 

@@ -116,6 +116,19 @@ int a2c_pool_ingest_bits(const uint64_t *rec, const uint8_t *frames, int64_t fra
                          float *done, uint8_t *frames_out, int64_t out_stride, a2c_stream_t stream);
 int a2c_unpack_bits(const uint8_t *src, int64_t src_stride, uint8_t *dst, int64_t dst_stride, int n,
                     int n_pixels, a2c_stream_t stream);
+/* a2c_pool_ingest / a2c_pool_ingest_bits (packed_bits != 0; frame_elems = uint8 pixels per frame) whose workgroup for env b
+ * also does env b's share of a2c_rollout_post_frames for the env step the answer belongs to (runner.py:208-232: rewards /
+ * dones / the TD residual of the step before, the valid-plane count of the next state, and for recurrent nets the hidden row
+ * of the next step): the same values as the two calls in sequence, one launch.  Arguments after out_stride as in
+ * a2c_rollout_post_frames (val = the value head's output of the state the action was sampled from).            */
+int a2c_pool_ingest_post(int packed_bits, const uint64_t *rec, const uint8_t *frames, int64_t frame_stride,
+                         int frame_elems, int n, const uint32_t *seq_base, uint32_t seq_off,
+                         int64_t timeout_ticks, int *err, float *rew, float *done, uint8_t *frames_out,
+                         int64_t out_stride, const float *val, int64_t val_stride, float *val_prev,
+                         float *rewards, float *dones, float *deltas, int64_t T, int64_t t, int64_t slot0,
+                         float gamma, int pong, float *done_eff, float *h, int hdim, float *h_rows,
+                         int64_t h_rows_stride, const float *h_src, int *nvalid_rows, int *nvalid_carry,
+                         a2c_stream_t stream);
 
 /* ------------------------------------------------------------------ f4: preprocessing on the device, single-frame store
  * a2c_frame_prep_u8 = pong_prep / breakout_prep (preprocessing.py:11-23) on n raw (H, W, C) uint8 frames, raw_stride

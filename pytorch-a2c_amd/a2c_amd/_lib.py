@@ -69,6 +69,9 @@ SIGNATURES = {
     "a2c_pool_ingest": (c_int, [P, P, c_int64, c_int, c_int, P, ctypes.c_uint32, c_int64, P, P, P, P, c_int64, P]),
     "a2c_pool_ingest_bits": (c_int, [P, P, c_int64, c_int, c_int, P, ctypes.c_uint32, c_int64, P, P, P, P, c_int64, P]),
     "a2c_unpack_bits": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P]),
+    "a2c_pool_ingest_post": (c_int, [c_int, P, P, c_int64, c_int, c_int, P, ctypes.c_uint32, c_int64, P, P, P, P, c_int64,
+                                     P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_int, P, P, c_int, P, c_int64, P,
+                                     P, P, P]),
     "a2c_store_u32_system": (c_int, [P, ctypes.c_uint32, P]),
     "a2c_softmax_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int, c_int, P]),
     "a2c_sample_probs": (c_int, [P, P, P, c_int64, c_int, P]),

@@ -298,6 +298,19 @@ def pool_ingest_bits(rec_ptr, frames_ptr, frame_stride, n_pixels, n, seq_base, s
                                      st if st is not None else stream()), "a2c_pool_ingest_bits")
 
 
+def pool_ingest_post(packed_bits, rec_ptr, frames_ptr, frame_stride, frame_elems, n, seq_base, seq_off, timeout_ticks, err, rew,
+                     done, frames_out_ptr, out_stride, val_ptr, val_stride, val_prev, rewards, dones, deltas, T, t, slot0, gamma,
+                     pong, done_eff, h, h_rows_ptr, h_rows_stride, h_src_ptr, nvalid_rows, nvalid_carry_ptr, st=None):
+    """pool_ingest[_bits] + rollout_post_frames of the same env step in one launch (the workgroup that fetched an env's answer
+    does that env's bookkeeping and hidden row)"""
+    check(lib().a2c_pool_ingest_post(int(bool(packed_bits)), rec_ptr, frames_ptr, frame_stride, frame_elems, n, _p(seq_base),
+                                     seq_off, timeout_ticks, _p(err), _p(rew), _p(done), frames_out_ptr, out_stride, val_ptr,
+                                     val_stride, _p(val_prev), _p(rewards), _p(dones), _p(deltas), T, t, slot0, float(gamma),
+                                     int(bool(pong)), _p(done_eff), _p(h), 0 if h is None else h.shape[1], h_rows_ptr,
+                                     h_rows_stride, h_src_ptr, _p(nvalid_rows), nvalid_carry_ptr,
+                                     st if st is not None else stream()), "a2c_pool_ingest_post")
+
+
 def store_u32_system(dev_ptr, value, st=None):
     """one system-scope 4-byte store from the stream (the host pool's phase word)"""
     check(lib().a2c_store_u32_system(dev_ptr, value, st if st is not None else stream()), "a2c_store_u32_system")

@@ -652,6 +652,25 @@ class Runner:
                 os.environ.get("A2C_NO_FUSED_POST") != "1" and ro((stash, slot0 * T, T), B) is not None:
             net._cells_done = T - 1          # every step of every slot went through the cell stash (eagerly or replayed)
 
+    def _post_frames_args(self, k, c, rew, done):
+        """arguments of a2c_rollout_post_frames for env step k - 1 of this segment context (after rew, done; before the stream):
+        where segment k - 1's forward left the values of its states and its new hidden rows -- the roll buffers, or rows of the
+        update's buffers (GRUModel's cell stash) -- a pure function of (net, k), safe under graph replay"""
+        net, slot0, env0, B, T, hyps = c["net"], c["slot0"], c["env0"], c["B"], c["T"], c["hyps"]
+        D, h = self.datas, c["h"]
+        hb, logits, vals = net._heads("roll", B)
+        ro = getattr(net, "_roll_outputs", None)
+        fused_post = h is not None and self.HW % 4 == 0 and self.S % 4 == 0 and os.environ.get("A2C_NO_FUSED_POST") != "1"
+        prev = ro((c["stash"], slot0 * T + k - 1, T), B) if (ro and c["stash"] is not None and k > 0 and fused_post) else None
+        v_ptr, v_ld, h_src = prev if prev else (vals.data_ptr(), vals.stride(0), 0)
+        F_, nv_rows, nv_carry = c["fs"]
+        hrow = 0
+        if h is not None:
+            hrow = D["h_states"].data_ptr() + 4 * (slot0 * T + k) * h.shape[1] if k < T else 0
+        return (v_ptr, v_ld, c["val_prev"], D["rewards"], D["dones"], D["deltas"], T, k - 1, slot0, hyps["gamma"],
+                "Pong" in hyps["env_type"], c["done_eff"], h, hrow, 0 if h is None else T * h.shape[1], h_src, nv_rows,
+                nv_carry.data_ptr() + 4 * env0)
+
     def _segment(self, k, c):
         """device work of segment k (see _rollout_block_segmented); only enqueues, never waits on the host"""
         net, slot0, env0, B, T, hyps = c["net"], c["slot0"], c["env0"], c["B"], c["T"], c["hyps"]
@@ -670,7 +689,13 @@ class Runner:
                 ds = F_.stride(0)
                 dst = F_.data_ptr() + slot0 * ds + (k + 3) * HW
             ticks = int(float(try_key(hyps, "env_timeout_s", 20.0)) * 1e8)
-            if self.dev_prep:        # raw frames cross the link; crop / stride / binarise on the device into dst
+            post = self._post_frames_args(k, c, rew, done) if (c.get("fs") is not None and not self.dev_prep
+                                                               and os.environ.get("A2C_NO_FUSED_POST_INGEST") != "1") else None
+            if post is not None:     # the ingest workgroup of an env also does its bookkeeping (rollout_post_frames) of step k - 1
+                ops.pool_ingest_post(self.bits, pool.dev_rec + 8 * env0, pool.dev_frames + env0 * fs, fs, HW if self.bits else fs, B,
+                                     self._seq_dev, k, ticks, self.rollout_err, rew, done, dst, ds, *post, st)
+                c["_post_done"] = k
+            elif self.dev_prep:      # raw frames cross the link; crop / stride / binarise on the device into dst
                 raw = self.d_raw.data_ptr() + env0 * fs
                 ops.pool_ingest(pool.dev_rec + 8 * env0, pool.dev_frames + env0 * fs, fs, fs, B, self._seq_dev, k,
                                 ticks, self.rollout_err, rew, done, raw, fs, st)
@@ -733,14 +758,12 @@ class Runner:
                 nvr, nvc = nv_rows.data_ptr() + 4 * slot0 * T, nv_carry.data_ptr() + 4 * env0
                 if k == 0:  # state 0 = the window the previous slot ended with (the bookmark, runner.py:190)
                     ops.frame_store_begin(f0, ss, T, C, HW, nvr, nvc, B, st)
+                elif c.get("_post_done") == k:      # ... done by the ingest launch of this segment (a2c_pool_ingest_post)
+                    h_row_done = h is not None
                 else:       # bookkeeping of env step k-1 (runner.py:212-232); the frame is already in the store
-                    hrow = 0
-                    if h is not None:
-                        hrow = D["h_states"].data_ptr() + 4 * (slot0 * T + k) * h.shape[1] if k < T else 0
-                        h_row_done = True
-                    ops.rollout_post_frames(rew, done, v_ptr, v_ld, val_prev, rewards, dones, deltas, T, k - 1, slot0, gamma,
-                                            pong, B, done_eff, h, hrow, 0 if h is None else T * h.shape[1], h_src, nv_rows, nvc,
-                                            st)
+                    pa = self._post_frames_args(k, c, rew, done)
+                    ops.rollout_post_frames(rew, done, *pa[:11], B, *pa[11:], st)
+                    h_row_done = h is not None
                 if k == T:  # the bookmark state stays materialised: any other rollout path can take over from here
                     ops.frames_to_states(f0 + T * HW, ss, nvc, 1, bm.data_ptr(), S, B, 1, C, HW, st)
                     net._frames_src = (f0 + T * HW, ss, 1, nvc, 1)

@@ -266,12 +266,25 @@ __global__ void store_u32_system_kernel(unsigned int* p, unsigned int v) {
   if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <bool BITS>
+// POST: the workgroup that fetched env b's answer also does env b's share of a2c_rollout_post_frames (the bookkeeping of the
+// env step the answer belongs to and, for recurrent nets, the hidden row of the next step): one launch fewer per env step,
+// same arithmetic (post_kernel's z == C / C + 1 layers).
+struct IngestPost {
+  const float* val; long vstride;
+  float* val_prev; float* rewards; float* dones; float* deltas;
+  long T, t, slot0;
+  float gamma; int pong;
+  float* done_eff; float* h; int hdim; float* h_rows; long h_rows_stride; const float* h_src;
+  int* nv_rows; int* nv_carry;
+};
+
+template <bool BITS, bool POST = false>
 __global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long long* __restrict__ rec,
                                                           const uint8_t* __restrict__ frames, long fstride, int fbytes,
                                                           const unsigned int* __restrict__ seq_base, unsigned int seq_off,
                                                           long timeout_ticks, int* __restrict__ err, float* __restrict__ rew,
-                                                          float* __restrict__ done, uint8_t* __restrict__ out, long ostride) {
+                                                          float* __restrict__ done, uint8_t* __restrict__ out, long ostride,
+                                                          IngestPost q = IngestPost{}) {
   __shared__ unsigned int sh[3];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {
@@ -300,6 +313,36 @@ __global__ __launch_bounds__(256) void pool_ingest_kernel(const unsigned long lo
   if (tid == 0) {
     rew[b] = __uint_as_float(lo);
     done[b] = (hi & 1u) ? 1.f : 0.f;
+  }
+  if (POST) {
+    const float r = __uint_as_float(lo);
+    const bool reset = (hi & 1u) != 0u;
+    if (tid == 64) {                                    // (a wave of its own: tid 0's wave starts the frame loads)
+      const long e = (q.slot0 + b) * q.T + q.t;
+      float d = reset ? 1.f : 0.f;
+      if (q.pong && r != 0.f) d = 1.f;
+      q.rewards[e] = r;
+      q.dones[e] = d;
+      if (q.done_eff) q.done_eff[b] = d;
+      const float v = q.val[b * q.vstride];
+      if (q.t > 0) {
+        const float pr = q.rewards[e - 1], pd = q.dones[e - 1];
+        const float gv = q.gamma * v;
+        q.deltas[e - 1] = (pr + gv * (1.f - pd)) - q.val_prev[b];
+      }
+      const int nv = reset ? 1 : min(q.nv_carry[b] + 1, 4);
+      q.nv_carry[b] = nv;
+      if (q.t + 1 < q.T) q.nv_rows[e + 1] = nv;
+      q.val_prev[b] = v;
+    }
+    if (q.h != nullptr) {
+      const bool d = reset || (q.pong && r != 0.f);
+      for (int i = tid; i < q.hdim; i += 256) {
+        const float v = d ? 0.f : q.h_src[(long)b * q.hdim + i];
+        if (d || q.h_src != q.h) q.h[(long)b * q.hdim + i] = v;
+        if (q.h_rows) q.h_rows[(long)b * q.h_rows_stride + i] = v;
+      }
+    }
   }
   // the frame was written before its rec granule (release): 16-byte system-scope loads straight from pinned host memory
   __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(frames + (long)b * fstride), 0, fbytes, 0x00020000);
@@ -568,9 +611,9 @@ int a2c_pool_ingest(const uint64_t* rec, const uint8_t* frames, int64_t frame_st
       out_stride < frame_bytes || timeout_ticks < 1 || ((uintptr_t)frames % 16) || ((uintptr_t)frames_out % 16))
     return A2C_ERR_ARG;
   if (n == 0) return A2C_OK;
-  hipLaunchKernelGGL(pool_ingest_kernel<false>, dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
+  hipLaunchKernelGGL((pool_ingest_kernel<false, false>), dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
                      (long)frame_stride, frame_bytes, seq_base, seq_off, (long)timeout_ticks, err, rew, done, frames_out,
-                     (long)out_stride);
+                     (long)out_stride, IngestPost{});
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }
@@ -583,9 +626,37 @@ int a2c_pool_ingest_bits(const uint64_t* rec, const uint8_t* frames, int64_t fra
       out_stride < n_pixels || timeout_ticks < 1 || ((uintptr_t)frames % 16) || ((uintptr_t)frames_out % 16))
     return A2C_ERR_ARG;
   if (n == 0) return A2C_OK;
-  hipLaunchKernelGGL(pool_ingest_kernel<true>, dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
+  hipLaunchKernelGGL((pool_ingest_kernel<true, false>), dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
                      (long)frame_stride, n_pixels / 8, seq_base, seq_off, (long)timeout_ticks, err, rew, done, frames_out,
-                     (long)out_stride);
+                     (long)out_stride, IngestPost{});
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_pool_ingest_post(int packed_bits, const uint64_t* rec, const uint8_t* frames, int64_t frame_stride, int frame_elems, int n,
+                         const uint32_t* seq_base, uint32_t seq_off, int64_t timeout_ticks, int* err, float* rew, float* done,
+                         uint8_t* frames_out, int64_t out_stride, const float* val, int64_t val_stride, float* val_prev,
+                         float* rewards, float* dones, float* deltas, int64_t T, int64_t t, int64_t slot0, float gamma, int pong,
+                         float* done_eff, float* h, int hdim, float* h_rows, int64_t h_rows_stride, const float* h_src,
+                         int* nvalid_rows, int* nvalid_carry, a2c_stream_t stream) {
+  if (n < 0 || !rec || !frames || !seq_base || !err || !rew || !done || !frames_out) return A2C_ERR_ARG;
+  if (T < 1 || t < 0 || t >= T || !val || !val_prev || !rewards || !dones || !deltas || !nvalid_rows || !nvalid_carry) return A2C_ERR_ARG;
+  if (h && hdim < 1) return A2C_ERR_ARG;
+  if (frame_stride % 16 || out_stride % 16 || out_stride < frame_elems || timeout_ticks < 1 || ((uintptr_t)frames % 16) ||
+      ((uintptr_t)frames_out % 16) || frame_elems < 16 || frame_elems % 16)
+    return A2C_ERR_ARG;
+  if (packed_bits ? frame_stride * 8 < frame_elems : frame_stride < frame_elems) return A2C_ERR_ARG;
+  if (n == 0) return A2C_OK;
+  const IngestPost q{val, (long)val_stride, val_prev, rewards, dones, deltas, (long)T, (long)t, (long)slot0, gamma, pong,
+                     done_eff, h, hdim, h_rows, (long)h_rows_stride, h_src ? h_src : h, nvalid_rows, nvalid_carry};
+  if (packed_bits)
+    hipLaunchKernelGGL((pool_ingest_kernel<true, true>), dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
+                       (long)frame_stride, frame_elems / 8, seq_base, seq_off, (long)timeout_ticks, err, rew, done, frames_out,
+                       (long)out_stride, q);
+  else
+    hipLaunchKernelGGL((pool_ingest_kernel<false, true>), dim3(n), dim3(256), 0, a2c_s(stream), (const unsigned long long*)rec, frames,
+                       (long)frame_stride, frame_elems, seq_base, seq_off, (long)timeout_ticks, err, rew, done, frames_out,
+                       (long)out_stride, q);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

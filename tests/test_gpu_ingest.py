@@ -463,3 +463,71 @@ def test_device_side_polls_across_the_2_31_step_counter_wrap(ingest, no_ring, mo
         assert pool.seq == s0 + 3 * T
     finally:
         r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,recurrent,t", [(True, True, 3), (True, False, 0), (False, True, 7)])
+def test_ingest_with_post_equals_ingest_then_post(bits, recurrent, t):
+    """a2c_pool_ingest_post (the workgroup that fetched env b's answer also does env b's bookkeeping of the env step it belongs to,
+    runner.py:208-232, and the hidden row of the next step, runner.py:201,219-221) against a2c_pool_ingest[_bits] followed by
+    a2c_rollout_post_frames: every output bit for bit (same arithmetic, one launch instead of two)."""
+    from a2c_amd import ops
+    B, T, HW, hd, slot0, seq0, k = 37, 8, 7056, 256, 2, 1000, 5
+    g = torch.Generator().manual_seed(77 + t)
+    rew = torch.where(torch.rand(B, generator=g) < 0.3, torch.randn(B, generator=g), torch.zeros(B))
+    dn = (torch.rand(B, generator=g) < 0.3)
+    rec = (((seq0 + k) & 0x7fffffff) << 33) | (dn.long() << 32) | rew.view(torch.int32).long().bitwise_and(0xffffffff)
+    fbytes = HW // 8 if bits else HW
+    fs = (fbytes + 15) // 16 * 16                              # slots of the pinned region are 16-byte multiples
+    frames = torch.randint(0, 256, (B, fs), dtype=torch.uint8, generator=g)
+    vals = torch.randn(B, 3, generator=g)                       # the value head's output is column 1 of a wider row
+    h_src = torch.randn(B, hd, generator=g)
+
+    def run(fused):
+        d = lambda x: x.clone().to(DEV)
+        recd, frd, seq = d(rec), d(frames), torch.tensor([seq0], dtype=torch.int32, device=DEV)
+        err = torch.zeros(1, dtype=torch.int32, device=DEV)
+        r_o, d_o = torch.full((B,), -9.0, device=DEV), torch.full((B,), -9.0, device=DEV)
+        out = torch.zeros(B, HW + 16, dtype=torch.uint8, device=DEV)
+        gen = torch.Generator().manual_seed(5)
+        val_prev, rewards, dones, deltas = (d(torch.randn(n, generator=gen)) for n in (B, (slot0 + B) * T, (slot0 + B) * T, (slot0 + B) * T))
+        done_eff = torch.full((B,), -9.0, device=DEV)
+        h = d(h_src) if recurrent else None
+        hs = d(torch.randn(B, hd, generator=gen)) if recurrent else None        # where the previous step left its hidden rows
+        h_rows = torch.full((B, T, hd), -9.0, device=DEV) if recurrent else None
+        nv_rows = torch.full(((slot0 + B) * T,), -9, dtype=torch.int32, device=DEV)
+        nv_carry = d(torch.randint(1, 5, (B,), dtype=torch.int32, generator=gen))
+        post = (vals.to(DEV).data_ptr() + 4, 3, val_prev, rewards, dones, deltas, T, t, slot0, 0.99, True, done_eff, h,
+                h_rows.data_ptr() + 4 * (t + 1) * hd if (recurrent and t + 1 < T) else 0, T * hd, hs.data_ptr() if recurrent else 0, nv_rows,
+                nv_carry.data_ptr())
+        v_keep = vals.to(DEV)
+        post = (v_keep.data_ptr() + 4,) + post[1:]
+        if fused:
+            ops.pool_ingest_post(bits, recd.data_ptr(), frd.data_ptr(), fs, HW if bits else fbytes, B, seq, k, 10 ** 8, err,
+                                 r_o, d_o, out.data_ptr(), HW + 16, *post)
+        else:
+            if bits:
+                ops.pool_ingest_bits(recd.data_ptr(), frd.data_ptr(), fs, HW, B, seq, k, 10 ** 8, err, r_o, d_o, out.data_ptr(), HW + 16)
+            else:
+                ops.pool_ingest(recd.data_ptr(), frd.data_ptr(), fs, fbytes, B, seq, k, 10 ** 8, err, r_o, d_o, out.data_ptr(), HW + 16)
+            ops.rollout_post_frames(r_o, d_o, *post[:11], B, *post[11:])
+        torch.cuda.synchronize()
+        assert int(err) == 0
+        res = dict(rew=r_o, done=d_o, out=out, val_prev=val_prev, rewards=rewards, dones=dones, deltas=deltas, done_eff=done_eff,
+                   nv_rows=nv_rows, nv_carry=nv_carry)
+        if recurrent:
+            res.update(h=h, h_rows=h_rows)
+        return {kk: vv.cpu() for kk, vv in res.items()}
+
+    a, b = run(True), run(False)
+    for kk in a:
+        assert torch.equal(a[kk].view(torch.uint8) if a[kk].dtype != torch.uint8 else a[kk],
+                           b[kk].view(torch.uint8) if b[kk].dtype != torch.uint8 else b[kk]), kk
+    assert torch.equal(a["rew"], rew) and torch.equal(a["done"], dn.float())
+    e = (slot0 + torch.arange(B)) * T + t
+    d_eff = torch.where(rew != 0, torch.ones(B), dn.float())          # Pong: a point ends the episode for the bookkeeping
+    assert torch.equal(a["dones"][e], d_eff) and torch.equal(a["rewards"][e], rew) and torch.equal(a["done_eff"], d_eff)
+    if recurrent:
+        assert bool((a["h"][d_eff != 0] == 0).all())
+        if t + 1 < T:       # (the last step of a slot has no next row)
+            assert bool((a["h_rows"][:, t + 1][d_eff != 0] == 0).all()) and torch.equal(a["h_rows"][:, t + 1], a["h"])

@@ -212,14 +212,37 @@ __attribute__((target("avx2"))) static unsigned pack_bits_avx2(const uint8_t *sr
 }
 #endif
 
-/* n uint8 pixels (each 0 / 1) -> ceil(n/8) bytes, pixel p = bit p%8 of byte p/8; returns the OR of all pixels */
+#ifdef A2C_HAVE_SSE2
+/* 64 pixels per step: vptestmb gives the 64 packed bits at once (Zen 4/5, Sapphire Rapids: full-rate AVX-512) */
+__attribute__((target("avx512f,avx512bw"))) static unsigned pack_bits_avx512(const uint8_t *src, uint8_t *dst, size_t n, size_t *done) {
+  __m512i acc = _mm512_setzero_si512();
+  const __m512i one = _mm512_set1_epi8(1);
+  size_t p = 0;
+  for (; p + 64 <= n; p += 64) {
+    const __m512i x = _mm512_loadu_si512((const void *)(src + p));
+    acc = _mm512_or_si512(acc, x);
+    const uint64_t m = (uint64_t)_mm512_test_epi8_mask(x, one);
+    memcpy(dst + (p >> 3), &m, 8);
+  }
+  *done = p;
+  return _mm512_test_epi8_mask(acc, _mm512_set1_epi8((char)0xfe)) ? 2u : (_mm512_test_epi8_mask(acc, one) ? 1u : 0u);
+}
+#endif
+
+/* n uint8 pixels (each 0 / 1) -> ceil(n/8) bytes, pixel p = bit p%8 of byte p/8; returns the OR of all pixels (anything above 1
+ * means "not a binary frame"; the wide paths report 2 for that) */
 static unsigned pack_bits(const uint8_t *src, uint8_t *dst, size_t n) {
   size_t p = 0;
   unsigned any = 0;
 #ifdef A2C_HAVE_SSE2
-  static int have_avx2 = -1;
-  if (have_avx2 < 0) have_avx2 = __builtin_cpu_supports("avx2") ? 1 : 0;
-  if (have_avx2) any = pack_bits_avx2(src, dst, n, &p);
+  static int have_avx2 = -1, have_avx512 = -1;
+  if (have_avx2 < 0) {
+    have_avx2 = __builtin_cpu_supports("avx2") ? 1 : 0;
+    const char *no512 = getenv("A2C_NO_AVX512");
+    have_avx512 = (__builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f") && !(no512 && no512[0] == '1')) ? 1 : 0;
+  }
+  if (have_avx512) any = pack_bits_avx512(src, dst, n, &p);
+  else if (have_avx2) any = pack_bits_avx2(src, dst, n, &p);
 #endif
 #ifdef A2C_HAVE_SSE2
   __m128i acc = _mm_setzero_si128();
@@ -345,7 +368,7 @@ static inline void wc_fence(void) {
 }
 /* the mirror in device memory: the frame (whole 16-byte pieces: the slots are 16-byte multiples), fence, the granule, fence */
 static void push_answer(const worker_arg *w, const a2c_pool_header *h, int env, const void *frame, uint32_t seq, float rew,
-                        int done) {
+                        int done, int lazy) {
   if (!w->push_rec) return;
   uint8_t *dst = w->push_frames + (size_t)env * h->frame_stride;
   const size_t nb = ((size_t)h->frame_bytes + 15u) & ~(size_t)15u;
@@ -358,7 +381,19 @@ static void push_answer(const worker_arg *w, const a2c_pool_header *h, int env, 
   uint32_t rb;
   memcpy(&rb, &rew, 4);
   __atomic_store_n(w->push_rec + env, ((uint64_t)((seq << 1) | (done ? 1u : 0u)) << 32) | rb, __ATOMIC_RELEASE);
-  wc_fence();
+  if (!lazy) wc_fence();     /* lazy: the caller has more answers to write -- the next one's fence (or its own, when it runs out of
+                              * work) pushes this granule out; the kernel waits for the LAST env of the step either way */
+}
+
+/* the native tape env (below): the worker warms the frame the NEXT env of its block is about to return -- an emulator has the
+ * frame it draws in its cache, a tape frame last touched `n envs` steps ago sits in L3 / DRAM (one thread serving 256 envs:
+ * 1.8 MB of frames between two visits).  A2C_TAPE_WARM=0 switches it off (A/B runs). */
+static const a2c_env_vtable tape_vtable;
+static void tape_warm(void *env);
+static int tape_warm_on(void) {
+  static int on = -1;
+  if (on < 0) { const char *v = getenv("A2C_TAPE_WARM"); on = !(v && v[0] == '0'); }
+  return on;
 }
 
 static void *worker_main(void *p) {
@@ -381,17 +416,27 @@ static void *worker_main(void *p) {
     if (bits && pack_bits(obs0, (uint8_t *)slot0, h->frame_elems) > 1u) bad = 1;
     if (bits) write_tagged(w->base, w->env0 + i, (const uint8_t *)slot0, h->seq_start, 0.f, 1);
     next_seq[i] = h->seq_start;
-    push_answer(w, h, w->env0 + i, slot0, h->seq_start, 0.f, 1);
+    push_answer(w, h, w->env0 + i, slot0, h->seq_start, 0.f, 1, 0);
     publish_inplace(w->base, w->env0 + i, h->seq_start, 0.f, 1);
   }
   if (bad) a2c_pool_worker_failed(w->base, w->env0);
   a2c_pool_worker_ready(w->base);
+  const int warm = w->vt == &tape_vtable && tape_warm_on();
   const char *rr_env = getenv("A2C_POLL_RR");
   const int rr = !(rr_env && rr_env[0] == '0');
   int start = 0;
+  const char *lf_env = getenv("A2C_PUSH_LAZY_FENCE");
+  const int lazy = w->push_rec != NULL && !(lf_env && lf_env[0] == '0');
+  int wc_dirty = 0;
   for (;;) {
     int32_t action = 0;
-    const int i = pool_poll_from(w->base, w->env0, w->n, next_seq, 200000000LL, rr ? start : 0);
+    int i = -1;
+    if (wc_dirty) {       /* one look at the env that is due next: if its action is not there yet, push the pending granule out */
+      const int nx = (rr && start < w->n) ? start : 0;
+      if ((uint32_t)(__atomic_load_n(cmd_of(w->base) + w->env0 + nx, __ATOMIC_ACQUIRE) >> 32) == next_seq[nx]) i = nx;
+      else { wc_fence(); wc_dirty = 0; }
+    }
+    if (i < 0) i = pool_poll_from(w->base, w->env0, w->n, next_seq, 200000000LL, rr ? start : 0);
     if (i == -2) break;
     if (i < 0) continue;
     action = a2c_pool_action(w->base, w->env0 + i);
@@ -416,8 +461,10 @@ static void *worker_main(void *p) {
     }
     next_seq[i] += 1;
     if (bits) write_tagged(w->base, j, (const uint8_t *)pinned, next_seq[i], rew, reset);
-    push_answer(w, h, j, pinned, next_seq[i], rew, reset);        /* the device's copy first: it is the one a kernel waits for */
+    push_answer(w, h, j, pinned, next_seq[i], rew, reset, lazy);  /* the device's copy first: it is the one a kernel waits for */
+    wc_dirty = lazy;
     publish_inplace(w->base, j, next_seq[i], rew, reset);
+    if (warm) tape_warm(w->envs[w->env0 + (i + 1 < w->n ? i + 1 : 0)]);
   }
   free(next_seq);
   free(ep_rew);
@@ -534,6 +581,12 @@ static void tape_step(void *env, int32_t action, void *frame_out, float *rew, in
     const uint8_t *nx = e->frames + (size_t)((e->t + 1) % e->length) * e->frame_bytes;
     for (int q = 0; q < e->frame_bytes; q += 64) __builtin_prefetch(nx + q, 0, 3);
   }
+}
+
+static void tape_warm(void *env) {
+  tape_env *e = (tape_env *)env;
+  const uint8_t *nx = e->frames + (size_t)((e->t + 1) % e->length) * e->frame_bytes;
+  for (int q = 0; q < e->frame_bytes; q += 64) __builtin_prefetch(nx + q, 0, 3);
 }
 
 static const a2c_env_vtable tape_vtable = {tape_reset, tape_step, tape_peek};

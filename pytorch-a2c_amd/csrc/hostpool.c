@@ -367,9 +367,7 @@ static inline void wc_fence(void) {
 #endif
 }
 /* the mirror in device memory: the frame (whole 16-byte pieces: the slots are 16-byte multiples), fence, the granule, fence */
-static void push_answer(const worker_arg *w, const a2c_pool_header *h, int env, const void *frame, uint32_t seq, float rew,
-                        int done, int lazy) {
-  if (!w->push_rec) return;
+static void push_frame(const worker_arg *w, const a2c_pool_header *h, int env, const void *frame) {
   uint8_t *dst = w->push_frames + (size_t)env * h->frame_stride;
   const size_t nb = ((size_t)h->frame_bytes + 15u) & ~(size_t)15u;
 #ifdef A2C_HAVE_SSE2
@@ -377,10 +375,18 @@ static void push_answer(const worker_arg *w, const a2c_pool_header *h, int env, 
 #else
   memcpy(dst, frame, nb);
 #endif
-  wc_fence();
+}
+static void push_rec(const worker_arg *w, int env, uint32_t seq, float rew, int done) {
   uint32_t rb;
   memcpy(&rb, &rew, 4);
   __atomic_store_n(w->push_rec + env, ((uint64_t)((seq << 1) | (done ? 1u : 0u)) << 32) | rb, __ATOMIC_RELEASE);
+}
+static void push_answer(const worker_arg *w, const a2c_pool_header *h, int env, const void *frame, uint32_t seq, float rew,
+                        int done, int lazy) {
+  if (!w->push_rec) return;
+  push_frame(w, h, env, frame);
+  wc_fence();
+  push_rec(w, env, seq, rew, done);
   if (!lazy) wc_fence();     /* lazy: the caller has more answers to write -- the next one's fence (or its own, when it runs out of
                               * work) pushes this granule out; the kernel waits for the LAST env of the step either way */
 }
@@ -428,13 +434,31 @@ static void *worker_main(void *p) {
   const char *lf_env = getenv("A2C_PUSH_LAZY_FENCE");
   const int lazy = w->push_rec != NULL && !(lf_env && lf_env[0] == '0');
   int wc_dirty = 0;
+  /* A thread that serves many envs (one thread per rank on a small host: 256 envs) is throughput-bound and the kernel waits for
+   * its LAST answer: the frames of up to FB answers share ONE fence, their granules follow it.  A thread with few envs (the
+   * headline: 17) answers one at a time -- its kernel proceeds env by env.  A2C_PUSH_BATCH overrides (1 = never batch). */
+  enum { FBMAX = 8 };
+  const char *fb_env = getenv("A2C_PUSH_BATCH");
+  int FB = fb_env ? atoi(fb_env) : (w->n >= 32 ? 4 : 1);
+  if (FB < 1 || !lazy) FB = 1;
+  if (FB > FBMAX) FB = FBMAX;
+  struct { int env; uint32_t seq; float rew; int done; } pend[FBMAX];
+  int npend = 0;
   for (;;) {
     int32_t action = 0;
     int i = -1;
-    if (wc_dirty) {       /* one look at the env that is due next: if its action is not there yet, push the pending granule out */
+    if (wc_dirty || npend) {   /* one look at the env that is due next: if its action is not there yet, push what is pending out */
       const int nx = (rr && start < w->n) ? start : 0;
       if ((uint32_t)(__atomic_load_n(cmd_of(w->base) + w->env0 + nx, __ATOMIC_ACQUIRE) >> 32) == next_seq[nx]) i = nx;
-      else { wc_fence(); wc_dirty = 0; }
+      else {
+        wc_fence();
+        if (npend) {
+          for (int q = 0; q < npend; ++q) push_rec(w, pend[q].env, pend[q].seq, pend[q].rew, pend[q].done);
+          npend = 0;
+          wc_fence();
+        }
+        wc_dirty = 0;
+      }
     }
     if (i < 0) i = pool_poll_from(w->base, w->env0, w->n, next_seq, 200000000LL, rr ? start : 0);
     if (i == -2) break;
@@ -461,8 +485,19 @@ static void *worker_main(void *p) {
     }
     next_seq[i] += 1;
     if (bits) write_tagged(w->base, j, (const uint8_t *)pinned, next_seq[i], rew, reset);
-    push_answer(w, h, j, pinned, next_seq[i], rew, reset, lazy);  /* the device's copy first: it is the one a kernel waits for */
-    wc_dirty = lazy;
+    if (FB > 1) {                /* the device's copy first: it is the one a kernel waits for */
+      push_frame(w, h, j, pinned);
+      pend[npend].env = j; pend[npend].seq = next_seq[i]; pend[npend].rew = rew; pend[npend].done = reset;
+      if (++npend == FB) {
+        wc_fence();
+        for (int q = 0; q < npend; ++q) push_rec(w, pend[q].env, pend[q].seq, pend[q].rew, pend[q].done);
+        npend = 0;
+        wc_dirty = 1;
+      }
+    } else {
+      push_answer(w, h, j, pinned, next_seq[i], rew, reset, lazy);
+      wc_dirty = lazy;
+    }
     publish_inplace(w->base, j, next_seq[i], rew, reset);
     if (warm) tape_warm(w->envs[w->env0 + (i + 1 < w->n ? i + 1 : 0)]);
   }

@@ -431,8 +431,10 @@ static void *worker_main(void *p) {
   const char *rr_env = getenv("A2C_POLL_RR");
   const int rr = !(rr_env && rr_env[0] == '0');
   int start = 0;
+  /* (threads with few envs -- the headline: 17 -- push every granule out at once: their kernel proceeds env by env, and a granule
+   * that waits for the next answer's fence cost the ring step 1.5 %; A2C_PUSH_LAZY_FENCE=1 / 0 forces either) */
   const char *lf_env = getenv("A2C_PUSH_LAZY_FENCE");
-  const int lazy = w->push_rec != NULL && !(lf_env && lf_env[0] == '0');
+  const int lazy = w->push_rec != NULL && (lf_env ? lf_env[0] != '0' : w->n >= 32);
   int wc_dirty = 0;
   /* A thread that serves many envs (one thread per rank on a small host: 256 envs) is throughput-bound and the kernel waits for
    * its LAST answer: the frames of up to FB answers share ONE fence, their granules follow it.  A thread with few envs (the

@@ -145,11 +145,12 @@ a2c_pool_threads *a2c_pool_threads_start(void *base, int n_threads, const a2c_en
                                          void *const *envs, int action_shift, int pong);
 /* the same, and every answer is ALSO written to a second place the caller names (a2c_push_buffer_alloc: device memory
  * mapped into this process): frame j at push_frames + j * frame_stride (the pool's stride), then -- behind an sfence,
- * the mapping is write-combining -- its rec granule at push_rec[j].  The granule is pushed out by the NEXT answer's
- * fence, or by a fence of the worker's own as soon as it finds no action waiting (A2C_PUSH_LAZY_FENCE=0: a second
- * fence behind every granule); a thread that serves 32 envs or more writes the frames of up to four answers before
- * one fence and their granules behind it (A2C_PUSH_BATCH=1: one at a time).  A frame is never visible after its
- * granule.  NULL pointers = no mirror. */
+ * the mapping is write-combining -- its rec granule at push_rec[j] and a second sfence.  A thread that serves 32 envs
+ * or more (throughput-bound: the kernel waits for its LAST answer) drops the second fence -- the granule is pushed out
+ * by the next answer's fence, or by a fence of the worker's own as soon as it finds no action waiting
+ * (A2C_PUSH_LAZY_FENCE=0 / 1 forces either) -- and writes the frames of up to four answers before one fence, their
+ * granules behind it (A2C_PUSH_BATCH=1: one at a time).  A frame is never visible after its granule.
+ * NULL pointers = no mirror. */
 a2c_pool_threads *a2c_pool_threads_start_push(void *base, int n_threads, const a2c_env_vtable *vt,
                                               void *const *envs, int action_shift, int pong,
                                               void *push_rec, void *push_frames);

@@ -100,3 +100,18 @@ def test_gloo_world2_sharded_statistics_and_gradient_allreduce():
         assert mean == pytest.approx(float(full.double().mean()), rel=1e-12)
         assert std == pytest.approx(float(full.double().std()), rel=1e-12)     # unbiased, like Tensor.std
         assert g0 == 3.0 and gs == 3000.0                                       # sum over ranks: 1 + 2
+
+
+def test_split_count_rule_for_few_tile_products(monkeypatch):
+    """ops.pick_splitk: products of a handful of 128 x 128 tiles over a short K (GRUModel's resize_emb at rollout batch) get
+    at most 256 / tiles slabs -- the reduce reads every slab back; big products keep the 512-workgroup target; the
+    environment override wins; products that fill the chip are not split."""
+    from a2c_amd import ops
+    monkeypatch.delenv("A2C_SPLITK_TARGET", raising=False)
+    monkeypatch.delenv("A2C_SPLITK_MIN_K", raising=False)
+    assert ops.pick_splitk(256, 256, 2304) == 64                 # 4 tiles: 256 / 4
+    assert ops.pick_splitk(32, 2000, 28224) == 32                # 16 tiles, long K: 512 / 16 (the 226 MB weight stream)
+    assert ops.pick_splitk(256, 256, 8192) == 128                # K > 4096: the general rule
+    assert ops.pick_splitk(32768, 2000, 28224) == 1
+    monkeypatch.setenv("A2C_SPLITK_TARGET", "512")
+    assert ops.pick_splitk(256, 256, 2304) == 72                 # min(512 / 4, 2304 / 32)

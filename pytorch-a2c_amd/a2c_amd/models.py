@@ -430,35 +430,37 @@ class A3CModel(_HipNet):
                     ops.gemm(1, 0, h, F, A, Wpi.data_ptr(), h, S.data_ptr(), F, dWp.data_ptr(), F, st=st)
                     ops.gemm(1, 0, h, 1, A, Wpi.data_ptr(), h, dbh.data_ptr(), 1, G("proj_matrx.bias").data_ptr(), 1, st=st)
 
-        if rank_bwd:
-            # da2 needs only dl and the composed matrix: the conv backward (2.5 of the update's 2.9 ms, four big launches)
-            # starts at once; the head / projection gradients run as a parallel branch beside it (ops.side_branch)
-            with ops.side_branch(0):
-                head_grads(ops.stream())
-            with ops.span("rank_bwd da2"):
-                ops.gemm(0, 0, B, F, A, dl.data_ptr(), dl.stride(0), self._Wc.data_ptr(), F, da2.data_ptr(), F,
-                         mask_ptr=a2.data_ptr(), ldmask=F, st=st)
-        else:
-            head_grads(st)
-            demb = ws.get("demb", (B, h))
-            linear_bwd_data(ws, db, P("pi.weight"), demb, B, st, n_cols=A)        # value head is detached
-            linear_bwd_weight(ws, demb, a2.data_ptr(), F, G("proj_matrx.weight"), G("proj_matrx.bias"), B, st)
-            linear_bwd_data(ws, demb, Wp, da2.view(B, -1), B, st, mask=a2)
-        self._c2.bwd_weight(a1.data_ptr(), a1[0].numel(), da2, G("convs.1.0.weight"), G("convs.1.0.bias"), B, ws, st)
-        da1 = ws.get("da1", (B,) + self._c1.out_shape)
-        self._c2.bwd_data(da2, a1, da1, B, st)
-        fr = getattr(self, "_bwd_frames", None)
-        if fr is not None:      # stack-on-load from the single-frame uint8 store: 28 KB instead of 113 KB per sample
-            fstore, nvalid, T = fr
-            buf = ws.bytes("conv_wgrad_ws", ops.conv_bwd_weight_ws_bytes(self._c1.d, B))
-            with ops.span("conv1.bwd_weight"):
-                ops.conv_bwd_weight_frames(self._c1.d, fstore, fstore.stride(0), T, nvalid, da1, G("convs.0.0.weight"),
-                                           G("convs.0.0.bias"), B, buf, st)
-        else:
-            if tag == "train":
-                self._need_states()
-            self._c1.bwd_weight(x_ptr, bstride, da1, G("convs.0.0.weight"), G("convs.0.0.bias"), B, ws, st)
-        ops.join_branches()
+        try:
+            if rank_bwd:
+                # da2 needs only dl and the composed matrix: the conv backward (2.5 of the update's 2.9 ms, four big launches)
+                # starts at once; the head / projection gradients run as a parallel branch beside it (ops.side_branch)
+                with ops.side_branch(0):
+                    head_grads(ops.stream())
+                with ops.span("rank_bwd da2"):
+                    ops.gemm(0, 0, B, F, A, dl.data_ptr(), dl.stride(0), self._Wc.data_ptr(), F, da2.data_ptr(), F,
+                             mask_ptr=a2.data_ptr(), ldmask=F, st=st)
+            else:
+                head_grads(st)
+                demb = ws.get("demb", (B, h))
+                linear_bwd_data(ws, db, P("pi.weight"), demb, B, st, n_cols=A)        # value head is detached
+                linear_bwd_weight(ws, demb, a2.data_ptr(), F, G("proj_matrx.weight"), G("proj_matrx.bias"), B, st)
+                linear_bwd_data(ws, demb, Wp, da2.view(B, -1), B, st, mask=a2)
+            self._c2.bwd_weight(a1.data_ptr(), a1[0].numel(), da2, G("convs.1.0.weight"), G("convs.1.0.bias"), B, ws, st)
+            da1 = ws.get("da1", (B,) + self._c1.out_shape)
+            self._c2.bwd_data(da2, a1, da1, B, st)
+            fr = getattr(self, "_bwd_frames", None)
+            if fr is not None:      # stack-on-load from the single-frame uint8 store: 28 KB instead of 113 KB per sample
+                fstore, nvalid, T = fr
+                buf = ws.bytes("conv_wgrad_ws", ops.conv_bwd_weight_ws_bytes(self._c1.d, B))
+                with ops.span("conv1.bwd_weight"):
+                    ops.conv_bwd_weight_frames(self._c1.d, fstore, fstore.stride(0), T, nvalid, da1, G("convs.0.0.weight"),
+                                               G("convs.0.0.bias"), B, buf, st)
+            else:
+                if tag == "train":
+                    self._need_states()
+                self._c1.bwd_weight(x_ptr, bstride, da1, G("convs.0.0.weight"), G("convs.0.0.bias"), B, ws, st)
+        finally:
+            ops.join_branches()       # also on an exception: no branch stays open (or unjoined inside a capture)
 
 
 def h_is_lockstep(stash, B, R, T):
@@ -531,14 +533,18 @@ class _ConvStackNet(_HipNet):
                     optrs = [bufs[k].data_ptr() + 4 * row0 * ns[k - 1] for k in range(1, nl)]
                     obss = [rstride * v for v in ns]
                     sg = {k - 1: (self._sign_bufs[k].data_ptr() + 4 * row0 * sl[k], rstride * sl[k]) for k in csl}
-                with ops.span("conv2-5.fwd_chain"):
-                    chain.fwd(ptr, bs, [c.wf for c in self._cl[1:]], [self.P(f"convs.{k}.0.bias") for k in range(1, nl)], optrs,
-                              obss, B, st, signs=sg or None)
-                for k in csl:
-                    self._signs_ok[k] = (self._signs_ok.get(k, True) if (stash is not None and stash[1]) else True)
-                for k in range(1, nl):
-                    acts.append((optrs[k - 1], obss[k - 1]))
-                return acts
+                # a2c_conv2d_fwd_chain wants 16-byte pointers and strides that are multiples of 4 floats (stash rows
+                # bufs[k] + 4*row0*n are 16-byte aligned only when n % 4 == 0); the per-layer launches below take anything
+                if ptr % 16 == 0 and bs % 4 == 0 and all(q % 16 == 0 for q in optrs) and all(o % 4 == 0 for o in obss):
+                    with ops.span("conv2-5.fwd_chain"):
+                        chain.fwd(ptr, bs, [c.wf for c in self._cl[1:]], [self.P(f"convs.{k}.0.bias") for k in range(1, nl)],
+                                  optrs, obss, B, st, signs=sg or None)
+                    for k in csl:
+                        self._signs_ok[k] = (self._signs_ok.get(k, True) if (stash is not None and stash[1]) else True)
+                    for k in range(1, nl):
+                        acts.append((optrs[k - 1], obss[k - 1]))
+                    return acts
+                chain = None
             if stash is None:
                 a = ws.get(f"a{i}", (B,) + l.out_shape)
                 sg = None
@@ -823,7 +829,7 @@ class _GruMixin:
         gx, gh, z, r, rh, rhu, c, hn = (bufs[k] for k in ("gx", "gh", "z", "r", "rh", "rhu", "c", "hn"))
         cat = getattr(self, "_WxC", None) is not None and os.environ.get("A2C_NO_GRU_CAT") != "1"
         if (cat and x is not None and B <= 1280 and hd % 32 == 0 and xs % 8 == 0 and x.stride(0) % 4 == 0
-                and os.environ.get("A2C_NO_GRU_FUSE") != "1"):
+                and x.data_ptr() % 16 == 0 and h_in.data_ptr() % 16 == 0 and os.environ.get("A2C_NO_GRU_FUSE") != "1"):
             # a step at rollout batch: the five launches below (5-6 us each, launch-bound) as two, bit-identical
             with ops.span("gru.cell_fwd"):
                 ops.gru_cell_fwd(x, h_in, self._WxC, self._WhC, Wh[2], b, gx, z, r, rh, c, hn, st)

@@ -102,8 +102,17 @@ def span(name):
 
 
 # ---------------------------------------------------------------- side branches (launch-latency-bound chains next to big kernels)
+import threading as _threading
+
 _SIDE_STREAMS = {}
-_BRANCHES = []
+_TLS = _threading.local()       # open branches per THREAD: a Runner thread's _prep must not join (and clear) the updater's branch
+
+
+def _open_branches():
+    b = getattr(_TLS, "branches", None)
+    if b is None:
+        b = _TLS.branches = []
+    return b
 
 
 class side_branch:
@@ -132,7 +141,7 @@ class side_branch:
         s.wait_stream(main)
         self.ctx = torch.cuda.stream(s)
         self.ctx.__enter__()
-        _BRANCHES.append(s)
+        _open_branches().append(s)
         return self
 
     def __exit__(self, *exc):
@@ -143,13 +152,17 @@ class side_branch:
 
 
 def join_branches():
-    """the current stream waits for every branch opened since the last join"""
-    if _BRANCHES:
+    """the current stream waits for every branch THIS THREAD opened since its last join (call it in a ``finally``: a branch
+    left open by an exception would otherwise stay an unjoined stream of a capture)"""
+    br = _open_branches()
+    if br:
         main = torch.cuda.current_stream()
-        for s in _BRANCHES:
-            if s != main:
-                main.wait_stream(s)
-        _BRANCHES.clear()
+        try:
+            for s in br:
+                if s != main:
+                    main.wait_stream(s)
+        finally:
+            br.clear()
 
 
 class graph_capture:

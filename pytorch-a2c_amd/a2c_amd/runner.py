@@ -26,6 +26,7 @@ Env pools (``env_pool=``):
 """
 import os
 import queue
+import warnings
 import time
 from collections import deque
 
@@ -252,17 +253,25 @@ class Runner:
                 stop = False
                 # The rest of the epoch's tokens: wait for them (a partial batch would be played with a different
                 # slot -> env mapping, which defeats the activation stash and captures a second set of slot graphs) --
-                # but never forever: after hyps["gate_timeout_s"] without a further token (default 30 s; 0.05 s when the
+                # but never forever: after hyps["gate_timeout_s"] without a further token (default 5 s; 0.05 s when the
                 # caller did not say how many slots an epoch has, i.e. no "n_rollouts" key) whatever arrived is played,
                 # so a caller that trickles fewer tokens, or two Runners sharing one gate_q, make progress and their
                 # stop_q consumers wake up.
                 gate_to = try_key(self.hyps, "gate_timeout_s", None)
                 if gate_to is None:
-                    gate_to = 30.0 if try_key(self.hyps, "n_rollouts", None) else 0.05
+                    gate_to = 5.0 if try_key(self.hyps, "n_rollouts", None) else 0.05
                 while len(idxs) < n_tok:
                     try:
                         tok = self.gate_q.get(timeout=gate_to)
                     except queue.Empty:
+                        # ONE Runner per gate_q is what performs: Runners sharing a gate_q (the reference's topology) each
+                        # take part of the epoch's tokens, stall here once per epoch and play partial batches (which also
+                        # re-capture slot graphs and defeat the activation stash).  Say so instead of stalling silently.
+                        if not getattr(self, "_warned_partial", False):
+                            self._warned_partial = True
+                            warnings.warn("a2c_amd.Runner: %d of %d gate tokens after %.2f s -- playing a partial batch; use ONE "
+                                          "Runner per gate_q (or set hyps['gate_timeout_s'])" % (len(idxs), n_tok, gate_to),
+                                          RuntimeWarning)
                         break
                     if tok is None:
                         stop = True

@@ -8,6 +8,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <vector>
 
 extern "C" {
 int a2c_pinned_register(void* host, size_t bytes, void** dev_out) {
@@ -78,19 +79,36 @@ int a2c_push_buffer_alloc(size_t bytes, void** ptr_out) {
   // hipExtMallocWithFlags succeeds without a large BAR too; the env worker threads would then fault on their first
   // _mm_stream store.  Guarded probe: the KERNEL stores a pattern through the pointer (read() from a pipe = copy_to_user:
   // EFAULT, not SIGSEGV, when the address is not mapped into this process) and the device must read that pattern back.
+  // One word per 4 KB page AND the last word of the buffer: a partially mapped BAR would otherwise only show up as a fault in
+  // a worker thread pushing the rec / frame rows of a high env index.
   bool ok = false;
   int pfd[2];
-  if (pipe(pfd) == 0) {
+  if (bytes >= sizeof(unsigned long long) && pipe(pfd) == 0) {
     const unsigned long long pat = 0xA2C0BA5EC0FFEE01ull;
-    unsigned long long back = 0;
-    if (write(pfd[1], &pat, sizeof pat) == (ssize_t)sizeof pat && read(pfd[0], d, sizeof pat) == (ssize_t)sizeof pat &&
-        hipMemcpy(&back, d, sizeof back, hipMemcpyDeviceToHost) == hipSuccess && back == pat)
-      ok = true;
+    const size_t W = sizeof pat;
+    std::vector<size_t> offs;
+    for (size_t off = 0; off + W <= bytes; off += 4096) offs.push_back(off);
+    const size_t last = (bytes - W) & ~(size_t)7;
+    if (offs.back() != last) offs.push_back(last);
+    ok = true;
+    for (size_t off : offs) {
+      const unsigned long long v = pat ^ (unsigned long long)off;
+      if (write(pfd[1], &v, W) != (ssize_t)W || read(pfd[0], (char*)d + off, W) != (ssize_t)W) { ok = false; break; }
+    }
+    if (ok) {
+      std::vector<char> back(bytes);
+      ok = hipMemcpy(back.data(), d, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+      for (size_t i = 0; ok && i < offs.size(); ++i) {
+        unsigned long long v;
+        memcpy(&v, back.data() + offs[i], W);
+        ok = v == (pat ^ (unsigned long long)offs[i]);
+      }
+    }
     close(pfd[0]);
     close(pfd[1]);
   }
   (void)hipGetLastError();
-  if (!ok || hipMemset(d, 0, sizeof(unsigned long long)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+  if (!ok || hipMemset(d, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     (void)hipGetLastError();
     (void)hipFree(d);
     return A2C_ERR_LAUNCH;         // not host-writable: the caller keeps the pinned host region (ThreadEnvPool: push_ptr = 0)

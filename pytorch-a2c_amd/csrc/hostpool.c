@@ -235,14 +235,20 @@ static unsigned pack_bits(const uint8_t *src, uint8_t *dst, size_t n) {
   size_t p = 0;
   unsigned any = 0;
 #ifdef A2C_HAVE_SSE2
-  static int have_avx2 = -1, have_avx512 = -1;
-  if (have_avx2 < 0) {
-    have_avx2 = __builtin_cpu_supports("avx2") ? 1 : 0;
+  /* ONE state word, computed into a local and published last: every worker thread packs its reset frame at start-up, and a
+   * thread that sees a half-written pair of flags must not take the AVX-512 path on a host without it.  0 = not probed yet,
+   * else 4 | (avx512 << 1) | avx2; racing threads compute the same value. */
+  static int isa_state = 0;
+  int isa = __atomic_load_n(&isa_state, __ATOMIC_ACQUIRE);
+  if (isa == 0) {
     const char *no512 = getenv("A2C_NO_AVX512");
-    have_avx512 = (__builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f") && !(no512 && no512[0] == '1')) ? 1 : 0;
+    const int a2 = __builtin_cpu_supports("avx2") ? 1 : 0;
+    const int a512 = (__builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f") && !(no512 && no512[0] == '1')) ? 1 : 0;
+    isa = 4 | (a512 << 1) | a2;
+    __atomic_store_n(&isa_state, isa, __ATOMIC_RELEASE);
   }
-  if (have_avx512) any = pack_bits_avx512(src, dst, n, &p);
-  else if (have_avx2) any = pack_bits_avx2(src, dst, n, &p);
+  if ((isa & 2) != 0) any = pack_bits_avx512(src, dst, n, &p);
+  else if ((isa & 1) != 0) any = pack_bits_avx2(src, dst, n, &p);
 #endif
 #ifdef A2C_HAVE_SSE2
   __m128i acc = _mm_setzero_si128();

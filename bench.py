@@ -94,17 +94,21 @@ class SyntheticDevicePool:
         return self.frames[t, sl], self.rew[t, sl], self.done[t, sl], self.done[t, sl]
 
 
-def make_host_pool(n_envs, T, kind, n_workers, seed, transport="bits"):
+def make_host_pool(n_envs, T, kind, n_workers, seed, transport="bits", grey=False):
     """host env workers stepping synthetic.TapeEnv tapes (binary uint8 frames, like pong_prep's) behind the pinned
-    region; transport "bits": the workers pack every frame to one bit per pixel on its way into the pinned slot"""
+    region; transport "bits": the workers pack every frame to one bit per pixel on its way into the pinned slot.
+    ``grey``: Breakout-like tapes (grey levels 0..255, what breakout_prep hands on: preprocessing.py:19-23) -- uint8
+    transport only (the packed one refuses them), real dones only (no Pong done-on-reward override, runner.py:213-214)"""
     from a2c_amd.hostpool import ProcessEnvPool, ThreadEnvPool
     from a2c_amd.synthetic import TapeEnv
     L = min(T + 1, 33)          # tape length per env: content does not affect cost, keeps host memory small
-    kws = [dict(env_id=seed * 100000 + j, length=L) for j in range(n_envs)]
+    kws = [dict(env_id=seed * 100000 + j, length=L, grey=grey) for j in range(n_envs)]
     bits = transport == "bits"
+    if grey and bits:
+        raise ValueError("grey-level frames need the uint8 transport")
     if kind == "native":
-        return ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=n_workers, pong=True, frame_bits=bits)
-    return ProcessEnvPool(TapeEnv, n_envs, env_kwargs=kws, n_workers=n_workers, pong=True, frame_shape=(1, 84, 84),
+        return ThreadEnvPool.from_tape_envs([TapeEnv(**k) for k in kws], n_threads=n_workers, pong=not grey, frame_bits=bits)
+    return ProcessEnvPool(TapeEnv, n_envs, env_kwargs=kws, n_workers=n_workers, pong=not grey, frame_shape=(1, 84, 84),
                           frame_dtype=np.uint8, frame_bits=bits)
 
 
@@ -142,7 +146,7 @@ def compact_line(full, side_file=None):
     if rf:
         line["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale",
                                                "traffic_source", "alg_flops_per_launch", "alg_bytes_per_launch", "avg_launch_us",
-                                               "launches_per_rollout", "hbm_GBs", "pipes", "frac_of_pipe_time") if k in rf}
+                                               "launches_per_rollout", "hbm_GBs", "pipes", "frac_fp32_equiv", "frac_of_pipe_time") if k in rf}
     cb = full.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "cpu_model", "kind", "rollout_steps_per_s",
@@ -165,6 +169,10 @@ def compact_line(full, side_file=None):
             ms[short] = [v.get("rollout_ms"), v.get("update_ms")]
     if ms:
         line["configs_rollout_update_ms"] = ms
+    cbs = full.get("cpu_baselines") or {}
+    cbv = {short: (cbs.get(key) or {}).get("value") for key, short in _CFG_SHORT if (cbs.get(key) or {}).get("value")}
+    if cbv:
+        line["cpu_baseline_values"] = cbv          # env-steps/s of the oracle port on this box's cores, per config
     for key in ("value_device_tape", "value_states_rows_written", "host_pinned_u8_transport", "host_pinned_process_workers",
                 "value_one_env_thread"):
         v = full.get(key)
@@ -173,6 +181,9 @@ def compact_line(full, side_file=None):
     for k in ("host_us_per_env_step", "rccl_ranks", "dist_backend", "allreduce_ms_per_update", "allreduce_bytes"):
         if full.get(k) is not None:
             line[k] = full[k]
+    p8 = full.get("predicted_8rank_weak")
+    if isinstance(p8, dict) and p8.get("value") is not None:
+        line["predicted_8rank_weak"] = p8["value"]       # 8 x the one-env-thread leg: a prediction, not a measurement
     if rf and rf.get("frac") is not None:
         line["roofline_frac"] = rf["frac"]
     if (cb or {}).get("value") and full.get("value"):
@@ -243,7 +254,7 @@ def _cpu_rollout_worker(args):
     return done_slots * T, time.perf_counter() - t0
 
 
-def cpu_baseline(model, n_envs, T, use_bptt, A, optim):
+def cpu_baseline(model, n_envs, T, use_bptt, A, optim, roll_s=5.0, budget=12.0):
     """Oracle timed like the reference runs on the host cores this container may use: rollout =
     min(n_envs, cores) processes x batch-1 forwards, 1 torch thread each (no scale-up); update = one process,
     all cores, on as large a batch as ~12 s allow (full N when it fits).  env-steps/sec of one epoch of the
@@ -256,7 +267,7 @@ def cpu_baseline(model, n_envs, T, use_bptt, A, optim):
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(workers) as pool:
-        res = pool.map(_cpu_rollout_worker, [(model, T, A, 5.0)] * workers)
+        res = pool.map(_cpu_rollout_worker, [(model, T, A, roll_s)] * workers)
     roll_rate = sum(r[0] / r[1] for r in res)          # aggregate env-steps/s of `workers` processes, measured
     torch.set_num_threads(cores)
     net = O.OracleNet(model, SS, A, 256)
@@ -279,7 +290,6 @@ def cpu_baseline(model, n_envs, T, use_bptt, A, optim):
 
     n_small, dt_small = time_update(4 if model != "ConvModel" else 1)
     n_small, dt_small = time_update(4 if model != "ConvModel" else 1)          # second call: warm
-    budget = 12.0
     R_big = int(max(1, min(n_envs, budget / max(dt_small / n_small, 1e-9) / T)))
     N_upd, dt_upd = time_update(R_big)
     upd_rate = N_upd / dt_upd
@@ -292,13 +302,14 @@ def cpu_baseline(model, n_envs, T, use_bptt, A, optim):
     return dict(value=round(value, 1), unit="env-steps/s", cores=cores, kind="port",
                 rollout_steps_per_s=round(roll_rate, 1), update_samples_per_s=round(upd_rate, 1),
                 rollout_processes=workers, update_batch=N_upd, extrapolated=bool(N_upd < N_full), cpu_model=cpu_model,
-                sample=f"oracle port: rollout {workers} procs x batch-1 fwd 5 s each (measured aggregate); update_model "
+                sample=f"oracle port: rollout {workers} procs x batch-1 fwd {roll_s:g} s each (measured aggregate); update_model "
                        f"N={N_upd}/{N_full}, {cores} torch threads; value=1/(1/r+1/u); wall {time.perf_counter() - t0:.0f}s")
 
 
 # ---------------------------------------------------------------- roofline helpers
-def conv_alg_bytes(d, B):
-    return 4.0 * B * (d.Cin * d.H * d.W + d.Cout * d.OH * d.OW)
+def conv_alg_bytes(d, B, in_bytes_per_sample=None):
+    """input + output bytes of one pass over B samples (fp32 both sides unless the input side is given)"""
+    return B * ((4.0 * d.Cin * d.H * d.W if in_bytes_per_sample is None else float(in_bytes_per_sample)) + 4.0 * d.Cout * d.OH * d.OW)
 
 
 def conv_flops(d, B):
@@ -399,7 +410,7 @@ class Bench:
     """net + rollout buffers + env pool + Runner + Updater of one workload; ``step()`` = rollout + update."""
 
     def __init__(self, workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, update_graph=True,
-                 transport="bits", frame_store=False):
+                 transport="bits", frame_store=False, grey=False):
         import a2c_amd
         from a2c_amd.runner import Runner
         from a2c_amd.updater import Updater
@@ -408,6 +419,10 @@ class Bench:
         if workload == "conv" and self.n_envs >= 256:
             self.T = 128                               # configs[4]: n_tsteps=128
         self.hyps = hyps_for(self.model, self.n_envs, self.T, self.use_bptt, optim)
+        self.grey = grey
+        if grey:            # configs[4] is BreakoutNoFrameskip-v4: 4 actions, grey-level frames, no Pong done override
+            self.A = 4
+            self.hyps["env_type"] = "Breakout-synthetic"
         if frame_store:     # single-frame uint8 store, first conv layer stacked on load, fp32 states on demand
             self.hyps.update(frame_store=True, lazy_states=True)
         self.frame_store = frame_store
@@ -429,7 +444,8 @@ class Bench:
             self.runner = Runner(D, self.hyps, None, None, None, env_pool=pool,
                                  uniform_fn=lambda t, B, e0: pool.uniforms[t, e0:e0 + B])
         else:
-            self.pool = pool = make_host_pool(self.n_envs, self.T, env_workers, n_workers, seed=shard.rank, transport=transport)
+            self.pool = pool = make_host_pool(self.n_envs, self.T, env_workers, n_workers, seed=shard.rank, transport=transport,
+                                              grey=grey)
             self.runner = Runner(D, self.hyps, None, None, None, env_pool=pool,
                                  ingest="memcpy" if ingest == "memcpy" else None)
         self.updater = Updater(net, self.hyps, shard=shard)
@@ -608,8 +624,13 @@ class Bench:
             pass
 
 
-def site_roofline(name, site, conv_layers, batch, launches_note=""):
-    """roofline entry of one conv launch site: algorithmic in+out bytes and flops / its average HIP-event duration"""
+def site_roofline(name, site, conv_layers, batch, u8_store=False, bf16_pipe=False):
+    """roofline entry of one launch site: algorithmic bytes and flops / its average HIP-event duration, each priced on what
+    the site really reads and really issues.  ``u8_store``: the first layer reads the single-frame uint8 store (one 7,056-byte
+    frame per sample: every frame is a plane of four consecutive states) instead of the 4 x 84 x 84 fp32 row.  ``bf16_pipe``:
+    conv1's weight gradient of A3CModel runs on the bf16 matrix pipe as three exact bf16 pieces per fp32 value
+    (`wgrad_stream_bf16_kernel`): its matrix time is 3 x flops at the bf16 peak, not flops at the fp32 peak -- priced the
+    fp32 way a fast launch "exceeds" the peak (round 5's side report printed 1.20), which is not a roofline."""
     lname, _, what = name.partition(".")
     out = dict(site=name, avg_ms=round(site["avg_ms"], 4), launches=site["launches"])
     if lname == "linear":            # "linear.<pass> NxK": a dense fp32 GEMM over `batch` rows
@@ -625,25 +646,59 @@ def site_roofline(name, site, conv_layers, batch, launches_note=""):
     if lname in conv_layers:
         d = conv_layers[lname].d
         sec = site["avg_ms"] * 1e-3
-        tf = conv_flops(d, batch) / sec / 1e12
-        gbs = conv_alg_bytes(d, batch) / sec / 1e9
-        out.update(batch=batch, tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / F32_PEAK_TFLOPS, 4),
-                   hbm_GBs=round(gbs, 1), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4),
-                   alg_bytes=conv_alg_bytes(d, batch), alg_flops=conv_flops(d, batch))
+        fl = conv_flops(d, batch)
+        from_store = u8_store and lname == "conv1" and what.split(" ")[0] in ("fwd", "bwd_weight")
+        by = conv_alg_bytes(d, batch, in_bytes_per_sample=d.H * d.W if from_store else None)
+        tf, gbs = fl / sec / 1e12, by / sec / 1e9
+        out.update(batch=batch, tflops=round(tf, 2), hbm_GBs=round(gbs, 1), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4),
+                   alg_bytes=by, alg_flops=fl)
+        if from_store:
+            out["input"] = "uint8 single-frame store: 7,056 B per sample"
+        if bf16_pipe and lname == "conv1" and what.split(" ")[0] == "bwd_weight":
+            t_pk = 3.0 * fl / (BF16_PEAK_TFLOPS * 1e12)
+            out.update(pipe="bf16 MFMA x3 (exact split, fp32 accumulate)", tflops_fp32_equiv=round(tf, 2),
+                       frac_of_pipe_peak=round(t_pk / sec, 4))
+        else:
+            out.update(pipe="fp32 MFMA", frac_of_f32_mfma_peak=round(tf / F32_PEAK_TFLOPS, 4), frac_of_pipe_peak=round(tf / F32_PEAK_TFLOPS, 4))
     return out
 
 
+def ring_roofline(A, n_envs, T, launches, us, bf16_conv1):
+    """`roofline` of the persistent A3CModel rollout launch, per pipe.  One launch = (T + 1) steps x n_envs / launches envs of
+    4.64 MFLOP each (step_alg_flops).  With conv1 on the bf16 pipe (three exact bf16 pieces per fp32 weight, uint8 pixels
+    exact in bf16) 71 % of those algorithmic fp32 flops are ISSUED as 3 x as many flops on a pipe 16 x as fast, so the peak
+    the launch is held against is the rate at which THIS instruction mix would run with every MFMA at its own pipe's peak:
+        peak = alg_flops / (3 * conv1_flops / bf16_peak + (alg_flops - conv1_flops) / fp32_peak)
+    frac = achieved / peak = matrix time at each instruction's own peak / launch duration  (<= 1 by construction).
+    `frac_fp32_equiv` = achieved / the fp32 MFMA peak: rounds 1-5's definition, kept for comparison only -- it is not a
+    roofline fraction once part of the work runs on the bf16 pipe."""
+    fl = step_alg_flops(A) * n_envs * (T + 1) / launches
+    tf = fl / (us * 1e-6) / 1e12
+    c1 = 2 * 16 * 400 * 256
+    if bf16_conv1:
+        t_step = 3.0 * c1 / (BF16_PEAK_TFLOPS * 1e12) + (step_alg_flops(A) - c1) / (F32_PEAK_TFLOPS * 1e12)
+        peak = step_alg_flops(A) / t_step / 1e12
+        pipes = "conv1: bf16 MFMA x3 (exact split, fp32 accumulate) @ %.1f TF; conv2/heads: fp32 MFMA @ %.1f TF" % (BF16_PEAK_TFLOPS, F32_PEAK_TFLOPS)
+    else:
+        peak, pipes = F32_PEAK_TFLOPS, "fp32 MFMA"
+    return dict(bound="mfma", achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
+                frac_fp32_equiv=round(tf / F32_PEAK_TFLOPS, 4), pipes=pipes, avg_launch_us=round(us, 2),
+                launches_per_rollout=launches, alg_flops_per_launch=fl)
+
+
 def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, steps, warmup, transport="bits",
-               frame_store=False):
+               frame_store=False, grey=False):
     """one extra BASELINE config: ms per step, env-steps/s, its dominant update and rollout launch sites"""
-    b = Bench(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, transport=transport, frame_store=frame_store)
+    b = Bench(workload, n_envs, optim, ingest, env_workers, n_workers, shard, dev, transport=transport, frame_store=frame_store,
+              grey=grey)
     try:
         b.step()
         b.capture()
         for _ in range(max(warmup - 1, 0)):
             b.step()
         elapsed, r_ms, u_ms = b.timed(steps)
-        out = dict(workload=f"{b.model} n_envs={b.n_envs} n_tsteps={b.T}{' +BPTT' if b.use_bptt else ''}", steps=steps,
+        out = dict(workload=f"{b.model} n_envs={b.n_envs} n_tsteps={b.T}{' +BPTT' if b.use_bptt else ''}"
+                            f"{' Breakout-like grey frames, 4 actions' if grey else ''}", steps=steps, transport=transport,
                    ms_per_step=round(1e3 * elapsed / steps, 3), value=round(b.N * steps / elapsed, 1), unit="env-steps/s",
                    rollout_ms=round(r_ms, 3), update_ms=round(u_ms, 3), ingest=b.describe_ingest(),
                    update="hipGraph" if b.ugraph is not None else "eager")
@@ -654,16 +709,21 @@ def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, d
         layers = getattr(b.net, "_cl", None) or ([b.net._c1, b.net._c2] if hasattr(b.net, "_c1") else [])
         conv = {l.name: l for l in layers}
         summ = b.site_timers(1)
+        # what the first layer reads / which pipe its weight gradient runs on (site_roofline prices each site on that)
+        st_live = bool(frame_store and getattr(b.runner, "_fstore", None) is not None and getattr(b.runner, "_fstore_ok", True))
+        bf_w = st_live and b.model == "A3CModel" and os.environ.get("A2C_WGRAD_F32") != "1"
         if summ:
             dom = max(summ, key=lambda k: summ[k]["total_ms"])
-            out["dominant_update_site"] = site_roofline(dom, summ[dom], conv, b.N)
-            out["update_conv_sites"] = {k: site_roofline(k, v, conv, b.N) for k, v in summ.items() if k.split(".")[0] in conv}
+            out["dominant_update_site"] = site_roofline(dom, summ[dom], conv, b.N, st_live, bf_w)
+            out["update_conv_sites"] = {k: site_roofline(k, v, conv, b.N, st_live, bf_w) for k, v in summ.items()
+                                        if k.split(".")[0] in conv}
         rs = b.rollout_site_timers()
         if rs:
             # the rollout's forwards run at batch n_envs, T+1 times per slot (north star: HBM GB/s on the conv forward)
             dom = max(rs, key=lambda k: rs[k]["total_ms"])
-            out["dominant_rollout_site"] = site_roofline(dom, rs[dom], conv, b.n_envs)
-            out["rollout_conv_fwd_sites"] = {k: site_roofline(k, v, conv, b.n_envs) for k, v in rs.items() if k.endswith(".fwd") and k.split(".")[0] in conv}
+            out["dominant_rollout_site"] = site_roofline(dom, rs[dom], conv, b.n_envs, st_live)
+            out["rollout_conv_fwd_sites"] = {k: site_roofline(k, v, conv, b.n_envs, st_live) for k, v in rs.items()
+                                             if k.endswith(".fwd") and k.split(".")[0] in conv}
             out["rollout_sites_total_ms"] = round(sum(v["total_ms"] for v in rs.values()), 3)
         if b.ingest != "device-tape" and r_ms > 0:
             out["h2d_GBs"] = round(b.N * FRAME_BYTES[transport] / (r_ms * 1e-3) / 1e9, 2)
@@ -708,6 +768,9 @@ def main():
     ap.add_argument("--transport", default="bits", choices=["bits", "u8"],
                     help="what crosses the host link per frame: bits = 1 bit/pixel (the synthetic frames are binary like "
                          "pong_prep's, preprocessing.py:15-16), u8 = one byte per pixel (any uint8 preprocessor)")
+    ap.add_argument("--grey", action="store_true",
+                    help="Breakout-like tapes: grey levels 0..255, 4 actions, real dones only; implies --transport u8 "
+                         "(configs[4]; the per-GPU shard leg of the default run sets it itself)")
     ap.add_argument("--env-workers", default="native", choices=["native", "process"])
     ap.add_argument("--n-workers", type=int, default=None, help="env worker threads/processes per rank")
     ap.add_argument("--sustain-steps", type=int, default=200,
@@ -723,6 +786,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
+    if args.grey:
+        args.transport = "u8"
 
     # the ONE JSON line goes to the real stdout; whatever else prints on the way (the model classes mirror the
     # reference's "Flat Features Size" print) goes to stderr
@@ -770,7 +835,7 @@ def main():
     # (Runner.materialize_states; not needed by rollout -> update -> rollout).  --no-frame-store writes the rows.
     fs_main = args.frame_store or (args.ingest == "host-pinned" and not args.no_frame_store)
     b = Bench(args.workload, n_envs, args.optim, args.ingest, args.env_workers, n_workers, shard, dev,
-              update_graph=not args.no_update_graph, transport=args.transport, frame_store=fs_main)
+              update_graph=not args.no_update_graph, transport=args.transport, frame_store=fs_main, grey=args.grey)
     model, T, A, N = b.model, b.T, b.A, b.N
     b.step()
     b.capture()
@@ -884,26 +949,16 @@ def main():
             name = ("%s (a2c_a3c_rollout: 1 launch = %d steps x %d envs, host-paced)"
                     % ("a3c_ring_kernel" if ring else "a3c_step_kernel<persistent>", T + 1, b.n_envs // launches)) if zero_copy else \
                    f"a3c_step_kernel (B={b.n_envs}, {T + 1} launches/rollout)"
-            out["roofline"] = dict(kernel=name, bound="mfma", achieved=round(tf, 2), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
-                                   frac=round(tf / F32_PEAK_TFLOPS, 4), traffic=None, avg_launch_us=round(us, 2),
-                                   launches_per_rollout=launches, hbm_GBs=round(by / (us * 1e-6) / 1e9, 1),
-                                   hbm_frac=round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                   alg_flops_per_launch=fl, alg_bytes_per_launch=by)
-            if ring and os.environ.get("A2C_RING_F32") != "1":
-                # conv1 (3.28 of the step's 4.64 MFLOP) runs on the BF16 matrix pipe as three exact bf16 pieces per fp32 weight
-                # (uint8 pixels are exact in bf16; fp32 accumulation: DESIGN 4): `frac` stays algorithmic fp32 flops over the
-                # fp32 MFMA peak (the contract's definition); `frac_of_pipe_time` prices the instructions actually issued --
-                # 3 x conv1 flops at the bf16 peak + the rest at the fp32 peak -- against the launch duration
-                c1 = 2 * 16 * 400 * 256
-                t_pk = (3.0 * c1 / (BF16_PEAK_TFLOPS * 1e12) + (step_alg_flops(A) - c1) / (F32_PEAK_TFLOPS * 1e12)) * b.n_envs * (T + 1) / launches
-                out["roofline"].update(pipes="conv1: bf16 MFMA x3 (exact split, fp32 accumulate); conv2/heads: fp32",
-                                       frac_of_pipe_time=round(t_pk / (us * 1e-6), 4))
+            bf_ring = bool(ring and os.environ.get("A2C_RING_F32") != "1")
+            out["roofline"] = dict(kernel=name, traffic=None, **ring_roofline(A, b.n_envs, T, launches, us, bf_ring),
+                                   hbm_GBs=round(by / (us * 1e-6) / 1e9, 1),
+                                   hbm_frac=round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), alg_bytes_per_launch=by)
             if zero_copy:
                 link = dict(out["h2d"], note="PCIe frame bytes / launch duration vs the 63 GB/s link")
                 if link["frac"] > out["roofline"]["frac"]:
                     # the launch is paced by the host link (uint8 transport): that fraction is the primary figure
                     out["roofline"].update(bound="host_link", achieved=link["achieved_GBs"], peak=PCIE_PEAK_GBS, unit="GB/s",
-                                           frac=link["frac"], mfma_TFLOPs=round(tf, 2), mfma_frac=round(tf / F32_PEAK_TFLOPS, 4))
+                                           frac=link["frac"], mfma_TFLOPs=round(tf, 2), mfma_frac=out["roofline"]["frac"])
                 out["roofline"]["host_link"] = link
         elif dom is not None:
             ms = summ[dom]["avg_ms"]
@@ -1024,6 +1079,11 @@ def main():
                                                        update_ms=round(u_ms, 3), env_threads=1,
                                                        us_per_rollout_step=round(r_ms * 1e3 / (T + 1), 2))
                     out["host_us_per_env_step"] = round(r_ms * 1e3 / ((T + 1) * d.n_envs), 4)
+                    # NOT a scaling measurement (the driver measures that): what 8 ranks add up to if each is paced like this
+                    # one-thread leg, i.e. on a box whose CPU quota leaves ONE env thread per rank (16 CPUs / 8 ranks)
+                    out["predicted_8rank_weak"] = dict(value=round(8 * d.N * 40 / e, 1), unit="env-steps/s",
+                                                       vs_1rank=round(8 * d.N * 40 / e / out["value"], 2),
+                                                       basis="8 x value_one_env_thread; prediction, host-bound, unmeasured")
                     d.close()
                     del d
                 except Exception as e:      # noqa: BLE001
@@ -1055,8 +1115,10 @@ def main():
                     # (the single-frame store, row f4, is the layout of every config that keeps it: the ring kernel's for
                     # A3CModel up to 256 envs, the relay path's for the conv-stack nets; --no-frame-store = fp32 rows)
                     fs_cfg = (not args.no_frame_store) and (wl != "a3c" or fs_main)
+                    # configs[4] is Breakout: grey levels 0..255 over the uint8 transport (the packed one is Pong's)
+                    brk = key.startswith("conv_2048x128") and args.ingest != "device-tape"
                     cfgs[key] = run_config(wl, ne, args.optim, args.ingest, args.env_workers, n_workers, shard, dev, st_, wu,
-                                           transport=args.transport, frame_store=fs_cfg)
+                                           transport="u8" if brk else args.transport, frame_store=fs_cfg, grey=brk)
                 except Exception as e:      # noqa: BLE001
                     cfgs[key] = dict(error=f"{type(e).__name__}: {e}")
             # row f4 measured: the same conv-stack configs writing the reference's fp32 `states` rows in the rollout
@@ -1081,6 +1143,29 @@ def main():
                                                    WORKLOADS[args.workload][3], A, args.optim)
             except Exception as e:      # noqa: BLE001
                 out["cpu_baseline"] = dict(value=None, error=f"{type(e).__name__}: {e}")
+            # north_star: every throughput figure "next to the reference's CPU updater timed on the same box".  The other
+            # configs of this line get their own bounded sample (3 s of rollout processes + ~6 s of update_model each: the
+            # per-sample cost of the oracle does not depend on the batch beyond that, `extrapolated` says when N was cut);
+            # the two other A3CModel sizes reuse the headline's measured rates (same model, same min(n_envs, cores) workers).
+            if out.get("configs") and out["cpu_baseline"].get("value"):
+                cbs = {}
+                for key, wl, ne in (("conv_32x64", "conv", 32), ("gru_bptt_256x128", "gru_bptt", 256)):
+                    try:
+                        m_, _, T_, bp_, A_ = WORKLOADS[wl]
+                        cbs[key] = cpu_baseline(m_, ne, T_, bp_, A_, args.optim, roll_s=3.0, budget=6.0)
+                    except Exception as e:      # noqa: BLE001
+                        cbs[key] = dict(value=None, error=f"{type(e).__name__}: {e}")
+                hb = out["cpu_baseline"]
+                for key, ne in (("a3c_32", 32), ("a3c_2048", 2048)):
+                    cbs[key] = dict(value=hb["value"], unit="env-steps/s", cores=hb["cores"], kind="port", extrapolated=True,
+                                    sample=f"the headline's measured A3CModel rates (rollout {hb['rollout_steps_per_s']}/s, update "
+                                           f"{hb['update_samples_per_s']}/s) at n_envs={ne}: same model, same worker count")
+                c32 = cbs.get("conv_32x64") or {}
+                if c32.get("value"):
+                    cbs["conv_2048x128_per_gpu_shard_256x128"] = dict(
+                        value=c32["value"], unit="env-steps/s", cores=c32["cores"], kind="port", extrapolated=True,
+                        sample="ConvModel's measured per-sample rates (conv_32x64 entry) at N = 32,768 per GPU")
+                out["cpu_baselines"] = cbs
     tag = f"{args.workload}_n{shard.world}" + (f"_e{args.n_envs}" if args.n_envs else "")
     side = write_side_file(out, tag)
     print("[bench] full report: " + json.dumps(_finite(out)), file=sys.stderr)

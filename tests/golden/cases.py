@@ -142,6 +142,25 @@ class RawAtariEnv(O.FakeEnv):
         return getattr(O, self.prep)(f)
 
 
+class GreyFakeEnv(O.FakeEnv):
+    """grey levels 0..255 as float64: what the reference's runner sees behind breakout_prep (preprocessing.py:19-23 hands
+    the uint8 slice on unchanged, runner.py:199 casts it to float) -- the oracle's side of GreyU8FakeEnv"""
+
+    def __init__(self, **kw):
+        kw.pop("binary", None)
+        super().__init__(binary=False, **kw)
+
+    def _frame(self):
+        return np.rint(super()._frame() * 255.0)      # formula_frames(binary=False) = b / 255 with b in 0..255: exact
+
+
+class GreyU8FakeEnv(GreyFakeEnv):
+    """the same frames as uint8: the host pool carries them over the uint8 transport (the packed one refuses them)"""
+
+    def _frame(self):
+        return super()._frame().astype(np.uint8)
+
+
 class PongLikeEnv(U8FakeEnv):
     """80x80 binary uint8 frames = what pong_prep hands on (preprocessing.py:11-17); built as env_fn(j)"""
 

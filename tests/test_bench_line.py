@@ -128,3 +128,54 @@ def test_traffic_is_only_quoted_from_a_manifest_of_this_tree(tmp_path):
     tr, src, stale = bench.lookup_traffic("a3c_ring_lazy", str(prof))
     assert tr == 222 and not stale and "r5_traffic.json" in src and "cafef00dcafe" in src
     assert bench.lookup_traffic("no_such_kernel", str(prof)) == (None, None, False)
+
+
+# ---------------------------------------------------------------- rooflines are priced per pipe and never exceed 1
+class _D:      # conv1 of A3CModel: 4 -> 16, 8x8 stride 4 on 84x84
+    Cin, H, W, Cout, OH, OW, ks = 4, 84, 84, 16, 20, 20, 8
+
+
+class _L:
+    d = _D
+    name = "conv1"
+
+
+def test_ring_roofline_is_a_per_pipe_fraction():
+    """round 5's line divided fp32-equivalent flops by the fp32 MFMA peak while 71 % of them ran on the bf16 pipe (0.55,
+    and 1.15-1.20 on conv1's weight gradient with the same definition).  frac = matrix time at each instruction's own
+    peak / launch duration = achieved / the mixed-pipe peak: round 5's driver numbers give 0.23, and no duration above the
+    matrix time itself can give more than 1."""
+    r = bench.ring_roofline(3, 256, 128, 1, 1773.4, True)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=2e-3)
+    assert 0.22 <= r["frac"] <= 0.24 and 0.54 <= r["frac_fp32_equiv"] <= 0.56
+    t_pk_us = r["alg_flops_per_launch"] / (r["peak"] * 1e12) * 1e6        # the launch at every pipe's peak
+    assert bench.ring_roofline(3, 256, 128, 1, t_pk_us * 1.001, True)["frac"] <= 1.0
+    f32 = bench.ring_roofline(3, 256, 128, 1, 2150.0, False)
+    assert f32["peak"] == bench.F32_PEAK_TFLOPS and f32["frac"] == f32["frac_fp32_equiv"]
+
+
+def test_site_roofline_prices_the_uint8_store_and_the_bf16_pipe():
+    """conv1.bwd_weight at 2048 envs x 128 steps in 4.45 ms: priced with fp32-row bytes and the fp32 peak (round 5) that is
+    1.20 of the MFMA peak and 1.00 of HBM -- the kernel reads the uint8 store (7,056 B per sample) and issues bf16 MFMAs."""
+    site = dict(avg_ms=4.45, launches=1, total_ms=4.45)
+    old = bench.site_roofline("conv1.bwd_weight", site, {"conv1": _L}, 262144)
+    assert old["frac_of_f32_mfma_peak"] > 1.0                     # what round 5 printed
+    new = bench.site_roofline("conv1.bwd_weight", site, {"conv1": _L}, 262144, u8_store=True, bf16_pipe=True)
+    assert "frac_of_f32_mfma_peak" not in new and new["frac_of_pipe_peak"] <= 1.0 and new["frac_of_hbm_peak"] <= 1.0
+    assert new["alg_bytes"] == 262144 * (7056 + 4 * 16 * 400)
+    assert new["frac_of_pipe_peak"] == pytest.approx(3 * new["alg_flops"] / (bench.BF16_PEAK_TFLOPS * 1e12) / 4.45e-3, rel=1e-3)
+    fwd = bench.site_roofline("conv1.fwd", site, {"conv1": _L}, 262144, u8_store=True)
+    assert fwd["alg_bytes"] == new["alg_bytes"] and fwd["pipe"] == "fp32 MFMA"
+    bd = bench.site_roofline("conv1.bwd_data", site, {"conv1": _L}, 262144, u8_store=True)
+    assert bd["alg_bytes"] == 262144 * 4 * (4 * 84 * 84 + 16 * 400)
+
+
+def test_line_carries_the_other_configs_cpu_baselines_and_the_8_rank_prediction():
+    full = _fat_report()
+    full["cpu_baselines"] = {"conv_32x64": dict(value=61.5), "gru_bptt_256x128": dict(value=171.0), "a3c_32": dict(value=15005.5),
+                             "conv_2048x128_per_gpu_shard_256x128": dict(value=None, error="x")}
+    full["predicted_8rank_weak"] = dict(value=2.4e7, vs_1rank=3.0, basis="b" * 80)
+    full["roofline"].update(frac_fp32_equiv=0.55)
+    d = _strict(bench.compact_line(full, "gpurun_out/x.json"))
+    assert d["cpu_baseline_values"] == {"conv_32x64": 61.5, "gru_bptt_256x128": 171.0, "a3c_32": 15005.5}
+    assert d["predicted_8rank_weak"] == 2.4e7 and d["roofline"]["frac_fp32_equiv"] == 0.55

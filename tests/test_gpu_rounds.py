@@ -331,3 +331,156 @@ def test_push_mirror_rollouts_match_oracle(kind, ingest, bits, monkeypatch):
             _compare_round(D, refs[rnd[0]], net.is_recurrent)
     finally:
         r.close()
+
+
+# ---------------------------------------------------------------------------------------------- grey levels 0..255
+# Round 5 moved conv1 of the ring kernel onto the bf16 matrix pipe (step.hip: every fp32 weight as three bf16 pieces, the
+# uint8 pixel as ONE bf16 value).  The exactness argument holds for any uint8 pixel; breakout_prep (preprocessing.py:19-23)
+# hands on grey levels 0..255, runner.py:199 casts them to float unchanged.  These tests put pixels above 1 in front of the
+# oracle on that kernel: through the uint8 transport (the packed one refuses such frames), both head widths.
+def _close_rel(name, got, want, rel, floor=0.0):
+    """|got - want| <= floor + rel * (max |want| + |want|)"""
+    close(name, got, want, floor + rel * float(want.abs().max()), rel)
+
+
+def _fp32_value_noise(kind, ss, A, h, onet, states):
+    """max |V_fp32 - V_fp64| of the ORACLE on these states.  Grey levels make conv1's sums ~1e2 times larger than binary
+    frames do while the formula weights cancel them back to O(1) values: the reference's own fp32 forward is then 6e-6 off
+    its fp64 evaluation on values of scale 0.5 (binary frames: 4e-8).  A 1e-5 comparison of two fp32 evaluations would test
+    that noise; the tests allow 1e-5 of the scale + 4 x this measured noise (a delta holds two values)."""
+    o64 = O.OracleNet(kind, ss, A, h, state_dict={k: v.double() for k, v in O.formula_state_dict(kind, ss, A, h).items()})
+    with torch.no_grad():
+        return float((onet(states)[0].double() - o64(states.double())[0]).abs().max())
+
+
+@pytest.mark.parametrize("A,store", [(3, False), (4, False), (4, True)], ids=["A3", "A4", "A4-store"])
+def test_ring_kernel_on_grey_uint8_frames_matches_oracle(A, store, monkeypatch):
+    """A3CModel, zero-copy ring kernel (bf16-pipe conv1, the default), env frames = uint8 grey levels 0..255 over the uint8
+    transport; three rounds with an update between them against O.SlotRunner + OracleUpdater: states / dones / actions
+    exact, rewards (bootstrap = gamma * V) and deltas at 1e-5 of their scale on the first round.  "store": the single-frame
+    uint8 store + lazy states (the timed layout).  Then the same first round with A2C_RING_F32=1 (fp32 MFMAs): the two
+    forms of conv1 agree to fp32 re-association."""
+    from cases import GreyFakeEnv, GreyU8FakeEnv
+    from a2c_amd.runner import Runner
+    from a2c_amd.updater import Updater
+    B, T, ss = 5, 6, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=2 + j % 3, done_period=4 + 2 * j) for j in range(B)]
+    hyps = base_hyps(env_type="FakeBreakout", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3, env_timeout_s=20.0)
+    if store:
+        hyps.update(frame_store=True, lazy_states=True)
+    us = torch.from_numpy(hashf(3 * T * B, 60606, 0, 1).reshape(3, T, B))
+    usd = us.to(DEV)
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    refs = _oracle_rollouts("A3CModel", onet, hyps, ekws, us, 3, B, T, ss, env_cls=GreyFakeEnv,
+                            updater=O.OracleUpdater(onet, hyps))
+    assert float(refs[0]["states"].max()) == 255.0 and float((refs[0]["states"] > 1).float().mean()) > 0.9
+    noise = _fp32_value_noise("A3CModel", ss, A, 256, O.OracleNet("A3CModel", ss, A, 256), refs[0]["states"])
+    first = {}
+    for f32 in (False, True):
+        if f32:
+            monkeypatch.setenv("A2C_RING_F32", "1")
+        net = make_net("A3CModel", ss, A, 256)
+        D = _datas(B * T, ss, False, actions_on_host=False)
+        rnd = [0]
+        pool = _pool(GreyU8FakeEnv, ekws, 2, pong=False)
+        r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy",
+                   uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+        upd = Updater(net, hyps)
+        try:
+            for rnd[0] in range(1 if f32 else 3):
+                r.rollout(net, list(range(B)), hyps)
+                r.finish()
+                assert r._zero_copy_ok(net) and pool.transport == "u8" and not r.bits
+                if store:
+                    assert r._states_stale
+                    r.materialize_states()
+                ref = refs[rnd[0]]
+                assert torch.equal(D["states"].cpu(), ref["states"])
+                assert torch.equal(D["dones"].cpu(), ref["dones"])
+                mism = int((D["actions"].cpu() != ref["actions"]).sum())
+                assert mism == 0 if rnd[0] == 0 else mism <= 1, mism
+                rel = 1e-5 if rnd[0] == 0 else 2e-3      # later rounds: weights that went through RMSprop steps (lr 1e-3)
+                _close_rel("rewards", D["rewards"].cpu(), ref["rewards"], rel, 4 * noise)
+                _close_rel("deltas", D["deltas"].cpu(), ref["deltas"], rel, 4 * noise)
+                if rnd[0] == 0:
+                    e = float((D["deltas"].cpu() - ref["deltas"]).abs().max())
+                    print(f"[grey ring A={A} store={store} f32={f32}] max |delta - oracle| {e:.3e}, scale "
+                          f"{float(ref['deltas'].abs().max()):.3g}, oracle fp32-vs-fp64 value noise {noise:.3e}")
+                if rnd[0] == 0:
+                    first[f32] = {k: v.cpu().clone() for k, v in D.items()}
+                if rnd[0] < 2 and not f32:
+                    info = upd.update_model(D)
+                    oi = ref["info"]
+                    for k in oi:
+                        assert abs(info[k] - oi[k]) <= 1e-4 + 2e-3 * abs(oi[k]), (rnd[0], k, info[k], oi[k])
+        finally:
+            r.close()
+    for k in ("states", "actions", "dones"):
+        assert torch.equal(first[True][k], first[False][k]), k
+    _close_rel("deltas bf16-pipe vs fp32 MFMA", first[False]["deltas"], first[True]["deltas"], 2e-6, 4 * noise)
+
+
+def test_full_size_headline_on_grey_frames_action_census():
+    """256 envs x 128 steps of grey-level (0..255) tapes through the headline path on the uint8 transport and the timed
+    layout (ring kernel, single-frame store, lazy states): the tapes come back as the states' newest planes, the frame-stack
+    property holds, and the oracle forward on 2,048 of the 32,768 states with the same uniforms samples the same actions
+    (a flip only where the fp32 cumsum is within 1e-6 of the uniform, at most 1e-4 of the samples); the values behind the
+    recorded deltas against the oracle's on those states at 1e-5 of their scale."""
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    B, T, A, ss = 256, 128, 4, (4, 84, 84)
+    hyps = base_hyps(env_type="Breakout-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, frame_store=True,
+                     lazy_states=True)
+    net = make_net("A3CModel", ss, A, 256)
+    onet = O.OracleNet("A3CModel", ss, A, 256)
+    D = _datas(B * T, ss, False, actions_on_host=False)
+    envs = [TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 100, grey=True) for j in range(B)]
+    pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=False, frame_bits=False)
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy")
+    try:
+        r.rollout(net, list(range(B)), hyps)
+        r.finish()
+        assert r._states_stale and r._fstore is not None
+        r.materialize_states()
+        u = r._u_keep.cpu()
+        st = D["states"].cpu().reshape(B, T, 4, -1)
+        acts = D["actions"].cpu().reshape(B, T)
+        dones = D["dones"].cpu().reshape(B, T)
+        assert float(st.max()) == 255.0 and bool((dones[:, -1] == 1).all())
+        assert int(acts.min()) >= 0 and int(acts.max()) <= A - 1
+        for j in (0, 17, 255):
+            for t in range(1, T):
+                assert np.array_equal(st[j, t, 3].numpy(), envs[j].frames[t % (T + 1)].reshape(-1).astype(np.float32)), (j, t)
+        real_done = torch.from_numpy(np.stack([e.dones[:T] for e in envs]).astype(np.float32))
+        for c in range(3):
+            same = (st[:, 1:, c] == st[:, :-1, c + 1]).all(-1)
+            zero = (st[:, 1:, c] == 0).all(-1)
+            assert bool((same | (zero & (real_done[:, :T - 1] == 1))).all())
+        idx = (np.arange(2048, dtype=np.int64) * 2654435761 % (B * T)).astype(np.int64)
+        with torch.no_grad():
+            vals, logits = onet(D["states"].cpu().reshape(B * T, *ss)[idx])
+        cs = torch.cumsum(torch.softmax(logits, -1), -1)
+        uu = u.t().reshape(-1)[idx]
+        ref = (cs >= uu[:, None]).float().argmax(-1)
+        ref[(cs < uu[:, None]).all(-1)] = A - 1
+        got = acts.reshape(-1)[idx]
+        flips = (ref != got).nonzero().flatten()
+        assert len(flips) <= max(1, int(1e-4 * len(idx))), len(flips)
+        for f in flips.tolist():
+            assert float((cs[f] - uu[f]).abs().min()) < 1e-6, (f, cs[f], uu[f])
+        # values: delta[t] = r[t] + gamma * V[t+1] * (1 - d[t]) - V[t]  (runner.py:231) on 256 sampled interior steps
+        base = np.array([e for e in idx.tolist() if e % T != T - 1][:256], dtype=np.int64)
+        with torch.no_grad():
+            v0 = onet(D["states"].cpu().reshape(B * T, *ss)[base])[0].reshape(-1)
+            v1 = onet(D["states"].cpu().reshape(B * T, *ss)[base + 1])[0].reshape(-1)
+        rew, dl, dn = D["rewards"].cpu()[base], D["deltas"].cpu()[base], D["dones"].cpu()[base]
+        want = rew + hyps["gamma"] * v1 * (1.0 - dn) - v0
+        scale = float(torch.maximum(v0.abs(), v1.abs()).max())
+        err = float((dl - want).abs().max())
+        noise = _fp32_value_noise("A3CModel", ss, A, 256, onet, D["states"].cpu().reshape(B * T, *ss)[base])
+        print(f"[grey census] value scale {scale:.4g}, max |delta - oracle| {err:.3e} = {err / scale:.2e} of the scale; "
+              f"oracle fp32-vs-fp64 value noise {noise:.3e}")
+        assert err <= 1e-5 * scale + 4 * noise, (err, scale, noise)
+    finally:
+        r.close()

@@ -228,12 +228,20 @@ def _oracle_updates_fp32_and_fp64(kind, ss, A, h, oupd, Do, hyps, monkeypatch):
 
 
 def _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, max_norm):
-    """The five infos at rel 3e-5 (and no further from the fp64 evaluation than the reference's fp32 path is); GradNorm
-    against the fp64 norm; every gradient tensor: rms deviation from the fp64 gradients <= 2 x the deviation of the
-    reference's own fp32 arithmetic + 5e-5 of the tensor's rms (the floor covers ReLU decisions of activations within
+    """The four loss infos at rel 3e-5 against the reference's fp32 arithmetic -- NOT north_star's 1e-5: at N = 32,768 the
+    oracle's own fp32 means sit up to ~2e-5 (relative) off their fp64 evaluation, so what is asserted beside the 3e-5 is the
+    fp64 yardstick: no further from fp64 than 2 x the reference's fp32 path is (+ a floor); the achieved relative deviations
+    are printed (pytest -s) and quoted in README.  GradNorm against the fp64 norm at 5e-6.  Every gradient tensor: rms
+    deviation from the fp64 gradients <= 4 x the deviation of the reference's own fp32 arithmetic + 5e-5 of the tensor's rms
+    (4 x, not 2 x: both deviations are single draws of sums of 1e7-1e8 rounding errors -- e_hip / e_ref between 0.1 and 2.7
+    has been measured across tensors and sizes, tools/dbg/fullsize_grad_stats.py -- and 4 keeps one-sigma luck out of the
+    verdict while a wrong term, which is O(1) of the rms, still fails; the floor covers ReLU decisions of activations within
     fp32 noise of zero: measured 1.4e-5 on ConvModel's 2048 x 2000 embedding); sampled post-step weights.
     fp32 conv gradients at these sizes are sums of 1e7-1e8 cancelling terms: torch's own deviate by ~1e-3 of the
     tensor's rms from fp64 (tools/dbg/fullsize_grad_stats.py), so an element-wise 1e-5 comparison with them would test noise."""
+    print("[full-size infos] achieved |hip - oracle fp32| / |oracle| : " + ", ".join(
+        f"{k} {abs(info[k] - oinfo[k]) / max(abs(oinfo[k]), 1e-30):.2e} (oracle fp32 vs fp64: "
+        f"{abs(oinfo[k] - oinfo64[k]) / max(abs(oinfo64[k]), 1e-30):.2e})" for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy", "GradNorm")))
     for k in ("Loss", "Pi_Loss", "ValLoss", "Entropy"):
         assert info[k] == pytest.approx(oinfo[k], rel=3e-5, abs=2e-6), (k, info[k], oinfo[k])
         # ... and no further from the fp64 evaluation than torch's fp32 path is, up to the noise floor of a mean of N terms
@@ -405,8 +413,10 @@ def test_config5_per_gpu_shard_conv_256x128_properties():
     net = make_net("ConvModel", ss, A, 256)
     onet = O.OracleNet("ConvModel", ss, A, 256)
     D = _datas(B * T, ss, False, actions_on_host=False)
-    envs = [TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 100) for j in range(B)]
-    pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=False, frame_bits=True)
+    # Breakout's preprocessor hands on grey levels 0..255 (preprocessing.py:19-23): uint8 transport (7,056 B per frame over
+    # the link; the packed 1-bit transport is Pong's and refuses such frames, tests/test_hostpool.py)
+    envs = [TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 100, grey=True) for j in range(B)]
+    pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=False, frame_bits=False)
     r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="relay")
     try:
         r.rollout(net, list(range(B)), hyps)
@@ -447,6 +457,7 @@ def test_config5_per_gpu_shard_conv_256x128_properties():
             close("rets", rets[j], O.discount_np(rews.numpy()[j], dones.numpy()[j], hyps["gamma"]), 0, 0)
         # the update's forward at the sampled rows == the oracle's forward (the heads the loss saw)
         hb = net._heads("train", B * T)[0][torch.from_numpy(idx).to(DEV)].cpu()
+        assert pool.transport == "u8" and float(D["states"][:T].max()) == 255.0
         close("logits at N=32768", hb[:, :A], logits, 2e-5, 1e-5)
         close("values at N=32768", hb[:, A], ovals.reshape(-1), 2e-5, 1e-5)
         # losses from the recorded heads, in fp64 on the host (updater.py:100-127)

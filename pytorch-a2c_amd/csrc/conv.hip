@@ -1705,6 +1705,118 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   }
 }
 
+// bwd_stream_kernel, second form (round 6).  Two things the first form pays for per sample, measured: (1) the flush of the
+// sample's dX (25.6 KB: LDS read, mask, global store) sits between two matrix phases with the matrix pipe idle, and the loop
+// top's wait for the next sample's dOut also waits for those fresh stores (loads and stores retire through one in-order
+// counter); (2) the ReLU mask is the fp32 activation itself, 25.6 KB per sample read for one bit per element (42 % of the
+// kernel's HBM bytes).  Here the dX image is DOUBLE BUFFERED in LDS: sample b's classes land in image b & 1 while image
+// (b - 1) & 1 is flushed at the HEAD of the iteration -- stores first, then the matrix phase, then the next sample's dOut
+// loads, so that no wait of the iteration sits behind a fresh store -- and the mask can come as LANE MASKS (MODE 2): for
+// every run of 64 float4 of the sample's activation, four 64-bit words [x, y, z, w] with bit l of word c = (act[4 (64 g + l)
+// + c] > 0), i.e. the `v_cmp` result of the wave that stored that run (the ring kernel writes them beside its a1 stash:
+// 800 B per sample instead of 25.6 KB).  The flushing wave's 64 lanes cover exactly one run, so the four words are
+// wave-uniform loads and lane l tests bit l.  Same sums in the same order as the first form: bit-identical dX.
+// MODE 0: no mask, 1: float mask, 2: lane masks.
+struct Bstream2P {
+  BstreamP s;
+  const unsigned long long* lmask;      // MODE 2: (B, lmw) 64-bit words
+  int lmw;                              // words per sample = Cin * H * W / 64
+};
+template <int MODE>
+__global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_stream2_kernel(Bstream2P pp) {
+  const BstreamP& p = pp.s;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ img = lds;                              // dOut of the sample with a one-pixel zero halo
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int WP = p.WP, PLANE = p.PLANE, HW = p.H * p.W;
+  const int obs = p.Cin * HW;                                 // floats per dX image
+  float* __restrict__ outb0 = lds + p.Cout * p.PLANE + 64;    // two dX images, [Cin][H*W] each
+  const int ohw = p.OH * p.OW, nel4 = (p.Cout * ohw) >> 2, n4 = obs >> 2;
+  for (int i = tid; i < p.Cout * PLANE + 64; i += BS_NT) img[i] = 0.f;       // halo stays 0 forever
+  const BwdClass k = p.cls[w & 3];
+  const int half = w >> 2;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  float af[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) af[s] = p.wfrag[k.frag_off + s * 64 + lane];
+  const int NP = k.PH * k.PW, ntile = (NP + 15) >> 4;
+  float4 d0 = {}, d1 = {}, d2 = {}, d3 = {}, d4 = {}, d5 = {}, m0 = {}, m1 = {}, m2 = {}, m3 = {};
+  unsigned int soff[12];
+  BS_OFF(0) BS_OFF(1) BS_OFF(2) BS_OFF(3) BS_OFF(4) BS_OFF(5)
+  long b = blockIdx.x;
+  if (b >= p.B) return;
+  {
+    const float* __restrict__ src = p.dout + b * (long)p.Cout * ohw;
+    BS_LDD(d0, 0, src) BS_LDD(d1, 1, src) BS_LDD(d2, 2, src) BS_LDD(d3, 3, src) BS_LDD(d4, 4, src) BS_LDD(d5, 5, src)
+  }
+  // flush unit u of sample pb_ out of image ob_: float4 number tid + u * BS_NT
+#define BS2_FLUSH(mv, u, pb_, ob_)                                                                          \
+  {                                                                                                         \
+    float* __restrict__ dst_ = p.din + (pb_) * (long)obs;                                                   \
+    if (MODE == 2) {                                                                                        \
+      const int grp_ = wu + (u) * (BS_NT / 64);          /* this wave's run of 64 float4: wave-uniform */   \
+      if (grp_ * 64 < n4) {                                                                                 \
+        const unsigned long long* __restrict__ lm_ = pp.lmask + (pb_) * (long)pp.lmw + grp_ * 4;            \
+        const unsigned long long mx_ = lm_[0], my_ = lm_[1], mz_ = lm_[2], mw_ = lm_[3];                     \
+        const unsigned long long bit_ = 1ull << lane;                                                       \
+        const int i_ = (tid + (u) * BS_NT) << 2;                                                            \
+        float4 v_ = *reinterpret_cast<const float4*>((ob_) + i_);                                           \
+        if (!(mx_ & bit_)) v_.x = 0.f;                                                                      \
+        if (!(my_ & bit_)) v_.y = 0.f;                                                                      \
+        if (!(mz_ & bit_)) v_.z = 0.f;                                                                      \
+        if (!(mw_ & bit_)) v_.w = 0.f;                                                                      \
+        *reinterpret_cast<float4*>(dst_ + i_) = v_;                                                         \
+      }                                                                                                     \
+    } else {                                                                                                \
+      const int i_ = min(tid + (u) * BS_NT, n4 - 1) << 2;                                                    \
+      float4 v_ = *reinterpret_cast<const float4*>((ob_) + i_);                                             \
+      if (MODE == 1) {                                                                                      \
+        if (!(mv.x > 0.f)) v_.x = 0.f;                                                                      \
+        if (!(mv.y > 0.f)) v_.y = 0.f;                                                                      \
+        if (!(mv.z > 0.f)) v_.z = 0.f;                                                                      \
+        if (!(mv.w > 0.f)) v_.w = 0.f;                                                                      \
+      }                                                                                                     \
+      *reinterpret_cast<float4*>(dst_ + i_) = v_;                                                           \
+    }                                                                                                       \
+  }
+  long pb = -1;
+  int cur = 0;
+  for (; b < p.B; b += gridDim.x) {
+    const long nb = (b + gridDim.x < p.B) ? b + gridDim.x : b;          // past the end: re-read this sample (discarded)
+    const float* __restrict__ nsrc = p.dout + nb * (long)p.Cout * ohw;
+    const float* __restrict__ msrc = p.mask + b * (long)obs;
+    float* __restrict__ outb = outb0 + cur * obs;
+    BS_STD(d0, 0) BS_STD(d1, 1) BS_STD(d2, 2) BS_STD(d3, 3) BS_STD(d4, 4) BS_STD(d5, 5)
+    __syncthreads();
+    if (pb >= 0) {                                              // the previous sample's dX: stores first
+      const float* __restrict__ ob = outb0 + (cur ^ 1) * obs;
+      BS2_FLUSH(m0, 0, pb, ob) BS2_FLUSH(m1, 1, pb, ob) BS2_FLUSH(m2, 2, pb, ob) BS2_FLUSH(m3, 3, pb, ob)
+    }
+    BS_PAIR(0)                                                  // tiles half, half + 2
+    if (MODE == 1) { BS_LDM(m0, 0, msrc) BS_LDM(m1, 1, msrc) BS_LDM(m2, 2, msrc) BS_LDM(m3, 3, msrc) }
+    BS_LDD(d0, 0, nsrc) BS_LDD(d1, 1, nsrc) BS_LDD(d2, 2, nsrc) BS_LDD(d3, 3, nsrc) BS_LDD(d4, 4, nsrc) BS_LDD(d5, 5, nsrc)
+    for (int tp = 2; tp * 2 + half < ntile; tp += 2) BS_PAIR(tp) // tiles half + 4, half + 6, ...
+    __syncthreads();                                            // every class has landed in this sample's image
+    pb = b;
+    cur ^= 1;
+  }
+  {
+    const float* __restrict__ ob = outb0 + (cur ^ 1) * obs;
+    BS2_FLUSH(m0, 0, pb, ob) BS2_FLUSH(m1, 1, pb, ob) BS2_FLUSH(m2, 2, pb, ob) BS2_FLUSH(m3, 3, pb, ob)
+  }
+}
+
+// lane masks of an activation tensor (see bwd_stream2_kernel): one wave per run of 64 float4
+__global__ __launch_bounds__(256) void lanemask_kernel(const float* __restrict__ act, unsigned long long* __restrict__ lm, long nruns) {
+  const int lane = threadIdx.x & 63;
+  for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < nruns; r += gridDim.x * 4L) {
+    const float4 v = reinterpret_cast<const float4*>(act)[r * 64 + lane];
+    const unsigned long long bx = __ballot(v.x > 0.f), by = __ballot(v.y > 0.f), bz = __ballot(v.z > 0.f), bw = __ballot(v.w > 0.f);
+    if (lane == 0) { lm[r * 4] = bx; lm[r * 4 + 1] = by; lm[r * 4 + 2] = bz; lm[r * 4 + 3] = bw; }
+  }
+}
+
 // Generic backward-data, any (ks, S <= 2, pad): a workgroup owns a BAND of TY rows of dX (all
 // columns, all input channels).  It stages the band's dOut rows (with zero halo) once, runs every
 // output-parity class as a stride-1 correlation into an LDS copy of the dX band, then flushes
@@ -3584,6 +3696,32 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
 
 int a2c_conv2d_bwd_data_signs_supported(const a2c_conv_desc* d) { return desc_ok(d) && c3_bwd_signs_supported(d) ? 1 : 0; }
 
+/* include/a2c_mi355x.h: lane masks of an activation tensor, and the backward-data pass that takes them as its ReLU mask */
+int a2c_lanemask_from_act(const float* act, uint64_t* lanemask, int64_t n_floats, a2c_stream_t stream) {
+  if (n_floats < 0 || n_floats % 256) return A2C_ERR_ARG;
+  if (n_floats == 0) return A2C_OK;
+  if (!act || !lanemask || ((uintptr_t)act % 16) || ((uintptr_t)lanemask % 8)) return A2C_ERR_ARG;
+  const long nruns = n_floats / 256;
+  const int grid = (int)(nruns / 4 + 1 < 4096 ? nruns / 4 + 1 : 4096);
+  hipLaunchKernelGGL(lanemask_kernel, dim3(grid), dim3(256), 0, a2c_s(stream), act, (unsigned long long*)lanemask, nruns);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+int a2c_conv2d_bwd_data_lanemask_supported(const a2c_conv_desc* d, int B) {
+  if (!desc_ok(d) || B < 1 || (d->Cin * d->H * d->W) % 256) return 0;
+  if (c3_supported(d, 1)) return 0;          // (the 3x3 stacks have their own sign-word kernels)
+  static const unsigned long long probe = 0;
+  return conv_bwd_data_generic(d, (const float*)16, (const float*)16, nullptr, (float*)16, B, nullptr, &probe, true) == A2C_OK ? 1 : 0;
+}
+int a2c_conv2d_bwd_data_lanemask(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const uint64_t* lanemask,
+                                 float* din, int B, a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!dout || !wprep_bwd || !din || !lanemask || ((uintptr_t)lanemask % 8)) return A2C_ERR_ARG;
+  if (!a2c_conv2d_bwd_data_lanemask_supported(d, B)) return A2C_ERR_ARG;
+  return conv_bwd_data_generic(d, dout, wprep_bwd, nullptr, din, B, stream, (const unsigned long long*)lanemask);
+}
+
 int a2c_conv2d_bwd_data_signs(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const uint32_t* signs,
                               int64_t signs_bstride, float* din, int B, a2c_stream_t stream) {
   if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
@@ -3595,8 +3733,9 @@ int a2c_conv2d_bwd_data_signs(const a2c_conv_desc* d, const float* dout, const f
 }
 }  // extern "C"
 namespace {
+// lmask != nullptr: the mask as lane masks (bwd_stream2_kernel); only the streaming path reads them: A2C_ERR_ARG otherwise
 int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask, float* din, int B,
-                          a2c_stream_t stream) {
+                          a2c_stream_t stream, const unsigned long long* lmask = nullptr, bool probe_only = false) {
   const int S = d->stride, P = d->pad;
   {  // fused-class pipelined path (unpadded ks = 2S layers whose dOut sample fits the prefetch registers)
     const int MTb = ceil_div(d->Cin, 16), c4n = d->Cout / 4;
@@ -3627,6 +3766,25 @@ int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float
         sp.Cout = d->Cout; sp.OH = d->OH; sp.OW = d->OW; sp.Cin = d->Cin; sp.H = d->H; sp.W = d->W; sp.B = B;
         sp.WP = q.WP; sp.PLANE = q.PLANE; sp.off0 = q.off0; sp.step_a = q.step_a; sp.step_b = q.step_b; sp.step_c = q.step_c;
         for (int cls = 0; cls < 4; ++cls) sp.cls[cls] = q.cls[cls];
+        const int n4 = d->Cin * d->H * d->W / 4;
+        // second form (two dX images, flush under the next sample's matrix phase, lane masks): A2C_BWD_STREAM_V1=1 keeps the first
+        const size_t slds2 = 4 * ((size_t)d->Cout * q.PLANE + 64 + 2 * (size_t)d->Cin * d->H * d->W);
+        const char* v1 = getenv("A2C_BWD_STREAM_V1");
+        const bool form2 = slds2 <= LDS_HARD_MAX && !(v1 && v1[0] == '1') && (!lmask || n4 % 64 == 0);
+        if (lmask && !form2) return A2C_ERR_ARG;
+        if (probe_only) return A2C_OK;
+        if (form2) {
+          Bstream2P s2;
+          s2.s = sp; s2.lmask = lmask; s2.lmw = n4 / 64 * 4;
+          const void* sk = lmask ? (const void*)bwd_stream2_kernel<2> : mask ? (const void*)bwd_stream2_kernel<1> : (const void*)bwd_stream2_kernel<0>;
+          if (slds2 > 64 * 1024) (void)hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds2);
+          const int sgrid = resident_grid(sk, slds2, B, BS_NT);
+          if (lmask) hipLaunchKernelGGL(bwd_stream2_kernel<2>, dim3(sgrid), dim3(BS_NT), slds2, a2c_s(stream), s2);
+          else if (mask) hipLaunchKernelGGL(bwd_stream2_kernel<1>, dim3(sgrid), dim3(BS_NT), slds2, a2c_s(stream), s2);
+          else hipLaunchKernelGGL(bwd_stream2_kernel<0>, dim3(sgrid), dim3(BS_NT), slds2, a2c_s(stream), s2);
+          A2C_CHECK_LAUNCH();
+          return A2C_OK;
+        }
         const size_t slds = 4 * ((size_t)d->Cout * q.PLANE + 64 + (size_t)d->Cin * d->H * d->W);
         const void* sk = mask ? (const void*)bwd_stream_kernel<true> : (const void*)bwd_stream_kernel<false>;
         if (slds > 64 * 1024) (void)hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
@@ -3636,6 +3794,7 @@ int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float
         A2C_CHECK_LAUNCH();
         return A2C_OK;
       }
+      if (lmask) return A2C_ERR_ARG;
       const size_t lds = 4 * (nfrag + (size_t)d->Cout * q.PLANE + 64 + (size_t)d->Cin * d->H * d->W);
       if (lds > LDS_HARD_MAX) return A2C_ERR_ARG;
       const void* k = MTb == 1 ? (const void*)bwd_fused_kernel<1> : (const void*)bwd_fused_kernel<2>;
@@ -3647,6 +3806,7 @@ int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float
       return A2C_OK;
     }
   }
+  if (lmask) return A2C_ERR_ARG;           // only the streaming kernel reads lane masks
   if (S * S <= MAX_CLS && !getenv("A2C_NO_BAND") && ((uintptr_t)din % 16 == 0) && (!mask || (uintptr_t)mask % 16 == 0)) {
     const int rc = bwd_band_tuned(d, dout, wprep_bwd, mask, din, B, stream);
     if (rc != BAND_NA) return rc;

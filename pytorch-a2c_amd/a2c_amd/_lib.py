@@ -48,7 +48,7 @@ class A3CRolloutArgs(Structure):
                 ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64), ("a1_rows", P), ("a2_rows", P), ("heads_rows", P), ("heads_rows_ld", c_int64),
                 ("frame_store", P), ("frame_store_slot_stride", c_int64), ("nvalid_rows", P), ("nvalid_carry", P),
                 ("frame_bits", c_int), ("conv1_weight", P), ("states_lazy", c_int),
-                ("tagged", P), ("tagged_stride", c_int64), ("tagged_chunks", c_int)]
+                ("tagged", P), ("tagged_stride", c_int64), ("tagged_chunks", c_int), ("a1_lanemask_rows", P)]
 
 
 PS = POINTER(A3CStepArgs)
@@ -127,6 +127,9 @@ SIGNATURES = {
     "a2c_conv2d_sign_words": (c_int64, [PD]),
     "a2c_conv2d_fwd_signs": (c_int, [PD, P, c_int64, P, P, c_int, P, c_int64, P, c_int64, c_int, P]),
     "a2c_conv2d_bwd_data_signs_supported": (c_int, [PD]),
+    "a2c_lanemask_from_act": (c_int, [P, P, c_int64, P]),
+    "a2c_conv2d_bwd_data_lanemask_supported": (c_int, [PD, c_int]),
+    "a2c_conv2d_bwd_data_lanemask": (c_int, [PD, P, P, P, P, c_int, P]),
     "a2c_conv2d_bwd_data_signs": (c_int, [PD, P, P, P, c_int64, P, c_int, P]),
     "a2c_conv2d_bwd_weight_ws_bytes": (c_size_t, [PD, c_int]),
     "a2c_conv2d_bwd_data_w1_ws_bytes": (c_size_t, [PD, PD, c_int]),

@@ -179,12 +179,15 @@ class ConvLayer:
         if self.padded:
             dW.copy_(dst[:, :self.cin])
 
-    def bwd_data(self, dout, mask, din, B, st, signs=None):
-        """mask: the float activation below; signs: its sign words (B, words) when its forward left them (preferred)"""
+    def bwd_data(self, dout, mask, din, B, st, signs=None, lanemask=None):
+        """mask: the float activation below; signs: its sign words (B, words) when its forward left them (preferred);
+        lanemask: its lane masks (B, n/64) int64 (A3CModel's conv2: written by the ring kernel beside the a1 stash)"""
         if self.padded:
             raise NotImplementedError("a2c_amd: input gradient of a channel-padded conv layer (only first layers are padded)")
         with ops.span(self.name + ".bwd_data"):
-            if signs is not None:
+            if lanemask is not None:
+                ops.conv_bwd_data_lanemask(self.d, dout, self.wb, lanemask, din, B, st)
+            elif signs is not None:
                 ops.conv_bwd_data_signs(self.d, dout, self.wb, signs, din, B, st)
             else:
                 ops.conv_bwd_data(self.d, dout, self.wb, mask, din, B, st)

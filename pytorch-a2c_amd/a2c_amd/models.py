@@ -91,6 +91,7 @@ class _HipNet(nn.Module):
         self._dirty = True
         self._stash = None
         self._stash_frames = None
+        self._stash_lm = False
 
     # ---- rollout -> update activation stash (models with a one-launch rollout step)
     def _conv_chain(self):
@@ -312,7 +313,20 @@ class A3CModel(_HipNet):
         # + the heads [logits | value] of every state: the rollout computed them through the composed matrix
         # Wc = [pi;value].proj_matrx, so the update needs neither the 2592 -> 256 forward GEMM nor the embedding
         return (ws.get("a1", (n_rows,) + self._c1.out_shape), ws.get("a2", (n_rows,) + self._c2.out_shape),
-                self._heads("train", n_rows)[0])
+                self._heads("train", n_rows)[0], self._a1_lanemask_rows(n_rows))
+
+    def _a1_lanemask_rows(self, n_rows):
+        """(n_rows, 16*OH1*OW1/64) int64: lane masks of the a1 stash rows (include/a2c_mi355x.h: a1_lanemask_rows), which the
+        ring kernel writes beside them -- conv2's backward-data then reads 800 B per sample as its ReLU mask instead of the
+        25.6 KB row.  None when the library's streaming kernel cannot take them at this batch (or A2C_NO_LANEMASK=1)."""
+        n = int(np.prod(self._c1.out_shape))
+        if os.environ.get("A2C_NO_LANEMASK") == "1" or n % 256 or not ops.conv_bwd_data_lanemask_supported(self._c2.d, n_rows):
+            return None
+        return self.ws("train").get("a1_lm", (n_rows, n // 64), dtype=torch.int64)
+
+    def stash_commit(self, states, n_rows, frames=None, lanemask=False):
+        super().stash_commit(states, n_rows, frames=frames)
+        self._stash_lm = bool(lanemask)
 
     def _fwd(self, x_ptr, bstride, B, tag, st, save, sampler=None):
         ws, P = self.ws(tag), self.P
@@ -447,7 +461,11 @@ class A3CModel(_HipNet):
                 linear_bwd_data(ws, demb, Wp, da2.view(B, -1), B, st, mask=a2)
             self._c2.bwd_weight(a1.data_ptr(), a1[0].numel(), da2, G("convs.1.0.weight"), G("convs.1.0.bias"), B, ws, st)
             da1 = ws.get("da1", (B,) + self._c1.out_shape)
-            self._c2.bwd_data(da2, a1, da1, B, st)
+            # the ring kernel left a1's lane masks beside the stash: 800 B per sample instead of the 25.6 KB row as the mask
+            lm = None
+            if tag == "train" and getattr(self, "_stash_lm", False) and self._stash_valid(x_ptr, B) and os.environ.get("A2C_NO_LANEMASK") != "1":
+                lm = self._a1_lanemask_rows(B)
+            self._c2.bwd_data(da2, a1, da1, B, st, lanemask=lm)
             fr = getattr(self, "_bwd_frames", None)
             if fr is not None:      # stack-on-load from the single-frame uint8 store: 28 KB instead of 113 KB per sample
                 fstore, nvalid, T = fr

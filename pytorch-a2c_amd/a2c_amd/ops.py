@@ -631,6 +631,24 @@ def conv_bwd_data_signs(d, dout, wprep_bwd, signs, din, B, st=None):
                                           st if st is not None else stream()), "a2c_conv2d_bwd_data_signs")
 
 
+def lanemask_from_act(act, lanemask, st=None):
+    """lane masks (include/a2c_mi355x.h: a2c_conv2d_bwd_data_lanemask) of a float activation tensor -> (rows, n/64) int64"""
+    _chk(act, "act"); _chk(lanemask, "lanemask", torch.int64)
+    check(lib().a2c_lanemask_from_act(_p(act), _p(lanemask), act.numel(), st if st is not None else stream()),
+          "a2c_lanemask_from_act")
+
+
+def conv_bwd_data_lanemask_supported(d, B):
+    return bool(lib().a2c_conv2d_bwd_data_lanemask_supported(ctypes.byref(d), int(B)))
+
+
+def conv_bwd_data_lanemask(d, dout, wprep_bwd, lanemask, din, B, st=None):
+    """conv_bwd_data with the ReLU mask given as the lane masks of the layer's input ((B, Cin*H*W/64) int64)"""
+    _chk(lanemask, "lanemask", torch.int64)
+    check(lib().a2c_conv2d_bwd_data_lanemask(ctypes.byref(d), _p(dout), _p(wprep_bwd), _p(lanemask), _p(din), B,
+                                             st if st is not None else stream()), "a2c_conv2d_bwd_data_lanemask")
+
+
 def conv_bwd_weight_ws_bytes(d, B):
     return lib().a2c_conv2d_bwd_weight_ws_bytes(ctypes.byref(d), B)
 

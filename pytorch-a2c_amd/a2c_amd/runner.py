@@ -334,6 +334,8 @@ class Runner:
         # whatever an earlier rollout stashed in the net describes states this call overwrites
         net._stash = None
         net._stash_frames = None
+        net._stash_lm = False
+        self._lm_written = False
         if hasattr(net, "_cells_done"):
             net._cells_done = -1
         # a call that fills EVERY row of the rollout buffer: the step kernels may stash the conv activations
@@ -377,7 +379,10 @@ class Runner:
         if dev_phase:       # ... the last env step has been played: the workers sleep-poll through the update
             ops.store_u32_system(dev_phase, 0)
         if stash_all:
-            net.stash_commit(self.datas["states"], N, frames=getattr(self, "_frames_written", None))
+            if getattr(self, "_lm_written", False):      # (A3CModel, ring kernel: lane masks of a1 beside the stash)
+                net.stash_commit(self.datas["states"], N, frames=getattr(self, "_frames_written", None), lanemask=True)
+            else:
+                net.stash_commit(self.datas["states"], N, frames=getattr(self, "_frames_written", None))
 
     def _uniforms(self, t, B, env0):
         if self.uniform_fn is not None:
@@ -911,8 +916,10 @@ class Runner:
         # only the ring kernel can leave the fp32 rows out (more envs than CUs: interleaved blocks of it, one after the
         # other); the library answers whether THIS call runs it (LDS budget, conv1 output size, weight alignment,
         # A2C_NO_RING / A2C_RING_BLOCKS) -- a shape that does not gets its rows written by the per-step body instead
-        lazy = (fs is not None and bool(try_key(hyps, "lazy_states", False)) and
-                ops.a3c_ring_supported(B, C, H, W, net.output_space, P("convs.0.0.weight").data_ptr()))
+        ring = ops.a3c_ring_supported(B, C, H, W, net.output_space, P("convs.0.0.weight").data_ptr())
+        lazy = fs is not None and bool(try_key(hyps, "lazy_states", False)) and ring
+        # ... and only the ring kernel writes the lane masks of the a1 stash rows (the update's conv2 backward-data mask)
+        lm = self._stash_bufs[3] if (ring and self._stash_bufs is not None and len(self._stash_bufs) > 3) else None
         ops.a3c_rollout(st, B=B, C=C, H=H, W=W, n_actions=net.output_space, states=D["states"].data_ptr(),
                         bookmark=bm.data_ptr(), wfrag1=net._c1.wf.data_ptr(), bias1=P("convs.0.0.bias").data_ptr(),
                         wfrag2=net._c2.wf.data_ptr(), bias2=P("convs.1.0.bias").data_ptr(), Wc=net._Wc.data_ptr(),
@@ -933,7 +940,9 @@ class Runner:
                         nvalid_rows=0 if fs is None else fs[1].data_ptr(),
                         nvalid_carry=0 if fs is None else fs[2][env0:env0 + B].data_ptr(), states_lazy=int(lazy),
                         tagged=getattr(pool, "dev_tagged", 0), tagged_stride=int(pool.header.tagged_stride),
-                        tagged_chunks=int(pool.header.tagged_chunks))
+                        tagged_chunks=int(pool.header.tagged_chunks), a1_lanemask_rows=0 if lm is None else lm.data_ptr())
+        # every block of the call must have written them (a rollout of several blocks: all ring launches, or none counts)
+        self._lm_written = (lm is not None) and (getattr(self, "_lm_written", False) or slot0 == 0)
         if lazy:            # (only after the launch was accepted: a refused call must not leave rows marked stale)
             self._states_stale = True
             net._materialize_states = self.materialize_states

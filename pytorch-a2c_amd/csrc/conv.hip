@@ -3680,7 +3680,7 @@ static int bwd_band_tuned(const a2c_conv_desc* d, const float* dout, const float
   }
 }
 int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask, float* din, int B,
-                          a2c_stream_t stream);
+                          a2c_stream_t stream, const unsigned long long* lmask = nullptr, bool probe_only = false);
 }  // namespace
 extern "C" {
 int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask,
@@ -3735,7 +3735,7 @@ int a2c_conv2d_bwd_data_signs(const a2c_conv_desc* d, const float* dout, const f
 namespace {
 // lmask != nullptr: the mask as lane masks (bwd_stream2_kernel); only the streaming path reads them: A2C_ERR_ARG otherwise
 int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask, float* din, int B,
-                          a2c_stream_t stream, const unsigned long long* lmask = nullptr, bool probe_only = false) {
+                          a2c_stream_t stream, const unsigned long long* lmask, bool probe_only) {
   const int S = d->stride, P = d->pad;
   {  // fused-class pipelined path (unpadded ks = 2S layers whose dOut sample fits the prefetch registers)
     const int MTb = ceil_div(d->Cin, 16), c4n = d->Cout / 4;

@@ -60,6 +60,7 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   long timeout_ticks;
   float* a1_rows;
   float* a2_rows;
+  unsigned long long* a1_lm;                       // ring kernel: lane masks of the a1 stash rows (a2c_conv2d_bwd_data_lanemask), or nullptr
   float* heads_rows; long heads_rows_ld;
   unsigned char* fstore; long fs_slot_stride;      // single-frame uint8 store (T+4 frames per slot)
   int* nvalid; int* nvalid_carry;
@@ -1236,10 +1237,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       if (p.x.a1_rows != nullptr && t < T) {
         float* __restrict__ a1o = p.x.a1_rows + (row + t) * (16L * NP1);
         const int n4 = NP1 >> 2;
+        // lane masks beside the stash (the update's conv2 backward-data reads 800 B of them per sample instead of the 25.6 KB
+        // row as its ReLU mask): a wave's 64 lanes store one run of 64 consecutive float4 (sid and sn are multiples of 64 per
+        // wave), so the four compare results of the wave ARE the run's four mask words -- no packing, one 32-byte store per run
+        unsigned long long* __restrict__ lmo = (p.x.a1_lm != nullptr && (16 * n4) % 64 == 0) ? p.x.a1_lm + (row + t) * (long)(16 * n4 / 16) : nullptr;
         for (int q = sid; q < 16 * n4; q += sn) {
           const int ch = q / n4, o4 = q - ch * n4;
           const float4 v = *reinterpret_cast<const float4*>(a1 + ch * p.PLANE2 + (o4 << 2));
           __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a1o) + q);
+          if (lmo != nullptr) {
+            const unsigned long long bx = __ballot(v.x > 0.f), by = __ballot(v.y > 0.f), bz = __ballot(v.z > 0.f), bw = __ballot(v.w > 0.f);
+            if (lane == 0) {
+              unsigned long long* __restrict__ o = lmo + (q >> 6) * 4;
+              o[0] = bx; o[1] = by; o[2] = bz; o[3] = bw;
+            }
+          }
         }
       }
       if (p.x.a2_rows != nullptr && t < T) {
@@ -1437,6 +1449,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.actions = r->actions; p.x.cmd = (unsigned long long*)r->cmd; p.x.rec = (const unsigned long long*)r->rec;
   p.x.seq0 = r->seq0; p.x.env0 = r->env0; p.x.err = r->err; p.x.timeout_ticks = (long)r->timeout_ticks;
   p.x.a1_rows = r->a1_rows; p.x.a2_rows = r->a2_rows;
+  p.x.a1_lm = (r->a1_rows != nullptr) ? (unsigned long long*)r->a1_lanemask_rows : nullptr;
   p.x.heads_rows = r->heads_rows; p.x.heads_rows_ld = (long)r->heads_rows_ld;
   p.x.fstore = r->frame_store; p.x.fs_slot_stride = (long)r->frame_store_slot_stride;
   p.x.nvalid = r->nvalid_rows; p.x.nvalid_carry = r->nvalid_carry;
@@ -1470,6 +1483,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
       r->env0 < 0)
     return A2C_ERR_ARG;
   if ((r->a1_rows || r->a2_rows) && ((p.OH1 * p.OW1) % 4 || (((uintptr_t)r->a1_rows | (uintptr_t)r->a2_rows) % 16))) return A2C_ERR_ARG;
+  if (r->a1_lanemask_rows && (!r->a1_rows || ((uintptr_t)r->a1_lanemask_rows % 8) || (16 * p.OH1 * p.OW1) % 256)) return A2C_ERR_ARG;
   if ((((uintptr_t)r->states | (uintptr_t)r->bookmark | (uintptr_t)r->frames | (uintptr_t)a.wfrag2 | (uintptr_t)a.Wc) % 16) ||
       (((uintptr_t)r->cmd | (uintptr_t)r->rec) % 8))
     return A2C_ERR_ARG;
@@ -1502,7 +1516,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
     }
     return A2C_OK;
   }
-  if (p.x.states_lazy) return A2C_ERR_ARG;      // only the ring kernel can leave the fp32 rows out
+  if (p.x.states_lazy || p.x.a1_lm) return A2C_ERR_ARG;      // only the ring kernel can leave the fp32 rows out / writes lane masks
   const size_t lds = step_lds(p);
   // one workgroup per CU at most (157 KB of LDS each): all of them resident, envs beyond that take turns
   const int grid = a.B < cus ? a.B : cus;

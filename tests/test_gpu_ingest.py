@@ -531,3 +531,46 @@ def test_ingest_with_post_equals_ingest_then_post(bits, recurrent, t):
         assert bool((a["h"][d_eff != 0] == 0).all())
         if t + 1 < T:       # (the last step of a slot has no next row)
             assert bool((a["h_rows"][:, t + 1][d_eff != 0] == 0).all()) and torch.equal(a["h_rows"][:, t + 1], a["h"])
+
+
+def test_ring_kernel_leaves_lane_masks_and_the_update_reads_them(monkeypatch):
+    """round 6: beside its a1 stash rows the ring kernel writes their LANE MASKS (include/a2c_mi355x.h: a1_lanemask_rows); the
+    update's conv2 backward-data takes those 800 B per sample as its ReLU mask instead of the 25.6 KB activation row
+    (a2c_conv2d_bwd_data_lanemask).  64 envs x 32 steps (2,048 rows: the streaming kernel's smallest batch): the masks the
+    kernel wrote == a2c_lanemask_from_act of the stashed activations, and the update's gradient arena and infos are
+    bit-identical to the same update reading the float mask (A2C_NO_LANEMASK=1)."""
+    from a2c_amd import ops
+    from a2c_amd.hostpool import ThreadEnvPool
+    from a2c_amd.runner import Runner
+    from a2c_amd.synthetic import TapeEnv
+    from a2c_amd.updater import Updater
+    B, T, A, ss = 64, 32, 3, (4, 84, 84)
+    hyps = base_hyps(env_type="Pong-synthetic", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-5)
+    res = {}
+    for mode in ("lanemask", "float"):
+        if mode == "float":
+            monkeypatch.setenv("A2C_NO_LANEMASK", "1")
+        net = make_net("A3CModel", ss, A, 256)
+        D = _datas(B * T, ss, False, actions_on_host=False)
+        envs = [TapeEnv(env_id=j, length=T + 1, p_done=1.0 / 20) for j in range(B)]
+        pool = ThreadEnvPool.from_tape_envs(envs, n_threads=4, pong=True, frame_bits=True)
+        r = Runner(D, hyps, None, None, None, env_pool=pool, ingest="zero-copy")
+        torch.manual_seed(11)
+        try:
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            assert net._stash is not None and bool(getattr(net, "_stash_lm", False)) == (mode == "lanemask")
+            if mode == "lanemask":
+                ws = net.ws("train")
+                a1 = ws.get("a1", (B * T,) + net._c1.out_shape)
+                lm = ws.get("a1_lm", (B * T, 100), dtype=torch.int64)
+                want = torch.zeros_like(lm)
+                ops.lanemask_from_act(a1, want)
+                torch.cuda.synchronize()
+                assert torch.equal(lm, want) and int((lm != 0).sum()) > 0
+            info = Updater(net, hyps).update_model(D)
+            res[mode] = (info, net._arena.train_grads().cpu().clone())
+        finally:
+            r.close()
+    assert res["lanemask"][0] == res["float"][0]
+    assert torch.equal(res["lanemask"][1], res["float"][1])

@@ -841,6 +841,52 @@ def test_conv2d_streaming_backward_data_matches_tiled_kernel(monkeypatch, with_m
     close("vs fp64", got[:32], ref, 1e-5 * float(ref.abs().max()), 1e-5)
 
 
+def _lanemask_ref(act):
+    """(B, n) float -> (B, n/64) int64: per run g of 64 float4, words [x, y, z, w], bit l of word c = act[4 (64 g + l) + c] > 0
+    (include/a2c_mi355x.h: a2c_conv2d_bwd_data_lanemask)"""
+    B, n = act.shape
+    bits = (act > 0).reshape(B, n // 256, 64, 4).permute(0, 1, 3, 2).to(torch.int64)          # (B, run, c, l)
+    sh = torch.arange(64, dtype=torch.int64)
+    lo = (bits[..., :63] << sh[:63]).sum(-1)
+    return (lo | torch.where(bits[..., 63] > 0, torch.tensor(-2 ** 63), torch.tensor(0))).reshape(B, n // 64)
+
+
+@pytest.mark.parametrize("B", [2048 + 55, 4096])
+def test_conv2d_streaming_backward_data_with_lane_masks(monkeypatch, B):
+    """round 6: the streaming backward-data kernel of A3CModel's conv2 takes its ReLU mask as LANE MASKS (800 B per sample
+    instead of the 25.6 KB activation row): a2c_lanemask_from_act == the layout's definition, and the masked dX equals the
+    float-mask call bit for bit -- on the second form of the kernel (two dX images, default) and against the first
+    (A2C_BWD_STREAM_V1=1)."""
+    ops = _ops()
+    d = ops.conv_desc(16, 20, 20, 32, 4, 2, 0)
+    assert ops.conv_bwd_data_lanemask_supported(d, B) and not ops.conv_bwd_data_lanemask_supported(d, 64)
+    gen = torch.Generator().manual_seed(14)
+    w = ((torch.rand(32, 16, 4, 4, generator=gen) - 0.5) * 0.2)
+    dout = ((torch.rand(B, 32, 9, 9, generator=gen) - 0.5) * (torch.rand(B, 32, 9, 9, generator=gen) < 0.6).float()).to(DEV)
+    act = torch.relu(torch.rand(B, 16, 20, 20, generator=gen) - 0.4)
+    act[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-45, float("nan")])       # zero, negative zero, a denormal, NaN: (x > 0)
+    actd = act.to(DEV)
+    lm = torch.zeros(B, 6400 // 64, dtype=torch.int64, device=DEV)
+    ops.lanemask_from_act(actd, lm)
+    torch.cuda.synchronize()
+    assert torch.equal(lm.cpu()[:64], _lanemask_ref(act.reshape(B, -1)[:64]))
+    wb = torch.empty(ops.conv_prep_floats(d, 1), device=DEV)
+    ops.conv_prep(d, 1, w.to(DEV), wb)
+    got = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+    ops.conv_bwd_data_lanemask(d, dout, wb, lm, got, B)
+    want = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+    ops.conv_bwd_data(d, dout, wb, actd, want, B)
+    monkeypatch.setenv("A2C_BWD_STREAM_V1", "1")
+    old = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+    ops.conv_bwd_data(d, dout, wb, actd, old, B)
+    with pytest.raises(RuntimeError):
+        ops.conv_bwd_data_lanemask(d, dout, wb, lm, got.clone(), B)            # the first form does not read lane masks
+    monkeypatch.delenv("A2C_BWD_STREAM_V1")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(want, old)
+    assert not bool(torch.isnan(got).any())
+
+
 # ------------------------------------------------------------------ GRU gates / LayerNorm
 def test_gru_kernels_vs_autograd():
     ops = _ops()

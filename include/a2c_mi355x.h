@@ -321,11 +321,11 @@ typedef struct {
    * bits).  One wave then fetches poll + frame + reward/done of an env step with ONE 16-byte load per lane -- one PCIe
    * round trip instead of two dependent ones (rec granule, then frame) -- and re-tries until every tag matches.    */
   const uint8_t *tagged; int64_t tagged_stride; int tagged_chunks;
-  /* optional, ring kernel only, with a1_rows: LANE MASKS of the a1 stash rows -- (16*OH1*OW1)/64 64-bit words per state, row
-   * e = (slot0+b)*T + t like a1_rows: for every run g of 64 consecutive float4 of the row, four words [x, y, z, w] with bit l
-   * of word c = (a1[4*(64 g + l) + c] > 0).  Consumer: a2c_conv2d_bwd_data_lanemask (the update's conv2 backward-data reads
-   * 800 B per sample instead of the 25.6 KB activation row as its ReLU mask, updater.py:128's autograd).  A2C_ERR_ARG when
-   * the launch cannot run as the ring kernel (ask a2c_a3c_ring_supported first) or 16*OH1*OW1 is not a multiple of 256. */
+  /* optional, ring kernel only, with a1_rows: the MASK BITS ("lane masks") of the a1 stash rows -- (16*OH1*OW1)/64 64-bit
+   * words per state, row e = (slot0+b)*T + t like a1_rows: bit (i & 7) of byte (i >> 3) of the row = (a1[i] > 0), i the flat
+   * (c, y, x) index.  Consumer: a2c_conv2d_bwd_data_lanemask (the update's conv2 backward-data reads 800 B per sample instead
+   * of the 25.6 KB activation row as its ReLU mask, updater.py:128's autograd).  A2C_ERR_ARG when the launch cannot run as
+   * the ring kernel (ask a2c_a3c_ring_supported first) or 16*OH1*OW1 is not a multiple of 256.                         */
   uint64_t *a1_lanemask_rows;
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
@@ -508,15 +508,14 @@ int a2c_conv2d_fwd_signs(const a2c_conv_desc *d, const float *in, int64_t in_bst
                          const float *bias, int relu, float *out, int64_t out_bstride, uint32_t *signs,
                          int64_t signs_bstride, int B, a2c_stream_t stream);
 int a2c_conv2d_bwd_data_signs_supported(const a2c_conv_desc *d);
-/* The ReLU mask as LANE MASKS (the streaming backward-data kernel of the 4x4 / stride-2 layer of A3CModel, models.py:35-37).
- * lanemask = (B, Cin*H*W/64) 64-bit words: for every run g of 64 consecutive float4 of sample b's (Cin, H, W) activation,
- * words [4g .. 4g+3] = [x, y, z, w] with bit l of word c = (act[b][4*(64 g + l) + c] > 0) -- what a wavefront's `v_cmp`
- * leaves when its 64 lanes hold one float4 each, so the producer (a2c_a3c_rollout's ring kernel: a1_lanemask_rows; or
- * a2c_lanemask_from_act over any tensor whose float count is a multiple of 256) packs nothing and the consumer's flushing
- * wave tests bit `lane` of four wave-uniform words.  din = conv_transpose(dout, W) * bit: the same values as
- * a2c_conv2d_bwd_data with the float mask, bit for bit, for 1/32 of the mask's HBM reads.
- * _supported(d, B) = 1 when a2c_conv2d_bwd_data_lanemask can run (layer shape, Cin*H*W % 256 == 0, B large enough for the
- * streaming kernel); otherwise use a2c_conv2d_bwd_data with the float mask.                                            */
+/* The ReLU mask as one bit per activation, in the layout a wavefront writes without packing work ("lane masks"; the streaming
+ * backward-data kernel of the 4x4 / stride-2 layer of A3CModel, models.py:35-37).  lanemask = (B, Cin*H*W/64) 64-bit words =
+ * Cin*H*W/8 bytes per sample: bit (i & 7) of byte (i >> 3) = (act[b][i] > 0), i the flat (c, y, x) index -- the four bits of
+ * a lane's float4 are one nibble, two neighbouring lanes make a byte.  Producers: a2c_a3c_rollout's ring kernel
+ * (a1_lanemask_rows) or a2c_lanemask_from_act over any tensor whose float count is a multiple of 256.
+ * din = conv_transpose(dout, W) * bit: the same values as a2c_conv2d_bwd_data with the float mask, bit for bit, for 1/32 of
+ * the mask's HBM reads.  _supported(d, B) = 1 when a2c_conv2d_bwd_data_lanemask can run (layer shape, Cin*H*W % 256 == 0,
+ * B large enough for the streaming kernel); otherwise use a2c_conv2d_bwd_data with the float mask.                     */
 int a2c_lanemask_from_act(const float *act, uint64_t *lanemask, int64_t n_floats, a2c_stream_t stream);
 int a2c_conv2d_bwd_data_lanemask_supported(const a2c_conv_desc *d, int B);
 int a2c_conv2d_bwd_data_lanemask(const a2c_conv_desc *d, const float *dout, const float *wprep_bwd, const uint64_t *lanemask,

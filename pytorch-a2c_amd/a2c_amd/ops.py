@@ -16,7 +16,157 @@ _F32 = torch.float32
 
 
 def lib():
+    """the C-ABI library (ctypes) -- or, with A2C_TORCH_OPS=1, the same entry points reached through
+    torch.ops.a2c_mi355x.abi_* (TorchAbi below): the launches of the hot loop then go through the PyTorch dispatcher"""
+    if _TORCH_ABI_ON():
+        return torch_abi()
     return _lib.load()
+
+
+def _TORCH_ABI_ON():
+    import os
+    return os.environ.get("A2C_TORCH_OPS") == "1"
+
+
+class TorchAbi:
+    """``lib()`` when A2C_TORCH_OPS=1: attribute access returns, for every kernel-launching entry point of
+    include/a2c_mi355x.h that has a generated op (csrc/torch_ops_abi.inc; tools/gen_torch_abi_ops.py), a callable with the
+    ctypes binding's positional signature that forwards the call to ``torch.ops.a2c_mi355x.abi_<name>(bufs, offs, ints,
+    floats)``: every pointer argument is replaced by (the torch tensor that owns that memory, byte offset into it) -- the
+    tensors this module has seen (workspaces, arenas, rollout buffers: ``note_tensor``) are looked up by address --, the
+    stream argument must be torch's current stream (it is what the op uses).  Same C function, same arguments: results are
+    bit-identical to the ctypes path (tests/test_gpu_system.py).  What cannot be expressed -- argument blocks
+    (a2c_a3c_step / a2c_a3c_rollout), pointer tables, addresses outside any torch tensor (the pinned pool region), a foreign
+    stream -- goes to the ctypes library and is counted in ``stats['ctypes']``."""
+
+    def __init__(self):
+        import importlib.util
+        import os
+        self._c = _lib.load()
+        self._ops = load_torch_ops()
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        # the parameter classes come from the same header parse that generated the C++ side
+        spec = importlib.util.spec_from_file_location("_a2c_gen_abi", os.path.join(root, "tools", "gen_torch_abi_ops.py"))
+        gen = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gen)
+        self._layout = {n: list(zip(kinds, [t for t, _ in params])) for n, params, kinds in gen.plan()[0]}
+        self._bases, self._refs = [], {}          # sorted storage base addresses -> weakref(tensor), nbytes
+        self._null = {}
+        self.stats = {"torch_ops": 0, "ctypes": 0, "by_name": {}, "unresolved": {}}
+        self._fns = {}
+
+    # -- address book
+    def note(self, t):
+        import bisect
+        import weakref
+        if t is None or not t.is_cuda:
+            return
+        st = t.untyped_storage()
+        base, nb = st.data_ptr(), st.nbytes()
+        if not nb:
+            return
+        ent = self._refs.get(base)
+        if ent is not None and ent[1] >= nb and ent[0]() is not None:
+            return
+        if ent is None:
+            bisect.insort(self._bases, base)
+        flat = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st, 0, (nb,))      # a byte view of the whole storage
+        self._keep = getattr(self, "_keep", {})
+        self._keep[base] = flat             # (the view keeps the storage alive: opt-in debugging / boundary mode only)
+        self._refs[base] = (weakref.ref(flat), nb)
+
+    def _find(self, addr):
+        import bisect
+        i = bisect.bisect_right(self._bases, addr) - 1
+        if i < 0:
+            return None
+        base = self._bases[i]
+        ref, nb = self._refs[base]
+        t = ref()
+        if t is None or addr >= base + nb:
+            return None
+        return t, addr - base
+
+    def _nul(self, dev):
+        t = self._null.get(dev)
+        if t is None:
+            t = self._null[dev] = torch.empty(0, device=dev)
+        return t
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name in ("stats", "note"):
+            raise AttributeError(name)
+        fn = self._fns.get(name)
+        if fn is None:
+            fn = self._fns[name] = self._make(name)
+        return fn
+
+    def _make(self, name):
+        cfn = getattr(self._c, name)
+        lay = self._layout.get(name)
+        if lay is None:
+            return cfn                      # queries (_supported, _ws_bytes ...), argument blocks, host-side entry points
+        op = getattr(self._ops, "abi_" + name[4:])
+        stats = self.stats
+
+        def call(*args):
+            st = args[-1]
+            st = int(st.value or 0) if hasattr(st, "value") else int(st or 0)
+            bufs, offs, ints, flts = [], [], [], []
+            ok = st == stream()
+            dev = torch.device("cuda", torch.cuda.current_device())
+            if ok:
+                for (kind, _), a in zip(lay, args[:-1]):
+                    if kind == "ptr":
+                        addr = int(getattr(a, "value", a) or 0)
+                        if addr == 0:
+                            bufs.append(self._nul(dev)); offs.append(0)
+                            continue
+                        hit = self._find(addr)
+                        if hit is None:
+                            stats["unresolved"][name] = stats["unresolved"].get(name, 0) + 1
+                            ok = False
+                            break
+                        bufs.append(hit[0]); offs.append(hit[1])
+                    elif kind == "int":
+                        ints.append(int(a))
+                    elif kind == "float":
+                        flts.append(float(a))
+                    else:                   # a2c_conv_desc*: ctypes.byref(desc)
+                        d = a._obj
+                        ints.extend(int(getattr(d, f)) for f in ("Cin", "H", "W", "Cout", "ks", "stride", "pad", "OH", "OW"))
+            if not ok:
+                stats["ctypes"] += 1
+                return cfn(*args)
+            stats["torch_ops"] += 1
+            stats["by_name"][name] = stats["by_name"].get(name, 0) + 1
+            try:
+                op(bufs, offs, ints, flts)
+            except RuntimeError as e:       # the op raises where the launcher returned an error code
+                msg = str(e)
+                for code in (-1, -2, -3):
+                    if self._c.a2c_error_string(code).decode() in msg:
+                        return code
+                raise
+            return 0
+        return call
+
+
+_torch_abi = None
+
+
+def torch_abi():
+    global _torch_abi
+    if _torch_abi is None:
+        _torch_abi = TorchAbi()
+    return _torch_abi
+
+
+def note_tensor(t):
+    """A2C_TORCH_OPS=1: remember which tensor owns this device memory (pointer arguments are looked up by address)"""
+    if _TORCH_ABI_ON():
+        torch_abi().note(t)
+    return t
 
 
 def load_torch_ops():
@@ -36,7 +186,11 @@ def stream():
 
 
 def _p(t):
-    return 0 if t is None else t.data_ptr()
+    if t is None:
+        return 0
+    if _TORCH_ABI_ON():
+        torch_abi().note(t)
+    return t.data_ptr()
 
 
 def _chk(t, name, dtype=_F32, contig=True):
@@ -216,6 +370,7 @@ class Workspace:
             self._bufs[key] = buf
             if zero:
                 buf.zero_()
+        note_tensor(buf)
         return buf[:n].view(shape)
 
     def bytes(self, name, nbytes):

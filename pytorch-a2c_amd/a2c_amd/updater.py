@@ -16,6 +16,10 @@ from .parallel import Shard
 from .utils import try_key
 
 
+def recurrent_key(shared_data):
+    return "h_states" in shared_data
+
+
 class _CutShard:
     """Shard stand-in used while capturing: every collective ends the graph being captured and starts the next"""
 
@@ -178,6 +182,12 @@ class Updater:
         n_global = cache[N]
         b = self._buffers(N)
         advs, rets, stats = b["advs"], b["rets"], b["stats"]
+        if ops._TORCH_ABI_ON():     # A2C_TORCH_OPS=1: the launches below go through torch.ops.a2c_mi355x.abi_* (ops.TorchAbi),
+            # which finds the tensor behind every address it is handed: tell it about the buffers that travel as raw rows
+            for t in (states, rewards, dones, deltas, actions, net._arena.params, net._arena.grads,
+                      shared_data.get("h_states") if recurrent_key(shared_data) else None, *[v for v in b.values() if torch.is_tensor(v)]):
+                if t is not None and t.is_cuda:
+                    ops.note_tensor(t)
 
         # advantages (gamma*lambda) and discounted returns (gamma) in one pass (updater.py:70-71, 86-88)
         with ops.span("gae_returns_scan"):

@@ -1711,11 +1711,12 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 // counter); (2) the ReLU mask is the fp32 activation itself, 25.6 KB per sample read for one bit per element (42 % of the
 // kernel's HBM bytes).  Here the dX image is DOUBLE BUFFERED in LDS: sample b's classes land in image b & 1 while image
 // (b - 1) & 1 is flushed at the HEAD of the iteration -- stores first, then the matrix phase, then the next sample's dOut
-// loads, so that no wait of the iteration sits behind a fresh store -- and the mask can come as LANE MASKS (MODE 2): for
-// every run of 64 float4 of the sample's activation, four 64-bit words [x, y, z, w] with bit l of word c = (act[4 (64 g + l)
-// + c] > 0), i.e. the `v_cmp` result of the wave that stored that run (the ring kernel writes them beside its a1 stash:
-// 800 B per sample instead of 25.6 KB).  The flushing wave's 64 lanes cover exactly one run, so the four words are
-// wave-uniform loads and lane l tests bit l.  Same sums in the same order as the first form: bit-identical dX.
+// loads, so that no wait of the iteration sits behind a fresh store -- and the mask can come as ONE BIT per activation
+// (MODE 2, "lane masks"): bit e & 7 of byte e >> 3 of the sample's row = (act[e] > 0) in flat (c, y, x) order, so the four
+// bits of a lane's float4 are one nibble and a flush unit needs ONE byte load per lane (the ring kernel writes the bits
+// beside its a1 stash: 800 B per sample instead of 25.6 KB).  The bytes of sample b are fetched during b's own matrix
+// phase (first version: at the flush, four loads whose latency nothing covered -- 0.73 -> 0.89 ms).  Same sums in the same
+// order as the first form: bit-identical dX.
 // MODE 0: no mask, 1: float mask, 2: lane masks.
 struct Bstream2P {
   BstreamP s;
@@ -1755,17 +1756,15 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   {                                                                                                         \
     float* __restrict__ dst_ = p.din + (pb_) * (long)obs;                                                   \
     if (MODE == 2) {                                                                                        \
-      const int grp_ = wu + (u) * (BS_NT / 64);          /* this wave's run of 64 float4: wave-uniform */   \
-      if (grp_ * 64 < n4) {                                                                                 \
-        const unsigned long long* __restrict__ lm_ = pp.lmask + (pb_) * (long)pp.lmw + grp_ * 4;            \
-        const unsigned long long mx_ = lm_[0], my_ = lm_[1], mz_ = lm_[2], mw_ = lm_[3];                     \
-        const unsigned long long bit_ = 1ull << lane;                                                       \
-        const int i_ = (tid + (u) * BS_NT) << 2;                                                            \
+      const int q_ = tid + (u) * BS_NT;                  /* this lane's float4; its four bits were fetched  */   \
+      if (q_ < n4) {                                     /* one iteration ago (BS2_LDB): byte u of lmb      */   \
+        const unsigned int nb_ = (lmb >> (8 * (u) + 4 * (q_ & 1))) & 0xfu;                                  \
+        const int i_ = q_ << 2;                                                                             \
         float4 v_ = *reinterpret_cast<const float4*>((ob_) + i_);                                           \
-        if (!(mx_ & bit_)) v_.x = 0.f;                                                                      \
-        if (!(my_ & bit_)) v_.y = 0.f;                                                                      \
-        if (!(mz_ & bit_)) v_.z = 0.f;                                                                      \
-        if (!(mw_ & bit_)) v_.w = 0.f;                                                                      \
+        if (!(nb_ & 1u)) v_.x = 0.f;                                                                        \
+        if (!(nb_ & 2u)) v_.y = 0.f;                                                                        \
+        if (!(nb_ & 4u)) v_.z = 0.f;                                                                        \
+        if (!(nb_ & 8u)) v_.w = 0.f;                                                                        \
         *reinterpret_cast<float4*>(dst_ + i_) = v_;                                                         \
       }                                                                                                     \
     } else {                                                                                                \
@@ -1782,6 +1781,7 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   }
   long pb = -1;
   int cur = 0;
+  unsigned int lmb = 0;                                         // MODE 2: the mask bits of sample pb for this thread's four flush units
   for (; b < p.B; b += gridDim.x) {
     const long nb = (b + gridDim.x < p.B) ? b + gridDim.x : b;          // past the end: re-read this sample (discarded)
     const float* __restrict__ nsrc = p.dout + nb * (long)p.Cout * ohw;
@@ -1795,8 +1795,16 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
     BS_PAIR(0)                                                  // tiles half, half + 2
     if (MODE == 1) { BS_LDM(m0, 0, msrc) BS_LDM(m1, 1, msrc) BS_LDM(m2, 2, msrc) BS_LDM(m3, 3, msrc) }
+    unsigned int lb0 = 0, lb1 = 0, lb2 = 0, lb3 = 0;
+    if (MODE == 2) {           // THIS sample's mask bits (its flush is the next iteration's first act): one byte per flush unit
+      const unsigned char* __restrict__ lmp = reinterpret_cast<const unsigned char*>(pp.lmask) + b * (long)pp.lmw * 8;
+      const int nby = n4 >> 1;
+      lb0 = lmp[min((tid + 0 * BS_NT) >> 1, nby - 1)]; lb1 = lmp[min((tid + 1 * BS_NT) >> 1, nby - 1)];
+      lb2 = lmp[min((tid + 2 * BS_NT) >> 1, nby - 1)]; lb3 = lmp[min((tid + 3 * BS_NT) >> 1, nby - 1)];
+    }
     BS_LDD(d0, 0, nsrc) BS_LDD(d1, 1, nsrc) BS_LDD(d2, 2, nsrc) BS_LDD(d3, 3, nsrc) BS_LDD(d4, 4, nsrc) BS_LDD(d5, 5, nsrc)
     for (int tp = 2; tp * 2 + half < ntile; tp += 2) BS_PAIR(tp) // tiles half + 4, half + 6, ...
+    if (MODE == 2) lmb = lb0 | (lb1 << 8) | (lb2 << 16) | (lb3 << 24);
     __syncthreads();                                            // every class has landed in this sample's image
     pb = b;
     cur ^= 1;
@@ -1807,13 +1815,13 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   }
 }
 
-// lane masks of an activation tensor (see bwd_stream2_kernel): one wave per run of 64 float4
-__global__ __launch_bounds__(256) void lanemask_kernel(const float* __restrict__ act, unsigned long long* __restrict__ lm, long nruns) {
-  const int lane = threadIdx.x & 63;
-  for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < nruns; r += gridDim.x * 4L) {
-    const float4 v = reinterpret_cast<const float4*>(act)[r * 64 + lane];
-    const unsigned long long bx = __ballot(v.x > 0.f), by = __ballot(v.y > 0.f), bz = __ballot(v.z > 0.f), bw = __ballot(v.w > 0.f);
-    if (lane == 0) { lm[r * 4] = bx; lm[r * 4 + 1] = by; lm[r * 4 + 2] = bz; lm[r * 4 + 3] = bw; }
+// the mask bits of an activation tensor (see bwd_stream2_kernel): a lane per float4, a byte per pair of lanes
+__global__ __launch_bounds__(256) void lanemask_kernel(const float* __restrict__ act, unsigned char* __restrict__ lm, long n4) {
+  for (long q = blockIdx.x * 256L + threadIdx.x; q < n4; q += gridDim.x * 256L) {          // n4 is even: whole lane pairs
+    const float4 v = reinterpret_cast<const float4*>(act)[q];
+    const unsigned int nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+    const unsigned int hi = __shfl_xor(nib, 1);
+    if (!(q & 1)) lm[q >> 1] = (unsigned char)(nib | (hi << 4));
   }
 }
 
@@ -3701,9 +3709,9 @@ int a2c_lanemask_from_act(const float* act, uint64_t* lanemask, int64_t n_floats
   if (n_floats < 0 || n_floats % 256) return A2C_ERR_ARG;
   if (n_floats == 0) return A2C_OK;
   if (!act || !lanemask || ((uintptr_t)act % 16) || ((uintptr_t)lanemask % 8)) return A2C_ERR_ARG;
-  const long nruns = n_floats / 256;
-  const int grid = (int)(nruns / 4 + 1 < 4096 ? nruns / 4 + 1 : 4096);
-  hipLaunchKernelGGL(lanemask_kernel, dim3(grid), dim3(256), 0, a2c_s(stream), act, (unsigned long long*)lanemask, nruns);
+  const long n4 = n_floats / 4;
+  const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(lanemask_kernel, dim3(grid), dim3(256), 0, a2c_s(stream), act, (unsigned char*)lanemask, n4);
   A2C_CHECK_LAUNCH();
   return A2C_OK;
 }

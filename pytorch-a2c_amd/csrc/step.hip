@@ -1237,20 +1237,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       if (p.x.a1_rows != nullptr && t < T) {
         float* __restrict__ a1o = p.x.a1_rows + (row + t) * (16L * NP1);
         const int n4 = NP1 >> 2;
-        // lane masks beside the stash (the update's conv2 backward-data reads 800 B of them per sample instead of the 25.6 KB
-        // row as its ReLU mask): a wave's 64 lanes store one run of 64 consecutive float4 (sid and sn are multiples of 64 per
-        // wave), so the four compare results of the wave ARE the run's four mask words -- no packing, one 32-byte store per run
-        unsigned long long* __restrict__ lmo = (p.x.a1_lm != nullptr && (16 * n4) % 64 == 0) ? p.x.a1_lm + (row + t) * (long)(16 * n4 / 16) : nullptr;
+        // mask bits beside the stash (the update's conv2 backward-data reads 800 B of them per sample instead of the 25.6 KB
+        // row as its ReLU mask): bit e of the row = (a1[e] > 0) -- a lane's float4 is one nibble, lane pairs make the bytes
+        unsigned char* __restrict__ lmo = (p.x.a1_lm != nullptr && (16 * n4) % 64 == 0)
+                                              ? reinterpret_cast<unsigned char*>(p.x.a1_lm) + (row + t) * (long)(16 * n4 / 2) : nullptr;
         for (int q = sid; q < 16 * n4; q += sn) {
           const int ch = q / n4, o4 = q - ch * n4;
           const float4 v = *reinterpret_cast<const float4*>(a1 + ch * p.PLANE2 + (o4 << 2));
           __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a1o) + q);
           if (lmo != nullptr) {
-            const unsigned long long bx = __ballot(v.x > 0.f), by = __ballot(v.y > 0.f), bz = __ballot(v.z > 0.f), bw = __ballot(v.w > 0.f);
-            if (lane == 0) {
-              unsigned long long* __restrict__ o = lmo + (q >> 6) * 4;
-              o[0] = bx; o[1] = by; o[2] = bz; o[3] = bw;
-            }
+            const unsigned int nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            const unsigned int hi = __shfl_xor(nib, 1);           // (whole waves run this loop: sid, sn, 16 * n4 are multiples of 64)
+            if (!(q & 1)) lmo[q >> 1] = (unsigned char)(nib | (hi << 4));
           }
         }
       }

@@ -267,7 +267,12 @@ at::Tensor clip_adam_(at::Tensor params, at::Tensor grads, at::Tensor exp_avg, a
 }
 }  // namespace
 
+// In-place ops over the kernel launchers themselves, one per entry point, generated from the header
+// (tools/gen_torch_abi_ops.py): what the hot loop calls when A2C_TORCH_OPS=1 (a2c_amd/ops.py: TorchAbi).
+#include "torch_ops_abi.inc"
+
 TORCH_LIBRARY(a2c_mi355x, m) {
+  A2C_ABI_OPS_DEF(m);
   m.def("discount(Tensor x, Tensor dones, float g, int n_seg=1) -> Tensor");
   m.def("gae_returns(Tensor deltas, Tensor rewards, Tensor dones, float g_adv, float g_ret, int n_seg) -> (Tensor, Tensor)");
   m.def("softmax_sample(Tensor logits, Tensor u) -> Tensor");
@@ -293,6 +298,7 @@ TORCH_LIBRARY(a2c_mi355x, m) {
 }
 
 TORCH_LIBRARY_IMPL(a2c_mi355x, CUDA, m) {      // "CUDA" is the HIP dispatch key on PyTorch-ROCm; no CPU implementation exists
+  A2C_ABI_OPS_IMPL(m);
   m.impl("discount", &discount);
   m.impl("gae_returns", &gae_returns);
   m.impl("softmax_sample", &softmax_sample);

@@ -105,3 +105,30 @@ def test_torch_library_ops_are_registered_without_cpu_kernels():
         assert hasattr(o, name), name
     with pytest.raises(NotImplementedError):
         o.discount(torch.zeros(4), torch.zeros(4), 0.9, 1)
+
+
+def test_generated_abi_ops_are_current_and_registered():
+    """csrc/torch_ops_abi.inc is generated from the header (tools/gen_torch_abi_ops.py): the committed file is what the
+    generator writes today, and every kernel-launching entry point it covers is a registered torch op (HIP key only)"""
+    import importlib.util
+    import sys
+    import torch
+    from a2c_amd import _lib, ops
+    gen_path = os.path.join(ROOT, "tools", "gen_torch_abi_ops.py")
+    assert subprocess.run([sys.executable, gen_path, "--check"]).returncode == 0
+    spec = importlib.util.spec_from_file_location("_gen_abi", gen_path)
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    planned, skipped = gen.plan()
+    o = ops.load_torch_ops()
+    names = [n for n, _, _ in planned]
+    assert len(names) >= 55 and set(names) | set(skipped) <= set(_lib.SIGNATURES)
+    for n in ("a2c_gae_returns_fused", "a2c_loss_fwd_bwd", "a2c_gemm_f32", "a2c_conv2d_bwd_data", "a2c_conv2d_bwd_weight",
+              "a2c_conv2d_bwd_data_lanemask", "a2c_clip_rmsprop", "a2c_clip_adam", "a2c_gru_cell_bwd", "a2c_layernorm_bwd"):
+        assert n in names, n
+    for n, params, kinds in planned:
+        assert hasattr(o, "abi_" + n[4:]), n
+        # the ctypes table and the header agree on how many parameters there are (+ the stream)
+        assert len(_lib.SIGNATURES[n][1]) == len(params) + 1, n
+    with pytest.raises(NotImplementedError):
+        o.abi_add([torch.zeros(4), torch.zeros(4), torch.zeros(4)], [0, 0, 0], [4], [])

@@ -842,13 +842,10 @@ def test_conv2d_streaming_backward_data_matches_tiled_kernel(monkeypatch, with_m
 
 
 def _lanemask_ref(act):
-    """(B, n) float -> (B, n/64) int64: per run g of 64 float4, words [x, y, z, w], bit l of word c = act[4 (64 g + l) + c] > 0
+    """(B, n) float -> (B, n/64) int64: bit (i & 7) of byte (i >> 3) of a row = (act[i] > 0)
     (include/a2c_mi355x.h: a2c_conv2d_bwd_data_lanemask)"""
-    B, n = act.shape
-    bits = (act > 0).reshape(B, n // 256, 64, 4).permute(0, 1, 3, 2).to(torch.int64)          # (B, run, c, l)
-    sh = torch.arange(64, dtype=torch.int64)
-    lo = (bits[..., :63] << sh[:63]).sum(-1)
-    return (lo | torch.where(bits[..., 63] > 0, torch.tensor(-2 ** 63), torch.tensor(0))).reshape(B, n // 64)
+    bits = np.packbits((act > 0).numpy().astype(np.uint8), axis=1, bitorder="little")
+    return torch.from_numpy(bits.copy().view(np.int64))
 
 
 @pytest.mark.parametrize("B", [2048 + 55, 4096])

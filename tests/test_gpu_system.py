@@ -378,3 +378,69 @@ def test_bench_world2_a3c_ring_with_two_env_threads_per_rank():
     full = json.load(open(os.path.join(root, d["full_report"])))
     assert all(np.isfinite(v) for v in full["last_info"].values()), full["last_info"]
     assert d["roofline"]["kernel"].startswith("a3c_ring_kernel")
+
+
+# ---------------------------------------------------------------------------------------------- the update through torch.ops
+@pytest.mark.parametrize("name", ["a3c_rms", "a3c_adam", "conv_small_rms", "gru_bptt_rms", "fc_cartpole_rms", "grufc_bptt_rms"])
+def test_eager_update_through_torch_custom_ops_is_bit_identical(name, monkeypatch):
+    """north_star / SURVEY 8b: "called from Python through PyTorch-ROCm custom ops".  A2C_TORCH_OPS=1 routes every kernel launch
+    of the eager Updater.update_model (scans, moments, loss, every conv / GEMM / GRU / LayerNorm pass, clip + optimiser, the
+    re-derivation of the inference weights) through torch.ops.a2c_mi355x.abi_<entry point> -- one in-place op per launcher of
+    include/a2c_mi355x.h, generated from the header, taking (owning tensor, byte offset) for every pointer -- instead of the
+    ctypes binding.  Same C function, same arguments: the two updates of each g6 case leave bit-identical infos, gradient
+    arenas and parameters; no launch of the update falls back to ctypes and no address goes unresolved."""
+    from a2c_amd import ops
+    from a2c_amd.updater import Updater
+    from cases import UPDATE_CASES, synth_shared
+    case = next(c for c in UPDATE_CASES if c[0] == name)
+    _, kind, ss, A, h, R_, T, opt, norm_advs, nstep, use_bptt, n_upd = case
+    res = {}
+    for mode in ("ctypes", "torch_ops"):
+        if mode == "torch_ops":
+            monkeypatch.setenv("A2C_TORCH_OPS", "1")
+            ab = ops.torch_abi()
+            ab.stats.update(torch_ops=0, ctypes=0, by_name={}, unresolved={})
+        net = make_net(kind, ss, A, h)
+        hyps = base_hyps(n_tsteps=T, n_rollouts=R_, optim_type=opt, norm_advs=norm_advs, use_nstep_rets=nstep, use_bptt=use_bptt,
+                         h_size=h)
+        upd = Updater(net, hyps)
+        out = []
+        for u in range(n_upd):
+            D = {k: v.to(DEV) for k, v in synth_shared(kind, ss, A, h, R_, T, seed=700 + 10 * u, recurrent=net.is_recurrent).items()}
+            info = upd.update_model(D)
+            torch.cuda.synchronize()
+            out.append((dict(info), net._arena.grads.cpu().clone(), net._arena.params.cpu().clone()))
+        res[mode] = out
+    monkeypatch.delenv("A2C_TORCH_OPS")
+    st = ops.torch_abi().stats
+    assert st["unresolved"] == {} and st["ctypes"] == 0, st
+    assert st["torch_ops"] >= 10 * n_upd and "a2c_gae_returns_fused" in st["by_name"] and "a2c_loss_fwd_bwd" in st["by_name"], st
+    assert any(k.startswith("a2c_clip_") for k in st["by_name"]) and any(k.startswith("a2c_gemm") for k in st["by_name"]), st
+    for (ia, ga, pa), (ib, gb, pb) in zip(res["ctypes"], res["torch_ops"]):
+        assert ia == ib, (ia, ib)
+        assert torch.equal(ga, gb) and torch.equal(pa, pb)
+    print(f"[torch ops] {name}: {st['torch_ops']} launches through torch.ops.a2c_mi355x.abi_*: "
+          + ", ".join(f"{k[4:]} x{v}" for k, v in sorted(st["by_name"].items())))
+
+
+def test_torch_abi_ops_validate_their_arguments():
+    """the generated ops refuse CPU tensors, offsets outside the owning tensor and wrong argument counts, and surface the
+    launcher's own error codes"""
+    from a2c_amd import ops
+    o = ops.load_torch_ops()
+    x = torch.arange(8, dtype=torch.float32, device=DEV)
+    y = torch.zeros(8, device=DEV)
+    o.abi_add([x, x, y], [0, 0, 0], [8], [])
+    torch.cuda.synchronize()
+    assert torch.equal(y, 2 * x)
+    o.abi_add([x, x, y], [16, 0, 16], [4], [])                  # rows of larger buffers: byte offsets
+    torch.cuda.synchronize()
+    assert torch.equal(y[4:], x[4:] + x[:4])
+    with pytest.raises(RuntimeError):
+        o.abi_add([x, x, y], [0, 0, 64], [8], [])               # offset outside the tensor
+    with pytest.raises(RuntimeError):
+        o.abi_add([x, x], [0, 0], [8], [])                      # wrong number of buffers
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        o.abi_add([x.cpu(), x.cpu(), y.cpu()], [0, 0, 0], [8], [])
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        o.abi_discount_scan([x, x, y, torch.empty(0, device=DEV)], [0, 0, 0, 0], [-1, 4], [0.9])

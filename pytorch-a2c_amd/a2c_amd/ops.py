@@ -75,7 +75,7 @@ class TorchAbi:
         self._keep[base] = flat             # (the view keeps the storage alive: opt-in debugging / boundary mode only)
         self._refs[base] = (weakref.ref(flat), nb)
 
-    def _find(self, addr):
+    def _lookup(self, addr):
         import bisect
         i = bisect.bisect_right(self._bases, addr) - 1
         if i < 0:
@@ -86,6 +86,25 @@ class TorchAbi:
         if t is None or addr >= base + nb:
             return None
         return t, addr - base
+
+    def _find(self, addr):
+        hit = self._lookup(addr)
+        if hit is None:
+            # an address this module was never handed as a tensor (a buffer a model allocated itself and passes as
+            # data_ptr() + offset): find the live HIP tensor whose storage contains it -- once per storage, then it is noted
+            import gc
+            for obj in gc.get_objects():
+                try:
+                    if isinstance(obj, torch.Tensor) and obj.is_cuda:
+                        st = obj.untyped_storage()
+                        b = st.data_ptr()
+                        if b <= addr < b + st.nbytes():
+                            self.note(obj)
+                            break
+                except Exception:      # noqa: BLE001  (tensors without storage, objects that refuse isinstance)
+                    continue
+            hit = self._lookup(addr)
+        return hit
 
     def _nul(self, dev):
         t = self._null.get(dev)

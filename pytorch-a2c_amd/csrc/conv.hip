@@ -2820,7 +2820,15 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int r = p0 / p.OW, c = p0 - r * p.OW;
     adst[u] = ok ? co * PA + (r * NG + (c >> 3)) * 8 + (c & 7) : -1;
   }
-  long n = blockIdx.x;
+  // Samples in CONTIGUOUS runs per workgroup (round 6; was n = blockIdx.x + k * gridDim.x): sample n + 1 of a slot shares
+  // three of its four frames with sample n, so the workgroup that just fetched them finds them in its XCD's L2 -- with the
+  // strided deal the four samples that share a frame ran on four different XCDs and every frame crossed the fabric four times
+  // (PMC: 1.77 GB per launch against 1.07 GB of frames + dOut).  A2C_WSB_STRIDED=1 (gq.dbg bit 2) keeps the strided deal.
+  const bool strided = (gq.dbg & 4) != 0;
+  const long chunk = (p.B + gridDim.x - 1) / gridDim.x;
+  const long nstep = strided ? (long)gridDim.x : 1L;
+  long n = strided ? (long)blockIdx.x : (long)blockIdx.x * chunk;
+  const long n_end = strided ? (long)p.B : (n + chunk < (long)p.B ? n + chunk : (long)p.B);
 #define WSB_LDU(var, u, src)                                                                                   \
   {                                                                                                            \
     const unsigned int* s_ = reinterpret_cast<const unsigned int*>((src) + soff[u]);                            \
@@ -2869,9 +2877,9 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     d_[2 * ps_] = __builtin_amdgcn_perm(__float_as_uint((float)((x1_ >> 16) & 0xffu)), __float_as_uint((float)((x0_ >> 16) & 0xffu)), 0x07060302u); \
     d_[3 * ps_] = __builtin_amdgcn_perm(__float_as_uint((float)(x1_ >> 24)), __float_as_uint((float)(x0_ >> 24)), 0x07060302u); \
   }
-  if (n < p.B) WSB_LOAD(n)
-  for (; n < p.B; n += gridDim.x) {
-    const long nn = (n + gridDim.x < p.B) ? n + gridDim.x : n;        // past the end: re-read this sample (discarded)
+  if (n < n_end) WSB_LOAD(n)
+  for (; n < n_end; n += nstep) {
+    const long nn = (n + nstep < n_end) ? n + nstep : n;              // past the end: re-read this sample (discarded)
     __syncthreads();                                 // everyone is done with the previous sample (and with the zero fill)
     if (!(gq.dbg & 2)) {
     WSB_STD(d0, 0) WSB_STD(d1, 1) WSB_STD(d2, 2) WSB_STD(d3, 3)
@@ -2951,7 +2959,8 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
 static bool plan_wstream_bf16(const a2c_conv_desc* d, const WstreamP& p, WsbGeo& gq, size_t& lds) {
   gq.NG = (d->OW + 7) / 8;
-  gq.dbg = getenv("A2C_WSB_DBG") ? atoi(getenv("A2C_WSB_DBG")) : 0;
+  gq.dbg = getenv("A2C_WSB_DBG") ? atoi(getenv("A2C_WSB_DBG")) & 3 : 0;
+  { const char* sd = getenv("A2C_WSB_STRIDED"); if (sd && sd[0] == '1') gq.dbg |= 4; }
   gq.NGT = d->OH * gq.NG;
   gq.NB = (gq.NGT + 3) / 4;
   const int need_dw = gq.NB * 16;                      // dwords of one channel's groups (8 bf16 = 4 dwords each)

@@ -327,6 +327,9 @@ typedef struct {
    * of the 25.6 KB activation row as its ReLU mask, updater.py:128's autograd).  A2C_ERR_ARG when the launch cannot run as
    * the ring kernel (ask a2c_a3c_ring_supported first) or 16*OH1*OW1 is not a multiple of 256.                         */
   uint64_t *a1_lanemask_rows;
+  /* ... and, with a2_rows, the mask bits of the a2 stash rows: F/8 bytes per state (F = 32*OH2*OW2, a multiple of 8), bit
+   * (i & 7) of byte (i >> 3) = (a2[i] > 0).  Consumer: a2c_small_n_bwd_data_bits.  Ring kernel only, like the field above. */
+  uint8_t *a2_maskbit_rows;
 } a2c_a3c_rollout_args;
 int a2c_a3c_rollout(const a2c_a3c_rollout_args *args, a2c_stream_t stream);
 /* 1 when a2c_a3c_rollout with these shapes, this many envs and this conv1_weight pointer runs the ring kernel (the only
@@ -424,6 +427,15 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
 /* Split-K phase only: writes `a2c_gemm_splits(K, splitk)` partial slabs [split][M][N] (dense,
  * no epilogue) into ws and leaves the fixed-order sum to the consumer (a2c_heads_fused).   */
 int a2c_gemm_splits(int64_t K, int splitk);
+/* dx[m, k] = (sum_{n < N} dy[m*ldy + n] * W[n*K + k]) * bit(m, k), N <= 8: the skinny input-gradient product of
+ * a2c_gemm_f32 (transA = transB = 0, K <= 8 there) with the ReLU mask of the layer below given as ONE BIT per activation
+ * -- bit (k & 7) of byte maskbits[m*mask_row_bytes + (k >> 3)] = (act[m][k] > 0) -- instead of the fp32 activation itself
+ * (A3CModel's da2 = (dl . Wc[:A]) * (a2 > 0), models.py:73-85 through autograd: 340 MB of mask reads per update become
+ * 10 MB).  The same FMA order as a2c_gemm_f32's path: bit-identical results.  K % 8 == 0, ldx % 4 == 0, W and dx 16-byte
+ * aligned.  Producer of the bits: a2c_a3c_rollout's ring kernel (a2_maskbit_rows).                                  */
+int a2c_small_n_bwd_data_bits(const float *dy, int64_t ldy, const float *W, float *dx, int64_t ldx,
+                              const uint8_t *maskbits, int64_t mask_row_bytes, int64_t M, int N, int64_t K,
+                              a2c_stream_t stream);
 int a2c_gemm_f32_partial(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A,
                          int64_t lda, const float *B, int64_t ldb, int splitk, void *ws,
                          size_t ws_bytes, a2c_stream_t stream);

@@ -48,7 +48,8 @@ class A3CRolloutArgs(Structure):
                 ("seq0", c_uint32), ("env0", c_int), ("err", P), ("timeout_ticks", c_int64), ("a1_rows", P), ("a2_rows", P), ("heads_rows", P), ("heads_rows_ld", c_int64),
                 ("frame_store", P), ("frame_store_slot_stride", c_int64), ("nvalid_rows", P), ("nvalid_carry", P),
                 ("frame_bits", c_int), ("conv1_weight", P), ("states_lazy", c_int),
-                ("tagged", P), ("tagged_stride", c_int64), ("tagged_chunks", c_int), ("a1_lanemask_rows", P)]
+                ("tagged", P), ("tagged_stride", c_int64), ("tagged_chunks", c_int), ("a1_lanemask_rows", P),
+                ("a2_maskbit_rows", P)]
 
 
 PS = POINTER(A3CStepArgs)
@@ -94,6 +95,7 @@ SIGNATURES = {
     "a2c_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64,
                               P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
     "a2c_gemm_splits": (c_int, [c_int64, c_int]),
+    "a2c_small_n_bwd_data_bits": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int64, c_int, c_int64, P]),
     "a2c_gemm_f32_partial": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, c_int, P, c_size_t, P]),
     "a2c_heads_fused": (c_int, [P, c_int, c_int64, c_int64, P, c_int, P, c_int64, P, P, P, c_int64, c_int64, c_int, c_int,
                                  P, c_int, P, c_int64, P]),

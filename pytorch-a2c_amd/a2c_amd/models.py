@@ -313,7 +313,15 @@ class A3CModel(_HipNet):
         # + the heads [logits | value] of every state: the rollout computed them through the composed matrix
         # Wc = [pi;value].proj_matrx, so the update needs neither the 2592 -> 256 forward GEMM nor the embedding
         return (ws.get("a1", (n_rows,) + self._c1.out_shape), ws.get("a2", (n_rows,) + self._c2.out_shape),
-                self._heads("train", n_rows)[0], self._a1_lanemask_rows(n_rows))
+                self._heads("train", n_rows)[0], self._a1_lanemask_rows(n_rows), self._a2_maskbit_rows(n_rows))
+
+    def _a2_maskbit_rows(self, n_rows):
+        """(n_rows, F/8) uint8: mask bits of the a2 stash rows (include/a2c_mi355x.h: a2_maskbit_rows), written by the ring
+        kernel; da2 = (dl . Wc) * (a2 > 0) then reads 324 B per sample instead of the 10.4 KB row (a2c_small_n_bwd_data_bits)"""
+        F = self.flat_size
+        if os.environ.get("A2C_NO_LANEMASK") == "1" or F % 8 or self.output_space + 1 > 8:
+            return None
+        return self.ws("train").get("a2_mb", (n_rows, F // 8), dtype=torch.uint8)
 
     def _a1_lanemask_rows(self, n_rows):
         """(n_rows, 16*OH1*OW1/64) int64: lane masks of the a1 stash rows (include/a2c_mi355x.h: a1_lanemask_rows), which the
@@ -451,8 +459,15 @@ class A3CModel(_HipNet):
                 with ops.side_branch(0):
                     head_grads(ops.stream())
                 with ops.span("rank_bwd da2"):
-                    ops.gemm(0, 0, B, F, A, dl.data_ptr(), dl.stride(0), self._Wc.data_ptr(), F, da2.data_ptr(), F,
-                             mask_ptr=a2.data_ptr(), ldmask=F, st=st)
+                    mb = None
+                    if (tag == "train" and getattr(self, "_stash_lm", False) and self._stash_valid(x_ptr, B)
+                            and os.environ.get("A2C_NO_LANEMASK") != "1"):
+                        mb = self._a2_maskbit_rows(B)       # the ring kernel left (a2 > 0) as bits beside the stash
+                    if mb is not None:
+                        ops.small_n_bwd_data_bits(dl, dl.stride(0), self._Wc, da2, F, mb, B, A, F, st)
+                    else:
+                        ops.gemm(0, 0, B, F, A, dl.data_ptr(), dl.stride(0), self._Wc.data_ptr(), F, da2.data_ptr(), F,
+                                 mask_ptr=a2.data_ptr(), ldmask=F, st=st)
             else:
                 head_grads(st)
                 demb = ws.get("demb", (B, h))

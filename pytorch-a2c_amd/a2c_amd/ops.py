@@ -805,6 +805,14 @@ def conv_bwd_data_signs(d, dout, wprep_bwd, signs, din, B, st=None):
                                           st if st is not None else stream()), "a2c_conv2d_bwd_data_signs")
 
 
+def small_n_bwd_data_bits(dy, ldy, W, dx, ldx, maskbits, M, N, K, st=None):
+    """dx[m, :K] = (dy[m, :N] . W[:N, :K]) * bit(m, k) with the ReLU mask as one bit per activation ((M, K/8) uint8 rows):
+    a2c_small_n_bwd_data_bits (A3CModel's da2 from the ring kernel's a2 mask bits)"""
+    _chk(dy, "dy", contig=False); _chk(W, "W"); _chk(dx, "dx"); _chk(maskbits, "maskbits", torch.uint8)
+    check(lib().a2c_small_n_bwd_data_bits(_p(dy), ldy, _p(W), _p(dx), ldx, _p(maskbits), maskbits.stride(0), M, N, K,
+                                          st if st is not None else stream()), "a2c_small_n_bwd_data_bits")
+
+
 def lanemask_from_act(act, lanemask, st=None):
     """lane masks (include/a2c_mi355x.h: a2c_conv2d_bwd_data_lanemask) of a float activation tensor -> (rows, n/64) int64"""
     _chk(act, "act"); _chk(lanemask, "lanemask", torch.int64)

@@ -920,6 +920,7 @@ class Runner:
         lazy = fs is not None and bool(try_key(hyps, "lazy_states", False)) and ring
         # ... and only the ring kernel writes the lane masks of the a1 stash rows (the update's conv2 backward-data mask)
         lm = self._stash_bufs[3] if (ring and self._stash_bufs is not None and len(self._stash_bufs) > 3) else None
+        mb = self._stash_bufs[4] if (lm is not None and len(self._stash_bufs) > 4) else None
         ops.a3c_rollout(st, B=B, C=C, H=H, W=W, n_actions=net.output_space, states=D["states"].data_ptr(),
                         bookmark=bm.data_ptr(), wfrag1=net._c1.wf.data_ptr(), bias1=P("convs.0.0.bias").data_ptr(),
                         wfrag2=net._c2.wf.data_ptr(), bias2=P("convs.1.0.bias").data_ptr(), Wc=net._Wc.data_ptr(),
@@ -940,7 +941,8 @@ class Runner:
                         nvalid_rows=0 if fs is None else fs[1].data_ptr(),
                         nvalid_carry=0 if fs is None else fs[2][env0:env0 + B].data_ptr(), states_lazy=int(lazy),
                         tagged=getattr(pool, "dev_tagged", 0), tagged_stride=int(pool.header.tagged_stride),
-                        tagged_chunks=int(pool.header.tagged_chunks), a1_lanemask_rows=0 if lm is None else lm.data_ptr())
+                        tagged_chunks=int(pool.header.tagged_chunks), a1_lanemask_rows=0 if lm is None else lm.data_ptr(),
+                        a2_maskbit_rows=0 if mb is None else mb.data_ptr())
         # every block of the call must have written them (a rollout of several blocks: all ring launches, or none counts)
         self._lm_written = (lm is not None) and (getattr(self, "_lm_written", False) or slot0 == 0)
         if lazy:            # (only after the launch was accepted: a refused call must not leave rows marked stale)

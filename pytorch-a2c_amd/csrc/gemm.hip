@@ -948,6 +948,40 @@ __global__ __launch_bounds__(256) void small_n_bwd_data_kernel(const float* __re
   }
 }
 
+// the same product with the mask as one bit per activation (include/a2c_mi355x.h: a2c_small_n_bwd_data_bits): a thread owns 8
+// consecutive columns = one mask byte; per column the FMA chain of small_n_bwd_data_kernel (n ascending): bit-identical
+__global__ __launch_bounds__(256) void small_n_bwd_data_bits_kernel(const float* __restrict__ dy, long ldy,
+                                                                    const float* __restrict__ W, float* __restrict__ dx,
+                                                                    long ldx, const unsigned char* __restrict__ mb,
+                                                                    long mb_row, long M, int N, int K) {
+  const int k8 = K >> 3;
+  const long tot = M * k8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < tot; i += gridDim.x * 256L) {
+    const long m = i / k8;
+    const int kb = (int)(i - m * k8), k = kb << 3;
+    const unsigned int bits = mb[m * mb_row + kb];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    for (int n = 0; n < N; ++n) {
+      const float g = dy[m * ldy + n];
+      const float4 w0 = *reinterpret_cast<const float4*>(W + (long)n * K + k);
+      const float4 w1 = *reinterpret_cast<const float4*>(W + (long)n * K + k + 4);
+      a.x += g * w0.x; a.y += g * w0.y; a.z += g * w0.z; a.w += g * w0.w;
+      b.x += g * w1.x; b.y += g * w1.y; b.z += g * w1.z; b.w += g * w1.w;
+    }
+    if (!(bits & 1u)) a.x = 0.f;
+    if (!(bits & 2u)) a.y = 0.f;
+    if (!(bits & 4u)) a.z = 0.f;
+    if (!(bits & 8u)) a.w = 0.f;
+    if (!(bits & 16u)) b.x = 0.f;
+    if (!(bits & 32u)) b.y = 0.f;
+    if (!(bits & 64u)) b.z = 0.f;
+    if (!(bits & 128u)) b.w = 0.f;
+    float4* o = reinterpret_cast<float4*>(dx + m * ldx + k);
+    o[0] = a;
+    o[1] = b;
+  }
+}
+
 // dW[n, k] = sum_m dy[m, n] x[m, k]: each workgroup owns a band of rows and all of (N, K<=1024)
 // with thread t holding columns k = 4t..4t+3; partial slabs [band][N][K] + fixed-order reduce.
 constexpr int SN_BANDS = 512;
@@ -1290,6 +1324,17 @@ size_t a2c_gemm_x9_ws_bytes(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 1 || K < 1 || !x9_eligible(M, N, K)) return 0;
   const size_t Mp = (size_t)(M + 127) / 128 * 128, Np = (size_t)(N + 127) / 128 * 128, Kp = (size_t)(K + 31) / 32 * 32;
   return 3 * 2 * (Mp + Np) * Kp + 256;
+}
+
+int a2c_small_n_bwd_data_bits(const float* dy, int64_t ldy, const float* W, float* dx, int64_t ldx, const uint8_t* maskbits,
+                              int64_t mask_row_bytes, int64_t M, int N, int64_t K, a2c_stream_t stream) {
+  if (M < 0 || N < 1 || N > SN_MAX || K < 0 || K % 8 || ldx % 4 || ldx < K || ldy < N || mask_row_bytes < K / 8) return A2C_ERR_ARG;
+  if (M == 0 || K == 0) return A2C_OK;
+  if (!dy || !W || !dx || !maskbits || ((uintptr_t)W % 16) || ((uintptr_t)dx % 16)) return A2C_ERR_ARG;
+  hipLaunchKernelGGL(small_n_bwd_data_bits_kernel, dim3(a2c_grid_1d(M * (K / 8), 256)), dim3(256), 0, a2c_s(stream), dy, (long)ldy,
+                     W, dx, (long)ldx, maskbits, (long)mask_row_bytes, (long)M, N, (int)K);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
 }
 
 int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,

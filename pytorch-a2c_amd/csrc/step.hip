@@ -61,6 +61,7 @@ struct RolloutX {              // what a2c_a3c_rollout adds to the per-step argu
   float* a1_rows;
   float* a2_rows;
   unsigned long long* a1_lm;                       // ring kernel: lane masks of the a1 stash rows (a2c_conv2d_bwd_data_lanemask), or nullptr
+  unsigned char* a2_mb;                            // ring kernel: mask bits of the a2 stash rows (a2c_small_n_bwd_data_bits), or nullptr
   float* heads_rows; long heads_rows_ld;
   unsigned char* fstore; long fs_slot_stride;      // single-frame uint8 store (T+4 frames per slot)
   int* nvalid; int* nvalid_carry;
@@ -1254,9 +1255,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
       if (p.x.a2_rows != nullptr && t < T) {
         float* __restrict__ a2o = p.x.a2_rows + (row + t) * (long)p.F;
+        // (+ its mask bits: the update's da2 = (dl . Wc) * (a2 > 0) reads F / 8 bytes per sample instead of the row)
+        unsigned char* __restrict__ mbo = (p.x.a2_mb != nullptr && (p.F & 7) == 0) ? p.x.a2_mb + (row + t) * (long)(p.F >> 3) : nullptr;
         for (int q = sid; q < (p.F >> 2); q += sn) {
           const float4 v = *reinterpret_cast<const float4*>(a2 + (q << 2));
           __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a2o) + q);
+          if (mbo != nullptr) {
+            const unsigned int nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            const unsigned int hi = __shfl_xor(nib, 1);           // (F / 4 is even: a lane and its partner run the same trips)
+            if (!(q & 1)) mbo[q >> 1] = (unsigned char)(nib | (hi << 4));
+          }
         }
       }
     }
@@ -1448,6 +1456,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
   p.x.seq0 = r->seq0; p.x.env0 = r->env0; p.x.err = r->err; p.x.timeout_ticks = (long)r->timeout_ticks;
   p.x.a1_rows = r->a1_rows; p.x.a2_rows = r->a2_rows;
   p.x.a1_lm = (r->a1_rows != nullptr) ? (unsigned long long*)r->a1_lanemask_rows : nullptr;
+  p.x.a2_mb = (r->a2_rows != nullptr) ? r->a2_maskbit_rows : nullptr;
   p.x.heads_rows = r->heads_rows; p.x.heads_rows_ld = (long)r->heads_rows_ld;
   p.x.fstore = r->frame_store; p.x.fs_slot_stride = (long)r->frame_store_slot_stride;
   p.x.nvalid = r->nvalid_rows; p.x.nvalid_carry = r->nvalid_carry;
@@ -1482,6 +1491,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
     return A2C_ERR_ARG;
   if ((r->a1_rows || r->a2_rows) && ((p.OH1 * p.OW1) % 4 || (((uintptr_t)r->a1_rows | (uintptr_t)r->a2_rows) % 16))) return A2C_ERR_ARG;
   if (r->a1_lanemask_rows && (!r->a1_rows || ((uintptr_t)r->a1_lanemask_rows % 8) || (16 * p.OH1 * p.OW1) % 256)) return A2C_ERR_ARG;
+  if (r->a2_maskbit_rows && (!r->a2_rows || p.F % 8)) return A2C_ERR_ARG;
   if ((((uintptr_t)r->states | (uintptr_t)r->bookmark | (uintptr_t)r->frames | (uintptr_t)a.wfrag2 | (uintptr_t)a.Wc) % 16) ||
       (((uintptr_t)r->cmd | (uintptr_t)r->rec) % 8))
     return A2C_ERR_ARG;
@@ -1514,7 +1524,7 @@ int a2c_a3c_rollout(const a2c_a3c_rollout_args* r, a2c_stream_t stream) {
     }
     return A2C_OK;
   }
-  if (p.x.states_lazy || p.x.a1_lm) return A2C_ERR_ARG;      // only the ring kernel can leave the fp32 rows out / writes lane masks
+  if (p.x.states_lazy || p.x.a1_lm || p.x.a2_mb) return A2C_ERR_ARG;      // only the ring kernel can leave the fp32 rows out / writes mask bits
   const size_t lds = step_lds(p);
   // one workgroup per CU at most (157 KB of LDS each): all of them resident, envs beyond that take turns
   const int grid = a.B < cus ? a.B : cus;

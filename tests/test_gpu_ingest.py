@@ -534,9 +534,10 @@ def test_ingest_with_post_equals_ingest_then_post(bits, recurrent, t):
 
 
 def test_ring_kernel_leaves_lane_masks_and_the_update_reads_them(monkeypatch):
-    """round 6: beside its a1 stash rows the ring kernel writes their LANE MASKS (include/a2c_mi355x.h: a1_lanemask_rows); the
-    update's conv2 backward-data takes those 800 B per sample as its ReLU mask instead of the 25.6 KB activation row
-    (a2c_conv2d_bwd_data_lanemask).  64 envs x 32 steps (2,048 rows: the streaming kernel's smallest batch): the masks the
+    """round 6: beside its a1 / a2 stash rows the ring kernel writes their MASK BITS (include/a2c_mi355x.h: a1_lanemask_rows,
+    a2_maskbit_rows); the update's conv2 backward-data takes 800 B per sample as its ReLU mask instead of the 25.6 KB
+    activation row (a2c_conv2d_bwd_data_lanemask), and da2 = (dl . Wc) * (a2 > 0) 324 B instead of 10.4 KB
+    (a2c_small_n_bwd_data_bits).  64 envs x 32 steps (2,048 rows: the streaming kernel's smallest batch): the masks the
     kernel wrote == a2c_lanemask_from_act of the stashed activations, and the update's gradient arena and infos are
     bit-identical to the same update reading the float mask (A2C_NO_LANEMASK=1)."""
     from a2c_amd import ops
@@ -568,6 +569,10 @@ def test_ring_kernel_leaves_lane_masks_and_the_update_reads_them(monkeypatch):
                 ops.lanemask_from_act(a1, want)
                 torch.cuda.synchronize()
                 assert torch.equal(lm, want) and int((lm != 0).sum()) > 0
+                a2 = ws.get("a2", (B * T,) + net._c2.out_shape)
+                mb = ws.get("a2_mb", (B * T, net.flat_size // 8), dtype=torch.uint8)
+                bits = np.packbits((a2.reshape(B * T, -1) > 0).cpu().numpy().astype(np.uint8), axis=1, bitorder="little")
+                assert np.array_equal(mb.cpu().numpy(), bits) and int(bits.sum()) > 0
             info = Updater(net, hyps).update_model(D)
             res[mode] = (info, net._arena.train_grads().cpu().clone())
         finally:

@@ -884,6 +884,29 @@ def test_conv2d_streaming_backward_data_with_lane_masks(monkeypatch, B):
     assert not bool(torch.isnan(got).any())
 
 
+@pytest.mark.parametrize("M,N", [(257, 3), (4096, 4), (5, 8)])
+def test_small_n_bwd_data_with_mask_bits_equals_the_float_mask_path(M, N):
+    """a2c_small_n_bwd_data_bits (A3CModel's da2 = (dl . Wc[:A]) * (a2 > 0) from the ring kernel's a2 mask bits) == the same
+    product through a2c_gemm_f32 with the fp32 activation as the mask, bit for bit; strided dy rows (dl is a view of [dl | dv])"""
+    ops = _ops()
+    K = 2592
+    gen = torch.Generator().manual_seed(15)
+    dyb = (torch.rand(M, N + 1, generator=gen) - 0.5).to(DEV)
+    W = (torch.rand(N, K, generator=gen) - 0.5).to(DEV)
+    act = torch.relu(torch.rand(M, K, generator=gen) - 0.5)
+    act[0, :3] = torch.tensor([0.0, -0.0, float("nan")])
+    mb = torch.from_numpy(np.packbits((act > 0).numpy().astype(np.uint8), axis=1, bitorder="little")).to(DEV)
+    got = torch.full((M, K), float("nan"), device=DEV)
+    ops.small_n_bwd_data_bits(dyb[:, :N], dyb.stride(0), W, got, K, mb, M, N, K)
+    want = torch.full((M, K), float("nan"), device=DEV)
+    actd = act.to(DEV)
+    ops.gemm(0, 0, M, K, N, dyb.data_ptr(), dyb.stride(0), W.data_ptr(), K, want.data_ptr(), K, mask_ptr=actd.data_ptr(), ldmask=K)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and not bool(torch.isnan(got).any())
+    ref = (dyb[:, :N].double().cpu() @ W.double().cpu()) * (act > 0)
+    close("vs fp64", got, ref, 1e-6, 1e-5)
+
+
 # ------------------------------------------------------------------ GRU gates / LayerNorm
 def test_gru_kernels_vs_autograd():
     ops = _ops()

@@ -2792,7 +2792,10 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
   for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dbv[4] = {0.f, 0.f, 0.f, 0.f};           // bias gradient: this thread's dOut quads belong to fixed channels
-  float4 d0 = {}, d1 = {}, d2 = {}, d3 = {};
+  // (ext vectors, not HIP's float4 STRUCT: the struct is split into four scalars, the register allocator scatters the
+  // loop-carried scalars, and the loop then ends in `s_waitcnt vmcnt(0)` + v_mov copies of the quad a load has to write
+  // contiguously -- a wait for the prefetch right behind its issue, in every version of this kernel up to round 5)
+  f32x4 d0 = {}, d1 = {}, d2 = {}, d3 = {};
   uint2 g0 = {}, g1 = {}, g2 = {}, g3 = {}, g4 = {}, g5 = {}, g6 = {}, g7 = {};
   int nv = 4;
   auto fsrc = [&](long nn_) { const long r_ = nn_ / p.T; return p.fstore + r_ * p.fs_slot_stride + (nn_ - r_ * p.T) * (long)HW; };
@@ -2810,6 +2813,27 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     sdst[u] = ok ? (c * 4) * PLS + row * PP + (row >> 2) * SK + 2 * sp : -1;
     smask[u] = ((2 * sp + 1 < w4) ? 0xffffff00u : 0u) | (unsigned int)c;      // low byte: the plane (zero planes of a fresh episode)
   }
+  // THE PLANES STAY IN LDS (round 6).  Sample n + 1 of a slot is sample n with its oldest plane dropped and one new frame
+  // (utils.py:26-43), and a workgroup walks a contiguous run of samples: the four plane slots of P are a RING -- logical
+  // plane c of the current sample lives in slot (c + rot) & 3 --, a successor sample loads and commits ONE frame (two slots
+  // per thread instead of eight: 7 KB instead of 28 KB through the CU's load path, a quarter of the byte -> bf16 commit), and
+  // the matrix phase reads plane c at pofs[c].  A sample that starts a slot or a run, or whose state has fewer than four
+  // real planes (a fresh episode: nvalid < 4), or whose predecessor had fewer than three, is loaded and committed whole, as
+  // before.  Same sums in the same order: bit-identical to A2C_WSB_NO_RING=1 (test_gpu_frames.py).
+  int soff2[2], sdst2[2];                        // the NEWEST plane only: slot u = (row, dword pair) of logical plane 3
+  unsigned int smask2[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + u * ST_NT;
+    const bool ok = idx < p.H * spr;
+    const int ii = ok ? idx : 0;
+    const int row = ii / spr, sp = ii - row * spr;
+    soff2[u] = (3 * p.H + row) * p.W + 8 * sp;
+    sdst2[u] = ok ? row * PP + (row >> 2) * SK + 2 * sp : -1;
+    smask2[u] = (2 * sp + 1 < w4) ? 1u : 0u;
+  }
+  int rot = 0;                                   // slot of logical plane 0
+  int pofs0 = 0, pofs1 = 4 * PLS, pofs2 = 8 * PLS, pofs3 = 12 * PLS;     // element offset of logical plane c's four phase planes
   int adst[4];                                   // element offset of dOut quad u in piece image 0, or -1 (no division in the loop)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -2825,6 +2849,7 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   // strided deal the four samples that share a frame ran on four different XCDs and every frame crossed the fabric four times
   // (PMC: 1.77 GB per launch against 1.07 GB of frames + dOut).  A2C_WSB_STRIDED=1 (gq.dbg bit 2) keeps the strided deal.
   const bool strided = (gq.dbg & 4) != 0;
+  const bool ring_off = strided || (gq.dbg & 8) != 0;          // A2C_WSB_NO_RING=1: every sample loaded and committed whole
   const long chunk = (p.B + gridDim.x - 1) / gridDim.x;
   const long nstep = strided ? (long)gridDim.x : 1L;
   long n = strided ? (long)blockIdx.x : (long)blockIdx.x * chunk;
@@ -2835,14 +2860,35 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     var.x = s_[0];                                                                                             \
     var.y = s_[(smask[u] >> 8) ? 1 : 0];                                                                       \
   }
-#define WSB_LOAD(NN)                                                                                           \
+  // dOut rows are prefetched TWO samples ahead (two register sets d / e, the loop unrolled twice), the frames one: stamps of
+  // the one-deep version (A2C_WSB_DBG=1/2/3, tools/a3c_wgrad_bench.py) -- loads alone 0.27 ms, + matrix 0.18, + commit 0.15 =
+  // the whole kernel: a load issued at the head of a 1.4 us matrix phase comes back after ~3.5 us under this kernel's own
+  // bursts, so every sample waited ~2 us for its dOut.  (The frames of sample n + 1 are mostly L2 hits since the contiguous
+  // deal: one sample of lookahead covers them.)
+#define WSB_LOADD(NN, D0, D1, D2, D3)                                                                          \
   {                                                                                                            \
     const float* __restrict__ ds_ = p.dout + (NN) * (long)p.Cout * NP;                                         \
+    D0 = *reinterpret_cast<const f32x4*>(ds_ + (min(tid + 0 * ST_NT, dtot4 - 1) << 2));                        \
+    D1 = *reinterpret_cast<const f32x4*>(ds_ + (min(tid + 1 * ST_NT, dtot4 - 1) << 2));                        \
+    D2 = *reinterpret_cast<const f32x4*>(ds_ + (min(tid + 2 * ST_NT, dtot4 - 1) << 2));                        \
+    D3 = *reinterpret_cast<const f32x4*>(ds_ + (min(tid + 3 * ST_NT, dtot4 - 1) << 2));                        \
+  }
+#define WSB_LDU2(var, u, src)                                                                                  \
+  {                                                                                                            \
+    const unsigned int* s_ = reinterpret_cast<const unsigned int*>((src) + soff2[u]);                           \
+    var.x = s_[0];                                                                                             \
+    var.y = s_[smask2[u] ? 1 : 0];                                                                             \
+  }
+  // frames of sample NN: INC_ = it continues the sample in LDS (its newest frame only), else all four planes
+#define WSB_LOADG(NN, INC_)                                                                                    \
+  {                                                                                                            \
     const unsigned char* __restrict__ us_ = fsrc(NN);                                                          \
-    nv = p.nvalid[NN];                                                                                         \
-    WS_LDD(d0, 0, ds_) WS_LDD(d1, 1, ds_) WS_LDD(d2, 2, ds_) WS_LDD(d3, 3, ds_)                                \
-    WSB_LDU(g0, 0, us_) WSB_LDU(g1, 1, us_) WSB_LDU(g2, 2, us_) WSB_LDU(g3, 3, us_)                            \
-    WSB_LDU(g4, 4, us_) WSB_LDU(g5, 5, us_) WSB_LDU(g6, 6, us_) WSB_LDU(g7, 7, us_)                            \
+    if (INC_) {                                                                                                \
+      WSB_LDU2(g0, 0, us_) WSB_LDU2(g1, 1, us_)                                                                \
+    } else {                                                                                                   \
+      WSB_LDU(g0, 0, us_) WSB_LDU(g1, 1, us_) WSB_LDU(g2, 2, us_) WSB_LDU(g3, 3, us_)                          \
+      WSB_LDU(g4, 4, us_) WSB_LDU(g5, 5, us_) WSB_LDU(g6, 6, us_) WSB_LDU(g7, 7, us_)                          \
+    }                                                                                                          \
   }
   // dOut quad u of this thread (4 consecutive pixels of one output row, OW % 4 == 0) -> the three piece images
 #define WSB_STD(var, u)                                                                                        \
@@ -2877,16 +2923,7 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     d_[2 * ps_] = __builtin_amdgcn_perm(__float_as_uint((float)((x1_ >> 16) & 0xffu)), __float_as_uint((float)((x0_ >> 16) & 0xffu)), 0x07060302u); \
     d_[3 * ps_] = __builtin_amdgcn_perm(__float_as_uint((float)(x1_ >> 24)), __float_as_uint((float)(x0_ >> 24)), 0x07060302u); \
   }
-  if (n < n_end) WSB_LOAD(n)
-  for (; n < n_end; n += nstep) {
-    const long nn = (n + nstep < n_end) ? n + nstep : n;              // past the end: re-read this sample (discarded)
-    __syncthreads();                                 // everyone is done with the previous sample (and with the zero fill)
-    if (!(gq.dbg & 2)) {
-    WSB_STD(d0, 0) WSB_STD(d1, 1) WSB_STD(d2, 2) WSB_STD(d3, 3)
-    WSB_STU(g0, 0) WSB_STU(g1, 1) WSB_STU(g2, 2) WSB_STU(g3, 3) WSB_STU(g4, 4) WSB_STU(g5, 5) WSB_STU(g6, 6) WSB_STU(g7, 7)
-    }
-    __syncthreads();
-    WSB_LOAD(nn)                                     // the next sample: in flight during the matrix phase
+  auto matrix = [&]() {
     for (int b = (gq.dbg & 1) ? NB : w; b < NB; b += ST_NT / 64) {
       const int grp = 4 * b + g;
       const unsigned short* __restrict__ ap = A + j * PA + grp * 8;
@@ -2899,7 +2936,8 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int ci = t >> 2, kxh = (t >> 1) & 1, kp = t & 1;
-        const unsigned short* __restrict__ bx = bp + (ci * 4 + 2 * kp) * PLS;
+        const int po = ci == 0 ? pofs0 : ci == 1 ? pofs1 : ci == 2 ? pofs2 : pofs3;       // (the ring: logical plane ci's slot)
+        const unsigned short* __restrict__ bx = bp + po + 2 * kp * PLS;
         const uint2 lo = *reinterpret_cast<const uint2*>(bx), hi = *reinterpret_cast<const uint2*>(bx + 4);
         u32x4w o;
         if (kxh) {
@@ -2917,8 +2955,70 @@ __global__ __launch_bounds__(ST_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bv, acc[t], 0, 0, 0);
       }
     }
+  };
+  // the newest frame of a successor sample -> the slot its oldest plane just left (= logical plane 3 after the rotation)
+#define WSB_STU2(var, u, PB_)                                                                                  \
+  if (sdst2[u] >= 0) {                                                                                         \
+    const unsigned int x0_ = var.x, x1_ = smask2[u] ? var.y : 0u;                                              \
+    unsigned int* d_ = reinterpret_cast<unsigned int*>(P + (PB_) + sdst2[u]);                                  \
+    const int ps_ = PLS >> 1;                                                                                  \
+    d_[0] = __builtin_amdgcn_perm(__float_as_uint((float)(x1_ & 0xffu)), __float_as_uint((float)(x0_ & 0xffu)), 0x07060302u); \
+    d_[ps_] = __builtin_amdgcn_perm(__float_as_uint((float)((x1_ >> 8) & 0xffu)), __float_as_uint((float)((x0_ >> 8) & 0xffu)), 0x07060302u); \
+    d_[2 * ps_] = __builtin_amdgcn_perm(__float_as_uint((float)((x1_ >> 16) & 0xffu)), __float_as_uint((float)((x0_ >> 16) & 0xffu)), 0x07060302u); \
+    d_[3 * ps_] = __builtin_amdgcn_perm(__float_as_uint((float)(x1_ >> 24)), __float_as_uint((float)(x0_ >> 24)), 0x07060302u); \
   }
-#undef WSB_LOAD
+  // may sample b_ be built from sample a_ in LDS?  the next sample of the same slot, all four of its planes real frames
+  // (... and the three planes it shares with a_ are real frames THERE too: nvalid[a_] >= 3.  The rollout's counts always
+  // satisfy that -- the count grows by one per step --, an arbitrary nvalid array need not.)
+  auto succ = [&](long a_, long b_, int nva_, int nvb_) {
+    return !ring_off && b_ == a_ + 1 && (b_ % p.T) != 0 && nvb_ == 4 && nva_ >= 3;
+  };
+  // one sample: commit it (its dOut set D0..D3, its frames g0..g7), then -- in flight during the matrix phase -- the dOut of
+  // the sample two steps on into the set just freed and the frames of the next sample; past the end: re-read this sample
+#define WSB_ITER(N_, D0, D1, D2, D3)                                                                           \
+  {                                                                                                            \
+    const long n2_ = ((N_) + 2 * nstep < n_end) ? (N_) + 2 * nstep : (N_);                                     \
+    const long n1_ = ((N_) + nstep < n_end) ? (N_) + nstep : (N_);                                             \
+    __syncthreads();                                 /* everyone is done with the previous sample (and the zero fill) */ \
+    if (inc_cur) rot = (rot + 1) & 3; else rot = 0;                                                            \
+    pofs0 = rot * 4 * PLS; pofs1 = ((rot + 1) & 3) * 4 * PLS; pofs2 = ((rot + 2) & 3) * 4 * PLS; pofs3 = ((rot + 3) & 3) * 4 * PLS; \
+    if (!(gq.dbg & 2)) {                                                                                       \
+      WSB_STD(D0, 0) WSB_STD(D1, 1) WSB_STD(D2, 2) WSB_STD(D3, 3)                                              \
+      if (inc_cur) {                                                                                           \
+        WSB_STU2(g0, 0, pofs3) WSB_STU2(g1, 1, pofs3)                                                          \
+      } else {                                                                                                 \
+        WSB_STU(g0, 0) WSB_STU(g1, 1) WSB_STU(g2, 2) WSB_STU(g3, 3) WSB_STU(g4, 4) WSB_STU(g5, 5) WSB_STU(g6, 6) WSB_STU(g7, 7) \
+      }                                                                                                        \
+    }                                                                                                          \
+    __syncthreads();                                                                                           \
+    /* frames FIRST: loads retire in order, and the next commit needs them before this dOut */                 \
+    inc_cur = n1_ != (N_) && succ((N_), n1_, nv, nv1);                                                         \
+    nv = nv1;                                        /* nvalid of sample n1_ (fetched one iteration ago) */     \
+    WSB_LOADG(n1_, inc_cur)                                                                                    \
+    nv1 = p.nvalid[n2_];                                                                                       \
+    WSB_LOADD(n2_, D0, D1, D2, D3)                                                                             \
+    matrix();                                                                                                  \
+  }
+  f32x4 e0 = {}, e1 = {}, e2 = {}, e3 = {};
+  bool inc_cur = false;                              // the sample about to be committed continues the one in LDS
+  int nv1 = 4;
+  if (n < n_end) {
+    const long n1 = (n + nstep < n_end) ? n + nstep : n;
+    WSB_LOADD(n, d0, d1, d2, d3)
+    nv = p.nvalid[n];
+    WSB_LOADG(n, false)
+    nv1 = p.nvalid[n1];
+    WSB_LOADD(n1, e0, e1, e2, e3)
+  }
+  for (; n < n_end; n += 2 * nstep) {
+    WSB_ITER(n, d0, d1, d2, d3)
+    if (n + nstep < n_end) WSB_ITER(n + nstep, e0, e1, e2, e3)
+  }
+#undef WSB_ITER
+#undef WSB_STU2
+#undef WSB_LDU2
+#undef WSB_LOADD
+#undef WSB_LOADG
 #undef WSB_LDU
 #undef WSB_STD
 #undef WSB_STU
@@ -2961,6 +3061,7 @@ static bool plan_wstream_bf16(const a2c_conv_desc* d, const WstreamP& p, WsbGeo&
   gq.NG = (d->OW + 7) / 8;
   gq.dbg = getenv("A2C_WSB_DBG") ? atoi(getenv("A2C_WSB_DBG")) & 3 : 0;
   { const char* sd = getenv("A2C_WSB_STRIDED"); if (sd && sd[0] == '1') gq.dbg |= 4; }
+  { const char* sd = getenv("A2C_WSB_NO_RING"); if (sd && sd[0] == '1') gq.dbg |= 8; }
   gq.NGT = d->OH * gq.NG;
   gq.NB = (gq.NGT + 3) / 4;
   const int need_dw = gq.NB * 16;                      // dwords of one channel's groups (8 bf16 = 4 dwords each)

@@ -335,20 +335,23 @@ def test_a3c_persistent_rollout_on_the_frame_store_with_lazy_states(no_ring, B, 
                     assert torch.equal(a, b), i
 
 
-@pytest.mark.parametrize("B,vmax", [(5, 256), (700, 256), (700, 2), (32768 // 8, 2)])
-def test_a3c_conv1_weight_gradient_on_the_bf16_pipe_is_the_fp32_sum(B, vmax, monkeypatch):
+@pytest.mark.parametrize("B,vmax,p4", [(5, 256, 0.25), (700, 256, 0.25), (700, 2, 0.9), (32768 // 8, 2, 0.97), (32768 // 8, 256, 1.0)])
+def test_a3c_conv1_weight_gradient_on_the_bf16_pipe_is_the_fp32_sum(B, vmax, p4, monkeypatch):
     """A3CModel conv1 (8x8 / stride 4, models.py:36) weight gradient from the single-frame uint8 store.  Default: the bf16
     matrix pipe with every fp32 dOut value split into three bf16 pieces (exact) and the uint8 pixels as bf16 (exact): every
     product is exact, all sums are fp32 -- so the result must be the fp32 MFMA kernel's (A2C_WGRAD_F32=1) up to
     re-association, for ANY uint8 pixel values (vmax = 256) and for binary frames (vmax = 2), and no further from the
-    fp64 gradient than the fp32 kernel is (rms over the tensor; 1.5 x + 1e-7 of the tensor's rms)."""
+    fp64 gradient than the fp32 kernel is (rms over the tensor; 1.5 x + 1e-7 of the tensor's rms).
+    Round 6: a workgroup keeps the planes of its current sample in LDS as a ring and loads ONE frame for a successor sample
+    (same slot, all four planes real: nvalid == 4 with probability p4 here, so runs of successors, fresh episodes and slot
+    starts alternate): bit-identical to loading every sample whole (A2C_WSB_NO_RING=1)."""
     ops = _ops()
     d = ops.conv_desc(4, 84, 84, 16, 8, 4, 0)
     T, HW = 8, 84 * 84
     R = (B + T - 1) // T
     rng = np.random.default_rng(900 + B + vmax)
     Fs = rng.integers(0, vmax, size=(R, T + 4, HW), dtype=np.uint8)
-    nv = rng.integers(1, 5, size=(R * T,), dtype=np.int32)
+    nv = np.where(rng.random(R * T) < p4, 4, rng.integers(1, 5, size=(R * T,))).astype(np.int32)
     Fd, nvd = torch.from_numpy(Fs).to(DEV), torch.from_numpy(nv).to(DEV)
     dout = (rnd((B, 16, 20, 20), 77) * torch.from_numpy(rng.lognormal(0, 2, size=(B, 1, 1, 1)).astype(np.float32))).to(DEV)
     ws = torch.empty((ops.conv_bwd_weight_ws_bytes(d, B) + 3) // 4, device=DEV)
@@ -363,6 +366,11 @@ def test_a3c_conv1_weight_gradient_on_the_bf16_pipe_is_the_fp32_sum(B, vmax, mon
         dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
         ops.conv_bwd_weight_frames(d, Fd, Fd.stride(0), T, nvd, dout, dW2, db2, B, ws)
         assert torch.equal(dW, dW2) and torch.equal(db, db2)          # deterministic
+        if not f32:
+            monkeypatch.setenv("A2C_WSB_NO_RING", "1")
+            ops.conv_bwd_weight_frames(d, Fd, Fd.stride(0), T, nvd, dout, dW2, db2, B, ws)
+            monkeypatch.delenv("A2C_WSB_NO_RING")
+            assert torch.equal(dW, dW2) and torch.equal(db, db2)      # the plane ring changes what is loaded, not what is summed
         res[f32] = (dW.cpu().double(), db.cpu().double())
     # fp64 gradient: dW[co][c][ky][kx] = sum_n sum_px dOut[n][co][px] x[n][c][4 oy + ky][4 ox + kx]
     xs = torch.zeros(B, 4, 84, 84, dtype=torch.float64)

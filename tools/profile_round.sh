@@ -5,7 +5,7 @@
 # in the container: the GPU box has no .git).  The program after `--` is always python3 bench.py itself (native env
 # threads: no child process under the profiler); counters (--pmc) run in passes of their own, never together with a trace.
 set -x
-RND=${1:-r5}
+RND=${1:-r6}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=/tmp/prof_$RND
@@ -15,7 +15,7 @@ COMMON="--sustain-steps 0 --no-configs --no-secondary --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_a3c -- python3 $R/bench.py --steps 20 --warmup 3 $COMMON > $O/trace_a3c.json 2> $O/trace_a3c.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_conv32 -- python3 $R/bench.py --workload conv --steps 10 --warmup 3 $COMMON > $O/trace_conv32.json 2> $O/trace_conv32.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_gru -- python3 $R/bench.py --workload gru_bptt --steps 5 --warmup 2 $COMMON > $O/trace_gru.json 2> $O/trace_gru.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_shard -- python3 $R/bench.py --workload conv --n-envs 256 --steps 3 --warmup 2 $COMMON > $O/trace_shard.json 2> $O/trace_shard.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_shard -- python3 $R/bench.py --workload conv --n-envs 256 --grey --steps 3 --warmup 2 $COMMON > $O/trace_shard.json 2> $O/trace_shard.err
 # 2. HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of the headline's kernels and of the GRU+BPTT config's
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_a3c_$c -- python3 $R/bench.py --steps 4 --warmup 2 $COMMON --no-kernel-timers > $O/pmc_a3c_$c.log 2>&1

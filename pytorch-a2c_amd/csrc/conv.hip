@@ -1722,6 +1722,7 @@ struct Bstream2P {
   BstreamP s;
   const unsigned long long* lmask;      // MODE 2: (B, lmw) 64-bit words
   int lmw;                              // words per sample = Cin * H * W / 64
+  int order;                            // third form: 0 = the two waves of a SIMD out of step, 1 = side work first, 2 = first tile pair first
 };
 template <int MODE>
 __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_stream2_kernel(Bstream2P pp) {
@@ -1813,6 +1814,101 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const float* __restrict__ ob = outb0 + (cur ^ 1) * obs;
     BS2_FLUSH(m0, 0, pb, ob) BS2_FLUSH(m1, 1, pb, ob) BS2_FLUSH(m2, 2, pb, ob) BS2_FLUSH(m3, 3, pb, ob)
   }
+}
+
+// Third form, OPT-IN (A2C_BWD_STREAM_FORM=3): built after the counters, measured, and slower -- 0.855 ms with the waves out of
+// step, 0.869 with the side work first on all waves, 0.913 with the first tile pair first, against 0.74 for the second form
+// (same box, alternating runs, tools/ab_bs3.sh).  Kept for the record and for the next look with a phase-stamp build.
+// (round 6, after the counters: MFMA pipe 54 % busy, the rest is time in which BOTH waves of a SIMD sit in the same
+// non-matrix phase -- staging, flush, the LDS reads at the head of a k block -- because two barriers per sample keep them in
+// step).  ONE barrier per sample: the dOut image is double buffered too (sample b + 1 is staged into the other image during
+// sample b's interval), and the two waves of a SIMD (class k, halves 0 and 1) run the interval's work in DIFFERENT orders --
+// half 0: first tile pair, flush, staging, loads, rest; half 1: flush, staging, loads, then its tiles -- so that one wave's
+// stores / LDS writes / address arithmetic run under the other's MFMAs.  Same sums in the same order: bit-identical dX.
+template <int MODE>
+__global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_stream3_kernel(Bstream2P pp) {
+  const BstreamP& p = pp.s;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int WP = p.WP, PLANE = p.PLANE, HW = p.H * p.W;
+  const int obs = p.Cin * HW;                                 // floats per dX image
+  const int IMG = p.Cout * p.PLANE + 64;                      // floats per dOut image (one-pixel zero halo)
+  float* __restrict__ img0 = lds;                             // two dOut images
+  float* __restrict__ outb0 = lds + 2 * IMG;                  // two dX images, [Cin][H*W] each
+  const int ohw = p.OH * p.OW, nel4 = (p.Cout * ohw) >> 2, n4 = obs >> 2;
+  for (int i = tid; i < 2 * IMG; i += BS_NT) img0[i] = 0.f;   // halos stay 0 forever
+  const BwdClass k = p.cls[w & 3];
+  const int half = __builtin_amdgcn_readfirstlane(w >> 2);
+  float af[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) af[s] = p.wfrag[k.frag_off + s * 64 + lane];
+  const int NP = k.PH * k.PW, ntile = (NP + 15) >> 4;
+  float4 d0 = {}, d1 = {}, d2 = {}, d3 = {}, d4 = {}, d5 = {}, m0 = {}, m1 = {}, m2 = {}, m3 = {};
+  unsigned int soff[12];
+  BS_OFF(0) BS_OFF(1) BS_OFF(2) BS_OFF(3) BS_OFF(4) BS_OFF(5)
+  long b = blockIdx.x;
+  if (b >= p.B) return;
+#define BS3_STD(var, u, base)                                                                   \
+  {                                                                                             \
+    (base)[soff[2 * (u)] & 0xffffu] = var.x; (base)[soff[2 * (u)] >> 16] = var.y;               \
+    (base)[soff[2 * (u) + 1] & 0xffffu] = var.z; (base)[soff[2 * (u) + 1] >> 16] = var.w;       \
+  }
+  __syncthreads();                                            // the zero fill, before anything is staged
+  {
+    const float* __restrict__ src = p.dout + b * (long)p.Cout * ohw;
+    BS_LDD(d0, 0, src) BS_LDD(d1, 1, src) BS_LDD(d2, 2, src) BS_LDD(d3, 3, src) BS_LDD(d4, 4, src) BS_LDD(d5, 5, src)
+    BS3_STD(d0, 0, img0) BS3_STD(d1, 1, img0) BS3_STD(d2, 2, img0) BS3_STD(d3, 3, img0) BS3_STD(d4, 4, img0) BS3_STD(d5, 5, img0)
+    const long b1 = (b + gridDim.x < p.B) ? b + gridDim.x : b;
+    const float* __restrict__ s1 = p.dout + b1 * (long)p.Cout * ohw;
+    BS_LDD(d0, 0, s1) BS_LDD(d1, 1, s1) BS_LDD(d2, 2, s1) BS_LDD(d3, 3, s1) BS_LDD(d4, 4, s1) BS_LDD(d5, 5, s1)
+  }
+  __syncthreads();
+  long pb = -1;
+  int cur = 0;
+  unsigned int lmb = 0;                                       // MODE 2: the mask bits of sample pb for this thread's four flush units
+  for (; b < p.B; b += gridDim.x) {
+    const long nb2 = (b + 2L * gridDim.x < p.B) ? b + 2L * gridDim.x : b;      // past the end: re-read this sample (discarded)
+    const float* __restrict__ nsrc = p.dout + nb2 * (long)p.Cout * ohw;
+    const float* __restrict__ msrc = p.mask + b * (long)obs;
+    const float* __restrict__ img = img0 + cur * IMG;         // this sample's dOut (staged during the previous interval)
+    float* __restrict__ imgn = img0 + (cur ^ 1) * IMG;        // the next sample's
+    float* __restrict__ outb = outb0 + cur * obs;             // this sample's dX
+    const float* __restrict__ ob = outb0 + (cur ^ 1) * obs;   // the previous sample's, flushed in this interval
+    unsigned int lb0 = 0, lb1 = 0, lb2 = 0, lb3 = 0;
+    // everything of the interval that is not this sample's matrix work
+#define BS3_SIDE                                                                                                   \
+    {                                                                                                              \
+      if (pb >= 0) { BS2_FLUSH(m0, 0, pb, ob) BS2_FLUSH(m1, 1, pb, ob) BS2_FLUSH(m2, 2, pb, ob) BS2_FLUSH(m3, 3, pb, ob) } \
+      BS3_STD(d0, 0, imgn) BS3_STD(d1, 1, imgn) BS3_STD(d2, 2, imgn) BS3_STD(d3, 3, imgn) BS3_STD(d4, 4, imgn) BS3_STD(d5, 5, imgn) \
+      if (MODE == 1) { BS_LDM(m0, 0, msrc) BS_LDM(m1, 1, msrc) BS_LDM(m2, 2, msrc) BS_LDM(m3, 3, msrc) }           \
+      if (MODE == 2) {                                                                                             \
+        const unsigned char* __restrict__ lmp = reinterpret_cast<const unsigned char*>(pp.lmask) + b * (long)pp.lmw * 8; \
+        const int nby = n4 >> 1;                                                                                   \
+        lb0 = lmp[min((tid + 0 * BS_NT) >> 1, nby - 1)]; lb1 = lmp[min((tid + 1 * BS_NT) >> 1, nby - 1)];          \
+        lb2 = lmp[min((tid + 2 * BS_NT) >> 1, nby - 1)]; lb3 = lmp[min((tid + 3 * BS_NT) >> 1, nby - 1)];          \
+      }                                                                                                            \
+      BS_LDD(d0, 0, nsrc) BS_LDD(d1, 1, nsrc) BS_LDD(d2, 2, nsrc) BS_LDD(d3, 3, nsrc) BS_LDD(d4, 4, nsrc) BS_LDD(d5, 5, nsrc) \
+    }
+    if (pp.order == 2 || (pp.order == 0 && half == 0)) {
+      BS_PAIR(0)
+      BS3_SIDE
+    } else {
+      BS3_SIDE
+      BS_PAIR(0)
+    }
+    for (int tp = 2; tp * 2 + half < ntile; tp += 2) BS_PAIR(tp) // tiles half + 4, half + 6, ...
+    if (MODE == 2) lmb = lb0 | (lb1 << 8) | (lb2 << 16) | (lb3 << 24);
+    __syncthreads();                                            // this sample's dX complete, the next sample's dOut staged
+    pb = b;
+    cur ^= 1;
+  }
+#undef BS3_SIDE
+  {
+    const float* __restrict__ ob = outb0 + (cur ^ 1) * obs;
+    BS2_FLUSH(m0, 0, pb, ob) BS2_FLUSH(m1, 1, pb, ob) BS2_FLUSH(m2, 2, pb, ob) BS2_FLUSH(m3, 3, pb, ob)
+  }
+#undef BS3_STD
 }
 
 // the mask bits of an activation tensor (see bwd_stream2_kernel): a lane per float4, a byte per pair of lanes
@@ -3891,9 +3987,25 @@ int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float
         const bool form2 = slds2 <= LDS_HARD_MAX && !(v1 && v1[0] == '1') && (!lmask || n4 % 64 == 0);
         if (lmask && !form2) return A2C_ERR_ARG;
         if (probe_only) return A2C_OK;
+        // third form (one barrier per sample, both images double buffered, the two waves of a SIMD out of step): A2C_BWD_STREAM_FORM=3
+        const size_t slds3 = 4 * (2 * ((size_t)d->Cout * q.PLANE + 64) + 2 * (size_t)d->Cin * d->H * d->W);
+        const char* fm = getenv("A2C_BWD_STREAM_FORM");
+        if (form2 && slds3 <= LDS_HARD_MAX && fm && fm[0] == '3') {        // OPT-IN: measured slower (0.855-0.913 vs 0.74 ms)
+          Bstream2P s3;
+          s3.s = sp; s3.lmask = lmask; s3.lmw = n4 / 64 * 4;
+          { const char* o = getenv("A2C_BS3_ORDER"); s3.order = o ? atoi(o) : 0; }
+          const void* sk = lmask ? (const void*)bwd_stream3_kernel<2> : mask ? (const void*)bwd_stream3_kernel<1> : (const void*)bwd_stream3_kernel<0>;
+          if (slds3 > 64 * 1024) (void)hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds3);
+          const int sgrid = resident_grid(sk, slds3, B, BS_NT);
+          if (lmask) hipLaunchKernelGGL(bwd_stream3_kernel<2>, dim3(sgrid), dim3(BS_NT), slds3, a2c_s(stream), s3);
+          else if (mask) hipLaunchKernelGGL(bwd_stream3_kernel<1>, dim3(sgrid), dim3(BS_NT), slds3, a2c_s(stream), s3);
+          else hipLaunchKernelGGL(bwd_stream3_kernel<0>, dim3(sgrid), dim3(BS_NT), slds3, a2c_s(stream), s3);
+          A2C_CHECK_LAUNCH();
+          return A2C_OK;
+        }
         if (form2) {
           Bstream2P s2;
-          s2.s = sp; s2.lmask = lmask; s2.lmw = n4 / 64 * 4;
+          s2.s = sp; s2.lmask = lmask; s2.lmw = n4 / 64 * 4; s2.order = 0;
           const void* sk = lmask ? (const void*)bwd_stream2_kernel<2> : mask ? (const void*)bwd_stream2_kernel<1> : (const void*)bwd_stream2_kernel<0>;
           if (slds2 > 64 * 1024) (void)hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds2);
           const int sgrid = resident_grid(sk, slds2, B, BS_NT);

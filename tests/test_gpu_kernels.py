@@ -873,6 +873,15 @@ def test_conv2d_streaming_backward_data_with_lane_masks(monkeypatch, B):
     ops.conv_bwd_data_lanemask(d, dout, wb, lm, got, B)
     want = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
     ops.conv_bwd_data(d, dout, wb, actd, want, B)
+    for order in ("0", "1", "2"):                            # the opt-in third form (one barrier per sample), its three schedules
+        monkeypatch.setenv("A2C_BWD_STREAM_FORM", "3")
+        monkeypatch.setenv("A2C_BS3_ORDER", order)
+        f3 = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+        ops.conv_bwd_data_lanemask(d, dout, wb, lm, f3, B)
+        torch.cuda.synchronize()
+        assert torch.equal(got, f3), order
+    monkeypatch.delenv("A2C_BWD_STREAM_FORM")
+    monkeypatch.delenv("A2C_BS3_ORDER")
     monkeypatch.setenv("A2C_BWD_STREAM_V1", "1")
     old = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
     ops.conv_bwd_data(d, dout, wb, actd, old, B)

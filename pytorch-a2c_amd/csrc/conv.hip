@@ -1718,13 +1718,15 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 // phase (first version: at the flush, four loads whose latency nothing covered -- 0.73 -> 0.89 ms).  Same sums in the same
 // order as the first form: bit-identical dX.
 // MODE 0: no mask, 1: float mask, 2: lane masks.
+static unsigned long long* g_bs2_dbg = nullptr;      // a2c_debug_bwd_stream_timing
 struct Bstream2P {
   BstreamP s;
   const unsigned long long* lmask;      // MODE 2: (B, lmw) 64-bit words
   int lmw;                              // words per sample = Cin * H * W / 64
   int order;                            // third form: 0 = the two waves of a SIMD out of step, 1 = side work first, 2 = first tile pair first
+  unsigned long long* dbg;              // second form: phase stamps of workgroup 0 (a2c_debug_bwd_stream_timing), [wave][8] shader clocks
 };
-template <int MODE>
+template <int MODE, bool STAMP = false>
 __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_stream2_kernel(Bstream2P pp) {
   const BstreamP& p = pp.s;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1783,18 +1785,26 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   long pb = -1;
   int cur = 0;
   unsigned int lmb = 0;                                         // MODE 2: the mask bits of sample pb for this thread's four flush units
+  // phase stamps (tools/bwd_stream_timing.py): per wave of workgroup 0, shader clocks summed over its samples
+  const bool stamp = STAMP && pp.dbg != nullptr && blockIdx.x == 0;       // (a template flag: the sums cost 18 VGPRs the kernel does not have)
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = stamp ? (unsigned long long)clock64() : 0ull;
+#define BS2_TS(i) do { if (stamp) { const unsigned long long n_ = (unsigned long long)clock64(); tsum[i] += n_ - tprev; tprev = n_; } } while (0)
   for (; b < p.B; b += gridDim.x) {
     const long nb = (b + gridDim.x < p.B) ? b + gridDim.x : b;          // past the end: re-read this sample (discarded)
     const float* __restrict__ nsrc = p.dout + nb * (long)p.Cout * ohw;
     const float* __restrict__ msrc = p.mask + b * (long)obs;
     float* __restrict__ outb = outb0 + cur * obs;
     BS_STD(d0, 0) BS_STD(d1, 1) BS_STD(d2, 2) BS_STD(d3, 3) BS_STD(d4, 4) BS_STD(d5, 5)
+    BS2_TS(0);                                                  // wait for the sample's dOut + staging
     __syncthreads();
+    BS2_TS(1);                                                  // barrier 1
     if (pb >= 0) {                                              // the previous sample's dX: stores first
       const float* __restrict__ ob = outb0 + (cur ^ 1) * obs;
       BS2_FLUSH(m0, 0, pb, ob) BS2_FLUSH(m1, 1, pb, ob) BS2_FLUSH(m2, 2, pb, ob) BS2_FLUSH(m3, 3, pb, ob)
     }
+    BS2_TS(2);                                                  // flush of the previous sample
     BS_PAIR(0)                                                  // tiles half, half + 2
+    BS2_TS(3);                                                  // first tile pair
     if (MODE == 1) { BS_LDM(m0, 0, msrc) BS_LDM(m1, 1, msrc) BS_LDM(m2, 2, msrc) BS_LDM(m3, 3, msrc) }
     unsigned int lb0 = 0, lb1 = 0, lb2 = 0, lb3 = 0;
     if (MODE == 2) {           // THIS sample's mask bits (its flush is the next iteration's first act): one byte per flush unit
@@ -1804,16 +1814,23 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       lb2 = lmp[min((tid + 2 * BS_NT) >> 1, nby - 1)]; lb3 = lmp[min((tid + 3 * BS_NT) >> 1, nby - 1)];
     }
     BS_LDD(d0, 0, nsrc) BS_LDD(d1, 1, nsrc) BS_LDD(d2, 2, nsrc) BS_LDD(d3, 3, nsrc) BS_LDD(d4, 4, nsrc) BS_LDD(d5, 5, nsrc)
+    BS2_TS(4);                                                  // issue of the next sample's loads
     for (int tp = 2; tp * 2 + half < ntile; tp += 2) BS_PAIR(tp) // tiles half + 4, half + 6, ...
     if (MODE == 2) lmb = lb0 | (lb1 << 8) | (lb2 << 16) | (lb3 << 24);
+    BS2_TS(5);                                                  // remaining tile pairs
     __syncthreads();                                            // every class has landed in this sample's image
+    BS2_TS(6);                                                  // barrier 2
     pb = b;
     cur ^= 1;
+    if (stamp) tsum[7] += 1;
   }
   {
     const float* __restrict__ ob = outb0 + (cur ^ 1) * obs;
     BS2_FLUSH(m0, 0, pb, ob) BS2_FLUSH(m1, 1, pb, ob) BS2_FLUSH(m2, 2, pb, ob) BS2_FLUSH(m3, 3, pb, ob)
   }
+  if (stamp && lane == 0)
+    for (int i = 0; i < 8; ++i) pp.dbg[w * 8 + i] = tsum[i];
+#undef BS2_TS
 }
 
 // Third form, OPT-IN (A2C_BWD_STREAM_FORM=3): built after the counters, measured, and slower -- 0.855 ms with the waves out of
@@ -3910,6 +3927,12 @@ int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* 
 
 int a2c_conv2d_bwd_data_signs_supported(const a2c_conv_desc* d) { return desc_ok(d) && c3_bwd_signs_supported(d) ? 1 : 0; }
 
+/* debug: device buffer of 8 waves x 8 uint64 that receives the summed phase stamps (shader clocks; [7] = samples) of workgroup
+ * 0 of every following bwd_stream2_kernel launch; NULL switches it off.  Not part of the drop-in boundary. */
+int a2c_debug_bwd_stream_timing(unsigned long long* dev_buf) {
+  g_bs2_dbg = dev_buf;
+  return A2C_OK;
+}
 /* include/a2c_mi355x.h: lane masks of an activation tensor, and the backward-data pass that takes them as its ReLU mask */
 int a2c_lanemask_from_act(const float* act, uint64_t* lanemask, int64_t n_floats, a2c_stream_t stream) {
   if (n_floats < 0 || n_floats % 256) return A2C_ERR_ARG;
@@ -3994,6 +4017,7 @@ int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float
           Bstream2P s3;
           s3.s = sp; s3.lmask = lmask; s3.lmw = n4 / 64 * 4;
           { const char* o = getenv("A2C_BS3_ORDER"); s3.order = o ? atoi(o) : 0; }
+          s3.dbg = nullptr;
           const void* sk = lmask ? (const void*)bwd_stream3_kernel<2> : mask ? (const void*)bwd_stream3_kernel<1> : (const void*)bwd_stream3_kernel<0>;
           if (slds3 > 64 * 1024) (void)hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds3);
           const int sgrid = resident_grid(sk, slds3, B, BS_NT);
@@ -4005,11 +4029,12 @@ int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float
         }
         if (form2) {
           Bstream2P s2;
-          s2.s = sp; s2.lmask = lmask; s2.lmw = n4 / 64 * 4; s2.order = 0;
+          s2.s = sp; s2.lmask = lmask; s2.lmw = n4 / 64 * 4; s2.order = 0; s2.dbg = g_bs2_dbg;
           const void* sk = lmask ? (const void*)bwd_stream2_kernel<2> : mask ? (const void*)bwd_stream2_kernel<1> : (const void*)bwd_stream2_kernel<0>;
           if (slds2 > 64 * 1024) (void)hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds2);
           const int sgrid = resident_grid(sk, slds2, B, BS_NT);
-          if (lmask) hipLaunchKernelGGL(bwd_stream2_kernel<2>, dim3(sgrid), dim3(BS_NT), slds2, a2c_s(stream), s2);
+          if (lmask && s2.dbg) hipLaunchKernelGGL((bwd_stream2_kernel<2, true>), dim3(sgrid), dim3(BS_NT), slds2, a2c_s(stream), s2);
+          else if (lmask) hipLaunchKernelGGL(bwd_stream2_kernel<2>, dim3(sgrid), dim3(BS_NT), slds2, a2c_s(stream), s2);
           else if (mask) hipLaunchKernelGGL(bwd_stream2_kernel<1>, dim3(sgrid), dim3(BS_NT), slds2, a2c_s(stream), s2);
           else hipLaunchKernelGGL(bwd_stream2_kernel<0>, dim3(sgrid), dim3(BS_NT), slds2, a2c_s(stream), s2);
           A2C_CHECK_LAUNCH();

@@ -444,3 +444,47 @@ def test_torch_abi_ops_validate_their_arguments():
         o.abi_add([x.cpu(), x.cpu(), y.cpu()], [0, 0, 0], [8], [])
     with pytest.raises(RuntimeError, match="invalid argument"):
         o.abi_discount_scan([x, x, y, torch.empty(0, device=DEV)], [0, 0, 0, 0], [-1, 4], [0.9])
+
+
+@pytest.mark.parametrize("kind,ingest", [("GRUModel", "relay"), ("ConvModel", "relay"), ("A3CModel", "memcpy"), ("FCModel", "relay")])
+def test_rollout_through_torch_custom_ops_matches_oracle(kind, ingest, monkeypatch):
+    """A2C_TORCH_OPS=1 on the ROLLOUT side: every per-step launch whose pointers live in torch tensors (conv / GEMM / GRU cell /
+    heads / bookkeeping kernels) goes through torch.ops.a2c_mi355x.abi_*; the launches that are handed addresses of the pinned
+    pool region (a2c_pool_ingest*, a2c_pool_publish_actions, a2c_store_u32_system: host memory mapped into the device, not a
+    tensor) and the argument-block launchers fall back to ctypes, call by call.  Two rounds against the oracle, as
+    tests/test_gpu_ingest.py::test_process_pool_rollouts_match_oracle does for the ctypes binding."""
+    from a2c_amd import ops
+    from a2c_amd.runner import Runner
+    from cases import U8FakeEnv
+    from test_gpu_ingest import _compare_round, _oracle_rollouts, _pool
+    monkeypatch.setenv("A2C_TORCH_OPS", "1")
+    ab = ops.torch_abi()
+    ab.stats.update(torch_ops=0, ctypes=0, by_name={}, unresolved={})
+    B, T, A, ss = 5, 6, 3, (4, 84, 84)
+    ekws = [dict(env_id=j, rew_period=3 + j % 3, done_period=5 + 2 * j) for j in range(B)]
+    hyps = base_hyps(env_type="FakePong-v0" if kind == "A3CModel" else "FakeBreakout", n_tsteps=T, n_rollouts=B,
+                     action_shift=0, n_envs=B, env_timeout_s=20.0)
+    net = make_net(kind, ss, A, 256)
+    onet = O.OracleNet(kind, ss, A, 256)
+    D = _datas(B * T, ss, net.is_recurrent, actions_on_host=False)
+    us = torch.from_numpy(hashf(2 * T * B, 901, 0, 1).reshape(2, T, B))
+    usd = us.to(DEV)
+    rnd = [0]
+    pool = _pool(U8FakeEnv, ekws, 2, pong="Pong" in hyps["env_type"])
+    r = Runner(D, hyps, None, None, None, env_pool=pool, ingest=ingest,
+               uniform_fn=lambda t, Bn, env0: usd[rnd[0], t, env0:env0 + Bn].contiguous())
+    try:
+        refs = _oracle_rollouts(kind, onet, hyps, ekws, us, 2, B, T, ss)
+        for rnd[0] in range(2):
+            r.rollout(net, list(range(B)), hyps)
+            r.finish()
+            _compare_round(D, refs[rnd[0]], net.is_recurrent)
+    finally:
+        r.close()
+    st = ab.stats
+    assert st["torch_ops"] > 20, st
+    # what may fall back: launches that take addresses inside the pinned pool region (not torch memory)
+    assert set(st["unresolved"]) <= {"a2c_pool_ingest", "a2c_pool_ingest_bits", "a2c_pool_ingest_post", "a2c_pool_publish_actions",
+                                     "a2c_store_u32_system", "a2c_heads_fused_publish", "a2c_memcpy_async", "a2c_unpack_bits"}, st["unresolved"]
+    print(f"[torch ops] rollout {kind}/{ingest}: {st['torch_ops']} launches through abi_* ops, {st['ctypes']} through ctypes "
+          f"({dict(st['unresolved'])})")

@@ -482,7 +482,9 @@ def test_rollout_through_torch_custom_ops_matches_oracle(kind, ingest, monkeypat
     finally:
         r.close()
     st = ab.stats
-    assert st["torch_ops"] > 20, st
+    # (A3CModel's per-step work is ONE argument-block launch, a2c_a3c_step: ctypes by design; its weight preparation and the
+    # first frame stack still go through the ops)
+    assert st["torch_ops"] > (20 if kind != "A3CModel" else 2), st
     # what may fall back: launches that take addresses inside the pinned pool region (not torch memory)
     assert set(st["unresolved"]) <= {"a2c_pool_ingest", "a2c_pool_ingest_bits", "a2c_pool_ingest_post", "a2c_pool_publish_actions",
                                      "a2c_store_u32_system", "a2c_heads_fused_publish", "a2c_memcpy_async", "a2c_unpack_bits"}, st["unresolved"]

@@ -51,6 +51,7 @@ class TorchAbi:
         spec.loader.exec_module(gen)
         self._layout = {n: list(zip(kinds, [t for t, _ in params])) for n, params, kinds in gen.plan()[0]}
         self._bases, self._refs = [], {}          # sorted storage base addresses -> weakref(tensor), nbytes
+        self._misses = set()                      # addresses no live tensor contains (looked for once)
         self._null = {}
         self.stats = {"torch_ops": 0, "ctypes": 0, "by_name": {}, "unresolved": {}}
         self._fns = {}
@@ -89,6 +90,8 @@ class TorchAbi:
 
     def _find(self, addr):
         hit = self._lookup(addr)
+        if hit is None and addr in self._misses:
+            return None                     # (an address of the pinned pool region: asked for at every relay step, never a tensor)
         if hit is None:
             # an address this module was never handed as a tensor (a buffer a model allocated itself and passes as
             # data_ptr() + offset): find the live HIP tensor whose storage contains it -- once per storage, then it is noted
@@ -104,6 +107,8 @@ class TorchAbi:
                 except Exception:      # noqa: BLE001  (tensors without storage, objects that refuse isinstance)
                     continue
             hit = self._lookup(addr)
+            if hit is None and len(self._misses) < 4096:
+                self._misses.add(addr)
         return hit
 
     def _nul(self, dev):

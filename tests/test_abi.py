@@ -73,6 +73,18 @@ def test_argument_validation_without_gpu():
     rargs = _lib.A3CRolloutArgs(B=2, C=4, H=84, W=84, n_actions=3, T=4)
     assert lib.a2c_a3c_rollout(ctypes.byref(rargs), None) == -1
     assert lib.a2c_frame_stack_push_u8(None, 7056, None, None, 0, None, 0, 2, 4, 7056, None) == -1
+    # round 6: the mask-bit entry points
+    assert lib.a2c_lanemask_from_act(None, None, 0, None) == 0 and lib.a2c_lanemask_from_act(None, None, 100, None) == -1
+    assert lib.a2c_lanemask_from_act(None, None, 256, None) == -1                      # NULL pointers
+    assert lib.a2c_small_n_bwd_data_bits(None, 4, None, None, 2592, None, 324, 0, 3, 2592, None) == 0      # no rows
+    assert lib.a2c_small_n_bwd_data_bits(None, 4, None, None, 2592, None, 324, 8, 3, 2592, None) == -1     # NULL pointers
+    assert lib.a2c_small_n_bwd_data_bits(None, 4, None, None, 2592, None, 324, 8, 9, 2592, None) == -1     # N > 8
+    assert lib.a2c_small_n_bwd_data_bits(None, 4, None, None, 2590, None, 324, 8, 3, 2590, None) == -1     # K % 8
+    d2 = _lib.ConvDesc(16, 20, 20, 32, 4, 2, 0, 9, 9)
+    assert lib.a2c_conv2d_bwd_data_lanemask_supported(ctypes.byref(d2), 0) == 0
+    assert lib.a2c_conv2d_bwd_data_lanemask(ctypes.byref(d2), None, None, None, None, 4096, None) == -1
+    rargs2 = _lib.A3CRolloutArgs(B=2, C=4, H=84, W=84, n_actions=3, T=4)
+    assert "a1_lanemask_rows" in dict(rargs2._fields_) and "a2_maskbit_rows" in dict(rargs2._fields_)
     assert lib.a2c_memcpy_async(None, None, 0, 1, None) == 0 and lib.a2c_memcpy_async(None, None, 8, 1, None) == -1
 
 

@@ -22,11 +22,20 @@ Multi-GPU: weak scaling, every rank plays its own n_envs envs (own pool); one RC
 gradient arena (+ 2 tiny ones for the whole-batch statistics) per update.  ``python bench.py --gpus N``
 without a launcher spawns ``torch.distributed.run`` itself (before this process touches the GPU).
 
-Prints ONE JSON line (rank 0): metric/value/... plus
-  "roofline":     the kernel the epoch spends most time in: algorithmic flops (bytes) / HIP-event duration,
+Prints ONE JSON line (rank 0, <= 4 KB: compact_line), the full report goes to gpurun_out/bench_full_<tag>.json and stderr:
+  "roofline":     the kernel the epoch spends most time in.  For the persistent ring rollout kernel `frac` is PER PIPE:
+                  achieved / the rate at which this instruction mix would run with every MFMA at its own pipe's peak
+                  (conv1 is issued as three exact bf16 products, the rest as fp32 MFMAs: ring_roofline) = matrix time at
+                  each instruction's own peak / launch duration; `frac_fp32_equiv` = algorithmic fp32 flops over the fp32
+                  peak (rounds 1-5's figure); `traffic` = HBM bytes per launch from profiles/<round>_traffic.json when its
+                  manifest matches the running tree,
   "cpu_baseline": the CPU oracle (restatement of the reference's algorithm) timed on this box's usable host
-                  cores on a bounded sample of the same workload (N=1 only),
-  "configs":      the other BASELINE.json configs (conv 32x64, gru+BPTT 256x128, a3c at 32 / 2048 envs).
+                  cores on a bounded sample of the same workload (N=1 only); "cpu_baseline_values": the same for the other
+                  configs of the line (side file: cpu_baselines),
+  value_<config>: the other BASELINE.json configs (conv 32x64, gru+BPTT 256x128, a3c at 32 / 2048 envs, and the per-GPU shard
+                  of configs[4]: ConvModel 256x128 on Breakout-like grey frames over the uint8 transport, --grey),
+  value_one_env_thread / host_us_per_env_step / predicted_8rank_weak: the headline with ONE env thread (what a rank of an
+                  8-rank run on a 16-CPU quota has) and 8 x that -- a prediction, not a scaling measurement.
 """
 import argparse
 import json

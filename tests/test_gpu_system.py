@@ -490,3 +490,35 @@ def test_rollout_through_torch_custom_ops_matches_oracle(kind, ingest, monkeypat
                                      "a2c_store_u32_system", "a2c_heads_fused_publish", "a2c_memcpy_async", "a2c_unpack_bits"}, st["unresolved"]
     print(f"[torch ops] rollout {kind}/{ingest}: {st['torch_ops']} launches through abi_* ops, {st['ctypes']} through ctypes "
           f"({dict(st['unresolved'])})")
+
+
+def test_integration_md_torch_ops_examples_run():
+    """the two abi_* calls INTEGRATION.md shows a reference-side caller: the in-place GAE + returns scan and conv1 over row t
+    of every slot of a rollout-major states buffer (byte offsets into the owning tensors, not views) -- against the ctypes path"""
+    from a2c_amd import ops
+    o = ops.load_torch_ops()
+    R, T, gamma, lam = 3, 5, 0.99, 0.98
+    N = R * T
+    deltas, rewards = torch.from_numpy(hashf(N, 1, -1, 1)).to(DEV), torch.from_numpy(hashf(N, 2, -1, 1)).to(DEV)
+    dones = (torch.from_numpy(hashf(N, 3)) < 0.2).float().to(DEV)
+    dones[T - 1::T] = 1
+    advs, rets, a2, r2 = (torch.empty(N, device=DEV) for _ in range(4))
+    null = torch.empty(0, device=DEV)
+    o.abi_gae_returns_fused([deltas, rewards, dones, advs, rets, null], [0] * 6, [R, T], [gamma * lam, gamma])
+    ops.gae_returns(deltas, rewards, dones, gamma * lam, gamma, R, T, a2, r2)
+    torch.cuda.synchronize()
+    assert torch.equal(advs, a2) and torch.equal(rets, r2)
+    # conv1 of A3CModel over state t of every slot
+    states = torch.from_numpy(hashf(N * 28224, 4).reshape(N, 4, 84, 84)).to(DEV)
+    w, bias = torch.from_numpy(hashf(16 * 4 * 64, 5, -.1, .1).reshape(16, 4, 8, 8)).to(DEV), torch.from_numpy(hashf(16, 6)).to(DEV)
+    d = ops.conv_desc(4, 84, 84, 16, 8, 4, 0)
+    wprep = torch.empty(ops.conv_prep_floats(d, 0), device=DEV)
+    ops.conv_prep(d, 0, w, wprep)
+    t = 2
+    out, want = torch.empty(R, 16, 20, 20, device=DEV), torch.empty(R, 16, 20, 20, device=DEV)
+    o.abi_conv2d_fwd([states, wprep, bias, out], [4 * t * 28224, 0, 0, 0], [4, 84, 84, 16, 8, 4, 0, 20, 20, T * 28224, 1, 6400, R], [])
+    ops.conv_fwd(d, states[t].data_ptr(), T * 28224, wprep, bias, True, want, R)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    ref = torch.relu(torch.nn.functional.conv2d(states[t::T].cpu().double(), w.cpu().double(), bias.cpu().double(), stride=4))
+    close("conv1 rows", out, ref, 1e-5, 1e-5)

@@ -96,16 +96,19 @@ class TorchAbi:
             # an address this module was never handed as a tensor (a buffer a model allocated itself and passes as
             # data_ptr() + offset): find the live HIP tensor whose storage contains it -- once per storage, then it is noted
             import gc
-            for obj in gc.get_objects():
-                try:
-                    if isinstance(obj, torch.Tensor) and obj.is_cuda:
-                        st = obj.untyped_storage()
-                        b = st.data_ptr()
-                        if b <= addr < b + st.nbytes():
-                            self.note(obj)
-                            break
-                except Exception:      # noqa: BLE001  (tensors without storage, objects that refuse isinstance)
-                    continue
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")       # (isinstance on lazily deprecated module attributes warns)
+                for obj in gc.get_objects():
+                    try:
+                        if isinstance(obj, torch.Tensor) and obj.is_cuda:
+                            st = obj.untyped_storage()
+                            b = st.data_ptr()
+                            if b <= addr < b + st.nbytes():
+                                self.note(obj)
+                                break
+                    except Exception:      # noqa: BLE001  (tensors without storage, objects that refuse isinstance)
+                        continue
             hit = self._lookup(addr)
             if hit is None and len(self._misses) < 4096:
                 self._misses.add(addr)

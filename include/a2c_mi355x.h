@@ -534,6 +534,21 @@ int a2c_conv2d_bwd_data_lanemask(const a2c_conv_desc *d, const float *dout, cons
                                  float *din, int B, a2c_stream_t stream);
 int a2c_conv2d_bwd_data_signs(const a2c_conv_desc *d, const float *dout, const float *wprep_bwd, const uint32_t *signs,
                               int64_t signs_bstride, float *din, int B, a2c_stream_t stream);
+/* a2c_conv2d_bwd_data_signs of layer d2 FUSED with a2c_conv2d_bwd_weight_frames of the FIRST layer d1 below it (round 6;
+ * GRUModel's conv2 over conv1, models.py:570-590: 16 <- 24 channels at stride 2 on 84 x 84 over 4 -> 16, 3 x 3, stride 1,
+ * pad 1).  The first layer's input needs no gradient, so layer 2's masked input gradient (the `din` of the unfused call:
+ * 16 x 84 x 84 floats per sample, 14.8 GB at N = 32,768) feeds nothing but d1's weight gradient: the kernel keeps each finished
+ * band of it in LDS, splits it into three exact bf16 pieces in registers and multiplies it against the band's rows of the
+ * uint8 frames (exact in bf16) on the bf16 matrix pipe -- it is never written to HBM and never read back (the two unfused
+ * launches move 29.6 GB for it).  dW1 (16, 4, 3, 3), db1 (16): the sums of a2c_conv2d_bwd_weight_frames over
+ * a2c_conv2d_bwd_data_signs's output, re-associated; per-workgroup partials in ws + a fixed-order reduction (deterministic).
+ * signs = the sign words of d1's OUTPUT (a2c_conv2d_fwd_signs / a2c_conv2d_fwd_frames), frame_store / nvalid as in
+ * a2c_conv2d_bwd_weight_frames.  _ws_bytes returns 0 when the pair of layers has no fused kernel (then use the two calls). */
+size_t a2c_conv2d_bwd_data_w1_frames_ws_bytes(const a2c_conv_desc *d2, const a2c_conv_desc *d1, int B);
+int a2c_conv2d_bwd_data_w1_frames(const a2c_conv_desc *d2, const float *dout, const float *wprep_bwd, const uint32_t *signs,
+                                  int64_t signs_bstride, const a2c_conv_desc *d1, const uint8_t *frame_store,
+                                  int64_t slot_stride, int64_t T, const int32_t *nvalid, float *dW1, float *db1, int B,
+                                  void *ws, size_t ws_bytes, a2c_stream_t stream);
 /* a2c_conv2d_bwd_data of layer d2 FUSED with a2c_conv2d_bwd_weight of the layer d1 below it, for the case where
  * nothing but d1's weight gradient reads d2's input gradient (d1 = first conv of the stack: models.py:196-215, its
  * input needs no gradient): the masked input gradient (the `din` of the call above) is assembled band by band

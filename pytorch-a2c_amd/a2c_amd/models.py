@@ -683,6 +683,24 @@ class _ConvStackNet(_HipNet):
                         ops.conv_bwd_data_w1(l.d, d, l.wb, acts[0], l0.d, x_ptr, bstride, self.G("convs.0.0.weight"),
                                              self.G("convs.0.0.bias"), B, buf, st)
                     return
+            if i == 1 and os.environ.get("A2C_NO_W1_FRAMES") != "1":
+                # Round 6: layer 2's input gradient (16 x 84 x 84 floats per sample: 14.8 GB at N = 32,768, written by one launch
+                # and read back by the next) only feeds layer 1's weight gradient.  With the single-frame store and layer 1's
+                # sign words at hand the fused pass keeps it in LDS and multiplies it against the uint8 frames on the bf16 pipe
+                # (a2c_conv2d_bwd_data_w1_frames): the same sums, re-associated; da0 never reaches HBM.
+                l0, sl = self._cl[0], self._sign_layers()
+                fr0 = self._stash_frames if (l0.frames_ok and self._stash_valid(x_ptr, B)
+                                             and os.environ.get("A2C_NO_FRAME_STORE") != "1") else None
+                if fr0 is not None and 0 in sl and self._signs_ok.get(0, False) and not l.padded:
+                    nb = ops.conv_bwd_data_w1_frames_ws_bytes(l.d, l0.d, B)
+                    if nb:
+                        fstore, nvalid, T = fr0
+                        buf = ws.bytes("conv_w1f_ws", nb)
+                        with ops.span("conv2.bwd_data+conv1.bwd_weight"):
+                            ops.conv_bwd_data_w1_frames(l.d, d, l.wb, ws.get("sg0", (B, sl[0]), dtype=torch.int32), l0.d, fstore,
+                                                        fstore.stride(0), T, nvalid, self.G("convs.0.0.weight"),
+                                                        self.G("convs.0.0.bias"), B, buf, st)
+                        return
             if i > 0:
                 dprev = ws.get(f"da{i-1}", (B,) + self._cl[i - 1].out_shape)
                 sl = self._sign_layers()

@@ -839,6 +839,19 @@ def conv_bwd_data_lanemask(d, dout, wprep_bwd, lanemask, din, B, st=None):
                                              st if st is not None else stream()), "a2c_conv2d_bwd_data_lanemask")
 
 
+def conv_bwd_data_w1_frames_ws_bytes(d2, d1, B):
+    """> 0 when layer d2's sign-word backward-data can absorb the first layer d1's weight gradient from the uint8 frame store"""
+    return lib().a2c_conv2d_bwd_data_w1_frames_ws_bytes(ctypes.byref(d2), ctypes.byref(d1), B)
+
+
+def conv_bwd_data_w1_frames(d2, dout, wprep_bwd, signs, d1, fstore, slot_stride, T, nvalid, dW1, db1, B, ws, st=None):
+    _chk(fstore, "frame_store", torch.uint8); _chk(nvalid, "nvalid", torch.int32); _chk(signs, "signs", torch.int32)
+    check(lib().a2c_conv2d_bwd_data_w1_frames(ctypes.byref(d2), _p(dout), _p(wprep_bwd), _p(signs), signs.stride(0), ctypes.byref(d1),
+                                              _p(fstore), slot_stride, T, _p(nvalid), _p(dW1), _p(db1), B, ws.data_ptr(),
+                                              ws.numel() * ws.element_size(), st if st is not None else stream()),
+          "a2c_conv2d_bwd_data_w1_frames")
+
+
 def conv_bwd_weight_ws_bytes(d, B):
     return lib().a2c_conv2d_bwd_weight_ws_bytes(ctypes.byref(d), B)
 

@@ -51,6 +51,11 @@ int c3_fwd_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long 
                   const float* bias, int relu, float* out, long out_bs, unsigned* signs, long signs_bs, int B, hipStream_t st);
 int c3w_bwd_weight_frames(const a2c_conv_desc* d, const unsigned char* f, long bs, long T, const int* nv, const float* dout,
                           float* dW, float* db, int B, void* ws, size_t ws_bytes, hipStream_t st);
+bool c3_bwd_data_w1_frames_supported(const a2c_conv_desc* d2, const a2c_conv_desc* d1);
+size_t c3_bwd_data_w1_frames_ws_bytes(const a2c_conv_desc* d2, const a2c_conv_desc* d1, int B);
+int c3_bwd_data_w1_frames(const a2c_conv_desc* d2, const a2c_conv_desc* d1, const float* dout, const float* frag, const unsigned* signs,
+                          long signs_bs, const unsigned char* f, long bs, long T, const int* nv, float* dW1, float* db1, int B, void* ws,
+                          size_t ws_bytes, hipStream_t st);
 
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -3967,6 +3972,27 @@ int a2c_conv2d_bwd_data_signs(const a2c_conv_desc* d, const float* dout, const f
   if (((uintptr_t)dout % 16) || ((uintptr_t)din % 16)) return A2C_ERR_ARG;
   if (signs && signs_bstride < (int64_t)d->Cin * d->H * ((d->W + 31) / 32)) return A2C_ERR_ARG;
   return c3_bwd_data(d, dout, wprep_bwd + prep_floats_base(d, 1), nullptr, signs, (long)signs_bstride, din, B, a2c_s(stream));
+}
+
+/* include/a2c_mi355x.h: layer 2's backward-data fused with the first layer's weight gradient from the uint8 frame store */
+size_t a2c_conv2d_bwd_data_w1_frames_ws_bytes(const a2c_conv_desc* d2, const a2c_conv_desc* d1, int B) {
+  if (!desc_ok(d2) || !desc_ok(d1) || B < 1) return 0;
+  return c3_bwd_data_w1_frames_ws_bytes(d2, d1, B);
+}
+int a2c_conv2d_bwd_data_w1_frames(const a2c_conv_desc* d2, const float* dout, const float* wprep_bwd, const uint32_t* signs,
+                                  int64_t signs_bstride, const a2c_conv_desc* d1, const uint8_t* frame_store, int64_t slot_stride,
+                                  int64_t T, const int32_t* nvalid, float* dW1, float* db1, int B, void* ws, size_t ws_bytes,
+                                  a2c_stream_t stream) {
+  if (!desc_ok(d2) || !desc_ok(d1) || B < 0) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!dout || !wprep_bwd || !signs || !frame_store || !nvalid || !dW1 || !db1 || !ws || T < 1) return A2C_ERR_ARG;
+  if (!c3_bwd_data_w1_frames_supported(d2, d1)) return A2C_ERR_ARG;
+  if (((uintptr_t)dout % 16) || ((uintptr_t)frame_store % 16) || slot_stride % 16 || slot_stride < (T + 3) * (int64_t)d1->H * d1->W ||
+      ((uintptr_t)ws % 16))
+    return A2C_ERR_ARG;
+  if (signs_bstride < (int64_t)d2->Cin * d2->H * ((d2->W + 31) / 32)) return A2C_ERR_ARG;
+  return c3_bwd_data_w1_frames(d2, d1, dout, wprep_bwd + prep_floats_base(d2, 1), signs, (long)signs_bstride, frame_store, (long)slot_stride,
+                               (long)T, nvalid, dW1, db1, B, ws, ws_bytes, a2c_s(stream));
 }
 }  // extern "C"
 namespace {

@@ -209,6 +209,7 @@ struct C3P {
   long sg_bs;                         // sample stride of the sign words (in words)
   C3U8 u8;                            // first layers: uint8 frame-store source instead of src (u8.f != nullptr)
   int prio;                           // loader waves at raised priority
+  float* w1_slab;                     // c3bs_kernel<..., W1>: per (workgroup, w1 wave) partial [16 x 36 | 16] of the FIRST layer's gradient
 };
 // (loader waves issue a few hundred instructions per chunk between the computing waves' MFMA streams: at equal priority they
 // were the critical path of the weight-gradient kernels; A2C_C3_PRIO=0 = round 3's schedule, for A/B runs)
@@ -1293,14 +1294,14 @@ __global__ __launch_bounds__((C3SGeo<CS, CD, H, W, S, R, DS>::NTHR)) void c3s_ke
 // MS: the computing waves also split the destination-channel tiles (MS groups of MT / MS tiles each) -- a 6 x 6 class image
 // (GRUModel conv5: 11 x 11 <- 6 x 6) is three pixel tiles, which would leave five of eight waves idle; with MS = 3 nine waves
 // each own one (pixel tile, channel tile) pair.
-template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES, bool ODD = false, int MS = 1>
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES, bool ODD = false, int MS = 1, bool W1 = false>
 struct C3BSGeo {
   static constexpr int H = 2 * HO - (ODD ? 1 : 0), W = 2 * WO - (ODD ? 1 : 0);
   static constexpr int NCH = CO / KC, C4 = KC / 4, MT = (CI + 15) / 16;
   static constexpr int NBAND = (HO + RQ - 1) / RQ;
   static constexpr int NPIX = RQ * WO;                 // class pixels per band
   static constexpr int NT = (NPIX + 15) / 16;
-  static constexpr int NW = MS == 3 ? 9 : 8, NL = 2, NS = 2;
+  static constexpr int NW = MS == 3 ? 9 : 8, NL = 2, NS = W1 ? 4 : 2;       // (w1 waves: four -- two took 11 us per band against the band's 6.6)
   static constexpr int NTW = NW / MS, MTW = MT / MS;   // waves over the pixel tiles; channel tiles per wave
   static constexpr int NTHR = 64 * (NW + NL + NS);
   static_assert(NW % MS == 0 && MT % MS == 0, "channel-tile split");
@@ -1328,24 +1329,41 @@ struct C3BSGeo {
   static constexpr int BITC = (ODD ? H : 2 * RQ) * RW;
   static_assert(!ODD || ((HO + RQ - 1) / RQ == 1 && (CI * H * W) % 4 == 0), "odd images: one band per sample, a flat 16-byte drain");
   static constexpr int BITB = ((CI * BITC + 3) / 4) * 4;
-  static constexpr size_t LDS_BYTES_S = ((size_t)D * SLOT + FRAG_ALL + STAGE + BITB) * 4;
+  // W1 (round 6): the finished dX band is NOT drained to HBM -- dX is the gradient of the FIRST layer's output, and nothing
+  // but that layer's weight gradient reads it (models.py:570-622: the input needs no gradient) -- the two storer waves become
+  // "w1 waves" that multiply the band (fp32 in `stage`, split into three exact bf16 pieces in registers) against the band's
+  // rows of the uint8 frames (exact in bf16) on the bf16 matrix pipe: dW1[co][ci][ky][kx] += dX[co][y][x] * F[ci][y+ky-1][x+kx-1].
+  // Frame band: rows 2 q0 - 1 .. 2 q0 + 2 RQ of the sample's 4 planes as raw bytes, [plane][row][W / 4 dwords], in a ring of
+  // THREE buffers (band it is multiplied during band it + 1's chunks while the loaders, one band ahead, fill band it + 2's).
+  static constexpr int FR = 2 * RQ + 2, FDW = 4 * FR * (W / 4);                 // rows per plane, data dwords per buffer
+  static constexpr int NIF = W1 ? 4 : 0;                                        // frame DMA instructions per loader and chunk
+  static constexpr int FBUF = W1 ? 8 + NCH * NL * NIF * 64 + 8 : 0;             // floats: pad | data (+ unused tail of the last DMA) | slack
+  static constexpr int NFB = 3;
+  static_assert(!W1 || (NCH * NL * NIF * 64 >= FDW && W % 4 == 0 && !ODD && MS == 1 && CI == 16 && MT == 1), "w1 waves: shape");
+  static constexpr size_t LDS_BYTES_S = ((size_t)D * SLOT + FRAG_ALL + STAGE + BITB + NFB * FBUF) * 4;
   static constexpr bool VEC = (H * W) % 4 == 0 && MROW % 4 == 0;
+  static constexpr long W1_PER = 16 * 36 + 16;                                   // floats per w1 slab: dW1 | db1
   // DMA instructions of one chunk per loader wave (constant by construction: planes and fragment pieces are dealt
   // round robin, a partly filled instruction still issues)
-  static constexpr int NI0 = (KC / NL) * NQ + (FRES ? 0 : (NFQ + 1) / 2);     // loader 0 / loader 1
-  static constexpr int NI1 = (KC / NL) * NQ + (FRES ? 0 : NFQ / 2);
+  static constexpr int NI0 = (KC / NL) * NQ + (FRES ? 0 : (NFQ + 1) / 2) + NIF;     // loader 0 / loader 1
+  static constexpr int NI1 = (KC / NL) * NQ + (FRES ? 0 : NFQ / 2) + NIF;
   static_assert(CO % KC == 0 && KC % NL == 0 && NL == 2, "every chunk is the same number of DMA instructions per loader");
   static_assert(LOOK >= 1 && LOOK <= NCH && (LOOK - 1) * NI0 <= 63, "lookahead: sign words land before X; vmcnt is 6 bits");
 };
 
 
-template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES, bool ODD = false, int MS = 1>
-__global__ __launch_bounds__((C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD, MS>::NTHR)) void c3bs_kernel(C3P p) {
-  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD, MS>;
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES, bool ODD = false, int MS = 1, bool W1 = false>
+__global__ __launch_bounds__((C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD, MS, W1>::NTHR)) void c3bs_kernel(C3P p) {
+  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD, MS, W1>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const fres = lds + D * G::SLOT;                     // resident fragments (FRES)
   float* const stage = fres + G::FRAG_ALL;
   unsigned* const bitb = reinterpret_cast<unsigned*>(stage + G::STAGE);
+  unsigned* const fbuf0 = bitb + G::BITB;                    // W1: three frame-band buffers of FBUF dwords (data at + 8)
+  if constexpr (W1) {                                        // pads / slack read as zero (column -1 of the first row, past the last)
+    for (int i = threadIdx.x; i < G::NFB * G::FBUF; i += G::NTHR) fbuf0[i] = 0u;
+    __syncthreads();
+  }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, j = lane & 15;
   const long ntile = (long)p.B * G::NBAND;
@@ -1397,20 +1415,148 @@ __global__ __launch_bounds__((C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD, MS>:
       }
       }
     };
+    // ---- W1: this wave's share of the first layer's weight gradient (see C3BSGeo).  MFMA 16x16x32 bf16: A = dX pieces, lane
+    // (g, j) = channel co = j, pixels x0 + 8 g .. + 7 of a band row; B = frame windows, lane (g, j) = window row (ci, ky) = (j / 3,
+    // j % 3) for j < 12, the same 8 pixels shifted by kx - 1 -- ONE 10-byte read serves kx = 0, 1, 2 (three accumulator tiles);
+    // D[co = 4 g + i][j] per kx.  Band row r of part `part`: 4 part + 2 sw + {0, 1}.
+    typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+    typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+    if constexpr (W1) {
+      if (p.prio) __builtin_amdgcn_s_setprio(2);              // (the band waits for them at X: 7.01 -> 6.87 ms at N = 32,768)
+    }
+    f32x4 wacc0 = {0.f, 0.f, 0.f, 0.f}, wacc1 = wacc0, wacc2 = wacc0;
+    float wdb = 0.f;
+    const int g = lane >> 4, j = lane & 15;
+    const int wci = j < 12 ? j / 3 : 0, wky = j < 12 ? j % 3 : 0;
+    auto w1 = [&](long tile, int it, int part) {
+     if constexpr (W1) {
+      const long b = (long)((unsigned)tile / (unsigned)G::NBAND);
+      const int q0 = (int)(tile - b * G::NBAND) * RQ;
+      const int nrows = 2 * min(RQ, HO - q0);
+      const int nvl = p.u8.nv ? p.u8.nv[b * p.u8.nv_s] : 4;
+      const bool blive = j < 12 && wci >= 4 - nvl;                                   // planes older than the last reset read as zero
+      const unsigned char* __restrict__ fb = reinterpret_cast<const unsigned char*>(fbuf0 + (it % G::NFB) * G::FBUF + 8);
+      constexpr int RPP = (2 * RQ) / (G::NCH * G::NS);                               // rows per part and wave
+      static_assert(RPP * G::NCH * G::NS == 2 * RQ, "band rows dealt evenly to parts and w1 waves");
+#pragma unroll 1
+      for (int rr = 0; rr < RPP; ++rr) {
+        const int r = (part * G::NS + sw) * RPP + rr;
+        if (r >= nrows) continue;
+        const float* __restrict__ arow = stage + j * G::MROWP + r * G::W;
+        const int brow = ((wci * G::FR + r + wky) * G::W);                           // byte offset of column 0 of this lane's frame row
+#pragma unroll
+        for (int x0 = 0; x0 < G::W; x0 += 32) {                                      // (unrolled: the three steps' LDS reads go out together)
+          const int px0 = x0 + 8 * g;                                                // this lane's first pixel
+          // A: eight dX values of channel j, three exact bf16 pieces each
+          float e[8];
+          if (px0 + 8 <= G::W) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(arow + px0), v1 = *reinterpret_cast<const f32x4*>(arow + px0 + 4);
+            e[0] = v0[0]; e[1] = v0[1]; e[2] = v0[2]; e[3] = v0[3]; e[4] = v1[0]; e[5] = v1[1]; e[6] = v1[2]; e[7] = v1[3];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = px0 + i < G::W ? arow[min(px0 + i, G::W - 1)] : 0.f;
+          }
+          unsigned int ah[4], am[4], al[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned short pc[3][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float ev = e[2 * i + h];
+              const __bf16 h0 = (__bf16)ev;
+              const float r1 = ev - (float)h0;
+              const __bf16 h1 = (__bf16)r1;
+              const float r2 = r1 - (float)h1;
+              pc[0][h] = __builtin_bit_cast(unsigned short, h0);
+              pc[1][h] = __builtin_bit_cast(unsigned short, h1);
+              pc[2][h] = __builtin_bit_cast(unsigned short, (__bf16)r2);
+              wdb += ev;
+            }
+            ah[i] = (unsigned int)pc[0][0] | ((unsigned int)pc[0][1] << 16);
+            am[i] = (unsigned int)pc[1][0] | ((unsigned int)pc[1][1] << 16);
+            al[i] = (unsigned int)pc[2][0] | ((unsigned int)pc[2][1] << 16);
+          }
+          // B: frame bytes of columns px0 - 1 .. px0 + 8 (ten), zero outside the row / the plane
+          const int a = brow + px0 - 1;                                             // (>= -1: the pad dword in front of the data)
+          const unsigned int* __restrict__ q = reinterpret_cast<const unsigned int*>(fb + (a & ~3));
+          const unsigned int d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+          const unsigned int sh = (unsigned int)(a & 3);
+          unsigned int s0 = __builtin_amdgcn_alignbyte(d1, d0, sh), s1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                       s2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+          if (px0 == 0) s0 &= 0xffffff00u;                                           // column -1
+          const int nvh = G::W - (px0 - 1);                                          // valid bytes from the first one
+          if (nvh < 10) {                                                            // (row tail: the bytes behind it are the next row's)
+            const unsigned int m0 = nvh >= 4 ? 0xffffffffu : nvh <= 0 ? 0u : (1u << (8 * nvh)) - 1u;
+            const unsigned int m1 = nvh >= 8 ? 0xffffffffu : nvh <= 4 ? 0u : (1u << (8 * (nvh - 4))) - 1u;
+            const unsigned int m2 = nvh >= 12 ? 0xffffffffu : nvh <= 8 ? 0u : (1u << (8 * (nvh - 8))) - 1u;
+            s0 &= m0; s1 &= m1; s2 &= m2;
+          }
+          if (!blive) { s0 = 0u; s1 = 0u; s2 = 0u; }
+          // bytes -> bf16 (the upper halves of the exact floats), pairs (e0 e1) (e2 e3) (e4 e5) (e6 e7) (e8 e9)
+          const unsigned int P0 = __builtin_amdgcn_perm(__float_as_uint((float)((s0 >> 8) & 0xffu)), __float_as_uint((float)(s0 & 0xffu)), 0x07060302u);
+          const unsigned int P1 = __builtin_amdgcn_perm(__float_as_uint((float)(s0 >> 24)), __float_as_uint((float)((s0 >> 16) & 0xffu)), 0x07060302u);
+          const unsigned int P2 = __builtin_amdgcn_perm(__float_as_uint((float)((s1 >> 8) & 0xffu)), __float_as_uint((float)(s1 & 0xffu)), 0x07060302u);
+          const unsigned int P3 = __builtin_amdgcn_perm(__float_as_uint((float)(s1 >> 24)), __float_as_uint((float)((s1 >> 16) & 0xffu)), 0x07060302u);
+          const unsigned int P4 = __builtin_amdgcn_perm(__float_as_uint((float)((s2 >> 8) & 0xffu)), __float_as_uint((float)(s2 & 0xffu)), 0x07060302u);
+          const u32x4s b0 = {P0, P1, P2, P3};
+          const u32x4s b1 = {__builtin_amdgcn_alignbit(P1, P0, 16u), __builtin_amdgcn_alignbit(P2, P1, 16u),
+                             __builtin_amdgcn_alignbit(P3, P2, 16u), __builtin_amdgcn_alignbit(P4, P3, 16u)};
+          const u32x4s b2 = {P1, P2, P3, P4};
+          const u32x4s ahv = {ah[0], ah[1], ah[2], ah[3]}, amv = {am[0], am[1], am[2], am[3]}, alv = {al[0], al[1], al[2], al[3]};
+          const bf16x8s A0 = __builtin_bit_cast(bf16x8s, ahv), A1 = __builtin_bit_cast(bf16x8s, amv), A2 = __builtin_bit_cast(bf16x8s, alv);
+          const bf16x8s B0 = __builtin_bit_cast(bf16x8s, b0), B1 = __builtin_bit_cast(bf16x8s, b1), B2 = __builtin_bit_cast(bf16x8s, b2);
+          wacc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0, B0, wacc0, 0, 0, 0);
+          wacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0, B1, wacc1, 0, 0, 0);
+          wacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0, B2, wacc2, 0, 0, 0);
+          wacc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B0, wacc0, 0, 0, 0);
+          wacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, wacc1, 0, 0, 0);
+          wacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B2, wacc2, 0, 0, 0);
+          wacc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, B0, wacc0, 0, 0, 0);
+          wacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, B1, wacc1, 0, 0, 0);
+          wacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, B2, wacc2, 0, 0, 0);
+        }
+      }
+     }
+    };
     long pend = -1;
+    int pend_it = 0;
     const bool stamp = C3_STAMPS && p.dbg != nullptr && blockIdx.x == 0 && sw == 0 && lane == 0;
     unsigned long long tdr = 0;
     for (long k = 0; k < nwork; ++k) {
       const int ch = (int)((unsigned)k % (unsigned)G::NCH);
       const unsigned long long t0 = stamp ? wall_clock64() : 0;
-      if (pend >= 0) drain(pend, ch);
+      if (pend >= 0) {
+        if constexpr (W1) w1(pend, pend_it, ch);
+        else drain(pend, ch);
+      }
       if (stamp) tdr += wall_clock64() - t0;
       if (ch == G::NCH - 1) c3_bar();      // X
       c3_bar();
-      if (ch == G::NCH - 1) pend = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
+      if (ch == G::NCH - 1) {
+        pend_it = (int)((unsigned)k / (unsigned)G::NCH);
+        pend = blockIdx.x + (long)pend_it * gridDim.x;
+      }
     }
     if (pend >= 0)
-      for (int part = 0; part < G::NCH; ++part) drain(pend, part);
+      for (int part = 0; part < G::NCH; ++part) {
+        if constexpr (W1) w1(pend, pend_it, part);
+        else drain(pend, part);
+      }
+    if constexpr (W1) {
+      // this wave's partial sums -> its slab: dW1 as [co][ci * 9 + ky * 3 + kx], then db1 (a fixed-order reduction adds the slabs)
+      float* __restrict__ sl = p.w1_slab + ((long)blockIdx.x * G::NS + sw) * G::W1_PER;
+      if (j < 12) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float* __restrict__ o = sl + (4 * g + i) * 36 + wci * 9 + wky * 3;
+          o[0] = wacc0[i]; o[1] = wacc1[i]; o[2] = wacc2[i];
+        }
+      }
+      float v = wdb;
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) sl[16 * 36 + j] = v;
+    }
     if (stamp) p.dbg[4] = tdr;
     return;
   }
@@ -1431,6 +1577,20 @@ __global__ __launch_bounds__((C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD, MS>:
         roff[q] = r * WO + x;
       }
     }
+    // W1: the band's frame rows travel as dwords, 64 consecutive dwords of the [plane][row][W / 4] buffer per instruction;
+    // instruction (ch, lw, u) of the band covers dwords ((ch * NL + lw) * NIF + u) * 64 + lane
+    int frow[G::NCH * (W1 ? G::NIF : 0) + 1], foff[G::NCH * (W1 ? G::NIF : 0) + 1];
+    if constexpr (W1) {
+#pragma unroll
+      for (int i = 0; i < G::NCH * G::NIF; ++i) {
+        const int ch_ = i / G::NIF, u_ = i % G::NIF;
+        const int dw = ((ch_ * G::NL + lw) * G::NIF + u_) * 64 + lane;
+        const int rowi = dw / (G::W / 4), x4 = dw - rowi * (G::W / 4);
+        const int ci = rowi / G::FR, fr = rowi - ci * G::FR;
+        frow[i] = dw < G::FDW ? fr : -100000;                      // frame row 2 q0 - 1 + fr of plane ci
+        foff[i] = (ci * G::H + fr - 1) * G::W + 4 * x4;            // (+ 2 q0 * W: byte offset in the sample's 4 planes)
+      }
+    }
     auto dma = [&](long k) {
       const long tile = blockIdx.x + ((unsigned)k / (unsigned)G::NCH) * gridDim.x;
       const int ch = (int)((unsigned)k % (unsigned)G::NCH);
@@ -1438,6 +1598,22 @@ __global__ __launch_bounds__((C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, ODD, MS>:
       const int q0 = (int)(tile - b * G::NBAND) * RQ;
       float* __restrict__ buf = lds + ((unsigned)k % (unsigned)D) * G::SLOT;
       const float* __restrict__ sb = p.src + b * p.src_bs + ((long)ch * KC * HO + q0) * WO;
+      if constexpr (W1) {
+        const unsigned bu_ = (unsigned)b, slot_ = bu_ / (unsigned)p.u8.T;
+        const unsigned char* __restrict__ fbs = p.u8.f + (long)slot_ * p.u8.bs + (long)(bu_ - slot_ * (unsigned)p.u8.T) * (G::H * G::W);
+        unsigned* __restrict__ fd = fbuf0 + (((unsigned)k / (unsigned)G::NCH) % (unsigned)G::NFB) * G::FBUF + 8;
+#pragma unroll
+        for (int u = 0; u < G::NIF; ++u) {
+          // (the table index must be a compile-time constant per unrolled trip: select among the NCH chunks' entries)
+          int fr_ = 0, fo_ = 0;
+#pragma unroll
+          for (int c_ = 0; c_ < G::NCH; ++c_)
+            if (c_ == ch) { fr_ = frow[c_ * G::NIF + u]; fo_ = foff[c_ * G::NIF + u]; }
+          const int y = 2 * q0 - 1 + fr_;
+          const void* gsrc = (fr_ >= 0 && y >= 0 && y < G::H) ? (const void*)(fbs + fo_ + 2 * q0 * G::W) : (const void*)p.zero;
+          __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(fd + ((ch * G::NL + lw) * G::NIF + u) * 64), 4, 0, 0);
+        }
+      }
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         if (c % G::NL != lw) continue;
@@ -1675,6 +1851,44 @@ int c3bs_launch(const C3P& p, hipStream_t st) {
   if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;      // (the kernels walk chunks with 32-bit arithmetic)
   const int grid = (int)(total < cus ? total : cus);
   hipLaunchKernelGGL((c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES, ODD, MS>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES_S, st, p);
+  if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
+  return A2C_OK;
+}
+
+__global__ void c3w_reduce_kernel(const float* __restrict__ slab, int nslab, long per, long nW, float* __restrict__ dW,
+                                  float* __restrict__ db);
+// c3bs_kernel<..., W1 = true>: backward-data of layer 2 with the FIRST layer's weight gradient taken from the band in LDS (the
+// input gradient of layer 2 never reaches HBM).  ws = [grid * NS] slabs of 16 x 36 + 16 floats; a fixed-order reduction -> dW1, db1.
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES>
+size_t c3bs_w1_ws_bytes(int B) {
+  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, false, 1, true>;
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  const long total = (long)B * G::NBAND;
+  const long grid = total < cus ? total : cus;
+  return (size_t)(grid * G::NS * G::W1_PER) * sizeof(float);
+}
+template <int CO, int CI, int HO, int WO, int RQ, int KC, int D, bool FRES>
+int c3bs_w1_launch(C3P p, float* dW1, float* db1, void* ws, size_t ws_bytes, hipStream_t st) {
+  using G = C3BSGeo<CO, CI, HO, WO, RQ, KC, D, FRES, false, 1, true>;
+  static_assert(G::LDS_BYTES_S <= 160 * 1024, "LDS");
+  const void* k = (const void*)c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES, false, 1, true>;
+  static int cus = 0;
+  if (!cus) {
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES_S) != hipSuccess) return A2C_ERR_LAUNCH;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const long total = (long)p.B * G::NBAND;
+  if (total * G::NCH >= (1L << 31)) return A2C_ERR_ARG;
+  const int grid = (int)(total < cus ? total : cus);
+  if (ws_bytes < (size_t)grid * G::NS * G::W1_PER * sizeof(float)) return A2C_ERR_WORKSPACE;
+  p.w1_slab = (float*)ws;
+  hipLaunchKernelGGL((c3bs_kernel<CO, CI, HO, WO, RQ, KC, D, FRES, false, 1, true>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES_S, st, p);
+  if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
+  hipLaunchKernelGGL(c3w_reduce_kernel, dim3(3), dim3(256), 0, st, (const float*)ws, grid * G::NS, G::W1_PER, (long)16 * 36, dW1, db1);
   if (hipGetLastError() != hipSuccess) return A2C_ERR_LAUNCH;
   return A2C_OK;
 }
@@ -2314,7 +2528,29 @@ int c3_bwd_data(const a2c_conv_desc* d, const float* dout, const float* frag, co
   return A2C_ERR_ARG;
 }
 
-// weight gradient: instantiations and their workspace
+// layer 2's backward-data (sign-word mask) + the first layer's weight gradient from the uint8 frame store, in one pass:
+// GRUModel's conv2 (16 <- 24, 84 x 84 <- 42 x 42, stride 2) over conv1 (4 -> 16, 3 x 3, stride 1, pad 1)
+bool c3_bwd_data_w1_frames_supported(const a2c_conv_desc* d2, const a2c_conv_desc* d1) {
+  static const bool off = getenv("A2C_NO_W1_FRAMES") && getenv("A2C_NO_W1_FRAMES")[0] == '1';
+  return !off && c3_supported(d2, 1) && d2->stride == 2 && d2->H == 84 && d2->W == 84 && d2->Cin == 16 && d2->Cout == 24 &&
+         d1->Cin == 4 && d1->Cout == 16 && d1->H == 84 && d1->W == 84 && d1->ks == 3 && d1->stride == 1 && d1->pad == 1;
+}
+size_t c3_bwd_data_w1_frames_ws_bytes(const a2c_conv_desc* d2, const a2c_conv_desc* d1, int B) {
+  if (B < 1 || !c3_bwd_data_w1_frames_supported(d2, d1)) return 0;
+  return c3bs_w1_ws_bytes<24, 16, 42, 42, 6, 8, 4, true>(B);
+}
+int c3_bwd_data_w1_frames(const a2c_conv_desc* d2, const a2c_conv_desc* d1, const float* dout, const float* frag, const unsigned* signs,
+                          long signs_bs, const unsigned char* f, long bs, long T, const int* nv, float* dW1, float* db1, int B, void* ws,
+                          size_t ws_bytes, hipStream_t st) {
+  if (!c3_bwd_data_w1_frames_supported(d2, d1)) return A2C_ERR_ARG;
+  C3P p{dout, (long)d2->Cout * d2->OH * d2->OW, frag, nullptr, nullptr, nullptr, 0, zero_page(), B, 0, g_c3_dbg,
+        nullptr, signs, signs_bs, C3U8{f, bs, nv, 1, T}};
+  if (!p.zero) return A2C_ERR_LAUNCH;
+  p.prio = c3_prio();
+  return c3bs_w1_launch<24, 16, 42, 42, 6, 8, 4, true>(p, dW1, db1, ws, ws_bytes, st);
+}
+
+// weight gradient: instantiations and their workspace// weight gradient: instantiations and their workspace
 // (CS, CD, H, W, S, R rows per band, KC channels per chunk, NCG, D chunk images in the ring)
 #define C3W_CASES(X)                                                                              \
   X(4, 16, 84, 84, 1, 6, 4, 1, 3)   /* conv1 of both models                                    */ \

@@ -227,8 +227,13 @@ def test_frame_store_rollouts_and_updates_equal_the_plain_path_bit_for_bit(kind,
             if k == 0:
                 assert float(D["states"].abs().sum()) == 0.0          # really never written
 
+    # (GRUModel: round 6's fused pass -- layer 2's backward-data with the first layer's weight gradient from the frames, on the
+    # bf16 pipe -- re-associates that one gradient; bit-for-bit equality with the plain path holds for the UNFUSED launches,
+    # the fused pass has its own test below)
+    monkeypatch.setenv("A2C_NO_W1_FRAMES", "1")
     plain = _run_engine(kind, base_hyps(**base), ekws, usd, B, T, A, ss, h, 3)
     store = _run_engine(kind, base_hyps(frame_store=True, lazy_states=lazy, **base), ekws, usd, B, T, A, ss, h, 3, check=check)
+    monkeypatch.delenv("A2C_NO_W1_FRAMES")
     assert seen["frames"] == 3 and (not lazy or seen["stale"] == 5)
     for k in range(3):
         for n in plain[k][0]:
@@ -241,6 +246,44 @@ def test_frame_store_rollouts_and_updates_equal_the_plain_path_bit_for_bit(kind,
     onet = O.OracleNet(kind, ss, A, h)
     ref = _oracle_rollouts(kind, onet, base_hyps(**base), ekws, us, 1, B, T, ss)[0]
     _compare_round({k: v for k, v in store[0][0].items()}, ref, onet.is_recurrent)
+
+
+@pytest.mark.parametrize("bptt", [True, False])
+def test_gru_update_with_the_fused_first_layer_gradient_equals_the_unfused_launches(bptt, monkeypatch):
+    """GRUModel on the single-frame store: the update's conv2 backward-data + conv1 weight gradient as ONE launch
+    (a2c_conv2d_bwd_data_w1_frames: the 16 x 84 x 84 input gradient of conv2 never reaches HBM) against the two launches it
+    replaces (A2C_NO_W1_FRAMES=1) after identical rollouts: every gradient but conv1's bit-identical, conv1's weight / bias
+    gradient at re-association tolerance (2e-6 of its scale), the reported infos to 1e-6 (GradNorm sums that gradient)."""
+    B, T, A, ss, h = 5, 6, 3, (4, 84, 84), 256
+    ekws = [dict(env_id=j, rew_period=2 + j % 2, done_period=4 + j) for j in range(B)]
+    base = dict(env_type="FakePong-v0", n_tsteps=T, n_rollouts=B, action_shift=0, n_envs=B, lr=1e-3, optim_type="RMSprop",
+                use_bptt=bptt, h_size=h, frame_store=True, lazy_states=True)
+    usd = torch.from_numpy(hashf(2 * T * B, 6152, 0, 1).reshape(2, T, B)).to(DEV)
+    res = {}
+    for mode in ("fused", "unfused"):
+        if mode == "unfused":
+            monkeypatch.setenv("A2C_NO_W1_FRAMES", "1")
+        grads, spans = [], []
+
+        def check(r, net, D, k, grads=grads):
+            if k == -1:                                         # right after the update: the arena still holds its gradients
+                grads.append({n: net.G(n).detach().cpu().clone() for n, _ in net.named_parameters() if n not in net._unused_params})
+        outs = _run_engine("GRUModel", base_hyps(**base), ekws, usd, B, T, A, ss, h, 2, check=check)
+        res[mode] = (outs, grads)
+    monkeypatch.delenv("A2C_NO_W1_FRAMES")
+    (fo, fg), (uo, ug) = res["fused"], res["unfused"]
+    for n in fo[0][0]:
+        assert torch.equal(fo[0][0][n], uo[0][0][n]), n            # the same rollout
+    assert len(fg) == 1 and len(ug) == 1
+    for n in fg[0]:
+        if n.startswith("convs.0.0"):
+            sc = float(ug[0][n].abs().max())
+            close(n, fg[0][n], ug[0][n], 2e-6 * sc, 1e-5)
+            assert not torch.equal(fg[0][n], ug[0][n]) or sc == 0.0      # (the fused pass really ran: another summation order)
+        else:
+            assert torch.equal(fg[0][n], ug[0][n]), n
+    for k in fo[0][1]:
+        assert fo[0][1][k] == pytest.approx(uo[0][1][k], rel=1e-6, abs=1e-9), k
 
 
 @pytest.mark.parametrize("prep,kind", [("pong_prep", "A3CModel"), ("breakout_prep", "FCModel")])

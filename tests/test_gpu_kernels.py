@@ -916,6 +916,64 @@ def test_small_n_bwd_data_with_mask_bits_equals_the_float_mask_path(M, N):
     close("vs fp64", got, ref, 1e-6, 1e-5)
 
 
+@pytest.mark.parametrize("B,vmax", [(3, 2), (40, 256), (300, 256)])
+def test_conv2_backward_data_fused_with_the_first_layers_weight_gradient_from_frames(B, vmax):
+    """round 6, GRUModel's conv2 over conv1 (models.py:570-590): a2c_conv2d_bwd_data_w1_frames keeps layer 2's masked input
+    gradient in LDS and takes the first layer's weight gradient from it on the bf16 pipe (three exact bf16 pieces x exact uint8
+    pixels, fp32 accumulation) -- against the two unfused launches (a2c_conv2d_bwd_data_signs, then
+    a2c_conv2d_bwd_weight_frames) at re-association tolerance, and no further from the fp64 gradient than they are.
+    B = 3 / 40 / 300: fewer bands than CUs, about one, several per workgroup; fresh episodes (nvalid < 4) mixed in."""
+    ops = _ops()
+    d2, d1 = ops.conv_desc(16, 84, 84, 24, 3, 2, 1), ops.conv_desc(4, 84, 84, 16, 3, 1, 1)
+    nb = ops.conv_bwd_data_w1_frames_ws_bytes(d2, d1, B)
+    assert nb > 0 and ops.conv_bwd_data_w1_frames_ws_bytes(ops.conv_desc(24, 42, 42, 32, 3, 2, 1), d1, B) == 0
+    T, HW = 8, 84 * 84
+    R = (B + T - 1) // T
+    rng = np.random.default_rng(4400 + B)
+    Fs = rng.integers(0, vmax, size=(R, T + 4, HW), dtype=np.uint8)
+    nv = np.where(rng.random(R * T) < 0.8, 4, rng.integers(1, 5, size=(R * T,))).astype(np.int32)
+    Fd, nvd = torch.from_numpy(Fs).to(DEV), torch.from_numpy(nv).to(DEV)
+    w2 = rnd((24, 16, 3, 3), 31) / 12.0
+    dout = (rnd((B, 24, 42, 42), 32) * torch.from_numpy(rng.lognormal(0, 1, size=(B, 1, 1, 1)).astype(np.float32))).to(DEV)
+    a1pos = torch.from_numpy(rng.random((B, 16, 84, 84)) < 0.6)
+    words = _sign_words(a1pos).to(DEV)
+    wb = torch.empty(ops.conv_prep_floats(d2, 1), device=DEV)
+    ops.conv_prep(d2, 1, w2.to(DEV), wb)
+    # unfused
+    din = torch.full((B, 16, 84, 84), float("nan"), device=DEV)
+    ops.conv_bwd_data_signs(d2, dout, wb, words, din, B)
+    dW_u, db_u = torch.full((16, 4, 3, 3), float("nan"), device=DEV), torch.full((16,), float("nan"), device=DEV)
+    ws_u = torch.empty((ops.conv_bwd_weight_ws_bytes(d1, B) + 3) // 4, device=DEV)
+    ops.conv_bwd_weight_frames(d1, Fd, Fd.stride(0), T, nvd, din, dW_u, db_u, B, ws_u)
+    # fused
+    dW_f, db_f = torch.full((16, 4, 3, 3), float("nan"), device=DEV), torch.full((16,), float("nan"), device=DEV)
+    ws_f = torch.empty((nb + 3) // 4, device=DEV)
+    ops.conv_bwd_data_w1_frames(d2, dout, wb, words, d1, Fd, Fd.stride(0), T, nvd, dW_f, db_f, B, ws_f)
+    dW_g, db_g = torch.empty_like(dW_f), torch.empty_like(db_f)
+    ops.conv_bwd_data_w1_frames(d2, dout, wb, words, d1, Fd, Fd.stride(0), T, nvd, dW_g, db_g, B, ws_f)
+    torch.cuda.synchronize()
+    assert torch.equal(dW_f, dW_g) and torch.equal(db_f, db_g)              # deterministic
+    # fp64: da1 = conv_transpose(dout, w2) * (a1 > 0); dW1 = conv1's weight gradient over the stacked frames
+    da1 = F.conv_transpose2d(dout.cpu().double(), w2.double(), stride=2, padding=1, output_padding=1) * a1pos
+    xs = torch.zeros(B, 4, 84, 84, dtype=torch.float64)
+    for n in range(B):
+        r, t = divmod(n, T)
+        for c in range(4):
+            if c >= 4 - nv[n]:
+                xs[n, c] = torch.from_numpy(Fs[r, t + c].astype(np.float64)).reshape(84, 84)
+    wt = torch.zeros(16, 4, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xs, wt, padding=1).backward(da1)
+    want, wantb = wt.grad, da1.sum((0, 2, 3))
+    rms = float(want.pow(2).mean().sqrt())
+    e_f = float((dW_f.cpu().double() - want).pow(2).mean().sqrt()) / rms
+    e_u = float((dW_u.cpu().double() - want).pow(2).mean().sqrt()) / rms
+    print(f"B={B} vmax={vmax}: rms(fused - fp64)/rms = {e_f:.2e}, rms(unfused - fp64)/rms = {e_u:.2e}")
+    assert e_f <= 2 * e_u + 2e-7, (e_f, e_u)
+    close("dW1 fused vs unfused", dW_f, dW_u, 2e-6 * float(want.abs().max()), 1e-5)
+    close("db1", db_f, wantb, 2e-6 * float(wantb.abs().max()) + 1e-6, 2e-6)
+    close("db1 unfused", db_u, wantb, 2e-6 * float(wantb.abs().max()) + 1e-6, 2e-6)
+
+
 # ------------------------------------------------------------------ GRU gates / LayerNorm
 def test_gru_kernels_vs_autograd():
     ops = _ops()

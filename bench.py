@@ -642,6 +642,18 @@ def site_roofline(name, site, conv_layers, batch, u8_store=False, bf16_pipe=Fals
     fp32 way a fast launch "exceeds" the peak (round 5's side report printed 1.20), which is not a roofline."""
     lname, _, what = name.partition(".")
     out = dict(site=name, avg_ms=round(site["avg_ms"], 4), launches=site["launches"])
+    if "+" in name:                  # a fused pass (GRUModel: conv2.bwd_data+conv1.bwd_weight): two layers' flops, one layer's bytes
+        l2, l1 = conv_layers.get("conv2"), conv_layers.get("conv1")
+        if l2 is not None and l1 is not None:
+            sec = site["avg_ms"] * 1e-3
+            by = batch * (4.0 * l2.d.Cout * l2.d.OH * l2.d.OW + l1.d.H * l1.d.W + l2.d.Cin * l2.d.H * l2.d.W / 8.0)
+            out.update(batch=batch, alg_bytes=by, hbm_GBs=round(by / sec / 1e9, 1), frac_of_hbm_peak=round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
+                       alg_flops=conv_flops(l2.d, batch) + conv_flops(l1.d, batch),
+                       note="layer 2's input gradient stays in LDS: bytes = its dOut + the uint8 frames + the sign words; the "
+                            "first layer's weight gradient runs on the bf16 pipe (3 x its flops), layer 2's backward on fp32 MFMAs")
+            t_pk = conv_flops(l2.d, batch) / (F32_PEAK_TFLOPS * 1e12) + 3.0 * conv_flops(l1.d, batch) / (BF16_PEAK_TFLOPS * 1e12)
+            out["frac_of_pipe_peak"] = round(t_pk / sec, 4)
+        return out
     if lname == "linear":            # "linear.<pass> NxK": a dense fp32 GEMM over `batch` rows
         try:
             n_, k_ = (int(v) for v in what.split(" ")[1].split("x"))

@@ -1745,7 +1745,6 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   for (int i = tid; i < p.Cout * PLANE + 64; i += BS_NT) img[i] = 0.f;       // halo stays 0 forever
   const BwdClass k = p.cls[w & 3];
   const int half = w >> 2;
-  const int wu = __builtin_amdgcn_readfirstlane(w);
   float af[32];
 #pragma unroll
   for (int s = 0; s < 32; ++s) af[s] = p.wfrag[k.frag_off + s * 64 + lane];

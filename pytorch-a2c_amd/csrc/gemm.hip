@@ -745,6 +745,158 @@ static bool launch_gemm_nt(long M, long N, long K, const float* A, long lda, con
   return launch_gemm_nt_shape<nt::Big>(M, N, K, A, lda, B, ldb, kps, splits, slab, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "bf16 x 6" (round 6): the large dense products of ConvModel's update (2048 .. 32768 rows against the 28224 x 2000 layer) on
+// the bf16 pipe with fp32 results.  Both fp32 operands are split into three bf16 pieces a = a0 + a1 + a2 (exact, see
+// split1_x9); of the nine piece products the SIX with qa + qb <= 2 are issued: the dropped ones are below 2^-24 of |a b| --
+// under the rounding of the fp32 product itself -- and every issued product is exact (8 x 8 bits) with the sums in the MFMA's
+// fp32 accumulator.  6 v_mfma_f32_32x32x16_bf16 (32 cycles) per 16-deep k-step replace 8 v_mfma_f32_32x32x2_f32 (64 cycles):
+// 0.375 of the fp32 matrix time.  What kept the x 9 form above at a tie was the operand traffic (1.5 x the bytes through L2 and
+// LDS, register staging, two barriers per 32-deep step); here:
+//   * x6_split_kernel writes the piece images in PANEL order img[q][row / 256][k / 16][(k / 8) & 1][row % 256][8]: the
+//     256 rows x 16 k of one (piece, row block, k block) are 8 KB contiguous, in the order the LDS wants them;
+//   * a workgroup (8 waves, 2 x 4, 128 x 64 per wave) owns a 256 x 256 tile: 16 B of operand per cycle and CU at full MFMA
+//     rate instead of 32; a stage (16 k of 512 rows, three pieces: 48 KB) arrives by LDS-DMA (global_load_lds_dwordx4, six
+//     instructions per wave and stage, no staging registers) into a ring of three, two stages ahead, counted vmcnt, ONE raw
+//     barrier per stage; an MFMA operand is one conflict-free ds_read_b128 (lanes of a k-half are 512 contiguous bytes);
+//   * work items (split, group of 8 row blocks, column block, row block) are dealt to the XCDs in contiguous runs (workgroup id
+//     & 7 = XCD), so that the 32 workgroups an XCD runs at a time are 8 row blocks x 4 column blocks reading the same panels
+//     at the same k: each panel crosses the fabric once per round, not once per tile.
+namespace x6 {
+constexpr int TM = 256, TN = 256, BK = 16, DEPTH = 3;
+constexpr int CH = 256 * BK;                           // bf16 elements of one chunk [k-half][row][8] = 8 KB
+constexpr int STG = 6 * CH;                            // A pieces 0..2, B pieces 0..2
+constexpr size_t LDS_BYTES = (size_t)DEPTH * STG * 2;  // 147,456
+}  // namespace x6
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void x6_split_kernel(const float* __restrict__ src, long ld, long R, long K, unsigned short* __restrict__ dst,
+                                                       long Rp, long Kp) {
+  const long pst = Rp * Kp, ng = Kp >> 3, ngb = (ng + 3) >> 2, nblk = (Rp >> 6) * ngb;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long r0 = (blk / ngb) << 6, g0 = (blk % ngb) << 2;
+    long r, g;
+    float e[8];
+    if (!TRANS) {                                      // src[r * ld + k]: four lanes read 128 B of one row
+      r = r0 + (threadIdx.x >> 2); g = g0 + (threadIdx.x & 3);
+      const long k = g << 3;
+      if (r < R && k + 7 < K && (ld & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+        const float4 v0 = *reinterpret_cast<const float4*>(src + r * ld + k), v1 = *reinterpret_cast<const float4*>(src + r * ld + k + 4);
+        e[0] = v0.x; e[1] = v0.y; e[2] = v0.z; e[3] = v0.w; e[4] = v1.x; e[5] = v1.y; e[6] = v1.z; e[7] = v1.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = (r < R && k + i < K) ? src[r * ld + k + i] : 0.f;
+      }
+    } else {                                           // src[k * ld + r]: a wave reads 256 B of one k, eight times
+      r = r0 + (threadIdx.x & 63); g = g0 + (threadIdx.x >> 6);
+      const long k = g << 3;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = (r < R && k + i < K) ? src[(k + i) * ld + r] : 0.f;
+    }
+    if (g < ng) split8_store(e, dst + (r >> 8) * (Kp << 8) + (g >> 1) * x6::CH + (g & 1) * 2048 + (r & 255) * 8, pst);
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_x6_kernel(long M, long N, const unsigned short* __restrict__ Ap, long apst,
+                                                      const unsigned short* __restrict__ Bp, long bpst, long Kp, int nmb, int nnb,
+                                                      int nsplit, int st_per_split, float* __restrict__ C, long ldc,
+                                                      const float* __restrict__ bias, int relu, const float* __restrict__ mask,
+                                                      long ldmask, int accumulate, float* __restrict__ slab) {
+  using namespace x6;
+  using nt::gptr_t;
+  using nt::lptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds6[];
+  long bm, bn, sp;
+  {
+    const long T = (long)nmb * nnb, Wk = T * nsplit, per = (Wk + 7) >> 3;
+    const long id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    const long j = xcd * per + idx;
+    if (idx >= per || j >= Wk) return;
+    sp = j / T;
+    const long rem = j - sp * T, full = (long)(nmb >> 3) * 8 * nnb;
+    if (rem < full) { const long g = rem / (8L * nnb), r2 = rem - g * 8L * nnb; bn = r2 >> 3; bm = 8 * g + (r2 & 7); }
+    else { const long tr = nmb & 7, r2 = rem - full; bn = r2 / tr; bm = (long)(nmb >> 3) * 8 + r2 % tr; }
+  }
+  const int nkb = (int)(Kp >> 4);
+  const int kb0 = (int)sp * st_per_split, nst = min(nkb, kb0 + st_per_split) - kb0;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 2, wc = w & 3, li = lane & 31, lk = lane >> 5;
+  // this wave's 1 KB of every chunk: [w * 64 + lane] * 16 B
+  const unsigned short* __restrict__ ga = Ap + bm * (Kp << 8) + (long)kb0 * CH + w * 512 + lane * 8;
+  const unsigned short* __restrict__ gb = Bp + bn * (Kp << 8) + (long)kb0 * CH + w * 512 + lane * 8;
+  auto dma = [&](int t, int buf) {
+    unsigned short* __restrict__ st = lds6 + buf * STG + w * 512;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(ga + q * apst + (long)t * CH), (lptr_t)(st + q * CH), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(gb + q * bpst + (long)t * CH), (lptr_t)(st + (3 + q) * CH), 16, 0, 0);
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (nst > 0) dma(0, 0);
+  if (nst > 1) dma(1, 1);
+  const int aoff = lk * 2048 + (wr * 128 + li) * 8, boff = 3 * CH + lk * 2048 + (wc * 64 + li) * 8;
+  int buf = 0;
+  for (int t = 0; t < nst; ++t) {
+    if (t + 1 < nst) nt::wait_vm<6>(); else nt::wait_vm<0>();
+    nt::bar();
+    int b2 = buf + 2; if (b2 >= DEPTH) b2 -= DEPTH;
+    if (t + 2 < nst) dma(t + 2, b2);
+    const unsigned short* __restrict__ st = lds6 + buf * STG;
+    bf16x8g a[4][3], b[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8g*>(st + boff + q * CH + j * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8g*>(st + aoff + q * CH + i * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // rising magnitude: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+      }
+    if (++buf == DEPTH) buf = 0;
+  }
+  // C/D map of a 32 x 32 tile: col (n) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const bool direct = (slab == nullptr);
+  float* __restrict__ out = direct ? C : slab + sp * M * N;
+  const long ldo = direct ? ldc : N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long n = bn * TN + wc * 64 + j * 32 + li;
+      if (n >= N) continue;
+      const float bv = (direct && bias) ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = bm * TM + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= M) continue;
+        float v = acc[i][j][r];
+        if (direct) {
+          if (accumulate) v += out[m * ldo + n];
+          v += bv;
+          if (relu) v = fmaxf(v, 0.f);
+          if (mask && !(mask[m * ldmask + n] > 0.f)) v = 0.f;
+        }
+        out[m * ldo + n] = v;
+      }
+    }
+}
+
 // Small products (the GRU cell's h x h and x x 3h GEMMs at rollout / BPTT batch, M = n_envs: a handful of
 // 128 x 128 tiles) used to run as split-K + slab reduce: two launches and a few MB of slab traffic for a few
 // MFLOP, 18 us per product, ~9 products per env step.  Here ONE launch: a workgroup owns a 32 x 32 tile of C, its
@@ -1310,19 +1462,27 @@ size_t a2c_gemm_ws_bytes(int64_t M, int64_t N, int splitk) {
 // bf16 x 9 path of a2c_gemm_f32 (large products): bytes of the three-piece bf16 images of both operands, rows padded to 128
 // and k to 32; 0 when the product does not take that path.  The caller's workspace must hold a2c_gemm_ws_bytes(M, N, splitk)
 // FOLLOWED by this (a2c_gemm_f32 falls back to the fp32 MFMA kernel when it does not).
-static bool x9_eligible(int64_t M, int64_t N, int64_t K) {
-  // OPT-IN (A2C_GEMM_X9=1; read per call): measured on MI355X (tools/gemm_x9_bench.py) the x 9 form ties the fp32 MFMA kernels on
-  // ConvModel's 28224 x 2000 layers -- 2048 rows: NN 2.30 vs 2.26 ms, TN 2.14 vs 2.23, NT 2.42 vs 2.74 including the two
-  // split passes (0.12-0.14 ms each); 32,768 rows: 29.9 / 34.1 / 33.3 vs 31.3 / 32.1 / 32.1 -- the bf16 pipe's 9/16 of the
-  // matrix time is eaten by 1.5 x the operand bytes through L2 / LDS and by the clock the part holds under dense bf16 MFMA on
-  // random data; it pays where ONE operand is exact in bf16 (uint8 frames: 3 pieces, not 9; conv.hip / step.hip).
+static int x9_env() {                        // A2C_GEMM_X9 (read per call): -1 unset, else its first digit
   const char* e9 = getenv("A2C_GEMM_X9");
-  if (!(e9 != nullptr && e9[0] == '1')) return false;
-  return M >= 256 && N >= 256 && K >= 256 && (double)M * (double)N * (double)K >= 2.5e8;
+  return (e9 != nullptr && e9[0] >= '0' && e9[0] <= '9') ? e9[0] - '0' : -1;
+}
+static bool x6_mode() { return x9_env() != 1; }      // the six-product panel kernel (gemm_x6_kernel) unless the x 9 form is asked for
+static bool x9_eligible(int64_t M, int64_t N, int64_t K) {
+  // Measured on MI355X (tools/gemm_x9_bench.py, ConvModel's 28224 x 2000 layers, split passes included):
+  //   x 6 (gemm_x6_kernel, DEFAULT for large products): 2048 rows NN 1.23 vs 2.26 ms fp32, TN 1.23 vs 2.20; 32,768 rows
+  //     16.8 vs 31.3 and 18.9 vs 32.1 (196-220 TF fp32-equivalent);
+  //   x 9 (gemm_x9_kernel, A2C_GEMM_X9=1): ties the fp32 MFMA kernels (2.33 / 2.18 ms; 30.2 / 34.1 ms) -- its 9/16 of the matrix
+  //     time is eaten by 1.5 x the operand bytes through L2 / LDS with 128 x 128 tiles and register staging.
+  // A2C_GEMM_X9=0: the fp32 MFMA kernels everywhere; =2: x 6 from the small threshold on (tests).
+  const int e = x9_env();
+  if (e == 0) return false;
+  if (e == 1 || e == 2) return M >= 256 && N >= 256 && K >= 256 && (double)M * (double)N * (double)K >= 2.5e8;
+  return M >= 1024 && N >= 1024 && K >= 1024 && (double)M * (double)N * (double)K >= 2e10;
 }
 size_t a2c_gemm_x9_ws_bytes(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 1 || K < 1 || !x9_eligible(M, N, K)) return 0;
-  const size_t Mp = (size_t)(M + 127) / 128 * 128, Np = (size_t)(N + 127) / 128 * 128, Kp = (size_t)(K + 31) / 32 * 32;
+  // (rows to 256, k to 32: room for either image layout)
+  const size_t Mp = (size_t)(M + 255) / 256 * 256, Np = (size_t)(N + 255) / 256 * 256, Kp = (size_t)(K + 31) / 32 * 32;
   return 3 * 2 * (Mp + Np) * Kp + 256;
 }
 
@@ -1426,7 +1586,45 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   {  // large products: the bf16 x 9 form (exact 3-way split of both operands, fp32 accumulation) when the workspace holds the images
     const size_t base = a2c_gemm_ws_bytes(M, N, splitk), need9 = a2c_gemm_x9_ws_bytes(M, N, K);
     const size_t off9 = (base + 255) / 256 * 256;
-    if (need9 && ws && ws_bytes >= off9 + need9) {
+    if (need9 && ws && ws_bytes >= off9 + need9 && x6_mode()) {
+      static std::once_flag once6;
+      static bool ready6 = false;
+      std::call_once(once6, [] {
+        ready6 = hipFuncSetAttribute((const void*)gemm_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x6::LDS_BYTES) == hipSuccess;
+      });
+      if (ready6) {
+        const long Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + 15) / 16 * 16;
+        unsigned short* Ap = reinterpret_cast<unsigned short*>((char*)ws + off9);
+        unsigned short* Bp = Ap + 3 * Mp * Kp;
+        const long ngb = (Kp / 8 + 3) / 4;
+        const int ga6 = (int)std::min<long>((Mp / 64) * ngb, 1L << 20), gb6 = (int)std::min<long>((Np / 64) * ngb, 1L << 20);
+        if (a_kc) hipLaunchKernelGGL((x6_split_kernel<false>), dim3(ga6), dim3(256), 0, st, A, (long)lda, (long)M, (long)K, Ap, Mp, Kp);
+        else hipLaunchKernelGGL((x6_split_kernel<true>), dim3(ga6), dim3(256), 0, st, A, (long)lda, (long)M, (long)K, Ap, Mp, Kp);
+        A2C_CHECK_LAUNCH();
+        if (b_kc) hipLaunchKernelGGL((x6_split_kernel<false>), dim3(gb6), dim3(256), 0, st, B, (long)ldb, (long)N, (long)K, Bp, Np, Kp);
+        else hipLaunchKernelGGL((x6_split_kernel<true>), dim3(gb6), dim3(256), 0, st, B, (long)ldb, (long)N, (long)K, Bp, Np, Kp);
+        A2C_CHECK_LAUNCH();
+        const int nmb = (int)(Mp / 256), nnb = (int)(Np / 256), nkb = (int)(Kp / 16);
+        // K splits only where the tiles alone leave CUs idle, and only as many as the caller's slabs hold
+        int want = 1;
+        if ((long)nmb * nnb < 192) want = (int)std::min<long>(256 / ((long)nmb * nnb), nkb / 32);
+        if (want > splitk) want = splitk;
+        if (want < 1) want = 1;
+        const int sps = (nkb + want - 1) / want, s6 = (nkb + sps - 1) / sps;
+        const long wk = (long)nmb * nnb * s6, per = (wk + 7) / 8;
+        hipLaunchKernelGGL(gemm_x6_kernel, dim3((unsigned)(per * 8)), dim3(512), x6::LDS_BYTES, st, (long)M, (long)N, Ap, Mp * Kp, Bp,
+                           Np * Kp, Kp, nmb, nnb, s6, sps, C, (long)ldc, bias, relu, mask, (long)ldmask, accumulate,
+                           s6 > 1 ? slab : nullptr);
+        A2C_CHECK_LAUNCH();
+        if (s6 > 1) {
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(a2c_grid_1d(M * N, 256)), dim3(256), 0, st, slab, s6, (long)M, (long)N, C,
+                             (long)ldc, bias, relu, mask, (long)ldmask, accumulate);
+          A2C_CHECK_LAUNCH();
+        }
+        return A2C_OK;
+      }
+    }
+    if (need9 && ws && ws_bytes >= off9 + need9 && !x6_mode()) {
       const long Mp = (M + 127) / 128 * 128, Np = (N + 127) / 128 * 128, Kp = (K + 31) / 32 * 32;
       unsigned short* Ap = reinterpret_cast<unsigned short*>((char*)ws + off9);
       unsigned short* Bp = Ap + 3 * Mp * Kp;

@@ -1305,8 +1305,9 @@ def test_gru_cell_fwd_two_launches_equal_the_five_bit_for_bit(B, xs, hd, inplace
         ops.gru_cell_fwd(x, h0[:, :hd - 8].contiguous(), WxC, WhC, Wh[2], b, gx2, z2, r2, rh2, c2, mk(B, hd))     # hdim % 32
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("tA,tB,M,N,K", [(0, 1, 1280, 1100, 2000), (0, 0, 1152, 900, 1000), (1, 0, 520, 1030, 777)])
-def test_gemm_bf16_x9_path_is_the_fp32_product(tA, tB, M, N, K, monkeypatch):
+def test_gemm_bf16_x9_path_is_the_fp32_product(tA, tB, M, N, K, mode, monkeypatch):
     """A2C_GEMM_X9=1 (opt-in): both operands split into three bf16 pieces (exact), nine exact piece products per element
     pair, fp32 accumulation -- against fp64 no less accurate than the fp32 MFMA kernels (1.5 x + 1e-7 of the rms), for every
     operand orientation, ragged sizes, bias + ReLU + mask in the epilogue; without the extra workspace the call falls back."""
@@ -1318,20 +1319,20 @@ def test_gemm_bf16_x9_path_is_the_fp32_product(tA, tB, M, N, K, monkeypatch):
     B64 = (b.t() if tB else b).double().cpu()
     want = torch.relu(A64 @ B64 + bias.double().cpu()) * (mask.cpu() > 0)
     res = {}
-    for x9 in ("1", "0"):
+    for x9 in (mode, "0"):
         monkeypatch.setenv("A2C_GEMM_X9", x9)
         nb = ops.gemm_ws_bytes(M, N, 1, K)
-        assert (nb > 0) == (x9 == "1")
+        assert (nb > 0) == (x9 == mode)
         ws = torch.empty(max(1, (nb + 3) // 4), device=DEV)
         c = torch.full((M, N), float("nan"), device=DEV)
         ops.gemm(tA, tB, M, N, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), N, bias=bias, relu=True,
                  mask_ptr=mask.data_ptr(), ldmask=N, ws=ws)
         res[x9] = c.cpu().double()
     rms = float(want.pow(2).mean().sqrt())
-    e9, e32 = (float((res[k] - want).pow(2).mean().sqrt()) / rms for k in ("1", "0"))
+    e9, e32 = (float((res[k] - want).pow(2).mean().sqrt()) / rms for k in (mode, "0"))
     assert e9 <= 1.5 * e32 + 1e-7, (e9, e32)
-    assert not torch.equal(res["1"], res["0"])          # (the x 9 kernel did run)
-    monkeypatch.setenv("A2C_GEMM_X9", "1")              # no room for the images: the fp32 kernel, bit for bit
+    assert not torch.equal(res[mode], res["0"])          # (the x 9 kernel did run)
+    monkeypatch.setenv("A2C_GEMM_X9", mode)              # no room for the images: the fp32 kernel, bit for bit
     c = torch.empty(M, N, device=DEV)
     ops.gemm(tA, tB, M, N, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), N, bias=bias, relu=True,
              mask_ptr=mask.data_ptr(), ldmask=N)

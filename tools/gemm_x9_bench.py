@@ -32,7 +32,7 @@ def timeit(fn, reps=3):
 
 def run(name, tA, tB, M, N, K, a, lda, b, ldb, ref_fn):
     out = {}
-    sk = ops.pick_splitk(M, N, K)
+    sk = int(os.environ.get("X9_SPLITK", 0)) or ops.pick_splitk(M, N, K)
     os.environ["A2C_GEMM_X9"] = "1"
     ws = torch.empty(max(1, (ops.gemm_ws_bytes(M, N, sk, K) + 3) // 4), device=dev)
     for x9 in ("1", "0") + tuple(os.environ.get("X9_EXTRA", "").split()):
@@ -48,7 +48,8 @@ def run(name, tA, tB, M, N, K, a, lda, b, ldb, ref_fn):
     fl = 2.0 * M * N * K
     for k in out:
         if k not in ("0", "1"):
-            print(f"   variant {k}: {out[k][0]:7.3f} ms")
+            ek = float((out[k][1][rows].double() - ref).pow(2).mean().sqrt()) / rms
+            print(f"   variant {k}: {out[k][0]:7.3f} ms {fl / out[k][0] / 1e9:6.1f} TF (err {ek:.2e})")
     print(f"{name:34s} splitk {sk:2d}  x9 {out['1'][0]:7.3f} ms {fl / out['1'][0] / 1e9:6.1f} TF (err {e9:.2e}) | "
           f"fp32 {out['0'][0]:7.3f} ms {fl / out['0'][0] / 1e9:6.1f} TF (err {e32:.2e})")
 

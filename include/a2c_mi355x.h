@@ -412,18 +412,33 @@ int a2c_loss_fwd_bwd(const float *logits, int64_t ld_logits, const float *vals, 
  * Linear forward  y = x W^T + b  (torch.nn.Linear, models.py:73,84,85 ...): transA=0, transB=1.
  * Linear backward dx = dy W: transA=0, transB=0;  dW = dy^T x: transA=1, transB=0.       */
 size_t a2c_gemm_ws_bytes(int64_t M, int64_t N, int splitk);
-/* OPT-IN (A2C_GEMM_X9=1; it ties the fp32 kernels on MI355X): large products (M, N, K >= 256 and
- * M N K >= 2.5e8) run on the BF16 matrix pipe with fp32 results when the workspace
- * also holds a2c_gemm_x9_ws_bytes(M, N, K) bytes BEHIND the a2c_gemm_ws_bytes(M, N, splitk) ones (rounded up to 256): each
- * operand is split, in one pass, into three bf16 images a = a1 + a2 + a3 (exact: 3 x 8 significant bits), every one of the
- * nine piece products is exact, every sum is the MFMA's fp32 accumulator's -- nn.Linear's fp32 sum (models.py:246-264),
- * re-associated, at 9/16 of the fp32 matrix time on paper.  0: the product does not take that path.
- * Without the extra bytes a2c_gemm_f32 runs the fp32 MFMA kernels.                                                  */
+/* Large products (M, N, K >= 1024 and M N K >= 2e10: ConvModel's 28224 x 2000 layers at update batch, models.py:246-264) run
+ * on the BF16 matrix pipe with fp32 results when the workspace also holds a2c_gemm_x9_ws_bytes(M, N, K) bytes BEHIND the
+ * a2c_gemm_ws_bytes(M, N, splitk) ones (rounded up to 256): each operand is split, in one pass, into three bf16 images
+ * a = a0 + a1 + a2 (exact: 3 x 8 significant bits); the SIX piece products with qa + qb <= 2 are issued (each exact; the
+ * three dropped ones are below 2^-24 of |a b|, under the rounding of the fp32 product itself) and every sum is the MFMA's
+ * fp32 accumulator's -- nn.Linear's fp32 sum, re-associated, at 6/16 of the fp32 matrix time on paper and 1.7-1.9 x the
+ * fp32 kernels measured (DESIGN.md section 4 "bf16 x 6").  A2C_GEMM_X9=0: fp32 MFMA kernels only; =1: all nine products
+ * (gemm_x9_kernel; ties the fp32 kernels); =2: the six-product kernel from M, N, K >= 256 and M N K >= 2.5e8 on (tests).
+ * 0: the product does not take that path.  Without the extra bytes a2c_gemm_f32 runs the fp32 MFMA kernels.            */
 size_t a2c_gemm_x9_ws_bytes(int64_t M, int64_t N, int64_t K);
 int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A,
                  int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                  const float *bias, int relu, const float *mask, int64_t ldmask, int accumulate,
                  int splitk, void *ws, size_t ws_bytes, a2c_stream_t stream);
+/* The same six-product kernel from PREBUILT images (a weight matrix split once per update and used by every step of the
+ * rollout: ConvModel's resize_emb at 256 envs, models.py:246): C[M][N] = A[M][K] B[N][K]^T with the epilogue of a2c_gemm_f32.
+ *   a2c_gemm_x6_image_bytes  bytes of the image of a rows x K operand (rows padded to 256, K to 16; 16-byte aligned)
+ *   a2c_gemm_x6_split        writes it: k_contiguous = 1: src[r * ld + k], 0: src[k * ld + r]; layout
+ *                            image[piece][row / 256][k / 16][(k / 8) & 1][row % 256][8] bf16
+ *   a2c_gemm_x6_images       the product; splitk = the largest number of K splits allowed (ws_bytes >= splitk * M * N * 4
+ *                            when > 1; the kernel takes fewer when the tiles alone fill the chip), slabs summed in fixed order */
+size_t a2c_gemm_x6_image_bytes(int64_t rows, int64_t K);
+int a2c_gemm_x6_split(const float *src, int64_t ld, int64_t rows, int64_t K, int k_contiguous, void *image,
+                      a2c_stream_t stream);
+int a2c_gemm_x6_images(int64_t M, int64_t N, int64_t K, const void *image_a, const void *image_b, float *C, int64_t ldc,
+                       const float *bias, int relu, const float *mask, int64_t ldmask, int accumulate, int splitk, void *ws,
+                       size_t ws_bytes, a2c_stream_t stream);
 /* Split-K phase only: writes `a2c_gemm_splits(K, splitk)` partial slabs [split][M][N] (dense,
  * no epilogue) into ws and leaves the fixed-order sum to the consumer (a2c_heads_fused).   */
 int a2c_gemm_splits(int64_t K, int splitk);

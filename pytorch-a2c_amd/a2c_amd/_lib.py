@@ -92,6 +92,9 @@ SIGNATURES = {
                                   c_float, P, c_int64, P, c_int64, P, P, P]),
     "a2c_gemm_ws_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "a2c_gemm_x9_ws_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "a2c_gemm_x6_image_bytes": (c_size_t, [c_int64, c_int64]),
+    "a2c_gemm_x6_split": (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
+    "a2c_gemm_x6_images": (c_int, [c_int64, c_int64, c_int64, P, P, P, c_int64, P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
     "a2c_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64,
                               P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
     "a2c_gemm_splits": (c_int, [c_int64, c_int]),

@@ -143,6 +143,10 @@ class _HipNet(nn.Module):
     def _prep(self, st):
         pass
 
+    def _prep_sig(self):
+        """what _prep derives: a captured update whose tail ran a different _prep leaves the net dirty after its replay"""
+        return ""
+
     def P(self, name):
         return self._pd[name]
 
@@ -755,8 +759,23 @@ class ConvModel(_ConvStackNet):
         """_fwd(..., sampler=(u, actions_ptr, act_stride)) samples inside the heads kernel (up to 7 actions)"""
         return self.output_space + 1 <= 8 and os.environ.get("A2C_NO_FUSED_TAIL") != "1"
 
+    def _set_rollout_batch(self, B):
+        """Runner, before a rollout block of B envs: at 128..256 rows the resize_emb product is matrix-bound (29 GFLOP per env
+        step) and runs on the bf16 pipe from a piece image of the weights that _prep keeps current from then on"""
+        if (128 <= B <= 256 and getattr(self, "_W6", None) is None and self.flat_size * self.CONV_H >= (1 << 24)
+                and os.environ.get("A2C_NO_X6_FWD") != "1" and os.environ.get("A2C_GEMM_X9", "") != "0"):
+            self._ensure_device()
+            self._W6 = torch.empty(ops.gemm_x6_image_bytes(self.CONV_H, self.flat_size) // 2, dtype=torch.int16, device=self._dev)
+            self._dirty = True
+
+    def _prep_sig(self):
+        return "x6" if getattr(self, "_W6", None) is not None else ""
+
     def _prep(self, st):
         super()._prep(st)
+        if getattr(self, "_W6", None) is not None:
+            W = self.P("resize_emb.0.weight")
+            ops.gemm_x6_split(W.data_ptr(), self.flat_size, self.CONV_H, self.flat_size, True, self._W6, st)
         # Inference-only: pi.2 and value.2 read the two halves of ONE hidden row (pi.0 | value.0 run as one GEMM), so
         # both heads are one (A+1) x 2h skinny layer with zero blocks: [[pi.2.weight, 0], [0, value.2.weight]]
         A, h = self.output_space, self.h_size
@@ -779,7 +798,19 @@ class ConvModel(_ConvStackNet):
             e = ws.get("e", (B, ch))                 # left here, row by row, by the rollout
         else:
             e = self._e_out(ws, B, stash)
-            linear_fwd(ws, acts[-1][0], acts[-1][1], P("resize_emb.0.weight"), P("resize_emb.0.bias"), e, B, st, relu=True)
+            if not save and getattr(self, "_W6", None) is not None and 128 <= B <= 256:
+                # rollout batch against the 226 MB layer: the bf16 piece image of the weights is rebuilt once per update
+                # (_prep), the activation rows are split per step; six exact piece products, fp32 sums (gemm_x6_kernel)
+                F = self.flat_size
+                img = ws.bytes("x6_act", ops.gemm_x6_image_bytes(B, F))
+                sk = 32
+                buf = ws.bytes("gemm_ws", 4 * sk * B * ch)
+                with ops.span(f"linear.fwd {ch}x{F}"):
+                    ops.gemm_x6_split(acts[-1][0], acts[-1][1], B, F, True, img, st)
+                    ops.gemm_x6_images(B, ch, F, img, self._W6, e.data_ptr(), e.stride(0), bias=P("resize_emb.0.bias"), relu=True,
+                                       splitk=sk, ws=buf, st=st)
+            else:
+                linear_fwd(ws, acts[-1][0], acts[-1][1], P("resize_emb.0.weight"), P("resize_emb.0.bias"), e, B, st, relu=True)
         lde = e.stride(0)
         hid = ws.get("hid", (B, 2 * h))
         W0, b0 = self._cat(self._arena.params, "pi.0.weight", 2 * h, ch), self._cat(self._arena.params, "pi.0.bias", 2 * h)

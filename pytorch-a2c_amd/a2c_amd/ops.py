@@ -722,6 +722,27 @@ def gemm(transA, transB, M, N, K, A_ptr, lda, B_ptr, ldb, C_ptr, ldc, bias=None,
                              st if st is not None else stream()), "a2c_gemm_f32")
 
 
+def gemm_x6_image_bytes(rows, K):
+    return lib().a2c_gemm_x6_image_bytes(rows, K)
+
+
+def gemm_x6_split(src_ptr, ld, rows, K, k_contiguous, image, st=None):
+    """three-piece bf16 panel image of a rows x K fp32 operand (include/a2c_mi355x.h: a2c_gemm_x6_split)"""
+    check(lib().a2c_gemm_x6_split(src_ptr, ld, rows, K, int(bool(k_contiguous)), _p(image), st if st is not None else stream()),
+          "a2c_gemm_x6_split")
+
+
+def gemm_x6_images(M, N, K, image_a, image_b, C_ptr, ldc, bias=None, relu=False, mask_ptr=0, ldmask=0, accumulate=False,
+                   splitk=1, ws=None, st=None):
+    """C = A B^T from two prebuilt images: six exact bf16 piece products per element pair, fp32 sums"""
+    ws_ptr, ws_bytes = (0, 0) if ws is None else (ws.data_ptr(), ws.numel() * ws.element_size())
+    if ws is not None:
+        note_tensor(ws)
+    check(lib().a2c_gemm_x6_images(M, N, K, _p(image_a), _p(image_b), C_ptr, ldc, _p(bias), int(bool(relu)), mask_ptr, ldmask,
+                                   int(bool(accumulate)), splitk, ws_ptr, ws_bytes, st if st is not None else stream()),
+          "a2c_gemm_x6_images")
+
+
 def gemm_partial(transA, transB, M, N, K, A_ptr, lda, B_ptr, ldb, splitk, ws, st=None):
     """split-K phase only; returns the number of [M][N] slabs written to ws"""
     check(lib().a2c_gemm_f32_partial(int(transA), int(transB), M, N, K, A_ptr, lda, B_ptr, ldb, splitk, ws.data_ptr(),

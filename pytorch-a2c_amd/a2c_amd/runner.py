@@ -416,6 +416,8 @@ class Runner:
         pong = "Pong" in hyps["env_type"]
         shift = hyps["action_shift"]
         st = ops.stream()
+        if hasattr(net, "_set_rollout_batch"):
+            net._set_rollout_batch(B)
         net._refresh(st)
         states, rewards, dones, deltas = D["states"], D["rewards"], D["dones"], D["deltas"]
         for name in ("states", "rewards", "dones", "deltas"):

@@ -66,11 +66,16 @@ class _GraphedUpdate:
             raise
         finally:
             upd.shard = real
+        self.prep_sig = net._prep_sig() if hasattr(net, "_prep_sig") else ""
         # the capture itself executed nothing: the net is still in the state the rollout left it in
         net._dirty, net._stash = dirty, stash
         if cells is not None:
             net._cells_done = cells
         upd.optim._steps -= 1
+
+    def _stale_prep(self):
+        net = self.upd.net
+        return (net._prep_sig() if hasattr(net, "_prep_sig") else "") != self.prep_sig
 
     def _begin(self):
         g = torch.cuda.CUDAGraph()
@@ -95,7 +100,8 @@ class _GraphedUpdate:
                 upd.shard.allreduce_(self.colls[i])
         upd.optim._steps += 1
         upd.net.mark_dirty()
-        upd.net._dirty = False      # (the captured tail re-derived the inference weights: _enqueue_update's net._refresh)
+        # (the captured tail re-derived the inference weights: _enqueue_update's net._refresh -- unless the net derives more now)
+        upd.net._dirty = self._stale_prep()
         return upd._finish_update(self.dev, self.n_global)
 
     __call__ = replay
@@ -110,7 +116,7 @@ class _GraphedUpdate:
                 upd.shard.allreduce_(self.colls[i])
         upd.optim._steps += 1
         upd.net.mark_dirty()
-        upd.net._dirty = False
+        upd.net._dirty = self._stale_prep()
         return upd._post_async(self.dev, self.n_global)
 
 

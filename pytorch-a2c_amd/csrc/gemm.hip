@@ -1449,6 +1449,44 @@ void launch_gemm(dim3 grid, hipStream_t st, long M, long N, long K, const float*
 }
 }  // namespace
 
+// ---- the x 6 path: images, split pass, launch (shared by a2c_gemm_f32 and the a2c_gemm_x6_* entry points)
+static bool x6_ready() {
+  static std::once_flag once6;
+  static bool ready6 = false;
+  std::call_once(once6, [] {
+    ready6 = hipFuncSetAttribute((const void*)gemm_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x6::LDS_BYTES) == hipSuccess;
+  });
+  return ready6;
+}
+static void x6_split(const float* src, long ld, long R, long K, bool k_contiguous, unsigned short* img, hipStream_t st) {
+  const long Rp = (R + 255) / 256 * 256, Kp = (K + 15) / 16 * 16, ngb = (Kp / 8 + 3) / 4;
+  const int g = (int)std::min<long>((Rp / 64) * ngb, 1L << 20);
+  if (k_contiguous) hipLaunchKernelGGL((x6_split_kernel<false>), dim3(g), dim3(256), 0, st, src, ld, R, K, img, Rp, Kp);
+  else hipLaunchKernelGGL((x6_split_kernel<true>), dim3(g), dim3(256), 0, st, src, ld, R, K, img, Rp, Kp);
+}
+// C = A B^T from two panel images; K splits only where the tiles alone leave CUs idle, and only as many as `splitk` (the
+// caller's slabs) allows
+static int x6_run(long M, long N, long K, const unsigned short* Ap, const unsigned short* Bp, float* C, long ldc, const float* bias,
+                  int relu, const float* mask, long ldmask, int accumulate, int splitk, float* slab, hipStream_t st) {
+  const long Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + 15) / 16 * 16;
+  const int nmb = (int)(Mp / 256), nnb = (int)(Np / 256), nkb = (int)(Kp / 16);
+  int want = 1;
+  if ((long)nmb * nnb < 192) want = (int)std::min<long>(256 / ((long)nmb * nnb), nkb / 32);
+  if (want > splitk || !slab) want = slab ? splitk : 1;
+  if (want < 1) want = 1;
+  const int sps = (nkb + want - 1) / want, s6 = (nkb + sps - 1) / sps;
+  const long wk = (long)nmb * nnb * s6, per = (wk + 7) / 8;
+  hipLaunchKernelGGL(gemm_x6_kernel, dim3((unsigned)(per * 8)), dim3(512), x6::LDS_BYTES, st, M, N, Ap, Mp * Kp, Bp, Np * Kp, Kp, nmb,
+                     nnb, s6, sps, C, ldc, bias, relu, mask, ldmask, accumulate, s6 > 1 ? slab : nullptr);
+  A2C_CHECK_LAUNCH();
+  if (s6 > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(a2c_grid_1d(M * N, 256)), dim3(256), 0, st, slab, s6, M, N, C, ldc, bias, relu, mask,
+                       ldmask, accumulate);
+    A2C_CHECK_LAUNCH();
+  }
+  return A2C_OK;
+}
+
 extern "C" {
 size_t a2c_gemm_ws_bytes(int64_t M, int64_t N, int splitk) {
   size_t need = splitk > 1 ? (size_t)splitk * (size_t)M * (size_t)N * sizeof(float) : 0;
@@ -1484,6 +1522,31 @@ size_t a2c_gemm_x9_ws_bytes(int64_t M, int64_t N, int64_t K) {
   // (rows to 256, k to 32: room for either image layout)
   const size_t Mp = (size_t)(M + 255) / 256 * 256, Np = (size_t)(N + 255) / 256 * 256, Kp = (size_t)(K + 31) / 32 * 32;
   return 3 * 2 * (Mp + Np) * Kp + 256;
+}
+
+size_t a2c_gemm_x6_image_bytes(int64_t rows, int64_t K) {
+  if (rows < 1 || K < 1) return 0;
+  return 3 * 2 * (size_t)((rows + 255) / 256 * 256) * (size_t)((K + 15) / 16 * 16);
+}
+
+int a2c_gemm_x6_split(const float* src, int64_t ld, int64_t rows, int64_t K, int k_contiguous, void* image, a2c_stream_t stream) {
+  if (rows < 1 || K < 1 || !src || !image || ((uintptr_t)image % 16) || ld < (k_contiguous ? K : rows)) return A2C_ERR_ARG;
+  x6_split(src, (long)ld, (long)rows, (long)K, k_contiguous != 0, reinterpret_cast<unsigned short*>(image), a2c_s(stream));
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
+int a2c_gemm_x6_images(int64_t M, int64_t N, int64_t K, const void* image_a, const void* image_b, float* C, int64_t ldc,
+                       const float* bias, int relu, const float* mask, int64_t ldmask, int accumulate, int splitk, void* ws,
+                       size_t ws_bytes, a2c_stream_t stream) {
+  if (M < 1 || N < 1 || K < 1 || !image_a || !image_b || !C || ldc < N || (mask && ldmask < N)) return A2C_ERR_ARG;
+  if (((uintptr_t)image_a % 16) || ((uintptr_t)image_b % 16)) return A2C_ERR_ARG;
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1 && (!ws || ws_bytes < (size_t)splitk * (size_t)M * (size_t)N * sizeof(float))) return A2C_ERR_WORKSPACE;
+  if (!x6_ready()) return A2C_ERR_LAUNCH;
+  return x6_run((long)M, (long)N, (long)K, reinterpret_cast<const unsigned short*>(image_a),
+                reinterpret_cast<const unsigned short*>(image_b), C, (long)ldc, bias, relu, mask, (long)ldmask, accumulate, splitk,
+                splitk > 1 ? (float*)ws : nullptr, a2c_s(stream));
 }
 
 int a2c_small_n_bwd_data_bits(const float* dy, int64_t ldy, const float* W, float* dx, int64_t ldx, const uint8_t* maskbits,
@@ -1586,43 +1649,15 @@ int a2c_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
   {  // large products: the bf16 x 9 form (exact 3-way split of both operands, fp32 accumulation) when the workspace holds the images
     const size_t base = a2c_gemm_ws_bytes(M, N, splitk), need9 = a2c_gemm_x9_ws_bytes(M, N, K);
     const size_t off9 = (base + 255) / 256 * 256;
-    if (need9 && ws && ws_bytes >= off9 + need9 && x6_mode()) {
-      static std::once_flag once6;
-      static bool ready6 = false;
-      std::call_once(once6, [] {
-        ready6 = hipFuncSetAttribute((const void*)gemm_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x6::LDS_BYTES) == hipSuccess;
-      });
-      if (ready6) {
-        const long Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + 15) / 16 * 16;
-        unsigned short* Ap = reinterpret_cast<unsigned short*>((char*)ws + off9);
-        unsigned short* Bp = Ap + 3 * Mp * Kp;
-        const long ngb = (Kp / 8 + 3) / 4;
-        const int ga6 = (int)std::min<long>((Mp / 64) * ngb, 1L << 20), gb6 = (int)std::min<long>((Np / 64) * ngb, 1L << 20);
-        if (a_kc) hipLaunchKernelGGL((x6_split_kernel<false>), dim3(ga6), dim3(256), 0, st, A, (long)lda, (long)M, (long)K, Ap, Mp, Kp);
-        else hipLaunchKernelGGL((x6_split_kernel<true>), dim3(ga6), dim3(256), 0, st, A, (long)lda, (long)M, (long)K, Ap, Mp, Kp);
-        A2C_CHECK_LAUNCH();
-        if (b_kc) hipLaunchKernelGGL((x6_split_kernel<false>), dim3(gb6), dim3(256), 0, st, B, (long)ldb, (long)N, (long)K, Bp, Np, Kp);
-        else hipLaunchKernelGGL((x6_split_kernel<true>), dim3(gb6), dim3(256), 0, st, B, (long)ldb, (long)N, (long)K, Bp, Np, Kp);
-        A2C_CHECK_LAUNCH();
-        const int nmb = (int)(Mp / 256), nnb = (int)(Np / 256), nkb = (int)(Kp / 16);
-        // K splits only where the tiles alone leave CUs idle, and only as many as the caller's slabs hold
-        int want = 1;
-        if ((long)nmb * nnb < 192) want = (int)std::min<long>(256 / ((long)nmb * nnb), nkb / 32);
-        if (want > splitk) want = splitk;
-        if (want < 1) want = 1;
-        const int sps = (nkb + want - 1) / want, s6 = (nkb + sps - 1) / sps;
-        const long wk = (long)nmb * nnb * s6, per = (wk + 7) / 8;
-        hipLaunchKernelGGL(gemm_x6_kernel, dim3((unsigned)(per * 8)), dim3(512), x6::LDS_BYTES, st, (long)M, (long)N, Ap, Mp * Kp, Bp,
-                           Np * Kp, Kp, nmb, nnb, s6, sps, C, (long)ldc, bias, relu, mask, (long)ldmask, accumulate,
-                           s6 > 1 ? slab : nullptr);
-        A2C_CHECK_LAUNCH();
-        if (s6 > 1) {
-          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(a2c_grid_1d(M * N, 256)), dim3(256), 0, st, slab, s6, (long)M, (long)N, C,
-                             (long)ldc, bias, relu, mask, (long)ldmask, accumulate);
-          A2C_CHECK_LAUNCH();
-        }
-        return A2C_OK;
-      }
+    if (need9 && ws && ws_bytes >= off9 + need9 && x6_mode() && x6_ready()) {
+      const long Mp = (M + 255) / 256 * 256, Kp = (K + 15) / 16 * 16;
+      unsigned short* Ap = reinterpret_cast<unsigned short*>((char*)ws + off9);
+      unsigned short* Bp = Ap + 3 * Mp * Kp;
+      x6_split(A, lda, M, K, a_kc, Ap, st);
+      A2C_CHECK_LAUNCH();
+      x6_split(B, ldb, N, K, b_kc, Bp, st);
+      A2C_CHECK_LAUNCH();
+      return x6_run(M, N, K, Ap, Bp, C, ldc, bias, relu, mask, ldmask, accumulate, splitk, slab, st);
     }
     if (need9 && ws && ws_bytes >= off9 + need9 && !x6_mode()) {
       const long Mp = (M + 127) / 128 * 128, Np = (N + 127) / 128 * 128, Kp = (K + 31) / 32 * 32;

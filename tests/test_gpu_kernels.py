@@ -1305,6 +1305,54 @@ def test_gru_cell_fwd_two_launches_equal_the_five_bit_for_bit(B, xs, hd, inplace
         ops.gru_cell_fwd(x, h0[:, :hd - 8].contiguous(), WxC, WhC, Wh[2], b, gx2, z2, r2, rh2, c2, mk(B, hd))     # hdim % 32
 
 
+@pytest.mark.parametrize("M,N,K,sk,kc", [(256, 2000, 28224, 32, True), (200, 300, 1000, 4, True), (520, 700, 330, 1, False)])
+def test_gemm_x6_from_prebuilt_images(M, N, K, sk, kc):
+    """a2c_gemm_x6_split + a2c_gemm_x6_images (ConvModel's resize_emb at rollout batch: the weight image built once per update):
+    C = relu(A B^T + bias) from two three-piece bf16 panel images, six exact products per element pair, fp32 sums -- against
+    fp64 no worse than 1.5 x the fp32 MFMA kernel's error; both source orientations, ragged rows / K, K splits; bit-identical
+    run to run."""
+    ops = _ops()
+    a = (rnd((M, K), 41) * (rnd((M, K), 42) > 0.2)).to(DEV)          # (ReLU-like zeros)
+    b = (rnd((N, K), 43) * 0.05).to(DEV)
+    bias = rnd((N,), 44).to(DEV)
+    ia = torch.empty(ops.gemm_x6_image_bytes(M, K) // 2, dtype=torch.int16, device=DEV)
+    ib = torch.empty(ops.gemm_x6_image_bytes(N, K) // 2, dtype=torch.int16, device=DEV)
+    if kc:
+        ops.gemm_x6_split(a.data_ptr(), K, M, K, True, ia)
+        ops.gemm_x6_split(b.data_ptr(), K, N, K, True, ib)
+    else:
+        at, bt = a.t().contiguous(), b.t().contiguous()
+        ops.gemm_x6_split(at.data_ptr(), M, M, K, False, ia)
+        ops.gemm_x6_split(bt.data_ptr(), N, N, K, False, ib)
+    ws = torch.empty(max(1, sk * M * N), device=DEV)
+    outs = []
+    for _ in range(2):
+        c = torch.full((M, N + 8), float("nan"), device=DEV)
+        ops.gemm_x6_images(M, N, K, ia, ib, c.data_ptr(), N + 8, bias=bias, relu=True, splitk=sk, ws=ws if sk > 1 else None)
+        assert torch.isnan(c[:, N:]).all()
+        outs.append(c[:, :N].clone())
+    assert torch.equal(outs[0], outs[1])
+    want = torch.relu(a.double().cpu() @ b.double().cpu().t() + bias.double().cpu())
+    c32 = torch.empty(M, N, device=DEV)
+    import os
+    old = os.environ.get("A2C_GEMM_X9")
+    os.environ["A2C_GEMM_X9"] = "0"
+    try:
+        ops.gemm(0, 1, M, N, K, a.data_ptr(), K, b.data_ptr(), K, c32.data_ptr(), N, bias=bias, relu=True)
+    finally:
+        if old is None:
+            del os.environ["A2C_GEMM_X9"]
+        else:
+            os.environ["A2C_GEMM_X9"] = old
+    rms = float(want.pow(2).mean().sqrt())
+    e6 = float((outs[0].double().cpu() - want).pow(2).mean().sqrt()) / rms
+    e32 = float((c32.double().cpu() - want).pow(2).mean().sqrt()) / rms
+    assert e6 <= 1.5 * e32 + 1e-7, (e6, e32)
+    from a2c_amd import _lib
+    with pytest.raises(_lib.A2CKernelError):             # K splits without their slabs
+        ops.gemm_x6_images(M, N, K, ia, ib, c32.data_ptr(), N, splitk=2, ws=None)
+
+
 @pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("tA,tB,M,N,K", [(0, 1, 1280, 1100, 2000), (0, 0, 1152, 900, 1000), (1, 0, 520, 1030, 777)])
 def test_gemm_bf16_x9_path_is_the_fp32_product(tA, tB, M, N, K, mode, monkeypatch):

@@ -633,6 +633,16 @@ class Bench:
             pass
 
 
+def linear_on_bf16_x6(batch, n, k, what):
+    """does `linear.<what> NxK` over `batch` rows run as gemm_x6_kernel?  (gemm.hip: x9_eligible -- every dimension >= 1024 and
+    2e10 multiply-adds -- or ConvModel's resize_emb forward at rollout batch 128..256 from the prebuilt weight image)"""
+    if os.environ.get("A2C_GEMM_X9", "") in ("0", "1"):
+        return False
+    if min(batch, n, k) >= 1024 and float(batch) * n * k >= 2e10:
+        return True
+    return (what == "fwd" and 128 <= batch <= 256 and n * k >= (1 << 24) and os.environ.get("A2C_NO_X6_FWD") != "1")
+
+
 def site_roofline(name, site, conv_layers, batch, u8_store=False, bf16_pipe=False):
     """roofline entry of one launch site: algorithmic bytes and flops / its average HIP-event duration, each priced on what
     the site really reads and really issues.  ``u8_store``: the first layer reads the single-frame uint8 store (one 7,056-byte
@@ -658,7 +668,13 @@ def site_roofline(name, site, conv_layers, batch, u8_store=False, bf16_pipe=Fals
         try:
             n_, k_ = (int(v) for v in what.split(" ")[1].split("x"))
             tf = 2.0 * batch * n_ * k_ / (site["avg_ms"] * 1e-3) / 1e12
-            out.update(batch=batch, tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / F32_PEAK_TFLOPS, 4))
+            if linear_on_bf16_x6(batch, n_, k_, what.split(" ")[0]):
+                # gemm_x6_kernel: six exact bf16 piece products per element pair -- 6 x the flops on the bf16 pipe
+                out.update(batch=batch, pipe="bf16 MFMA x6 (exact 3-way split of both operands, fp32 accumulate)",
+                           tflops_fp32_equiv=round(tf, 2), frac_of_pipe_peak=round(6.0 * tf / BF16_PEAK_TFLOPS, 4))
+            else:
+                out.update(batch=batch, pipe="fp32 MFMA", tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / F32_PEAK_TFLOPS, 4),
+                           frac_of_pipe_peak=round(tf / F32_PEAK_TFLOPS, 4))
             if batch <= 64:          # skinny: the weights are the traffic
                 gbs = 4.0 * n_ * k_ / (site["avg_ms"] * 1e-3) / 1e9
                 out.update(weight_GBs=round(gbs, 1), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))

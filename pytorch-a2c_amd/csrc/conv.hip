@@ -1932,6 +1932,199 @@ __global__ __launch_bounds__(BS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #undef BS3_STD
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bwd_x6_kernel (round 6): the same layer -- A3CModel conv2's backward-data, 32 -> 16 channels, 4 x 4, stride 2, 9 x 9 ->
+// 20 x 20 -- on the BF16 matrix pipe with fp32 results.  bwd_stream2_kernel is bound by the fp32 MFMAs it issues (82 TF, the
+// pipe 54 % busy in step-locked phases); here both operands are split into three bf16 pieces (exact) and
+// the six piece products with qa + qb <= 2 are issued (the dropped ones are below 2^-24 of |a b|: gemm_x6_kernel's argument),
+// 6 v_mfma_f32_16x16x32_bf16 (16 cycles) per 32-deep k step instead of 8 v_mfma_f32_16x16x4_f32 (32 cycles): 0.375 of the
+// matrix time.  What makes the layer fit the bf16 instruction:
+//   * all four output-parity classes gather the SAME dOut pixels: dX[ci][2cy+ry][2cx+rx] = sum over taps (a, b) and co of
+//     dOut[co][cy-a][cx-b] W[co][ci][ry+2a][rx+2b] -- per sample ONE product D[(class, ci)][(cy, cx)] = Wt[(class, ci)][(tap, co)]
+//     G[(tap, co)][(cy, cx)] with M = 64, N = 100 (7 tiles of 16), K = 128;
+//   * k runs over co inside a tap, so a lane's 8 consecutive k are 8 consecutive channels of ONE dOut pixel: the sample is
+//     staged as [piece][co / 8][pixel][8] bf16 (a thread loads the 8 channels of its pixel, splits, three ds_write_b128) and an
+//     MFMA operand is ONE ds_read_b128 at a per-lane pixel slot (taps outside the 9 x 9 grid read a zero slot) -- no halo
+//     image, no gather instructions;
+//   * a wave owns two classes (their weight fragments, 2 x 4 taps x 3 pieces, live in 96 registers for the whole launch) and
+//     two 16-pixel tiles: a dOut fragment read feeds up to 12 MFMAs; (tile, class) units are dealt 4 / 4 / 3 / 3 to the four
+//     waves of a class pair so that the two waves of a SIMD carry 7 of the 28 units each.
+// The rest is bwd_stream2_kernel's skeleton: next sample's dOut in flight in registers during the matrix phase, two dX images
+// in LDS, the previous sample flushed (ReLU mask bits, coalesced float4 stores) at the head of the iteration.
+constexpr int BX_NT = 512, BX_SLOT0 = 81, BX_GST = 82 * 8, BX_PST = 4 * BX_GST, BX_IMG = 3 * BX_PST;    // bf16 elements
+typedef __bf16 bf16x8x __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4x __attribute__((ext_vector_type(4)));
+struct BwdX6P {
+  const float* dout; float* din; const float* wfrag; const unsigned long long* lmask;
+  int lmw, B;
+  int frag_off[4];
+};
+__device__ __forceinline__ void bx_split8(const float e[8], u32x4x o[3]) {
+  unsigned short pc[3][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h0 = (__bf16)e[i];
+    const float r1 = e[i] - (float)h0;                 // exact
+    const __bf16 h1 = (__bf16)r1;
+    const float r2 = r1 - (float)h1;                   // exact, at most 8 significant bits
+    pc[0][i] = __builtin_bit_cast(unsigned short, h0);
+    pc[1][i] = __builtin_bit_cast(unsigned short, h1);
+    pc[2][i] = __builtin_bit_cast(unsigned short, (__bf16)r2);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    o[q] = (u32x4x){(unsigned int)pc[q][0] | ((unsigned int)pc[q][1] << 16), (unsigned int)pc[q][2] | ((unsigned int)pc[q][3] << 16),
+                    (unsigned int)pc[q][4] | ((unsigned int)pc[q][5] << 16), (unsigned int)pc[q][6] | ((unsigned int)pc[q][7] << 16)};
+}
+template <int MODE>                                   // 0: no mask, 2: lane masks
+__global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsx[];
+  unsigned short* __restrict__ img = reinterpret_cast<unsigned short*>(ldsx);          // dOut of the sample, three piece images
+  float* __restrict__ outb0 = reinterpret_cast<float*>(ldsx + 2 * BX_IMG);            // two dX images, [16][400] each
+  constexpr int HW = 400, OBS = 6400, N4 = 1600, OHW = 81;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int cp = w & 1, mg = w >> 1;                  // class pair (ry = cp; rx = 0, 1) and tile group
+  if (tid < 12) *reinterpret_cast<u32x4x*>(img + tid * BX_GST + BX_SLOT0 * 8) = (u32x4x){0u, 0u, 0u, 0u};    // the zero pixel of every plane
+  // weight fragments: lane (ci = j, k group g) of class c, tap t: W[co = 8 g + i][ci][ry + 2 a][rx + 2 b], i = 0..7, three pieces
+  bf16x8x wf[2][4][3];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int co = 8 * g + i;
+        e[i] = p.wfrag[p.frag_off[2 * cp + c] + (t * 8 + (co >> 2)) * 64 + (((co & 3) << 4) | j)];
+      }
+      u32x4x o[3];
+      bx_split8(e, o);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) wf[c][t][q] = __builtin_bit_cast(bf16x8x, o[q]);
+    }
+  // this wave's two tiles, which of its classes each carries, and where lane j's pixel of each tile reads / writes
+  const int tl0 = mg == 3 ? 5 : 2 * mg, tl1 = tl0 + 1;
+  const bool do00 = mg != 3, do01 = true, do10 = true, do11 = mg != 2;          // do<job><class>
+  int boff[2][4], pix[2][2];
+  bool okp[2];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    const int m = (jb ? tl1 : tl0) * 16 + j;
+    okp[jb] = m < 100;
+    const int cy = m / 10, cx = m - cy * 10;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int oy = cy - (t >> 1), ox = cx - (t & 1);
+      const int slot = (okp[jb] && oy >= 0 && oy <= 8 && ox >= 0 && ox <= 8) ? oy * 9 + ox : BX_SLOT0;
+      boff[jb][t] = g * BX_GST + slot * 8;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) pix[jb][c] = (2 * cy + cp) * 20 + 2 * cx + c;
+  }
+  // staging role: thread (pixel s, channel group gg) of the sample's 81 x 4 cells
+  const bool stg = tid < 4 * OHW;
+  const int ss = stg ? tid % OHW : 0, gg = stg ? tid / OHW : 0;
+  float pre[8];
+  long b = blockIdx.x;
+  if (b >= p.B) return;
+#define BX_LDD(src)                                                                         \
+  if (stg) { _Pragma("unroll") for (int i = 0; i < 8; ++i) pre[i] = (src)[(8 * gg + i) * OHW + ss]; }
+  {
+    const float* __restrict__ src = p.dout + b * (long)(32 * OHW);
+    BX_LDD(src)
+  }
+#define BX_FLUSH(u, pb_, ob_)                                                                               \
+  {                                                                                                         \
+    const int q_ = tid + (u) * BX_NT;                                                                       \
+    if (q_ < N4) {                                                                                          \
+      float* __restrict__ dst_ = p.din + (pb_) * (long)OBS;                                                 \
+      const int i_ = q_ << 2;                                                                               \
+      float4 v_ = *reinterpret_cast<const float4*>((ob_) + i_);                                             \
+      if (MODE == 2) {                                                                                      \
+        const unsigned int nb_ = (lmb >> (8 * (u) + 4 * (q_ & 1))) & 0xfu;                                  \
+        if (!(nb_ & 1u)) v_.x = 0.f;                                                                        \
+        if (!(nb_ & 2u)) v_.y = 0.f;                                                                        \
+        if (!(nb_ & 4u)) v_.z = 0.f;                                                                        \
+        if (!(nb_ & 8u)) v_.w = 0.f;                                                                        \
+      }                                                                                                     \
+      *reinterpret_cast<float4*>(dst_ + i_) = v_;                                                           \
+    }                                                                                                       \
+  }
+  long pb = -1;
+  int cur = 0;
+  unsigned int lmb = 0;
+  __syncthreads();                                            // the zero pixels
+  for (; b < p.B; b += gridDim.x) {
+    const long nb = (b + gridDim.x < p.B) ? b + gridDim.x : b;          // past the end: re-read this sample (discarded)
+    const float* __restrict__ nsrc = p.dout + nb * (long)(32 * OHW);
+    float* __restrict__ outb = outb0 + cur * OBS;
+    if (stg) {
+      u32x4x o[3];
+      bx_split8(pre, o);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4x*>(img + q * BX_PST + gg * BX_GST + ss * 8) = o[q];
+    }
+    __syncthreads();
+    if (pb >= 0) {                                              // the previous sample's dX: stores first
+      const float* __restrict__ ob = outb0 + (cur ^ 1) * OBS;
+      BX_FLUSH(0, pb, ob) BX_FLUSH(1, pb, ob) BX_FLUSH(2, pb, ob) BX_FLUSH(3, pb, ob)
+    }
+    unsigned int lb0 = 0, lb1 = 0, lb2 = 0, lb3 = 0;
+    if (MODE == 2) {           // THIS sample's mask bits (its flush is the next iteration's first act): one byte per flush unit
+      const unsigned char* __restrict__ lmp = reinterpret_cast<const unsigned char*>(p.lmask) + b * (long)p.lmw * 8;
+      lb0 = lmp[min((tid + 0 * BX_NT) >> 1, N4 / 2 - 1)]; lb1 = lmp[min((tid + 1 * BX_NT) >> 1, N4 / 2 - 1)];
+      lb2 = lmp[min((tid + 2 * BX_NT) >> 1, N4 / 2 - 1)]; lb3 = lmp[min((tid + 3 * BX_NT) >> 1, N4 / 2 - 1)];
+    }
+    BX_LDD(nsrc)
+    {
+      f32x4 a00 = (f32x4){0.f, 0.f, 0.f, 0.f}, a01 = a00, a10 = a00, a11 = a00;     // a<job><class>
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bf16x8x d0[3], d1[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          d0[q] = *reinterpret_cast<const bf16x8x*>(img + q * BX_PST + boff[0][t]);
+          d1[q] = *reinterpret_cast<const bf16x8x*>(img + q * BX_PST + boff[1][t]);
+        }
+        // rising magnitude: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0); the four chains interleaved
+#define BX_MM(QA, QB)                                                                                                  \
+        if (do00) a00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t][QA], d0[QB], a00, 0, 0, 0);                     \
+        if (do01) a01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t][QA], d0[QB], a01, 0, 0, 0);                     \
+        if (do10) a10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t][QA], d1[QB], a10, 0, 0, 0);                     \
+        if (do11) a11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t][QA], d1[QB], a11, 0, 0, 0);
+        BX_MM(2, 0) BX_MM(1, 1) BX_MM(0, 2) BX_MM(1, 0) BX_MM(0, 1) BX_MM(0, 0)
+#undef BX_MM
+      }
+      // D: lane holds pixel j (column), channels 4 g + r (rows)
+      if (okp[0]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (do00) outb[(4 * g + r) * HW + pix[0][0]] = a00[r];
+          if (do01) outb[(4 * g + r) * HW + pix[0][1]] = a01[r];
+        }
+      }
+      if (okp[1]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (do10) outb[(4 * g + r) * HW + pix[1][0]] = a10[r];
+          if (do11) outb[(4 * g + r) * HW + pix[1][1]] = a11[r];
+        }
+      }
+    }
+    if (MODE == 2) lmb = lb0 | (lb1 << 8) | (lb2 << 16) | (lb3 << 24);
+    __syncthreads();                                            // every class has landed in this sample's image
+    pb = b;
+    cur ^= 1;
+  }
+  {
+    const float* __restrict__ ob = outb0 + (cur ^ 1) * OBS;
+    BX_FLUSH(0, pb, ob) BX_FLUSH(1, pb, ob) BX_FLUSH(2, pb, ob) BX_FLUSH(3, pb, ob)
+  }
+#undef BX_FLUSH
+#undef BX_LDD
+}
+
 // the mask bits of an activation tensor (see bwd_stream2_kernel): a lane per float4, a byte per pair of lanes
 __global__ __launch_bounds__(256) void lanemask_kernel(const float* __restrict__ act, unsigned char* __restrict__ lm, long n4) {
   for (long q = blockIdx.x * 256L + threadIdx.x; q < n4; q += gridDim.x * 256L) {          // n4 is even: whole lane pairs
@@ -4035,6 +4228,23 @@ int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float
         const bool form2 = slds2 <= LDS_HARD_MAX && !(v1 && v1[0] == '1') && (!lmask || n4 % 64 == 0);
         if (lmask && !form2) return A2C_ERR_ARG;
         if (probe_only) return A2C_OK;
+        {  // the bf16 x 6 form (bwd_x6_kernel): exactly A3CModel's conv2, mask as bits or none; A2C_BWD_X6=0 keeps the fp32 MFMA kernels
+          const char* x6 = getenv("A2C_BWD_X6");
+          if (d->Cout == 32 && d->Cin == 16 && d->OH == 9 && d->OW == 9 && d->H == 20 && d->W == 20 && P == 0 && (lmask || !mask) &&
+              !(x6 && x6[0] == '0')) {
+            BwdX6P xp;
+            xp.dout = dout; xp.din = din; xp.wfrag = wprep_bwd; xp.lmask = lmask; xp.lmw = n4 / 64 * 4; xp.B = B;
+            for (int cls = 0; cls < 4; ++cls) xp.frag_off[cls] = q.cls[cls].frag_off;
+            const size_t xlds = 2 * (size_t)BX_IMG + 2 * 4 * (size_t)d->Cin * d->H * d->W;
+            const void* xk = lmask ? (const void*)bwd_x6_kernel<2> : (const void*)bwd_x6_kernel<0>;
+            if (xlds > 64 * 1024) (void)hipFuncSetAttribute(xk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds);
+            const int xgrid = resident_grid(xk, xlds, B, BX_NT);
+            if (lmask) hipLaunchKernelGGL(bwd_x6_kernel<2>, dim3(xgrid), dim3(BX_NT), xlds, a2c_s(stream), xp);
+            else hipLaunchKernelGGL(bwd_x6_kernel<0>, dim3(xgrid), dim3(BX_NT), xlds, a2c_s(stream), xp);
+            A2C_CHECK_LAUNCH();
+            return A2C_OK;
+          }
+        }
         // third form (one barrier per sample, both images double buffered, the two waves of a SIMD out of step): A2C_BWD_STREAM_FORM=3
         const size_t slds3 = 4 * (2 * ((size_t)d->Cout * q.PLANE + 64) + 2 * (size_t)d->Cin * d->H * d->W);
         const char* fm = getenv("A2C_BWD_STREAM_FORM");

@@ -170,6 +170,20 @@ def test_site_roofline_prices_the_uint8_store_and_the_bf16_pipe():
     assert bd["alg_bytes"] == 262144 * 4 * (4 * 84 * 84 + 16 * 400)
 
 
+def test_site_roofline_prices_the_large_linear_layers_on_the_bf16_pipe():
+    """ConvModel's 28224 x 2000 layers at update batch run as six bf16 piece products (gemm_x6_kernel): 231 GFLOP in 1.0 ms is
+    1.47 of the fp32 MFMA peak -- not a roofline -- and 0.55 of what the bf16 pipe could issue; small or skinny products stay
+    priced on the fp32 pipe."""
+    site = dict(avg_ms=1.0, launches=1, total_ms=1.0)
+    r = bench.site_roofline("linear.bwd_data 2000x28224", site, {}, 2048)
+    assert "frac_of_f32_mfma_peak" not in r and r["pipe"].startswith("bf16 MFMA x6")
+    assert r["frac_of_pipe_peak"] == pytest.approx(6 * 2.0 * 2048 * 2000 * 28224 / 1e-3 / (bench.BF16_PEAK_TFLOPS * 1e12), rel=1e-3)
+    assert r["frac_of_pipe_peak"] <= 1.0 and r["tflops_fp32_equiv"] > bench.F32_PEAK_TFLOPS
+    assert bench.site_roofline("linear.fwd 2000x28224", dict(avg_ms=0.12, launches=1, total_ms=0.12), {}, 256)["pipe"].startswith("bf16")
+    for nm, batch in (("linear.fwd 2000x28224", 32), ("linear.bwd_data 512x2000", 2048), ("linear.bwd_weight 2000x28224", 512)):
+        assert bench.site_roofline(nm, site, {}, batch)["pipe"] == "fp32 MFMA"
+
+
 def test_line_carries_the_other_configs_cpu_baselines_and_the_8_rank_prediction():
     full = _fat_report()
     full["cpu_baselines"] = {"conv_32x64": dict(value=61.5), "gru_bptt_256x128": dict(value=171.0), "a3c_32": dict(value=15005.5),

@@ -855,6 +855,7 @@ def test_conv2d_streaming_backward_data_with_lane_masks(monkeypatch, B):
     float-mask call bit for bit -- on the second form of the kernel (two dX images, default) and against the first
     (A2C_BWD_STREAM_V1=1)."""
     ops = _ops()
+    monkeypatch.setenv("A2C_BWD_X6", "0")                    # (the fp32 MFMA kernels; the bf16 x 6 form has its own test below)
     d = ops.conv_desc(16, 20, 20, 32, 4, 2, 0)
     assert ops.conv_bwd_data_lanemask_supported(d, B) and not ops.conv_bwd_data_lanemask_supported(d, 64)
     gen = torch.Generator().manual_seed(14)
@@ -891,6 +892,47 @@ def test_conv2d_streaming_backward_data_with_lane_masks(monkeypatch, B):
     torch.cuda.synchronize()
     assert torch.equal(got, want) and torch.equal(want, old)
     assert not bool(torch.isnan(got).any())
+
+
+@pytest.mark.parametrize("B", [2048 + 55, 4096])
+def test_conv2d_backward_data_on_the_bf16_pipe_is_the_fp32_sum(monkeypatch, B):
+    """bwd_x6_kernel (default for A3CModel's conv2 at streaming batch, mask as bits or none): dOut and the weights split into
+    three bf16 pieces each (exact), the six piece products with qa + qb <= 2 on the bf16 pipe, fp32 sums -- against the fp64
+    transposed convolution no worse than 1.5 x the fp32 MFMA kernel's error (A2C_BWD_X6=0), masks applied exactly, every
+    sample written (ragged batch), bit-identical run to run."""
+    ops = _ops()
+    d = ops.conv_desc(16, 20, 20, 32, 4, 2, 0)
+    gen = torch.Generator().manual_seed(21)
+    w = ((torch.rand(32, 16, 4, 4, generator=gen) - 0.5) * 0.2)
+    dout = ((torch.rand(B, 32, 9, 9, generator=gen) - 0.5) * (torch.rand(B, 32, 9, 9, generator=gen) < 0.6).float())
+    dout[1] = torch.randn(32, 9, 9, generator=gen) * 1e3                      # a dense sample at another scale
+    act = torch.relu(torch.rand(B, 16, 20, 20, generator=gen) - 0.4)
+    doutd, actd = dout.to(DEV), act.to(DEV)
+    lm = torch.zeros(B, 6400 // 64, dtype=torch.int64, device=DEV)
+    ops.lanemask_from_act(actd, lm)
+    wb = torch.empty(ops.conv_prep_floats(d, 1), device=DEV)
+    ops.conv_prep(d, 1, w.to(DEV), wb)
+    res = {}
+    for x6 in ("1", "0"):
+        monkeypatch.setenv("A2C_BWD_X6", x6)
+        a = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+        ops.conv_bwd_data_lanemask(d, doutd, wb, lm, a, B)
+        b = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+        ops.conv_bwd_data(d, doutd, wb, None, b, B)
+        a2 = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+        ops.conv_bwd_data_lanemask(d, doutd, wb, lm, a2, B)
+        torch.cuda.synchronize()
+        assert torch.equal(a, a2) and not bool(torch.isnan(a).any()) and not bool(torch.isnan(b).any())
+        assert torch.equal(a, b * (actd > 0))                                 # the mask bits, exactly
+        res[x6] = b.cpu()
+    assert not torch.equal(res["1"], res["0"])                                # (the bf16 kernel did run)
+    idx = torch.cat([torch.arange(0, 48), torch.arange(B - 16, B)])
+    ref = torch.nn.functional.conv_transpose2d(dout[idx].double(), w.double(), stride=2)
+    for i in range(len(idx)):                                                 # per sample: the scales differ
+        rms = float(ref[i].pow(2).mean().sqrt())
+        e6 = float((res["1"][idx[i]].double() - ref[i]).pow(2).mean().sqrt()) / rms
+        e32 = float((res["0"][idx[i]].double() - ref[i]).pow(2).mean().sqrt()) / rms
+        assert e6 <= 1.5 * e32 + 1e-7, (i, e6, e32)
 
 
 @pytest.mark.parametrize("M,N", [(257, 3), (4096, 4), (5, 8)])

@@ -817,6 +817,7 @@ def test_conv2d_streaming_backward_data_matches_tiled_kernel(monkeypatch, with_m
     """A3C conv2 input gradient at update-sized batch (persistent streaming kernel) == the tiled
     kernel bit for bit (same (tap, channel-quad) order of the fp32 MFMA chain), and == fp64 to 1e-5."""
     ops = _ops()
+    monkeypatch.setenv("A2C_BWD_X6", "0")        # (the fp32 MFMA streaming kernel; the bf16 x 6 form has its own test)
     spec = (16, 20, 20, 32, 4, 2, 0)
     B = 2048 + 55
     d = ops.conv_desc(*spec)

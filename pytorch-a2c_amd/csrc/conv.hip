@@ -2078,7 +2078,9 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
     }
     BX_LDD(nsrc)
     {
-      f32x4 a00 = (f32x4){0.f, 0.f, 0.f, 0.f}, a01 = a00, a10 = a00, a11 = a00;     // a<job><class>
+      // a<job><class>: the (0,0) products; s<job><class>: the five small ones (their roundings are relative to a sum 2^-8 of the
+      // first; the main chain takes one addition per tap: against fp64 no less accurate than the fp32 kernel)
+      f32x4 a00 = (f32x4){0.f, 0.f, 0.f, 0.f}, a01 = a00, a10 = a00, a11 = a00, s00 = a00, s01 = a00, s10 = a00, s11 = a00;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         bf16x8x d0[3], d1[3];
@@ -2088,27 +2090,27 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
           d1[q] = *reinterpret_cast<const bf16x8x*>(img + q * BX_PST + boff[1][t]);
         }
         // rising magnitude: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0); the four chains interleaved
-#define BX_MM(QA, QB)                                                                                                  \
-        if (do00) a00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t][QA], d0[QB], a00, 0, 0, 0);                     \
-        if (do01) a01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t][QA], d0[QB], a01, 0, 0, 0);                     \
-        if (do10) a10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t][QA], d1[QB], a10, 0, 0, 0);                     \
-        if (do11) a11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t][QA], d1[QB], a11, 0, 0, 0);
-        BX_MM(2, 0) BX_MM(1, 1) BX_MM(0, 2) BX_MM(1, 0) BX_MM(0, 1) BX_MM(0, 0)
+#define BX_MM(P, QA, QB)                                                                                               \
+        if (do00) P##00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t][QA], d0[QB], P##00, 0, 0, 0);                 \
+        if (do01) P##01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t][QA], d0[QB], P##01, 0, 0, 0);                 \
+        if (do10) P##10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t][QA], d1[QB], P##10, 0, 0, 0);                 \
+        if (do11) P##11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t][QA], d1[QB], P##11, 0, 0, 0);
+        BX_MM(s, 2, 0) BX_MM(s, 1, 1) BX_MM(s, 0, 2) BX_MM(s, 1, 0) BX_MM(s, 0, 1) BX_MM(a, 0, 0)
 #undef BX_MM
       }
       // D: lane holds pixel j (column), channels 4 g + r (rows)
       if (okp[0]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (do00) outb[(4 * g + r) * HW + pix[0][0]] = a00[r];
-          if (do01) outb[(4 * g + r) * HW + pix[0][1]] = a01[r];
+          if (do00) outb[(4 * g + r) * HW + pix[0][0]] = a00[r] + s00[r];
+          if (do01) outb[(4 * g + r) * HW + pix[0][1]] = a01[r] + s01[r];
         }
       }
       if (okp[1]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (do10) outb[(4 * g + r) * HW + pix[1][0]] = a10[r];
-          if (do11) outb[(4 * g + r) * HW + pix[1][1]] = a11[r];
+          if (do10) outb[(4 * g + r) * HW + pix[1][0]] = a10[r] + s10[r];
+          if (do11) outb[(4 * g + r) * HW + pix[1][1]] = a11[r] + s11[r];
         }
       }
     }
@@ -2871,6 +2873,204 @@ __global__ __launch_bounds__(256) void wgrad_run_kernel(WrunP p) {
     float s = 0.f;
     for (int q = 0; q < nparts; ++q) s += red[q * Cm + tid];
     sl[(long)p.Cout * p.K + tid] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad_x6_kernel (round 6): A3CModel conv2's weight gradient -- dW[co][ci][ky][kx] = sum over samples and the 9 x 9 output
+// pixels of dOut[co][oy][ox] a1[ci][2 oy + ky][2 ox + kx] -- on the BF16 matrix pipe with fp32 results, the twin of
+// bwd_x6_kernel: both operands split into three bf16 pieces (exact), the six piece products with qa + qb <= 2 issued
+// (gemm_x6_kernel's argument), v_mfma_f32_16x16x32_bf16 with k = PIXELS.  Per sample one product D[32 co][256 n] +=
+// A[co][k] B[n][k] over 96 pixel slots in 12 groups of 8: groups 0..8 = the eight pixels ox 0..7 of output row oy, group 9 =
+// the column ox = 8 of rows 0..7, group 10 = the corner pixel (8, 8) + zeros, group 11 = zeros (81 of 96 slots carry data).
+//   * the sample's a1 (25.6 KB) and dOut (10.4 KB) arrive by LDS-DMA into an fp32 scratch, issued for the NEXT sample at the
+//     head of the matrix phase (no prefetch registers);
+//   * a conversion phase splits them into the piece images: a1 as phase runs P[ci][y][x parity][m] = a1[ci][y][2 m + parity]
+//     (a tap column kx = 2 kxh + kxl of output pixels ox 0..7 is elements m = ox + kxh of parity kxl: eight consecutive
+//     elements; kxh = 1 shifts the fragment by one element with v_alignbit, wave-uniform per 16-column tile), the column
+//     group and the corner as 16-byte cells per weight column, dOut as [co][slot];
+//   * wave w owns the weight columns of input channels 4 w .. 4 w + 3 (four 16-column tiles: a channel pair x kxh) and both
+//     16-row co tiles: 18 fragment reads feed 48 MFMAs per 32-slot step;
+//   * per-workgroup slabs [32 x 256 + 32] (db = sum of dOut in fp32) go to wgrad_reduce_kernel as before.
+namespace wx {
+constexpr int NT = 512;
+constexpr int SCR_A1 = 0, SCR_DO = 25600, P0 = SCR_DO + 16384, PQ = 15360, PRUN = 24;      // bytes
+constexpr int C2_0 = P0 + 3 * PQ, CQ = 4096, X2_0 = C2_0 + 3 * CQ;
+constexpr int A_0 = X2_0 + 3 * CQ, AQ = 6656, AROW = 208;
+constexpr int ZERO = A_0 + 3 * AQ, LDS_BYTES = ZERO + 32;
+}  // namespace wx
+struct WgradX6P { const float* in; long in_bs; const float* dout; float* slab; int B; int dbg; };
+__device__ __forceinline__ void wx_split2(float a, float b, unsigned int o[3]) {
+  const __bf16 a0 = (__bf16)a, b0 = (__bf16)b;
+  const float ra = a - (float)a0, rb = b - (float)b0;                 // exact
+  const __bf16 a1 = (__bf16)ra, b1 = (__bf16)rb;
+  const float sa = ra - (float)a1, sb = rb - (float)b1;               // exact, at most 8 significant bits
+  const __bf16 a2 = (__bf16)sa, b2 = (__bf16)sb;
+  o[0] = (unsigned int)__builtin_bit_cast(unsigned short, a0) | ((unsigned int)__builtin_bit_cast(unsigned short, b0) << 16);
+  o[1] = (unsigned int)__builtin_bit_cast(unsigned short, a1) | ((unsigned int)__builtin_bit_cast(unsigned short, b1) << 16);
+  o[2] = (unsigned int)__builtin_bit_cast(unsigned short, a2) | ((unsigned int)__builtin_bit_cast(unsigned short, b2) << 16);
+}
+__global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
+  using namespace wx;
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+  typedef unsigned int u32x2x __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsw[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wq = w & 3, th = w >> 2;                   // channel group (input channels 4 wq .. 4 wq + 3) and tile half
+  const float* __restrict__ sa1 = reinterpret_cast<const float*>(ldsw + SCR_A1);
+  const float* __restrict__ sdo = reinterpret_cast<const float*>(ldsw + SCR_DO);
+  for (int i = tid; i < (LDS_BYTES - P0) / 16; i += NT) *reinterpret_cast<u32x4x*>(ldsw + P0 + i * 16) = (u32x4x){0u, 0u, 0u, 0u};
+  // ---- matrix-phase addresses of this lane: tiles tt = 0 (kxh = 0) and 1 (kxh = 1) of channel pair 2 wq + th
+  int b0[2], b2[2], ncol[2];
+  const int qs2 = g == 0 ? PQ : (g == 3 ? 0 : CQ);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int ci = 2 * (2 * wq + th) + (l16 >> 3), ky = (l16 >> 1) & 3, kxl = l16 & 1;
+    const int n = (ci * 4 + ky) * 4 + 2 * tt + kxl;
+    ncol[tt] = n;
+    b0[tt] = P0 + ((ci * 20 + 2 * g + ky) * 2 + kxl) * PRUN;                 // step 0: output row oy = g (step 1: + 16 runs)
+    b2[tt] = g == 0 ? P0 + ((ci * 20 + 16 + ky) * 2 + kxl) * PRUN : g == 1 ? C2_0 + n * 16 : g == 2 ? X2_0 + n * 16 : ZERO;
+  }
+  const int aaddr = A_0 + l16 * AROW + g * 16;
+  // two accumulators per tile: the (0,0) products (one addition per 32 pixel slots: fewer roundings than the fp32 MFMA chain's one
+  // per 4) and the five small ones (their roundings are relative to a sum 2^-8 of the first): against fp64 the result is no less
+  // accurate than the fp32 kernel's
+  f32x4 acc[2][2], acs[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) acc[mt][tt] = acs[mt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dbacc = 0.f;
+  const int bco = tid & 31, bpart = tid >> 5;
+  auto dma = [&](long b) {
+    const float* __restrict__ ga = p.in + b * p.in_bs;
+    const float* __restrict__ gd = p.dout + b * 2592L;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < 3 || w == 0)
+        __builtin_amdgcn_global_load_lds((gptr_t)(ga + (long)(i * NT + tid) * 4), (lptr_t)(ldsw + SCR_A1 + (i * NT + w * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {             // 648 chunks of 16 B; the lanes past them re-read chunk 647 into the scratch's slack
+      const int c = min(i * NT + tid, 647);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gd + (long)c * 4), (lptr_t)(ldsw + SCR_DO + (i * NT + w * 64) * 16), 16, 0, 0);
+    }
+  };
+  // one a1 half row (ci, y, parity): elements m = 0..9 of the phase run
+  auto half_row = [&](int h) {
+    const int ci = h / 40, rem = h - ci * 40, y = rem >> 1, par = rem & 1;
+    const float* __restrict__ row = sa1 + ci * 400 + y * 20 + par;
+    unsigned int o[5][3];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wx_split2(row[4 * i], row[4 * i + 2], o[i]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      unsigned char* dst = ldsw + P0 + q * PQ + h * PRUN;
+      *reinterpret_cast<u32x2x*>(dst) = (u32x2x){o[0][q], o[1][q]};
+      *reinterpret_cast<u32x2x*>(dst + 8) = (u32x2x){o[2][q], o[3][q]};
+      *reinterpret_cast<unsigned int*>(dst + 16) = o[4][q];
+    }
+  };
+  long b = blockIdx.x;
+  if (b < p.B) dma(b);
+  for (; b < p.B; b += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // the sample's scratch has landed; the previous matrix phase is over
+    // ---- conversion (waves 0-1: two half rows; 2-3: half row + dOut group; 4-7: half row, weight column, dOut group)
+    if (!(p.dbg & 1)) {
+      half_row(tid);
+      if (tid < 128) half_row(512 + tid);
+      if (tid >= 256) {  // the column ox = 8 (rows oy 0..7) and the corner of weight column n
+        const int n = tid - 256, ci = n >> 4, ky = (n >> 2) & 3, kx = n & 3;
+        const float* __restrict__ col = sa1 + ci * 400 + ky * 20 + 16 + kx;
+        unsigned int o[4][3], oc[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wx_split2(col[80 * i], col[80 * i + 40], o[i]);
+        wx_split2(col[320], 0.f, oc);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          *reinterpret_cast<u32x4x*>(ldsw + C2_0 + q * CQ + n * 16) = (u32x4x){o[0][q], o[1][q], o[2][q], o[3][q]};
+          *reinterpret_cast<unsigned int*>(ldsw + X2_0 + q * CQ + n * 16) = oc[q];
+        }
+      }
+    }
+    if (!(p.dbg & 2) && tid >= 128 && tid < 480) {     // dOut group (co, gi): 0..8 rows, 9 the column, 10 the corner
+      const int id = tid - 128, co = id / 11, gi = id - co * 11;
+      const float* __restrict__ src = sdo + co * 81;
+      float e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = gi < 9 ? gi * 9 + i : gi == 9 ? i * 9 + 8 : 80;
+        e[i] = (gi == 10 && i > 0) ? 0.f : src[idx];
+      }
+      u32x4x o[3];
+      bx_split8(e, o);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4x*>(ldsw + A_0 + q * AQ + co * AROW + gi * 16) = o[q];
+    }
+    {  // bias partial sums (fp32, fixed order)
+      const float* __restrict__ src = sdo + bco * 81;
+      float s0 = 0.f;
+      for (int i = bpart; i < 81; i += 16) s0 += src[i];
+      dbacc += s0;
+    }
+    __syncthreads();                                   // pieces complete; the scratch is free
+    if (b + gridDim.x < p.B && !(p.dbg & 8)) dma(b + gridDim.x);
+    // ---- matrix phase: three steps of 32 pixel slots; all twelve fragments of a step first, then its 24 MFMAs
+    if (!(p.dbg & 4))
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      bf16x8x a[2][3], bf[2][3];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          a[mt][q] = *reinterpret_cast<const bf16x8x*>(ldsw + aaddr + mt * 16 * AROW + s * 64 + q * AQ);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int base = s == 0 ? b0[tt] : s == 1 ? b0[tt] + 16 * PRUN : b2[tt];
+        const int qs = s == 2 ? qs2 : PQ;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const unsigned char* src = ldsw + base + q * qs;
+          const u32x2x lo = *reinterpret_cast<const u32x2x*>(src), hi = *reinterpret_cast<const u32x2x*>(src + 8);
+          u32x4x v = (u32x4x){lo[0], lo[1], hi[0], hi[1]};
+          if (tt == 1) {                                // kxh = 1: the run one element further
+            const unsigned int ex = *reinterpret_cast<const unsigned int*>(src + 16);
+            u32x4x sh = (u32x4x){__builtin_amdgcn_alignbit(lo[1], lo[0], 16), __builtin_amdgcn_alignbit(hi[0], lo[1], 16),
+                                 __builtin_amdgcn_alignbit(hi[1], hi[0], 16), __builtin_amdgcn_alignbit(ex, hi[1], 16)};
+            if (s < 2 || g == 0) v = sh;              // (step 2: only the lanes reading a row run)
+          }
+          bf[tt][q] = __builtin_bit_cast(bf16x8x, v);
+        }
+      }
+      // rising magnitude: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0)   (a: dOut pieces, b: a1 pieces); the four chains interleaved
+#define WX_MM(AC, QA, QB)                                                                                               \
+      _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                  \
+        _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                                \
+          AC[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][QA], bf[tt][QB], AC[mt][tt], 0, 0, 0);
+      WX_MM(acs, 2, 0) WX_MM(acs, 1, 1) WX_MM(acs, 0, 2) WX_MM(acs, 1, 0) WX_MM(acs, 0, 1) WX_MM(acc, 0, 0)
+#undef WX_MM
+    }
+  }
+  // partials: D row (co) = mt * 16 + 4 g + r, column = this lane's weight column of tile tt
+  float* sl = p.slab + (long)blockIdx.x * (32 * 256 + 32);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sl[(mt * 16 + 4 * g + r) * 256 + ncol[tt]] = acc[mt][tt][r] + acs[mt][tt][r];
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(ldsw);          // [16 parts][32]
+  red[bpart * 32 + bco] = dbacc;
+  __syncthreads();
+  if (tid < 32) {
+    float sdb = 0.f;
+    for (int q = 0; q < 16; ++q) sdb += red[q * 32 + tid];
+    sl[32 * 256 + tid] = sdb;
   }
 }
 
@@ -4470,6 +4670,28 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
       const long nWs = (long)wp.Cout * wp.K, pers = nWs + wp.Cout;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(pers, 256)), dim3(256), 0, st, (const float*)ws, grid, pers, nWs,
                          dW, db);
+      A2C_CHECK_LAUNCH();
+      return A2C_OK;
+    }
+  }
+  {  // the bf16 x 6 form (wgrad_x6_kernel): exactly A3CModel's conv2 at streaming batch; A2C_WGRAD_X6=0 keeps the fp32 MFMA kernel
+    const char* x6 = getenv("A2C_WGRAD_X6");
+    const int grid = stream_grid() < pl.grid ? stream_grid() : pl.grid;
+    if (pl.run == 2 && d->Cin == 16 && d->Cout == 32 && d->H == 20 && d->W == 20 && d->ks == 4 && d->stride == 2 && d->pad == 0 &&
+        aligned && ((uintptr_t)dout % 16 == 0) && B >= 8 * grid && !(x6 && x6[0] == '0')) {
+      static bool attrx = false;
+      if (!attrx) {
+        if (hipFuncSetAttribute((const void*)wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wx::LDS_BYTES) != hipSuccess)
+          return A2C_ERR_LAUNCH;
+        attrx = true;
+      }
+      WgradX6P xp;
+      xp.in = in; xp.in_bs = (long)in_bstride; xp.dout = dout; xp.slab = (float*)ws; xp.B = B;
+      { const char* dg = getenv("A2C_WGRAD_X6_DBG"); xp.dbg = dg ? atoi(dg) : 0; }      // timing experiments only (wrong sums)
+      hipLaunchKernelGGL(wgrad_x6_kernel, dim3(grid), dim3(wx::NT), wx::LDS_BYTES, st, xp);
+      A2C_CHECK_LAUNCH();
+      const long nWx = 32L * 256, perx = nWx + 32;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(perx, 256)), dim3(256), 0, st, (const float*)ws, grid, perx, nWx, dW, db);
       A2C_CHECK_LAUNCH();
       return A2C_OK;
     }

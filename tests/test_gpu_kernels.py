@@ -936,6 +936,44 @@ def test_conv2d_backward_data_on_the_bf16_pipe_is_the_fp32_sum(monkeypatch, B):
         assert e6 <= 1.5 * e32 + 1e-7, (i, e6, e32)
 
 
+@pytest.mark.parametrize("B,pad", [(2048 + 55, 0), (4096, 64)])
+def test_conv2d_weight_gradient_on_the_bf16_pipe_is_the_fp32_sum(monkeypatch, B, pad):
+    """wgrad_x6_kernel (default for A3CModel's conv2 at streaming batch): dOut and the activations split into three bf16 pieces
+    each (exact), the six piece products with qa + qb <= 2 on the bf16 pipe with k = pixels (row groups, the ox = 8 column
+    group, the corner), fp32 sums -- against the fp64 weight gradient no worse than 1.5 x the fp32 MFMA kernel's error
+    (A2C_WGRAD_X6=0); db too; strided activation rows; bit-identical run to run."""
+    ops = _ops()
+    d = ops.conv_desc(16, 20, 20, 32, 4, 2, 0)
+    gen = torch.Generator().manual_seed(22)
+    a1 = torch.relu(torch.rand(B, 6400 + pad, generator=gen) - 0.3).to(DEV)
+    dout = ((torch.rand(B, 32, 9, 9, generator=gen) - 0.5) * (torch.rand(B, 32, 9, 9, generator=gen) < 0.6).float()).to(DEV)
+    ws = torch.empty(ops.conv_bwd_weight_ws_bytes(d, B) // 4 + 1, device=DEV)
+    res = {}
+    for x6 in ("1", "0"):
+        monkeypatch.setenv("A2C_WGRAD_X6", x6)
+        outs = []
+        for _ in range(2):
+            dW = torch.full((32, 16, 4, 4), float("nan"), device=DEV)
+            db = torch.full((32,), float("nan"), device=DEV)
+            ops.conv_bwd_weight(d, a1.data_ptr(), 6400 + pad, dout, dW, db, B, ws)
+            torch.cuda.synchronize()
+            outs.append((dW.clone(), db.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        res[x6] = (outs[0][0].double().reshape(32, 256), outs[0][1].double())
+    assert not torch.equal(res["1"][0], res["0"][0])                          # (the bf16 kernel did run)
+    x = a1[:, :6400].reshape(B, 16, 20, 20).double()
+    ref = torch.zeros(32, 256, dtype=torch.float64, device=DEV)
+    for i in range(0, B, 512):
+        patches = F.unfold(x[i:i + 512], 4, stride=2)                         # (b, 256, 81), k = (ci, ky, kx)
+        ref += torch.einsum("bcp,bkp->ck", dout[i:i + 512].reshape(-1, 32, 81).double(), patches)
+    rms = float(ref.pow(2).mean().sqrt())
+    e6 = float((res["1"][0] - ref).pow(2).mean().sqrt()) / rms
+    e32 = float((res["0"][0] - ref).pow(2).mean().sqrt()) / rms
+    assert e6 <= 1.5 * e32 + 1e-7, (e6, e32)
+    dbref = dout.double().sum(dim=(0, 2, 3))
+    close("db vs fp64", res["1"][1].float(), dbref, 1e-5 * float(dbref.abs().max()) + 1e-4, 1e-5)
+
+
 @pytest.mark.parametrize("M,N", [(257, 3), (4096, 4), (5, 8)])
 def test_small_n_bwd_data_with_mask_bits_equals_the_float_mask_path(M, N):
     """a2c_small_n_bwd_data_bits (A3CModel's da2 = (dl . Wc[:A]) * (a2 > 0) from the ring kernel's a2 mask bits) == the same

@@ -547,6 +547,25 @@ int a2c_lanemask_from_act(const float *act, uint64_t *lanemask, int64_t n_floats
 int a2c_conv2d_bwd_data_lanemask_supported(const a2c_conv_desc *d, int B);
 int a2c_conv2d_bwd_data_lanemask(const a2c_conv_desc *d, const float *dout, const float *wprep_bwd, const uint64_t *lanemask,
                                  float *din, int B, a2c_stream_t stream);
+/* The same layer below a rank-n_logits head (A3CModel's update: updater.py:128's autograd through pi(emb), proj_matrx and the
+ * ReLU of conv2, models.py:35-37, 73, 84): the layer's dOut is never materialised.  With Wc = pi.weight proj_matrx.weight
+ * (n_logits x Cout*OH*OW, a2c_compose_heads) and the ReLU mask of the layer's OUTPUT as one bit per activation (maskbits:
+ * bit e & 7 of byte e >> 3 of a row of mask_row_bytes bytes, e the flat (co, oy, ox) index; the ring kernel's a2_maskbit_rows),
+ *     dOut[b][e] = (act[b][e] > 0) ? sum over n < n_logits of dl[b * ld_dl + n] * Wc[n][e] : 0
+ * is formed while a sample is staged -- the sums of a2c_small_n_bwd_data_bits (n ascending, separate multiply and add), so both
+ * passes return bit for bit what they return on that entry point's output -- by
+ *   a2c_conv2d_bwd_data_lanemask_rank   din = conv_transpose(dOut, W) * bit(lanemask)            (bwd_x6_kernel)
+ *   a2c_conv2d_bwd_weight_rank          dW = sum dOut (x) patches(in), db = sum dOut             (wgrad_x6_kernel)
+ * both on the bf16 matrix pipe as six exact piece products with fp32 sums.  _supported = 1 for A3CModel's conv2
+ * (16 x 20 x 20 -> 32 x 9 x 9, 4 x 4, stride 2) at streaming batch with n_logits <= 4; otherwise form dOut with
+ * a2c_small_n_bwd_data_bits and call the plain entry points.                                                            */
+int a2c_conv2d_bwd_rank_supported(const a2c_conv_desc *d, int n_logits, int B);
+int a2c_conv2d_bwd_data_lanemask_rank(const a2c_conv_desc *d, const float *dl, int64_t ld_dl, int n_logits, const float *Wc,
+                                      const uint8_t *maskbits, int64_t mask_row_bytes, const float *wprep_bwd,
+                                      const uint64_t *lanemask, float *din, int B, a2c_stream_t stream);
+int a2c_conv2d_bwd_weight_rank(const a2c_conv_desc *d, const float *in, int64_t in_bstride, const float *dl, int64_t ld_dl,
+                               int n_logits, const float *Wc, const uint8_t *maskbits, int64_t mask_row_bytes, float *dW,
+                               float *db, int B, void *ws, size_t ws_bytes, a2c_stream_t stream);
 int a2c_conv2d_bwd_data_signs(const a2c_conv_desc *d, const float *dout, const float *wprep_bwd, const uint32_t *signs,
                               int64_t signs_bstride, float *din, int B, a2c_stream_t stream);
 /* a2c_conv2d_bwd_data_signs of layer d2 FUSED with a2c_conv2d_bwd_weight_frames of the FIRST layer d1 below it (round 6;

@@ -136,6 +136,9 @@ SIGNATURES = {
     "a2c_conv2d_bwd_data_w1_frames": (c_int, [PD, P, P, P, c_int64, PD, P, c_int64, c_int64, P, P, P, c_int, P, c_size_t, P]),
     "a2c_lanemask_from_act": (c_int, [P, P, c_int64, P]),
     "a2c_conv2d_bwd_data_lanemask_supported": (c_int, [PD, c_int]),
+    "a2c_conv2d_bwd_rank_supported": (c_int, [PD, c_int, c_int]),
+    "a2c_conv2d_bwd_data_lanemask_rank": (c_int, [PD, P, c_int64, c_int, P, P, c_int64, P, P, P, c_int, P]),
+    "a2c_conv2d_bwd_weight_rank": (c_int, [PD, P, c_int64, P, c_int64, c_int, P, P, c_int64, P, P, c_int, P, c_size_t, P]),
     "a2c_conv2d_bwd_data_lanemask": (c_int, [PD, P, P, P, P, c_int, P]),
     "a2c_conv2d_bwd_data_signs": (c_int, [PD, P, P, P, c_int64, P, c_int, P]),
     "a2c_conv2d_bwd_weight_ws_bytes": (c_size_t, [PD, c_int]),

@@ -456,35 +456,53 @@ class A3CModel(_HipNet):
                     ops.gemm(1, 0, h, F, A, Wpi.data_ptr(), h, S.data_ptr(), F, dWp.data_ptr(), F, st=st)
                     ops.gemm(1, 0, h, 1, A, Wpi.data_ptr(), h, dbh.data_ptr(), 1, G("proj_matrx.bias").data_ptr(), 1, st=st)
 
+        fuse_da2, mb = False, None
         try:
             if rank_bwd:
                 # da2 needs only dl and the composed matrix: the conv backward (2.5 of the update's 2.9 ms, four big launches)
                 # starts at once; the head / projection gradients run as a parallel branch beside it (ops.side_branch)
                 with ops.side_branch(0):
                     head_grads(ops.stream())
-                with ops.span("rank_bwd da2"):
-                    mb = None
-                    if (tag == "train" and getattr(self, "_stash_lm", False) and self._stash_valid(x_ptr, B)
-                            and os.environ.get("A2C_NO_LANEMASK") != "1"):
-                        mb = self._a2_maskbit_rows(B)       # the ring kernel left (a2 > 0) as bits beside the stash
-                    if mb is not None:
-                        ops.small_n_bwd_data_bits(dl, dl.stride(0), self._Wc, da2, F, mb, B, A, F, st)
-                    else:
-                        ops.gemm(0, 0, B, F, A, dl.data_ptr(), dl.stride(0), self._Wc.data_ptr(), F, da2.data_ptr(), F,
-                                 mask_ptr=a2.data_ptr(), ldmask=F, st=st)
+                mb = None
+                if (tag == "train" and getattr(self, "_stash_lm", False) and self._stash_valid(x_ptr, B)
+                        and os.environ.get("A2C_NO_LANEMASK") != "1"):
+                    mb = self._a2_maskbit_rows(B)       # the ring kernel left (a2 > 0) as bits beside the stash
+                # da2 = (dl . Wc) * (a2 > 0) formed INSIDE conv2's two backward kernels while they stage a sample (340 MB less
+                # written and 680 MB less read per update, one launch fewer): A2C_NO_RANK_FUSE=1 keeps the tensor
+                fuse_da2 = (mb is not None and os.environ.get("A2C_NO_RANK_FUSE") != "1" and a1[0].numel() % 4 == 0
+                            and ops.conv_bwd_rank_supported(self._c2.d, A, B))
+                if not fuse_da2:
+                    with ops.span("rank_bwd da2"):
+                        if mb is not None:
+                            ops.small_n_bwd_data_bits(dl, dl.stride(0), self._Wc, da2, F, mb, B, A, F, st)
+                        else:
+                            ops.gemm(0, 0, B, F, A, dl.data_ptr(), dl.stride(0), self._Wc.data_ptr(), F, da2.data_ptr(), F,
+                                     mask_ptr=a2.data_ptr(), ldmask=F, st=st)
             else:
                 head_grads(st)
                 demb = ws.get("demb", (B, h))
                 linear_bwd_data(ws, db, P("pi.weight"), demb, B, st, n_cols=A)        # value head is detached
                 linear_bwd_weight(ws, demb, a2.data_ptr(), F, G("proj_matrx.weight"), G("proj_matrx.bias"), B, st)
                 linear_bwd_data(ws, demb, Wp, da2.view(B, -1), B, st, mask=a2)
-            self._c2.bwd_weight(a1.data_ptr(), a1[0].numel(), da2, G("convs.1.0.weight"), G("convs.1.0.bias"), B, ws, st)
+            if fuse_da2:
+                buf = ws.bytes("conv_wgrad_ws", ops.conv_bwd_weight_ws_bytes(self._c2.d, B))
+                with ops.span("conv2.bwd_weight"):
+                    ops.conv_bwd_weight_rank(self._c2.d, a1.data_ptr(), a1[0].numel(), dl, dl.stride(0), A, self._Wc, mb, mb.stride(0),
+                                             G("convs.1.0.weight"), G("convs.1.0.bias"), B, buf, st)
+            else:
+                self._c2.bwd_weight(a1.data_ptr(), a1[0].numel(), da2, G("convs.1.0.weight"), G("convs.1.0.bias"), B, ws, st)
             da1 = ws.get("da1", (B,) + self._c1.out_shape)
             # the ring kernel left a1's lane masks beside the stash: 800 B per sample instead of the 25.6 KB row as the mask
             lm = None
             if tag == "train" and getattr(self, "_stash_lm", False) and self._stash_valid(x_ptr, B) and os.environ.get("A2C_NO_LANEMASK") != "1":
                 lm = self._a1_lanemask_rows(B)
-            self._c2.bwd_data(da2, a1, da1, B, st, lanemask=lm)
+            if fuse_da2 and lm is not None:
+                with ops.span("conv2.bwd_data"):
+                    ops.conv_bwd_data_lanemask_rank(self._c2.d, dl, dl.stride(0), A, self._Wc, mb, mb.stride(0), self._c2.wb, lm, da1, B, st)
+            else:
+                if fuse_da2:      # (no lane masks after all: the tensor is needed)
+                    ops.small_n_bwd_data_bits(dl, dl.stride(0), self._Wc, da2, F, mb, B, A, F, st)
+                self._c2.bwd_data(da2, a1, da1, B, st, lanemask=lm)
             fr = getattr(self, "_bwd_frames", None)
             if fr is not None:      # stack-on-load from the single-frame uint8 store: 28 KB instead of 113 KB per sample
                 fstore, nvalid, T = fr

@@ -894,6 +894,25 @@ def conv_bwd_weight(d, in_ptr, in_bstride, dout, dW, db, B, ws, st=None):
                                       st if st is not None else stream()), "a2c_conv2d_bwd_weight")
 
 
+def conv_bwd_rank_supported(d, n_logits, B):
+    """both backward passes of the layer below a rank-n_logits head can form their dOut in the kernels (A3CModel's conv2)"""
+    return bool(lib().a2c_conv2d_bwd_rank_supported(ctypes.byref(d), n_logits, B))
+
+
+def conv_bwd_data_lanemask_rank(d, dl, ld_dl, n_logits, Wc, maskbits, mask_row_bytes, wprep_bwd, lanemask, din, B, st=None):
+    _chk(maskbits, "maskbits", torch.uint8); _chk(lanemask, "lanemask", torch.int64)
+    check(lib().a2c_conv2d_bwd_data_lanemask_rank(ctypes.byref(d), _p(dl), ld_dl, n_logits, _p(Wc), _p(maskbits), mask_row_bytes,
+                                                  _p(wprep_bwd), _p(lanemask), _p(din), B, st if st is not None else stream()),
+          "a2c_conv2d_bwd_data_lanemask_rank")
+
+
+def conv_bwd_weight_rank(d, in_ptr, in_bstride, dl, ld_dl, n_logits, Wc, maskbits, mask_row_bytes, dW, db, B, ws, st=None):
+    _chk(maskbits, "maskbits", torch.uint8)
+    check(lib().a2c_conv2d_bwd_weight_rank(ctypes.byref(d), in_ptr, in_bstride, _p(dl), ld_dl, n_logits, _p(Wc), _p(maskbits),
+                                           mask_row_bytes, _p(dW), _p(db), B, ws.data_ptr(), ws.numel() * ws.element_size(),
+                                           st if st is not None else stream()), "a2c_conv2d_bwd_weight_rank")
+
+
 def conv_bwd_weight_frames(d, fstore, slot_stride, T, nvalid, dout, dW, db, B, ws, st=None):
     """first-layer weight gradient from the rollout's single-frame uint8 store (stack-on-load)"""
     _chk(fstore, "frame_store", torch.uint8); _chk(nvalid, "nvalid", torch.int32)

@@ -1958,6 +1958,9 @@ struct BwdX6P {
   const float* dout; float* din; const float* wfrag; const unsigned long long* lmask;
   int lmw, B;
   int frag_off[4];
+  // RANK: dOut is not read but formed while the sample is staged -- dOut[e] = (a2[e] > 0) ? sum_n dl[n] Wc[n][e] : 0, the sums of
+  // small_n_bwd_data_bits_kernel (n ascending, separate multiply and add): A3CModel's da2 never exists in HBM
+  const float* dl; long ldl; int nlog; const float* Wc; const unsigned char* a2b; long a2b_row;
 };
 __device__ __forceinline__ void bx_split8(const float e[8], u32x4x o[3]) {
   unsigned short pc[3][8];
@@ -1976,7 +1979,7 @@ __device__ __forceinline__ void bx_split8(const float e[8], u32x4x o[3]) {
     o[q] = (u32x4x){(unsigned int)pc[q][0] | ((unsigned int)pc[q][1] << 16), (unsigned int)pc[q][2] | ((unsigned int)pc[q][3] << 16),
                     (unsigned int)pc[q][4] | ((unsigned int)pc[q][5] << 16), (unsigned int)pc[q][6] | ((unsigned int)pc[q][7] << 16)};
 }
-template <int MODE>                                   // 0: no mask, 2: lane masks
+template <int MODE, bool RANK = false>               // MODE 0: no mask, 2: lane masks
 __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsx[];
   unsigned short* __restrict__ img = reinterpret_cast<unsigned short*>(ldsx);          // dOut of the sample, three piece images
@@ -2026,11 +2029,30 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
   const bool stg = tid < 4 * OHW;
   const int ss = stg ? tid % OHW : 0, gg = stg ? tid / OHW : 0;
   float pre[8];
+  // RANK: this thread's eight elements e = (8 gg + i) * 81 + ss of the composed matrix (all samples), the next sample's dl and
+  // the eight mask bytes of its elements
+  float gl[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned int mbv[RANK ? 8 : 1];
+  const int e0 = 8 * gg * OHW + ss;
+  // (the composed matrix transposed in LDS, a float4 of up to four logit rows per element: in registers the 32 values per
+  // thread spill, and a spill reload's vmcnt(0) waits for every prefetch load and flush store in flight)
+  float4* __restrict__ wcl = reinterpret_cast<float4*>(ldsx + 2 * BX_IMG + 2 * 4 * OBS);
+  if (RANK) {
+    for (int e = tid; e < 32 * OHW; e += BX_NT)
+      wcl[e] = make_float4(p.Wc[e], p.nlog > 1 ? p.Wc[32 * OHW + e] : 0.f, p.nlog > 2 ? p.Wc[2 * 32 * OHW + e] : 0.f,
+                           p.nlog > 3 ? p.Wc[3 * 32 * OHW + e] : 0.f);
+  }
   long b = blockIdx.x;
   if (b >= p.B) return;
 #define BX_LDD(src)                                                                         \
   if (stg) { _Pragma("unroll") for (int i = 0; i < 8; ++i) pre[i] = (src)[(8 * gg + i) * OHW + ss]; }
-  {
+#define BX_LDR(bn)                                                                          \
+  if (stg) {                                                                                \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) gl[n] = n < p.nlog ? p.dl[(bn) * p.ldl + n] : 0.f;      \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) mbv[RANK ? i : 0] = p.a2b[(bn) * p.a2b_row + ((e0 + i * OHW) >> 3)];   \
+  }
+  if (RANK) { BX_LDR(b) }
+  else {
     const float* __restrict__ src = p.dout + b * (long)(32 * OHW);
     BX_LDD(src)
   }
@@ -2059,6 +2081,16 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
     const long nb = (b + gridDim.x < p.B) ? b + gridDim.x : b;          // past the end: re-read this sample (discarded)
     const float* __restrict__ nsrc = p.dout + nb * (long)(32 * OHW);
     float* __restrict__ outb = outb0 + cur * OBS;
+    if (RANK && stg) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 w4 = wcl[e0 + i * OHW];
+        float a = 0.f;
+        a += gl[0] * w4.x; a += gl[1] * w4.y; a += gl[2] * w4.z; a += gl[3] * w4.w;      // (columns past nlog add 0 * 0)
+        if (!((mbv[RANK ? i : 0] >> ((e0 + i * OHW) & 7)) & 1u)) a = 0.f;
+        pre[i] = a;
+      }
+    }
     if (stg) {
       u32x4x o[3];
       bx_split8(pre, o);
@@ -2076,7 +2108,7 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
       lb0 = lmp[min((tid + 0 * BX_NT) >> 1, N4 / 2 - 1)]; lb1 = lmp[min((tid + 1 * BX_NT) >> 1, N4 / 2 - 1)];
       lb2 = lmp[min((tid + 2 * BX_NT) >> 1, N4 / 2 - 1)]; lb3 = lmp[min((tid + 3 * BX_NT) >> 1, N4 / 2 - 1)];
     }
-    BX_LDD(nsrc)
+    if (RANK) { BX_LDR(nb) } else { BX_LDD(nsrc) }
     {
       // a<job><class>: the (0,0) products; s<job><class>: the five small ones (their roundings are relative to a sum 2^-8 of the
       // first; the main chain takes one addition per tap: against fp64 no less accurate than the fp32 kernel)
@@ -2125,6 +2157,7 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
   }
 #undef BX_FLUSH
 #undef BX_LDD
+#undef BX_LDR
 }
 
 // the mask bits of an activation tensor (see bwd_stream2_kernel): a lane per float4, a byte per pair of lanes
@@ -2899,7 +2932,11 @@ constexpr int C2_0 = P0 + 3 * PQ, CQ = 4096, X2_0 = C2_0 + 3 * CQ;
 constexpr int A_0 = X2_0 + 3 * CQ, AQ = 6656, AROW = 208;
 constexpr int ZERO = A_0 + 3 * AQ, LDS_BYTES = ZERO + 32;
 }  // namespace wx
-struct WgradX6P { const float* in; long in_bs; const float* dout; float* slab; int B; int dbg; };
+struct WgradX6P {
+  const float* in; long in_bs; const float* dout; float* slab; int B; int dbg;
+  // RANK (see BwdX6P): dOut formed in the kernel, written to the fp32 scratch in place of the DMA
+  const float* dl; long ldl; int nlog; const float* Wc; const unsigned char* a2b; long a2b_row;
+};
 __device__ __forceinline__ void wx_split2(float a, float b, unsigned int o[3]) {
   const __bf16 a0 = (__bf16)a, b0 = (__bf16)b;
   const float ra = a - (float)a0, rb = b - (float)b0;                 // exact
@@ -2910,6 +2947,7 @@ __device__ __forceinline__ void wx_split2(float a, float b, unsigned int o[3]) {
   o[1] = (unsigned int)__builtin_bit_cast(unsigned short, a1) | ((unsigned int)__builtin_bit_cast(unsigned short, b1) << 16);
   o[2] = (unsigned int)__builtin_bit_cast(unsigned short, a2) | ((unsigned int)__builtin_bit_cast(unsigned short, b2) << 16);
 }
+template <bool RANK>
 __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
   using namespace wx;
   typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -2952,10 +2990,40 @@ __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
       if (i < 3 || w == 0)
         __builtin_amdgcn_global_load_lds((gptr_t)(ga + (long)(i * NT + tid) * 4), (lptr_t)(ldsw + SCR_A1 + (i * NT + w * 64) * 16), 16, 0, 0);
     }
+    if (!RANK) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {             // 648 chunks of 16 B; the lanes past them re-read chunk 647 into the scratch's slack
-      const int c = min(i * NT + tid, 647);
-      __builtin_amdgcn_global_load_lds((gptr_t)(gd + (long)c * 4), (lptr_t)(ldsw + SCR_DO + (i * NT + w * 64) * 16), 16, 0, 0);
+      for (int i = 0; i < 2; ++i) {           // 648 chunks of 16 B; the lanes past them re-read chunk 647 into the scratch's slack
+        const int c = min(i * NT + tid, 647);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gd + (long)c * 4), (lptr_t)(ldsw + SCR_DO + (i * NT + w * 64) * 16), 16, 0, 0);
+      }
+    }
+  };
+  // RANK: this thread's elements e = tid + 512 j of the sample's dOut: their rows of the composed matrix (all samples), the raw
+  // inputs of the NEXT sample to be formed (its dl and the mask bytes of the elements)
+  float wc[RANK ? 6 : 1][4], gl[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned int mbv[RANK ? 6 : 1];
+  if (RANK) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) wc[RANK ? j : 0][n] = (tid + 512 * j < 2592 && n < p.nlog) ? p.Wc[(long)n * 2592 + tid + 512 * j] : 0.f;
+  }
+  auto raw = [&](long bn) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) gl[n] = n < p.nlog ? p.dl[bn * p.ldl + n] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) mbv[RANK ? j : 0] = p.a2b[bn * p.a2b_row + (min(tid + 512 * j, 2591) >> 3)];
+  };
+  auto form = [&]() {        // dOut[e] = (a2[e] > 0) ? sum_n dl[n] Wc[n][e] : 0 -- small_n_bwd_data_bits_kernel's sums -- into the scratch
+    float* __restrict__ dst = reinterpret_cast<float*>(ldsw + SCR_DO);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int e = tid + 512 * j;
+      float a = 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) a += gl[n] * wc[RANK ? j : 0][n];
+      if (!((mbv[RANK ? j : 0] >> (e & 7)) & 1u)) a = 0.f;
+      if (e < 2592) dst[e] = a;
     }
   };
   // one a1 half row (ci, y, parity): elements m = 0..9 of the phase run
@@ -2974,6 +3042,11 @@ __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
     }
   };
   long b = blockIdx.x;
+  if (RANK && b < p.B) {
+    raw(b);
+    form();
+    raw(b + gridDim.x < p.B ? b + gridDim.x : b);
+  }
   if (b < p.B) dma(b);
   for (; b < p.B; b += gridDim.x) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3017,6 +3090,11 @@ __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
       dbacc += s0;
     }
     __syncthreads();                                   // pieces complete; the scratch is free
+    if (RANK && b + gridDim.x < p.B) {                 // the next sample's dOut from the raw inputs fetched one iteration ago
+      form();                                          // (before the DMA: the compiler orders plain LDS writes behind LDS-DMA with a vmcnt(0))
+      const long b2 = b + 2L * gridDim.x;
+      raw(b2 < p.B ? b2 : b);                          // (and the small loads first: the loop top waits for the youngest)
+    }
     if (b + gridDim.x < p.B && !(p.dbg & 8)) dma(b + gridDim.x);
     // ---- matrix phase: three steps of 32 pixel slots; all twelve fragments of a step first, then its 24 MFMAs
     if (!(p.dbg & 4))
@@ -4307,8 +4385,11 @@ static int bwd_band_tuned(const a2c_conv_desc* d, const float* dout, const float
     return launch_bwd_band(d, dout, wprep_bwd, mask, din, B, best, stream);
   }
 }
+// rank != nullptr: dOut formed inside the kernel from (dl, Wc, mask bits of the layer above): bwd_x6_kernel<2, true> only
+struct RankSrc { const float* dl; long ldl; int nlog; const float* Wc; const unsigned char* a2b; long a2b_row; };
 int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask, float* din, int B,
-                          a2c_stream_t stream, const unsigned long long* lmask = nullptr, bool probe_only = false);
+                          a2c_stream_t stream, const unsigned long long* lmask = nullptr, bool probe_only = false,
+                          const RankSrc* rank = nullptr);
 }  // namespace
 extern "C" {
 int a2c_conv2d_bwd_data(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask,
@@ -4356,6 +4437,29 @@ int a2c_conv2d_bwd_data_lanemask(const a2c_conv_desc* d, const float* dout, cons
   return conv_bwd_data_generic(d, dout, wprep_bwd, nullptr, din, B, stream, (const unsigned long long*)lanemask);
 }
 
+/* include/a2c_mi355x.h: the two backward passes of the layer below a rank-n_logits head with dOut formed in the kernels */
+int a2c_conv2d_bwd_rank_supported(const a2c_conv_desc* d, int n_logits, int B) {
+  if (!desc_ok(d) || B < 1 || n_logits < 1 || n_logits > 4 || (d->Cin * d->H * d->W) % 256 || c3_supported(d, 1)) return 0;
+  { const char* e = getenv("A2C_WGRAD_X6"); if (e && e[0] == '0') return 0; }
+  static const unsigned long long probe = 0;
+  static const RankSrc rprobe = {(const float*)16, 4, 1, (const float*)16, (const unsigned char*)16, 324};
+  if (conv_bwd_data_generic(d, (const float*)16, (const float*)16, nullptr, (float*)16, B, nullptr, &probe, true, &rprobe) != A2C_OK) return 0;
+  WgradPlan pl;
+  if (!plan_wgrad(d, B, pl, true) || pl.run != 2) return 0;
+  const int grid = stream_grid() < pl.grid ? stream_grid() : pl.grid;
+  return B >= 8 * grid ? 1 : 0;
+}
+int a2c_conv2d_bwd_data_lanemask_rank(const a2c_conv_desc* d, const float* dl, int64_t ld_dl, int n_logits, const float* Wc,
+                                      const uint8_t* maskbits, int64_t mask_row_bytes, const float* wprep_bwd,
+                                      const uint64_t* lanemask, float* din, int B, a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
+  if (B == 0) return A2C_OK;
+  if (!dl || !Wc || !maskbits || !wprep_bwd || !din || !lanemask || ((uintptr_t)lanemask % 8) || ((uintptr_t)din % 16)) return A2C_ERR_ARG;
+  if (ld_dl < n_logits || mask_row_bytes < (int64_t)d->Cout * d->OH * d->OW / 8 || !a2c_conv2d_bwd_rank_supported(d, n_logits, B)) return A2C_ERR_ARG;
+  const RankSrc rk = {dl, (long)ld_dl, n_logits, Wc, maskbits, (long)mask_row_bytes};
+  return conv_bwd_data_generic(d, nullptr, wprep_bwd, nullptr, din, B, stream, (const unsigned long long*)lanemask, false, &rk);
+}
+
 int a2c_conv2d_bwd_data_signs(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const uint32_t* signs,
                               int64_t signs_bstride, float* din, int B, a2c_stream_t stream) {
   if (!desc_ok(d) || B < 0) return A2C_ERR_ARG;
@@ -4390,7 +4494,7 @@ int a2c_conv2d_bwd_data_w1_frames(const a2c_conv_desc* d2, const float* dout, co
 namespace {
 // lmask != nullptr: the mask as lane masks (bwd_stream2_kernel); only the streaming path reads them: A2C_ERR_ARG otherwise
 int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float* wprep_bwd, const float* mask, float* din, int B,
-                          a2c_stream_t stream, const unsigned long long* lmask, bool probe_only) {
+                          a2c_stream_t stream, const unsigned long long* lmask, bool probe_only, const RankSrc* rank) {
   const int S = d->stride, P = d->pad;
   {  // fused-class pipelined path (unpadded ks = 2S layers whose dOut sample fits the prefetch registers)
     const int MTb = ceil_div(d->Cin, 16), c4n = d->Cout / 4;
@@ -4427,24 +4531,29 @@ int conv_bwd_data_generic(const a2c_conv_desc* d, const float* dout, const float
         const char* v1 = getenv("A2C_BWD_STREAM_V1");
         const bool form2 = slds2 <= LDS_HARD_MAX && !(v1 && v1[0] == '1') && (!lmask || n4 % 64 == 0);
         if (lmask && !form2) return A2C_ERR_ARG;
-        if (probe_only) return A2C_OK;
+        if (probe_only && !rank) return A2C_OK;
         {  // the bf16 x 6 form (bwd_x6_kernel): exactly A3CModel's conv2, mask as bits or none; A2C_BWD_X6=0 keeps the fp32 MFMA kernels
           const char* x6 = getenv("A2C_BWD_X6");
           if (d->Cout == 32 && d->Cin == 16 && d->OH == 9 && d->OW == 9 && d->H == 20 && d->W == 20 && P == 0 && (lmask || !mask) &&
               !(x6 && x6[0] == '0')) {
+            if (probe_only) return A2C_OK;
             BwdX6P xp;
             xp.dout = dout; xp.din = din; xp.wfrag = wprep_bwd; xp.lmask = lmask; xp.lmw = n4 / 64 * 4; xp.B = B;
             for (int cls = 0; cls < 4; ++cls) xp.frag_off[cls] = q.cls[cls].frag_off;
-            const size_t xlds = 2 * (size_t)BX_IMG + 2 * 4 * (size_t)d->Cin * d->H * d->W;
-            const void* xk = lmask ? (const void*)bwd_x6_kernel<2> : (const void*)bwd_x6_kernel<0>;
+            xp.dl = nullptr; xp.ldl = 0; xp.nlog = 0; xp.Wc = nullptr; xp.a2b = nullptr; xp.a2b_row = 0;
+            if (rank) { xp.dl = rank->dl; xp.ldl = rank->ldl; xp.nlog = rank->nlog; xp.Wc = rank->Wc; xp.a2b = rank->a2b; xp.a2b_row = rank->a2b_row; }
+            const size_t xlds = 2 * (size_t)BX_IMG + 2 * 4 * (size_t)d->Cin * d->H * d->W + (rank ? 16 * 2592 : 0);
+            const void* xk = rank ? (const void*)bwd_x6_kernel<2, true> : lmask ? (const void*)bwd_x6_kernel<2> : (const void*)bwd_x6_kernel<0>;
             if (xlds > 64 * 1024) (void)hipFuncSetAttribute(xk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds);
             const int xgrid = resident_grid(xk, xlds, B, BX_NT);
-            if (lmask) hipLaunchKernelGGL(bwd_x6_kernel<2>, dim3(xgrid), dim3(BX_NT), xlds, a2c_s(stream), xp);
+            if (rank) hipLaunchKernelGGL((bwd_x6_kernel<2, true>), dim3(xgrid), dim3(BX_NT), xlds, a2c_s(stream), xp);
+            else if (lmask) hipLaunchKernelGGL(bwd_x6_kernel<2>, dim3(xgrid), dim3(BX_NT), xlds, a2c_s(stream), xp);
             else hipLaunchKernelGGL(bwd_x6_kernel<0>, dim3(xgrid), dim3(BX_NT), xlds, a2c_s(stream), xp);
             A2C_CHECK_LAUNCH();
             return A2C_OK;
           }
         }
+        if (rank) return A2C_ERR_ARG;
         // third form (one barrier per sample, both images double buffered, the two waves of a SIMD out of step): A2C_BWD_STREAM_FORM=3
         const size_t slds3 = 4 * (2 * ((size_t)d->Cout * q.PLANE + 64) + 2 * (size_t)d->Cin * d->H * d->W);
         const char* fm = getenv("A2C_BWD_STREAM_FORM");
@@ -4641,6 +4750,35 @@ int a2c_conv2d_bwd_weight_frames(const a2c_conv_desc* d, const uint8_t* fstore, 
   return A2C_OK;
 }
 
+int a2c_conv2d_bwd_weight_rank(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* dl, int64_t ld_dl,
+                               int n_logits, const float* Wc, const uint8_t* maskbits, int64_t mask_row_bytes, float* dW, float* db,
+                               int B, void* ws, size_t ws_bytes, a2c_stream_t stream) {
+  if (!desc_ok(d) || B < 1 || !in || !dl || !Wc || !maskbits || !dW || !db) return A2C_ERR_ARG;
+  if (in_bstride % 4 || ((uintptr_t)in % 16) || ld_dl < n_logits || mask_row_bytes < (int64_t)d->Cout * d->OH * d->OW / 8 ||
+      in_bstride < (int64_t)d->Cin * d->H * d->W || !a2c_conv2d_bwd_rank_supported(d, n_logits, B))
+    return A2C_ERR_ARG;
+  if (!ws || ws_bytes < a2c_conv2d_bwd_weight_ws_bytes(d, B)) return A2C_ERR_WORKSPACE;
+  WgradPlan pl;
+  if (!plan_wgrad(d, B, pl, true)) return A2C_ERR_ARG;
+  const int grid = stream_grid() < pl.grid ? stream_grid() : pl.grid;
+  hipStream_t st = a2c_s(stream);
+  static bool attrr = false;
+  if (!attrr) {
+    if (hipFuncSetAttribute((const void*)wgrad_x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wx::LDS_BYTES) != hipSuccess)
+      return A2C_ERR_LAUNCH;
+    attrr = true;
+  }
+  WgradX6P xp;
+  xp.in = in; xp.in_bs = (long)in_bstride; xp.dout = nullptr; xp.slab = (float*)ws; xp.B = B; xp.dbg = 0;
+  xp.dl = dl; xp.ldl = (long)ld_dl; xp.nlog = n_logits; xp.Wc = Wc; xp.a2b = maskbits; xp.a2b_row = (long)mask_row_bytes;
+  hipLaunchKernelGGL(wgrad_x6_kernel<true>, dim3(grid), dim3(wx::NT), wx::LDS_BYTES, st, xp);
+  A2C_CHECK_LAUNCH();
+  const long nWx = 32L * 256, perx = nWx + 32;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(perx, 256)), dim3(256), 0, st, (const float*)ws, grid, perx, nWx, dW, db);
+  A2C_CHECK_LAUNCH();
+  return A2C_OK;
+}
+
 int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bstride, const float* dout, float* dW,
                           float* db, int B, void* ws, size_t ws_bytes, a2c_stream_t stream) {
   WgradPlan pl;
@@ -4681,14 +4819,16 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
         aligned && ((uintptr_t)dout % 16 == 0) && B >= 8 * grid && !(x6 && x6[0] == '0')) {
       static bool attrx = false;
       if (!attrx) {
-        if (hipFuncSetAttribute((const void*)wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wx::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)wgrad_x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wx::LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wx::LDS_BYTES) != hipSuccess)
           return A2C_ERR_LAUNCH;
         attrx = true;
       }
       WgradX6P xp;
       xp.in = in; xp.in_bs = (long)in_bstride; xp.dout = dout; xp.slab = (float*)ws; xp.B = B;
+      xp.dl = nullptr; xp.ldl = 0; xp.nlog = 0; xp.Wc = nullptr; xp.a2b = nullptr; xp.a2b_row = 0;
       { const char* dg = getenv("A2C_WGRAD_X6_DBG"); xp.dbg = dg ? atoi(dg) : 0; }      // timing experiments only (wrong sums)
-      hipLaunchKernelGGL(wgrad_x6_kernel, dim3(grid), dim3(wx::NT), wx::LDS_BYTES, st, xp);
+      hipLaunchKernelGGL(wgrad_x6_kernel<false>, dim3(grid), dim3(wx::NT), wx::LDS_BYTES, st, xp);
       A2C_CHECK_LAUNCH();
       const long nWx = 32L * 256, perx = nWx + 32;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a2c_grid_1d(perx, 256)), dim3(256), 0, st, (const float*)ws, grid, perx, nWx, dW, db);

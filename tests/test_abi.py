@@ -83,6 +83,15 @@ def test_argument_validation_without_gpu():
     d2 = _lib.ConvDesc(16, 20, 20, 32, 4, 2, 0, 9, 9)
     assert lib.a2c_conv2d_bwd_data_lanemask_supported(ctypes.byref(d2), 0) == 0
     assert lib.a2c_conv2d_bwd_data_lanemask(ctypes.byref(d2), None, None, None, None, 4096, None) == -1
+    # the rank-head forms of conv2's two backward passes and the prebuilt-image form of the bf16 x 6 GEMM: argument checks
+    assert lib.a2c_conv2d_bwd_rank_supported(ctypes.byref(d2), 5, 4096) == 0 and lib.a2c_conv2d_bwd_rank_supported(ctypes.byref(d2), 3, 0) == 0
+    assert lib.a2c_conv2d_bwd_data_lanemask_rank(ctypes.byref(d2), None, 4, 3, None, None, 324, None, None, None, 4096, None) == -1
+    assert lib.a2c_conv2d_bwd_data_lanemask_rank(ctypes.byref(d2), None, 4, 3, None, None, 324, None, None, None, 0, None) == 0
+    assert lib.a2c_conv2d_bwd_weight_rank(ctypes.byref(d2), None, 6400, None, 4, 3, None, None, 324, None, None, 4096, None, 0, None) == -1
+    assert lib.a2c_gemm_x6_image_bytes(256, 28224) == 3 * 2 * 256 * 28224 and lib.a2c_gemm_x6_image_bytes(0, 5) == 0
+    assert lib.a2c_gemm_x6_image_bytes(257, 17) == 3 * 2 * 512 * 32
+    assert lib.a2c_gemm_x6_split(None, 8, 4, 8, 1, None, None) == -1
+    assert lib.a2c_gemm_x6_images(4, 4, 8, None, None, None, 4, None, 0, None, 0, 0, 1, None, 0, None) == -1
     rargs2 = _lib.A3CRolloutArgs(B=2, C=4, H=84, W=84, n_actions=3, T=4)
     assert "a1_lanemask_rows" in dict(rargs2._fields_) and "a2_maskbit_rows" in dict(rargs2._fields_)
     assert lib.a2c_memcpy_async(None, None, 0, 1, None) == 0 and lib.a2c_memcpy_async(None, None, 8, 1, None) == -1

@@ -974,6 +974,42 @@ def test_conv2d_weight_gradient_on_the_bf16_pipe_is_the_fp32_sum(monkeypatch, B,
     close("db vs fp64", res["1"][1].float(), dbref, 1e-5 * float(dbref.abs().max()) + 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("B,A", [(2048 + 55, 3), (4096, 4), (2500, 1)])
+def test_conv2_backward_passes_form_their_dout_from_the_rank_a_head(B, A):
+    """a2c_conv2d_bwd_data_lanemask_rank / a2c_conv2d_bwd_weight_rank (A3CModel's update): dOut = (dl . Wc) * (a2 > 0) formed inside
+    the two bf16-pipe kernels while they stage a sample == the same kernels reading the tensor a2c_small_n_bwd_data_bits wrote,
+    bit for bit (dX, dW, db); strided dl rows, ragged batch, 1 / 3 / 4 logits."""
+    ops = _ops()
+    d = ops.conv_desc(16, 20, 20, 32, 4, 2, 0)
+    assert ops.conv_bwd_rank_supported(d, A, B) and not ops.conv_bwd_rank_supported(d, 5, B) and not ops.conv_bwd_rank_supported(d, A, 64)
+    gen = torch.Generator().manual_seed(23)
+    w = ((torch.rand(32, 16, 4, 4, generator=gen) - 0.5) * 0.2).to(DEV)
+    dlb = (torch.rand(B, A + 1, generator=gen) - 0.5).to(DEV)                # [dl | dv] rows: stride A + 1
+    Wc = (torch.rand(A + 1, 2592, generator=gen) - 0.5).to(DEV)
+    a2 = torch.relu(torch.rand(B, 2592, generator=gen) - 0.5)
+    a1 = torch.relu(torch.rand(B, 6400, generator=gen) - 0.3).to(DEV)
+    mb = torch.from_numpy(np.packbits((a2 > 0).numpy().astype(np.uint8), axis=1, bitorder="little")).to(DEV)
+    lm = torch.zeros(B, 100, dtype=torch.int64, device=DEV)
+    ops.lanemask_from_act(a1, lm)
+    wb = torch.empty(ops.conv_prep_floats(d, 1), device=DEV)
+    ops.conv_prep(d, 1, w, wb)
+    ws = torch.empty(ops.conv_bwd_weight_ws_bytes(d, B) // 4 + 1, device=DEV)
+    da2 = torch.empty(B, 32, 9, 9, device=DEV)
+    ops.small_n_bwd_data_bits(dlb, A + 1, Wc, da2, 2592, mb, B, A, 2592)
+    assert float(da2.abs().max()) > 0
+    dX0 = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+    ops.conv_bwd_data_lanemask(d, da2, wb, lm, dX0, B)
+    dW0, db0 = torch.empty(32, 16, 4, 4, device=DEV), torch.empty(32, device=DEV)
+    ops.conv_bwd_weight(d, a1.data_ptr(), 6400, da2, dW0, db0, B, ws)
+    dX1 = torch.full((B, 16, 20, 20), float("nan"), device=DEV)
+    ops.conv_bwd_data_lanemask_rank(d, dlb, A + 1, A, Wc, mb, mb.stride(0), wb, lm, dX1, B)
+    dW1, db1 = torch.full((32, 16, 4, 4), float("nan"), device=DEV), torch.full((32,), float("nan"), device=DEV)
+    ops.conv_bwd_weight_rank(d, a1.data_ptr(), 6400, dlb, A + 1, A, Wc, mb, mb.stride(0), dW1, db1, B, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(dX0, dX1)
+    assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+
+
 @pytest.mark.parametrize("M,N", [(257, 3), (4096, 4), (5, 8)])
 def test_small_n_bwd_data_with_mask_bits_equals_the_float_mask_path(M, N):
     """a2c_small_n_bwd_data_bits (A3CModel's da2 = (dl . Wc[:A]) * (a2 > 0) from the ring kernel's a2 mask bits) == the same

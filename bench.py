@@ -643,7 +643,15 @@ def linear_on_bf16_x6(batch, n, k, what):
     return (what == "fwd" and 128 <= batch <= 256 and n * k >= (1 << 24) and os.environ.get("A2C_NO_X6_FWD") != "1")
 
 
-def site_roofline(name, site, conv_layers, batch, u8_store=False, bf16_pipe=False):
+def a3c_x6_layers(model, batch):
+    """layers whose two backward passes run as six bf16 piece products (conv.hip: bwd_x6_kernel, wgrad_x6_kernel): A3CModel's conv2
+    at streaming batch (>= 8 samples per CU), unless switched off"""
+    if model == "A3CModel" and batch >= 2048 and os.environ.get("A2C_BWD_X6") != "0" and os.environ.get("A2C_WGRAD_X6") != "0":
+        return ("conv2",)
+    return ()
+
+
+def site_roofline(name, site, conv_layers, batch, u8_store=False, bf16_pipe=False, x6_layers=()):
     """roofline entry of one launch site: algorithmic bytes and flops / its average HIP-event duration, each priced on what
     the site really reads and really issues.  ``u8_store``: the first layer reads the single-frame uint8 store (one 7,056-byte
     frame per sample: every frame is a plane of four consecutive states) instead of the 4 x 84 x 84 fp32 row.  ``bf16_pipe``:
@@ -695,6 +703,12 @@ def site_roofline(name, site, conv_layers, batch, u8_store=False, bf16_pipe=Fals
             t_pk = 3.0 * fl / (BF16_PEAK_TFLOPS * 1e12)
             out.update(pipe="bf16 MFMA x3 (exact split, fp32 accumulate)", tflops_fp32_equiv=round(tf, 2),
                        frac_of_pipe_peak=round(t_pk / sec, 4))
+        elif lname in x6_layers and what.split(" ")[0] in ("bwd_data", "bwd_weight"):
+            # bwd_x6_kernel / wgrad_x6_kernel (A3CModel's conv2 at update batch): both operands split, six piece products
+            t_pk = 6.0 * fl / (BF16_PEAK_TFLOPS * 1e12)
+            out.update(pipe="bf16 MFMA x6 (exact 3-way split of both operands, fp32 accumulate)", tflops_fp32_equiv=round(tf, 2),
+                       frac_of_pipe_peak=round(t_pk / sec, 4))
+            del out["tflops"]
         else:
             out.update(pipe="fp32 MFMA", frac_of_f32_mfma_peak=round(tf / F32_PEAK_TFLOPS, 4), frac_of_pipe_peak=round(tf / F32_PEAK_TFLOPS, 4))
     return out
@@ -749,10 +763,11 @@ def run_config(workload, n_envs, optim, ingest, env_workers, n_workers, shard, d
         # what the first layer reads / which pipe its weight gradient runs on (site_roofline prices each site on that)
         st_live = bool(frame_store and getattr(b.runner, "_fstore", None) is not None and getattr(b.runner, "_fstore_ok", True))
         bf_w = st_live and b.model == "A3CModel" and os.environ.get("A2C_WGRAD_F32") != "1"
+        x6l = a3c_x6_layers(b.model, b.N)
         if summ:
             dom = max(summ, key=lambda k: summ[k]["total_ms"])
-            out["dominant_update_site"] = site_roofline(dom, summ[dom], conv, b.N, st_live, bf_w)
-            out["update_conv_sites"] = {k: site_roofline(k, v, conv, b.N, st_live, bf_w) for k, v in summ.items()
+            out["dominant_update_site"] = site_roofline(dom, summ[dom], conv, b.N, st_live, bf_w, x6l)
+            out["update_conv_sites"] = {k: site_roofline(k, v, conv, b.N, st_live, bf_w, x6l) for k, v in summ.items()
                                         if k.split(".")[0] in conv}
         rs = b.rollout_site_timers()
         if rs:

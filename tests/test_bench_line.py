@@ -170,6 +170,28 @@ def test_site_roofline_prices_the_uint8_store_and_the_bf16_pipe():
     assert bd["alg_bytes"] == 262144 * 4 * (4 * 84 * 84 + 16 * 400)
 
 
+class _D2:     # conv2 of A3CModel: 16 -> 32, 4x4 stride 2 on 20x20
+    Cin, H, W, Cout, OH, OW, ks = 16, 20, 20, 32, 9, 9, 4
+
+
+class _L2:
+    d = _D2
+    name = "conv2"
+
+
+def test_site_roofline_prices_a3c_conv2_backward_on_the_bf16_x6_pipe():
+    """A3CModel's conv2 backward passes at update batch issue six bf16 piece products per element pair (bwd_x6_kernel,
+    wgrad_x6_kernel): priced at 6 x the algorithmic flops on the bf16 pipe; the forward and small batches stay on the fp32 pipe."""
+    assert bench.a3c_x6_layers("A3CModel", 32768) == ("conv2",) and bench.a3c_x6_layers("A3CModel", 1024) == ()
+    assert bench.a3c_x6_layers("GRUModel", 32768) == ()
+    site = dict(avg_ms=0.36, launches=1, total_ms=0.36)
+    r = bench.site_roofline("conv2.bwd_data", site, {"conv2": _L2}, 32768, x6_layers=("conv2",))
+    assert r["pipe"].startswith("bf16 MFMA x6") and "frac_of_f32_mfma_peak" not in r and r["frac_of_pipe_peak"] <= 1.0
+    assert r["frac_of_pipe_peak"] == pytest.approx(6 * r["alg_flops"] / (bench.BF16_PEAK_TFLOPS * 1e12) / 0.36e-3, rel=1e-3)
+    assert bench.site_roofline("conv2.fwd", site, {"conv2": _L2}, 32768, x6_layers=("conv2",))["pipe"] == "fp32 MFMA"
+    assert bench.site_roofline("conv2.bwd_data", site, {"conv2": _L2}, 32768)["pipe"] == "fp32 MFMA"
+
+
 def test_site_roofline_prices_the_large_linear_layers_on_the_bf16_pipe():
     """ConvModel's 28224 x 2000 layers at update batch run as six bf16 piece products (gemm_x6_kernel): 231 GFLOP in 1.0 ms is
     1.47 of the fp32 MFMA peak -- not a roofline -- and 0.55 of what the bf16 pipe could issue; small or skinny products stay

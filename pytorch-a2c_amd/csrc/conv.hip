@@ -2927,7 +2927,12 @@ __global__ __launch_bounds__(256) void wgrad_run_kernel(WrunP p) {
 //   * per-workgroup slabs [32 x 256 + 32] (db = sum of dOut in fp32) go to wgrad_reduce_kernel as before.
 namespace wx {
 constexpr int NT = 512;
-constexpr int SCR_A1 = 0, SCR_DO = 25600, P0 = SCR_DO + 16384, PQ = 15360, PRUN = 24;      // bytes
+constexpr int SCR_A1 = 0, SCR_DO = 25600, SCR_BYTES = SCR_DO + 16384;      // the fp32 scratch: a STATIC array of its own -- as part of
+// the dynamic block the compiler cannot tell the LDS-DMA's writes from the fragment reads and waits vmcnt(0) in the matrix phase
+constexpr int P0 = 0, PQ = 15360, PBLK = 48;                               // the piece images (dynamic block), bytes
+// P[q][(ci, y)]: a 48-byte block = [parity 0: m 0..7][parity 1: m 0..7][m 8, 9 of parity 0 | of parity 1 | 8 B pad]: a fragment is
+// ONE ds_read_b128 (+ the tail dword when the run is shifted); at a 24-byte run pitch the two 8-byte halves compiled to
+// ds_read2_b64: 8 LDS cycles per wave-instruction at 128 B/clk instead of 4 at 256
 constexpr int C2_0 = P0 + 3 * PQ, CQ = 4096, X2_0 = C2_0 + 3 * CQ;
 constexpr int A_0 = X2_0 + 3 * CQ, AQ = 6656, AROW = 208;
 constexpr int ZERO = A_0 + 3 * AQ, LDS_BYTES = ZERO + 32;
@@ -2952,24 +2957,26 @@ __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
   using namespace wx;
   typedef const void __attribute__((address_space(1)))* gptr_t;
   typedef void __attribute__((address_space(3)))* lptr_t;
-  typedef unsigned int u32x2x __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) unsigned char scrw[SCR_BYTES];
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsw[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
   const int wq = w & 3, th = w >> 2;                   // channel group (input channels 4 wq .. 4 wq + 3) and tile half
-  const float* __restrict__ sa1 = reinterpret_cast<const float*>(ldsw + SCR_A1);
-  const float* __restrict__ sdo = reinterpret_cast<const float*>(ldsw + SCR_DO);
-  for (int i = tid; i < (LDS_BYTES - P0) / 16; i += NT) *reinterpret_cast<u32x4x*>(ldsw + P0 + i * 16) = (u32x4x){0u, 0u, 0u, 0u};
+  const float* __restrict__ sa1 = reinterpret_cast<const float*>(scrw + SCR_A1);
+  const float* __restrict__ sdo = reinterpret_cast<const float*>(scrw + SCR_DO);
+  for (int i = tid; i < LDS_BYTES / 16; i += NT) *reinterpret_cast<u32x4x*>(ldsw + i * 16) = (u32x4x){0u, 0u, 0u, 0u};
   // ---- matrix-phase addresses of this lane: tiles tt = 0 (kxh = 0) and 1 (kxh = 1) of channel pair 2 wq + th
-  int b0[2], b2[2], ncol[2];
+  int b0[2], b2[2], t0[2], t2[2], ncol[2];
   const int qs2 = g == 0 ? PQ : (g == 3 ? 0 : CQ);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
     const int ci = 2 * (2 * wq + th) + (l16 >> 3), ky = (l16 >> 1) & 3, kxl = l16 & 1;
     const int n = (ci * 4 + ky) * 4 + 2 * tt + kxl;
     ncol[tt] = n;
-    b0[tt] = P0 + ((ci * 20 + 2 * g + ky) * 2 + kxl) * PRUN;                 // step 0: output row oy = g (step 1: + 16 runs)
-    b2[tt] = g == 0 ? P0 + ((ci * 20 + 16 + ky) * 2 + kxl) * PRUN : g == 1 ? C2_0 + n * 16 : g == 2 ? X2_0 + n * 16 : ZERO;
+    b0[tt] = P0 + (ci * 20 + 2 * g + ky) * PBLK + 16 * kxl;                  // step 0: output row oy = g (step 1: + 8 rows)
+    b2[tt] = g == 0 ? P0 + (ci * 20 + 16 + ky) * PBLK + 16 * kxl : g == 1 ? C2_0 + n * 16 : g == 2 ? X2_0 + n * 16 : ZERO;
+    t0[tt] = P0 + (ci * 20 + 2 * g + ky) * PBLK + 32 + 4 * kxl;              // the tail dword (m 8, 9) of that run
+    t2[tt] = g == 0 ? P0 + (ci * 20 + 16 + ky) * PBLK + 32 + 4 * kxl : ZERO;
   }
   const int aaddr = A_0 + l16 * AROW + g * 16;
   // two accumulators per tile: the (0,0) products (one addition per 32 pixel slots: fewer roundings than the fp32 MFMA chain's one
@@ -2988,13 +2995,13 @@ __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < 3 || w == 0)
-        __builtin_amdgcn_global_load_lds((gptr_t)(ga + (long)(i * NT + tid) * 4), (lptr_t)(ldsw + SCR_A1 + (i * NT + w * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(ga + (long)(i * NT + tid) * 4), (lptr_t)(scrw + SCR_A1 + (i * NT + w * 64) * 16), 16, 0, 0);
     }
     if (!RANK) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {           // 648 chunks of 16 B; the lanes past them re-read chunk 647 into the scratch's slack
         const int c = min(i * NT + tid, 647);
-        __builtin_amdgcn_global_load_lds((gptr_t)(gd + (long)c * 4), (lptr_t)(ldsw + SCR_DO + (i * NT + w * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gd + (long)c * 4), (lptr_t)(scrw + SCR_DO + (i * NT + w * 64) * 16), 16, 0, 0);
       }
     }
   };
@@ -3015,7 +3022,7 @@ __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
     for (int j = 0; j < 6; ++j) mbv[RANK ? j : 0] = p.a2b[bn * p.a2b_row + (min(tid + 512 * j, 2591) >> 3)];
   };
   auto form = [&]() {        // dOut[e] = (a2[e] > 0) ? sum_n dl[n] Wc[n][e] : 0 -- small_n_bwd_data_bits_kernel's sums -- into the scratch
-    float* __restrict__ dst = reinterpret_cast<float*>(ldsw + SCR_DO);
+    float* __restrict__ dst = reinterpret_cast<float*>(scrw + SCR_DO);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int e = tid + 512 * j;
@@ -3035,10 +3042,9 @@ __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
     for (int i = 0; i < 5; ++i) wx_split2(row[4 * i], row[4 * i + 2], o[i]);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      unsigned char* dst = ldsw + P0 + q * PQ + h * PRUN;
-      *reinterpret_cast<u32x2x*>(dst) = (u32x2x){o[0][q], o[1][q]};
-      *reinterpret_cast<u32x2x*>(dst + 8) = (u32x2x){o[2][q], o[3][q]};
-      *reinterpret_cast<unsigned int*>(dst + 16) = o[4][q];
+      unsigned char* dst = ldsw + P0 + q * PQ + (h >> 1) * PBLK;
+      *reinterpret_cast<u32x4x*>(dst + 16 * par) = (u32x4x){o[0][q], o[1][q], o[2][q], o[3][q]};
+      *reinterpret_cast<unsigned int*>(dst + 32 + 4 * par) = o[4][q];
     }
   };
   long b = blockIdx.x;
@@ -3100,29 +3106,44 @@ __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
     if (!(p.dbg & 4))
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
+      // The fragment reads go through inline asm: hipcc's waitcnt insertion treats every LDS access of a kernel that issues
+      // LDS-DMA as a possible reader of an in-flight DMA and puts `s_waitcnt vmcnt(0)` in front of it -- here a wait for the next
+      // sample's scratch (issued a few instructions earlier) at the head of the matrix phase that was meant to cover it.
       bf16x8x a[2][3], bf[2][3];
+      u32x4x ra[2][3], rb[2][3];
+      unsigned int rt[3] = {0u, 0u, 0u};
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-          a[mt][q] = *reinterpret_cast<const bf16x8x*>(ldsw + aaddr + mt * 16 * AROW + s * 64 + q * AQ);
+          asm volatile("ds_read_b128 %0, %1" : "=v"(ra[mt][q]) : "v"((unsigned)(unsigned long)(lptr_t)(ldsw + aaddr + mt * 16 * AROW + s * 64 + q * AQ)));
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        const int base = s == 0 ? b0[tt] : s == 1 ? b0[tt] + 16 * PRUN : b2[tt];
+        const int base = s == 0 ? b0[tt] : s == 1 ? b0[tt] + 8 * PBLK : b2[tt];
+        const int tail = s == 0 ? t0[tt] : s == 1 ? t0[tt] + 8 * PBLK : t2[tt];
         const int qs = s == 2 ? qs2 : PQ;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          const unsigned char* src = ldsw + base + q * qs;
-          const u32x2x lo = *reinterpret_cast<const u32x2x*>(src), hi = *reinterpret_cast<const u32x2x*>(src + 8);
-          u32x4x v = (u32x4x){lo[0], lo[1], hi[0], hi[1]};
-          if (tt == 1) {                                // kxh = 1: the run one element further
-            const unsigned int ex = *reinterpret_cast<const unsigned int*>(src + 16);
-            u32x4x sh = (u32x4x){__builtin_amdgcn_alignbit(lo[1], lo[0], 16), __builtin_amdgcn_alignbit(hi[0], lo[1], 16),
-                                 __builtin_amdgcn_alignbit(hi[1], hi[0], 16), __builtin_amdgcn_alignbit(ex, hi[1], 16)};
-            if (s < 2 || g == 0) v = sh;              // (step 2: only the lanes reading a row run)
-          }
-          bf[tt][q] = __builtin_bit_cast(bf16x8x, v);
+          asm volatile("ds_read_b128 %0, %1" : "=v"(rb[tt][q]) : "v"((unsigned)(unsigned long)(lptr_t)(ldsw + base + q * qs)));
+          if (tt == 1) asm volatile("ds_read_b32 %0, %1" : "=v"(rt[q]) : "v"((unsigned)(unsigned long)(lptr_t)(ldsw + tail + q * qs)));
         }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[0][2]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[1][2]), "+v"(rb[0][0]), "+v"(rb[0][1]),
+                     "+v"(rb[0][2]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[1][2]), "+v"(rt[0]), "+v"(rt[1]), "+v"(rt[2])
+                   :: "memory");
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[mt][q] = __builtin_bit_cast(bf16x8x, ra[mt][q]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        bf[0][q] = __builtin_bit_cast(bf16x8x, rb[0][q]);
+        u32x4x v = rb[1][q];                            // kxh = 1: the run one element further
+        const u32x4x sh = (u32x4x){__builtin_amdgcn_alignbit(v[1], v[0], 16), __builtin_amdgcn_alignbit(v[2], v[1], 16),
+                                   __builtin_amdgcn_alignbit(v[3], v[2], 16), __builtin_amdgcn_alignbit(rt[q], v[3], 16)};
+        if (s < 2 || g == 0) v = sh;                    // (step 2: only the lanes reading a row run)
+        bf[1][q] = __builtin_bit_cast(bf16x8x, v);
       }
       // rising magnitude: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0)   (a: dOut pieces, b: a1 pieces); the four chains interleaved
 #define WX_MM(AC, QA, QB)                                                                                               \
@@ -3142,12 +3163,255 @@ __global__ __launch_bounds__(wx::NT) void wgrad_x6_kernel(WgradX6P p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) sl[(mt * 16 + 4 * g + r) * 256 + ncol[tt]] = acc[mt][tt][r] + acs[mt][tt][r];
   __syncthreads();
-  float* red = reinterpret_cast<float*>(ldsw);          // [16 parts][32]
+  float* red = reinterpret_cast<float*>(scrw);          // [16 parts][32]
   red[bpart * 32 + bco] = dbacc;
   __syncthreads();
   if (tid < 32) {
     float sdb = 0.f;
     for (int q = 0; q < 16; ++q) sdb += red[q * 32 + tid];
+    sl[32 * 256 + tid] = sdb;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad_x6p_kernel, OPT-IN (A2C_WGRAD_X6=2): built to run the conversion of sample n + 1 UNDER the matrix phase of sample n,
+// measured, and no faster -- 0.48-0.50 ms against 0.46 for wgrad_x6_kernel (same box, tools/wgrad_x6_timing.py): matrix phase
+// alone 0.31, conversion alone 0.21-0.25, together 0.48 whether the two waves of a SIMD run them in opposite order or in the
+// same order.  The phases do not compete for the matrix pipe and the vector ALU but for the LDS: ~390 ds_write_b32 / b16 per
+// sample at 4 cycles each on the store path beside ~650 fragment reads, 40 % of whose LDS cycles are bank conflicts.  Kept for
+// the record and for the next step there (wider stores, a conflict-free run pitch); dW is bit-identical to wgrad_x6_kernel.
+// wgrad_x6_kernel runs its two phases in sequence (conversion 0.22 ms + matrix phase 0.31 of its 0.47-0.51 ms): both waves of a
+// SIMD convert, then both multiply.  Here the piece images exist twice (two sets of 72 KB: phase runs at a 20-byte pitch --
+// fragments are four or five ds_read_b32 --, the corner cells as single dwords) and there is no fp32 scratch: a thread converts
+// straight from the float4s it prefetched (the next sample's, in registers during the whole interval).  Per sample ONE barrier;
+// between two barriers every wave multiplies sample n out of set n & 1 and converts sample n + 1 into the other set -- waves
+// 0-3 multiply first, waves 4-7 convert first, and waves w and w + 4 share a SIMD: its matrix pipe and its vector ALU work at
+// the same time.  Same MFMA order per accumulator as wgrad_x6_kernel: dW is bit-identical to it (db: sums in another order).
+namespace wxp {
+constexpr int NT = 512;
+constexpr int PQ = 12800, PRUN = 20, P0 = 0;                       // [q][run 640][10 el]
+constexpr int C2_0 = P0 + 3 * PQ, CQ = 4096;                       // [q][n 256][8 el]
+constexpr int X2_0 = C2_0 + 3 * CQ, XQ = 1024;                     // [q][n 256] one dword: the corner element, 0
+constexpr int A_0 = X2_0 + 3 * XQ, AQ = 6656, AROW = 208;          // [q][co 32][104 el]
+constexpr int SET = A_0 + 3 * AQ;                                  // 73,728
+constexpr int LDS_BYTES = 2 * SET;
+static_assert(SET == 73728 && SET % 16 == 0, "set");
+}  // namespace wxp
+template <bool RANK>
+__global__ __launch_bounds__(wxp::NT) void wgrad_x6p_kernel(WgradX6P p) {
+  using namespace wxp;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsp[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wq = w & 3, th = w >> 2;                   // channel pair 2 wq + th; th also = "converts first"
+  for (int i = tid; i < LDS_BYTES / 16; i += NT) *reinterpret_cast<u32x4x*>(ldsp + i * 16) = (u32x4x){0u, 0u, 0u, 0u};
+  // ---- matrix-phase addresses of this lane (within a set)
+  int ncol[2];
+  const int ci_l = 2 * (2 * wq + th) + (l16 >> 3), ky_l = (l16 >> 1) & 3, kxl_l = l16 & 1;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) ncol[tt] = (ci_l * 4 + ky_l) * 4 + 2 * tt + kxl_l;
+  const int prow0 = P0 + ((ci_l * 20 + 2 * g + ky_l) * 2 + kxl_l) * PRUN;      // step 0: output row oy = g (step 1: + 16 runs)
+  const int prow8 = P0 + ((ci_l * 20 + 16 + ky_l) * 2 + kxl_l) * PRUN;         // step 2, g = 0: output row 8
+  const int aaddr = A_0 + l16 * AROW + g * 16;
+  f32x4 acc[2][2], acs[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) acc[mt][tt] = acs[mt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // ---- conversion role: regular float4s r = tid + 512 j of the sample's a1 (columns 0..15 of every row: j < 3, the third only
+  // for tid < 256), edge float4s d = tid - 192 (columns 16..19 of row (ci, y) = (d / 20, d % 20): tid >= 192), dOut elements
+  // e = tid + 512 j (j < 6)
+  int rsrc[3], rdst[3];                                // float offset in the sample; byte offset of the par-0 dword in a set
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int r = min(tid + 512 * j, 1279), ci = r / 80, rem = r - ci * 80, y = rem >> 2, f = rem & 3;
+    rsrc[j] = (ci * 20 + y) * 20 + 4 * f;
+    rdst[j] = P0 + ((ci * 20 + y) * 2) * PRUN + 4 * f;
+  }
+  const bool edge = tid >= 192;
+  const int ed = edge ? tid - 192 : 0, eci = ed / 20, ey = ed - eci * 20;
+  const int esrc = (eci * 20 + ey) * 20 + 16, edst = P0 + ((eci * 20 + ey) * 2) * PRUN + 16;
+  f32x4 pa[3], pe;
+  float pd[6];
+  float wc[RANK ? 6 : 1][4], gl[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned int mbv[RANK ? 6 : 1];
+  float dbs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (RANK) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) wc[RANK ? j : 0][n] = (tid + 512 * j < 2592 && n < p.nlog) ? p.Wc[(long)n * 2592 + tid + 512 * j] : 0.f;
+  }
+  auto load_raw = [&](long bn) {
+    const float* __restrict__ ga = p.in + bn * p.in_bs;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (j < 2 || tid < 256) pa[j] = *reinterpret_cast<const f32x4*>(ga + rsrc[j]);
+    if (edge) pe = *reinterpret_cast<const f32x4*>(ga + esrc);
+    if (RANK) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) gl[n] = n < p.nlog ? p.dl[bn * p.ldl + n] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) mbv[RANK ? j : 0] = p.a2b[bn * p.a2b_row + (min(tid + 512 * j, 2591) >> 3)];
+    } else {
+      const float* __restrict__ gd = p.dout + bn * 2592L;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) pd[j] = gd[min(tid + 512 * j, 2591)];
+    }
+  };
+  auto convert = [&](unsigned char* __restrict__ set) {
+    // a1: a float4 (x0 .. x0 + 3) is one dword of the parity-0 run (x0, x0 + 2) and one of the parity-1 run (x0 + 1, x0 + 3)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j < 2 || tid < 256) {
+        unsigned int o0[3], o1[3];
+        wx_split2(pa[j][0], pa[j][2], o0);
+        wx_split2(pa[j][1], pa[j][3], o1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          *reinterpret_cast<unsigned int*>(set + q * PQ + rdst[j]) = o0[q];
+          *reinterpret_cast<unsigned int*>(set + q * PQ + rdst[j] + PRUN) = o1[q];
+        }
+      }
+    }
+    if (edge) {      // columns 16..19 = taps kx 0..3 of the column ox = 8: also the column cells (oy <= 7) and the corner (oy = 8)
+      unsigned int o0[3], o1[3];
+      wx_split2(pe[0], pe[2], o0);
+      wx_split2(pe[1], pe[3], o1);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        *reinterpret_cast<unsigned int*>(set + q * PQ + edst) = o0[q];
+        *reinterpret_cast<unsigned int*>(set + q * PQ + edst + PRUN) = o1[q];
+      }
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const int ky = (ey & 1) + 2 * kh, dd = ey - ky, oy = dd >> 1;
+        if (dd >= 0 && oy <= 8) {
+          const int n0 = (eci * 4 + ky) * 4;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const unsigned short v0 = (unsigned short)(o0[q] & 0xffffu), v2 = (unsigned short)(o0[q] >> 16);
+            const unsigned short v1 = (unsigned short)(o1[q] & 0xffffu), v3 = (unsigned short)(o1[q] >> 16);
+            if (oy <= 7) {
+              unsigned short* c = reinterpret_cast<unsigned short*>(set + C2_0 + q * CQ + n0 * 16) + oy;
+              c[0] = v0; c[8] = v1; c[16] = v2; c[24] = v3;
+            } else {
+              unsigned short* x = reinterpret_cast<unsigned short*>(set + X2_0 + q * XQ + n0 * 4);
+              x[0] = v0; x[2] = v1; x[4] = v2; x[6] = v3;
+            }
+          }
+        }
+      }
+    }
+    // dOut: element e = (co, oy, ox) -> slot 8 oy + ox (ox < 8), 72 + oy (ox = 8, oy < 8), 80 (the corner)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int e = tid + 512 * j;
+      float a;
+      if (RANK) {
+        a = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) a += gl[n] * wc[RANK ? j : 0][n];
+        if (!((mbv[RANK ? j : 0] >> (e & 7)) & 1u)) a = 0.f;
+      } else {
+        a = pd[j];
+      }
+      if (e < 2592) {
+        dbs[j] += a;
+        const int co = e / 81, px = e - co * 81, oy = px / 9, ox = px - oy * 9;
+        const int slot = ox < 8 ? 8 * oy + ox : (oy < 8 ? 72 + oy : 80);
+        const __bf16 h0 = (__bf16)a;
+        const float r1 = a - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        unsigned short* dst = reinterpret_cast<unsigned short*>(set + A_0 + co * AROW) + slot;
+        dst[0] = __builtin_bit_cast(unsigned short, h0);
+        dst[AQ / 2] = __builtin_bit_cast(unsigned short, h1);
+        dst[AQ] = __builtin_bit_cast(unsigned short, (__bf16)r2);
+      }
+    }
+  };
+  auto matrix = [&](const unsigned char* __restrict__ set) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      bf16x8x a[2][3], bf[2][3];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          a[mt][q] = *reinterpret_cast<const bf16x8x*>(set + aaddr + mt * 16 * AROW + s * 64 + q * AQ);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const unsigned int* pr = reinterpret_cast<const unsigned int*>(set + q * PQ + (s == 0 ? prow0 : s == 1 ? prow0 + 16 * PRUN : (g == 0 ? prow8 : prow0)));
+          const unsigned int d0 = pr[0], d1 = pr[1], d2 = pr[2], d3 = pr[3];
+          u32x4x v = (u32x4x){d0, d1, d2, d3};
+          if (tt == 1) {                                // kxh = 1: the run one element further
+            const unsigned int d4 = pr[4];
+            v = (u32x4x){__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                         __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)};
+          }
+          if (s == 2) {                                 // lanes g = 1: the column cells, g = 2: the corner, g = 3: nothing
+            const u32x4x vc = *reinterpret_cast<const u32x4x*>(set + C2_0 + q * CQ + ncol[tt] * 16);
+            const unsigned int vx = *reinterpret_cast<const unsigned int*>(set + X2_0 + q * XQ + ncol[tt] * 4);
+            if (g == 1) v = vc;
+            else if (g == 2) v = (u32x4x){vx, 0u, 0u, 0u};
+            else if (g == 3) v = (u32x4x){0u, 0u, 0u, 0u};
+          }
+          bf[tt][q] = __builtin_bit_cast(bf16x8x, v);
+        }
+      }
+#define WXP_MM(AC, QA, QB)                                                                                              \
+      _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                  \
+        _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                                \
+          AC[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][QA], bf[tt][QB], AC[mt][tt], 0, 0, 0);
+      WXP_MM(acs, 2, 0) WXP_MM(acs, 1, 1) WXP_MM(acs, 0, 2) WXP_MM(acs, 1, 0) WXP_MM(acs, 0, 1) WXP_MM(acc, 0, 0)
+#undef WXP_MM
+    }
+  };
+  long b = blockIdx.x;
+  if (b < p.B) {
+    __syncthreads();                                   // the zero fill
+    load_raw(b);
+    convert(ldsp);
+    if (b + gridDim.x < p.B) load_raw(b + gridDim.x);
+    __syncthreads();
+  }
+  int cur = 0;
+  for (; b < p.B; b += gridDim.x) {
+    const bool nxt = b + gridDim.x < p.B;
+    const long b2 = b + 2L * gridDim.x;
+    unsigned char* __restrict__ sc = ldsp + cur * SET;
+    unsigned char* __restrict__ sn = ldsp + (cur ^ 1) * SET;
+    const bool do_c = nxt && !(p.dbg & 1), do_l = b2 < p.B && !(p.dbg & 8), do_m = !(p.dbg & 4);
+    if (th == 0 || (p.dbg & 16)) {                     // (dbg 16: every wave multiplies first -- the in-phase order, for timing)
+      if (do_m) matrix(sc);
+      if (do_c) convert(sn);
+      if (nxt && do_l) load_raw(b2);
+    } else {
+      if (do_c) convert(sn);
+      if (nxt && do_l) load_raw(b2);
+      if (do_m) matrix(sc);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // partials: D row (co) = mt * 16 + 4 g + r, column = this lane's weight column of tile tt
+  float* sl = p.slab + (long)blockIdx.x * (32 * 256 + 32);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sl[(mt * 16 + 4 * g + r) * 256 + ncol[tt]] = acc[mt][tt][r] + acs[mt][tt][r];
+  float* red = reinterpret_cast<float*>(ldsp);          // [e 3072]: this workgroup's sum over its samples of dOut element e
+#pragma unroll
+  for (int j = 0; j < 6; ++j) red[tid + 512 * j] = dbs[j];
+  __syncthreads();
+  if (tid < 32) {
+    float sdb = 0.f;
+    for (int i = 0; i < 81; ++i) sdb += red[tid * 81 + i];
     sl[32 * 256 + tid] = sdb;
   }
 }
@@ -4771,6 +5035,16 @@ int a2c_conv2d_bwd_weight_rank(const a2c_conv_desc* d, const float* in, int64_t 
   WgradX6P xp;
   xp.in = in; xp.in_bs = (long)in_bstride; xp.dout = nullptr; xp.slab = (float*)ws; xp.B = B; xp.dbg = 0;
   xp.dl = dl; xp.ldl = (long)ld_dl; xp.nlog = n_logits; xp.Wc = Wc; xp.a2b = maskbits; xp.a2b_row = (long)mask_row_bytes;
+  const char* x6 = getenv("A2C_WGRAD_X6");
+  if (x6 && x6[0] == '2') {
+    static bool attrq = false;
+    if (!attrq) {
+      if (hipFuncSetAttribute((const void*)wgrad_x6p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wxp::LDS_BYTES) != hipSuccess)
+        return A2C_ERR_LAUNCH;
+      attrq = true;
+    }
+    hipLaunchKernelGGL(wgrad_x6p_kernel<true>, dim3(grid), dim3(wxp::NT), wxp::LDS_BYTES, st, xp);
+  } else
   hipLaunchKernelGGL(wgrad_x6_kernel<true>, dim3(grid), dim3(wx::NT), wx::LDS_BYTES, st, xp);
   A2C_CHECK_LAUNCH();
   const long nWx = 32L * 256, perx = nWx + 32;
@@ -4828,6 +5102,15 @@ int a2c_conv2d_bwd_weight(const a2c_conv_desc* d, const float* in, int64_t in_bs
       xp.in = in; xp.in_bs = (long)in_bstride; xp.dout = dout; xp.slab = (float*)ws; xp.B = B;
       xp.dl = nullptr; xp.ldl = 0; xp.nlog = 0; xp.Wc = nullptr; xp.a2b = nullptr; xp.a2b_row = 0;
       { const char* dg = getenv("A2C_WGRAD_X6_DBG"); xp.dbg = dg ? atoi(dg) : 0; }      // timing experiments only (wrong sums)
+      if (x6 && x6[0] == '2') {              // OPT-IN (A2C_WGRAD_X6=2): conversion under the matrix phase -- measured slower, see the kernel
+        static bool attrp = false;
+        if (!attrp) {
+          if (hipFuncSetAttribute((const void*)wgrad_x6p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wxp::LDS_BYTES) != hipSuccess)
+            return A2C_ERR_LAUNCH;
+          attrp = true;
+        }
+        hipLaunchKernelGGL(wgrad_x6p_kernel<false>, dim3(grid), dim3(wxp::NT), wxp::LDS_BYTES, st, xp);
+      } else
       hipLaunchKernelGGL(wgrad_x6_kernel<false>, dim3(grid), dim3(wx::NT), wx::LDS_BYTES, st, xp);
       A2C_CHECK_LAUNCH();
       const long nWx = 32L * 256, perx = nWx + 32;

@@ -961,6 +961,12 @@ def test_conv2d_weight_gradient_on_the_bf16_pipe_is_the_fp32_sum(monkeypatch, B,
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         res[x6] = (outs[0][0].double().reshape(32, 256), outs[0][1].double())
     assert not torch.equal(res["1"][0], res["0"][0])                          # (the bf16 kernel did run)
+    monkeypatch.setenv("A2C_WGRAD_X6", "2")               # the opt-in form with the conversion under the matrix phase: the same dW
+    dW2, db2 = torch.full((32, 16, 4, 4), float("nan"), device=DEV), torch.full((32,), float("nan"), device=DEV)
+    ops.conv_bwd_weight(d, a1.data_ptr(), 6400 + pad, dout, dW2, db2, B, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(dW2.double().reshape(32, 256), res["1"][0])
+    close("db, pipelined form", db2, res["1"][1], 1e-5 * float(res["1"][1].abs().max()) + 1e-4, 1e-5)
     x = a1[:, :6400].reshape(B, 16, 20, 20).double()
     ref = torch.zeros(32, 256, dtype=torch.float64, device=DEV)
     for i in range(0, B, 512):

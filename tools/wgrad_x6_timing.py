@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A3CModel conv2's weight gradient alone at N = 32768: wgrad_x6_kernel against the fp32 MFMA kernel, and the bf16 kernel with
-parts switched off (A2C_WGRAD_X6_DBG bits: 1 = no a1 conversion, 2 = no dOut conversion, 4 = no MFMAs, 8 = no DMA; wrong sums)."""
+"""A3CModel conv2's weight gradient alone at N = 32768: wgrad_x6_kernel against the fp32 MFMA kernel and the opt-in pipelined
+form (A2C_WGRAD_X6=2), each with parts switched off (A2C_WGRAD_X6_DBG bits: 1 = no a1 conversion, 2 = no dOut conversion,
+4 = no MFMAs, 8 = no DMA / loads, 16 = pipelined form with every wave multiplying first; wrong sums)."""
 import os
 import sys
 
@@ -32,6 +33,12 @@ def t(reps=10):
 for rnd in range(2):
     os.environ["A2C_WGRAD_X6"] = "0"
     print(f"fp32 MFMA kernel            {t():.3f} ms")
+    os.environ["A2C_WGRAD_X6"] = "2"
+    for dbg, name in ((0, "bf16 x 6, pipelined"), (1, "  p: no conversion"), (4, "  p: no MFMAs"), (8, "  p: no loads"), (16, "  p: all waves multiply first"),
+                      (9, "  p: matrix only"), (12, "  p: conversion only"), (5, "  p: loads + barrier only")):
+        os.environ["A2C_WGRAD_X6_DBG"] = str(dbg)
+        print(f"{name:28s}{t():.3f} ms")
+    os.environ.pop("A2C_WGRAD_X6_DBG")
     os.environ["A2C_WGRAD_X6"] = "1"
     for dbg, name in ((0, "bf16 x 6"), (1, "  no a1 conversion"), (2, "  no dOut conversion"), (3, "  no conversion"), (4, "  no MFMAs"),
                       (8, "  no DMA"), (7, "  DMA + barriers only"), (11, "  MFMAs only"), (12, "  conversion only")):

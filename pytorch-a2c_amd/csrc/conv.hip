@@ -2025,10 +2025,14 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) pix[jb][c] = (2 * cy + cp) * 20 + 2 * cx + c;
   }
-  // staging role: thread (pixel s, channel group gg) of the sample's 81 x 4 cells
-  const bool stg = tid < 4 * OHW;
-  const int ss = stg ? tid % OHW : 0, gg = stg ? tid / OHW : 0;
+  // staging role: thread (pixel s, channel group gg) of the sample's 81 x 4 cells -- the LAST 324 threads: waves 4-7 carry three
+  // (tile, class) units against the four of waves 0-3, and the next sample is formed and split in that slack (before the
+  // iteration's closing barrier); only the three ds_write_b128 stay at the head of the next iteration
+  const bool stg = tid >= BX_NT - 4 * OHW;
+  const int st_ = stg ? tid - (BX_NT - 4 * OHW) : 0;
+  const int ss = st_ % OHW, gg = st_ / OHW;
   float pre[8];
+  u32x4x so[3] = {(u32x4x){0u, 0u, 0u, 0u}, (u32x4x){0u, 0u, 0u, 0u}, (u32x4x){0u, 0u, 0u, 0u}};
   // RANK: this thread's eight elements e = (8 gg + i) * 81 + ss of the composed matrix (all samples), the next sample's dl and
   // the eight mask bytes of its elements
   float gl[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2056,6 +2060,20 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
     const float* __restrict__ src = p.dout + b * (long)(32 * OHW);
     BX_LDD(src)
   }
+  // the fetched sample -> its three piece vectors (RANK: formed first)
+#define BX_FORM()                                                                                           \
+  if (stg) {                                                                                                \
+    if (RANK) {                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                       \
+        const float4 w4 = wcl[e0 + i * OHW];                                                                \
+        float a = 0.f;                                                                                      \
+        a += gl[0] * w4.x; a += gl[1] * w4.y; a += gl[2] * w4.z; a += gl[3] * w4.w;   /* (columns past nlog add 0 * 0) */ \
+        if (!((mbv[RANK ? i : 0] >> ((e0 + i * OHW) & 7)) & 1u)) a = 0.f;                                   \
+        pre[i] = a;                                                                                         \
+      }                                                                                                     \
+    }                                                                                                       \
+    bx_split8(pre, so);                                                                                     \
+  }
 #define BX_FLUSH(u, pb_, ob_)                                                                               \
   {                                                                                                         \
     const int q_ = tid + (u) * BX_NT;                                                                       \
@@ -2076,26 +2094,15 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
   long pb = -1;
   int cur = 0;
   unsigned int lmb = 0;
-  __syncthreads();                                            // the zero pixels
+  __syncthreads();                                            // the zero pixels (RANK: the composed matrix)
+  BX_FORM()
   for (; b < p.B; b += gridDim.x) {
     const long nb = (b + gridDim.x < p.B) ? b + gridDim.x : b;          // past the end: re-read this sample (discarded)
     const float* __restrict__ nsrc = p.dout + nb * (long)(32 * OHW);
     float* __restrict__ outb = outb0 + cur * OBS;
-    if (RANK && stg) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float4 w4 = wcl[e0 + i * OHW];
-        float a = 0.f;
-        a += gl[0] * w4.x; a += gl[1] * w4.y; a += gl[2] * w4.z; a += gl[3] * w4.w;      // (columns past nlog add 0 * 0)
-        if (!((mbv[RANK ? i : 0] >> ((e0 + i * OHW) & 7)) & 1u)) a = 0.f;
-        pre[i] = a;
-      }
-    }
     if (stg) {
-      u32x4x o[3];
-      bx_split8(pre, o);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4x*>(img + q * BX_PST + gg * BX_GST + ss * 8) = o[q];
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4x*>(img + q * BX_PST + gg * BX_GST + ss * 8) = so[q];
     }
     __syncthreads();
     if (pb >= 0) {                                              // the previous sample's dX: stores first
@@ -2147,6 +2154,7 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
       }
     }
     if (MODE == 2) lmb = lb0 | (lb1 << 8) | (lb2 << 16) | (lb3 << 24);
+    BX_FORM()                                                   // the next sample (fetched during the matrix phase above)
     __syncthreads();                                            // every class has landed in this sample's image
     pb = b;
     cur ^= 1;
@@ -2158,6 +2166,7 @@ __global__ __launch_bounds__(BX_NT) void bwd_x6_kernel(BwdX6P p) {
 #undef BX_FLUSH
 #undef BX_LDD
 #undef BX_LDR
+#undef BX_FORM
 }
 
 // the mask bits of an activation tensor (see bwd_stream2_kernel): a lane per float4, a byte per pair of lanes

@@ -258,6 +258,7 @@ def _compare_full_update(net, info, onet, oinfo, g32, oinfo64, g64, max_norm):
         gh, gr, gx = net.G(n).cpu().double(), g32[n].double(), g64[n]
         rms = float(gx.pow(2).mean().sqrt())
         e_hip, e_ref = float((gh - gx).pow(2).mean().sqrt()), float((gr - gx).pow(2).mean().sqrt())
+        print(f"[full-size grads] {n}: rms deviation from fp64 / rms  hip {e_hip / max(rms, 1e-30):.2e}  reference fp32 {e_ref / max(rms, 1e-30):.2e}")
         assert e_hip <= 4 * e_ref + 5e-5 * rms, (n, e_hip / rms, e_ref / rms)
         assert float((gh - gx).abs().max()) <= 4 * float((gr - gx).abs().max()) + 5e-3 * rms, n
         idx = torch.from_numpy(np.unique(sample_idx(p.numel())))
